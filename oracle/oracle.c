@@ -1,0 +1,1241 @@
+/*
+ * oracle.c -- CPU restatement of the GMRES + BoomerAMG path.  TEST INFRASTRUCTURE
+ * ONLY, PARITY UNPINNED: see oracle.h for the scope statement.
+ *
+ * Every function cites the reference call site it serves (paths relative to
+ * /root/reference) and the HYPRE source file whose published algorithm it
+ * restates (libHYPRE itself is absent from this image).
+ */
+#include "oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static int g_threads = 1;
+void oracle_set_threads(int n) {
+  g_threads = n < 1 ? 1 : n;
+#ifdef _OPENMP
+  omp_set_num_threads(g_threads);
+#endif
+}
+
+#define C_PT 1
+#define F_PT (-1)
+#define SF_PT (-3)
+
+static void *xmalloc(size_t n) {
+  void *p = malloc(n ? n : 1);
+  if (!p) {
+    fprintf(stderr, "oracle: out of memory (%zu bytes)\n", n);
+    abort();
+  }
+  return p;
+}
+static void *xcalloc(size_t n, size_t s) {
+  void *p = calloc(n ? n : 1, s);
+  if (!p) {
+    fprintf(stderr, "oracle: out of memory\n");
+    abort();
+  }
+  return p;
+}
+
+/* ------------------------------------------------------------------ CSR -- */
+
+ocsr *ocsr_new(int nrows, int ncols, obig nnz) {
+  ocsr *A = (ocsr *)xmalloc(sizeof(ocsr));
+  A->nrows = nrows;
+  A->ncols = ncols;
+  A->ia = (obig *)xcalloc((size_t)nrows + 1, sizeof(obig));
+  A->ja = (int *)xmalloc(sizeof(int) * (size_t)nnz);
+  A->a = (double *)xmalloc(sizeof(double) * (size_t)nnz);
+  return A;
+}
+void ocsr_free(ocsr *A) {
+  if (!A) return;
+  free(A->ia);
+  free(A->ja);
+  free(A->a);
+  free(A);
+}
+ocsr *ocsr_from_arrays(int nrows, int ncols, const obig *ia, const int *ja, const double *a) {
+  ocsr *A = ocsr_new(nrows, ncols, ia[nrows]);
+  memcpy(A->ia, ia, sizeof(obig) * ((size_t)nrows + 1));
+  memcpy(A->ja, ja, sizeof(int) * (size_t)ia[nrows]);
+  memcpy(A->a, a, sizeof(double) * (size_t)ia[nrows]);
+  return A;
+}
+obig ocsr_nnz(const ocsr *A) { return A->ia[A->nrows]; }
+void ocsr_copy_out(const ocsr *A, obig *ia, int *ja, double *a) {
+  memcpy(ia, A->ia, sizeof(obig) * ((size_t)A->nrows + 1));
+  memcpy(ja, A->ja, sizeof(int) * (size_t)A->ia[A->nrows]);
+  memcpy(a, A->a, sizeof(double) * (size_t)A->ia[A->nrows]);
+}
+
+/* y = alpha*A*x + beta*b  (hypre_ParCSRMatrixMatvecOutOfPlace) */
+void ocsr_matvec(double alpha, const ocsr *A, const double *x, double beta, const double *b, double *y) {
+  const int n = A->nrows;
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+  for (int i = 0; i < n; i++) {
+    double s = 0.0;
+    for (obig k = A->ia[i]; k < A->ia[i + 1]; k++) s += A->a[k] * x[A->ja[k]];
+    y[i] = (beta == 0.0) ? alpha * s : alpha * s + beta * b[i];
+  }
+}
+
+ocsr *ocsr_transpose(const ocsr *A) {
+  const obig nnz = ocsr_nnz(A);
+  ocsr *T = ocsr_new(A->ncols, A->nrows, nnz);
+  for (obig k = 0; k < nnz; k++) T->ia[A->ja[k] + 1]++;
+  for (int i = 0; i < A->ncols; i++) T->ia[i + 1] += T->ia[i];
+  obig *pos = (obig *)xmalloc(sizeof(obig) * ((size_t)A->ncols + 1));
+  memcpy(pos, T->ia, sizeof(obig) * ((size_t)A->ncols + 1));
+  for (int i = 0; i < A->nrows; i++)
+    for (obig k = A->ia[i]; k < A->ia[i + 1]; k++) {
+      obig q = pos[A->ja[k]]++;
+      T->ja[q] = i;
+      T->a[q] = A->a[k];
+    }
+  free(pos);
+  return T;
+}
+
+static int cmp_int(const void *a, const void *b) {
+  int x = *(const int *)a, y = *(const int *)b;
+  return (x > y) - (x < y);
+}
+
+/* C = A*B, Gustavson row by row: for k in row i of A (stored order), for j in
+ * row k of B (stored order) acc[j] += a_ik*b_kj; output columns ascending.
+ * (Galerkin product of par_rap.c is R*(A*P) evaluated with this routine.) */
+ocsr *ocsr_matmul(const ocsr *A, const ocsr *B) {
+  const int n = A->nrows, m = B->ncols;
+  int *mark = (int *)xmalloc(sizeof(int) * (size_t)m);
+  for (int j = 0; j < m; j++) mark[j] = -1;
+  obig *cia = (obig *)xcalloc((size_t)n + 1, sizeof(obig));
+  for (int i = 0; i < n; i++) {
+    obig cnt = 0;
+    for (obig ka = A->ia[i]; ka < A->ia[i + 1]; ka++) {
+      int k = A->ja[ka];
+      for (obig kb = B->ia[k]; kb < B->ia[k + 1]; kb++) {
+        int j = B->ja[kb];
+        if (mark[j] != i) {
+          mark[j] = i;
+          cnt++;
+        }
+      }
+    }
+    cia[i + 1] = cia[i] + cnt;
+  }
+  ocsr *C = ocsr_new(n, m, cia[n]);
+  memcpy(C->ia, cia, sizeof(obig) * ((size_t)n + 1));
+  free(cia);
+  double *acc = (double *)xcalloc((size_t)m, sizeof(double));
+  for (int j = 0; j < m; j++) mark[j] = -1;
+  for (int i = 0; i < n; i++) {
+    obig q = C->ia[i];
+    for (obig ka = A->ia[i]; ka < A->ia[i + 1]; ka++) {
+      int k = A->ja[ka];
+      double av = A->a[ka];
+      for (obig kb = B->ia[k]; kb < B->ia[k + 1]; kb++) {
+        int j = B->ja[kb];
+        if (mark[j] != i) {
+          mark[j] = i;
+          C->ja[q++] = j;
+          acc[j] = av * B->a[kb];
+        } else
+          acc[j] += av * B->a[kb];
+      }
+    }
+    qsort(C->ja + C->ia[i], (size_t)(C->ia[i + 1] - C->ia[i]), sizeof(int), cmp_int);
+    for (obig k = C->ia[i]; k < C->ia[i + 1]; k++) C->a[k] = acc[C->ja[k]];
+  }
+  free(acc);
+  free(mark);
+  return C;
+}
+
+/* ------------------------------------------------------------ generator -- */
+
+/* src/laplace_3d_weak_scaling.hpp:216-322 (stencil offsets dz,dy,dx in k order,
+ * out-of-domain neighbours dropped), :558/:600 (values), :321 (rhs = row sum);
+ * 7-point variant per BASELINE.json / SURVEY 8(d). */
+ocsr *oracle_laplace(int nx, int ny, int nz, int stencil, double *rhs) {
+  const obig n = (obig)nx * ny * nz;
+  const double dv = (stencil == 27) ? 26.0 : 6.0;
+  obig nnz = 0;
+  for (int z = 0; z < nz; z++)
+    for (int y = 0; y < ny; y++)
+      for (int x = 0; x < nx; x++)
+        for (int dz = -1; dz <= 1; dz++)
+          for (int dy = -1; dy <= 1; dy++)
+            for (int dx = -1; dx <= 1; dx++) {
+              if (stencil == 7 && (abs(dx) + abs(dy) + abs(dz) > 1)) continue;
+              int X = x + dx, Y = y + dy, Z = z + dz;
+              if (X < 0 || X >= nx || Y < 0 || Y >= ny || Z < 0 || Z >= nz) continue;
+              nnz++;
+            }
+  ocsr *A = ocsr_new((int)n, (int)n, nnz);
+  obig q = 0;
+  for (int z = 0; z < nz; z++)
+    for (int y = 0; y < ny; y++)
+      for (int x = 0; x < nx; x++) {
+        obig row = x + (obig)nx * (y + (obig)ny * z);
+        double sum = 0.0;
+        for (int dz = -1; dz <= 1; dz++)
+          for (int dy = -1; dy <= 1; dy++)
+            for (int dx = -1; dx <= 1; dx++) {
+              if (stencil == 7 && (abs(dx) + abs(dy) + abs(dz) > 1)) continue;
+              int X = x + dx, Y = y + dy, Z = z + dz;
+              if (X < 0 || X >= nx || Y < 0 || Y >= ny || Z < 0 || Z >= nz) continue;
+              obig col = X + (obig)nx * (Y + (obig)ny * Z);
+              double v = (col == row) ? dv : -1.0;
+              A->ja[q] = (int)col;
+              A->a[q] = v;
+              sum += v;
+              q++;
+            }
+        A->ia[row + 1] = q;
+        if (rhs) rhs[row] = sum;
+      }
+  return A;
+}
+
+/* ------------------------------------------------------------------ RNG -- */
+/* hypre_SeedRand / hypre_Rand (utilities/random.c): Park-Miller, a = 16807,
+ * m = 2^31-1, q = 127773, r = 2836.  PMIS seeds it with 2747 + rank. */
+static int g_seed = 13579;
+void oracle_rand_seed(int seed) {
+  if (seed == 0) seed = 13579;
+  g_seed = seed;
+}
+double oracle_rand(void) {
+  const int a = 16807, m = 2147483647, q = 127773, r = 2836;
+  int lo = g_seed % q, hi = g_seed / q;
+  int t = a * lo - r * hi;
+  g_seed = (t > 0) ? t : t + m;
+  return (double)g_seed / m;
+}
+
+/* ------------------------------------------------------------ AMG setup -- */
+
+typedef struct olevel {
+  ocsr *A, *P, *R;
+  int own_A, own_P;
+  int *cf;       /* C_PT / F_PT per row (NULL on coarsest) */
+  double *diag;  /* a_ii */
+  double *l1gs;  /* l1 norm option 4, chunk/part/CF aware (relax 8,13,14) */
+  double *l1jac; /* full row l1 norm (relax 18) */
+  obig *part_starts;
+  double *u, *f, *tmp, *old; /* work vectors (u,f unused on level 0) */
+  double *Cinv;              /* dense inverse of the coarsest operator (relax 9) */
+} olevel;
+
+struct oamg {
+  oamg_params p;
+  int nlev;
+  olevel *L;
+};
+
+void oamg_default_params(oamg_params *p) {
+  memset(p, 0, sizeof(*p));
+  p->coarsen_type = 8;
+  p->interp_type = 6;
+  p->strong_threshold = 0.57;
+  p->max_row_sum = 0.9;
+  p->trunc_factor = 0.0;
+  p->pmax_elmts = 4;
+  p->max_levels = 20;
+  p->max_coarse_size = 9;
+  p->min_coarse_size = 0;
+  p->relax_type[0] = p->relax_type[1] = 8;
+  p->relax_type[2] = 9;
+  p->num_sweeps[0] = p->num_sweeps[1] = p->num_sweeps[2] = 1;
+  p->relax_order = 1;
+  p->relax_weight = 1.0;
+  p->outer_weight = 1.0;
+  p->cycle_type = 1;
+  p->gs_chunk = 8;
+  p->nparts = 1;
+  p->part_starts = NULL;
+  p->max_iter = 1;
+  p->tol = 0.0;
+}
+
+static int *part_of_rows(int n, int nparts, const obig *ps) {
+  int *po = (int *)xmalloc(sizeof(int) * (size_t)n);
+  for (int p = 0; p < nparts; p++)
+    for (obig i = ps[p]; i < ps[p + 1]; i++) po[i] = p;
+  return po;
+}
+
+/* Strength of connection (par_strength.c): for a_ii > 0 entry j is
+ * strong iff a_ij < theta * min_k a_ik; rows with |row sum| > max_row_sum*|a_ii|
+ * have no strong connections.  Returns CSR pattern S (off-diagonal only). */
+static void strength(const ocsr *A, double theta, double max_row_sum, obig **Sia_out, int **Sja_out) {
+  const int n = A->nrows;
+  obig *Sia = (obig *)xcalloc((size_t)n + 1, sizeof(obig));
+  int *Sja = (int *)xmalloc(sizeof(int) * (size_t)ocsr_nnz(A));
+  obig q = 0;
+  for (int i = 0; i < n; i++) {
+    double diag = 0.0, row_sum = 0.0, scale = 0.0;
+    for (obig k = A->ia[i]; k < A->ia[i + 1]; k++) {
+      row_sum += A->a[k];
+      if (A->ja[k] == i) diag = A->a[k];
+    }
+    for (obig k = A->ia[i]; k < A->ia[i + 1]; k++) {
+      if (A->ja[k] == i) continue;
+      if (diag < 0) {
+        if (A->a[k] > scale) scale = A->a[k];
+      } else {
+        if (A->a[k] < scale) scale = A->a[k];
+      }
+    }
+    int all_weak = (fabs(row_sum) > fabs(diag) * max_row_sum) && (max_row_sum < 1.0);
+    if (!all_weak)
+      for (obig k = A->ia[i]; k < A->ia[i + 1]; k++) {
+        if (A->ja[k] == i) continue;
+        int strong = (diag < 0) ? (A->a[k] > theta * scale) : (A->a[k] < theta * scale);
+        if (strong) Sja[q++] = A->ja[k];
+      }
+    Sia[i + 1] = q;
+  }
+  *Sia_out = Sia;
+  *Sja_out = Sja;
+}
+
+/* PMIS (par_coarsen.c hypre_BoomerAMGCoarsenPMIS; coarsen_type 8,
+ * HypreSystem.cpp:126).  Rank-local variant: only strong connections inside the
+ * row's own partition take part; measure = |S^T row| + rand, seed 2747+part. */
+static void pmis(int n, const obig *Sia, const int *Sja, const int *part_of, int nparts, const obig *ps, int *cf) {
+  double *measure = (double *)xcalloc((size_t)n, sizeof(double));
+  for (int i = 0; i < n; i++)
+    for (obig k = Sia[i]; k < Sia[i + 1]; k++)
+      if (part_of[Sja[k]] == part_of[i]) measure[Sja[k]] += 1.0;
+  for (int p = 0; p < nparts; p++) {
+    oracle_rand_seed(2747 + p);
+    for (obig i = ps[p]; i < ps[p + 1]; i++) measure[i] += oracle_rand();
+  }
+  int *graph = (int *)xmalloc(sizeof(int) * (size_t)n);
+  int *tmp = (int *)xmalloc(sizeof(int) * (size_t)n);
+  int ng = 0;
+  for (int i = 0; i < n; i++) {
+    int nloc = 0;
+    for (obig k = Sia[i]; k < Sia[i + 1]; k++)
+      if (part_of[Sja[k]] == part_of[i]) nloc++;
+    if (nloc == 0) {
+      cf[i] = SF_PT;
+      measure[i] = 0.0;
+    } else if (measure[i] < 1.0) {
+      cf[i] = F_PT;
+      measure[i] = 0.0;
+    } else {
+      cf[i] = 0;
+      graph[ng++] = i;
+    }
+  }
+  while (ng > 0) {
+    for (int g = 0; g < ng; g++) tmp[graph[g]] = 1;
+    for (int g = 0; g < ng; g++) {
+      int i = graph[g];
+      for (obig k = Sia[i]; k < Sia[i + 1]; k++) {
+        int j = Sja[k];
+        if (part_of[j] != part_of[i] || cf[j] != 0) continue; /* decided points have left the graph */
+        if (measure[i] > measure[j])
+          tmp[j] = 0;
+        else if (measure[j] > measure[i])
+          tmp[i] = 0;
+      }
+    }
+    for (int g = 0; g < ng; g++) {
+      int i = graph[g];
+      if (tmp[i] == 1) {
+        cf[i] = C_PT;
+        measure[i] = 0.0;
+      }
+    }
+    for (int g = 0; g < ng; g++) {
+      int i = graph[g];
+      if (cf[i] != 0) continue;
+      for (obig k = Sia[i]; k < Sia[i + 1]; k++) {
+        int j = Sja[k];
+        if (part_of[j] == part_of[i] && cf[j] == C_PT) {
+          cf[i] = F_PT;
+          measure[i] = 0.0;
+          break;
+        }
+      }
+    }
+    int m = 0;
+    for (int g = 0; g < ng; g++)
+      if (cf[graph[g]] == 0) graph[m++] = graph[g];
+    ng = m;
+  }
+  free(measure);
+  free(graph);
+  free(tmp);
+}
+
+/* Truncation (par_interp.c hypre_BoomerAMGInterpTruncation): drop entries below
+ * trunc_factor*max|p|, keep the pmax largest by (|p| desc, position asc), and
+ * rescale the row to its original sum.  Kept entries stay in stored order. */
+static int truncate_row(int len, int *cols, double *vals, double trunc_factor, int pmax, int *keep_scratch) {
+  if (len == 0) return 0;
+  double row_sum = 0.0, maxabs = 0.0;
+  for (int k = 0; k < len; k++) {
+    row_sum += vals[k];
+    if (fabs(vals[k]) > maxabs) maxabs = fabs(vals[k]);
+  }
+  int *keep = keep_scratch;
+  for (int k = 0; k < len; k++) keep[k] = (trunc_factor > 0.0) ? (fabs(vals[k]) >= trunc_factor * maxabs) : 1;
+  int nk = 0;
+  for (int k = 0; k < len; k++) nk += keep[k];
+  if (pmax > 0)
+    while (nk > pmax) { /* drop the smallest |p|; ties: the later position goes first */
+      int worst = -1;
+      for (int k = 0; k < len; k++)
+        if (keep[k] && (worst < 0 || fabs(vals[k]) <= fabs(vals[worst]))) worst = k;
+      keep[worst] = 0;
+      nk--;
+    }
+  double kept_sum = 0.0;
+  for (int k = 0; k < len; k++)
+    if (keep[k]) kept_sum += vals[k];
+  double scale = (kept_sum != 0.0) ? row_sum / kept_sum : 1.0;
+  int m = 0;
+  for (int k = 0; k < len; k++)
+    if (keep[k]) {
+      cols[m] = cols[k];
+      vals[m] = vals[k] * scale;
+      m++;
+    }
+  return m;
+}
+
+/* Interpolation.  interp_type 6: extended+i (par_lr_interp.c
+ * hypre_BoomerAMGBuildExtPIInterp, De Sterck/Falgout/Nolting/Yang 2008);
+ * 3: direct (par_interp.c hypre_BoomerAMGBuildDirInterp);
+ * 0: classical modified (par_interp.c hypre_BoomerAMGBuildInterp).
+ * Rank-local variant: neighbours outside the row's partition are treated as
+ * weak (lumped into the diagonal), so P has no off-partition columns.
+ * Columns of P are coarse indices (fine_to_coarse = running count of C points). */
+static ocsr *build_interp(const ocsr *A, const obig *Sia, const int *Sja, int *cf, const int *part_of, int interp_type,
+                          double trunc_factor, int pmax, int *ncoarse_out) {
+  const int n = A->nrows;
+  int *f2c = (int *)xmalloc(sizeof(int) * (size_t)n);
+  int nc = 0;
+  for (int i = 0; i < n; i++) f2c[i] = (cf[i] == C_PT) ? nc++ : -1;
+  *ncoarse_out = nc;
+  int *Pmark = (int *)xmalloc(sizeof(int) * (size_t)n); /* position of fine col in current row, or marker */
+  for (int i = 0; i < n; i++) Pmark[i] = -1;
+  /* growing buffers */
+  obig cap = (obig)n * 4 + 16, q = 0;
+  int *pj = (int *)xmalloc(sizeof(int) * (size_t)cap);
+  double *pa = (double *)xmalloc(sizeof(double) * (size_t)cap);
+  obig *pia = (obig *)xcalloc((size_t)n + 1, sizeof(obig));
+  int rowcap = 64;
+  int *rc = (int *)xmalloc(sizeof(int) * (size_t)rowcap);
+  double *rv = (double *)xmalloc(sizeof(double) * (size_t)rowcap);
+  int *keep = (int *)xmalloc(sizeof(int) * (size_t)rowcap);
+  int strong_f_marker = -2;
+#define GROW_ROW()                                            \
+  do {                                                        \
+    if (len >= rowcap) {                                      \
+      rowcap *= 2;                                            \
+      rc = (int *)realloc(rc, sizeof(int) * (size_t)rowcap);  \
+      rv = (double *)realloc(rv, sizeof(double) * (size_t)rowcap); \
+      keep = (int *)realloc(keep, sizeof(int) * (size_t)rowcap);   \
+    }                                                         \
+  } while (0)
+  for (int i = 0; i < n; i++) {
+    int len = 0;
+    if (cf[i] == C_PT) {
+      rc[0] = i;
+      rv[0] = 1.0;
+      len = 1;
+    } else if (cf[i] != SF_PT) {
+      const int mypart = part_of[i];
+      strong_f_marker--;
+      /* ---- interpolatory set: rc[0..len) are FINE indices for now */
+      for (obig k = Sia[i]; k < Sia[i + 1]; k++) {
+        int i1 = Sja[k];
+        if (part_of[i1] != mypart) continue;
+        if (cf[i1] == C_PT) {
+          if (Pmark[i1] < 0) {
+            GROW_ROW();
+            Pmark[i1] = len;
+            rc[len] = i1;
+            rv[len] = 0.0;
+            len++;
+          }
+        } else if (cf[i1] != SF_PT && interp_type == 6) {
+          Pmark[i1] = strong_f_marker;
+          for (obig kk = Sia[i1]; kk < Sia[i1 + 1]; kk++) {
+            int k1 = Sja[kk];
+            if (part_of[k1] != mypart || cf[k1] != C_PT) continue;
+            if (Pmark[k1] < 0) {
+              GROW_ROW();
+              Pmark[k1] = len;
+              rc[len] = k1;
+              rv[len] = 0.0;
+              len++;
+            }
+          }
+        } else if (cf[i1] != SF_PT && interp_type == 0) {
+          Pmark[i1] = strong_f_marker;
+        }
+      }
+#define IN_SET(j) (Pmark[j] >= 0)
+      double diagonal = 0.0;
+      for (obig k = A->ia[i]; k < A->ia[i + 1]; k++)
+        if (A->ja[k] == i) diagonal = A->a[k];
+      if (interp_type == 3) {
+        /* direct interpolation */
+        double sum_N_pos = 0, sum_N_neg = 0, sum_P_pos = 0, sum_P_neg = 0;
+        for (obig k = A->ia[i]; k < A->ia[i + 1]; k++) {
+          int j = A->ja[k];
+          if (j == i) continue;
+          double v = A->a[k];
+          if (v > 0)
+            sum_N_pos += v;
+          else
+            sum_N_neg += v;
+          if (IN_SET(j)) {
+            rv[Pmark[j]] += v;
+            if (v > 0)
+              sum_P_pos += v;
+            else
+              sum_P_neg += v;
+          }
+        }
+        double alfa = 1.0, beta = 1.0;
+        if (sum_P_neg != 0) alfa = sum_N_neg / sum_P_neg / diagonal;
+        if (sum_P_pos != 0) beta = sum_N_pos / sum_P_pos / diagonal;
+        if (sum_P_pos == 0) {
+          /* no positive C connections: lump positive entries into the diagonal */
+          double d2 = diagonal + sum_N_pos;
+          if (sum_P_neg != 0) alfa = sum_N_neg / sum_P_neg / d2;
+          beta = 0.0;
+        }
+        for (int k = 0; k < len; k++) rv[k] = (rv[k] > 0) ? -beta * rv[k] : -alfa * rv[k];
+      } else {
+        for (obig k = A->ia[i]; k < A->ia[i + 1]; k++) {
+          int i1 = A->ja[k];
+          if (i1 == i) continue;
+          double aik = A->a[k];
+          if (IN_SET(i1)) {
+            rv[Pmark[i1]] += aik;
+          } else if (Pmark[i1] == strong_f_marker) {
+            /* strong F neighbour: distribute a_ik over the set through row i1 */
+            double dk = 0.0;
+            for (obig kk = A->ia[i1]; kk < A->ia[i1 + 1]; kk++)
+              if (A->ja[kk] == i1) dk = A->a[kk];
+            double sgn = (dk < 0) ? -1.0 : 1.0;
+            double sum = 0.0;
+            for (obig kk = A->ia[i1]; kk < A->ia[i1 + 1]; kk++) {
+              int i2 = A->ja[kk];
+              if (i2 == i1) continue;
+              if ((IN_SET(i2) || (interp_type == 6 && i2 == i)) && sgn * A->a[kk] < 0) sum += A->a[kk];
+            }
+            if (sum != 0.0) {
+              double distribute = aik / sum;
+              for (obig kk = A->ia[i1]; kk < A->ia[i1 + 1]; kk++) {
+                int i2 = A->ja[kk];
+                if (i2 == i1) continue;
+                if (sgn * A->a[kk] < 0) {
+                  if (IN_SET(i2))
+                    rv[Pmark[i2]] += distribute * A->a[kk];
+                  else if (interp_type == 6 && i2 == i)
+                    diagonal += distribute * A->a[kk];
+                }
+              }
+            } else
+              diagonal += aik;
+          } else {
+            /* weak neighbour (or any off-partition neighbour) */
+            diagonal += aik;
+          }
+        }
+        if (diagonal != 0.0)
+          for (int k = 0; k < len; k++) rv[k] /= -diagonal;
+      }
+#undef IN_SET
+      for (int k = 0; k < len; k++) Pmark[rc[k]] = -1;
+      len = truncate_row(len, rc, rv, trunc_factor, pmax, keep);
+    }
+    if (q + len > cap) {
+      cap = (q + len) * 2;
+      pj = (int *)realloc(pj, sizeof(int) * (size_t)cap);
+      pa = (double *)realloc(pa, sizeof(double) * (size_t)cap);
+    }
+    /* sort the row by coarse column, insertion sort (rows are short) */
+    for (int k = 0; k < len; k++) rc[k] = f2c[rc[k]];
+    for (int a = 1; a < len; a++) {
+      int c = rc[a];
+      double v = rv[a];
+      int b = a - 1;
+      while (b >= 0 && rc[b] > c) {
+        rc[b + 1] = rc[b];
+        rv[b + 1] = rv[b];
+        b--;
+      }
+      rc[b + 1] = c;
+      rv[b + 1] = v;
+    }
+    for (int k = 0; k < len; k++) {
+      pj[q] = rc[k];
+      pa[q] = rv[k];
+      q++;
+    }
+    pia[i + 1] = q;
+  }
+#undef GROW_ROW
+  ocsr *P = (ocsr *)xmalloc(sizeof(ocsr));
+  P->nrows = n;
+  P->ncols = nc;
+  P->ia = pia;
+  P->ja = pj;
+  P->a = pa;
+  /* special F points act as plain F points from here on (par_amg_setup.c) */
+  for (int i = 0; i < n; i++)
+    if (cf[i] == SF_PT) cf[i] = F_PT;
+  free(f2c);
+  free(Pmark);
+  free(rc);
+  free(rv);
+  free(keep);
+  return P;
+}
+
+/* l1 norms.  l1gs: hypre_ParCSRComputeL1NormsThreads option 4 (par_relax_more.c),
+ * "threads" = hybrid-GS chunks: |a_ii| + 0.5*sum |a_ij| over entries outside the
+ * row's chunk (incl. other partitions) whose C/F type equals the row's (all of
+ * them when cf == NULL), truncated to a_ii when <= 4/3 a_ii (Remark 6.2 of
+ * Baker/Falgout/Kolev/Yang 2011); negative diagonal flips the sign.
+ * l1jac: full row l1 norm (option 1), used by relax 18. */
+static void level_norms(olevel *L, int chunk, int nparts) {
+  const ocsr *A = L->A;
+  const int n = A->nrows;
+  L->diag = (double *)xcalloc((size_t)n, sizeof(double));
+  L->l1gs = (double *)xcalloc((size_t)n, sizeof(double));
+  L->l1jac = (double *)xcalloc((size_t)n, sizeof(double));
+  for (int p = 0; p < nparts; p++)
+    for (obig cs = L->part_starts[p]; cs < L->part_starts[p + 1]; cs += chunk) {
+      obig ce = cs + chunk;
+      if (ce > L->part_starts[p + 1]) ce = L->part_starts[p + 1];
+      for (obig i = cs; i < ce; i++) {
+        double d = 0.0, l1 = 0.0, full = 0.0;
+        for (obig k = A->ia[i]; k < A->ia[i + 1]; k++) {
+          int j = A->ja[k];
+          double av = fabs(A->a[k]);
+          full += av;
+          if (j == i) {
+            d = A->a[k];
+            l1 += av;
+          } else if (j < cs || j >= ce) {
+            if (!L->cf || L->cf[j] == L->cf[i]) l1 += 0.5 * av;
+          }
+        }
+        if (l1 <= 4.0 / 3.0 * fabs(d)) l1 = fabs(d);
+        if (d < 0) {
+          l1 = -l1;
+          full = -full;
+        }
+        L->diag[i] = d;
+        L->l1gs[i] = l1;
+        L->l1jac[i] = full;
+      }
+    }
+}
+
+static void dense_inverse(const ocsr *A, double *inv) {
+  /* Gauss-Jordan with partial pivoting; relax type 9 (par_relax.c / par_gauss_elim) */
+  const int n = A->nrows;
+  double *M = (double *)xcalloc((size_t)n * n, sizeof(double));
+  for (int i = 0; i < n; i++)
+    for (obig k = A->ia[i]; k < A->ia[i + 1]; k++) M[(size_t)i * n + A->ja[k]] = A->a[k];
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) inv[(size_t)i * n + j] = (i == j) ? 1.0 : 0.0;
+  for (int c = 0; c < n; c++) {
+    int piv = c;
+    for (int r = c + 1; r < n; r++)
+      if (fabs(M[(size_t)r * n + c]) > fabs(M[(size_t)piv * n + c])) piv = r;
+    if (piv != c)
+      for (int j = 0; j < n; j++) {
+        double t = M[(size_t)c * n + j];
+        M[(size_t)c * n + j] = M[(size_t)piv * n + j];
+        M[(size_t)piv * n + j] = t;
+        t = inv[(size_t)c * n + j];
+        inv[(size_t)c * n + j] = inv[(size_t)piv * n + j];
+        inv[(size_t)piv * n + j] = t;
+      }
+    double d = M[(size_t)c * n + c];
+    if (d == 0.0) continue;
+    double id = 1.0 / d;
+    for (int j = 0; j < n; j++) {
+      M[(size_t)c * n + j] *= id;
+      inv[(size_t)c * n + j] *= id;
+    }
+    for (int r = 0; r < n; r++) {
+      if (r == c) continue;
+      double f = M[(size_t)r * n + c];
+      if (f == 0.0) continue;
+      for (int j = 0; j < n; j++) {
+        M[(size_t)r * n + j] -= f * M[(size_t)c * n + j];
+        inv[(size_t)r * n + j] -= f * inv[(size_t)c * n + j];
+      }
+    }
+  }
+  free(M);
+}
+
+#define ORACLE_MAX_DENSE 4096
+
+static void finish_levels(oamg *h) {
+  for (int l = 0; l < h->nlev; l++) {
+    olevel *L = &h->L[l];
+    const int n = L->A->nrows;
+    level_norms(L, h->p.gs_chunk, h->p.nparts);
+    L->u = (double *)xcalloc((size_t)n, sizeof(double));
+    L->f = (double *)xcalloc((size_t)n, sizeof(double));
+    L->tmp = (double *)xcalloc((size_t)n, sizeof(double));
+    L->old = (double *)xcalloc((size_t)n, sizeof(double));
+    if (L->P) L->R = ocsr_transpose(L->P);
+  }
+  olevel *Lc = &h->L[h->nlev - 1];
+  if (h->p.relax_type[2] == 9 && Lc->A->nrows <= ORACLE_MAX_DENSE) {
+    Lc->Cinv = (double *)xmalloc(sizeof(double) * (size_t)Lc->A->nrows * Lc->A->nrows);
+    dense_inverse(Lc->A, Lc->Cinv);
+  }
+}
+
+/* hypre_BoomerAMGSetup (par_amg_setup.c), reached from solverSetupPtr_
+ * (src/HypreSystem.cpp:692) through HYPRE_ParCSRGMRESSetup -> precond setup. */
+oamg *oamg_setup(const ocsr *A0, const oamg_params *p) {
+  oamg *h = (oamg *)xcalloc(1, sizeof(oamg));
+  h->p = *p;
+  if (h->p.gs_chunk < 1) h->p.gs_chunk = 1;
+  const int nparts = p->nparts > 0 ? p->nparts : 1;
+  h->p.nparts = nparts;
+  h->L = (olevel *)xcalloc((size_t)(p->max_levels > 0 ? p->max_levels : 1), sizeof(olevel));
+  h->L[0].A = (ocsr *)A0;
+  h->L[0].own_A = 0;
+  h->L[0].part_starts = (obig *)xmalloc(sizeof(obig) * ((size_t)nparts + 1));
+  if (p->part_starts)
+    memcpy(h->L[0].part_starts, p->part_starts, sizeof(obig) * ((size_t)nparts + 1));
+  else {
+    h->L[0].part_starts[0] = 0;
+    h->L[0].part_starts[1] = A0->nrows;
+  }
+  h->p.part_starts = NULL;
+  int l = 0;
+  while (l < p->max_levels - 1 && h->L[l].A->nrows > p->max_coarse_size) {
+    olevel *L = &h->L[l];
+    const ocsr *A = L->A;
+    const int n = A->nrows;
+    obig *Sia;
+    int *Sja;
+    strength(A, p->strong_threshold, p->max_row_sum, &Sia, &Sja);
+    int *part_of = part_of_rows(n, nparts, L->part_starts);
+    int *cf = (int *)xmalloc(sizeof(int) * (size_t)n);
+    pmis(n, Sia, Sja, part_of, nparts, L->part_starts, cf);
+    int nc = 0;
+    for (int i = 0; i < n; i++) nc += (cf[i] == C_PT);
+    if (nc == 0 || nc == n || nc < p->min_coarse_size) {
+      free(Sia);
+      free(Sja);
+      free(part_of);
+      free(cf);
+      break;
+    }
+    int nc2;
+    ocsr *P = build_interp(A, Sia, Sja, cf, part_of, p->interp_type, p->trunc_factor, p->pmax_elmts, &nc2);
+    L->cf = cf;
+    L->P = P;
+    L->own_P = 1;
+    ocsr *R = ocsr_transpose(P);
+    ocsr *AP = ocsr_matmul(A, P);
+    ocsr *Ac = ocsr_matmul(R, AP);
+    ocsr_free(AP);
+    ocsr_free(R);
+    olevel *Ln = &h->L[l + 1];
+    Ln->A = Ac;
+    Ln->own_A = 1;
+    Ln->part_starts = (obig *)xcalloc((size_t)nparts + 1, sizeof(obig));
+    for (int i = 0; i < n; i++)
+      if (cf[i] == C_PT) Ln->part_starts[part_of[i] + 1]++;
+    for (int q = 0; q < nparts; q++) Ln->part_starts[q + 1] += Ln->part_starts[q];
+    free(Sia);
+    free(Sja);
+    free(part_of);
+    l++;
+  }
+  h->nlev = l + 1;
+  finish_levels(h);
+  return h;
+}
+
+oamg *oamg_from_levels(int nlev, const ocsr *const *A, const ocsr *const *P, const int *const *cf,
+                       const obig *const *part_starts, const oamg_params *p) {
+  oamg *h = (oamg *)xcalloc(1, sizeof(oamg));
+  h->p = *p;
+  if (h->p.gs_chunk < 1) h->p.gs_chunk = 1;
+  const int nparts = p->nparts > 0 ? p->nparts : 1;
+  h->p.nparts = nparts;
+  h->p.part_starts = NULL;
+  h->nlev = nlev;
+  h->L = (olevel *)xcalloc((size_t)nlev, sizeof(olevel));
+  for (int l = 0; l < nlev; l++) {
+    olevel *L = &h->L[l];
+    L->A = (ocsr *)A[l];
+    L->part_starts = (obig *)xmalloc(sizeof(obig) * ((size_t)nparts + 1));
+    if (part_starts && part_starts[l])
+      memcpy(L->part_starts, part_starts[l], sizeof(obig) * ((size_t)nparts + 1));
+    else {
+      L->part_starts[0] = 0;
+      L->part_starts[1] = A[l]->nrows;
+    }
+    if (l < nlev - 1) {
+      L->P = (ocsr *)P[l];
+      L->cf = (int *)xmalloc(sizeof(int) * (size_t)A[l]->nrows);
+      memcpy(L->cf, cf[l], sizeof(int) * (size_t)A[l]->nrows);
+    }
+  }
+  finish_levels(h);
+  return h;
+}
+
+void oamg_free(oamg *h) {
+  if (!h) return;
+  for (int l = 0; l < h->nlev; l++) {
+    olevel *L = &h->L[l];
+    if (L->own_A) ocsr_free(L->A);
+    if (L->own_P) ocsr_free(L->P);
+    ocsr_free(L->R);
+    free(L->cf);
+    free(L->diag);
+    free(L->l1gs);
+    free(L->l1jac);
+    free(L->part_starts);
+    free(L->u);
+    free(L->f);
+    free(L->tmp);
+    free(L->old);
+    free(L->Cinv);
+  }
+  free(h->L);
+  free(h);
+}
+int oamg_num_levels(const oamg *h) { return h->nlev; }
+const ocsr *oamg_A(const oamg *h, int l) { return h->L[l].A; }
+const ocsr *oamg_P(const oamg *h, int l) { return h->L[l].P; }
+const int *oamg_cf(const oamg *h, int l) { return h->L[l].cf; }
+const double *oamg_l1(const oamg *h, int l) { return h->L[l].l1gs; }
+const obig *oamg_part_starts(const oamg *h, int l) { return h->L[l].part_starts; }
+
+/* ------------------------------------------------------------ AMG solve -- */
+
+/* hypre_BoomerAMGRelax (par_relax.c), SURVEY A.4.  Hybrid types use the chunk
+ * partition as HYPRE uses its OpenMP threads: current values inside the chunk,
+ * the pre-sweep snapshot outside it (other chunks, other partitions). */
+void oamg_relax(const oamg *h, int level, int type, int points, const double *f, double *u) {
+  const olevel *L = &h->L[level];
+  const ocsr *A = L->A;
+  const int n = A->nrows;
+  const double w = h->p.relax_weight * h->p.outer_weight;
+  const int *cf = L->cf;
+  if (type == 9) {
+    if (L->Cinv) {
+      for (int i = 0; i < n; i++) {
+        double s = 0.0;
+        for (int j = 0; j < n; j++) s += L->Cinv[(size_t)i * n + j] * f[j];
+        u[i] = s;
+      }
+      return;
+    }
+    type = h->p.relax_type[0]; /* coarsest level too large for a dense solve */
+  }
+  double *old = L->old;
+  memcpy(old, u, sizeof(double) * (size_t)n);
+  if (type == 0 || type == 7 || type == 18) {
+    const double *d = (type == 18) ? L->l1jac : L->diag;
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+    for (int i = 0; i < n; i++) {
+      if (points != 0 && cf && cf[i] != points) continue;
+      if (d[i] == 0.0) continue;
+      double res = f[i];
+      for (obig k = A->ia[i]; k < A->ia[i + 1]; k++) res -= A->a[k] * old[A->ja[k]];
+      u[i] = old[i] + w * res / d[i];
+    }
+    return;
+  }
+  const int l1 = (type == 8 || type == 13 || type == 14);
+  const int fwd = (type == 3 || type == 6 || type == 8 || type == 13);
+  const int bwd = (type == 4 || type == 6 || type == 8 || type == 14);
+  if (!fwd && !bwd) {
+    fprintf(stderr, "oracle: relax type %d not restated\n", type);
+    abort();
+  }
+  const double *dd = l1 ? L->l1gs : L->diag;
+  const int chunk = h->p.gs_chunk;
+  for (int p = 0; p < h->p.nparts; p++) {
+    const obig ps = L->part_starts[p], pe = L->part_starts[p + 1];
+    const obig nch = (pe - ps + chunk - 1) / chunk;
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+    for (obig c = 0; c < nch; c++) {
+      const obig cs = ps + c * chunk;
+      const obig ce = (cs + chunk < pe) ? cs + chunk : pe;
+      for (int dir = 0; dir < 2; dir++) {
+        if ((dir == 0 && !fwd) || (dir == 1 && !bwd)) continue;
+        for (obig t = 0; t < ce - cs; t++) {
+          const obig i = (dir == 0) ? cs + t : ce - 1 - t;
+          if (points != 0 && cf && cf[i] != points) continue;
+          if (dd[i] == 0.0) continue;
+          double res = f[i];
+          for (obig k = A->ia[i]; k < A->ia[i + 1]; k++) {
+            const int j = A->ja[k];
+            res -= A->a[k] * ((j >= cs && j < ce) ? u[j] : old[j]);
+          }
+          /* res holds f - (A u)_i including the diagonal term, so both the l1
+           * form (u += res/l1) and the plain form (u = (f - sum_{j!=i})/a_ii
+           * == u + res/a_ii) are the same statement with their own divisor */
+          u[i] += w * res / dd[i];
+        }
+      }
+    }
+  }
+}
+
+static void relax_sweeps(const oamg *h, int l, int which, const double *f, double *u) {
+  /* which: 0 down, 1 up, 2 coarsest; par_cycle.c / hypre_BoomerAMGRelaxIF:
+   * relax_order 1 => C then F going down, F then C going up, all on coarsest */
+  const int type = h->p.relax_type[which];
+  for (int s = 0; s < h->p.num_sweeps[which]; s++) {
+    if (which == 2 || h->p.relax_order != 1 || !h->L[l].cf) {
+      oamg_relax(h, l, type, 0, f, u);
+    } else if (which == 0) {
+      oamg_relax(h, l, type, C_PT, f, u);
+      oamg_relax(h, l, type, F_PT, f, u);
+    } else {
+      oamg_relax(h, l, type, F_PT, f, u);
+      oamg_relax(h, l, type, C_PT, f, u);
+    }
+  }
+}
+
+static void cycle_level(const oamg *h, int l, const double *f, double *u) {
+  /* hypre_BoomerAMGCycle (par_cycle.c), SURVEY A.3 */
+  const olevel *L = &h->L[l];
+  if (l == h->nlev - 1) {
+    relax_sweeps(h, l, 2, f, u);
+    return;
+  }
+  const olevel *Ln = &h->L[l + 1];
+  relax_sweeps(h, l, 0, f, u);
+  ocsr_matvec(-1.0, L->A, u, 1.0, f, L->tmp);      /* r = f - A u */
+  ocsr_matvec(1.0, L->R, L->tmp, 0.0, NULL, Ln->f); /* f_c = P^T r */
+  const int ncyc = (h->p.cycle_type == 2 && l + 1 < h->nlev - 1) ? 2 : 1;
+  memset(Ln->u, 0, sizeof(double) * (size_t)Ln->A->nrows);
+  for (int c = 0; c < ncyc; c++) cycle_level(h, l + 1, Ln->f, Ln->u);
+  ocsr_matvec(1.0, L->P, Ln->u, 1.0, u, u); /* u += P e */
+  relax_sweeps(h, l, 1, f, u);
+}
+
+void oamg_cycle(const oamg *h, const double *f, double *u) { cycle_level(h, 0, f, u); }
+
+static double vnorm(const double *x, int n) {
+  double s = 0.0;
+#pragma omp parallel for reduction(+ : s) schedule(static) if (g_threads > 1)
+  for (int i = 0; i < n; i++) s += x[i] * x[i];
+  return sqrt(s);
+}
+static double vdot(const double *x, const double *y, int n) {
+  double s = 0.0;
+#pragma omp parallel for reduction(+ : s) schedule(static) if (g_threads > 1)
+  for (int i = 0; i < n; i++) s += x[i] * y[i];
+  return s;
+}
+static void vaxpy(double a, const double *x, double *y, int n) {
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+  for (int i = 0; i < n; i++) y[i] += a * x[i];
+}
+static void vscale(double a, double *x, int n) {
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+  for (int i = 0; i < n; i++) x[i] *= a;
+}
+
+/* HYPRE_BoomerAMGSolve (par_amg_solve.c): as a preconditioner max_iter 1, tol 0
+ * (src/HypreSystem.cpp:154-155) => exactly one cycle, no norms. */
+int oamg_solve(const oamg *h, const double *b, double *x, int *iters, double *relres) {
+  const int n = h->L[0].A->nrows;
+  int it = 0;
+  double rel = 0.0;
+  double bn = 0.0;
+  double *r = NULL;
+  if (h->p.tol > 0.0) {
+    r = (double *)xmalloc(sizeof(double) * (size_t)n);
+    bn = vnorm(b, n);
+  }
+  while (it < h->p.max_iter) {
+    oamg_cycle(h, b, x);
+    it++;
+    if (h->p.tol > 0.0) {
+      ocsr_matvec(-1.0, h->L[0].A, x, 1.0, b, r);
+      double rn = vnorm(r, n);
+      rel = (bn > 0) ? rn / bn : rn;
+      if (rel <= h->p.tol) break;
+    }
+  }
+  free(r);
+  if (iters) *iters = it;
+  if (relres) *relres = rel;
+  return 0;
+}
+
+void oamg_precond(void *ctx, const double *r, double *z) {
+  const oamg *h = (const oamg *)ctx;
+  oamg_solve(h, r, z, NULL, NULL);
+}
+
+/* ---------------------------------------------------------------- GMRES -- */
+
+/* hypre_GMRESSolve (krylov/gmres.c); called through solverSolvePtr_
+ * at src/HypreSystem.cpp:723 with tol/max_iter/k_dim from :393-397, x0 = 0 (:580). */
+void ogmres_solve(const ocsr *A, const double *b, double *x, int kdim, double tol, double atol, int maxit,
+                  oprecond_fn M, void *Mctx, okrylov_result *res, double *norms) {
+  const int n = A->nrows;
+  const double epsmac = 1.e-16;
+  double **p = (double **)xmalloc(sizeof(double *) * ((size_t)kdim + 1));
+  for (int i = 0; i <= kdim; i++) p[i] = (double *)xcalloc((size_t)n, sizeof(double));
+  double *r = (double *)xcalloc((size_t)n, sizeof(double));
+  double *w = (double *)xcalloc((size_t)n, sizeof(double));
+  double *c = (double *)xcalloc((size_t)kdim + 1, sizeof(double));
+  double *s = (double *)xcalloc((size_t)kdim + 1, sizeof(double));
+  double *rs = (double *)xcalloc((size_t)kdim + 1, sizeof(double));
+  double **hh = (double **)xmalloc(sizeof(double *) * ((size_t)kdim + 1));
+  for (int i = 0; i <= kdim; i++) hh[i] = (double *)xcalloc((size_t)kdim, sizeof(double));
+
+  ocsr_matvec(-1.0, A, x, 1.0, b, p[0]);
+  const double b_norm = vnorm(b, n);
+  double r_norm = vnorm(p[0], n);
+  const double den = (b_norm > 0.0) ? b_norm : r_norm;
+  const double eps = fmax(atol, tol * den);
+  int iter = 0, converged = 0;
+  if (norms) norms[0] = r_norm;
+
+  while (iter < maxit) {
+    rs[0] = r_norm;
+    if (r_norm == 0.0) {
+      converged = 1;
+      break;
+    }
+    if (r_norm <= eps) {
+      ocsr_matvec(-1.0, A, x, 1.0, b, r);
+      r_norm = vnorm(r, n);
+      if (r_norm <= eps) {
+        converged = 1;
+        break;
+      }
+      /* false convergence 1: carry on from the true residual norm */
+    }
+    vscale(1.0 / r_norm, p[0], n);
+    int i = 0;
+    while (i < kdim && iter < maxit) {
+      i++;
+      iter++;
+      memset(r, 0, sizeof(double) * (size_t)n);
+      if (M)
+        M(Mctx, p[i - 1], r);
+      else
+        memcpy(r, p[i - 1], sizeof(double) * (size_t)n);
+      ocsr_matvec(1.0, A, r, 0.0, NULL, p[i]);
+      for (int j = 0; j < i; j++) {
+        hh[j][i - 1] = vdot(p[j], p[i], n);
+        vaxpy(-hh[j][i - 1], p[j], p[i], n);
+      }
+      double t = vnorm(p[i], n);
+      hh[i][i - 1] = t;
+      if (t != 0.0) vscale(1.0 / t, p[i], n);
+      for (int j = 1; j < i; j++) {
+        double tt = hh[j - 1][i - 1];
+        hh[j - 1][i - 1] = s[j - 1] * hh[j][i - 1] + c[j - 1] * tt;
+        hh[j][i - 1] = -s[j - 1] * tt + c[j - 1] * hh[j][i - 1];
+      }
+      double gamma = sqrt(hh[i - 1][i - 1] * hh[i - 1][i - 1] + hh[i][i - 1] * hh[i][i - 1]);
+      if (gamma == 0.0) gamma = epsmac;
+      c[i - 1] = hh[i - 1][i - 1] / gamma;
+      s[i - 1] = hh[i][i - 1] / gamma;
+      rs[i] = -hh[i][i - 1] * rs[i - 1];
+      rs[i] /= gamma;
+      rs[i - 1] = c[i - 1] * rs[i - 1];
+      hh[i - 1][i - 1] = s[i - 1] * hh[i][i - 1] + c[i - 1] * hh[i - 1][i - 1];
+      r_norm = fabs(rs[i]);
+      if (norms) norms[iter] = r_norm;
+      if (r_norm <= eps) break;
+    }
+    /* back substitution */
+    double *y = (double *)xcalloc((size_t)i + 1, sizeof(double));
+    memcpy(y, rs, sizeof(double) * (size_t)i);
+    y[i - 1] = y[i - 1] / hh[i - 1][i - 1];
+    for (int k = i - 2; k >= 0; k--) {
+      double t = 0.0;
+      for (int j = k + 1; j < i; j++) t -= hh[k][j] * y[j];
+      t += y[k];
+      y[k] = t / hh[k][k];
+    }
+    /* w = sum y_j p_j ; x += M^-1 w */
+    memcpy(w, p[i - 1], sizeof(double) * (size_t)n);
+    vscale(y[i - 1], w, n);
+    for (int j = i - 2; j >= 0; j--) vaxpy(y[j], p[j], w, n);
+    free(y);
+    memset(r, 0, sizeof(double) * (size_t)n);
+    if (M)
+      M(Mctx, w, r);
+    else
+      memcpy(r, w, sizeof(double) * (size_t)n);
+    vaxpy(1.0, r, x, n);
+    if (r_norm <= eps) {
+      ocsr_matvec(-1.0, A, x, 1.0, b, r);
+      r_norm = vnorm(r, n);
+      if (r_norm <= eps) {
+        converged = 1;
+        break;
+      }
+      /* false convergence 2: restart from the true residual */
+      memcpy(p[0], r, sizeof(double) * (size_t)n);
+      i = 0;
+    }
+    /* residual vector for the restart, rebuilt from the Givens data */
+    for (int j = i; j > 0; j--) {
+      rs[j - 1] = -s[j - 1] * rs[j];
+      rs[j] = c[j - 1] * rs[j];
+    }
+    if (i) vaxpy(rs[i] - 1.0, p[i], p[i], n);
+    for (int j = i - 1; j > 0; j--) vaxpy(rs[j], p[j], p[i], n);
+    if (i) {
+      vaxpy(rs[0] - 1.0, p[0], p[0], n);
+      vaxpy(1.0, p[i], p[0], n);
+    }
+  }
+  if (res) {
+    res->iters = iter;
+    res->converged = converged;
+    res->rel_res = (b_norm > 0.0) ? r_norm / b_norm : r_norm;
+    ocsr_matvec(-1.0, A, x, 1.0, b, r);
+    double tn = vnorm(r, n);
+    res->true_rel_res = (b_norm > 0.0) ? tn / b_norm : tn;
+  }
+  for (int i = 0; i <= kdim; i++) {
+    free(p[i]);
+    free(hh[i]);
+  }
+  free(p);
+  free(hh);
+  free(r);
+  free(w);
+  free(c);
+  free(s);
+  free(rs);
+}
+
+/* ------------------------------------------------------------- BiCGSTAB -- */
+
+/* hypre_BiCGSTABSolve (krylov/bicgstab.c); bound at
+ * src/HypreSystem.cpp:423-438. */
+void obicgstab_solve(const ocsr *A, const double *b, double *x, double tol, double atol, int maxit, oprecond_fn M,
+                     void *Mctx, okrylov_result *res, double *norms) {
+  const int n = A->nrows;
+  const double epsmac = 1.e-128;
+  double *r0 = (double *)xcalloc((size_t)n, sizeof(double));
+  double *r = (double *)xcalloc((size_t)n, sizeof(double));
+  double *p = (double *)xcalloc((size_t)n, sizeof(double));
+  double *v = (double *)xcalloc((size_t)n, sizeof(double));
+  double *q = (double *)xcalloc((size_t)n, sizeof(double));
+  double *s = (double *)xcalloc((size_t)n, sizeof(double));
+  double *t = (double *)xcalloc((size_t)n, sizeof(double));
+  ocsr_matvec(-1.0, A, x, 1.0, b, r0);
+  memcpy(r, r0, sizeof(double) * (size_t)n);
+  memcpy(p, r0, sizeof(double) * (size_t)n);
+  const double b_norm = vnorm(b, n);
+  double rho = vdot(r0, r0, n);
+  double r_norm = sqrt(rho);
+  const double den = (b_norm > 0.0) ? b_norm : r_norm;
+  const double eps = fmax(atol, tol * den);
+  int iter = 0, converged = 0;
+  if (norms) norms[0] = r_norm;
+  if (r_norm == 0.0) converged = 1;
+  while (!converged && iter < maxit) {
+    iter++;
+    memset(v, 0, sizeof(double) * (size_t)n);
+    if (M)
+      M(Mctx, p, v);
+    else
+      memcpy(v, p, sizeof(double) * (size_t)n);
+    ocsr_matvec(1.0, A, v, 0.0, NULL, q);
+    double temp = vdot(r0, q, n);
+    if (fabs(temp) < epsmac) break;
+    double alpha = rho / temp;
+    vaxpy(alpha, v, x, n);
+    vaxpy(-alpha, q, r, n);
+    r_norm = vnorm(r, n);
+    if (r_norm <= eps) {
+      ocsr_matvec(-1.0, A, x, 1.0, b, t);
+      double tn = vnorm(t, n);
+      if (tn <= eps) {
+        r_norm = tn;
+        if (norms) norms[iter] = r_norm;
+        converged = 1;
+        break;
+      }
+    }
+    memset(v, 0, sizeof(double) * (size_t)n);
+    if (M)
+      M(Mctx, r, v);
+    else
+      memcpy(v, r, sizeof(double) * (size_t)n);
+    ocsr_matvec(1.0, A, v, 0.0, NULL, s);
+    double ss = vdot(s, s, n);
+    double gamma = (ss != 0.0) ? vdot(r, s, n) / ss : 0.0;
+    vaxpy(gamma, v, x, n);
+    vaxpy(-gamma, s, r, n);
+    r_norm = vnorm(r, n);
+    if (norms) norms[iter] = r_norm;
+    if (r_norm <= eps) {
+      ocsr_matvec(-1.0, A, x, 1.0, b, t);
+      double tn = vnorm(t, n);
+      if (tn <= eps) {
+        r_norm = tn;
+        converged = 1;
+        break;
+      }
+    }
+    if (fabs(rho) < epsmac) break;
+    double beta = 1.0 / rho;
+    rho = vdot(r0, r, n);
+    beta *= rho;
+    vaxpy(-gamma, q, p, n);
+    if (fabs(gamma) < epsmac) break;
+    vscale(beta * alpha / gamma, p, n);
+    vaxpy(1.0, r, p, n);
+  }
+  if (res) {
+    res->iters = iter;
+    res->converged = converged;
+    res->rel_res = (b_norm > 0.0) ? r_norm / b_norm : r_norm;
+    ocsr_matvec(-1.0, A, x, 1.0, b, t);
+    double tn = vnorm(t, n);
+    res->true_rel_res = (b_norm > 0.0) ? tn / b_norm : tn;
+  }
+  free(r0);
+  free(r);
+  free(p);
+  free(v);
+  free(q);
+  free(s);
+  free(t);
+}
