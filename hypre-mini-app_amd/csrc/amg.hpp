@@ -1,0 +1,75 @@
+// BoomerAMG-shaped preconditioner/solver object: parameters, hierarchy, V-cycle.
+#pragma once
+#include "parcsr.hpp"
+
+namespace mi {
+
+struct AmgParams {
+  int print_level = 0;
+  int debug_flag = 0;
+  int coarsen_type = 10;          // library default HMIS; the app sets 8 (HypreSystem.cpp:126)
+  int interp_type = 6;            // extended+i
+  double strong_threshold = 0.25; // the app sets 0.57 (HypreSystem.cpp:159)
+  double max_row_sum = 0.9;
+  double trunc_factor = 0.0;
+  int pmax_elmts = 4;
+  int max_levels = 25;
+  int max_coarse_size = 9;
+  int min_coarse_size = 0;
+  int relax_type[3] = {13, 14, 9};  // down, up, coarsest
+  int num_sweeps[3] = {1, 1, 1};
+  int relax_order = 0;
+  double relax_weight = 1.0;
+  double outer_weight = 1.0;
+  int cycle_type = 1;
+  int max_iter = 20;
+  double tol = 1e-7;
+  int gs_chunk = 0;  // 0 => runtime default (ctx().gs_chunk)
+  int agg_num_levels = 0, agg_interp_type = 4, agg_pmax_elmts = 0, keep_transpose = 0, rap2 = 0;
+  int smooth_num_sweeps = 1;
+};
+
+struct AmgLevel {
+  ParCSR *A = nullptr;
+  std::unique_ptr<ParCSR> A_own;
+  int n = 0;
+  HostCSR P, R;  // rank-local interpolation and its transpose
+  DevCSR dP, dR;
+  std::vector<int> cf;  // +1 C, -1 F (empty on the coarsest level)
+  DVec<signed char> d_cf;
+  std::vector<double> diag, l1gs, l1jac;
+  DVec<double> d_diag, d_l1gs, d_l1jac;
+  DVec<double> u, f, tmp, snap;
+  // coarsest level dense solve (relax type 9)
+  DVec<double> Cinv;    // n_local x (size*slot) padded inverse rows
+  DVec<double> fgather; // size*slot
+  DVec<double> fslot;   // slot
+  int slot = 0;
+  bool dense = false;
+};
+
+struct BoomerAMG {
+  AmgParams p;
+  std::vector<AmgLevel> L;
+  bool is_setup = false;
+  int num_iterations = 0;
+  double final_rel_res = 0.0;
+  double setup_seconds = 0.0;
+  int chunk() const;
+
+  void setup(ParCSR &A);
+  // HYPRE_BoomerAMGSolve: x is the initial guess; up to max_iter cycles
+  void solve(ParCSR &A, ParVector &b, ParVector &x);
+
+  // pieces (exposed for the parity tests)
+  void relax(int level, int type, int points, const double *f, DVec<double> &u);
+  void relax_sweeps(int level, int which, const double *f, DVec<double> &u);
+  void cycle(int level, const double *f, DVec<double> &u);
+  double operator_complexity() const;
+};
+
+// host algorithms (amg_setup.cpp), exposed for tests
+void host_transpose(const HostCSR &A, HostCSR &T);
+void host_spgemm(const HostCSR &A, const HostCSR &B, HostCSR &C);
+
+}  // namespace mi

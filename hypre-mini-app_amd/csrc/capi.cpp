@@ -1,0 +1,1134 @@
+// extern "C" boundary: the HYPRE-shaped C ABI declared in include/*.h.
+// Plain pointers and sizes in, HYPRE_Int error codes out; C++ exceptions never
+// cross it.  The driver ignores return codes (src/HypreSystem.cpp:723), so
+// failures also print to stderr and accumulate in the HYPRE-style error flag.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <thread>
+
+#include "HYPRE_mi_ext.h"
+#include "_hypre_parcsr_ls.h"
+#include "kernels.hpp"
+#include "profile.hpp"
+#include "solvers.hpp"
+
+using namespace mi;
+
+namespace {
+
+int g_error_flag = 0;
+std::string g_last_error;
+
+int record_error(int code, const std::string &msg) {
+  g_error_flag |= code;
+  g_last_error = msg;
+  fprintf(stderr, "mi_hypre error (%d): %s\n", code, msg.c_str());
+  fflush(stderr);
+  return code;
+}
+
+#define API_BEGIN try {
+#define API_END                                             \
+  }                                                         \
+  catch (const mi::Error &e) {                              \
+    return record_error(e.code, e.what());                  \
+  }                                                         \
+  catch (const std::bad_alloc &) {                          \
+    return record_error(HYPRE_ERROR_MEMORY, "out of host memory"); \
+  }                                                         \
+  catch (const std::exception &e) {                         \
+    return record_error(HYPRE_ERROR_GENERIC, e.what());     \
+  }                                                         \
+  return 0;
+
+struct IJMatrixObj {
+  gidx ilower, iupper, jlower, jupper;
+  std::vector<IJEntryBatch> batches;
+  ParCSR par;
+  bool assembled = false;
+};
+
+struct IJVectorObj {
+  gidx jlower, jupper;
+  int ncomp = 1;
+  ParVector par;
+  bool initialized = false;
+};
+
+inline IJMatrixObj *M(HYPRE_IJMatrix m) { return reinterpret_cast<IJMatrixObj *>(m); }
+inline IJVectorObj *V(HYPRE_IJVector v) { return reinterpret_cast<IJVectorObj *>(v); }
+inline ParCSR *PM(HYPRE_ParCSRMatrix a) { return reinterpret_cast<ParCSR *>(a); }
+inline ParVector *PV(HYPRE_ParVector v) { return reinterpret_cast<ParVector *>(v); }
+inline SolverBase *S(HYPRE_Solver s) { return reinterpret_cast<SolverBase *>(s); }
+
+template <class T>
+T *as(HYPRE_Solver s, SolverBase::Kind k, const char *what) {
+  SolverBase *b = S(s);
+  if (!b) fail(HYPRE_ERROR_ARG, std::string(what) + ": NULL solver handle");
+  if (b->kind != k) fail(HYPRE_ERROR_ARG, std::string(what) + ": handle is not of the expected solver type");
+  return static_cast<T *>(b);
+}
+AmgSolver *AMG(HYPRE_Solver s) { return as<AmgSolver>(s, SolverBase::K_AMG, "BoomerAMG"); }
+GmresSolver *GM(HYPRE_Solver s) { return as<GmresSolver>(s, SolverBase::K_GMRES, "GMRES"); }
+BicgstabSolver *BI(HYPRE_Solver s) { return as<BicgstabSolver>(s, SolverBase::K_BICGSTAB, "BiCGSTAB"); }
+KrylovSolver *KR(HYPRE_Solver s) {
+  SolverBase *b = S(s);
+  if (!b || (b->kind != SolverBase::K_GMRES && b->kind != SolverBase::K_BICGSTAB))
+    fail(HYPRE_ERROR_ARG, "handle is not a Krylov solver");
+  return static_cast<KrylovSolver *>(b);
+}
+
+// copy n elements from a host-or-device pointer into a host vector
+template <class T>
+void fetch(const T *src, size_t n, std::vector<T> &dst) {
+  dst.resize(n);
+  if (!n) return;
+  if (is_device_pointer(src))
+    MI_HIP(hipMemcpy(dst.data(), src, n * sizeof(T), hipMemcpyDeviceToHost));
+  else
+    memcpy(dst.data(), src, n * sizeof(T));
+}
+
+void ij_stage(IJMatrixObj *m, int nrows, const int *ncols, const gidx *rows, const int *row_indexes, const gidx *cols,
+              const double *vals, bool add) {
+  if (m->assembled) fail(HYPRE_ERROR_GENERIC, "IJMatrix: values set after Assemble (re-assembly is not supported)");
+  if (nrows <= 0) return;
+  IJEntryBatch b;
+  b.add = add;
+  if (!ncols) {
+    // one entry per "row" (src/HypreSystem.cpp:942: ncols == NULL, row_indexes == NULL)
+    fetch(rows, (size_t)nrows, b.rows);
+    fetch(cols, (size_t)nrows, b.cols);
+    fetch(vals, (size_t)nrows, b.vals);
+  } else {
+    std::vector<int> nc, ri;
+    std::vector<gidx> r;
+    fetch(ncols, (size_t)nrows, nc);
+    fetch(rows, (size_t)nrows, r);
+    if (row_indexes) fetch(row_indexes, (size_t)nrows, ri);
+    size_t total = 0, span = 0;
+    for (int i = 0; i < nrows; i++) {
+      total += (size_t)nc[(size_t)i];
+      const size_t endi = (row_indexes ? (size_t)ri[(size_t)i] : total - (size_t)nc[(size_t)i]) + (size_t)nc[(size_t)i];
+      span = std::max(span, endi);
+    }
+    std::vector<gidx> c;
+    std::vector<double> v;
+    fetch(cols, span, c);
+    fetch(vals, span, v);
+    b.rows.reserve(total);
+    b.cols.reserve(total);
+    b.vals.reserve(total);
+    size_t run = 0;
+    for (int i = 0; i < nrows; i++) {
+      const size_t start = row_indexes ? (size_t)ri[(size_t)i] : run;
+      for (int k = 0; k < nc[(size_t)i]; k++) {
+        b.rows.push_back(r[(size_t)i]);
+        b.cols.push_back(c[start + (size_t)k]);
+        b.vals.push_back(v[start + (size_t)k]);
+      }
+      run += (size_t)nc[(size_t)i];
+    }
+  }
+  m->batches.push_back(std::move(b));
+}
+
+void vec_set(IJVectorObj *v, int n, const gidx *indices, const double *values, bool add) {
+  if (!v->initialized) fail(HYPRE_ERROR_GENERIC, "IJVector: SetValues before Initialize");
+  if (n <= 0) return;
+  ensure_init();
+  hipStream_t s = ctx().stream;
+  std::vector<gidx> idx;
+  std::vector<int> loc((size_t)n);
+  if (indices) {
+    fetch(indices, (size_t)n, idx);
+    for (int i = 0; i < n; i++) {
+      const gidx g = idx[(size_t)i];
+      if (g < v->jlower || g > v->jupper) fail(HYPRE_ERROR_ARG, "IJVector: index outside the local range");
+      loc[(size_t)i] = (int)(g - v->jlower);
+    }
+  } else {
+    if (n > v->par.n) fail(HYPRE_ERROR_ARG, "IJVector: more values than local entries");
+    for (int i = 0; i < n; i++) loc[(size_t)i] = i;
+  }
+  DVec<int> dloc;
+  dloc.upload(loc);
+  DVec<double> dval;
+  const double *src = values;
+  if (!is_device_pointer(values)) {
+    dval.alloc((size_t)n);
+    dval.upload(values, (size_t)n);
+    src = dval.p;
+  }
+  if (add)
+    k::scatter_add(v->par.data(), dloc.p, src, n, s);
+  else
+    k::scatter_set(v->par.data(), dloc.p, src, n, s);
+  MI_HIP(hipStreamSynchronize(s));
+}
+
+int stub_fail(const char *family) {
+  return record_error(HYPRE_ERROR_GENERIC, std::string(family) +
+                                               " is outside the north-star path of this library (GMRES/BiCGSTAB + "
+                                               "BoomerAMG) and is not implemented");
+}
+
+void write_ij_matrix(const ParCSR &A, const char *filename, int rank) {
+  char fn[2048];
+  snprintf(fn, sizeof(fn), "%s.%05d", filename, rank);
+  FILE *fp = fopen(fn, "w");
+  if (!fp) fail(HYPRE_ERROR_GENERIC, std::string("cannot open ") + fn);
+  fprintf(fp, "%lld %lld %lld %lld\n", (long long)A.row_start, (long long)A.row_end - 1, (long long)A.row_start,
+          (long long)A.row_end - 1);
+  for (int i = 0; i < A.nrows; i++) {
+    // merge diag and offd in ascending global column order
+    std::vector<std::pair<gidx, double>> row;
+    for (int64_t k = A.diag.ia[(size_t)i]; k < A.diag.ia[(size_t)i + 1]; k++)
+      row.push_back({A.row_start + A.diag.ja[(size_t)k], A.diag.a[(size_t)k]});
+    for (int64_t k = A.offd.ia[(size_t)i]; k < A.offd.ia[(size_t)i + 1]; k++)
+      row.push_back({A.col_map_offd[(size_t)A.offd.ja[(size_t)k]], A.offd.a[(size_t)k]});
+    std::sort(row.begin(), row.end());
+    for (auto &e : row) fprintf(fp, "%lld %lld %.14e\n", (long long)(A.row_start + i), (long long)e.first, e.second);
+  }
+  fclose(fp);
+}
+
+}  // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------ utilities
+HYPRE_Int HYPRE_Initialize(void) {
+  API_BEGIN
+  ensure_init();
+  API_END
+}
+HYPRE_Int HYPRE_Init(void) { return HYPRE_Initialize(); }
+HYPRE_Int HYPRE_Initialized(void) { return ctx().inited ? 1 : 0; }
+HYPRE_Int HYPRE_Finalize(void) {
+  API_BEGIN
+  Ctx &c = ctx();
+  if (c.inited) {
+    MI_HIP(hipDeviceSynchronize());
+    delete c.timer;
+    c.timer = nullptr;
+    c.comm.reset();
+    c.red_partials.release();
+    c.red_out.release();
+    if (c.h_pinned) (void)hipHostFree(c.h_pinned);
+    c.h_pinned = nullptr;
+    if (c.stream) (void)hipStreamDestroy(c.stream);
+    c.stream = nullptr;
+    c.inited = false;
+  }
+  API_END
+}
+HYPRE_Int HYPRE_GetError(void) { return g_error_flag; }
+HYPRE_Int HYPRE_ClearAllErrors(void) {
+  g_error_flag = 0;
+  g_last_error.clear();
+  return 0;
+}
+const char *HYPRE_MI_LastErrorMessage(void) { return g_last_error.c_str(); }
+
+HYPRE_Int HYPRE_SetMemoryLocation(HYPRE_MemoryLocation loc) {
+  if (loc != HYPRE_MEMORY_DEVICE)
+    return record_error(HYPRE_ERROR_ARG, "HYPRE_SetMemoryLocation: only HYPRE_MEMORY_DEVICE is implemented (no CPU path)");
+  return 0;
+}
+HYPRE_Int HYPRE_SetExecutionPolicy(HYPRE_ExecutionPolicy pol) {
+  if (pol != HYPRE_EXEC_DEVICE)
+    return record_error(HYPRE_ERROR_ARG, "HYPRE_SetExecutionPolicy: only HYPRE_EXEC_DEVICE is implemented (no CPU path)");
+  return 0;
+}
+HYPRE_Int HYPRE_SetGPUMemoryPoolSize(HYPRE_Int, HYPRE_Int, HYPRE_Int, size_t) { return 0; }
+HYPRE_Int hypre_SetCubMemPoolSize(unsigned, unsigned, unsigned, size_t) { return 0; }
+HYPRE_Int HYPRE_SetUmpireDevicePoolName(const char *) { return 0; }
+HYPRE_Int HYPRE_SetUmpireDevicePoolSize(size_t) { return 0; }
+HYPRE_Int HYPRE_SetSpGemmUseVendor(HYPRE_Int) { return 0; }
+HYPRE_Int HYPRE_SetSpMVUseVendor(HYPRE_Int) { return 0; }
+HYPRE_Int HYPRE_SetSpTransUseVendor(HYPRE_Int) { return 0; }
+HYPRE_Int hypre_ResetDeviceRandGenerator(unsigned long long, unsigned long long) { return 0; }
+
+void *hypre_MAlloc(size_t bytes, HYPRE_MemoryLocation loc) {
+  if (bytes == 0) return nullptr;
+  if (loc == HYPRE_MEMORY_DEVICE) {
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+      record_error(HYPRE_ERROR_MEMORY, "hypre_MAlloc: hipMalloc of " + std::to_string(bytes) + " bytes failed");
+      return nullptr;
+    }
+    return p;
+  }
+  return malloc(bytes);
+}
+void *hypre_CAlloc(size_t count, size_t elt, HYPRE_MemoryLocation loc) {
+  void *p = hypre_MAlloc(count * elt, loc);
+  if (!p) return p;
+  if (loc == HYPRE_MEMORY_DEVICE)
+    (void)hipMemset(p, 0, count * elt);
+  else
+    memset(p, 0, count * elt);
+  return p;
+}
+void hypre_Free(void *ptr, HYPRE_MemoryLocation loc) {
+  if (!ptr) return;
+  if (loc == HYPRE_MEMORY_DEVICE)
+    (void)hipFree(ptr);
+  else
+    free(ptr);
+}
+void hypre_Memcpy(void *dst, const void *src, size_t bytes, HYPRE_MemoryLocation, HYPRE_MemoryLocation) {
+  if (!bytes) return;
+  if (hipMemcpy(dst, src, bytes, hipMemcpyDefault) != hipSuccess)
+    record_error(HYPRE_ERROR_GENERIC, "hypre_Memcpy failed");
+}
+
+// ------------------------------------------------------------------ IJ matrix
+HYPRE_Int HYPRE_IJMatrixCreate(MPI_Comm, HYPRE_BigInt ilower, HYPRE_BigInt iupper, HYPRE_BigInt jlower,
+                               HYPRE_BigInt jupper, HYPRE_IJMatrix *matrix) {
+  API_BEGIN
+  if (!matrix) fail(HYPRE_ERROR_ARG, "IJMatrixCreate: NULL output");
+  if (iupper < ilower - 1 || jupper < jlower - 1) fail(HYPRE_ERROR_ARG, "IJMatrixCreate: bad range");
+  IJMatrixObj *m = new IJMatrixObj();
+  m->ilower = ilower;
+  m->iupper = iupper;
+  m->jlower = jlower;
+  m->jupper = jupper;
+  m->par.row_start = ilower;
+  m->par.row_end = iupper + 1;
+  m->par.nrows = (int)(iupper - ilower + 1);
+  *matrix = reinterpret_cast<HYPRE_IJMatrix>(m);
+  API_END
+}
+HYPRE_Int HYPRE_IJMatrixDestroy(HYPRE_IJMatrix matrix) {
+  API_BEGIN
+  delete M(matrix);
+  API_END
+}
+HYPRE_Int HYPRE_IJMatrixSetObjectType(HYPRE_IJMatrix, HYPRE_Int type) {
+  if (type != HYPRE_PARCSR) return record_error(HYPRE_ERROR_ARG, "IJMatrixSetObjectType: only HYPRE_PARCSR");
+  return 0;
+}
+HYPRE_Int HYPRE_IJMatrixInitialize(HYPRE_IJMatrix matrix) {
+  API_BEGIN
+  if (!matrix) fail(HYPRE_ERROR_ARG, "IJMatrixInitialize: NULL handle");
+  ensure_init();
+  API_END
+}
+HYPRE_Int HYPRE_IJMatrixGetObject(HYPRE_IJMatrix matrix, void **object) {
+  API_BEGIN
+  if (!matrix || !object) fail(HYPRE_ERROR_ARG, "IJMatrixGetObject: NULL argument");
+  *object = &M(matrix)->par;
+  API_END
+}
+HYPRE_Int HYPRE_IJMatrixSetConstantValues(HYPRE_IJMatrix matrix, HYPRE_Complex value) {
+  API_BEGIN
+  IJMatrixObj *m = M(matrix);
+  if (!m) fail(HYPRE_ERROR_ARG, "IJMatrixSetConstantValues: NULL handle");
+  if (m->assembled) fail(HYPRE_ERROR_GENERIC, "IJMatrixSetConstantValues after Assemble is not supported");
+  for (auto &b : m->batches) std::fill(b.vals.begin(), b.vals.end(), value);
+  API_END
+}
+HYPRE_Int HYPRE_IJMatrixSetValues2(HYPRE_IJMatrix matrix, HYPRE_Int nrows, HYPRE_Int *ncols, const HYPRE_BigInt *rows,
+                                   const HYPRE_Int *row_indexes, const HYPRE_BigInt *cols,
+                                   const HYPRE_Complex *values) {
+  API_BEGIN
+  ij_stage(M(matrix), nrows, ncols, rows, row_indexes, cols, values, false);
+  API_END
+}
+HYPRE_Int HYPRE_IJMatrixAddToValues2(HYPRE_IJMatrix matrix, HYPRE_Int nrows, HYPRE_Int *ncols,
+                                     const HYPRE_BigInt *rows, const HYPRE_Int *row_indexes,
+                                     const HYPRE_BigInt *cols, const HYPRE_Complex *values) {
+  API_BEGIN
+  ij_stage(M(matrix), nrows, ncols, rows, row_indexes, cols, values, true);
+  API_END
+}
+HYPRE_Int HYPRE_IJMatrixSetValues(HYPRE_IJMatrix matrix, HYPRE_Int nrows, HYPRE_Int *ncols, const HYPRE_BigInt *rows,
+                                  const HYPRE_BigInt *cols, const HYPRE_Complex *values) {
+  return HYPRE_IJMatrixSetValues2(matrix, nrows, ncols, rows, nullptr, cols, values);
+}
+HYPRE_Int HYPRE_IJMatrixAddToValues(HYPRE_IJMatrix matrix, HYPRE_Int nrows, HYPRE_Int *ncols,
+                                    const HYPRE_BigInt *rows, const HYPRE_BigInt *cols, const HYPRE_Complex *values) {
+  return HYPRE_IJMatrixAddToValues2(matrix, nrows, ncols, rows, nullptr, cols, values);
+}
+HYPRE_Int HYPRE_IJMatrixAssemble(HYPRE_IJMatrix matrix) {
+  API_BEGIN
+  IJMatrixObj *m = M(matrix);
+  if (!m) fail(HYPRE_ERROR_ARG, "IJMatrixAssemble: NULL handle");
+  if (m->assembled) return 0;
+  ensure_init();
+  Comm &comm = *ctx().comm;
+  assemble_parcsr(comm, m->ilower, m->iupper, m->jlower, m->jupper, m->batches, m->par);
+  m->par.finalize(comm);
+  m->assembled = true;
+  API_END
+}
+HYPRE_Int HYPRE_IJMatrixPrint(HYPRE_IJMatrix matrix, const char *filename) {
+  API_BEGIN
+  IJMatrixObj *m = M(matrix);
+  if (!m || !m->assembled) fail(HYPRE_ERROR_GENERIC, "IJMatrixPrint: matrix is not assembled");
+  write_ij_matrix(m->par, filename, ctx().comm->rank);
+  API_END
+}
+HYPRE_Int HYPRE_IJMatrixGetLocalRange(HYPRE_IJMatrix matrix, HYPRE_BigInt *ilower, HYPRE_BigInt *iupper,
+                                      HYPRE_BigInt *jlower, HYPRE_BigInt *jupper) {
+  API_BEGIN
+  IJMatrixObj *m = M(matrix);
+  if (!m) fail(HYPRE_ERROR_ARG, "IJMatrixGetLocalRange: NULL handle");
+  *ilower = m->ilower;
+  *iupper = m->iupper;
+  *jlower = m->jlower;
+  *jupper = m->jupper;
+  API_END
+}
+HYPRE_Int HYPRE_IJMatrixSetMaxOnProcElmts(HYPRE_IJMatrix, HYPRE_Int) { return 0; }
+HYPRE_Int HYPRE_IJMatrixSetOffProcSendElmts(HYPRE_IJMatrix, HYPRE_Int) { return 0; }
+HYPRE_Int HYPRE_IJMatrixSetOffProcRecvElmts(HYPRE_IJMatrix, HYPRE_Int) { return 0; }
+HYPRE_Int HYPRE_IJMatrixRead(const char *, MPI_Comm, HYPRE_Int, HYPRE_IJMatrix *) {
+  return stub_fail("HYPRE_IJMatrixRead (dead code in the driver, src/HypreSystem.cpp:1086-1133)");
+}
+
+// ------------------------------------------------------------------ IJ vector
+HYPRE_Int HYPRE_IJVectorCreate(MPI_Comm, HYPRE_BigInt jlower, HYPRE_BigInt jupper, HYPRE_IJVector *vector) {
+  API_BEGIN
+  if (!vector) fail(HYPRE_ERROR_ARG, "IJVectorCreate: NULL output");
+  IJVectorObj *v = new IJVectorObj();
+  v->jlower = jlower;
+  v->jupper = jupper;
+  *vector = reinterpret_cast<HYPRE_IJVector>(v);
+  API_END
+}
+HYPRE_Int HYPRE_IJVectorDestroy(HYPRE_IJVector vector) {
+  API_BEGIN
+  delete V(vector);
+  API_END
+}
+HYPRE_Int HYPRE_IJVectorSetObjectType(HYPRE_IJVector, HYPRE_Int type) {
+  if (type != HYPRE_PARCSR) return record_error(HYPRE_ERROR_ARG, "IJVectorSetObjectType: only HYPRE_PARCSR");
+  return 0;
+}
+HYPRE_Int HYPRE_IJVectorSetNumComponents(HYPRE_IJVector vector, HYPRE_Int n) {
+  API_BEGIN
+  IJVectorObj *v = V(vector);
+  if (!v || n < 1) fail(HYPRE_ERROR_ARG, "IJVectorSetNumComponents: bad argument");
+  if (v->initialized) fail(HYPRE_ERROR_GENERIC, "IJVectorSetNumComponents after Initialize");
+  v->ncomp = n;
+  API_END
+}
+HYPRE_Int HYPRE_IJVectorSetComponent(HYPRE_IJVector vector, HYPRE_Int c) {
+  API_BEGIN
+  IJVectorObj *v = V(vector);
+  if (!v || c < 0 || c >= v->ncomp) fail(HYPRE_ERROR_ARG, "IJVectorSetComponent: component out of range");
+  v->par.cur = c;
+  API_END
+}
+HYPRE_Int HYPRE_IJVectorInitialize(HYPRE_IJVector vector) {
+  API_BEGIN
+  IJVectorObj *v = V(vector);
+  if (!v) fail(HYPRE_ERROR_ARG, "IJVectorInitialize: NULL handle");
+  ensure_init();
+  v->par.init(v->jlower, v->jupper + 1, v->ncomp);
+  v->initialized = true;
+  API_END
+}
+HYPRE_Int HYPRE_IJVectorGetObject(HYPRE_IJVector vector, void **object) {
+  API_BEGIN
+  if (!vector || !object) fail(HYPRE_ERROR_ARG, "IJVectorGetObject: NULL argument");
+  *object = &V(vector)->par;
+  API_END
+}
+HYPRE_Int HYPRE_IJVectorSetValues(HYPRE_IJVector vector, HYPRE_Int nvalues, const HYPRE_BigInt *indices,
+                                  const HYPRE_Complex *values) {
+  API_BEGIN
+  vec_set(V(vector), nvalues, indices, values, false);
+  API_END
+}
+HYPRE_Int HYPRE_IJVectorAddToValues(HYPRE_IJVector vector, HYPRE_Int nvalues, const HYPRE_BigInt *indices,
+                                    const HYPRE_Complex *values) {
+  API_BEGIN
+  vec_set(V(vector), nvalues, indices, values, true);
+  API_END
+}
+HYPRE_Int HYPRE_IJVectorGetValues(HYPRE_IJVector vector, HYPRE_Int nvalues, const HYPRE_BigInt *indices,
+                                  HYPRE_Complex *values) {
+  API_BEGIN
+  IJVectorObj *v = V(vector);
+  if (!v || !v->initialized) fail(HYPRE_ERROR_GENERIC, "IJVectorGetValues: vector not initialised");
+  if (nvalues <= 0) return 0;
+  hipStream_t s = ctx().stream;
+  const bool dev_out = is_device_pointer(values);
+  if (!indices) {
+    if (nvalues > v->par.n) fail(HYPRE_ERROR_ARG, "IJVectorGetValues: more values than local entries");
+    MI_HIP(hipMemcpyAsync(values, v->par.data(), (size_t)nvalues * sizeof(double),
+                          dev_out ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    return 0;
+  }
+  std::vector<gidx> idx;
+  fetch(indices, (size_t)nvalues, idx);
+  std::vector<int> loc((size_t)nvalues);
+  for (int i = 0; i < nvalues; i++) {
+    if (idx[(size_t)i] < v->jlower || idx[(size_t)i] > v->jupper)
+      fail(HYPRE_ERROR_ARG, "IJVectorGetValues: index outside the local range");
+    loc[(size_t)i] = (int)(idx[(size_t)i] - v->jlower);
+  }
+  DVec<int> dloc;
+  dloc.upload(loc);
+  DVec<double> tmp((size_t)nvalues);
+  k::gather(v->par.data(), dloc.p, tmp.p, nvalues, s);
+  MI_HIP(hipMemcpyAsync(values, tmp.p, (size_t)nvalues * sizeof(double),
+                        dev_out ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+  API_END
+}
+HYPRE_Int HYPRE_IJVectorAssemble(HYPRE_IJVector vector) {
+  API_BEGIN
+  if (!vector) fail(HYPRE_ERROR_ARG, "IJVectorAssemble: NULL handle");
+  API_END
+}
+HYPRE_Int HYPRE_IJVectorPrint(HYPRE_IJVector vector, const char *filename) {
+  API_BEGIN
+  IJVectorObj *v = V(vector);
+  if (!v || !v->initialized) fail(HYPRE_ERROR_GENERIC, "IJVectorPrint: vector not initialised");
+  std::vector<double> h((size_t)v->par.n);
+  if (v->par.n) MI_HIP(hipMemcpy(h.data(), v->par.data(), h.size() * sizeof(double), hipMemcpyDeviceToHost));
+  char fn[2048];
+  snprintf(fn, sizeof(fn), "%s.%05d", filename, ctx().comm->rank);
+  FILE *fp = fopen(fn, "w");
+  if (!fp) fail(HYPRE_ERROR_GENERIC, std::string("cannot open ") + fn);
+  fprintf(fp, "%lld %lld\n", (long long)v->jlower, (long long)v->jupper);
+  for (int i = 0; i < v->par.n; i++) fprintf(fp, "%lld %.14e\n", (long long)(v->jlower + i), h[(size_t)i]);
+  fclose(fp);
+  API_END
+}
+HYPRE_Int HYPRE_IJVectorSetMaxOnProcElmts(HYPRE_IJVector, HYPRE_Int) { return 0; }
+HYPRE_Int HYPRE_IJVectorSetOffProcSendElmts(HYPRE_IJVector, HYPRE_Int) { return 0; }
+HYPRE_Int HYPRE_IJVectorSetOffProcRecvElmts(HYPRE_IJVector, HYPRE_Int) { return 0; }
+HYPRE_Int HYPRE_IJVectorRead(const char *, MPI_Comm, HYPRE_Int, HYPRE_IJVector *) {
+  return stub_fail("HYPRE_IJVectorRead (dead code in the driver, src/HypreSystem.cpp:1086-1133)");
+}
+
+// ------------------------------------------------------------------ ParCSR / ParVector
+HYPRE_Int HYPRE_ParCSRMatrixMatvec(HYPRE_Complex alpha, HYPRE_ParCSRMatrix A, HYPRE_ParVector x, HYPRE_Complex beta,
+                                   HYPRE_ParVector y) {
+  API_BEGIN
+  if (!A || !x || !y) fail(HYPRE_ERROR_ARG, "ParCSRMatrixMatvec: NULL argument");
+  ParCSR *a = PM(A);
+  if (PV(x)->n != a->nrows || PV(y)->n != a->nrows) fail(HYPRE_ERROR_ARG, "ParCSRMatrixMatvec: size mismatch");
+  a->matvec(*ctx().comm, alpha, PV(x)->data(), beta, PV(y)->data(), PV(y)->data(), ctx().stream, k::PROF_SPMV_L0);
+  MI_HIP(hipStreamSynchronize(ctx().stream));
+  API_END
+}
+HYPRE_Int HYPRE_ParCSRMatrixGetDims(HYPRE_ParCSRMatrix A, HYPRE_BigInt *Mr, HYPRE_BigInt *Nc) {
+  API_BEGIN
+  if (!A) fail(HYPRE_ERROR_ARG, "ParCSRMatrixGetDims: NULL handle");
+  *Mr = *Nc = PM(A)->global_rows();
+  API_END
+}
+HYPRE_Int HYPRE_ParCSRMatrixGetLocalRange(HYPRE_ParCSRMatrix A, HYPRE_BigInt *rs, HYPRE_BigInt *re, HYPRE_BigInt *cs,
+                                          HYPRE_BigInt *ce) {
+  API_BEGIN
+  if (!A) fail(HYPRE_ERROR_ARG, "ParCSRMatrixGetLocalRange: NULL handle");
+  *rs = *cs = PM(A)->row_start;
+  *re = *ce = PM(A)->row_end - 1;
+  API_END
+}
+HYPRE_Int hypre_ParCSRMatrixPrintIJ(const hypre_ParCSRMatrix *A, HYPRE_Int, HYPRE_Int, const char *filename) {
+  API_BEGIN
+  if (!A) fail(HYPRE_ERROR_ARG, "ParCSRMatrixPrintIJ: NULL handle");
+  write_ij_matrix(*reinterpret_cast<const ParCSR *>(A), filename, ctx().comm->rank);
+  API_END
+}
+HYPRE_Int HYPRE_ParVectorSetConstantValues(HYPRE_ParVector v, HYPRE_Complex value) {
+  API_BEGIN
+  if (!v) fail(HYPRE_ERROR_ARG, "ParVectorSetConstantValues: NULL handle");
+  ParVector *p = PV(v);
+  k::fill(p->d.p, p->n * p->ncomp, value, ctx().stream);
+  MI_HIP(hipStreamSynchronize(ctx().stream));
+  API_END
+}
+HYPRE_Int HYPRE_ParVectorInnerProd(HYPRE_ParVector x, HYPRE_ParVector y, HYPRE_Real *prod) {
+  API_BEGIN
+  if (!x || !y || !prod) fail(HYPRE_ERROR_ARG, "ParVectorInnerProd: NULL argument");
+  *prod = par_dot_host(*ctx().comm, PV(x)->data(), PV(y)->data(), PV(x)->n, ctx().stream);
+  API_END
+}
+HYPRE_Int HYPRE_ParVectorAxpy(HYPRE_Complex alpha, HYPRE_ParVector x, HYPRE_ParVector y) {
+  API_BEGIN
+  if (!x || !y) fail(HYPRE_ERROR_ARG, "ParVectorAxpy: NULL argument");
+  k::axpy(alpha, PV(x)->data(), PV(y)->data(), PV(x)->n, ctx().stream);
+  MI_HIP(hipStreamSynchronize(ctx().stream));
+  API_END
+}
+HYPRE_Int HYPRE_ParVectorScale(HYPRE_Complex alpha, HYPRE_ParVector y) {
+  API_BEGIN
+  if (!y) fail(HYPRE_ERROR_ARG, "ParVectorScale: NULL argument");
+  k::scale(alpha, PV(y)->data(), PV(y)->n, ctx().stream);
+  MI_HIP(hipStreamSynchronize(ctx().stream));
+  API_END
+}
+HYPRE_Int HYPRE_ParVectorCopy(HYPRE_ParVector x, HYPRE_ParVector y) {
+  API_BEGIN
+  if (!x || !y) fail(HYPRE_ERROR_ARG, "ParVectorCopy: NULL argument");
+  k::copy(PV(x)->data(), PV(y)->data(), PV(x)->n, ctx().stream);
+  MI_HIP(hipStreamSynchronize(ctx().stream));
+  API_END
+}
+
+// ------------------------------------------------------------------ BoomerAMG
+HYPRE_Int HYPRE_BoomerAMGCreate(HYPRE_Solver *solver) {
+  API_BEGIN
+  if (!solver) fail(HYPRE_ERROR_ARG, "BoomerAMGCreate: NULL output");
+  *solver = reinterpret_cast<HYPRE_Solver>(static_cast<SolverBase *>(new AmgSolver()));
+  API_END
+}
+HYPRE_Int HYPRE_BoomerAMGDestroy(HYPRE_Solver solver) {
+  API_BEGIN
+  delete S(solver);
+  API_END
+}
+HYPRE_Int HYPRE_BoomerAMGSetup(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector, HYPRE_ParVector) {
+  API_BEGIN
+  if (!A) fail(HYPRE_ERROR_ARG, "BoomerAMGSetup: NULL matrix");
+  AMG(solver)->amg.setup(*PM(A));
+  API_END
+}
+HYPRE_Int HYPRE_BoomerAMGSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x) {
+  API_BEGIN
+  if (!A || !b || !x) fail(HYPRE_ERROR_ARG, "BoomerAMGSolve: NULL argument");
+  AMG(solver)->amg.solve(*PM(A), *PV(b), *PV(x));
+  API_END
+}
+#define AMG_SET(NAME, TYPE, STMT)                               \
+  HYPRE_Int HYPRE_BoomerAMGSet##NAME(HYPRE_Solver solver, TYPE v) { \
+    API_BEGIN                                                   \
+    AmgParams &p = AMG(solver)->amg.p;                          \
+    (void)p;                                                    \
+    STMT;                                                       \
+    API_END                                                     \
+  }
+AMG_SET(PrintLevel, HYPRE_Int, p.print_level = v)
+AMG_SET(DebugFlag, HYPRE_Int, p.debug_flag = v)
+AMG_SET(CoarsenType, HYPRE_Int, p.coarsen_type = v)
+AMG_SET(CycleType, HYPRE_Int, if (v != 1 && v != 2) fail(HYPRE_ERROR_ARG, "cycle_type must be 1 or 2"); p.cycle_type = v)
+AMG_SET(RelaxType, HYPRE_Int, p.relax_type[0] = p.relax_type[1] = v; p.relax_type[2] = 9)
+AMG_SET(NumSweeps, HYPRE_Int, if (v < 1) fail(HYPRE_ERROR_ARG, "num_sweeps < 1"); p.num_sweeps[0] = p.num_sweeps[1] = v; p.num_sweeps[2] = 1)
+AMG_SET(SmoothNumSweeps, HYPRE_Int, p.smooth_num_sweeps = v)
+AMG_SET(Tol, HYPRE_Real, p.tol = v)
+AMG_SET(MaxIter, HYPRE_Int, p.max_iter = v)
+AMG_SET(RelaxOrder, HYPRE_Int, p.relax_order = v)
+AMG_SET(MaxLevels, HYPRE_Int, if (v < 1) fail(HYPRE_ERROR_ARG, "max_levels < 1"); p.max_levels = v)
+AMG_SET(StrongThreshold, HYPRE_Real, p.strong_threshold = v)
+AMG_SET(MaxRowSum, HYPRE_Real, p.max_row_sum = v)
+AMG_SET(InterpType, HYPRE_Int, if (v != 0 && v != 3 && v != 6) fprintf(stderr, "mi_hypre BoomerAMG: interp_type %d is not restated; using extended+i (6)\n", v); p.interp_type = (v == 0 || v == 3) ? v : 6)
+AMG_SET(TruncFactor, HYPRE_Real, p.trunc_factor = v)
+AMG_SET(PMaxElmts, HYPRE_Int, p.pmax_elmts = v)
+AMG_SET(MinCoarseSize, HYPRE_Int, p.min_coarse_size = v)
+AMG_SET(MaxCoarseSize, HYPRE_Int, p.max_coarse_size = v)
+AMG_SET(RelaxWt, HYPRE_Real, p.relax_weight = v)
+AMG_SET(OuterWt, HYPRE_Real, p.outer_weight = v)
+AMG_SET(AggNumLevels, HYPRE_Int, p.agg_num_levels = v)
+AMG_SET(AggInterpType, HYPRE_Int, p.agg_interp_type = v)
+AMG_SET(AggPMaxElmts, HYPRE_Int, p.agg_pmax_elmts = v)
+AMG_SET(KeepTranspose, HYPRE_Int, p.keep_transpose = v)
+AMG_SET(RAP2, HYPRE_Int, p.rap2 = v)
+AMG_SET(Variant, HYPRE_Int, (void)v)
+AMG_SET(NonGalerkinTol, HYPRE_Real, (void)v)
+AMG_SET(SmoothType, HYPRE_Int, (void)v)
+AMG_SET(SmoothNumLevels, HYPRE_Int, (void)v)
+AMG_SET(ILUType, HYPRE_Int, (void)v)
+AMG_SET(ILULevel, HYPRE_Int, (void)v)
+AMG_SET(ILULocalReordering, HYPRE_Int, (void)v)
+AMG_SET(ILUMaxRowNnz, HYPRE_Int, (void)v)
+AMG_SET(ILUMaxIter, HYPRE_Int, (void)v)
+AMG_SET(ILUDroptol, HYPRE_Real, (void)v)
+AMG_SET(ILUIterSetupType, HYPRE_Int, (void)v)
+AMG_SET(ILUIterSetupOption, HYPRE_Int, (void)v)
+AMG_SET(ILUIterSetupMaxIter, HYPRE_Int, (void)v)
+AMG_SET(ILUIterSetupTolerance, HYPRE_Real, (void)v)
+AMG_SET(ILUTriSolve, HYPRE_Int, (void)v)
+AMG_SET(ILULowerJacobiIters, HYPRE_Int, (void)v)
+AMG_SET(ILUUpperJacobiIters, HYPRE_Int, (void)v)
+#undef AMG_SET
+HYPRE_Int HYPRE_BoomerAMGSetLevelNonGalerkinTol(HYPRE_Solver solver, HYPRE_Real, HYPRE_Int) {
+  API_BEGIN
+  (void)AMG(solver);
+  API_END
+}
+HYPRE_Int HYPRE_BoomerAMGSetCycleRelaxType(HYPRE_Solver solver, HYPRE_Int relax_type, HYPRE_Int k) {
+  API_BEGIN
+  if (k < 1 || k > 3) fail(HYPRE_ERROR_ARG, "SetCycleRelaxType: k must be 1, 2 or 3");
+  AMG(solver)->amg.p.relax_type[k - 1] = relax_type;
+  API_END
+}
+HYPRE_Int HYPRE_BoomerAMGSetCycleNumSweeps(HYPRE_Solver solver, HYPRE_Int num_sweeps, HYPRE_Int k) {
+  API_BEGIN
+  if (k < 1 || k > 3) fail(HYPRE_ERROR_ARG, "SetCycleNumSweeps: k must be 1, 2 or 3");
+  if (num_sweeps < 0) fail(HYPRE_ERROR_ARG, "SetCycleNumSweeps: negative sweeps");
+  AMG(solver)->amg.p.num_sweeps[k - 1] = num_sweeps;
+  API_END
+}
+HYPRE_Int HYPRE_BoomerAMGGetNumIterations(HYPRE_Solver solver, HYPRE_Int *n) {
+  API_BEGIN
+  *n = AMG(solver)->amg.num_iterations;
+  API_END
+}
+HYPRE_Int HYPRE_BoomerAMGGetFinalRelativeResidualNorm(HYPRE_Solver solver, HYPRE_Real *r) {
+  API_BEGIN
+  *r = AMG(solver)->amg.final_rel_res;
+  API_END
+}
+
+// ------------------------------------------------------------------ GMRES / BiCGSTAB
+HYPRE_Int HYPRE_ParCSRGMRESCreate(MPI_Comm, HYPRE_Solver *solver) {
+  API_BEGIN
+  if (!solver) fail(HYPRE_ERROR_ARG, "GMRESCreate: NULL output");
+  *solver = reinterpret_cast<HYPRE_Solver>(static_cast<SolverBase *>(new GmresSolver()));
+  API_END
+}
+HYPRE_Int HYPRE_ParCSRGMRESDestroy(HYPRE_Solver solver) {
+  API_BEGIN
+  delete S(solver);
+  API_END
+}
+HYPRE_Int HYPRE_ParCSRGMRESSetup(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x) {
+  API_BEGIN
+  if (!A || !b || !x) fail(HYPRE_ERROR_ARG, "GMRESSetup: NULL argument");
+  GM(solver)->setup(*PM(A), *PV(b), *PV(x));
+  API_END
+}
+HYPRE_Int HYPRE_ParCSRGMRESSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x) {
+  try {
+    if (!A || !b || !x) fail(HYPRE_ERROR_ARG, "GMRESSolve: NULL argument");
+    const int rc = GM(solver)->solve(*PM(A), *PV(b), *PV(x));
+    if (rc) g_error_flag |= rc;  // HYPRE_ERROR_CONV: reported, never fatal
+    return rc;
+  } catch (const std::exception &e) {
+    return record_error(HYPRE_ERROR_GENERIC, e.what());
+  }
+}
+#define KRYLOV_COMMON(NAME, GET)                                                                                  \
+  HYPRE_Int HYPRE_ParCSR##NAME##SetPrecond(HYPRE_Solver solver, HYPRE_PtrToParSolverFcn precond,                  \
+                                           HYPRE_PtrToParSolverFcn precond_setup, HYPRE_Solver precond_solver) {  \
+    API_BEGIN                                                                                                     \
+    KrylovSolver *k_ = GET(solver);                                                                               \
+    k_->precond_solve = reinterpret_cast<ParSolverFcn>(precond);                                                  \
+    k_->precond_setup = reinterpret_cast<ParSolverFcn>(precond_setup);                                            \
+    k_->precond_data = precond_solver;                                                                            \
+    API_END                                                                                                       \
+  }                                                                                                               \
+  HYPRE_Int HYPRE_ParCSR##NAME##SetTol(HYPRE_Solver solver, HYPRE_Real v) {                                       \
+    API_BEGIN GET(solver)->tol = v;                                                                               \
+    API_END                                                                                                       \
+  }                                                                                                               \
+  HYPRE_Int HYPRE_ParCSR##NAME##SetAbsoluteTol(HYPRE_Solver solver, HYPRE_Real v) {                               \
+    API_BEGIN GET(solver)->atol = v;                                                                              \
+    API_END                                                                                                       \
+  }                                                                                                               \
+  HYPRE_Int HYPRE_ParCSR##NAME##SetMaxIter(HYPRE_Solver solver, HYPRE_Int v) {                                    \
+    API_BEGIN GET(solver)->max_iter = v;                                                                          \
+    API_END                                                                                                       \
+  }                                                                                                               \
+  HYPRE_Int HYPRE_ParCSR##NAME##SetMinIter(HYPRE_Solver solver, HYPRE_Int v) {                                    \
+    API_BEGIN GET(solver)->min_iter = v;                                                                          \
+    API_END                                                                                                       \
+  }                                                                                                               \
+  HYPRE_Int HYPRE_ParCSR##NAME##SetKDim(HYPRE_Solver solver, HYPRE_Int v) {                                       \
+    API_BEGIN if (v < 1) fail(HYPRE_ERROR_ARG, "k_dim < 1");                                                      \
+    GET(solver)->k_dim = v;                                                                                       \
+    API_END                                                                                                       \
+  }                                                                                                               \
+  HYPRE_Int HYPRE_ParCSR##NAME##SetPrintLevel(HYPRE_Solver solver, HYPRE_Int v) {                                 \
+    API_BEGIN GET(solver)->print_level = v;                                                                       \
+    API_END                                                                                                       \
+  }                                                                                                               \
+  HYPRE_Int HYPRE_ParCSR##NAME##SetLogging(HYPRE_Solver solver, HYPRE_Int v) {                                    \
+    API_BEGIN GET(solver)->logging = v;                                                                           \
+    API_END                                                                                                       \
+  }                                                                                                               \
+  HYPRE_Int HYPRE_ParCSR##NAME##GetNumIterations(HYPRE_Solver solver, HYPRE_Int *n) {                             \
+    API_BEGIN *n = GET(solver)->num_iterations;                                                                   \
+    API_END                                                                                                       \
+  }                                                                                                               \
+  HYPRE_Int HYPRE_ParCSR##NAME##GetFinalRelativeResidualNorm(HYPRE_Solver solver, HYPRE_Real *r) {                \
+    API_BEGIN *r = GET(solver)->rel_residual_norm;                                                                \
+    API_END                                                                                                       \
+  }
+KRYLOV_COMMON(GMRES, GM)
+KRYLOV_COMMON(BiCGSTAB, BI)
+#undef KRYLOV_COMMON
+HYPRE_Int HYPRE_ParCSRGMRESSetCGS(HYPRE_Solver solver, HYPRE_Int) {
+  API_BEGIN(void) GM(solver);
+  API_END
+}
+
+HYPRE_Int HYPRE_ParCSRBiCGSTABCreate(MPI_Comm, HYPRE_Solver *solver) {
+  API_BEGIN
+  if (!solver) fail(HYPRE_ERROR_ARG, "BiCGSTABCreate: NULL output");
+  *solver = reinterpret_cast<HYPRE_Solver>(static_cast<SolverBase *>(new BicgstabSolver()));
+  API_END
+}
+HYPRE_Int HYPRE_ParCSRBiCGSTABDestroy(HYPRE_Solver solver) {
+  API_BEGIN
+  delete S(solver);
+  API_END
+}
+HYPRE_Int HYPRE_ParCSRBiCGSTABSetup(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x) {
+  API_BEGIN
+  if (!A || !b || !x) fail(HYPRE_ERROR_ARG, "BiCGSTABSetup: NULL argument");
+  BI(solver)->setup(*PM(A), *PV(b), *PV(x));
+  API_END
+}
+HYPRE_Int HYPRE_ParCSRBiCGSTABSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x) {
+  try {
+    if (!A || !b || !x) fail(HYPRE_ERROR_ARG, "BiCGSTABSolve: NULL argument");
+    const int rc = BI(solver)->solve(*PM(A), *PV(b), *PV(x));
+    if (rc) g_error_flag |= rc;
+    return rc;
+  } catch (const std::exception &e) {
+    return record_error(HYPRE_ERROR_GENERIC, e.what());
+  }
+}
+
+// ------------------------------------------------------------------ stubs
+#define KRYLOV_STUB(NAME)                                                                                       \
+  HYPRE_Int HYPRE_ParCSR##NAME##Create(MPI_Comm, HYPRE_Solver *solver) {                                        \
+    API_BEGIN *solver = reinterpret_cast<HYPRE_Solver>(static_cast<SolverBase *>(new StubSolver(#NAME)));       \
+    API_END                                                                                                     \
+  }                                                                                                             \
+  HYPRE_Int HYPRE_ParCSR##NAME##Destroy(HYPRE_Solver solver) {                                                  \
+    API_BEGIN delete S(solver);                                                                                 \
+    API_END                                                                                                     \
+  }                                                                                                             \
+  HYPRE_Int HYPRE_ParCSR##NAME##Setup(HYPRE_Solver, HYPRE_ParCSRMatrix, HYPRE_ParVector, HYPRE_ParVector) {     \
+    return stub_fail("HYPRE_ParCSR" #NAME);                                                                     \
+  }                                                                                                             \
+  HYPRE_Int HYPRE_ParCSR##NAME##Solve(HYPRE_Solver, HYPRE_ParCSRMatrix, HYPRE_ParVector, HYPRE_ParVector) {     \
+    return stub_fail("HYPRE_ParCSR" #NAME);                                                                     \
+  }                                                                                                             \
+  HYPRE_Int HYPRE_ParCSR##NAME##SetPrecond(HYPRE_Solver, HYPRE_PtrToParSolverFcn, HYPRE_PtrToParSolverFcn,      \
+                                           HYPRE_Solver) {                                                      \
+    return 0;                                                                                                   \
+  }                                                                                                             \
+  HYPRE_Int HYPRE_ParCSR##NAME##SetTol(HYPRE_Solver, HYPRE_Real) { return 0; }                                  \
+  HYPRE_Int HYPRE_ParCSR##NAME##SetMaxIter(HYPRE_Solver, HYPRE_Int) { return 0; }                               \
+  HYPRE_Int HYPRE_ParCSR##NAME##SetKDim(HYPRE_Solver, HYPRE_Int) { return 0; }                                  \
+  HYPRE_Int HYPRE_ParCSR##NAME##SetPrintLevel(HYPRE_Solver, HYPRE_Int) { return 0; }
+KRYLOV_STUB(COGMRES)
+KRYLOV_STUB(FlexGMRES)
+KRYLOV_STUB(PCG)
+#undef KRYLOV_STUB
+HYPRE_Int HYPRE_ParCSRCOGMRESSetCGS(HYPRE_Solver, HYPRE_Int) { return 0; }
+
+HYPRE_Int HYPRE_ILUCreate(HYPRE_Solver *solver) {
+  API_BEGIN *solver = reinterpret_cast<HYPRE_Solver>(static_cast<SolverBase *>(new StubSolver("ILU")));
+  API_END
+}
+HYPRE_Int HYPRE_ILUDestroy(HYPRE_Solver solver) {
+  API_BEGIN delete S(solver);
+  API_END
+}
+HYPRE_Int HYPRE_ILUSetup(HYPRE_Solver, HYPRE_ParCSRMatrix, HYPRE_ParVector, HYPRE_ParVector) { return stub_fail("HYPRE_ILU"); }
+HYPRE_Int HYPRE_ILUSolve(HYPRE_Solver, HYPRE_ParCSRMatrix, HYPRE_ParVector, HYPRE_ParVector) { return stub_fail("HYPRE_ILU"); }
+#define ILU_SET(NAME, TYPE) \
+  HYPRE_Int HYPRE_ILUSet##NAME(HYPRE_Solver, TYPE) { return 0; }
+ILU_SET(Type, HYPRE_Int)
+ILU_SET(MaxIter, HYPRE_Int)
+ILU_SET(Tol, HYPRE_Real)
+ILU_SET(LocalReordering, HYPRE_Int)
+ILU_SET(PrintLevel, HYPRE_Int)
+ILU_SET(LevelOfFill, HYPRE_Int)
+ILU_SET(MaxNnzPerRow, HYPRE_Int)
+ILU_SET(DropThreshold, HYPRE_Real)
+ILU_SET(IterativeSetupType, HYPRE_Int)
+ILU_SET(IterativeSetupOption, HYPRE_Int)
+ILU_SET(IterativeSetupMaxIter, HYPRE_Int)
+ILU_SET(IterativeSetupTolerance, HYPRE_Real)
+ILU_SET(TriSolve, HYPRE_Int)
+ILU_SET(LowerJacobiIters, HYPRE_Int)
+ILU_SET(UpperJacobiIters, HYPRE_Int)
+#undef ILU_SET
+
+// ------------------------------------------------------------------ AMG internals used by the driver's level dump
+static thread_local std::vector<hypre_ParCSRMatrix *> g_level_ptrs;
+hypre_ParCSRMatrix **hypre_ParAMGDataAArray(hypre_ParAMGData *amg_data) {
+  try {
+    AmgSolver *a = AMG(reinterpret_cast<HYPRE_Solver>(amg_data));
+    g_level_ptrs.clear();
+    for (auto &l : a->amg.L) g_level_ptrs.push_back(reinterpret_cast<hypre_ParCSRMatrix *>(l.A));
+    return g_level_ptrs.data();
+  } catch (const std::exception &e) {
+    record_error(HYPRE_ERROR_ARG, e.what());
+    return nullptr;
+  }
+}
+HYPRE_Int hypre_ParAMGDataNumLevels(hypre_ParAMGData *amg_data) {
+  try {
+    return (HYPRE_Int)AMG(reinterpret_cast<HYPRE_Solver>(amg_data))->amg.L.size();
+  } catch (const std::exception &e) {
+    record_error(HYPRE_ERROR_ARG, e.what());
+    return 0;
+  }
+}
+
+// ------------------------------------------------------------------ extensions
+HYPRE_Int HYPRE_MI_CommGetUniqueId(void *id128) {
+  API_BEGIN
+  ensure_init();
+  rccl_get_unique_id(id128);
+  API_END
+}
+HYPRE_Int HYPRE_MI_CommInitRCCL(const void *id128, HYPRE_Int rank, HYPRE_Int size) {
+  API_BEGIN
+  ensure_init();
+  if (size < 1 || rank < 0 || rank >= size) fail(HYPRE_ERROR_ARG, "CommInitRCCL: bad rank/size");
+  if (size == 1)
+    ctx().comm = make_self_comm();
+  else
+    ctx().comm = make_rccl_comm(id128, rank, size);
+  API_END
+}
+HYPRE_Int HYPRE_MI_CommInitCallbacks(void *cctx, HYPRE_MI_AllreduceFn ar, HYPRE_MI_AllgatherFn ag,
+                                     HYPRE_MI_ExchangeFn ex, HYPRE_Int rank, HYPRE_Int size) {
+  API_BEGIN
+  ensure_init();
+  if (!ar || !ag || !ex) fail(HYPRE_ERROR_ARG, "CommInitCallbacks: NULL callback");
+  CommCallbacks cb{cctx, ar, ag, ex};
+  ctx().comm = make_callback_comm(cb, rank, size);
+  API_END
+}
+HYPRE_Int HYPRE_MI_CommFinalize(void) {
+  API_BEGIN
+  if (ctx().inited) {
+    MI_HIP(hipDeviceSynchronize());
+    ctx().comm = make_self_comm();
+  }
+  API_END
+}
+HYPRE_Int HYPRE_MI_CommRank(HYPRE_Int *rank) {
+  *rank = ctx().comm ? ctx().comm->rank : 0;
+  return 0;
+}
+HYPRE_Int HYPRE_MI_CommSize(HYPRE_Int *size) {
+  *size = ctx().comm ? ctx().comm->size : 1;
+  return 0;
+}
+HYPRE_Int HYPRE_MI_CommBarrier(void) {
+  API_BEGIN
+  ensure_init();
+  ctx().comm->barrier();
+  API_END
+}
+HYPRE_Int HYPRE_MI_CommAllreduce(void *buf, size_t count, int dtype, int op) {
+  API_BEGIN
+  ensure_init();
+  if (dtype < 0 || dtype > 3 || op < 0 || op > 2) fail(HYPRE_ERROR_ARG, "CommAllreduce: bad dtype/op");
+  ctx().comm->allreduce_host(buf, count, (CommDType)dtype, (CommOp)op);
+  API_END
+}
+HYPRE_Int HYPRE_MI_GetStream(void **hip_stream) {
+  API_BEGIN
+  ensure_init();
+  *hip_stream = (void *)ctx().stream;
+  API_END
+}
+HYPRE_Int HYPRE_MI_StreamSynchronize(void) {
+  API_BEGIN
+  ensure_init();
+  MI_HIP(hipStreamSynchronize(ctx().stream));
+  API_END
+}
+HYPRE_Int HYPRE_MI_SetGSChunk(HYPRE_Int rows) {
+  API_BEGIN
+  if (rows < 1 || rows > k::GS_MAX_CHUNK) fail(HYPRE_ERROR_ARG, "SetGSChunk: 1..32");
+  ctx().gs_chunk = rows;
+  API_END
+}
+HYPRE_Int HYPRE_MI_GetGSChunk(HYPRE_Int *rows) {
+  *rows = ctx().gs_chunk;
+  return 0;
+}
+HYPRE_Int HYPRE_MI_KrylovGetResidualHistory(HYPRE_Solver solver, HYPRE_Real *norms, HYPRE_Int max_n, HYPRE_Int *n) {
+  API_BEGIN
+  KrylovSolver *kk = KR(solver);
+  const int m = std::min<int>(max_n, (int)kk->norms.size());
+  for (int i = 0; i < m; i++) norms[i] = kk->norms[(size_t)i];
+  if (n) *n = (int)kk->norms.size();
+  API_END
+}
+HYPRE_Int HYPRE_MI_KrylovGetSolveSeconds(HYPRE_Solver solver, HYPRE_Real *seconds) {
+  API_BEGIN
+  *seconds = KR(solver)->solve_seconds;
+  API_END
+}
+HYPRE_Int HYPRE_MI_BoomerAMGGetNumLevels(HYPRE_Solver solver, HYPRE_Int *n) {
+  API_BEGIN
+  *n = (HYPRE_Int)AMG(solver)->amg.L.size();
+  API_END
+}
+HYPRE_Int HYPRE_MI_BoomerAMGGetOperatorComplexity(HYPRE_Solver solver, HYPRE_Real *cx) {
+  API_BEGIN
+  *cx = AMG(solver)->amg.operator_complexity();
+  API_END
+}
+HYPRE_Int HYPRE_MI_BoomerAMGGetSetupSeconds(HYPRE_Solver solver, HYPRE_Real *seconds) {
+  API_BEGIN
+  *seconds = AMG(solver)->amg.setup_seconds;
+  API_END
+}
+static const HostCSR &level_csr(AmgSolver *a, int level, int which) {
+  if (level < 0 || level >= (int)a->amg.L.size()) fail(HYPRE_ERROR_ARG, "AMG level out of range");
+  AmgLevel &L = a->amg.L[(size_t)level];
+  switch (which) {
+    case 0: return L.A->diag;
+    case 1: return L.A->offd;
+    case 2: return L.P;
+    case 3: return L.R;
+    default: fail(HYPRE_ERROR_ARG, "which must be 0..3");
+  }
+}
+HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSRSize(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int which, HYPRE_Int *nrows,
+                                            HYPRE_Int *ncols, HYPRE_BigInt *nnz) {
+  API_BEGIN
+  const HostCSR &c = level_csr(AMG(solver), level, which);
+  *nrows = c.nrows;
+  *ncols = c.ncols;
+  *nnz = c.nnz();
+  API_END
+}
+HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSR(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int which, HYPRE_BigInt *ia,
+                                        HYPRE_Int *ja, HYPRE_Complex *a) {
+  API_BEGIN
+  const HostCSR &c = level_csr(AMG(solver), level, which);
+  if (c.ia.empty()) {
+    for (int i = 0; i <= c.nrows; i++) ia[i] = 0;
+    return 0;
+  }
+  for (int i = 0; i <= c.nrows; i++) ia[i] = c.ia[(size_t)i];
+  memcpy(ja, c.ja.data(), c.ja.size() * sizeof(int));
+  memcpy(a, c.a.data(), c.a.size() * sizeof(double));
+  API_END
+}
+HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCF(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int *cf) {
+  API_BEGIN
+  AmgSolver *a = AMG(solver);
+  if (level < 0 || level >= (int)a->amg.L.size()) fail(HYPRE_ERROR_ARG, "AMG level out of range");
+  const auto &v = a->amg.L[(size_t)level].cf;
+  for (size_t i = 0; i < v.size(); i++) cf[i] = v[i];
+  API_END
+}
+HYPRE_Int HYPRE_MI_BoomerAMGGetLevelColMap(HYPRE_Solver solver, HYPRE_Int level, HYPRE_BigInt *col_map_offd,
+                                           HYPRE_BigInt *row_start) {
+  API_BEGIN
+  AmgSolver *a = AMG(solver);
+  if (level < 0 || level >= (int)a->amg.L.size()) fail(HYPRE_ERROR_ARG, "AMG level out of range");
+  const ParCSR &A = *a->amg.L[(size_t)level].A;
+  if (col_map_offd)
+    for (size_t i = 0; i < A.col_map_offd.size(); i++) col_map_offd[i] = A.col_map_offd[i];
+  if (row_start) *row_start = A.row_start;
+  API_END
+}
+HYPRE_Int HYPRE_MI_BoomerAMGRelaxLevel(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int relax_type, HYPRE_Int points,
+                                       const HYPRE_Real *f_host, HYPRE_Real *u_host) {
+  API_BEGIN
+  AmgSolver *a = AMG(solver);
+  if (!a->amg.is_setup) fail(HYPRE_ERROR_GENERIC, "RelaxLevel: AMG is not set up");
+  if (level < 0 || level >= (int)a->amg.L.size()) fail(HYPRE_ERROR_ARG, "AMG level out of range");
+  const int n = a->amg.L[(size_t)level].n;
+  DVec<double> f((size_t)n), u((size_t)n);
+  if (n) {
+    f.upload(f_host, (size_t)n);
+    u.upload(u_host, (size_t)n);
+  }
+  a->amg.relax(level, relax_type, points, f.p, u);
+  MI_HIP(hipStreamSynchronize(ctx().stream));
+  if (n) u.download(u_host, (size_t)n);
+  API_END
+}
+HYPRE_Int HYPRE_MI_ProfileEnable(HYPRE_Int id, HYPRE_Int capacity) {
+  API_BEGIN
+  ensure_init();
+  if (id < 0 || id >= k::PROF_COUNT) fail(HYPRE_ERROR_ARG, "ProfileEnable: bad id");
+  if (!ctx().timer) ctx().timer = new KernelTimer();
+  ctx().timer->enable(id, (size_t)capacity);
+  API_END
+}
+HYPRE_Int HYPRE_MI_ProfileReset(void) {
+  API_BEGIN
+  if (ctx().timer) {
+    MI_HIP(hipStreamSynchronize(ctx().stream));
+    ctx().timer->reset();
+  }
+  API_END
+}
+HYPRE_Int HYPRE_MI_ProfileGet(HYPRE_Int id, long long *launches, double *total_ms, double *min_ms) {
+  API_BEGIN
+  *launches = 0;
+  *total_ms = *min_ms = 0.0;
+  if (ctx().timer) ctx().timer->collect(id, launches, total_ms, min_ms);
+  API_END
+}
+
+HYPRE_Int HYPRE_MI_Laplace3D(HYPRE_Int nx, HYPRE_Int ny, HYPRE_Int nz, HYPRE_Int stencil, HYPRE_BigInt ilower,
+                             HYPRE_BigInt iupper, HYPRE_BigInt *nnz_out, HYPRE_BigInt **rows_out,
+                             HYPRE_BigInt **cols_out, HYPRE_Complex **vals_out, HYPRE_Complex **rhs_out) {
+  API_BEGIN
+  if (stencil != 7 && stencil != 27) fail(HYPRE_ERROR_ARG, "Laplace3D: stencil must be 7 or 27");
+  const gidx N = (gidx)nx * ny * nz;
+  if (ilower < 0 || iupper >= N || iupper < ilower - 1) fail(HYPRE_ERROR_ARG, "Laplace3D: bad row range");
+  const int64_t nloc = iupper - ilower + 1;
+  const double dv = (stencil == 27) ? 26.0 : 6.0;
+  auto row_nnz = [&](gidx row) {
+    const int x = (int)(row % nx), y = (int)((row / nx) % ny), z = (int)(row / ((gidx)nx * ny));
+    const int cx = 1 + (x > 0) + (x < nx - 1), cy = 1 + (y > 0) + (y < ny - 1), cz = 1 + (z > 0) + (z < nz - 1);
+    return (stencil == 27) ? cx * cy * cz : 1 + (cx - 1) + (cy - 1) + (cz - 1);
+  };
+  std::vector<int64_t> off((size_t)nloc + 1, 0);
+  parallel_for(nloc, [&](int64_t b, int64_t e, int) {
+    for (int64_t i = b; i < e; i++) off[(size_t)i + 1] = row_nnz(ilower + i);
+  });
+  for (int64_t i = 0; i < nloc; i++) off[(size_t)i + 1] += off[(size_t)i];
+  const int64_t nnz = off[(size_t)nloc];
+  gidx *rows = (gidx *)malloc(sizeof(gidx) * (size_t)std::max<int64_t>(nnz, 1));
+  gidx *cols = (gidx *)malloc(sizeof(gidx) * (size_t)std::max<int64_t>(nnz, 1));
+  double *vals = (double *)malloc(sizeof(double) * (size_t)std::max<int64_t>(nnz, 1));
+  double *rhs = (double *)malloc(sizeof(double) * (size_t)std::max<int64_t>(nloc, 1));
+  if (!rows || !cols || !vals || !rhs) {
+    free(rows), free(cols), free(vals), free(rhs);
+    fail(HYPRE_ERROR_MEMORY, "Laplace3D: out of host memory");
+  }
+  parallel_for(nloc, [&](int64_t b, int64_t e, int) {
+    for (int64_t i = b; i < e; i++) {
+      const gidx row = ilower + i;
+      const int x = (int)(row % nx), y = (int)((row / nx) % ny), z = (int)(row / ((gidx)nx * ny));
+      int64_t q = off[(size_t)i];
+      double sum = 0.0;
+      for (int dz = -1; dz <= 1; dz++)
+        for (int dy = -1; dy <= 1; dy++)
+          for (int dx = -1; dx <= 1; dx++) {
+            if (stencil == 7 && (std::abs(dx) + std::abs(dy) + std::abs(dz) > 1)) continue;
+            const int X = x + dx, Y = y + dy, Z = z + dz;
+            if (X < 0 || X >= nx || Y < 0 || Y >= ny || Z < 0 || Z >= nz) continue;
+            const gidx col = X + (gidx)nx * (Y + (gidx)ny * Z);
+            const double v = (col == row) ? dv : -1.0;
+            rows[q] = row;
+            cols[q] = col;
+            vals[q] = v;
+            sum += v;
+            q++;
+          }
+      rhs[i] = sum;
+    }
+  });
+  *nnz_out = nnz;
+  *rows_out = rows;
+  *cols_out = cols;
+  *vals_out = vals;
+  *rhs_out = rhs;
+  API_END
+}
+void HYPRE_MI_Free(void *p) { free(p); }
+
+}  // extern "C"

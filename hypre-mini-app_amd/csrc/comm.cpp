@@ -1,0 +1,261 @@
+// One rank per GPU.  Three transports behind one interface:
+//   self      size-1 no-op
+//   rccl      RCCL over xGMI, loaded with dlopen so that a single-GPU run has no
+//             dependency on it and a torch process shares torch's copy
+//   callback  caller-supplied host transport (tests: gloo; several ranks may then
+//             share one GPU, which RCCL refuses)
+// The halo exchange is a neighbour send/recv group (<= 2 peers for slab
+// partitions), the dot products are 8-byte all-reduces: both latency-bound, so
+// what matters is how few of them the solver issues, not their algorithm.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+
+#include "mi_internal.hpp"
+
+namespace mi {
+
+// ------------------------------------------------------------------ host helpers (blocking)
+static size_t dtype_size(CommDType t) {
+  switch (t) {
+    case CommDType::F64: return 8;
+    case CommDType::I64: return 8;
+    case CommDType::I32: return 4;
+    default: return 1;
+  }
+}
+
+void Comm::allreduce_host(void *buf, size_t count, CommDType t, CommOp op) {
+  if (size == 1 || count == 0) return;
+  ensure_init();
+  hipStream_t s = ctx().stream;
+  const size_t bytes = count * dtype_size(t);
+  DVec<char> d(bytes);
+  MI_HIP(hipMemcpyAsync(d.p, buf, bytes, hipMemcpyHostToDevice, s));
+  allreduce_dev(d.p, count, t, op, s);
+  MI_HIP(hipMemcpyAsync(buf, d.p, bytes, hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+}
+
+void Comm::allgather_host(const void *send, void *recv, size_t bytes_per_rank) {
+  if (size == 1) {
+    memcpy(recv, send, bytes_per_rank);
+    return;
+  }
+  ensure_init();
+  hipStream_t s = ctx().stream;
+  DVec<char> ds(bytes_per_rank), dr(bytes_per_rank * (size_t)size);
+  MI_HIP(hipMemcpyAsync(ds.p, send, bytes_per_rank, hipMemcpyHostToDevice, s));
+  allgather_dev(ds.p, dr.p, bytes_per_rank, s);
+  MI_HIP(hipMemcpyAsync(recv, dr.p, bytes_per_rank * (size_t)size, hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+}
+
+void Comm::barrier() {
+  if (size == 1) return;
+  long long one = 1;
+  allreduce_host(&one, 1, CommDType::I64, CommOp::SUM);
+}
+
+void Comm::exchange_host(const std::vector<int> &peers_send, const std::vector<std::vector<char>> &send,
+                         std::vector<int> &peers_recv, std::vector<std::vector<char>> &recv) {
+  peers_recv.clear();
+  recv.clear();
+  if (size == 1) return;
+  ensure_init();
+  hipStream_t s = ctx().stream;
+  std::vector<long long> mine((size_t)size, 0), all((size_t)size * size, 0);
+  for (size_t i = 0; i < peers_send.size(); i++) mine[(size_t)peers_send[i]] = (long long)send[i].size();
+  allgather_host(mine.data(), all.data(), sizeof(long long) * (size_t)size);
+  std::vector<DVec<char>> dsend(peers_send.size()), drecv;
+  std::vector<PeerBuf> sb, rb;
+  for (size_t i = 0; i < peers_send.size(); i++) {
+    if (send[i].empty()) continue;
+    dsend[i].alloc(send[i].size());
+    MI_HIP(hipMemcpyAsync(dsend[i].p, send[i].data(), send[i].size(), hipMemcpyHostToDevice, s));
+    sb.push_back({peers_send[i], dsend[i].p, send[i].size()});
+  }
+  for (int p = 0; p < size; p++) {
+    const long long bytes = all[(size_t)p * size + rank];
+    if (p == rank || bytes == 0) continue;
+    peers_recv.push_back(p);
+    recv.emplace_back((size_t)bytes);
+  }
+  drecv.resize(peers_recv.size());
+  for (size_t i = 0; i < peers_recv.size(); i++) {
+    drecv[i].alloc(recv[i].size());
+    rb.push_back({peers_recv[i], drecv[i].p, recv[i].size()});
+  }
+  exchange_dev(sb, rb, s);
+  for (size_t i = 0; i < peers_recv.size(); i++)
+    MI_HIP(hipMemcpyAsync(recv[i].data(), drecv[i].p, recv[i].size(), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+}
+
+// ------------------------------------------------------------------ self
+namespace {
+struct SelfComm : Comm {
+  const char *name() const override { return "self"; }
+  void allreduce_dev(void *, size_t, CommDType, CommOp, hipStream_t) override {}
+  void exchange_dev(const std::vector<PeerBuf> &, const std::vector<PeerBuf> &, hipStream_t) override {}
+  void allgather_dev(const void *send, void *recv, size_t bytes, hipStream_t s) override {
+    MI_HIP(hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, s));
+  }
+};
+
+// ------------------------------------------------------------------ RCCL (dlopen)
+struct RcclApi {
+  void *h = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+RcclApi &rccl() {
+  static RcclApi api;
+  if (api.h) return api;
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char *n : names) {
+    api.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (api.h) break;
+  }
+  if (!api.h) fail(1, std::string("mi_hypre: cannot dlopen librccl: ") + dlerror());
+#define LOAD(sym)                                                          \
+  api.sym = reinterpret_cast<decltype(api.sym)>(dlsym(api.h, "nccl" #sym)); \
+  if (!api.sym) fail(1, "mi_hypre: librccl lacks nccl" #sym)
+  LOAD(GetUniqueId);
+  LOAD(CommInitRank);
+  LOAD(CommDestroy);
+  LOAD(AllReduce);
+  LOAD(AllGather);
+  LOAD(Send);
+  LOAD(Recv);
+  LOAD(GroupStart);
+  LOAD(GroupEnd);
+  LOAD(GetErrorString);
+#undef LOAD
+  return api;
+}
+
+#define MI_NCCL(call)                                                                                          \
+  do {                                                                                                         \
+    ncclResult_t r_ = (call);                                                                                  \
+    if (r_ != ncclSuccess)                                                                                     \
+      fail(1, std::string("RCCL error ") + rccl().GetErrorString(r_) + " in " #call " at " + __FILE__ + ":" + \
+                  std::to_string(__LINE__));                                                                   \
+  } while (0)
+
+struct RcclComm : Comm {
+  ncclComm_t comm = nullptr;
+  RcclComm(const void *id128, int rank_, int size_) {
+    rank = rank_;
+    size = size_;
+    ncclUniqueId id;
+    static_assert(sizeof(id) == 128, "ncclUniqueId size");
+    memcpy(&id, id128, sizeof(id));
+    MI_NCCL(rccl().CommInitRank(&comm, size, id, rank));
+  }
+  ~RcclComm() override {
+    if (comm) (void)rccl().CommDestroy(comm);
+  }
+  const char *name() const override { return "rccl"; }
+  static ncclDataType_t dt(CommDType t) {
+    switch (t) {
+      case CommDType::F64: return ncclFloat64;
+      case CommDType::I64: return ncclInt64;
+      case CommDType::I32: return ncclInt32;
+      default: return ncclUint8;
+    }
+  }
+  static ncclRedOp_t op(CommOp o) { return o == CommOp::SUM ? ncclSum : (o == CommOp::MIN ? ncclMin : ncclMax); }
+  void allreduce_dev(void *buf, size_t count, CommDType t, CommOp o, hipStream_t s) override {
+    MI_NCCL(rccl().AllReduce(buf, buf, count, dt(t), op(o), comm, s));
+  }
+  void allgather_dev(const void *send, void *recv, size_t bytes, hipStream_t s) override {
+    MI_NCCL(rccl().AllGather(send, recv, bytes, ncclUint8, comm, s));
+  }
+  void exchange_dev(const std::vector<PeerBuf> &sends, const std::vector<PeerBuf> &recvs, hipStream_t s) override {
+    if (sends.empty() && recvs.empty()) return;
+    MI_NCCL(rccl().GroupStart());
+    for (const auto &b : recvs) MI_NCCL(rccl().Recv(b.ptr, b.bytes, ncclUint8, b.peer, comm, s));
+    for (const auto &b : sends) MI_NCCL(rccl().Send(b.ptr, b.bytes, ncclUint8, b.peer, comm, s));
+    MI_NCCL(rccl().GroupEnd());
+  }
+};
+
+// ------------------------------------------------------------------ callback (host-staged)
+struct CallbackComm : Comm {
+  CommCallbacks cb;
+  CallbackComm(const CommCallbacks &c, int rank_, int size_) : cb(c) {
+    rank = rank_;
+    size = size_;
+  }
+  const char *name() const override { return "callback"; }
+  void allreduce_dev(void *buf, size_t count, CommDType t, CommOp o, hipStream_t s) override {
+    const size_t bytes = count * dtype_size(t);
+    std::vector<char> h(bytes);
+    MI_HIP(hipMemcpyAsync(h.data(), buf, bytes, hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    cb.allreduce(cb.ctx, h.data(), count, (int)t, (int)o);
+    MI_HIP(hipMemcpyAsync(buf, h.data(), bytes, hipMemcpyHostToDevice, s));
+    MI_HIP(hipStreamSynchronize(s));
+  }
+  void allgather_dev(const void *send, void *recv, size_t bytes, hipStream_t s) override {
+    std::vector<char> hs(bytes), hr(bytes * (size_t)size);
+    MI_HIP(hipMemcpyAsync(hs.data(), send, bytes, hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    cb.allgather(cb.ctx, hs.data(), hr.data(), bytes);
+    MI_HIP(hipMemcpyAsync(recv, hr.data(), hr.size(), hipMemcpyHostToDevice, s));
+    MI_HIP(hipStreamSynchronize(s));
+  }
+  void exchange_dev(const std::vector<PeerBuf> &sends, const std::vector<PeerBuf> &recvs, hipStream_t s) override {
+    if (sends.empty() && recvs.empty()) return;
+    std::vector<std::vector<char>> hs(sends.size()), hr(recvs.size());
+    std::vector<int> sp, rp;
+    std::vector<void *> sptr, rptr;
+    std::vector<size_t> sby, rby;
+    for (size_t i = 0; i < sends.size(); i++) {
+      hs[i].resize(sends[i].bytes);
+      MI_HIP(hipMemcpyAsync(hs[i].data(), sends[i].ptr, sends[i].bytes, hipMemcpyDeviceToHost, s));
+      sp.push_back(sends[i].peer);
+      sptr.push_back(hs[i].data());
+      sby.push_back(sends[i].bytes);
+    }
+    for (size_t i = 0; i < recvs.size(); i++) {
+      hr[i].resize(recvs[i].bytes);
+      rp.push_back(recvs[i].peer);
+      rptr.push_back(hr[i].data());
+      rby.push_back(recvs[i].bytes);
+    }
+    MI_HIP(hipStreamSynchronize(s));
+    cb.exchange(cb.ctx, (int)sp.size(), sp.data(), sptr.data(), sby.data(), (int)rp.size(), rp.data(), rptr.data(),
+                rby.data());
+    for (size_t i = 0; i < recvs.size(); i++)
+      MI_HIP(hipMemcpyAsync(recvs[i].ptr, hr[i].data(), recvs[i].bytes, hipMemcpyHostToDevice, s));
+    MI_HIP(hipStreamSynchronize(s));
+  }
+};
+}  // namespace
+
+std::unique_ptr<Comm> make_self_comm() { return std::unique_ptr<Comm>(new SelfComm()); }
+std::unique_ptr<Comm> make_rccl_comm(const void *id, int rank, int size) {
+  return std::unique_ptr<Comm>(new RcclComm(id, rank, size));
+}
+void rccl_get_unique_id(void *out128) {
+  ncclUniqueId id;
+  MI_NCCL(rccl().GetUniqueId(&id));
+  memcpy(out128, &id, sizeof(id));
+}
+std::unique_ptr<Comm> make_callback_comm(const CommCallbacks &cb, int rank, int size) {
+  return std::unique_ptr<Comm>(new CallbackComm(cb, rank, size));
+}
+
+}  // namespace mi

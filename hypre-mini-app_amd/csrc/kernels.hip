@@ -1,0 +1,444 @@
+// Hand-written HIP kernels for gfx950 (MI355X, wave64, 256 CUs in 8 XCDs).
+//
+// Everything on this path is HBM-bandwidth bound sparse/vector work (arithmetic
+// intensity ~0.13 flop/B): no MFMA.  The rules that matter are coalesced 16-byte
+// streaming loads of the matrix, LDS staging of the per-entry products so that
+// short rows reduce without divergence, __shfl wave reductions, and a
+// workgroup->row-range map that keeps each XCD's L2 on its own slice of x.
+#include "kernels.hpp"
+#include "profile.hpp"
+
+namespace mi {
+namespace k {
+
+namespace {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an
+// L2).  Remap so that XCD g walks the contiguous row-block range
+// [g*chunk, (g+1)*chunk): neighbouring rows (and the x planes they gather) stay
+// in one L2.  Speed only -- any placement gives the same result.
+__device__ __forceinline__ int xcd_remap(int bid, int chunk) { return (bid & 7) * chunk + (bid >> 3); }
+
+// ---------------------------------------------------------------------------
+// LDS-staged row-block SpMV ("CSR-stream") with fused epilogues.
+//   phase 1: the workgroup streams its contiguous slice of (col,val) with
+//            16-byte/8-byte coalesced loads, gathers x, writes products to LDS
+//   phase 2: G lanes per row (G = 1..64, uniform per workgroup) sum the row's
+//            products out of LDS; G > 1 finishes with __shfl_down
+// A block that holds exactly one row longer than the tile takes the
+// whole-workgroup path instead.
+// EPI 0: y = alpha*s + beta*b          (matvec / residual / restrict / prolong)
+// EPI 1: masked Jacobi  y = x_i + w*(f - offc - s)/d on selected rows, else x_i
+// ---------------------------------------------------------------------------
+struct EpiArgs {
+  double alpha, beta;      // EPI 0
+  const double *b;         // EPI 0: b ; EPI 1: f
+  const double *offc;      // EPI 1 (nullable)
+  const double *d;         // EPI 1
+  const signed char *cf;   // EPI 1 (nullable)
+  int points;              // EPI 1
+};
+
+template <int EPI>
+__device__ __forceinline__ void epilogue(int r, double s, const double *__restrict__ x, double *__restrict__ y,
+                                         const EpiArgs &e) {
+  if (EPI == 0) {
+    y[r] = (e.beta == 0.0) ? e.alpha * s : e.alpha * s + e.beta * e.b[r];
+  } else {
+    const double xi = x[r];
+    double out = xi;
+    const bool sel = (e.points == 0) || (e.cf == nullptr) || (e.cf[r] == e.points);
+    const double d = e.d[r];
+    if (sel && d != 0.0) {
+      double res = e.b[r] - s;
+      if (e.offc) res -= e.offc[r];
+      out = xi + e.alpha * res / d;
+    }
+    y[r] = out;
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream(int nb, int xchunk, const int *__restrict__ rb,
+                                                          const int *__restrict__ ia, const int *__restrict__ ja,
+                                                          const double *__restrict__ av, const double *__restrict__ x,
+                                                          double *__restrict__ y, EpiArgs e) {
+  __shared__ double prod[SPMV_TILE];
+  const int blk = xcd_remap(blockIdx.x, xchunk);
+  if (blk >= nb) return;
+  const int tid = threadIdx.x;
+  const int r0 = rb[blk], r1 = rb[blk + 1];
+  const int base = ia[r0], end = ia[r1];
+  if (end - base >= SPMV_TILE) {
+    // one long row: every lane strides over it, two-level reduction
+    double s = 0.0;
+    for (int k = base + tid; k < end; k += SPMV_BLOCK) s += av[k] * x[ja[k]];
+    s = wave_sum(s);
+    if ((tid & 63) == 0) prod[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) epilogue<EPI>(r0, prod[0] + prod[1] + prod[2] + prod[3], x, y, e);
+    return;
+  }
+  // phase 1: aligned pairs -> double2 / int2 loads (arrays carry 2 pad entries)
+  const int base_al = base & ~1;
+  const int cnt = end - base_al;  // <= SPMV_TILE
+  for (int k = 2 * tid; k < cnt; k += 2 * SPMV_BLOCK) {
+    const double2 v = *reinterpret_cast<const double2 *>(av + base_al + k);
+    const int2 c = *reinterpret_cast<const int2 *>(ja + base_al + k);
+    const bool ok0 = (base_al + k >= base);
+    const bool ok1 = (base_al + k + 1 < end);
+    const double x0 = ok0 ? x[c.x] : 0.0;
+    const double x1 = ok1 ? x[c.y] : 0.0;
+    prod[k] = v.x * x0;
+    if (k + 1 < SPMV_TILE) prod[k + 1] = v.y * x1;
+  }
+  __syncthreads();
+  // phase 2
+  const int nr = r1 - r0;
+  int G = 1;
+  while (G < 64 && nr * G * 2 <= SPMV_BLOCK) G <<= 1;
+  const int lane = tid & (G - 1);
+  for (int rr = tid / G; rr < nr; rr += SPMV_BLOCK / G) {
+    const int r = r0 + rr;
+    const int s0 = ia[r] - base_al, s1 = ia[r + 1] - base_al;
+    double s = 0.0;
+    for (int k = s0 + lane; k < s1; k += G) s += prod[k];
+    for (int off = G >> 1; off > 0; off >>= 1) s += __shfl_down(s, off, G);
+    if (lane == 0) epilogue<EPI>(r, s, x, y, e);
+  }
+}
+
+// compressed-row off-diagonal block: one lane per stored row (halo rows are few
+// and short); MODE 0: y[row] += alpha*s ; MODE 1: y[row] = s
+template <int MODE>
+__global__ __launch_bounds__(256) void spmv_offd_k(int nrc, const int *__restrict__ rows, const int *__restrict__ ia,
+                                                   const int *__restrict__ ja, const double *__restrict__ av,
+                                                   const double *__restrict__ xext, double alpha,
+                                                   double *__restrict__ y) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= nrc) return;
+  double s = 0.0;
+  for (int q = ia[k]; q < ia[k + 1]; q++) s += av[q] * xext[ja[q]];
+  const int r = rows[k];
+  if (MODE == 0)
+    y[r] += alpha * s;
+  else
+    y[r] = s;
+}
+
+// ---------------------------------------------------------------------------
+// Hybrid Gauss-Seidel: lane c owns the chunk of `chunk` consecutive rows
+// [c*chunk, ...), sweeps it sequentially (forward and/or backward) with its own
+// running values in LDS, and reads every other chunk's PRE-sweep value from
+// u_old.  This is HYPRE's hybrid smoother with chunks in the role of its
+// threads/ranks (par_relax.c) and is bitwise independent of
+// scheduling because u_old is never written.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(GS_BLOCK) void gs_hybrid_k(int n, int nchunks, int chunk, const int *__restrict__ ia,
+                                                        const int *__restrict__ ja, const double *__restrict__ av,
+                                                        const signed char *__restrict__ cf, int points,
+                                                        const double *__restrict__ dd, const double *__restrict__ f,
+                                                        const double *__restrict__ offc,
+                                                        const double *__restrict__ u_old, double *__restrict__ u_new,
+                                                        int fwd, int bwd, double w) {
+  extern __shared__ double ucur[];  // [chunk][GS_BLOCK]
+  const int tid = threadIdx.x;
+  const long long c = (long long)blockIdx.x * GS_BLOCK + tid;
+  if (c >= nchunks) return;
+  const int cs = (int)(c * chunk);
+  const int len = min(chunk, n - cs);
+  for (int t = 0; t < len; t++) ucur[t * GS_BLOCK + tid] = u_old[cs + t];
+  for (int dir = 0; dir < 2; dir++) {
+    if (dir == 0 ? !fwd : !bwd) continue;
+    for (int t = 0; t < len; t++) {
+      const int tt = (dir == 0) ? t : len - 1 - t;
+      const int i = cs + tt;
+      if (points != 0 && cf != nullptr && cf[i] != points) continue;
+      const double d = dd[i];
+      if (d == 0.0) continue;
+      double res = f[i];
+      if (offc) res -= offc[i];
+      const int k1 = ia[i + 1];
+      for (int k = ia[i]; k < k1; k++) {
+        const int j = ja[k];
+        const unsigned o = (unsigned)(j - cs);
+        const double v = (o < (unsigned)len) ? ucur[o * GS_BLOCK + tid] : u_old[j];
+        res -= av[k] * v;
+      }
+      ucur[tt * GS_BLOCK + tid] += w * res / d;
+    }
+  }
+  for (int t = 0; t < len; t++) u_new[cs + t] = ucur[t * GS_BLOCK + tid];
+}
+
+// ---------------------------------------------------------------------------
+// BLAS-1
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dot_partial_k(const double *__restrict__ x, const double *__restrict__ y, int n,
+                                                     double *__restrict__ partials) {
+  __shared__ double ws[4];
+  const int tid = threadIdx.x;
+  double s = 0.0;
+  const long long stride = (long long)gridDim.x * 512;
+  long long i = ((long long)blockIdx.x * 256 + tid) * 2;
+  for (; i + 1 < n; i += stride) {
+    const double2 a = *reinterpret_cast<const double2 *>(x + i);
+    const double2 b = *reinterpret_cast<const double2 *>(y + i);
+    s += a.x * b.x + a.y * b.y;
+  }
+  if (i < n) s += x[i] * y[i];
+  s = wave_sum(s);
+  if ((tid & 63) == 0) ws[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) partials[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+__global__ __launch_bounds__(256) void reduce_final_k(const double *__restrict__ partials, int nb,
+                                                      double *__restrict__ out) {
+  __shared__ double ws[4];
+  const int tid = threadIdx.x;
+  double s = 0.0;
+  for (int i = tid; i < nb; i += 256) s += partials[i];
+  s = wave_sum(s);
+  if ((tid & 63) == 0) ws[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) out[0] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+// y += (scale * (alpha_dev ? *alpha_dev : 1)) * x
+__global__ __launch_bounds__(256) void axpy_k(const double *__restrict__ alpha_dev, double scale,
+                                              const double *__restrict__ x, double *__restrict__ y, int n) {
+  const double a = scale * (alpha_dev ? alpha_dev[0] : 1.0);
+  const long long stride = (long long)gridDim.x * 512;
+  long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 2;
+  for (; i + 1 < n; i += stride) {
+    const double2 xv = *reinterpret_cast<const double2 *>(x + i);
+    double2 yv = *reinterpret_cast<double2 *>(y + i);
+    yv.x += a * xv.x;
+    yv.y += a * xv.y;
+    *reinterpret_cast<double2 *>(y + i) = yv;
+  }
+  if (i < n) y[i] += a * x[i];
+}
+
+// MODE 0: x *= scale ; MODE 1: x *= 1/sqrt(*sumsq_dev) when *sumsq_dev > 0
+template <int MODE>
+__global__ __launch_bounds__(256) void scale_k(const double *__restrict__ sumsq_dev, double scale,
+                                               double *__restrict__ x, int n) {
+  double a = scale;
+  if (MODE == 1) {
+    const double t = sumsq_dev[0];
+    if (!(t > 0.0)) return;
+    a = 1.0 / sqrt(t);
+  }
+  const long long stride = (long long)gridDim.x * 512;
+  long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 2;
+  for (; i + 1 < n; i += stride) {
+    double2 v = *reinterpret_cast<double2 *>(x + i);
+    v.x *= a;
+    v.y *= a;
+    *reinterpret_cast<double2 *>(x + i) = v;
+  }
+  if (i < n) x[i] *= a;
+}
+
+__global__ __launch_bounds__(256) void fill_k(double *__restrict__ x, int n, double v) {
+  const long long stride = (long long)gridDim.x * 512;
+  long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 2;
+  for (; i + 1 < n; i += stride) *reinterpret_cast<double2 *>(x + i) = make_double2(v, v);
+  if (i < n) x[i] = v;
+}
+
+__global__ __launch_bounds__(256) void gather_k(const double *__restrict__ x, const int *__restrict__ map,
+                                                double *__restrict__ out, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = x[map[i]];
+}
+
+template <int ADD>
+__global__ __launch_bounds__(256) void scatter_k(double *__restrict__ x, const int *__restrict__ idx,
+                                                 const double *__restrict__ vals, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    if (ADD)
+      x[idx[i]] += vals[i];  // caller guarantees unique indices
+    else
+      x[idx[i]] = vals[i];
+  }
+}
+
+// u = M f for the coarsest level (relax type 9: M = dense inverse, n small)
+__global__ __launch_bounds__(256) void dense_matvec_k(const double *__restrict__ M, const double *__restrict__ f,
+                                                      double *__restrict__ u, int n, int m) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int j = 0; j < m; j++) s += M[(size_t)i * m + j] * f[j];
+  u[i] = s;
+}
+
+inline int vec_grid(int n) {
+  long long want = ((long long)n + 511) / 512;
+  if (want < 1) want = 1;
+  if (want > RED_MAX_BLOCKS) want = RED_MAX_BLOCKS;
+  return (int)want;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- host side
+
+std::vector<int> build_row_blocks(int nrows, const int64_t *ia) {
+  std::vector<int> rb;
+  rb.reserve((size_t)nrows / 200 + 2);
+  rb.push_back(0);
+  int r = 0;
+  while (r < nrows) {
+    const int64_t start = ia[r];
+    int e = r;
+    // keep one slot of slack for the aligned-pair start
+    while (e < nrows && e - r < SPMV_BLOCK && ia[e + 1] - start <= SPMV_TILE - 1) e++;
+    if (e == r) e = r + 1;  // a single row longer than the tile
+    rb.push_back(e);
+    r = e;
+  }
+  return rb;
+}
+
+static void launch_stream(int epi, const DevCSR &A, const double *x, double *y, const EpiArgs &e, hipStream_t s) {
+  if (A.nrows == 0) return;
+  const int nb = A.nblocks;
+  const int xchunk = (nb + 7) / 8;
+  const dim3 grid(xchunk * 8), block(SPMV_BLOCK);
+  if (epi == 0)
+    hipLaunchKernelGGL(spmv_stream<0>, grid, block, 0, s, nb, xchunk, A.rb.p, A.ia.p, A.ja.p, A.a.p, x, y, e);
+  else
+    hipLaunchKernelGGL(spmv_stream<1>, grid, block, 0, s, nb, xchunk, A.rb.p, A.ia.p, A.ja.p, A.a.p, x, y, e);
+  MI_HIP(hipGetLastError());
+}
+
+void spmv(const DevCSR &A, const double *x, double alpha, double beta, const double *b, double *y, hipStream_t s,
+          int prof) {
+  EpiArgs e{};
+  e.alpha = alpha;
+  e.beta = beta;
+  e.b = b;
+  prof_begin(prof, s);
+  launch_stream(0, A, x, y, e, s);
+  prof_end(prof, s);
+}
+
+void jacobi(const DevCSR &A, const double *u_old, double *u_new, const double *f, const double *offc, const double *d,
+            const signed char *cf, int points, double w, hipStream_t s, int prof) {
+  EpiArgs e{};
+  e.alpha = w;
+  e.b = f;
+  e.offc = offc;
+  e.d = d;
+  e.cf = cf;
+  e.points = points;
+  prof_begin(prof, s);
+  launch_stream(1, A, u_old, u_new, e, s);
+  prof_end(prof, s);
+}
+
+void spmv_offd_add(const DevOffd &B, const double *xext, double alpha, double *y, hipStream_t s) {
+  if (B.nrows_c == 0) return;
+  hipLaunchKernelGGL(spmv_offd_k<0>, dim3((B.nrows_c + 255) / 256), dim3(256), 0, s, B.nrows_c, B.rows.p, B.ia.p,
+                     B.ja.p, B.a.p, xext, alpha, y);
+  MI_HIP(hipGetLastError());
+}
+void spmv_offd_set(const DevOffd &B, const double *xext, double *out, hipStream_t s) {
+  if (B.nrows_c == 0) return;
+  hipLaunchKernelGGL(spmv_offd_k<1>, dim3((B.nrows_c + 255) / 256), dim3(256), 0, s, B.nrows_c, B.rows.p, B.ia.p,
+                     B.ja.p, B.a.p, xext, 1.0, out);
+  MI_HIP(hipGetLastError());
+}
+
+void gs_hybrid(const DevCSR &A, const double *u_old, double *u_new, const double *f, const double *offc,
+               const double *d, const signed char *cf, int points, int chunk, bool fwd, bool bwd, double w,
+               hipStream_t s, int prof) {
+  if (A.nrows == 0) return;
+  MI_REQUIRE(chunk >= 1 && chunk <= GS_MAX_CHUNK, "hybrid GS chunk out of range");
+  const long long nchunks = ((long long)A.nrows + chunk - 1) / chunk;
+  const size_t lds = (size_t)chunk * GS_BLOCK * sizeof(double);
+  prof_begin(prof, s);
+  hipLaunchKernelGGL(gs_hybrid_k, dim3((unsigned)((nchunks + GS_BLOCK - 1) / GS_BLOCK)), dim3(GS_BLOCK), lds, s,
+                     A.nrows, (int)nchunks, chunk, A.ia.p, A.ja.p, A.a.p, cf, points, d, f, offc, u_old, u_new,
+                     fwd ? 1 : 0, bwd ? 1 : 0, w);
+  MI_HIP(hipGetLastError());
+  prof_end(prof, s);
+}
+
+void dot(const double *x, const double *y, int n, double *out_dev, hipStream_t s) {
+  const int g = vec_grid(n);
+  double *partials = ctx().red_partials.p;
+  prof_begin(PROF_DOT, s);
+  hipLaunchKernelGGL(dot_partial_k, dim3(g), dim3(256), 0, s, x, y, n, partials);
+  hipLaunchKernelGGL(reduce_final_k, dim3(1), dim3(256), 0, s, partials, g, out_dev);
+  prof_end(PROF_DOT, s);
+  MI_HIP(hipGetLastError());
+}
+
+void axpy(double alpha, const double *x, double *y, int n, hipStream_t s) {
+  if (n == 0) return;
+  prof_begin(PROF_AXPY, s);
+  hipLaunchKernelGGL(axpy_k, dim3(vec_grid(n)), dim3(256), 0, s, (const double *)nullptr, alpha, x, y, n);
+  prof_end(PROF_AXPY, s);
+  MI_HIP(hipGetLastError());
+}
+void axpy_dev(const double *alpha_dev, double scale_, const double *x, double *y, int n, hipStream_t s) {
+  if (n == 0) return;
+  prof_begin(PROF_AXPY, s);
+  hipLaunchKernelGGL(axpy_k, dim3(vec_grid(n)), dim3(256), 0, s, alpha_dev, scale_, x, y, n);
+  prof_end(PROF_AXPY, s);
+  MI_HIP(hipGetLastError());
+}
+void scale(double alpha, double *x, int n, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(scale_k<0>, dim3(vec_grid(n)), dim3(256), 0, s, (const double *)nullptr, alpha, x, n);
+  MI_HIP(hipGetLastError());
+}
+void scale_inv_sqrt_dev(const double *sumsq_dev, double *x, int n, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(scale_k<1>, dim3(vec_grid(n)), dim3(256), 0, s, sumsq_dev, 1.0, x, n);
+  MI_HIP(hipGetLastError());
+}
+void fill(double *x, int n, double v, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(fill_k, dim3(vec_grid(n)), dim3(256), 0, s, x, n, v);
+  MI_HIP(hipGetLastError());
+}
+void copy(const double *x, double *y, int n, hipStream_t s) {
+  if (n == 0 || x == y) return;
+  MI_HIP(hipMemcpyAsync(y, x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+}
+void gather(const double *x, const int *map, double *out, int n, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(gather_k, dim3((n + 255) / 256), dim3(256), 0, s, x, map, out, n);
+  MI_HIP(hipGetLastError());
+}
+void scatter_set(double *x, const int *idx, const double *vals, int n, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(scatter_k<0>, dim3((n + 255) / 256), dim3(256), 0, s, x, idx, vals, n);
+  MI_HIP(hipGetLastError());
+}
+void scatter_add(double *x, const int *idx, const double *vals, int n, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(scatter_k<1>, dim3((n + 255) / 256), dim3(256), 0, s, x, idx, vals, n);
+  MI_HIP(hipGetLastError());
+}
+void dense_matvec(const double *M, const double *f, double *u, int n, int m, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(dense_matvec_k, dim3((n + 255) / 256), dim3(256), 0, s, M, f, u, n, m);
+  MI_HIP(hipGetLastError());
+}
+
+}  // namespace k
+}  // namespace mi

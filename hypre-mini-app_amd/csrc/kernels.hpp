@@ -1,0 +1,56 @@
+// Launchers of the hand-written gfx950 kernels (kernels.hip).  All launches are
+// asynchronous on the given stream; pointers are device pointers.
+#pragma once
+#include "mi_internal.hpp"
+
+namespace mi {
+namespace k {
+
+constexpr int SPMV_BLOCK = 256;   // threads per workgroup (4 wave64)
+constexpr int SPMV_TILE = 2048;   // LDS-staged products per workgroup
+constexpr int RED_MAX_BLOCKS = 2048;
+constexpr int GS_BLOCK = 256;     // chunks (lanes) per workgroup
+constexpr int GS_MAX_CHUNK = 32;
+
+// kernel classes that can be timed with HIP events (profile.cpp)
+enum ProfId { PROF_NONE = -1, PROF_SPMV_L0 = 0, PROF_RELAX_L0 = 1, PROF_DOT = 2, PROF_AXPY = 3, PROF_COUNT = 4 };
+
+// host: row-block schedule for spmv_stream (<= 256 rows and < SPMV_TILE entries
+// per block, or exactly one longer row)
+std::vector<int> build_row_blocks(int nrows, const int64_t *ia);
+
+// y = alpha*A*x + beta*b   (b may alias y)
+void spmv(const DevCSR &A, const double *x, double alpha, double beta, const double *b, double *y, hipStream_t s,
+          int prof = PROF_NONE);
+// y[rows[k]] += alpha * (B*xext)[k]
+void spmv_offd_add(const DevOffd &B, const double *xext, double alpha, double *y, hipStream_t s);
+// out[rows[k]] = (B*xext)[k]   (other entries of out untouched)
+void spmv_offd_set(const DevOffd &B, const double *xext, double *out, hipStream_t s);
+
+// masked Jacobi family: u_new = u_old + w*(f - offc - A*u_old)/d on selected rows, copy elsewhere
+void jacobi(const DevCSR &A, const double *u_old, double *u_new, const double *f, const double *offc, const double *d,
+            const signed char *cf, int points, double w, hipStream_t s, int prof = PROF_NONE);
+// hybrid Gauss-Seidel family: chunks of `chunk` consecutive rows are swept
+// sequentially (forward and/or backward), chunks see each other's pre-sweep values
+void gs_hybrid(const DevCSR &A, const double *u_old, double *u_new, const double *f, const double *offc, const double *d,
+               const signed char *cf, int points, int chunk, bool fwd, bool bwd, double w, hipStream_t s,
+               int prof = PROF_NONE);
+
+// BLAS-1
+void dot(const double *x, const double *y, int n, double *out_dev, hipStream_t s);  // local sum, no collective
+void axpy(double alpha, const double *x, double *y, int n, hipStream_t s);
+void axpy_dev(const double *alpha_dev, double scale, const double *x, double *y, int n, hipStream_t s);
+void scale(double alpha, double *x, int n, hipStream_t s);
+void scale_inv_sqrt_dev(const double *sumsq_dev, double *x, int n, hipStream_t s);
+void fill(double *x, int n, double v, hipStream_t s);
+void copy(const double *x, double *y, int n, hipStream_t s);
+void gather(const double *x, const int *map, double *out, int n, hipStream_t s);
+// u = M f, M dense n x m row-major
+void dense_matvec(const double *M, const double *f, double *u, int n, int m, hipStream_t s);
+
+// IJ helpers
+void scatter_set(double *x, const int *idx, const double *vals, int n, hipStream_t s);
+void scatter_add(double *x, const int *idx, const double *vals, int n, hipStream_t s);
+
+}  // namespace k
+}  // namespace mi

@@ -1,0 +1,266 @@
+// Krylov control loops on the host, vectors and reductions on the device.
+//   GMRES   : hypre_GMRESSolve (krylov/gmres.c), SURVEY A.1 -- the Solve call timed
+//             at src/HypreSystem.cpp:715-727 (solverSolvePtr_, bound at :403)
+//   BiCGSTAB: hypre_BiCGSTABSolve (krylov/bicgstab.c), SURVEY A.6 (bound at :423-438)
+// Modified Gram-Schmidt keeps its coefficients on the device: every <p_j,p_i>
+// lands in a device slot that the following axpy reads, so one Arnoldi step
+// costs a single host synchronisation (the Hessenberg column copy).
+#include <cmath>
+#include <cstring>
+
+#include "kernels.hpp"
+#include "solvers.hpp"
+
+namespace mi {
+
+void KrylovSolver::apply_precond(ParCSR &A, ParVector &rhs, ParVector &out) {
+  hipStream_t s = ctx().stream;
+  if (precond_solve) {
+    k::fill(out.data(), out.n, 0.0, s);
+    precond_solve(precond_data, &A, &rhs, &out);
+  } else {
+    k::copy(rhs.data(), out.data(), out.n, s);
+  }
+}
+
+void GmresSolver::setup(ParCSR &A, ParVector &b, ParVector &x) {
+  ensure_init();
+  MI_REQUIRE(b.ncomp == 1 && x.ncomp == 1, "GMRES: multi-component vectors are not supported");
+  // Krylov basis vectors are created on demand in solve(): GMRES(50) rarely
+  // fills its basis behind an AMG preconditioner
+  r.init(b.start, b.end, 1);
+  w.init(b.start, b.end, 1);
+  if (precond_setup) precond_setup(precond_data, &A, &b, &x);
+}
+
+int GmresSolver::solve(ParCSR &A, ParVector &b, ParVector &x) {
+  ensure_init();
+  Ctx &c = ctx();
+  Comm &comm = *c.comm;
+  hipStream_t s = c.stream;
+  const double t_start = wall_time();
+  const int n = b.n;
+  const int kd = k_dim < 1 ? 1 : k_dim;
+  MI_REQUIRE(kd + 2 <= 250, "GMRES: k_dim too large for the device scalar slots");
+  if (r.n != n) setup(A, b, x);
+  const double epsmac = 1.e-16;
+  auto basis = [&](int i) -> ParVector & {
+    while ((int)p.size() <= i) {
+      std::unique_ptr<ParVector> v(new ParVector());
+      v->init(b.start, b.end, 1);
+      p.push_back(std::move(v));
+    }
+    return *p[(size_t)i];
+  };
+  std::vector<double> cs((size_t)kd + 1, 0.0), sn((size_t)kd + 1, 0.0), rs((size_t)kd + 1, 0.0);
+  std::vector<std::vector<double>> hh((size_t)kd + 1, std::vector<double>((size_t)kd, 0.0));
+  double *slots = c.red_out.p;
+
+  ParVector &p0 = basis(0);
+  A.matvec(comm, -1.0, x.data(), 1.0, b.data(), p0.data(), s, k::PROF_SPMV_L0);
+  const double b_norm = std::sqrt(par_dot_host(comm, b.data(), b.data(), n, s));
+  double r_norm = std::sqrt(par_dot_host(comm, p0.data(), p0.data(), n, s));
+  const double r_norm_0 = r_norm;
+  const double den = (b_norm > 0.0) ? b_norm : r_norm;
+  const double eps = std::max(atol, tol * den);
+  int iter = 0;
+  converged = false;
+  norms.clear();
+  norms.push_back(r_norm);
+  const bool chatty = print_level > 1 && comm.rank == 0;
+  if (chatty) {
+    printf("=============================================\n\n");
+    printf("Iters     resid.norm     conv.rate  rel.res.norm\n");
+    printf("-----    ------------    ---------- ------------\n");
+  }
+
+  while (iter < max_iter) {
+    rs[0] = r_norm;
+    if (r_norm == 0.0) {
+      converged = true;
+      break;
+    }
+    if (r_norm <= eps && iter >= min_iter) {
+      A.matvec(comm, -1.0, x.data(), 1.0, b.data(), r.data(), s, k::PROF_SPMV_L0);
+      r_norm = std::sqrt(par_dot_host(comm, r.data(), r.data(), n, s));
+      if (r_norm <= eps) {
+        converged = true;
+        break;
+      }
+      if (chatty) printf("false convergence 1\n");
+    }
+    k::scale(1.0 / r_norm, basis(0).data(), n, s);
+    int i = 0;
+    while (i < kd && iter < max_iter) {
+      i++;
+      iter++;
+      ParVector &pi = basis(i);
+      ParVector &pim1 = basis(i - 1);
+      apply_precond(A, pim1, r);
+      A.matvec(comm, 1.0, r.data(), 0.0, nullptr, pi.data(), s, k::PROF_SPMV_L0);
+      for (int j = 0; j < i; j++) {
+        par_dot(comm, basis(j).data(), pi.data(), n, slots + j, s);
+        k::axpy_dev(slots + j, -1.0, basis(j).data(), pi.data(), n, s);
+      }
+      par_dot(comm, pi.data(), pi.data(), n, slots + i, s);
+      k::scale_inv_sqrt_dev(slots + i, pi.data(), n, s);
+      MI_HIP(hipMemcpyAsync(c.h_pinned, slots, (size_t)(i + 1) * sizeof(double), hipMemcpyDeviceToHost, s));
+      MI_HIP(hipStreamSynchronize(s));
+      for (int j = 0; j < i; j++) hh[(size_t)j][(size_t)i - 1] = c.h_pinned[j];
+      const double t = std::sqrt(c.h_pinned[i] > 0.0 ? c.h_pinned[i] : 0.0);
+      hh[(size_t)i][(size_t)i - 1] = t;
+      for (int j = 1; j < i; j++) {
+        const double tt = hh[(size_t)j - 1][(size_t)i - 1];
+        hh[(size_t)j - 1][(size_t)i - 1] = sn[(size_t)j - 1] * hh[(size_t)j][(size_t)i - 1] + cs[(size_t)j - 1] * tt;
+        hh[(size_t)j][(size_t)i - 1] = -sn[(size_t)j - 1] * tt + cs[(size_t)j - 1] * hh[(size_t)j][(size_t)i - 1];
+      }
+      double gamma = std::sqrt(hh[(size_t)i - 1][(size_t)i - 1] * hh[(size_t)i - 1][(size_t)i - 1] +
+                               hh[(size_t)i][(size_t)i - 1] * hh[(size_t)i][(size_t)i - 1]);
+      if (gamma == 0.0) gamma = epsmac;
+      cs[(size_t)i - 1] = hh[(size_t)i - 1][(size_t)i - 1] / gamma;
+      sn[(size_t)i - 1] = hh[(size_t)i][(size_t)i - 1] / gamma;
+      rs[(size_t)i] = -hh[(size_t)i][(size_t)i - 1] * rs[(size_t)i - 1];
+      rs[(size_t)i] /= gamma;
+      rs[(size_t)i - 1] = cs[(size_t)i - 1] * rs[(size_t)i - 1];
+      hh[(size_t)i - 1][(size_t)i - 1] =
+          sn[(size_t)i - 1] * hh[(size_t)i][(size_t)i - 1] + cs[(size_t)i - 1] * hh[(size_t)i - 1][(size_t)i - 1];
+      const double prev = r_norm;
+      r_norm = std::fabs(rs[(size_t)i]);
+      norms.push_back(r_norm);
+      if (chatty)
+        printf("% 5d    %e    %f   %e\n", iter, r_norm, prev > 0 ? r_norm / prev : 0.0,
+               b_norm > 0 ? r_norm / b_norm : r_norm);
+      if (r_norm <= eps && iter >= min_iter) break;
+    }
+    // back substitution
+    std::vector<double> y(rs.begin(), rs.begin() + i);
+    y[(size_t)i - 1] = y[(size_t)i - 1] / hh[(size_t)i - 1][(size_t)i - 1];
+    for (int kk = i - 2; kk >= 0; kk--) {
+      double t = 0.0;
+      for (int j = kk + 1; j < i; j++) t -= hh[(size_t)kk][(size_t)j] * y[(size_t)j];
+      t += y[(size_t)kk];
+      y[(size_t)kk] = t / hh[(size_t)kk][(size_t)kk];
+    }
+    // w = sum_j y_j p_j ; x += M^-1 w
+    k::copy(basis(i - 1).data(), w.data(), n, s);
+    k::scale(y[(size_t)i - 1], w.data(), n, s);
+    for (int j = i - 2; j >= 0; j--) k::axpy(y[(size_t)j], basis(j).data(), w.data(), n, s);
+    apply_precond(A, w, r);
+    k::axpy(1.0, r.data(), x.data(), n, s);
+    if (r_norm <= eps && iter >= min_iter) {
+      A.matvec(comm, -1.0, x.data(), 1.0, b.data(), r.data(), s, k::PROF_SPMV_L0);
+      r_norm = std::sqrt(par_dot_host(comm, r.data(), r.data(), n, s));
+      if (r_norm <= eps) {
+        converged = true;
+        break;
+      }
+      if (chatty) printf("false convergence 2\n");
+      k::copy(r.data(), basis(0).data(), n, s);
+      i = 0;
+    }
+    // residual vector for the restart, rebuilt from the Givens data
+    for (int j = i; j > 0; j--) {
+      rs[(size_t)j - 1] = -sn[(size_t)j - 1] * rs[(size_t)j];
+      rs[(size_t)j] = cs[(size_t)j - 1] * rs[(size_t)j];
+    }
+    if (i) k::scale(rs[(size_t)i], basis(i).data(), n, s);  // p_i += (rs_i - 1) p_i
+    for (int j = i - 1; j > 0; j--) k::axpy(rs[(size_t)j], basis(j).data(), basis(i).data(), n, s);
+    if (i) {
+      k::scale(rs[0], basis(0).data(), n, s);
+      k::axpy(1.0, basis(i).data(), basis(0).data(), n, s);
+    }
+  }
+  MI_HIP(hipStreamSynchronize(s));
+  num_iterations = iter;
+  rel_residual_norm = (b_norm > 0.0) ? r_norm / b_norm : r_norm;
+  solve_seconds = wall_time() - t_start;
+  if (chatty) {
+    printf("\n\nFinal L2 norm of residual: %e\n\n", r_norm);
+    (void)r_norm_0;
+  }
+  return (iter >= max_iter && r_norm > eps) ? 256 : 0;  // HYPRE_ERROR_CONV
+}
+
+void BicgstabSolver::setup(ParCSR &A, ParVector &b, ParVector &x) {
+  ensure_init();
+  MI_REQUIRE(b.ncomp == 1 && x.ncomp == 1, "BiCGSTAB: multi-component vectors are not supported");
+  for (ParVector *v : {&r0, &r, &pv, &v, &q, &sv, &t}) v->init(b.start, b.end, 1);
+  if (precond_setup) precond_setup(precond_data, &A, &b, &x);
+}
+
+int BicgstabSolver::solve(ParCSR &A, ParVector &b, ParVector &x) {
+  ensure_init();
+  Ctx &c = ctx();
+  Comm &comm = *c.comm;
+  hipStream_t s = c.stream;
+  const double t_start = wall_time();
+  const int n = b.n;
+  if (r.n != n) setup(A, b, x);
+  const double epsmac = 1.e-128;
+  A.matvec(comm, -1.0, x.data(), 1.0, b.data(), r0.data(), s, k::PROF_SPMV_L0);
+  k::copy(r0.data(), r.data(), n, s);
+  k::copy(r0.data(), pv.data(), n, s);
+  const double b_norm = std::sqrt(par_dot_host(comm, b.data(), b.data(), n, s));
+  double rho = par_dot_host(comm, r0.data(), r0.data(), n, s);
+  double r_norm = std::sqrt(rho);
+  const double den = (b_norm > 0.0) ? b_norm : r_norm;
+  const double eps = std::max(atol, tol * den);
+  int iter = 0;
+  converged = (r_norm == 0.0);
+  norms.clear();
+  norms.push_back(r_norm);
+  const bool chatty = print_level > 1 && comm.rank == 0;
+  auto true_res_ok = [&]() {
+    A.matvec(comm, -1.0, x.data(), 1.0, b.data(), t.data(), s, k::PROF_SPMV_L0);
+    const double tn = std::sqrt(par_dot_host(comm, t.data(), t.data(), n, s));
+    if (tn <= eps) {
+      r_norm = tn;
+      return true;
+    }
+    return false;
+  };
+  while (!converged && iter < max_iter) {
+    iter++;
+    apply_precond(A, pv, v);
+    A.matvec(comm, 1.0, v.data(), 0.0, nullptr, q.data(), s, k::PROF_SPMV_L0);
+    const double temp = par_dot_host(comm, r0.data(), q.data(), n, s);
+    if (std::fabs(temp) < epsmac) break;
+    const double alpha = rho / temp;
+    k::axpy(alpha, v.data(), x.data(), n, s);
+    k::axpy(-alpha, q.data(), r.data(), n, s);
+    r_norm = std::sqrt(par_dot_host(comm, r.data(), r.data(), n, s));
+    if (r_norm <= eps && iter >= min_iter && true_res_ok()) {
+      norms.push_back(r_norm);
+      converged = true;
+      break;
+    }
+    apply_precond(A, r, v);
+    A.matvec(comm, 1.0, v.data(), 0.0, nullptr, sv.data(), s, k::PROF_SPMV_L0);
+    const double ss = par_dot_host(comm, sv.data(), sv.data(), n, s);
+    const double gamma = (ss != 0.0) ? par_dot_host(comm, r.data(), sv.data(), n, s) / ss : 0.0;
+    k::axpy(gamma, v.data(), x.data(), n, s);
+    k::axpy(-gamma, sv.data(), r.data(), n, s);
+    r_norm = std::sqrt(par_dot_host(comm, r.data(), r.data(), n, s));
+    norms.push_back(r_norm);
+    if (chatty) printf("% 5d    %e    %e\n", iter, r_norm, b_norm > 0 ? r_norm / b_norm : r_norm);
+    if (r_norm <= eps && iter >= min_iter && true_res_ok()) {
+      converged = true;
+      break;
+    }
+    if (std::fabs(rho) < epsmac) break;
+    double beta = 1.0 / rho;
+    rho = par_dot_host(comm, r0.data(), r.data(), n, s);
+    beta *= rho;
+    k::axpy(-gamma, q.data(), pv.data(), n, s);
+    if (std::fabs(gamma) < epsmac) break;
+    k::scale(beta * alpha / gamma, pv.data(), n, s);
+    k::axpy(1.0, r.data(), pv.data(), n, s);
+  }
+  MI_HIP(hipStreamSynchronize(s));
+  num_iterations = iter;
+  rel_residual_norm = (b_norm > 0.0) ? r_norm / b_norm : r_norm;
+  solve_seconds = wall_time() - t_start;
+  return (!converged && iter >= max_iter) ? 256 : 0;
+}
+
+}  // namespace mi

@@ -1,0 +1,188 @@
+// Internal definitions shared by the host control plane and the HIP kernels.
+// Nothing here is part of the C ABI (see include/*.h for that).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace mi {
+
+using gidx = long long;  // global row/column id (HYPRE_BigInt)
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+[[noreturn]] inline void fail(int code, const std::string &msg) { throw Error(code, msg); }
+
+#define MI_HIP(call)                                                                             \
+  do {                                                                                           \
+    hipError_t mi_e_ = (call);                                                                   \
+    if (mi_e_ != hipSuccess)                                                                     \
+      ::mi::fail(1, std::string("HIP error ") + hipGetErrorString(mi_e_) + " in " #call " at " + \
+                        __FILE__ + ":" + std::to_string(__LINE__));                              \
+  } while (0)
+
+#define MI_REQUIRE(cond, msg)                                                                          \
+  do {                                                                                                 \
+    if (!(cond)) ::mi::fail(4, std::string(msg) + " (" #cond ") at " + __FILE__ + ":" + std::to_string(__LINE__)); \
+  } while (0)
+
+// ---------------------------------------------------------------- device memory
+template <class T>
+struct DVec {
+  T *p = nullptr;
+  size_t n = 0;
+  DVec() = default;
+  explicit DVec(size_t n_) { alloc(n_); }
+  DVec(const DVec &) = delete;
+  DVec &operator=(const DVec &) = delete;
+  DVec(DVec &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr, o.n = 0; }
+  DVec &operator=(DVec &&o) noexcept {
+    if (this != &o) {
+      release();
+      p = o.p, n = o.n;
+      o.p = nullptr, o.n = 0;
+    }
+    return *this;
+  }
+  ~DVec() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr, n = 0;
+  }
+  // pad elements are allocated and zeroed past n (kernels read whole vectors of 2)
+  void alloc(size_t n_, size_t pad = 2) {
+    release();
+    n = n_;
+    MI_HIP(hipMalloc((void **)&p, (n + pad) * sizeof(T)));
+    if (pad) MI_HIP(hipMemset((void *)(p + n), 0, pad * sizeof(T)));
+  }
+  void upload(const T *h, size_t cnt) { MI_HIP(hipMemcpy(p, h, cnt * sizeof(T), hipMemcpyHostToDevice)); }
+  void upload(const std::vector<T> &h) {
+    alloc(h.size());
+    if (!h.empty()) upload(h.data(), h.size());
+  }
+  void download(T *h, size_t cnt) const { MI_HIP(hipMemcpy(h, p, cnt * sizeof(T), hipMemcpyDeviceToHost)); }
+  std::vector<T> to_host() const {
+    std::vector<T> h(n);
+    if (n) download(h.data(), n);
+    return h;
+  }
+};
+
+// ---------------------------------------------------------------- host CSR
+struct HostCSR {
+  int nrows = 0, ncols = 0;
+  std::vector<int64_t> ia;  // nrows+1
+  std::vector<int> ja;      // columns ascending inside a row
+  std::vector<double> a;
+  int64_t nnz() const { return ia.empty() ? 0 : ia.back(); }
+};
+
+// ---------------------------------------------------------------- device CSR
+// int32 row pointers: every per-rank, per-level block must hold < 2^31 entries.
+struct DevCSR {
+  int nrows = 0, ncols = 0;
+  int64_t nnz = 0;
+  DVec<int> ia;
+  DVec<int> ja;
+  DVec<double> a;
+  // row-block schedule of the LDS-staged SpMV (kernels.hip: spmv_stream)
+  DVec<int> rb;
+  int nblocks = 0;
+  bool empty() const { return nrows == 0 || nnz == 0; }
+  void upload(const HostCSR &h);
+};
+
+// compressed-row CSR for the off-diagonal (halo) block: only rows that own
+// halo entries are stored
+struct DevOffd {
+  int nrows_c = 0;  // rows with halo entries
+  int next = 0;     // number of halo columns
+  int64_t nnz = 0;
+  DVec<int> rows;  // local row id per compressed row
+  DVec<int> ia, ja;
+  DVec<double> a;
+  void upload(int nrows, const HostCSR &h);
+};
+
+// ---------------------------------------------------------------- communication
+enum class CommDType { F64, I64, I32, U8 };
+enum class CommOp { SUM, MIN, MAX };
+
+struct PeerBuf {
+  int peer;
+  void *ptr;
+  size_t bytes;
+};
+
+// One rank per GPU.  Device-buffer collectives are enqueued on `stream`; the
+// host-buffer ones are blocking and only used by setup and the loaders.
+struct Comm {
+  int rank = 0, size = 1;
+  virtual ~Comm() {}
+  virtual const char *name() const = 0;
+  virtual void allreduce_dev(void *buf, size_t count, CommDType t, CommOp op, hipStream_t s) = 0;
+  virtual void exchange_dev(const std::vector<PeerBuf> &sends, const std::vector<PeerBuf> &recvs, hipStream_t s) = 0;
+  virtual void allgather_dev(const void *send, void *recv, size_t bytes_per_rank, hipStream_t s) = 0;
+  // blocking host-side helpers built on the above
+  void allreduce_host(void *buf, size_t count, CommDType t, CommOp op);
+  void allgather_host(const void *send, void *recv, size_t bytes_per_rank);
+  // variable-size neighbour exchange of host byte strings; recv sizes are learnt
+  // through an all-gather of the size matrix
+  void exchange_host(const std::vector<int> &peers_send, const std::vector<std::vector<char>> &send,
+                     std::vector<int> &peers_recv, std::vector<std::vector<char>> &recv);
+  void barrier();
+};
+
+std::unique_ptr<Comm> make_self_comm();
+// RCCL communicator from a 128-byte ncclUniqueId (dlopen'ed librccl.so.1)
+std::unique_ptr<Comm> make_rccl_comm(const void *unique_id, int rank, int size);
+void rccl_get_unique_id(void *out128);
+
+// caller-supplied transport (tests: torch.distributed gloo through host staging)
+struct CommCallbacks {
+  void *ctx;
+  // all buffers are HOST pointers; the library stages device data itself
+  void (*allreduce)(void *ctx, void *buf, size_t count, int dtype, int op);
+  void (*allgather)(void *ctx, const void *send, void *recv, size_t bytes_per_rank);
+  void (*exchange)(void *ctx, int nsend, const int *send_peers, void *const *send_ptrs, const size_t *send_bytes,
+                   int nrecv, const int *recv_peers, void *const *recv_ptrs, const size_t *recv_bytes);
+};
+std::unique_ptr<Comm> make_callback_comm(const CommCallbacks &cb, int rank, int size);
+
+// ---------------------------------------------------------------- runtime context
+struct KernelTimer;  // profile.cpp
+
+struct Ctx {
+  bool inited = false;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::unique_ptr<Comm> comm;
+  // scratch for two-stage reductions
+  DVec<double> red_partials;  // MAX_RED_BLOCKS * MAX_RED_SLOTS
+  DVec<double> red_out;       // result slots (device scalars)
+  double *h_pinned = nullptr; // pinned host mirror of result slots
+  int gs_chunk = 8;
+  int verbose = 0;
+  KernelTimer *timer = nullptr;
+};
+Ctx &ctx();
+void ensure_init();
+
+// ---------------------------------------------------------------- small helpers
+void parallel_for(int64_t n, const std::function<void(int64_t, int64_t, int)> &fn, int max_threads = 0);
+int host_threads();
+double wall_time();
+
+}  // namespace mi

@@ -1,0 +1,73 @@
+// ParCSR matrix / ParVector objects: host structure, device mirror, halo plan.
+// Layout follows HYPRE's ParCSR model: a contiguous block-row
+// partition, diag block with local int32 columns, offd block with compressed
+// columns + sorted col_map_offd of global ids.
+#pragma once
+#include "mi_internal.hpp"
+
+namespace mi {
+
+struct ParVector {
+  gidx start = 0, end = 0;  // global range [start, end)
+  int n = 0;
+  int ncomp = 1, cur = 0;
+  DVec<double> d;  // ncomp * n, component-major
+  double *data() { return d.p + (size_t)cur * n; }
+  const double *data() const { return d.p + (size_t)cur * n; }
+  void init(gidx s, gidx e, int nc);
+};
+
+// neighbour exchange plan of one matrix (hypre_ParCSRCommPkg)
+struct HaloPlan {
+  std::vector<int> recv_peers, recv_starts;  // offsets into x_ext, size peers+1
+  std::vector<int> send_peers, send_starts;  // offsets into send_map
+  std::vector<int> send_map;                 // local row ids
+  DVec<int> d_send_map;
+  DVec<double> d_send_buf, d_xext;
+  int nsend() const { return (int)send_map.size(); }
+};
+
+struct ParCSR {
+  gidx row_start = 0, row_end = 0;  // [start, end)
+  int nrows = 0;
+  std::vector<gidx> row_starts;  // size+1 global partition (square matrices: also the column partition)
+  HostCSR diag, offd;
+  std::vector<gidx> col_map_offd;
+  HaloPlan halo;
+  DevCSR d_diag;
+  DevOffd d_offd;
+  DVec<double> d_offc;  // per-row halo contribution scratch (zero outside halo rows)
+  bool on_device = false;
+  gidx global_rows() const { return row_starts.empty() ? nrows : row_starts.back(); }
+
+  // build the halo plan from col_map_offd (collective) and mirror to the device
+  void finalize(Comm &comm);
+  // x_ext <- halo values of x (pack + neighbour exchange), enqueued on stream
+  void halo_exchange(Comm &comm, const double *x, hipStream_t s);
+  // host-side halo exchange of an arbitrary per-row int array (setup only)
+  std::vector<int> halo_exchange_host_int(Comm &comm, const std::vector<int> &local) const;
+  // y = alpha*A*x + beta*b
+  void matvec(Comm &comm, double alpha, const double *x, double beta, const double *b, double *y, hipStream_t s,
+              int prof = -1);
+  // offc[halo rows] = A_offd * x_ext(x)   (used by the smoothers)
+  const double *offd_contrib(Comm &comm, const double *x, hipStream_t s);
+};
+
+// global dot product: local two-stage reduction + one all-reduce; result stays on
+// the device in out_dev (the caller decides when to read it)
+void par_dot(Comm &comm, const double *x, const double *y, int n, double *out_dev, hipStream_t s);
+// blocking variant returning the value
+double par_dot_host(Comm &comm, const double *x, const double *y, int n, hipStream_t s);
+
+// IJ assembly: COO triples (global ids) -> ParCSR
+struct IJEntryBatch {
+  std::vector<gidx> rows, cols;
+  std::vector<double> vals;
+  bool add = false;
+};
+void assemble_parcsr(Comm &comm, gidx ilower, gidx iupper, gidx jlower, gidx jupper,
+                     std::vector<IJEntryBatch> &batches, ParCSR &out);
+
+bool is_device_pointer(const void *p);
+
+}  // namespace mi

@@ -1,0 +1,154 @@
+// Runtime context: device/stream ownership, scratch, device CSR upload,
+// event timers, the host thread helper.
+#include <chrono>
+#include <thread>
+
+#include "kernels.hpp"
+#include "mi_internal.hpp"
+#include "profile.hpp"
+
+namespace mi {
+
+static Ctx g_ctx;
+Ctx &ctx() { return g_ctx; }
+
+double wall_time() {
+  using namespace std::chrono;
+  return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+
+int host_threads() {
+  static int n = 0;
+  if (n == 0) {
+    const char *e = getenv("MI_HYPRE_HOST_THREADS");
+    n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    if (!e && n > 16) n = 16;  // one GPU's CPU share on the target nodes
+    if (n > 64) n = 64;
+  }
+  return n;
+}
+
+void parallel_for(int64_t n, const std::function<void(int64_t, int64_t, int)> &fn, int max_threads) {
+  int nt = host_threads();
+  if (max_threads > 0 && nt > max_threads) nt = max_threads;
+  if (n < 4096 || nt == 1) {
+    fn(0, n, 0);
+    return;
+  }
+  if (nt > n) nt = (int)n;
+  std::vector<std::thread> th;
+  std::vector<std::exception_ptr> errs((size_t)nt);
+  for (int t = 0; t < nt; t++) {
+    const int64_t b = n * t / nt, e = n * (t + 1) / nt;
+    th.emplace_back([&, b, e, t]() {
+      try {
+        fn(b, e, t);
+      } catch (...) {
+        errs[(size_t)t] = std::current_exception();
+      }
+    });
+  }
+  for (auto &x : th) x.join();
+  for (auto &e : errs)
+    if (e) std::rethrow_exception(e);
+}
+
+// The product path has no CPU fallback: without a HIP device every entry point
+// fails loudly here.
+void ensure_init() {
+  Ctx &c = g_ctx;
+  if (c.inited) return;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    fail(1, "mi_hypre: no HIP device available (this library has no CPU path; it needs an MI355X/gfx950 GPU)");
+  MI_HIP(hipGetDevice(&c.device));
+  MI_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  c.red_partials.alloc((size_t)k::RED_MAX_BLOCKS);
+  c.red_out.alloc(256);
+  MI_HIP(hipHostMalloc((void **)&c.h_pinned, 256 * sizeof(double), hipHostMallocDefault));
+  if (!c.comm) c.comm = make_self_comm();
+  const char *ch = getenv("MI_HYPRE_GS_CHUNK");
+  if (ch) c.gs_chunk = atoi(ch);
+  if (c.gs_chunk < 1) c.gs_chunk = 1;
+  if (c.gs_chunk > k::GS_MAX_CHUNK) c.gs_chunk = k::GS_MAX_CHUNK;
+  const char *vb = getenv("MI_HYPRE_VERBOSE");
+  if (vb) c.verbose = atoi(vb);
+  c.inited = true;
+}
+
+void DevCSR::upload(const HostCSR &h) {
+  nrows = h.nrows;
+  ncols = h.ncols;
+  nnz = h.nnz();
+  MI_REQUIRE(nnz < (int64_t)2147483000, "per-rank matrix block exceeds int32 row pointers");
+  std::vector<int> ia32((size_t)nrows + 1);
+  for (int i = 0; i <= nrows; i++) ia32[(size_t)i] = (int)h.ia[(size_t)i];
+  ia.upload(ia32);
+  ja.upload(h.ja);
+  a.upload(h.a);
+  std::vector<int> blocks = k::build_row_blocks(nrows, h.ia.data());
+  nblocks = (int)blocks.size() - 1;
+  rb.upload(blocks);
+}
+
+void DevOffd::upload(int nrows, const HostCSR &h) {
+  next = h.ncols;
+  std::vector<int> r, ia32;
+  ia32.push_back(0);
+  for (int i = 0; i < nrows; i++)
+    if (h.ia[(size_t)i + 1] > h.ia[(size_t)i]) {
+      r.push_back(i);
+      ia32.push_back((int)h.ia[(size_t)i + 1]);
+    }
+  nrows_c = (int)r.size();
+  nnz = h.nnz();
+  rows.upload(r);
+  ia.upload(ia32);
+  ja.upload(h.ja);
+  a.upload(h.a);
+}
+
+// ---------------------------------------------------------------- KernelTimer
+void KernelTimer::enable(int id, size_t capacity) {
+  if (id < 0 || id >= k::PROF_COUNT) return;
+  while (start[id].size() < capacity) {
+    hipEvent_t a, b;
+    MI_HIP(hipEventCreate(&a));
+    MI_HIP(hipEventCreate(&b));
+    start[id].push_back(a);
+    stop[id].push_back(b);
+  }
+  enabled[id] = true;
+  used[id] = 0;
+  dropped[id] = 0;
+}
+void KernelTimer::reset() {
+  for (int i = 0; i < k::PROF_COUNT; i++) used[i] = 0, dropped[i] = 0;
+}
+void KernelTimer::collect(int id, long long *count, double *total_ms, double *min_ms) {
+  *count = 0;
+  *total_ms = 0.0;
+  *min_ms = 0.0;
+  if (id < 0 || id >= k::PROF_COUNT) return;
+  MI_HIP(hipStreamSynchronize(ctx().stream));
+  double mn = 1e300;
+  for (size_t i = 0; i < used[id]; i++) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, start[id][i], stop[id][i]) == hipSuccess) {
+      *total_ms += ms;
+      (*count)++;
+      if (ms < mn) mn = ms;
+    }
+  }
+  if (*count) *min_ms = mn;
+}
+KernelTimer::~KernelTimer() {
+  for (int i = 0; i < k::PROF_COUNT; i++) {
+    for (auto e : start[i]) (void)hipEventDestroy(e);
+    for (auto e : stop[i]) (void)hipEventDestroy(e);
+  }
+}
+
+}  // namespace mi

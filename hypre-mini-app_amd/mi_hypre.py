@@ -1,0 +1,427 @@
+"""ctypes view of libmi_hypre.so for tests/ and bench.py.
+
+This is plumbing, not the product: the host side of the product is the C++
+driver in host/ (HypreSystem + main, mirroring /root/reference/src).  Everything
+here goes through the C ABI declared in include/*.h.  There is no fallback: if
+the shared library is missing, or no HIP device is present at HYPRE_Init, this
+raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi_hypre.so")
+
+HYPRE_PARCSR = 5555
+HYPRE_MEMORY_DEVICE = 1
+HYPRE_EXEC_DEVICE = 1
+HYPRE_ERROR_CONV = 256
+
+c_big = C.c_longlong
+c_int = C.c_int
+c_dbl = C.c_double
+vp = C.c_void_p
+
+PROF_SPMV_L0, PROF_RELAX_L0, PROF_DOT, PROF_AXPY = 0, 1, 2, 3
+
+ALLREDUCE_FN = C.CFUNCTYPE(None, vp, vp, C.c_size_t, c_int, c_int)
+ALLGATHER_FN = C.CFUNCTYPE(None, vp, vp, vp, C.c_size_t)
+EXCHANGE_FN = C.CFUNCTYPE(None, vp, c_int, C.POINTER(c_int), C.POINTER(vp), C.POINTER(C.c_size_t), c_int,
+                          C.POINTER(c_int), C.POINTER(vp), C.POINTER(C.c_size_t))
+
+
+class HypreError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (no compute happens here, so this works without a GPU)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HypreError(
+                f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
+                "(make -C hypre-mini-app_amd). There is no CPU fallback.")
+        _lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        _lib.HYPRE_MI_LastErrorMessage.restype = C.c_char_p
+        _lib.hypre_MAlloc.restype = vp
+        _lib.hypre_MAlloc.argtypes = [C.c_size_t, c_int]
+        _lib.hypre_Free.argtypes = [vp, c_int]
+        _lib.hypre_Memcpy.argtypes = [vp, vp, C.c_size_t, c_int, c_int]
+        _lib.HYPRE_MI_Free.argtypes = [vp]
+    return _lib
+
+
+def _conv(a):
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(vp)
+    if isinstance(a, float):
+        return c_dbl(a)
+    if isinstance(a, (int, np.integer)):
+        return a
+    return a
+
+
+def call(name, *args, allow=()):
+    """Call an ABI entry point; raise on a non-zero HYPRE_Int unless allowed."""
+    fn = getattr(lib(), name)
+    rc = fn(*[_conv(a) for a in args])
+    if rc != 0 and rc not in allow:
+        msg = lib().HYPRE_MI_LastErrorMessage()
+        raise HypreError(f"{name} returned {rc}: {msg.decode() if msg else ''}")
+    return rc
+
+
+def init():
+    call("HYPRE_Init")
+    call("HYPRE_SetMemoryLocation", HYPRE_MEMORY_DEVICE)
+    call("HYPRE_SetExecutionPolicy", HYPRE_EXEC_DEVICE)
+
+
+def finalize():
+    call("HYPRE_Finalize")
+
+
+def big(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def dbl(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def row_partition(total_rows, nproc, iproc):
+    """init_row_decomposition, /root/reference/src/HypreSystem.cpp:525-544 (inclusive bounds)."""
+    per, rem = divmod(total_rows, nproc)
+    ilower = per * iproc + min(iproc, rem)
+    iupper = per * (iproc + 1) + min(iproc + 1, rem) - 1
+    return ilower, iupper
+
+
+class IJMatrix:
+    def __init__(self, ilower, iupper, jlower=None, jupper=None):
+        jlower = ilower if jlower is None else jlower
+        jupper = iupper if jupper is None else jupper
+        self.h = vp()
+        self.ilower, self.iupper = ilower, iupper
+        call("HYPRE_IJMatrixCreate", 0, c_big(ilower), c_big(iupper), c_big(jlower), c_big(jupper), C.byref(self.h))
+        call("HYPRE_IJMatrixSetObjectType", self.h, HYPRE_PARCSR)
+        call("HYPRE_IJMatrixInitialize", self.h)
+        self.par = vp()
+        call("HYPRE_IJMatrixGetObject", self.h, C.byref(self.par))
+
+    def set_values_coo(self, rows, cols, vals, add=False):
+        """One entry per 'row', ncols == NULL -- the shape the driver uses (HypreSystem.cpp:942)."""
+        n = len(vals) if not isinstance(vals, int) else None
+        fn = "HYPRE_IJMatrixAddToValues2" if add else "HYPRE_IJMatrixSetValues2"
+        if isinstance(rows, np.ndarray):
+            rows, cols, vals = big(rows), big(cols), dbl(vals)
+            # HYPRE_Int nrows: split calls that would overflow int32
+            step = 1 << 30
+            for s in range(0, len(vals), step):
+                e = min(len(vals), s + step)
+                call(fn, self.h, e - s, None, rows[s:e], None, cols[s:e], vals[s:e])
+        else:
+            raise TypeError("numpy arrays expected")
+        return n
+
+    def set_values_ptr(self, n, rows_ptr, cols_ptr, vals_ptr, add=False):
+        fn = "HYPRE_IJMatrixAddToValues2" if add else "HYPRE_IJMatrixSetValues2"
+        step = 1 << 30
+        for s in range(0, n, step):
+            e = min(n, s + step)
+            call(fn, self.h, e - s, None, vp(rows_ptr + 8 * s), None, vp(cols_ptr + 8 * s), vp(vals_ptr + 8 * s))
+
+    def assemble(self):
+        call("HYPRE_IJMatrixAssemble", self.h)
+        call("HYPRE_IJMatrixGetObject", self.h, C.byref(self.par))
+
+    def destroy(self):
+        if self.h:
+            call("HYPRE_IJMatrixDestroy", self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class IJVector:
+    def __init__(self, jlower, jupper, values=None):
+        self.h = vp()
+        self.jlower, self.jupper = jlower, jupper
+        self.n = jupper - jlower + 1
+        call("HYPRE_IJVectorCreate", 0, c_big(jlower), c_big(jupper), C.byref(self.h))
+        call("HYPRE_IJVectorSetObjectType", self.h, HYPRE_PARCSR)
+        call("HYPRE_IJVectorInitialize", self.h)
+        self.par = vp()
+        call("HYPRE_IJVectorGetObject", self.h, C.byref(self.par))
+        if values is not None:
+            self.set(values)
+        call("HYPRE_IJVectorAssemble", self.h)
+
+    def set(self, values):
+        values = dbl(values)
+        idx = np.arange(self.jlower, self.jupper + 1, dtype=np.int64)
+        call("HYPRE_IJVectorSetValues", self.h, self.n, idx, values)
+
+    def fill(self, v):
+        call("HYPRE_ParVectorSetConstantValues", self.par, float(v))
+
+    def get(self):
+        out = np.empty(self.n)
+        if self.n:
+            call("HYPRE_IJVectorGetValues", self.h, self.n, None, out)
+        return out
+
+    def destroy(self):
+        if self.h:
+            call("HYPRE_IJVectorDestroy", self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+# YAML keys of boomeramg_settings with the app's defaults (HypreSystem.cpp:119-159)
+APP_AMG_DEFAULTS = dict(print_level=1, debug_flag=1, coarsen_type=8, cycle_type=1, relax_type=8, num_sweeps=1,
+                        smooth_num_sweeps=1, tolerance=0.0, max_iterations=1, relax_order=1, max_levels=20,
+                        strong_threshold=0.57)
+
+
+class BoomerAMG:
+    """setup_boomeramg_precond, /root/reference/src/HypreSystem.cpp:119-326, same YAML keys."""
+
+    def __init__(self, **node):
+        cfg = dict(APP_AMG_DEFAULTS)
+        cfg.update(node)
+        self.cfg = cfg
+        self.h = vp()
+        call("HYPRE_BoomerAMGCreate", C.byref(self.h))
+        s = self.h
+        call("HYPRE_BoomerAMGSetPrintLevel", s, cfg["print_level"])
+        call("HYPRE_BoomerAMGSetDebugFlag", s, cfg["debug_flag"])
+        call("HYPRE_BoomerAMGSetCoarsenType", s, cfg["coarsen_type"])
+        call("HYPRE_BoomerAMGSetCycleType", s, cfg["cycle_type"])
+        if all(k in cfg for k in ("down_relax_type", "up_relax_type", "coarse_relax_type")):
+            call("HYPRE_BoomerAMGSetCycleRelaxType", s, cfg["down_relax_type"], 1)
+            call("HYPRE_BoomerAMGSetCycleRelaxType", s, cfg["up_relax_type"], 2)
+            call("HYPRE_BoomerAMGSetCycleRelaxType", s, cfg["coarse_relax_type"], 3)
+        else:
+            call("HYPRE_BoomerAMGSetRelaxType", s, cfg["relax_type"])
+        if all(k in cfg for k in ("num_down_sweeps", "num_up_sweeps", "num_coarse_sweeps")):
+            call("HYPRE_BoomerAMGSetCycleNumSweeps", s, cfg["num_down_sweeps"], 1)
+            call("HYPRE_BoomerAMGSetCycleNumSweeps", s, cfg["num_up_sweeps"], 2)
+            call("HYPRE_BoomerAMGSetCycleNumSweeps", s, cfg["num_coarse_sweeps"], 3)
+        else:
+            call("HYPRE_BoomerAMGSetNumSweeps", s, cfg["num_sweeps"])
+        call("HYPRE_BoomerAMGSetSmoothNumSweeps", s, cfg["smooth_num_sweeps"])
+        call("HYPRE_BoomerAMGSetTol", s, float(cfg["tolerance"]))
+        call("HYPRE_BoomerAMGSetMaxIter", s, cfg["max_iterations"])
+        call("HYPRE_BoomerAMGSetRelaxOrder", s, cfg["relax_order"])
+        call("HYPRE_BoomerAMGSetMaxLevels", s, cfg["max_levels"])
+        call("HYPRE_BoomerAMGSetStrongThreshold", s, float(cfg["strong_threshold"]))
+        for key, fn, conv in (("interp_type", "HYPRE_BoomerAMGSetInterpType", int),
+                              ("min_coarse_size", "HYPRE_BoomerAMGSetMinCoarseSize", int),
+                              ("max_coarse_size", "HYPRE_BoomerAMGSetMaxCoarseSize", int),
+                              ("agg_num_levels", "HYPRE_BoomerAMGSetAggNumLevels", int),
+                              ("trunc_factor", "HYPRE_BoomerAMGSetTruncFactor", float),
+                              ("keep_transpose", "HYPRE_BoomerAMGSetKeepTranspose", int),
+                              ("rap2", "HYPRE_BoomerAMGSetRAP2", int),
+                              ("true_pmax_elmts", "HYPRE_BoomerAMGSetPMaxElmts", int)):
+            if key in cfg:
+                call(fn, s, conv(cfg[key]))
+
+    def setup(self, A):
+        call("HYPRE_BoomerAMGSetup", self.h, A.par, None, None)
+
+    def solve(self, A, b, x):
+        call("HYPRE_BoomerAMGSolve", self.h, A.par, b.par, x.par)
+
+    @property
+    def num_levels(self):
+        n = c_int()
+        call("HYPRE_MI_BoomerAMGGetNumLevels", self.h, C.byref(n))
+        return n.value
+
+    @property
+    def operator_complexity(self):
+        v = c_dbl()
+        call("HYPRE_MI_BoomerAMGGetOperatorComplexity", self.h, C.byref(v))
+        return v.value
+
+    @property
+    def setup_seconds(self):
+        v = c_dbl()
+        call("HYPRE_MI_BoomerAMGGetSetupSeconds", self.h, C.byref(v))
+        return v.value
+
+    def level_csr(self, level, which):
+        """which: 0 A diag, 1 A offd, 2 P, 3 R -> (ia int64, ja int32, a f64, shape)."""
+        nr, nc, nnz = c_int(), c_int(), c_big()
+        call("HYPRE_MI_BoomerAMGGetLevelCSRSize", self.h, level, which, C.byref(nr), C.byref(nc), C.byref(nnz))
+        ia = np.zeros(nr.value + 1, dtype=np.int64)
+        ja = np.zeros(max(nnz.value, 1), dtype=np.int32)
+        a = np.zeros(max(nnz.value, 1), dtype=np.float64)
+        call("HYPRE_MI_BoomerAMGGetLevelCSR", self.h, level, which, ia, ja, a)
+        return ia, ja[: nnz.value], a[: nnz.value], (nr.value, nc.value)
+
+    def level_cf(self, level):
+        nr, nc, nnz = c_int(), c_int(), c_big()
+        call("HYPRE_MI_BoomerAMGGetLevelCSRSize", self.h, level, 0, C.byref(nr), C.byref(nc), C.byref(nnz))
+        cf = np.zeros(nr.value, dtype=np.int32)
+        call("HYPRE_MI_BoomerAMGGetLevelCF", self.h, level, cf)
+        return cf
+
+    def level_colmap(self, level):
+        nr, nc, nnz = c_int(), c_int(), c_big()
+        call("HYPRE_MI_BoomerAMGGetLevelCSRSize", self.h, level, 1, C.byref(nr), C.byref(nc), C.byref(nnz))
+        cm = np.zeros(max(nc.value, 1), dtype=np.int64)
+        rs = c_big()
+        call("HYPRE_MI_BoomerAMGGetLevelColMap", self.h, level, cm, C.byref(rs))
+        return cm[: nc.value], rs.value
+
+    def relax_level(self, level, relax_type, points, f, u):
+        f = dbl(f)
+        u = np.array(u, dtype=np.float64)
+        call("HYPRE_MI_BoomerAMGRelaxLevel", self.h, level, relax_type, points, f, u)
+        return u
+
+    def destroy(self):
+        if self.h:
+            call("HYPRE_BoomerAMGDestroy", self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class _Krylov:
+    prefix = None
+
+    def __init__(self, tolerance=1e-5, max_iterations=1000, kspace=10, print_level=4):
+        """setup_gmres / setup_bicg, /root/reference/src/HypreSystem.cpp:390-404, :423-438 (same defaults)."""
+        self.h = vp()
+        call(f"{self.prefix}Create", 0, C.byref(self.h))
+        call(f"{self.prefix}SetTol", self.h, float(tolerance))
+        call(f"{self.prefix}SetMaxIter", self.h, int(max_iterations))
+        if self.prefix.endswith("GMRES"):
+            call(f"{self.prefix}SetKDim", self.h, int(kspace))
+        call(f"{self.prefix}SetPrintLevel", self.h, int(print_level))
+        self.precond = None
+
+    def set_precond(self, amg):
+        """solverPrecondPtr_(solver_, precondSolvePtr_, precondSetupPtr_, precond_), HypreSystem.cpp:687."""
+        L = lib()
+        call(f"{self.prefix}SetPrecond", self.h, C.cast(L.HYPRE_BoomerAMGSolve, vp), C.cast(L.HYPRE_BoomerAMGSetup, vp),
+             amg.h)
+        self.precond = amg
+
+    def setup(self, A, b, x):
+        call(f"{self.prefix}Setup", self.h, A.par, b.par, x.par)
+
+    def solve(self, A, b, x):
+        return call(f"{self.prefix}Solve", self.h, A.par, b.par, x.par, allow=(HYPRE_ERROR_CONV,))
+
+    @property
+    def num_iterations(self):
+        n = c_int()
+        call(f"{self.prefix}GetNumIterations", self.h, C.byref(n))
+        return n.value
+
+    @property
+    def final_rel_res(self):
+        v = c_dbl()
+        call(f"{self.prefix}GetFinalRelativeResidualNorm", self.h, C.byref(v))
+        return v.value
+
+    @property
+    def solve_seconds(self):
+        v = c_dbl()
+        call("HYPRE_MI_KrylovGetSolveSeconds", self.h, C.byref(v))
+        return v.value
+
+    def residual_history(self):
+        n = c_int()
+        buf = np.zeros(4096)
+        call("HYPRE_MI_KrylovGetResidualHistory", self.h, buf, len(buf), C.byref(n))
+        return buf[: min(n.value, len(buf))].copy()
+
+    def destroy(self):
+        if self.h:
+            call(f"{self.prefix}Destroy", self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class GMRES(_Krylov):
+    prefix = "HYPRE_ParCSRGMRES"
+
+
+class BiCGSTAB(_Krylov):
+    prefix = "HYPRE_ParCSRBiCGSTAB"
+
+
+def laplace3d(nx, ny, nz, stencil, ilower, iupper):
+    """Synthetic COO triples + rhs for global rows [ilower, iupper] (library-side generator)."""
+    nnz = c_big()
+    rows, cols, vals, rhs = vp(), vp(), vp(), vp()
+    call("HYPRE_MI_Laplace3D", nx, ny, nz, stencil, c_big(ilower), c_big(iupper), C.byref(nnz), C.byref(rows),
+         C.byref(cols), C.byref(vals), C.byref(rhs))
+    return dict(nnz=nnz.value, rows=rows.value, cols=cols.value, vals=vals.value, rhs=rhs.value,
+                nloc=iupper - ilower + 1)
+
+
+def laplace3d_free(g):
+    for k in ("rows", "cols", "vals", "rhs"):
+        if g.get(k):
+            lib().HYPRE_MI_Free(vp(g[k]))
+            g[k] = None
+
+
+def build_laplace_system(nx, ny, nz, stencil=7, rank=0, size=1):
+    """IJ matrix + rhs + zero x for this rank's block rows of the n^3 Laplacian."""
+    N = nx * ny * nz
+    ilower, iupper = row_partition(N, size, rank)
+    g = laplace3d(nx, ny, nz, stencil, ilower, iupper)
+    A = IJMatrix(ilower, iupper)
+    A.set_values_ptr(g["nnz"], g["rows"], g["cols"], g["vals"])
+    A.assemble()
+    rhs = np.ctypeslib.as_array(C.cast(g["rhs"], C.POINTER(c_dbl)), shape=(g["nloc"],)).copy()
+    laplace3d_free(g)
+    b = IJVector(ilower, iupper, rhs)
+    x = IJVector(ilower, iupper)
+    x.fill(0.0)
+    return A, b, x, rhs
+
+
+def profile_enable(pid, capacity=4096):
+    call("HYPRE_MI_ProfileEnable", pid, capacity)
+
+
+def profile_reset():
+    call("HYPRE_MI_ProfileReset")
+
+
+def profile_get(pid):
+    n, tot, mn = C.c_longlong(), c_dbl(), c_dbl()
+    call("HYPRE_MI_ProfileGet", pid, C.byref(n), C.byref(tot), C.byref(mn))
+    return n.value, tot.value, mn.value

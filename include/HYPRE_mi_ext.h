@@ -1,0 +1,78 @@
+/* HYPRE_mi_ext.h -- entry points that HYPRE does not have: rank/GPU binding over
+ * RCCL, hierarchy inspection for the parity tests, HIP-event kernel timing for
+ * bench.py's roofline figure, and the synthetic problem generator. */
+#ifndef HYPRE_MI_EXT_HEADER
+#define HYPRE_MI_EXT_HEADER
+#include "HYPRE_parcsr_ls.h"
+#include "HYPRE_IJ_mv.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- communicator (one rank per GPU).  Replaces the MPI_Comm that libHYPRE
+ * takes from src/main.cpp:33-35 / src/HypreSystem.cpp:12-13. */
+#define HYPRE_MI_UNIQUE_ID_BYTES 128
+HYPRE_Int HYPRE_MI_CommGetUniqueId(void *id128);               /* rank 0, then broadcast by the launcher */
+HYPRE_Int HYPRE_MI_CommInitRCCL(const void *id128, HYPRE_Int rank, HYPRE_Int size);
+/* host-staged transport supplied by the caller (tests: torch.distributed gloo) */
+typedef void (*HYPRE_MI_AllreduceFn)(void *ctx, void *buf, size_t count, int dtype /*0 f64,1 i64,2 i32,3 u8*/,
+                                     int op /*0 sum,1 min,2 max*/);
+typedef void (*HYPRE_MI_AllgatherFn)(void *ctx, const void *send, void *recv, size_t bytes_per_rank);
+typedef void (*HYPRE_MI_ExchangeFn)(void *ctx, int nsend, const int *send_peers, void *const *send_ptrs,
+                                    const size_t *send_bytes, int nrecv, const int *recv_peers, void *const *recv_ptrs,
+                                    const size_t *recv_bytes);
+HYPRE_Int HYPRE_MI_CommInitCallbacks(void *ctx, HYPRE_MI_AllreduceFn ar, HYPRE_MI_AllgatherFn ag,
+                                     HYPRE_MI_ExchangeFn ex, HYPRE_Int rank, HYPRE_Int size);
+HYPRE_Int HYPRE_MI_CommFinalize(void);
+HYPRE_Int HYPRE_MI_CommRank(HYPRE_Int *rank);
+HYPRE_Int HYPRE_MI_CommSize(HYPRE_Int *size);
+HYPRE_Int HYPRE_MI_CommBarrier(void);
+/* blocking all-reduce of a HOST buffer (loaders: src/HypreSystem.cpp:1166-1167, :829) */
+HYPRE_Int HYPRE_MI_CommAllreduce(void *buf, size_t count, int dtype, int op);
+
+/* ---- device / stream */
+HYPRE_Int HYPRE_MI_GetStream(void **hip_stream);
+HYPRE_Int HYPRE_MI_StreamSynchronize(void);
+HYPRE_Int HYPRE_MI_SetGSChunk(HYPRE_Int rows_per_chunk);   /* hybrid-GS "thread" size, default 8 */
+HYPRE_Int HYPRE_MI_GetGSChunk(HYPRE_Int *rows_per_chunk);
+
+/* ---- results the driver never asks HYPRE for */
+HYPRE_Int HYPRE_MI_KrylovGetResidualHistory(HYPRE_Solver solver, HYPRE_Real *norms, HYPRE_Int max_n, HYPRE_Int *n);
+HYPRE_Int HYPRE_MI_KrylovGetSolveSeconds(HYPRE_Solver solver, HYPRE_Real *seconds);
+
+/* ---- hierarchy inspection (parity tests; mirrors hypre_ParAMGDataAArray) */
+HYPRE_Int HYPRE_MI_BoomerAMGGetNumLevels(HYPRE_Solver solver, HYPRE_Int *num_levels);
+HYPRE_Int HYPRE_MI_BoomerAMGGetOperatorComplexity(HYPRE_Solver solver, HYPRE_Real *cx);
+HYPRE_Int HYPRE_MI_BoomerAMGGetSetupSeconds(HYPRE_Solver solver, HYPRE_Real *seconds);
+/* which: 0 A diag block, 1 A offd block, 2 P (local), 3 R (local) */
+HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSRSize(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int which, HYPRE_Int *nrows,
+                                            HYPRE_Int *ncols, HYPRE_BigInt *nnz);
+HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSR(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int which, HYPRE_BigInt *ia,
+                                        HYPRE_Int *ja, HYPRE_Complex *a);
+HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCF(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int *cf);
+HYPRE_Int HYPRE_MI_BoomerAMGGetLevelColMap(HYPRE_Solver solver, HYPRE_Int level, HYPRE_BigInt *col_map_offd,
+                                           HYPRE_BigInt *row_start);
+/* one relaxation call / one cycle on HOST arrays of the level's local length */
+HYPRE_Int HYPRE_MI_BoomerAMGRelaxLevel(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int relax_type, HYPRE_Int points,
+                                       const HYPRE_Real *f_host, HYPRE_Real *u_host);
+
+/* ---- HIP-event timing of kernel classes on the library stream.
+ * id: 0 level-0 SpMV, 1 level-0 relaxation, 2 dot, 3 axpy */
+HYPRE_Int HYPRE_MI_ProfileEnable(HYPRE_Int id, HYPRE_Int capacity);
+HYPRE_Int HYPRE_MI_ProfileReset(void);
+HYPRE_Int HYPRE_MI_ProfileGet(HYPRE_Int id, long long *launches, double *total_ms, double *min_ms);
+
+/* ---- synthetic problem: n^3-type Laplacian, true lexicographic global numbering
+ * (7-point: diag 6 / off -1; 27-point: diag 26 / off -1 as
+ * src/laplace_3d_weak_scaling.hpp:558,600; rhs = row sum, :321).  Fills COO
+ * triples for global rows [ilower, iupper]; buffers come from malloc and are
+ * released with HYPRE_MI_Free. */
+HYPRE_Int HYPRE_MI_Laplace3D(HYPRE_Int nx, HYPRE_Int ny, HYPRE_Int nz, HYPRE_Int stencil, HYPRE_BigInt ilower,
+                             HYPRE_BigInt iupper, HYPRE_BigInt *nnz, HYPRE_BigInt **rows, HYPRE_BigInt **cols,
+                             HYPRE_Complex **vals, HYPRE_Complex **rhs);
+void HYPRE_MI_Free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

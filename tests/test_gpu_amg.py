@@ -1,0 +1,185 @@
+"""Parity of the GMRES + BoomerAMG path (setup, relaxation, V-cycle, Krylov loop)
+against the CPU oracle on the same seeded inputs, through the C ABI.
+
+Tolerances (fp64):
+  * hierarchy: C/F splitting identical; P and the Galerkin operators agree to
+    1e-14 relative (the host setup follows the oracle's loop order);
+  * one relaxation call / one V-cycle: 1e-12 relative to max|u| (FMA contraction
+    and reduction order differ between the HIP kernels and the oracle);
+  * GMRES: same iteration count, residual history equal to 1e-8 relative per
+    step, final relative residual equal within 1e-10 (the north-star bar),
+    solution within the reference's own closeness rule rtol 1e-6 / atol 1e-8
+    (/root/reference/src/HypreSystem.cpp:815-818) of both the oracle and x* = 1.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _chunk(mi):
+    c = mi.c_int()
+    mi.call("HYPRE_MI_GetGSChunk", mi.C.byref(c))
+    return c.value
+
+
+def _setup(mi, oc, n, stencil=7, **amg_kw):
+    A, b, x, rhs = mi.build_laplace_system(n, n, n, stencil)
+    amg = mi.BoomerAMG(print_level=0, **amg_kw)
+    amg.setup(A)
+    Ao, bo = oc.Csr.laplace(n, n, n, stencil)
+    okw = dict(gs_chunk=_chunk(mi))
+    if "relax_type" in amg_kw:
+        okw["relax_type"] = amg_kw["relax_type"]
+    if "num_sweeps" in amg_kw:
+        okw["num_sweeps"] = amg_kw["num_sweeps"]
+    for k in ("interp_type", "relax_order", "max_coarse_size", "strong_threshold", "cycle_type", "max_levels"):
+        if k in amg_kw:
+            okw[k] = amg_kw[k]
+    oamg = oc.Amg(Ao, oc.default_params(**okw))
+    return A, b, x, amg, Ao, bo, oamg
+
+
+@pytest.mark.parametrize("n,stencil,interp", [(12, 7, 6), (20, 7, 6), (10, 27, 6), (16, 7, 3), (16, 7, 0)])
+def test_hierarchy_matches_oracle(mi, oc, n, stencil, interp):
+    A, b, x, amg, Ao, bo, oamg = _setup(mi, oc, n, stencil, interp_type=interp)
+    assert amg.num_levels == oamg.num_levels
+    for l in range(amg.num_levels):
+        ia, ja, a, shape = amg.level_csr(l, 0)
+        oia, oja, oa = oamg.level_A(l).arrays()
+        assert shape == oamg.level_A(l).shape
+        assert np.array_equal(ia, oia) and np.array_equal(ja, oja)
+        assert np.allclose(a, oa, rtol=1e-14, atol=1e-14)
+        if l < amg.num_levels - 1:
+            assert np.array_equal(amg.level_cf(l), oamg.level_cf(l))
+            pia, pja, pa, pshape = amg.level_csr(l, 2)
+            qia, qja, qa = oamg.level_P(l).arrays()
+            assert np.array_equal(pia, qia) and np.array_equal(pja, qja)
+            assert np.allclose(pa, qa, rtol=1e-14, atol=1e-14)
+
+
+@pytest.mark.parametrize("rtype", [0, 7, 18, 3, 4, 6, 8, 13, 14])
+@pytest.mark.parametrize("points", [0, 1, -1])
+def test_relax_matches_oracle(mi, oc, rtype, points):
+    A, b, x, amg, Ao, bo, oamg = _setup(mi, oc, 14)
+    rng = np.random.default_rng(100 + rtype)
+    for level in (0, 1):
+        nl = oamg.level_A(level).shape[0]
+        f, u0 = rng.standard_normal(nl), rng.standard_normal(nl)
+        got = amg.relax_level(level, rtype, points, f, u0)
+        ref = oamg.relax(level, rtype, points, f, u0)
+        assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+        if points != 0:
+            cf = oamg.level_cf(level)
+            assert np.array_equal(got[cf != points], u0[cf != points])
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(relax_type=18), dict(relax_type=6, num_sweeps=2, interp_type=0),
+                                dict(relax_order=0), dict(cycle_type=2), dict(max_coarse_size=200)])
+def test_vcycle_matches_oracle(mi, oc, kw):
+    A, b, x, amg, Ao, bo, oamg = _setup(mi, oc, 16, **kw)
+    rng = np.random.default_rng(7)
+    f = rng.standard_normal(16 ** 3)
+    fi = mi.IJVector(0, 16 ** 3 - 1, f)
+    ui = mi.IJVector(0, 16 ** 3 - 1, np.zeros(16 ** 3))
+    amg.solve(A, fi, ui)  # max_iterations 1, tolerance 0: exactly one cycle
+    got = ui.get()
+    ref = oamg.cycle(f)
+    assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+    # the cycle is a linear operator: M(a f) = a M(f)
+    fi2 = mi.IJVector(0, 16 ** 3 - 1, -2.5 * f)
+    ui2 = mi.IJVector(0, 16 ** 3 - 1, np.zeros(16 ** 3))
+    amg.solve(A, fi2, ui2)
+    assert np.abs(ui2.get() + 2.5 * got).max() <= 1e-12 * np.abs(got).max() * 2.5
+
+
+def _allclose_ref(x, xref, rtol=1e-6, atol=1e-8):
+    """check_solution's rule, /root/reference/src/HypreSystem.cpp:815-818."""
+    diff = np.abs(x - xref)
+    return np.all(diff < np.maximum(rtol * np.maximum(np.abs(x), np.abs(xref)), atol))
+
+
+@pytest.mark.parametrize("n,stencil,kdim,tol", [(16, 7, 50, 1e-8), (24, 7, 5, 1e-10), (12, 27, 50, 1e-8),
+                                                  (32, 7, 50, 1e-6)])
+def test_gmres_amg_matches_oracle(mi, oc, n, stencil, kdim, tol):
+    A, b, x, amg, Ao, bo, oamg = _setup(mi, oc, n, stencil)
+    gm = mi.GMRES(tolerance=tol, max_iterations=100, kspace=kdim, print_level=0)
+    gm.set_precond(amg)
+    gm.setup(A, b, x)
+    rc = gm.solve(A, b, x)
+    assert rc == 0
+    xo, info = oc.gmres(Ao, bo, kdim=kdim, tol=tol, maxit=100, amg=oamg)
+    assert gm.num_iterations == info["iters"]
+    hist = gm.residual_history()
+    assert len(hist) == len(info["norms"])
+    assert np.allclose(hist, info["norms"], rtol=1e-8, atol=0.0)
+    assert abs(gm.final_rel_res - info["rel_res"]) <= 1e-10
+    xs = x.get()
+    assert _allclose_ref(xs, xo)
+    assert _allclose_ref(xs, np.ones_like(xs), rtol=max(1e-6, 100 * tol))
+    # true residual of the device solution, computed by the oracle's SpMV
+    r = bo - Ao.matvec(xs)
+    assert np.linalg.norm(r) / np.linalg.norm(bo) <= tol * 1.0000001
+
+
+def test_gmres_no_precond_and_restart(mi, oc):
+    n = 10
+    A, b, x, rhs = mi.build_laplace_system(n, n, n, 7)
+    gm = mi.GMRES(tolerance=1e-9, max_iterations=200, kspace=7, print_level=0)
+    gm.setup(A, b, x)
+    gm.solve(A, b, x)
+    Ao, bo = oc.Csr.laplace(n, n, n, 7)
+    xo, info = oc.gmres(Ao, bo, kdim=7, tol=1e-9, maxit=200, amg=None)
+    assert gm.num_iterations == info["iters"]
+    assert np.allclose(gm.residual_history(), info["norms"], rtol=1e-7)
+    assert _allclose_ref(x.get(), xo)
+
+
+def test_gmres_maxiter_reports_conv_error(mi):
+    n = 12
+    A, b, x, rhs = mi.build_laplace_system(n, n, n, 7)
+    gm = mi.GMRES(tolerance=1e-14, max_iterations=3, kspace=50, print_level=0)
+    gm.setup(A, b, x)
+    assert gm.solve(A, b, x) == mi.HYPRE_ERROR_CONV
+    assert gm.num_iterations == 3
+    mi.call("HYPRE_ClearAllErrors")
+
+
+def test_bicgstab_amg_matches_oracle(mi, oc):
+    A, b, x, amg, Ao, bo, oamg = _setup(mi, oc, 16)
+    bi = mi.BiCGSTAB(tolerance=1e-8, max_iterations=50, print_level=0)
+    bi.set_precond(amg)
+    bi.setup(A, b, x)
+    assert bi.solve(A, b, x) == 0
+    xo, info = oc.bicgstab(Ao, bo, tol=1e-8, maxit=50, amg=oamg)
+    assert bi.num_iterations == info["iters"]
+    assert abs(bi.final_rel_res - info["rel_res"]) <= 1e-10
+    assert _allclose_ref(x.get(), xo)
+
+
+def test_against_direct_solve(mi):
+    """Independent known answer: scipy's sparse direct solve of a non-symmetric system."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+
+    rng = np.random.default_rng(42)
+    n = 3000
+    M = sp.random(n, n, density=0.002, random_state=rng, format="csr")
+    M = (M - sp.diags(M.diagonal())).tocsr()
+    M = (-abs(M) + sp.diags(abs(M).sum(axis=1).A1 + 0.5)).tocsr()
+    M.sort_indices()
+    xstar = rng.standard_normal(n)
+    rhs = M @ xstar
+    A = mi.IJMatrix(0, n - 1)
+    coo = M.tocoo()
+    A.set_values_coo(coo.row.astype(np.int64), coo.col.astype(np.int64), coo.data)
+    A.assemble()
+    b = mi.IJVector(0, n - 1, rhs)
+    x = mi.IJVector(0, n - 1, np.zeros(n))
+    amg = mi.BoomerAMG(print_level=0)
+    gm = mi.GMRES(tolerance=1e-12, max_iterations=200, kspace=50, print_level=0)
+    gm.set_precond(amg)
+    gm.setup(A, b, x)
+    assert gm.solve(A, b, x) == 0
+    xd = spl.spsolve(M.tocsc(), rhs)
+    assert np.abs(x.get() - xd).max() <= 1e-8 * np.abs(xd).max()

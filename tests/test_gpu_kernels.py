@@ -1,0 +1,129 @@
+"""Parity of the HIP kernels against the CPU oracle, through the C ABI.
+
+Tolerances: SpMV / BLAS-1 / relaxation results are sums of <= a few hundred
+fp64 products whose association differs between the wave/LDS reductions and the
+oracle's sequential loops, so they must agree to 1e-13 relative to the magnitude
+of the terms (stated per test).
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_dd_matrix(n, density, seed, longrow=None):
+    """Random diagonally dominant CSR with ragged rows (incl. empty off-diagonals)."""
+    rng = np.random.default_rng(seed)
+    M = sp.random(n, n, density=density, random_state=rng, format="lil")
+    if longrow is not None:
+        r, cnt = longrow
+        cols = rng.choice(n, size=cnt, replace=False)
+        for c in cols:
+            M[r, c] = rng.standard_normal()
+    M = M.tocsr()
+    M.setdiag(0.0)
+    M.eliminate_zeros()
+    d = np.abs(M).sum(axis=1).A1 + 1.0
+    M = (M + sp.diags(d)).tocsr()
+    M.sort_indices()
+    return M
+
+
+def _ij_from_scipy(mi, M):
+    n = M.shape[0]
+    A = mi.IJMatrix(0, n - 1)
+    coo = M.tocoo()
+    A.set_values_coo(coo.row.astype(np.int64), coo.col.astype(np.int64), coo.data)
+    A.assemble()
+    return A
+
+
+@pytest.mark.parametrize("n,density,longrow", [(1, 1.0, None), (7, 0.5, None), (1000, 0.01, None),
+                                                (5000, 0.002, (17, 3000)), (20000, 0.0005, None)])
+def test_spmv_vs_oracle(mi, oc, n, density, longrow):
+    M = _rand_dd_matrix(n, density, 1234 + n, longrow)
+    A = _ij_from_scipy(mi, M)
+    rng = np.random.default_rng(n)
+    xv, yv = rng.standard_normal(n), rng.standard_normal(n)
+    x = mi.IJVector(0, n - 1, xv)
+    y = mi.IJVector(0, n - 1, yv)
+    mi.call("HYPRE_ParCSRMatrixMatvec", -1.5, A.par, x.par, 0.75, y.par)
+    got = y.get()
+    Ao = oc.Csr.from_scipy(M)
+    ref = Ao.matvec(xv, alpha=-1.5, beta=0.75, b=yv)
+    scale = (abs(M) @ np.abs(xv)) * 1.5 + np.abs(yv)
+    assert np.all(np.abs(got - ref) <= 1e-13 * (scale + 1.0))
+
+
+def test_spmv_laplace_bitwise(mi, oc):
+    """Short rows take the one-lane-per-row reduction whose order equals the oracle's: bit-exact."""
+    n = 24
+    A, b, x, rhs = mi.build_laplace_system(n, n, n, 7)
+    Ao, bo = oc.Csr.laplace(n, n, n, 7)
+    assert np.array_equal(rhs, bo)
+    rng = np.random.default_rng(5)
+    xv = rng.standard_normal(n ** 3)
+    xi = mi.IJVector(0, n ** 3 - 1, xv)
+    yi = mi.IJVector(0, n ** 3 - 1, np.zeros(n ** 3))
+    mi.call("HYPRE_ParCSRMatrixMatvec", 1.0, A.par, xi.par, 0.0, yi.par)
+    assert np.array_equal(yi.get(), Ao.matvec(xv))
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 511, 100003])
+def test_blas1(mi, n):
+    rng = np.random.default_rng(n)
+    xv, yv = rng.standard_normal(n), rng.standard_normal(n)
+    x = mi.IJVector(0, n - 1, xv)
+    y = mi.IJVector(0, n - 1, yv)
+    prod = mi.c_dbl()
+    mi.call("HYPRE_ParVectorInnerProd", x.par, y.par, mi.C.byref(prod))
+    assert abs(prod.value - float(xv @ yv)) <= 1e-13 * float(np.abs(xv) @ np.abs(yv)) + 1e-300
+    mi.call("HYPRE_ParVectorAxpy", 0.3, x.par, y.par)
+    assert np.allclose(y.get(), yv + 0.3 * xv, rtol=1e-15, atol=1e-15)
+    mi.call("HYPRE_ParVectorScale", -2.0, y.par)
+    assert np.allclose(y.get(), -2.0 * (yv + 0.3 * xv), rtol=1e-15, atol=1e-15)
+    mi.call("HYPRE_ParVectorCopy", x.par, y.par)
+    assert np.array_equal(y.get(), xv)
+    y.fill(3.25)
+    assert np.all(y.get() == 3.25)
+
+
+def test_ij_set_add_semantics(mi):
+    """Set overwrites, AddTo accumulates, duplicates are folded in submission order."""
+    n = 6
+    A = mi.IJMatrix(0, n - 1)
+    rows = np.array([0, 0, 1, 5, 0], dtype=np.int64)
+    cols = np.array([0, 3, 1, 5, 0], dtype=np.int64)
+    vals = np.array([1.0, 2.0, 3.0, 4.0, 10.0])
+    A.set_values_coo(rows, cols, vals)                       # (0,0) set twice: last wins = 10
+    A.set_values_coo(np.array([0, 2], dtype=np.int64), np.array([3, 2], dtype=np.int64), np.array([5.0, 7.0]),
+                     add=True)                               # (0,3): 2 + 5
+    A.assemble()
+    dense = np.zeros((n, n))
+    for j in range(n):
+        e = np.zeros(n)
+        e[j] = 1.0
+        x = mi.IJVector(0, n - 1, e)
+        y = mi.IJVector(0, n - 1, np.zeros(n))
+        mi.call("HYPRE_ParCSRMatrixMatvec", 1.0, A.par, x.par, 0.0, y.par)
+        dense[:, j] = y.get()
+    want = np.zeros((n, n))
+    want[0, 0], want[0, 3], want[1, 1], want[5, 5], want[2, 2] = 10.0, 7.0, 3.0, 4.0, 7.0
+    assert np.array_equal(dense, want)
+
+
+def test_vector_get_set_indices(mi):
+    n = 50
+    v = mi.IJVector(10, 10 + n - 1, np.arange(n, dtype=float))
+    idx = np.array([10, 59, 33], dtype=np.int64)
+    out = np.zeros(3)
+    mi.call("HYPRE_IJVectorGetValues", v.h, 3, idx, out)
+    assert np.array_equal(out, [0.0, 49.0, 23.0])
+    mi.call("HYPRE_IJVectorAddToValues", v.h, 3, idx, np.array([1.0, 1.0, 1.0]))
+    mi.call("HYPRE_IJVectorGetValues", v.h, 3, idx, out)
+    assert np.array_equal(out, [1.0, 50.0, 24.0])
+    bad = np.array([9], dtype=np.int64)
+    with pytest.raises(mi.HypreError):
+        mi.call("HYPRE_IJVectorGetValues", v.h, 1, bad, out)
+    mi.call("HYPRE_ClearAllErrors")
