@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Solve-phase benchmark of the GMRES + BoomerAMG path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one HYPRE_ParCSRGMRESSolve call (x0 = 0 -> converged) on the
+synthetic laplace_3d problem, exactly the "Solve" timer of the reference driver
+(/root/reference/src/HypreSystem.cpp:715-727: barrier-fenced, setup excluded).
+The global grid is fixed (strong scaling): rank r owns the contiguous block of
+rows of init_row_decomposition (HypreSystem.cpp:525-544), i.e. z-slabs.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md:36
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=int(os.environ.get("MI_BENCH_N", "512")), help="grid points per side")
+    ap.add_argument("--stencil", type=int, default=7)
+    ap.add_argument("--tol", type=float, default=1e-8)
+    ap.add_argument("--kdim", type=int, default=50)
+    ap.add_argument("--max-iter", type=int, default=200)
+    ap.add_argument("--cpu-n", type=int, default=int(os.environ.get("MI_BENCH_CPU_N", "128")),
+                    help="grid side of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, chunk):
+    """Oracle (CPU restatement of the HYPRE algorithm; libHYPRE is not available offline)
+    timed on this host on a bounded sample of the same workload."""
+    oc = ge.load_oracle()
+    n = args.cpu_n
+    cores = min(os.cpu_count() or 1, 16)
+    oc.lib().oracle_set_threads(cores)
+    A, b = oc.Csr.laplace(n, n, n, args.stencil)
+    t0 = time.time()
+    amg = oc.Amg(A, oc.default_params(gs_chunk=chunk))
+    t_setup = time.time() - t0
+    t0 = time.time()
+    x, info = oc.gmres(A, b, kdim=args.kdim, tol=args.tol, maxit=args.max_iter, amg=amg)
+    t_solve = time.time() - t0
+    ndof = n ** 3
+    return {
+        "value": ndof * info["iters"] / t_solve / 1e9,
+        "unit": "GDOF/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"laplace_3d {n}^3 {args.stencil}-pt, GMRES({args.kdim})+AMG tol {args.tol:g}: "
+                  f"{info['iters']} iterations in {t_solve:.2f} s solve (+{t_setup:.2f} s setup, 1 thread), "
+                  f"rel res {info['rel_res']:.2e}; HYPRE-algorithm CPU restatement (oracle/), OpenMP {cores} threads",
+        "iterations": info["iters"],
+        "iterations_per_s": info["iters"] / t_solve,
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+
+        dist = dist_
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    mi = ge.load_binding()
+    mi.init()
+    if world > 1:
+        # ncclUniqueId from rank 0 to everyone, then the library opens its own RCCL communicator
+        idbuf = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            raw = (C.c_ubyte * 128)()
+            mi.call("HYPRE_MI_CommGetUniqueId", raw)
+            idbuf = torch.tensor(list(raw), dtype=torch.uint8)
+        idbuf = idbuf.cuda()
+        dist.broadcast(idbuf, src=0)
+        raw = (C.c_ubyte * 128)(*idbuf.cpu().tolist())
+        mi.call("HYPRE_MI_CommInitRCCL", raw, rank, world)
+
+    n = args.n
+    ndof = n ** 3
+    t0 = time.time()
+    A, b, x, _ = mi.build_laplace_system(n, n, n, args.stencil, rank, world)
+    t_build = time.time() - t0
+    amg = mi.BoomerAMG(print_level=1 if (rank == 0 and os.environ.get("MI_BENCH_VERBOSE")) else 0)
+    gm = mi.GMRES(tolerance=args.tol, max_iterations=args.max_iter, kspace=args.kdim, print_level=0)
+    gm.set_precond(amg)
+    t0 = time.time()
+    gm.setup(A, b, x)  # "Preconditioner setup" timer of the reference (HypreSystem.cpp:685-696)
+    t_setup = time.time() - t0
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        mi.call("HYPRE_MI_StreamSynchronize")
+
+    def one_solve():
+        x.fill(0.0)  # x0 = 0 (HypreSystem.cpp:580)
+        gm.solve(A, b, x)
+        return gm.num_iterations
+
+    for _ in range(args.warmup):
+        one_solve()
+    cap = 8192
+    mi.profile_enable(mi.PROF_SPMV_L0, cap)
+    mi.profile_enable(mi.PROF_RELAX_L0, cap)
+    barrier()
+    t0 = time.perf_counter()
+    iters_total = 0
+    for _ in range(args.steps):
+        iters_total += one_solve()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    spmv_n, spmv_ms, spmv_min = mi.profile_get(mi.PROF_SPMV_L0)
+    rel_n, rel_ms, rel_min = mi.profile_get(mi.PROF_RELAX_L0)
+    rel_res = gm.final_rel_res
+    iters = gm.num_iterations
+    xs = x.get()
+    err = float(np.abs(xs - 1.0).max()) if xs.size else 0.0
+    nlev = amg.num_levels
+    opcx = amg.operator_complexity
+
+    # algorithmic bytes of one level-0 launch on this rank (DESIGN.md "Kernels")
+    ia, ja, av, shape = (None, None, None, None)
+    nr, nc, nnz = C.c_int(), C.c_int(), C.c_longlong()
+    mi.call("HYPRE_MI_BoomerAMGGetLevelCSRSize", amg.h, 0, 0, C.byref(nr), C.byref(nc), C.byref(nnz))
+    nloc, nnz_loc = nr.value, nnz.value
+    spmv_bytes = 12.0 * nnz_loc + 20.0 * nloc
+    # one relaxation launch updates the C or the F half: the selected rows' entries once
+    # (forward+backward sweep out of one read), u_old in, u_new out, f and divisor of the
+    # selected rows, the C/F marker
+    relax_bytes = 12.0 * nnz_loc / 2 + 16.0 * nloc + 16.0 * nloc / 2 + nloc
+
+    out = None
+    if rank == 0:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                key = f"{n}^3/{args.stencil}pt/{world}gpu"
+                traffic = tj.get(key, {}).get("spmv_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = None
+        if spmv_n:
+            a = spmv_bytes / (spmv_ms / spmv_n * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "spmv_stream<0> (level-0 CSR SpMV, diag block)", "achieved": a,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": traffic,
+                    "launches": spmv_n, "avg_ms": spmv_ms / spmv_n, "min_ms": spmv_min,
+                    "algorithmic_bytes_per_launch": spmv_bytes}
+        roof_relax = None
+        if rel_n:
+            a = relax_bytes / (rel_ms / rel_n * 1e-3) / 1e9
+            roof_relax = {"bound": "hbm", "kernel": "gs_hybrid_k (level-0 l1 hybrid symmetric GS, one C or F pass)",
+                          "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
+                          "launches": rel_n, "avg_ms": rel_ms / rel_n, "min_ms": rel_min,
+                          "algorithmic_bytes_per_launch": relax_bytes}
+        chunk = C.c_int()
+        mi.call("HYPRE_MI_GetGSChunk", C.byref(chunk))
+        out = {
+            "metric": "GMRES+AMG solve GDOF/s (N_global * iterations / t_solve)",
+            "value": ndof * iters_total / elapsed / 1e9,
+            "unit": "GDOF/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"laplace_3d {n}^3 {args.stencil}-pt (N={ndof}), GMRES({args.kdim})+BoomerAMG "
+                            f"(PMIS, ext+i, C/F l1-hybrid-SGS chunk {chunk.value}, V(1,1)), tol {args.tol:g}, x0=0",
+                "row_partition": f"{world} contiguous block-row slab(s)",
+            },
+            "iterations_per_solve": iters,
+            "iterations_per_s": iters_total / elapsed,
+            "final_rel_residual": rel_res,
+            "max_abs_error_vs_ones": err,
+            "amg_levels": nlev,
+            "operator_complexity": opcx,
+            "setup_s": t_setup,
+            "build_s": t_build,
+            "roofline": roof,
+            "roofline_relax": roof_relax,
+        }
+        if not args.no_cpu and args.cpu_n > 0:
+            out["cpu_baseline"] = cpu_baseline(args, chunk.value)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        mi.call("HYPRE_MI_CommFinalize")
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

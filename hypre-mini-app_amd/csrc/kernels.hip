@@ -178,6 +178,136 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_hybrid_k(int n, int nchunks, int 
 }
 
 // ---------------------------------------------------------------------------
+// Hybrid Gauss-Seidel, cooperative form (the one that runs when chunk == 8).
+// A group of LPC lanes (8/16/32/64, chosen from the level's mean row length)
+// owns one chunk of R = 8 consecutive rows; a wave holds 64/LPC chunks, so for
+// the 7-point fine level the wave's 64 lanes read 64 consecutive rows' entries.
+//   phase A  every row of the chunk is loaded up front: lane g takes entries
+//            g, g+LPC, ... of each row (adjacent lanes -> adjacent addresses),
+//            and gathers u_old for the columns outside the chunk.  Nothing in
+//            this phase depends on the sweep, so all loads are in flight at once.
+//   phase B  the 8 rows are swept in order (forward and/or backward).  The
+//            chunk's running values live one per lane (lane g holds row g) and
+//            are read with __shfl; the row's dot product is a __shfl_xor
+//            butterfly over the group.
+// u_old is never written, so the result does not depend on scheduling.
+// ---------------------------------------------------------------------------
+template <int LPC>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+  for (int m = LPC >> 1; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+template <int LPC, int E>
+__global__ __launch_bounds__(256) void gs_group_k(int n, int nchunks, const int *__restrict__ ia,
+                                                  const int *__restrict__ ja, const double *__restrict__ av,
+                                                  const signed char *__restrict__ cf, int points,
+                                                  const double *__restrict__ dd, const double *__restrict__ f,
+                                                  const double *__restrict__ offc,
+                                                  const double *__restrict__ u_old, double *__restrict__ u_new,
+                                                  int fwd, int bwd, double w) {
+  constexpr int R = 8;
+  constexpr int CPW = 64 / LPC;
+  const int lane = threadIdx.x & 63;
+  const int g = lane & (LPC - 1);
+  const int gbase = lane & ~(LPC - 1);
+  const long long wave = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const long long c = wave * CPW + (lane / LPC);
+  const bool live = c < nchunks;
+  const int cs = live ? (int)(c * R) : 0;
+  const int len = live ? min(R, n - cs) : 0;
+
+  // owner lane g < len holds the state of row cs+g
+  double myu = 0.0, myrhs = 0.0, myd = 0.0;
+  bool mysel = false;
+  if (g < len) {
+    const int i = cs + g;
+    myu = u_old[i];
+    myd = dd[i];
+    mysel = (points == 0 || cf == nullptr || cf[i] == points) && myd != 0.0;
+    if (mysel) {
+      myrhs = f[i];
+      if (offc) myrhs -= offc[i];
+    }
+  }
+  // phase A
+  double val[R][E], uo[R][E];
+  int off[R][E];
+  unsigned longmask = 0;
+#pragma unroll
+  for (int t = 0; t < R; t++) {
+    bool sel = false;
+    int k0 = 0, k1 = 0;
+    if (t < len) {
+      const int i = cs + t;
+      sel = (points == 0 || cf == nullptr || cf[i] == points);
+      if (sel) {
+        k0 = ia[i];
+        k1 = ia[i + 1];
+      }
+    }
+    if (k1 - k0 > LPC * E) longmask |= 1u << t;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int k = k0 + g + e * LPC;
+      double v = 0.0, x = 0.0;
+      int o = -1;
+      if (k < k1) {
+        v = av[k];
+        const int j = ja[k];
+        const unsigned oo = (unsigned)(j - cs);
+        if (oo < (unsigned)len)
+          o = (int)oo;
+        else
+          x = u_old[j];
+      }
+      val[t][e] = v;
+      uo[t][e] = x;
+      off[t][e] = o;
+    }
+  }
+  // phase B
+#pragma unroll
+  for (int dir = 0; dir < 2; dir++) {
+    if (dir == 0 ? !fwd : !bwd) continue;
+#pragma unroll
+    for (int tt = 0; tt < R; tt++) {
+      const int t = (dir == 0) ? tt : R - 1 - tt;
+      double part = 0.0;
+#pragma unroll
+      for (int e = 0; e < E; e++) {
+        const int o = off[t][e];
+        const double cur = __shfl(myu, gbase + (o < 0 ? 0 : o), 64);
+        part += val[t][e] * (o < 0 ? uo[t][e] : cur);
+      }
+      if (longmask & (1u << t)) {  // entries beyond the preloaded strip (group-uniform branch)
+        const int i = cs + t;
+        const int k1 = ia[i + 1];
+        for (int k = ia[i] + LPC * E + g; k - g < k1; k += LPC) {
+          double v = 0.0, x = 0.0;
+          int o = -1;
+          if (k < k1) {
+            v = av[k];
+            const int j = ja[k];
+            const unsigned oo = (unsigned)(j - cs);
+            if (oo < (unsigned)len)
+              o = (int)oo;
+            else
+              x = u_old[j];
+          }
+          const double cur = __shfl(myu, gbase + (o < 0 ? 0 : o), 64);
+          part += v * (o < 0 ? x : cur);
+        }
+      }
+      const double sum = group_sum<LPC>(part);
+      if (g == t && mysel) myu += w * (myrhs - sum) / myd;
+    }
+  }
+  if (g < len) u_new[cs + g] = myu;
+}
+
+// ---------------------------------------------------------------------------
 // BLAS-1
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dot_partial_k(const double *__restrict__ x, const double *__restrict__ y, int n,
@@ -311,6 +441,15 @@ std::vector<int> build_row_blocks(int nrows, const int64_t *ia) {
   return rb;
 }
 
+static bool gs_force_generic() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("MI_HYPRE_GS_GENERIC");
+    v = (e && atoi(e)) ? 1 : 0;
+  }
+  return v == 1;
+}
+
 static void launch_stream(int epi, const DevCSR &A, const double *x, double *y, const EpiArgs &e, hipStream_t s) {
   if (A.nrows == 0) return;
   const int nb = A.nblocks;
@@ -367,11 +506,33 @@ void gs_hybrid(const DevCSR &A, const double *u_old, double *u_new, const double
   if (A.nrows == 0) return;
   MI_REQUIRE(chunk >= 1 && chunk <= GS_MAX_CHUNK, "hybrid GS chunk out of range");
   const long long nchunks = ((long long)A.nrows + chunk - 1) / chunk;
-  const size_t lds = (size_t)chunk * GS_BLOCK * sizeof(double);
   prof_begin(prof, s);
-  hipLaunchKernelGGL(gs_hybrid_k, dim3((unsigned)((nchunks + GS_BLOCK - 1) / GS_BLOCK)), dim3(GS_BLOCK), lds, s,
-                     A.nrows, (int)nchunks, chunk, A.ia.p, A.ja.p, A.a.p, cf, points, d, f, offc, u_old, u_new,
-                     fwd ? 1 : 0, bwd ? 1 : 0, w);
+  if (chunk == 8 && !gs_force_generic()) {
+    const double avg = (double)A.nnz / (double)A.nrows;
+#define GS_LAUNCH(LPC, E)                                                                                         \
+  {                                                                                                               \
+    const long long waves = (nchunks + (64 / LPC) - 1) / (64 / LPC);                                              \
+    hipLaunchKernelGGL((gs_group_k<LPC, E>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, A.nrows,         \
+                       (int)nchunks, A.ia.p, A.ja.p, A.a.p, cf, points, d, f, offc, u_old, u_new, fwd ? 1 : 0,     \
+                       bwd ? 1 : 0, w);                                                                           \
+  }
+    if (avg <= 8.0)
+      GS_LAUNCH(8, 1)
+    else if (avg <= 16.0)
+      GS_LAUNCH(16, 1)
+    else if (avg <= 32.0)
+      GS_LAUNCH(32, 1)
+    else if (avg <= 64.0)
+      GS_LAUNCH(64, 1)
+    else
+      GS_LAUNCH(64, 2)
+#undef GS_LAUNCH
+  } else {
+    const size_t lds = (size_t)chunk * GS_BLOCK * sizeof(double);
+    hipLaunchKernelGGL(gs_hybrid_k, dim3((unsigned)((nchunks + GS_BLOCK - 1) / GS_BLOCK)), dim3(GS_BLOCK), lds, s,
+                       A.nrows, (int)nchunks, chunk, A.ia.p, A.ja.p, A.a.p, cf, points, d, f, offc, u_old, u_new,
+                       fwd ? 1 : 0, bwd ? 1 : 0, w);
+  }
   MI_HIP(hipGetLastError());
   prof_end(prof, s);
 }

@@ -74,6 +74,58 @@ def test_relax_matches_oracle(mi, oc, rtype, points):
             assert np.array_equal(got[cf != points], u0[cf != points])
 
 
+@pytest.mark.parametrize("density,longrow", [(0.004, None), (0.02, None), (0.05, (40, 1500)), (0.12, None)])
+def test_relax_irregular_rows(mi, oc, density, longrow):
+    """Ragged / long rows: every lanes-per-chunk variant of the cooperative GS kernel and its
+    beyond-the-strip path, plus the Jacobi epilogue, against the oracle on level 0."""
+    import scipy.sparse as sp
+
+    n = 2000
+    rng = np.random.default_rng(int(density * 1000))
+    M = sp.random(n, n, density=density, random_state=rng, format="lil")
+    if longrow:
+        for c in rng.choice(n, size=longrow[1], replace=False):
+            M[longrow[0], c] = rng.standard_normal()
+    M = M.tocsr()
+    M.setdiag(0.0)
+    M.eliminate_zeros()
+    M = -abs(M)  # M-matrix: negative couplings, weakly dominant diagonal
+    M = (M + sp.diags(np.abs(M).sum(axis=1).A1 * 1.01 + 1e-3)).tocsr()
+    M.sort_indices()
+    A = mi.IJMatrix(0, n - 1)
+    coo = M.tocoo()
+    A.set_values_coo(coo.row.astype(np.int64), coo.col.astype(np.int64), coo.data)
+    A.assemble()
+    amg = mi.BoomerAMG(print_level=0)
+    amg.setup(A)
+    oamg = oc.Amg(oc.Csr.from_scipy(M), oc.default_params(gs_chunk=_chunk(mi)))
+    assert amg.num_levels == oamg.num_levels and amg.num_levels > 1
+    assert np.array_equal(amg.level_cf(0), oamg.level_cf(0))
+    f, u0 = rng.standard_normal(n), rng.standard_normal(n)
+    for rtype in (8, 3, 14, 18):
+        for points in (0, 1, -1):
+            got = amg.relax_level(0, rtype, points, f, u0)
+            ref = oamg.relax(0, rtype, points, f, u0)
+            assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("chunk", [1, 4, 16])
+def test_relax_other_chunk_sizes(mi, oc, chunk):
+    """Chunk sizes other than 8 take the generic lane-per-chunk kernel."""
+    old = _chunk(mi)
+    mi.call("HYPRE_MI_SetGSChunk", chunk)
+    try:
+        A, b, x, amg, Ao, bo, oamg = _setup(mi, oc, 12)
+        rng = np.random.default_rng(chunk)
+        f, u0 = rng.standard_normal(12 ** 3), rng.standard_normal(12 ** 3)
+        for points in (0, 1, -1):
+            got = amg.relax_level(0, 8, points, f, u0)
+            ref = oamg.relax(0, 8, points, f, u0)
+            assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    finally:
+        mi.call("HYPRE_MI_SetGSChunk", old)
+
+
 @pytest.mark.parametrize("kw", [dict(), dict(relax_type=18), dict(relax_type=6, num_sweeps=2, interp_type=0),
                                 dict(relax_order=0), dict(cycle_type=2), dict(max_coarse_size=200)])
 def test_vcycle_matches_oracle(mi, oc, kw):
