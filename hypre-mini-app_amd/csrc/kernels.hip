@@ -221,50 +221,53 @@ __global__ __launch_bounds__(256) void gs_group_k(int n, int nchunks, const int 
   // owner lane g < len holds the state of row cs+g
   double myu = 0.0, myrhs = 0.0, myd = 0.0;
   bool mysel = false;
+  int my_k0 = 0, my_k1 = 0;
   if (g < len) {
     const int i = cs + g;
+    my_k0 = ia[i];
+    const int a1 = ia[i + 1];
+    const int mark = (points != 0 && cf != nullptr) ? (int)cf[i] : points;
     myu = u_old[i];
     myd = dd[i];
-    mysel = (points == 0 || cf == nullptr || cf[i] == points) && myd != 0.0;
-    if (mysel) {
-      myrhs = f[i];
-      if (offc) myrhs -= offc[i];
-    }
+    myrhs = f[i];
+    if (offc) myrhs -= offc[i];
+    const bool rowsel = (mark == points);
+    my_k1 = rowsel ? a1 : my_k0;  // unselected rows load nothing
+    mysel = rowsel && myd != 0.0;
   }
-  // phase A
+  // phase A: three waves of independent loads (row pointers+marker, entries,
+  // gathers); no load waits on a branch
   double val[R][E], uo[R][E];
   int off[R][E];
+  int k0s[R], k1s[R];
   unsigned longmask = 0;
 #pragma unroll
   for (int t = 0; t < R; t++) {
-    bool sel = false;
-    int k0 = 0, k1 = 0;
-    if (t < len) {
-      const int i = cs + t;
-      sel = (points == 0 || cf == nullptr || cf[i] == points);
-      if (sel) {
-        k0 = ia[i];
-        k1 = ia[i + 1];
-      }
-    }
-    if (k1 - k0 > LPC * E) longmask |= 1u << t;
+    // row pointers travel from the owner lane by shuffle: one load round trip for all 8 rows
+    k0s[t] = __shfl(my_k0, gbase + t, 64);
+    k1s[t] = __shfl(my_k1, gbase + t, 64);
+  }
+  int cols[R][E];
+#pragma unroll
+  for (int t = 0; t < R; t++) {
+    if (k1s[t] - k0s[t] > LPC * E) longmask |= 1u << t;
 #pragma unroll
     for (int e = 0; e < E; e++) {
-      const int k = k0 + g + e * LPC;
-      double v = 0.0, x = 0.0;
-      int o = -1;
-      if (k < k1) {
-        v = av[k];
-        const int j = ja[k];
-        const unsigned oo = (unsigned)(j - cs);
-        if (oo < (unsigned)len)
-          o = (int)oo;
-        else
-          x = u_old[j];
-      }
-      val[t][e] = v;
-      uo[t][e] = x;
-      off[t][e] = o;
+      const int k = k0s[t] + g + e * LPC;
+      const bool ok = k < k1s[t];
+      val[t][e] = ok ? av[k] : 0.0;
+      cols[t][e] = ok ? ja[k] : cs;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < R; t++) {
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int j = cols[t][e];
+      const unsigned oo = (unsigned)(j - cs);
+      const bool inch = oo < (unsigned)len;
+      off[t][e] = inch ? (int)oo : -1;
+      uo[t][e] = u_old[j];  // unconditional: in-chunk values are simply not used
     }
   }
   // phase B
