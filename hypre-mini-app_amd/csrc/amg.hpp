@@ -41,6 +41,7 @@ struct AmgLevel {
   DVec<double> d_diag, d_l1gs, d_l1jac;
   DVec<double> u, f, tmp, snap;
   // coarsest level dense solve (relax type 9)
+  std::vector<double> Cinv_host;
   DVec<double> Cinv;    // n_local x (size*slot) padded inverse rows
   DVec<double> fgather; // size*slot
   DVec<double> fslot;   // slot
@@ -51,13 +52,21 @@ struct AmgLevel {
 struct BoomerAMG {
   AmgParams p;
   std::vector<AmgLevel> L;
-  bool is_setup = false;
+  bool is_setup = false, host_ready = false;
+  double t_setup_start = 0.0;
   int num_iterations = 0;
   double final_rel_res = 0.0;
   double setup_seconds = 0.0;
   int chunk() const;
 
-  void setup(ParCSR &A);
+  void setup(ParCSR &A) {
+    setup_host(A);
+    setup_device();
+  }
+  // hierarchy construction: host only (threads + host collectives)
+  void setup_host(ParCSR &A);
+  // device mirror of the hierarchy (needs a GPU)
+  void setup_device();
   // HYPRE_BoomerAMGSolve: x is the initial guess; up to max_iter cycles
   void solve(ParCSR &A, ParVector &b, ParVector &x);
 

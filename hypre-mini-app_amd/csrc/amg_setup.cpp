@@ -520,15 +520,15 @@ double BoomerAMG::operator_complexity() const {
   return base > 0 ? tot / base : 0.0;
 }
 
-void BoomerAMG::setup(ParCSR &A0) {
-  ensure_init();
-  Comm &comm = *ctx().comm;
-  const double t0 = wall_time();
+void BoomerAMG::setup_host(ParCSR &A0) {
+  Comm &comm = current_comm();
+  t_setup_start = wall_time();
+  is_setup = false;
   L.clear();
   L.reserve((size_t)std::max(1, p.max_levels));
   L.emplace_back();
   L[0].A = &A0;
-  MI_REQUIRE(A0.on_device, "BoomerAMGSetup: matrix is not assembled");
+  MI_REQUIRE(!A0.row_starts.empty(), "BoomerAMGSetup: matrix is not assembled");
   if (p.print_level > 0 && comm.rank == 0 && p.coarsen_type != 8 && p.coarsen_type != 10)
     printf("mi_hypre BoomerAMG: coarsen_type %d is not restated; using PMIS (8)\n", p.coarsen_type);
 
@@ -716,14 +716,14 @@ void BoomerAMG::setup(ParCSR &A0) {
       On.ncols = (int)cm.size();
       An->col_map_offd = cm;
     }
-    An->finalize(comm);
+    An->build_halo_plan(comm);
     L.emplace_back();
     L[(size_t)l + 1].A_own = std::move(An);
     L[(size_t)l + 1].A = L[(size_t)l + 1].A_own.get();
     l++;
   }
 
-  // per-level device data
+  // per-level norms (host)
   const int ch = chunk();
   for (size_t li = 0; li < L.size(); li++) {
     AmgLevel &Lv = L[li];
@@ -732,26 +732,6 @@ void BoomerAMG::setup(ParCSR &A0) {
     std::vector<int> cf_ext;
     if (!Lv.cf.empty()) cf_ext = A.halo_exchange_host_int(comm, Lv.cf);
     level_norms(A, Lv.cf, cf_ext, ch, Lv.diag, Lv.l1gs, Lv.l1jac);
-    Lv.d_diag.upload(Lv.diag);
-    Lv.d_l1gs.upload(Lv.l1gs);
-    Lv.d_l1jac.upload(Lv.l1jac);
-    if (!Lv.cf.empty()) {
-      std::vector<signed char> c8(Lv.cf.size());
-      for (size_t i = 0; i < c8.size(); i++) c8[i] = (signed char)Lv.cf[i];
-      Lv.d_cf.upload(c8);
-      Lv.dP.upload(Lv.P);
-      Lv.dR.upload(Lv.R);
-    }
-    Lv.u.alloc((size_t)Lv.n);
-    Lv.f.alloc((size_t)Lv.n);
-    Lv.tmp.alloc((size_t)Lv.n);
-    Lv.snap.alloc((size_t)Lv.n);
-    if (Lv.n) {
-      MI_HIP(hipMemset(Lv.u.p, 0, (size_t)Lv.n * sizeof(double)));
-      MI_HIP(hipMemset(Lv.f.p, 0, (size_t)Lv.n * sizeof(double)));
-      MI_HIP(hipMemset(Lv.tmp.p, 0, (size_t)Lv.n * sizeof(double)));
-      MI_HIP(hipMemset(Lv.snap.p, 0, (size_t)Lv.n * sizeof(double)));
-    }
   }
 
   // coarsest level: dense inverse (relax type 9), every rank holds its own rows
@@ -814,16 +794,53 @@ void BoomerAMG::setup(ParCSR &A0) {
         for (gidx g = rs; g < re; g++)
           Mp[(size_t)i * width + (size_t)r * maxloc + (size_t)(g - rs)] = inv[(size_t)(A.row_start + i) * ng + (size_t)g];
       }
-    Lc.Cinv.upload(Mp);
-    Lc.fgather.alloc(width);
-    Lc.fslot.alloc((size_t)maxloc);
-    MI_HIP(hipMemset(Lc.fslot.p, 0, ((size_t)maxloc + 2) * sizeof(double)));
-    MI_HIP(hipMemset(Lc.fgather.p, 0, (width + 2) * sizeof(double)));
+    Lc.Cinv_host.swap(Mp);
     Lc.dense = true;
+  }
+  host_ready = true;
+}
+
+void BoomerAMG::setup_device() {
+  MI_REQUIRE(host_ready, "BoomerAMG: setup_device before setup_host");
+  ensure_init();
+  Comm &comm = current_comm();
+  const int ch = chunk();
+  for (size_t li = 0; li < L.size(); li++) {
+    AmgLevel &Lv = L[li];
+    if (li > 0 || !Lv.A->on_device) Lv.A->to_device();
+    Lv.d_diag.upload(Lv.diag);
+    Lv.d_l1gs.upload(Lv.l1gs);
+    Lv.d_l1jac.upload(Lv.l1jac);
+    if (!Lv.cf.empty()) {
+      std::vector<signed char> c8(Lv.cf.size());
+      for (size_t i = 0; i < c8.size(); i++) c8[i] = (signed char)Lv.cf[i];
+      Lv.d_cf.upload(c8);
+      Lv.dP.upload(Lv.P);
+      Lv.dR.upload(Lv.R);
+    }
+    Lv.u.alloc((size_t)Lv.n);
+    Lv.f.alloc((size_t)Lv.n);
+    Lv.tmp.alloc((size_t)Lv.n);
+    Lv.snap.alloc((size_t)Lv.n);
+    if (Lv.n) {
+      MI_HIP(hipMemset(Lv.u.p, 0, (size_t)Lv.n * sizeof(double)));
+      MI_HIP(hipMemset(Lv.f.p, 0, (size_t)Lv.n * sizeof(double)));
+      MI_HIP(hipMemset(Lv.tmp.p, 0, (size_t)Lv.n * sizeof(double)));
+      MI_HIP(hipMemset(Lv.snap.p, 0, (size_t)Lv.n * sizeof(double)));
+    }
+  }
+  AmgLevel &Lc = L.back();
+  if (Lc.dense) {
+    const size_t width = (size_t)comm.size * (size_t)Lc.slot;
+    Lc.Cinv.upload(Lc.Cinv_host);
+    Lc.fgather.alloc(width);
+    Lc.fslot.alloc((size_t)Lc.slot);
+    MI_HIP(hipMemset(Lc.fslot.p, 0, ((size_t)Lc.slot + 2) * sizeof(double)));
+    MI_HIP(hipMemset(Lc.fgather.p, 0, (width + 2) * sizeof(double)));
   }
   MI_HIP(hipDeviceSynchronize());
   is_setup = true;
-  setup_seconds = wall_time() - t0;
+  setup_seconds = wall_time() - t_setup_start;
   if (p.print_level > 0 && comm.rank == 0) {
     printf("mi_hypre BoomerAMG setup: %zu levels, operator complexity %.3f, chunk %d, %.3f s\n", L.size(),
            operator_complexity(), ch, setup_seconds);

@@ -14,7 +14,7 @@ namespace mi {
 void BoomerAMG::relax(int level, int type, int points, const double *f, DVec<double> &u) {
   AmgLevel &Lv = L[(size_t)level];
   ParCSR &A = *Lv.A;
-  Comm &comm = *ctx().comm;
+  Comm &comm = current_comm();
   hipStream_t s = ctx().stream;
   const int prof = (level == 0) ? k::PROF_RELAX_L0 : k::PROF_NONE;
   if (type == 9) {
@@ -73,7 +73,7 @@ void BoomerAMG::cycle(int level, const double *f, DVec<double> &u) {
   }
   AmgLevel &Lv = L[(size_t)level];
   AmgLevel &Ln = L[(size_t)level + 1];
-  Comm &comm = *ctx().comm;
+  Comm &comm = current_comm();
   hipStream_t s = ctx().stream;
   relax_sweeps(level, 0, f, u);
   // r = f - A u ; f_c = P^T r ; u_c = 0
@@ -91,7 +91,7 @@ void BoomerAMG::solve(ParCSR &A, ParVector &b, ParVector &x) {
   if (!is_setup) setup(A);
   MI_REQUIRE(x.ncomp == 1 && b.ncomp == 1, "BoomerAMGSolve: multi-component vectors are not supported");
   MI_REQUIRE(x.n == L[0].n && b.n == L[0].n, "BoomerAMGSolve: vector size does not match the matrix");
-  Comm &comm = *ctx().comm;
+  Comm &comm = current_comm();
   hipStream_t s = ctx().stream;
   int it = 0;
   double rel = 0.0, bn = 0.0;

@@ -357,19 +357,53 @@ HYPRE_Int HYPRE_IJMatrixAssemble(HYPRE_IJMatrix matrix) {
   API_BEGIN
   IJMatrixObj *m = M(matrix);
   if (!m) fail(HYPRE_ERROR_ARG, "IJMatrixAssemble: NULL handle");
-  if (m->assembled) return 0;
-  ensure_init();
-  Comm &comm = *ctx().comm;
-  assemble_parcsr(comm, m->ilower, m->iupper, m->jlower, m->jupper, m->batches, m->par);
-  m->par.finalize(comm);
-  m->assembled = true;
+  if (!m->assembled) {
+    Comm &comm = current_comm();
+    assemble_parcsr(comm, m->ilower, m->iupper, m->jlower, m->jupper, m->batches, m->par);
+    m->par.build_halo_plan(comm);
+    m->assembled = true;
+  }
+  if (!m->par.on_device) m->par.to_device();
+  API_END
+}
+HYPRE_Int HYPRE_MI_IJMatrixAssembleHostOnly(HYPRE_IJMatrix matrix) {
+  API_BEGIN
+  IJMatrixObj *m = M(matrix);
+  if (!m) fail(HYPRE_ERROR_ARG, "IJMatrixAssembleHostOnly: NULL handle");
+  if (!m->assembled) {
+    Comm &comm = current_comm();
+    assemble_parcsr(comm, m->ilower, m->iupper, m->jlower, m->jupper, m->batches, m->par);
+    m->par.build_halo_plan(comm);
+    m->assembled = true;
+  }
+  API_END
+}
+HYPRE_Int HYPRE_MI_BoomerAMGSetupHostOnly(HYPRE_Solver solver, HYPRE_ParCSRMatrix A) {
+  API_BEGIN
+  if (!A) fail(HYPRE_ERROR_ARG, "BoomerAMGSetupHostOnly: NULL matrix");
+  AMG(solver)->amg.setup_host(*PM(A));
+  API_END
+}
+HYPRE_Int HYPRE_MI_ParCSRGetHaloPlan(HYPRE_ParCSRMatrix A, HYPRE_Int *nsend_peers, HYPRE_Int *send_peers,
+                                     HYPRE_Int *send_starts, HYPRE_Int *send_map, HYPRE_Int *nrecv_peers,
+                                     HYPRE_Int *recv_peers, HYPRE_Int *recv_starts) {
+  API_BEGIN
+  if (!A) fail(HYPRE_ERROR_ARG, "ParCSRGetHaloPlan: NULL matrix");
+  const HaloPlan &h = PM(A)->halo;
+  *nsend_peers = (HYPRE_Int)h.send_peers.size();
+  *nrecv_peers = (HYPRE_Int)h.recv_peers.size();
+  if (send_peers) std::copy(h.send_peers.begin(), h.send_peers.end(), send_peers);
+  if (send_starts) std::copy(h.send_starts.begin(), h.send_starts.end(), send_starts);
+  if (send_map) std::copy(h.send_map.begin(), h.send_map.end(), send_map);
+  if (recv_peers) std::copy(h.recv_peers.begin(), h.recv_peers.end(), recv_peers);
+  if (recv_starts) std::copy(h.recv_starts.begin(), h.recv_starts.end(), recv_starts);
   API_END
 }
 HYPRE_Int HYPRE_IJMatrixPrint(HYPRE_IJMatrix matrix, const char *filename) {
   API_BEGIN
   IJMatrixObj *m = M(matrix);
   if (!m || !m->assembled) fail(HYPRE_ERROR_GENERIC, "IJMatrixPrint: matrix is not assembled");
-  write_ij_matrix(m->par, filename, ctx().comm->rank);
+  write_ij_matrix(m->par, filename, current_comm().rank);
   API_END
 }
 HYPRE_Int HYPRE_IJMatrixGetLocalRange(HYPRE_IJMatrix matrix, HYPRE_BigInt *ilower, HYPRE_BigInt *iupper,
@@ -495,7 +529,7 @@ HYPRE_Int HYPRE_IJVectorPrint(HYPRE_IJVector vector, const char *filename) {
   std::vector<double> h((size_t)v->par.n);
   if (v->par.n) MI_HIP(hipMemcpy(h.data(), v->par.data(), h.size() * sizeof(double), hipMemcpyDeviceToHost));
   char fn[2048];
-  snprintf(fn, sizeof(fn), "%s.%05d", filename, ctx().comm->rank);
+  snprintf(fn, sizeof(fn), "%s.%05d", filename, current_comm().rank);
   FILE *fp = fopen(fn, "w");
   if (!fp) fail(HYPRE_ERROR_GENERIC, std::string("cannot open ") + fn);
   fprintf(fp, "%lld %lld\n", (long long)v->jlower, (long long)v->jupper);
@@ -517,7 +551,7 @@ HYPRE_Int HYPRE_ParCSRMatrixMatvec(HYPRE_Complex alpha, HYPRE_ParCSRMatrix A, HY
   if (!A || !x || !y) fail(HYPRE_ERROR_ARG, "ParCSRMatrixMatvec: NULL argument");
   ParCSR *a = PM(A);
   if (PV(x)->n != a->nrows || PV(y)->n != a->nrows) fail(HYPRE_ERROR_ARG, "ParCSRMatrixMatvec: size mismatch");
-  a->matvec(*ctx().comm, alpha, PV(x)->data(), beta, PV(y)->data(), PV(y)->data(), ctx().stream, k::PROF_SPMV_L0);
+  a->matvec(current_comm(), alpha, PV(x)->data(), beta, PV(y)->data(), PV(y)->data(), ctx().stream, k::PROF_SPMV_L0);
   MI_HIP(hipStreamSynchronize(ctx().stream));
   API_END
 }
@@ -538,7 +572,7 @@ HYPRE_Int HYPRE_ParCSRMatrixGetLocalRange(HYPRE_ParCSRMatrix A, HYPRE_BigInt *rs
 HYPRE_Int hypre_ParCSRMatrixPrintIJ(const hypre_ParCSRMatrix *A, HYPRE_Int, HYPRE_Int, const char *filename) {
   API_BEGIN
   if (!A) fail(HYPRE_ERROR_ARG, "ParCSRMatrixPrintIJ: NULL handle");
-  write_ij_matrix(*reinterpret_cast<const ParCSR *>(A), filename, ctx().comm->rank);
+  write_ij_matrix(*reinterpret_cast<const ParCSR *>(A), filename, current_comm().rank);
   API_END
 }
 HYPRE_Int HYPRE_ParVectorSetConstantValues(HYPRE_ParVector v, HYPRE_Complex value) {
@@ -552,7 +586,7 @@ HYPRE_Int HYPRE_ParVectorSetConstantValues(HYPRE_ParVector v, HYPRE_Complex valu
 HYPRE_Int HYPRE_ParVectorInnerProd(HYPRE_ParVector x, HYPRE_ParVector y, HYPRE_Real *prod) {
   API_BEGIN
   if (!x || !y || !prod) fail(HYPRE_ERROR_ARG, "ParVectorInnerProd: NULL argument");
-  *prod = par_dot_host(*ctx().comm, PV(x)->data(), PV(y)->data(), PV(x)->n, ctx().stream);
+  *prod = par_dot_host(current_comm(), PV(x)->data(), PV(y)->data(), PV(x)->n, ctx().stream);
   API_END
 }
 HYPRE_Int HYPRE_ParVectorAxpy(HYPRE_Complex alpha, HYPRE_ParVector x, HYPRE_ParVector y) {
@@ -893,7 +927,6 @@ HYPRE_Int HYPRE_MI_CommInitRCCL(const void *id128, HYPRE_Int rank, HYPRE_Int siz
 HYPRE_Int HYPRE_MI_CommInitCallbacks(void *cctx, HYPRE_MI_AllreduceFn ar, HYPRE_MI_AllgatherFn ag,
                                      HYPRE_MI_ExchangeFn ex, HYPRE_Int rank, HYPRE_Int size) {
   API_BEGIN
-  ensure_init();
   if (!ar || !ag || !ex) fail(HYPRE_ERROR_ARG, "CommInitCallbacks: NULL callback");
   CommCallbacks cb{cctx, ar, ag, ex};
   ctx().comm = make_callback_comm(cb, rank, size);
@@ -901,31 +934,27 @@ HYPRE_Int HYPRE_MI_CommInitCallbacks(void *cctx, HYPRE_MI_AllreduceFn ar, HYPRE_
 }
 HYPRE_Int HYPRE_MI_CommFinalize(void) {
   API_BEGIN
-  if (ctx().inited) {
-    MI_HIP(hipDeviceSynchronize());
-    ctx().comm = make_self_comm();
-  }
+  if (ctx().inited) MI_HIP(hipDeviceSynchronize());
+  ctx().comm = make_self_comm();
   API_END
 }
 HYPRE_Int HYPRE_MI_CommRank(HYPRE_Int *rank) {
-  *rank = ctx().comm ? ctx().comm->rank : 0;
+  *rank = current_comm().rank;
   return 0;
 }
 HYPRE_Int HYPRE_MI_CommSize(HYPRE_Int *size) {
-  *size = ctx().comm ? ctx().comm->size : 1;
+  *size = current_comm().size;
   return 0;
 }
 HYPRE_Int HYPRE_MI_CommBarrier(void) {
   API_BEGIN
-  ensure_init();
-  ctx().comm->barrier();
+  current_comm().barrier();
   API_END
 }
 HYPRE_Int HYPRE_MI_CommAllreduce(void *buf, size_t count, int dtype, int op) {
   API_BEGIN
-  ensure_init();
   if (dtype < 0 || dtype > 3 || op < 0 || op > 2) fail(HYPRE_ERROR_ARG, "CommAllreduce: bad dtype/op");
-  ctx().comm->allreduce_host(buf, count, (CommDType)dtype, (CommOp)op);
+  current_comm().allreduce_host(buf, count, (CommDType)dtype, (CommOp)op);
   API_END
 }
 HYPRE_Int HYPRE_MI_GetStream(void **hip_stream) {

@@ -58,23 +58,39 @@ void Comm::barrier() {
   allreduce_host(&one, 1, CommDType::I64, CommOp::SUM);
 }
 
+void Comm::exchange_host_fixed(const std::vector<PeerBuf> &sends, const std::vector<PeerBuf> &recvs) {
+  if (size == 1 || (sends.empty() && recvs.empty())) return;
+  ensure_init();
+  hipStream_t s = ctx().stream;
+  std::vector<DVec<char>> dsend(sends.size()), drecv(recvs.size());
+  std::vector<PeerBuf> sb, rb;
+  for (size_t i = 0; i < sends.size(); i++) {
+    dsend[i].alloc(sends[i].bytes);
+    MI_HIP(hipMemcpyAsync(dsend[i].p, sends[i].ptr, sends[i].bytes, hipMemcpyHostToDevice, s));
+    sb.push_back({sends[i].peer, dsend[i].p, sends[i].bytes});
+  }
+  for (size_t i = 0; i < recvs.size(); i++) {
+    drecv[i].alloc(recvs[i].bytes);
+    rb.push_back({recvs[i].peer, drecv[i].p, recvs[i].bytes});
+  }
+  exchange_dev(sb, rb, s);
+  for (size_t i = 0; i < recvs.size(); i++)
+    MI_HIP(hipMemcpyAsync(recvs[i].ptr, drecv[i].p, recvs[i].bytes, hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+}
+
 void Comm::exchange_host(const std::vector<int> &peers_send, const std::vector<std::vector<char>> &send,
                          std::vector<int> &peers_recv, std::vector<std::vector<char>> &recv) {
   peers_recv.clear();
   recv.clear();
   if (size == 1) return;
-  ensure_init();
-  hipStream_t s = ctx().stream;
   std::vector<long long> mine((size_t)size, 0), all((size_t)size * size, 0);
   for (size_t i = 0; i < peers_send.size(); i++) mine[(size_t)peers_send[i]] = (long long)send[i].size();
   allgather_host(mine.data(), all.data(), sizeof(long long) * (size_t)size);
-  std::vector<DVec<char>> dsend(peers_send.size()), drecv;
   std::vector<PeerBuf> sb, rb;
   for (size_t i = 0; i < peers_send.size(); i++) {
     if (send[i].empty()) continue;
-    dsend[i].alloc(send[i].size());
-    MI_HIP(hipMemcpyAsync(dsend[i].p, send[i].data(), send[i].size(), hipMemcpyHostToDevice, s));
-    sb.push_back({peers_send[i], dsend[i].p, send[i].size()});
+    sb.push_back({peers_send[i], (void *)send[i].data(), send[i].size()});
   }
   for (int p = 0; p < size; p++) {
     const long long bytes = all[(size_t)p * size + rank];
@@ -82,15 +98,8 @@ void Comm::exchange_host(const std::vector<int> &peers_send, const std::vector<s
     peers_recv.push_back(p);
     recv.emplace_back((size_t)bytes);
   }
-  drecv.resize(peers_recv.size());
-  for (size_t i = 0; i < peers_recv.size(); i++) {
-    drecv[i].alloc(recv[i].size());
-    rb.push_back({peers_recv[i], drecv[i].p, recv[i].size()});
-  }
-  exchange_dev(sb, rb, s);
-  for (size_t i = 0; i < peers_recv.size(); i++)
-    MI_HIP(hipMemcpyAsync(recv[i].data(), drecv[i].p, recv[i].size(), hipMemcpyDeviceToHost, s));
-  MI_HIP(hipStreamSynchronize(s));
+  for (size_t i = 0; i < peers_recv.size(); i++) rb.push_back({peers_recv[i], recv[i].data(), recv[i].size()});
+  exchange_host_fixed(sb, rb);
 }
 
 // ------------------------------------------------------------------ self
@@ -199,6 +208,24 @@ struct CallbackComm : Comm {
     size = size_;
   }
   const char *name() const override { return "callback"; }
+  // the transport is a host transport: host collectives go straight through
+  void allreduce_host(void *buf, size_t count, CommDType t, CommOp o) override {
+    if (size == 1 || count == 0) return;
+    cb.allreduce(cb.ctx, buf, count, (int)t, (int)o);
+  }
+  void allgather_host(const void *send, void *recv, size_t bytes) override {
+    cb.allgather(cb.ctx, send, recv, bytes);
+  }
+  void exchange_host_fixed(const std::vector<PeerBuf> &sends, const std::vector<PeerBuf> &recvs) override {
+    if (sends.empty() && recvs.empty()) return;
+    std::vector<int> sp, rp;
+    std::vector<void *> sptr, rptr;
+    std::vector<size_t> sby, rby;
+    for (auto &b : sends) sp.push_back(b.peer), sptr.push_back(b.ptr), sby.push_back(b.bytes);
+    for (auto &b : recvs) rp.push_back(b.peer), rptr.push_back(b.ptr), rby.push_back(b.bytes);
+    cb.exchange(cb.ctx, (int)sp.size(), sp.data(), sptr.data(), sby.data(), (int)rp.size(), rp.data(), rptr.data(),
+                rby.data());
+  }
   void allreduce_dev(void *buf, size_t count, CommDType t, CommOp o, hipStream_t s) override {
     const size_t bytes = count * dtype_size(t);
     std::vector<char> h(bytes);

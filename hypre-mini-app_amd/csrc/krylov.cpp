@@ -36,7 +36,7 @@ void GmresSolver::setup(ParCSR &A, ParVector &b, ParVector &x) {
 int GmresSolver::solve(ParCSR &A, ParVector &b, ParVector &x) {
   ensure_init();
   Ctx &c = ctx();
-  Comm &comm = *c.comm;
+  Comm &comm = current_comm();
   hipStream_t s = c.stream;
   const double t_start = wall_time();
   const int n = b.n;
@@ -191,7 +191,7 @@ void BicgstabSolver::setup(ParCSR &A, ParVector &b, ParVector &x) {
 int BicgstabSolver::solve(ParCSR &A, ParVector &b, ParVector &x) {
   ensure_init();
   Ctx &c = ctx();
-  Comm &comm = *c.comm;
+  Comm &comm = current_comm();
   hipStream_t s = c.stream;
   const double t_start = wall_time();
   const int n = b.n;

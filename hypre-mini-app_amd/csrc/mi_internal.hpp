@@ -135,9 +135,12 @@ struct Comm {
   virtual void allreduce_dev(void *buf, size_t count, CommDType t, CommOp op, hipStream_t s) = 0;
   virtual void exchange_dev(const std::vector<PeerBuf> &sends, const std::vector<PeerBuf> &recvs, hipStream_t s) = 0;
   virtual void allgather_dev(const void *send, void *recv, size_t bytes_per_rank, hipStream_t s) = 0;
-  // blocking host-side helpers built on the above
-  void allreduce_host(void *buf, size_t count, CommDType t, CommOp op);
-  void allgather_host(const void *send, void *recv, size_t bytes_per_rank);
+  // blocking host-side helpers; the defaults stage through device buffers and
+  // the device collectives above
+  virtual void allreduce_host(void *buf, size_t count, CommDType t, CommOp op);
+  virtual void allgather_host(const void *send, void *recv, size_t bytes_per_rank);
+  // fixed-size neighbour exchange of host buffers (sizes known on both sides)
+  virtual void exchange_host_fixed(const std::vector<PeerBuf> &sends, const std::vector<PeerBuf> &recvs);
   // variable-size neighbour exchange of host byte strings; recv sizes are learnt
   // through an all-gather of the size matrix
   void exchange_host(const std::vector<int> &peers_send, const std::vector<std::vector<char>> &send,
@@ -179,6 +182,7 @@ struct Ctx {
 };
 Ctx &ctx();
 void ensure_init();
+Comm &current_comm();  // never needs a device (self comm by default)
 
 // ---------------------------------------------------------------- small helpers
 void parallel_for(int64_t n, const std::function<void(int64_t, int64_t, int)> &fn, int max_threads = 0);

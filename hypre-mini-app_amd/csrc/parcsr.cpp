@@ -169,7 +169,7 @@ void assemble_parcsr(Comm &comm, gidx ilower, gidx iupper, gidx jlower, gidx jup
 }
 
 // ------------------------------------------------------------------ halo plan + device mirror
-void ParCSR::finalize(Comm &comm) {
+void ParCSR::build_halo_plan(Comm &comm) {
   halo = HaloPlan();
   if (comm.size == 1) {
     MI_REQUIRE(col_map_offd.empty(), "matrix has columns outside the single rank's range");
@@ -209,6 +209,10 @@ void ParCSR::finalize(Comm &comm) {
       halo.send_starts.push_back((int)halo.send_map.size());
     }
   }
+}
+
+void ParCSR::to_device() {
+  ensure_init();
   d_diag.upload(diag);
   d_offd.upload(nrows, offd);
   halo.d_send_map.upload(halo.send_map);

@@ -40,8 +40,14 @@ struct ParCSR {
   bool on_device = false;
   gidx global_rows() const { return row_starts.empty() ? nrows : row_starts.back(); }
 
-  // build the halo plan from col_map_offd (collective) and mirror to the device
-  void finalize(Comm &comm);
+  // build the halo plan from col_map_offd (collective, host only)
+  void build_halo_plan(Comm &comm);
+  // mirror matrix + plan to the device (needs a GPU)
+  void to_device();
+  void finalize(Comm &comm) {
+    build_halo_plan(comm);
+    to_device();
+  }
   // x_ext <- halo values of x (pack + neighbour exchange), enqueued on stream
   void halo_exchange(Comm &comm, const double *x, hipStream_t s);
   // host-side halo exchange of an arbitrary per-row int array (setup only)

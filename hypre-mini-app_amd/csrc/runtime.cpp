@@ -12,6 +12,11 @@ namespace mi {
 static Ctx g_ctx;
 Ctx &ctx() { return g_ctx; }
 
+Comm &current_comm() {
+  if (!g_ctx.comm) g_ctx.comm = make_self_comm();
+  return *g_ctx.comm;
+}
+
 double wall_time() {
   using namespace std::chrono;
   return duration<double>(steady_clock::now().time_since_epoch()).count();

@@ -425,3 +425,89 @@ def profile_get(pid):
     n, tot, mn = C.c_longlong(), c_dbl(), c_dbl()
     call("HYPRE_MI_ProfileGet", pid, C.byref(n), C.byref(tot), C.byref(mn))
     return n.value, tot.value, mn.value
+
+
+# ---------------------------------------------------------------------------
+# torch.distributed transport for the callback communicator (tests only: gloo,
+# host buffers).  The benchmark path uses the library's own RCCL communicator.
+_comm_keep = []
+
+
+def init_comm_torch(dist):
+    """Bind the library's communicator to a torch.distributed process group through
+    host-buffer callbacks (several ranks may share one GPU this way)."""
+    import torch
+
+    rank, size = dist.get_rank(), dist.get_world_size()
+    np_dt = {0: np.float64, 1: np.int64, 2: np.int32, 3: np.uint8}
+    ops = {0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MIN, 2: dist.ReduceOp.MAX}
+
+    def _view(ptr, nbytes, dtype=np.uint8):
+        buf = (C.c_char * nbytes).from_address(ptr)
+        return np.frombuffer(buf, dtype=dtype)
+
+    def allreduce(ctx, buf, count, dtype, op):
+        dt = np_dt[dtype]
+        a = _view(buf, count * np.dtype(dt).itemsize, dt)
+        t = torch.from_numpy(a)
+        dist.all_reduce(t, op=ops[op])
+
+    def allgather(ctx, send, recv, nbytes):
+        s = torch.from_numpy(_view(send, nbytes).copy())
+        out = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(size)]
+        dist.all_gather(out, s)
+        r = _view(recv, nbytes * size)
+        for i, o in enumerate(out):
+            r[i * nbytes:(i + 1) * nbytes] = o.numpy()
+
+    def exchange(ctx, nsend, speers, sptrs, sbytes, nrecv, rpeers, rptrs, rbytes):
+        reqs, rbufs = [], []
+        for i in range(nrecv):
+            t = torch.empty(rbytes[i], dtype=torch.uint8)
+            rbufs.append(t)
+            reqs.append(dist.irecv(t, src=rpeers[i]))
+        for i in range(nsend):
+            t = torch.from_numpy(_view(sptrs[i], sbytes[i]).copy())
+            reqs.append(dist.isend(t, dst=speers[i]))
+        for r in reqs:
+            r.wait()
+        for i in range(nrecv):
+            _view(rptrs[i], rbytes[i])[:] = rbufs[i].numpy()
+
+    cbs = (ALLREDUCE_FN(allreduce), ALLGATHER_FN(allgather), EXCHANGE_FN(exchange))
+    _comm_keep.append(cbs)
+    call("HYPRE_MI_CommInitCallbacks", None, cbs[0], cbs[1], cbs[2], rank, size)
+    return rank, size
+
+
+def build_laplace_system_host(nx, ny, nz, stencil, rank, size):
+    """IJ matrix of this rank's rows, assembled on the HOST only (no device)."""
+    N = nx * ny * nz
+    ilower, iupper = row_partition(N, size, rank)
+    g = laplace3d(nx, ny, nz, stencil, ilower, iupper)
+    A = IJMatrix.__new__(IJMatrix)
+    A.h = vp()
+    A.ilower, A.iupper = ilower, iupper
+    call("HYPRE_IJMatrixCreate", 0, c_big(ilower), c_big(iupper), c_big(ilower), c_big(iupper), C.byref(A.h))
+    call("HYPRE_IJMatrixSetObjectType", A.h, HYPRE_PARCSR)
+    A.par = vp()
+    call("HYPRE_IJMatrixGetObject", A.h, C.byref(A.par))
+    A.set_values_ptr(g["nnz"], g["rows"], g["cols"], g["vals"])
+    call("HYPRE_MI_IJMatrixAssembleHostOnly", A.h)
+    rhs = np.ctypeslib.as_array(C.cast(g["rhs"], C.POINTER(c_dbl)), shape=(g["nloc"],)).copy()
+    laplace3d_free(g)
+    return A, rhs
+
+
+def halo_plan(A):
+    ns, nr = c_int(), c_int()
+    call("HYPRE_MI_ParCSRGetHaloPlan", A.par, C.byref(ns), None, None, None, C.byref(nr), None, None, None)
+    sp = np.zeros(max(ns.value, 1), dtype=np.int32)
+    ss = np.zeros(ns.value + 1, dtype=np.int32)
+    rp = np.zeros(max(nr.value, 1), dtype=np.int32)
+    rs = np.zeros(nr.value + 1, dtype=np.int32)
+    call("HYPRE_MI_ParCSRGetHaloPlan", A.par, C.byref(ns), sp, ss, None, C.byref(nr), rp, rs)
+    sm = np.zeros(max(int(ss[-1]), 1), dtype=np.int32)
+    call("HYPRE_MI_ParCSRGetHaloPlan", A.par, C.byref(ns), sp, ss, sm, C.byref(nr), rp, rs)
+    return dict(send_peers=sp[: ns.value], send_starts=ss, send_map=sm[: int(ss[-1])], recv_peers=rp[: nr.value],
+                recv_starts=rs)

@@ -30,6 +30,16 @@ HYPRE_Int HYPRE_MI_CommBarrier(void);
 /* blocking all-reduce of a HOST buffer (loaders: src/HypreSystem.cpp:1166-1167, :829) */
 HYPRE_Int HYPRE_MI_CommAllreduce(void *buf, size_t count, int dtype, int op);
 
+/* ---- host-only halves of Assemble / Setup (no device needed): the N>1 host logic
+ * -- row partition, halo plan, rank-local coarsening, P-row exchange, Galerkin
+ * product -- is exercised by world_size-2 gloo tests on CPU through these. */
+HYPRE_Int HYPRE_MI_IJMatrixAssembleHostOnly(HYPRE_IJMatrix matrix);
+HYPRE_Int HYPRE_MI_BoomerAMGSetupHostOnly(HYPRE_Solver solver, HYPRE_ParCSRMatrix A);
+/* arrays may be NULL to query the counts; send_starts/recv_starts hold npeers+1 offsets */
+HYPRE_Int HYPRE_MI_ParCSRGetHaloPlan(HYPRE_ParCSRMatrix A, HYPRE_Int *nsend_peers, HYPRE_Int *send_peers,
+                                     HYPRE_Int *send_starts, HYPRE_Int *send_map, HYPRE_Int *nrecv_peers,
+                                     HYPRE_Int *recv_peers, HYPRE_Int *recv_starts);
+
 /* ---- device / stream */
 HYPRE_Int HYPRE_MI_GetStream(void **hip_stream);
 HYPRE_Int HYPRE_MI_StreamSynchronize(void);

@@ -1,0 +1,148 @@
+"""One rank of a multi-process parity run (launched by torch.distributed.run).
+
+  --mode host   CPU only: IJ assembly, halo plan and the whole multi-rank AMG setup
+                (rank-local coarsening, P-row exchange, Galerkin product) through the
+                C ABI with a gloo transport, checked against the oracle's emulation
+                of the same row partition.
+  --mode solve  GPU: the same plus the device solve (ranks share the visible GPU;
+                the transport is still gloo -- RCCL refuses two ranks on one device).
+Exit code 0 = every rank's checks passed.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import scipy.sparse as sp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+
+def local_rows_global(amg, level, which_cols_global_n, rank):
+    """This rank's rows of level `level` as a scipy CSR over GLOBAL columns."""
+    ia, ja, a, shape = amg.level_csr(level, 0)
+    oia, oja, oa, oshape = amg.level_csr(level, 1)
+    cm, row_start = amg.level_colmap(level)
+    n = shape[0]
+    D = sp.csr_matrix((a, ja + row_start, ia), shape=(n, which_cols_global_n))
+    if oshape[1] > 0 and len(oa):
+        O = sp.csr_matrix((oa, cm[oja], oia), shape=(n, which_cols_global_n))
+        return (D + O).tocsr(), row_start
+    return D, row_start
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", default="host")
+    ap.add_argument("--grid", type=int, default=12)
+    ap.add_argument("--stencil", type=int, default=7)
+    args = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group(backend="gloo")
+    rank, size = dist.get_rank(), dist.get_world_size()
+    mi = ge.load_binding()
+    oc = ge.load_oracle()
+    if args.mode == "solve":
+        mi.init()
+    mi.init_comm_torch(dist)
+    n, st = args.grid, args.stencil
+    N = n ** 3
+    starts = [mi.row_partition(N, size, r)[0] for r in range(size)] + [N]
+
+    # ---- oracle emulation of the same partition (every rank computes it; it is small)
+    Ao, bo = oc.Csr.laplace(n, n, n, st)
+    chunk = mi.c_int()
+    mi.call("HYPRE_MI_GetGSChunk", mi.C.byref(chunk))
+    oamg = oc.Amg(Ao, oc.default_params(gs_chunk=chunk.value, part_starts=starts))
+
+    if args.mode == "host":
+        A, rhs = mi.build_laplace_system_host(n, n, n, st, rank, size)
+    else:
+        A, b, x, rhs = mi.build_laplace_system(n, n, n, st, rank, size)
+    assert np.array_equal(rhs, bo[starts[rank]:starts[rank + 1]])
+
+    # ---- halo plan: z-slab neighbours only, what I send is what my neighbour receives
+    plan = mi.halo_plan(A)
+    expect = [r for r in (rank - 1, rank + 1) if 0 <= r < size]
+    assert list(plan["recv_peers"]) == expect, (rank, plan)
+    assert list(plan["send_peers"]) == expect, (rank, plan)
+    S = Ao.to_scipy()
+    for i, p in enumerate(plan["recv_peers"]):
+        # columns of peer p that my rows touch
+        sub = S[starts[rank]:starts[rank + 1], starts[p]:starts[p + 1]]
+        need = np.unique(sub.indices)
+        assert plan["recv_starts"][i + 1] - plan["recv_starts"][i] == len(need)
+    for i, p in enumerate(plan["send_peers"]):
+        sub = S[starts[p]:starts[p + 1], starts[rank]:starts[rank + 1]]
+        need = np.unique(sub.indices)
+        got = plan["send_map"][plan["send_starts"][i]:plan["send_starts"][i + 1]]
+        assert np.array_equal(np.sort(got), need), (rank, p)
+
+    # ---- hierarchy
+    amg = mi.BoomerAMG(print_level=0)
+    if args.mode == "host":
+        mi.call("HYPRE_MI_BoomerAMGSetupHostOnly", amg.h, A.par)
+    else:
+        amg.setup(A)
+    assert amg.num_levels == oamg.num_levels, (amg.num_levels, oamg.num_levels)
+    for l in range(amg.num_levels):
+        OA = oamg.level_A(l).to_scipy()
+        ps = oamg.level_part_starts(l)
+        mine, row_start = local_rows_global(amg, l, OA.shape[1], rank)
+        assert row_start == ps[rank] and mine.shape[0] == ps[rank + 1] - ps[rank], (l, rank)
+        ref = OA[ps[rank]:ps[rank + 1]]
+        diff = abs(mine - ref)
+        scale = abs(ref).max() if ref.nnz else 1.0
+        assert (diff.max() if diff.nnz else 0.0) <= 1e-12 * scale, (l, rank, diff.max())
+        assert (mine != 0).nnz == (ref != 0).nnz
+        if l < amg.num_levels - 1:
+            cf = amg.level_cf(l)
+            assert np.array_equal(cf, oamg.level_cf(l)[ps[rank]:ps[rank + 1]]), (l, rank)
+            pia, pja, pa, pshape = amg.level_csr(l, 2)
+            OP = oamg.level_P(l).to_scipy()
+            psn = oamg.level_part_starts(l + 1)
+            refP = OP[ps[rank]:ps[rank + 1], psn[rank]:psn[rank + 1]]
+            assert OP[ps[rank]:ps[rank + 1]].nnz == refP.nnz  # P has no off-rank columns
+            Pm = sp.csr_matrix((pa, pja, pia), shape=pshape)
+            d = abs(Pm - refP)
+            assert (d.max() if d.nnz else 0.0) <= 1e-13
+
+    if args.mode == "solve":
+        gm = mi.GMRES(tolerance=1e-8, max_iterations=60, kspace=20, print_level=0)
+        gm.set_precond(amg)
+        gm.setup(A, b, x)
+        rc = gm.solve(A, b, x)
+        assert rc == 0
+        xo, info = oc.gmres(Ao, bo, kdim=20, tol=1e-8, maxit=60, amg=oamg)
+        assert gm.num_iterations == info["iters"], (gm.num_iterations, info["iters"])
+        hist = gm.residual_history()
+        assert np.allclose(hist, info["norms"], rtol=1e-7), (hist, info["norms"])
+        assert abs(gm.final_rel_res - info["rel_res"]) <= 1e-10
+        xs = x.get()
+        ref = xo[starts[rank]:starts[rank + 1]]
+        assert np.all(np.abs(xs - ref) < np.maximum(1e-6 * np.maximum(np.abs(xs), np.abs(ref)), 1e-8))
+        # distributed matvec / dot against the serial oracle
+        rng = np.random.default_rng(3)
+        v = rng.standard_normal(N)
+        xv = mi.IJVector(starts[rank], starts[rank + 1] - 1, v[starts[rank]:starts[rank + 1]])
+        yv = mi.IJVector(starts[rank], starts[rank + 1] - 1, np.zeros(starts[rank + 1] - starts[rank]))
+        mi.call("HYPRE_ParCSRMatrixMatvec", 1.0, A.par, xv.par, 0.0, yv.par)
+        assert np.allclose(yv.get(), Ao.matvec(v)[starts[rank]:starts[rank + 1]], rtol=1e-13, atol=1e-13)
+        prod = mi.c_dbl()
+        mi.call("HYPRE_ParVectorInnerProd", xv.par, xv.par, mi.C.byref(prod))
+        assert abs(prod.value - float(v @ v)) <= 1e-12 * float(v @ v)
+        if rank == 0:
+            print(f"dist solve ok: {size} ranks, {gm.num_iterations} iterations, rel res {gm.final_rel_res:.3e}")
+    elif rank == 0:
+        print(f"dist host setup ok: {size} ranks, {amg.num_levels} levels")
+    dist.barrier()
+    mi.call("HYPRE_MI_CommFinalize")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
