@@ -924,6 +924,37 @@ HYPRE_Int HYPRE_MI_CommInitRCCL(const void *id128, HYPRE_Int rank, HYPRE_Int siz
     ctx().comm = make_rccl_comm(id128, rank, size);
   API_END
 }
+HYPRE_Int HYPRE_MI_CommInitFromEnv(void) {
+  API_BEGIN
+  ensure_init();
+  ctx().comm = make_comm_from_env();
+  API_END
+}
+HYPRE_Int HYPRE_MI_CommSelfTestRCCL(void) {
+  // a world of one rank through the real RCCL entry points: dlopen + symbols,
+  // CommInitRank, AllReduce, AllGather and a grouped Send/Recv to self
+  API_BEGIN
+  ensure_init();
+  unsigned char id[128];
+  rccl_get_unique_id(id);
+  std::unique_ptr<Comm> rc = make_rccl_comm(id, 0, 1);
+  hipStream_t s = ctx().stream;
+  std::vector<double> h = {1.5, -2.0, 3.25, 4.0};
+  DVec<double> a, b(4), g(4);
+  a.upload(h);
+  rc->allreduce_dev(a.p, 4, CommDType::F64, CommOp::SUM, s);
+  rc->allgather_dev(a.p, g.p, 4 * sizeof(double), s);
+  rc->exchange_dev({{0, a.p, 4 * sizeof(double)}}, {{0, b.p, 4 * sizeof(double)}}, s);
+  MI_HIP(hipStreamSynchronize(s));
+  std::vector<double> ha = a.to_host(), hb = b.to_host(), hg = g.to_host();
+  for (int i = 0; i < 4; i++)
+    if (ha[(size_t)i] != h[(size_t)i] || hb[(size_t)i] != h[(size_t)i] || hg[(size_t)i] != h[(size_t)i])
+      fail(HYPRE_ERROR_GENERIC, "RCCL self test: wrong data");
+  long long v = 7;
+  rc->allreduce_host(&v, 1, CommDType::I64, CommOp::MAX);
+  if (v != 7) fail(HYPRE_ERROR_GENERIC, "RCCL self test: host all-reduce");
+  API_END
+}
 HYPRE_Int HYPRE_MI_CommInitCallbacks(void *cctx, HYPRE_MI_AllreduceFn ar, HYPRE_MI_AllgatherFn ag,
                                      HYPRE_MI_ExchangeFn ex, HYPRE_Int rank, HYPRE_Int size) {
   API_BEGIN

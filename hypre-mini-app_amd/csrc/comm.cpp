@@ -7,8 +7,17 @@
 // The halo exchange is a neighbour send/recv group (<= 2 peers for slab
 // partitions), the dot products are 8-byte all-reduces: both latency-bound, so
 // what matters is how few of them the solver issues, not their algorithm.
+#include <arpa/inet.h>
 #include <dlfcn.h>
+#include <netdb.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
 #include <rccl/rccl.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <thread>
 
 #include <cstring>
 
@@ -283,6 +292,84 @@ void rccl_get_unique_id(void *out128) {
 }
 std::unique_ptr<Comm> make_callback_comm(const CommCallbacks &cb, int rank, int size) {
   return std::unique_ptr<Comm>(new CallbackComm(cb, rank, size));
+}
+
+// ------------------------------------------------------------------ launcher-agnostic bootstrap
+// One process per GPU started by any launcher that exports RANK / WORLD_SIZE /
+// MASTER_ADDR / MASTER_PORT (torchrun does).  Rank 0 creates the ncclUniqueId and
+// hands it to the other ranks over a short-lived TCP connection.
+static int env_int(const char *a, const char *b, const char *c, int dflt) {
+  for (const char *n : {a, b, c})
+    if (n && getenv(n)) return atoi(getenv(n));
+  return dflt;
+}
+static void send_all(int fd, const void *buf, size_t n) {
+  const char *p = (const char *)buf;
+  while (n) {
+    ssize_t w = ::send(fd, p, n, 0);
+    if (w <= 0) fail(1, "comm bootstrap: send failed");
+    p += w;
+    n -= (size_t)w;
+  }
+}
+static void recv_all(int fd, void *buf, size_t n) {
+  char *p = (char *)buf;
+  while (n) {
+    ssize_t r = ::recv(fd, p, n, 0);
+    if (r <= 0) fail(1, "comm bootstrap: recv failed");
+    p += r;
+    n -= (size_t)r;
+  }
+}
+std::unique_ptr<Comm> make_comm_from_env() {
+  const int size = env_int("WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE", 1);
+  const int rank = env_int("RANK", "OMPI_COMM_WORLD_RANK", "PMI_RANK", 0);
+  if (size <= 1) return make_self_comm();
+  const char *addr = getenv("MASTER_ADDR") ? getenv("MASTER_ADDR") : "127.0.0.1";
+  int port = getenv("MI_HYPRE_PORT") ? atoi(getenv("MI_HYPRE_PORT"))
+                                     : (getenv("MASTER_PORT") ? atoi(getenv("MASTER_PORT")) + 17 : 29517);
+  unsigned char id[128];
+  if (rank == 0) {
+    rccl_get_unique_id(id);
+    int ls = ::socket(AF_INET, SOCK_STREAM, 0);
+    if (ls < 0) fail(1, "comm bootstrap: socket");
+    int one = 1;
+    setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+    sockaddr_in sa{};
+    sa.sin_family = AF_INET;
+    sa.sin_addr.s_addr = htonl(INADDR_ANY);
+    sa.sin_port = htons((uint16_t)port);
+    if (::bind(ls, (sockaddr *)&sa, sizeof(sa)) != 0 || ::listen(ls, size) != 0) {
+      ::close(ls);
+      fail(1, "comm bootstrap: cannot listen on port " + std::to_string(port));
+    }
+    for (int k = 1; k < size; k++) {
+      int fd = ::accept(ls, nullptr, nullptr);
+      if (fd < 0) fail(1, "comm bootstrap: accept");
+      send_all(fd, id, sizeof(id));
+      ::close(fd);
+    }
+    ::close(ls);
+  } else {
+    addrinfo hints{}, *res = nullptr;
+    hints.ai_family = AF_INET;
+    hints.ai_socktype = SOCK_STREAM;
+    if (getaddrinfo(addr, std::to_string(port).c_str(), &hints, &res) != 0 || !res)
+      fail(1, std::string("comm bootstrap: cannot resolve ") + addr);
+    int fd = -1;
+    for (int attempt = 0; attempt < 600; attempt++) {
+      fd = ::socket(AF_INET, SOCK_STREAM, 0);
+      if (fd >= 0 && ::connect(fd, res->ai_addr, res->ai_addrlen) == 0) break;
+      if (fd >= 0) ::close(fd);
+      fd = -1;
+      std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    }
+    freeaddrinfo(res);
+    if (fd < 0) fail(1, "comm bootstrap: cannot reach rank 0");
+    recv_all(fd, id, sizeof(id));
+    ::close(fd);
+  }
+  return make_rccl_comm(id, rank, size);
 }
 
 }  // namespace mi

@@ -163,6 +163,8 @@ struct CommCallbacks {
                    int nrecv, const int *recv_peers, void *const *recv_ptrs, const size_t *recv_bytes);
 };
 std::unique_ptr<Comm> make_callback_comm(const CommCallbacks &cb, int rank, int size);
+// RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT bootstrap (TCP hand-off of the ncclUniqueId)
+std::unique_ptr<Comm> make_comm_from_env();
 
 // ---------------------------------------------------------------- runtime context
 struct KernelTimer;  // profile.cpp

@@ -1,0 +1,1089 @@
+// nalu::HypreSystem against the MI355X-native HYPRE-shaped C ABI.
+// Behavioural contract: /root/reference/src/HypreSystem.cpp (cited per method);
+// written from scratch -- the loaders parse the mapped file in place, the
+// synthetic generators use true neighbour columns, check_solution really
+// reduces its verdict, and the AMG hierarchy is set up once per matrix.
+#include "HypreSystem.h"
+
+#include <fcntl.h>
+#include <hip/hip_runtime.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <iomanip>
+#include <iostream>
+#include <limits>
+#include <sstream>
+#include <stdexcept>
+
+namespace nalu {
+
+namespace {
+
+struct Stopwatch {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  double seconds() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+std::string part_name(const std::string &base, int part) {
+  std::ostringstream s;
+  s << base << "." << std::setw(5) << std::setfill('0') << part;
+  return s.str();
+}
+
+// read-only mapping of a whole file
+struct MappedFile {
+  const char *data = nullptr;
+  size_t size = 0;
+  int fd = -1;
+  explicit MappedFile(const std::string &path) {
+    fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("Cannot open file: " + path);
+    struct stat st;
+    if (fstat(fd, &st) != 0) throw std::runtime_error("Cannot stat file: " + path);
+    size = (size_t)st.st_size;
+    if (size) {
+      void *p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+      if (p == MAP_FAILED) throw std::runtime_error("Cannot mmap file: " + path);
+      data = (const char *)p;
+    }
+  }
+  ~MappedFile() {
+    if (data) munmap((void *)data, size);
+    if (fd >= 0) ::close(fd);
+  }
+};
+
+// cursor over a mapped text file: line-wise, numbers parsed in place
+struct TextCursor {
+  const char *p, *end;
+  TextCursor(const char *b, size_t n) : p(b), end(b + n) {}
+  bool done() const { return p >= end; }
+  // [p, eol) of the current line; advances past the newline
+  std::pair<const char *, const char *> line() {
+    const char *b = p;
+    const char *e = (const char *)memchr(p, '\n', (size_t)(end - p));
+    if (!e) e = end;
+    p = (e < end) ? e + 1 : end;
+    return {b, e};
+  }
+};
+inline bool blank(const char *b, const char *e) {
+  for (; b < e; b++)
+    if (!isspace((unsigned char)*b)) return false;
+  return true;
+}
+// bounded number parsing (the mapping is not NUL terminated)
+inline bool next_ll(const char *&b, const char *e, long long &v) {
+  while (b < e && isspace((unsigned char)*b)) b++;
+  if (b >= e) return false;
+  char buf[64];
+  size_t n = 0;
+  while (b < e && !isspace((unsigned char)*b) && n < sizeof(buf) - 1) buf[n++] = *b++;
+  buf[n] = 0;
+  char *q = nullptr;
+  v = strtoll(buf, &q, 10);
+  return q != buf;
+}
+inline bool next_dbl(const char *&b, const char *e, double &v) {
+  while (b < e && isspace((unsigned char)*b)) b++;
+  if (b >= e) return false;
+  char buf[96];
+  size_t n = 0;
+  while (b < e && !isspace((unsigned char)*b) && n < sizeof(buf) - 1) buf[n++] = *b++;
+  buf[n] = 0;
+  char *q = nullptr;
+  v = strtod(buf, &q);
+  return q != buf;
+}
+
+// Matrix Market banner + size line (the part of mmio.c the driver uses,
+// /root/reference/src/mmio.c:86-247)
+struct MMHeader {
+  bool coordinate = false, array = false, complex_field = false, pattern = false;
+  long long m = 0, n = 0, nnz = 0;
+};
+MMHeader read_mm_header(TextCursor &cur, const std::string &path) {
+  MMHeader h;
+  auto ln = cur.line();
+  std::string banner(ln.first, ln.second);
+  std::transform(banner.begin(), banner.end(), banner.begin(), ::tolower);
+  if (banner.rfind("%%matrixmarket", 0) != 0) throw std::runtime_error("Cannot read matrix banner: " + path);
+  std::istringstream ss(banner);
+  std::string tag, object, format, field, symmetry;
+  ss >> tag >> object >> format >> field >> symmetry;
+  if (object != "matrix") throw std::runtime_error("Invalid matrix market file encountered: " + path);
+  h.coordinate = (format == "coordinate");
+  h.array = (format == "array");
+  h.complex_field = (field == "complex");
+  h.pattern = (field == "pattern");
+  if (!h.coordinate && !h.array) throw std::runtime_error("Invalid matrix market file encountered: " + path);
+  while (!cur.done()) {
+    const char *save = cur.p;
+    ln = cur.line();
+    if (ln.first < ln.second && *ln.first == '%') continue;
+    if (blank(ln.first, ln.second)) continue;
+    (void)save;
+    const char *b = ln.first;
+    bool ok = next_ll(b, ln.second, h.m) && next_ll(b, ln.second, h.n);
+    if (h.coordinate) ok = ok && next_ll(b, ln.second, h.nnz);
+    if (!ok) throw std::runtime_error("Cannot read matrix sizes in file: " + path);
+    return h;
+  }
+  throw std::runtime_error("Cannot read matrix sizes in file: " + path);
+}
+
+// process grid of the reference generator
+// (/root/reference/src/laplace_3d_weak_scaling.hpp:80-169)
+void process_grid(int nproc, int &npx, int &npy, int &npz) {
+  std::vector<int> f;
+  int r = nproc;
+  for (int d = 2; (long long)d * d <= r; d++)
+    while (r % d == 0) {
+      f.push_back(d);
+      r /= d;
+    }
+  if (r > 1) f.push_back(r);
+  const int m = (int)f.size();
+  npx = npy = npz = 1;
+  if (m == 1) {
+    npx = f[0];
+  } else if (m == 2) {
+    npx = f[1];
+    npy = f[0];
+  } else if (m == 3) {
+    npx = f[2];
+    npy = f[1];
+    npz = f[0];
+  } else if (m > 3) {
+    int lo = 0, hi = m - 1;
+    npx = f[(size_t)hi--];
+    while ((double)npx < std::cbrt((double)nproc) && lo <= hi) npx *= f[(size_t)lo++];
+    if (lo <= hi) npy = f[(size_t)hi--];
+    while ((double)npy < std::sqrt((double)nproc / npx) && lo <= hi) npy *= f[(size_t)lo++];
+    while (lo <= hi) npz *= f[(size_t)lo++];
+  }
+}
+
+}  // namespace
+
+HypreSystem::HypreSystem(MPI_Comm comm, YAML::Node &inpfile) : comm_(comm), inpfile_(inpfile) {
+  MPI_Comm_rank(comm, &iproc_);
+  MPI_Comm_size(comm, &nproc_);
+}
+
+// /root/reference/src/HypreSystem.cpp:16-47
+void HypreSystem::load() {
+  YAML::Node linsys = inpfile_["linear_system"];
+  if (!linsys) throw std::runtime_error("Input file has no linear_system section");
+  writeAmgMatrices_ = get_optional(linsys, "write_amg_matrices", false);
+  std::string mat_format = get_optional<std::string>(linsys, "type", "matrix_market");
+  if (iproc_ == 0) printf("%s : Using %s mat_format\n", __FUNCTION__, mat_format.c_str());
+
+  if (mat_format == "matrix_market") {
+    load_matrix_market();
+  } else if (mat_format == "hypre_ij") {
+    load_hypre_format();
+  } else if (mat_format == "build_27pt_stencil") {
+    // the reference's generator: nx,ny,nz are PER-RANK box dims (weak scaling)
+    build_stencil(27, true);
+  } else if (mat_format == "laplace_3d") {
+    // the north-star problem: nx,ny,nz are GLOBAL dims, lexicographic numbering, 7-point by default
+    build_stencil(7, false);
+  } else {
+    throw std::runtime_error("Invalid linear system format option: " + mat_format);
+  }
+  outputSystem_ = get_optional(linsys, "write_outputs", false);
+  outputSolution_ = get_optional(linsys, "write_solution", false);
+}
+
+// /root/reference/src/HypreSystem.cpp:49-89
+void HypreSystem::setup_precon_and_solver() {
+  YAML::Node solver = inpfile_["solver_settings"];
+  if (!solver || !solver["method"] || !solver["preconditioner"])
+    throw std::runtime_error("solver_settings needs 'method' and 'preconditioner'");
+  const std::string method = solver["method"].as<std::string>();
+  const std::string preconditioner = solver["preconditioner"].as<std::string>();
+  if (iproc_ == 0)
+    printf("%s : Using %s solver with %s preconditioner\n", __FUNCTION__, method.c_str(), preconditioner.c_str());
+
+  if (preconditioner == "boomeramg")
+    setup_boomeramg_precond();
+  else if (preconditioner == "ilu")
+    setup_ilu_precond();
+  else if (preconditioner == "none")
+    usePrecond_ = false;
+  else
+    throw std::runtime_error("Invalid option for preconditioner provided" + preconditioner);
+
+  if (method == "gmres")
+    setup_gmres();
+  else if (method == "cg")
+    setup_cg();
+  else if (method == "bicg")
+    setup_bicg();
+  else if (method == "fgmres")
+    setup_fgmres();
+  else if (method == "boomeramg")
+    setup_boomeramg_solver();
+  else if (method == "cogmres")
+    setup_cogmres();
+  else if (method == "ilu")
+    setup_ilu();
+  else
+    throw std::runtime_error("Invalid option for solver method provided: " + method);
+  MPI_Barrier(comm_);
+  fflush(stdout);
+}
+
+// /root/reference/src/HypreSystem.cpp:91-117.  The reference configures precond_
+// (NULL) there; this one configures the solver it just created.
+void HypreSystem::setup_boomeramg_solver() {
+  YAML::Node node = inpfile_["solver_settings"];
+  HYPRE_BoomerAMGCreate(&solver_);
+  HYPRE_BoomerAMGSetTol(solver_, get_optional(node, "tolerance", 1.0e-5));
+  HYPRE_BoomerAMGSetMaxIter(solver_, get_optional(node, "max_iterations", 1000));
+  HYPRE_BoomerAMGSetPrintLevel(solver_, get_optional(node, "print_level", 4));
+  HYPRE_BoomerAMGSetCoarsenType(solver_, get_optional(node, "coarsen_type", 8));
+  HYPRE_BoomerAMGSetCycleType(solver_, get_optional(node, "cycle_type", 1));
+  HYPRE_BoomerAMGSetRelaxType(solver_, get_optional(node, "relax_type", 6));
+  HYPRE_BoomerAMGSetNumSweeps(solver_, get_optional(node, "num_sweeps", 1));
+  HYPRE_BoomerAMGSetSmoothNumSweeps(solver_, get_optional(node, "smooth_num_sweeps", 1));
+  HYPRE_BoomerAMGSetRelaxOrder(solver_, get_optional(node, "relax_order", 1));
+  HYPRE_BoomerAMGSetMaxLevels(solver_, get_optional(node, "max_levels", 20));
+  HYPRE_BoomerAMGSetStrongThreshold(solver_, get_optional(node, "strong_threshold", 0.57));
+  solverDestroyPtr_ = &HYPRE_BoomerAMGDestroy;
+  solverSetupPtr_ = &HYPRE_BoomerAMGSetup;
+  solverPrecondPtr_ = nullptr;
+  solverSolvePtr_ = &HYPRE_BoomerAMGSolve;
+  solverItersPtr_ = &HYPRE_BoomerAMGGetNumIterations;
+  solverResPtr_ = &HYPRE_BoomerAMGGetFinalRelativeResidualNorm;
+  usePrecond_ = false;
+}
+
+// /root/reference/src/HypreSystem.cpp:119-326, key for key
+void HypreSystem::setup_boomeramg_precond() {
+  YAML::Node node = inpfile_["boomeramg_settings"];
+  HYPRE_BoomerAMGCreate(&precond_);
+  HYPRE_BoomerAMGSetPrintLevel(precond_, get_optional(node, "print_level", 1));
+  HYPRE_BoomerAMGSetDebugFlag(precond_, get_optional(node, "debug_flag", 1));
+  HYPRE_BoomerAMGSetCoarsenType(precond_, get_optional(node, "coarsen_type", 8));
+  HYPRE_BoomerAMGSetCycleType(precond_, get_optional(node, "cycle_type", 1));
+
+  if (node["down_relax_type"] && node["up_relax_type"] && node["coarse_relax_type"]) {
+    HYPRE_BoomerAMGSetCycleRelaxType(precond_, get_optional(node, "down_relax_type", 8), 1);
+    HYPRE_BoomerAMGSetCycleRelaxType(precond_, get_optional(node, "up_relax_type", 8), 2);
+    HYPRE_BoomerAMGSetCycleRelaxType(precond_, get_optional(node, "coarse_relax_type", 8), 3);
+  } else {
+    HYPRE_BoomerAMGSetRelaxType(precond_, get_optional(node, "relax_type", 8));
+  }
+  if (node["num_down_sweeps"] && node["num_up_sweeps"] && node["num_coarse_sweeps"]) {
+    HYPRE_BoomerAMGSetCycleNumSweeps(precond_, get_optional(node, "num_down_sweeps", 1), 1);
+    HYPRE_BoomerAMGSetCycleNumSweeps(precond_, get_optional(node, "num_up_sweeps", 1), 2);
+    HYPRE_BoomerAMGSetCycleNumSweeps(precond_, get_optional(node, "num_coarse_sweeps", 1), 3);
+  } else {
+    HYPRE_BoomerAMGSetNumSweeps(precond_, get_optional(node, "num_sweeps", 1));
+  }
+  HYPRE_BoomerAMGSetSmoothNumSweeps(precond_, get_optional(node, "smooth_num_sweeps", 1));
+  HYPRE_BoomerAMGSetTol(precond_, get_optional(node, "tolerance", 0.0));
+  HYPRE_BoomerAMGSetMaxIter(precond_, get_optional(node, "max_iterations", 1));
+  HYPRE_BoomerAMGSetRelaxOrder(precond_, get_optional(node, "relax_order", 1));
+  HYPRE_BoomerAMGSetMaxLevels(precond_, get_optional(node, "max_levels", 20));
+  HYPRE_BoomerAMGSetStrongThreshold(precond_, get_optional(node, "strong_threshold", 0.57));
+
+  if (node["non_galerkin_tol"]) {
+    HYPRE_BoomerAMGSetNonGalerkinTol(precond_, node["non_galerkin_tol"].as<double>());
+    if (node["non_galerkin_level_tols"]) {
+      YAML::Node ng = node["non_galerkin_level_tols"];
+      std::vector<int> levels = ng["levels"].as<std::vector<int>>();
+      std::vector<double> tol = ng["tolerances"].as<std::vector<double>>();
+      if (levels.size() != tol.size()) throw std::runtime_error("Hypre Config:: Invalid non_galerkin_level_tols");
+      for (size_t i = 0; i < levels.size(); i++) HYPRE_BoomerAMGSetLevelNonGalerkinTol(precond_, tol[i], levels[i]);
+    }
+  }
+  struct IntKey {
+    const char *key;
+    HYPRE_Int (*fn)(HYPRE_Solver, HYPRE_Int);
+  };
+  const IntKey int_keys[] = {
+      {"variant", HYPRE_BoomerAMGSetVariant},
+      {"rap2", HYPRE_BoomerAMGSetRAP2},
+      {"keep_transpose", HYPRE_BoomerAMGSetKeepTranspose},
+      {"interp_type", HYPRE_BoomerAMGSetInterpType},
+      {"min_coarse_size", HYPRE_BoomerAMGSetMinCoarseSize},
+      {"max_coarse_size", HYPRE_BoomerAMGSetMaxCoarseSize},
+      {"pmax_elmts", HYPRE_BoomerAMGSetAggPMaxElmts}, /* sic: the reference routes it there, :210-213 */
+      {"agg_num_levels", HYPRE_BoomerAMGSetAggNumLevels},
+      {"agg_interp_type", HYPRE_BoomerAMGSetAggInterpType},
+      {"agg_pmax_elmts", HYPRE_BoomerAMGSetAggPMaxElmts},
+      {"smooth_type", HYPRE_BoomerAMGSetSmoothType},
+      {"smooth_num_sweeps", HYPRE_BoomerAMGSetSmoothNumSweeps},
+      {"smooth_num_levels", HYPRE_BoomerAMGSetSmoothNumLevels},
+      {"ilu_type", HYPRE_BoomerAMGSetILUType},
+      {"ilu_level", HYPRE_BoomerAMGSetILULevel},
+      {"ilu_reordering_type", HYPRE_BoomerAMGSetILULocalReordering},
+      {"ilu_max_row_nnz", HYPRE_BoomerAMGSetILUMaxRowNnz},
+      {"ilu_max_iter", HYPRE_BoomerAMGSetILUMaxIter},
+      {"iterative_ilu_algorithm_type", HYPRE_BoomerAMGSetILUIterSetupType},
+      {"iterative_ilu_setup_option", HYPRE_BoomerAMGSetILUIterSetupOption},
+      {"iterative_ilu_max_iterations", HYPRE_BoomerAMGSetILUIterSetupMaxIter},
+      {"ilu_tri_solve", HYPRE_BoomerAMGSetILUTriSolve},
+      {"ilu_lower_jacobi_iters", HYPRE_BoomerAMGSetILULowerJacobiIters},
+      {"ilu_upper_jacobi_iters", HYPRE_BoomerAMGSetILUUpperJacobiIters},
+  };
+  for (const IntKey &k : int_keys)
+    if (node[k.key]) k.fn(precond_, node[k.key].as<int>());
+  if (node["trunc_factor"]) HYPRE_BoomerAMGSetTruncFactor(precond_, node["trunc_factor"].as<double>());
+  if (node["ilu_drop_tol"]) HYPRE_BoomerAMGSetILUDroptol(precond_, node["ilu_drop_tol"].as<double>());
+  if (node["iterative_ilu_tolerance"])
+    HYPRE_BoomerAMGSetILUIterSetupTolerance(precond_, node["iterative_ilu_tolerance"].as<double>());
+
+  precondSetupPtr_ = &HYPRE_BoomerAMGSetup;
+  precondSolvePtr_ = &HYPRE_BoomerAMGSolve;
+  precondDestroyPtr_ = &HYPRE_BoomerAMGDestroy;
+}
+
+// /root/reference/src/HypreSystem.cpp:328-370 -- outside the north-star path: the
+// handle exists, Setup/Solve report HYPRE_ERROR_GENERIC
+void HypreSystem::setup_ilu_precond() {
+  HYPRE_ILUCreate(&precond_);
+  precondSetupPtr_ = &HYPRE_ILUSetup;
+  precondSolvePtr_ = &HYPRE_ILUSolve;
+  precondDestroyPtr_ = &HYPRE_ILUDestroy;
+}
+void HypreSystem::setup_ilu() {
+  HYPRE_ILUCreate(&solver_);
+  solverDestroyPtr_ = &HYPRE_ILUDestroy;
+  solverSetupPtr_ = &HYPRE_ILUSetup;
+  solverPrecondPtr_ = nullptr;
+  solverSolvePtr_ = &HYPRE_ILUSolve;
+  usePrecond_ = false;
+}
+
+// /root/reference/src/HypreSystem.cpp:390-404
+void HypreSystem::setup_gmres() {
+  YAML::Node node = inpfile_["solver_settings"];
+  HYPRE_ParCSRGMRESCreate(comm_, &solver_);
+  HYPRE_ParCSRGMRESSetTol(solver_, get_optional(node, "tolerance", 1.0e-5));
+  HYPRE_ParCSRGMRESSetMaxIter(solver_, get_optional(node, "max_iterations", 1000));
+  HYPRE_ParCSRGMRESSetKDim(solver_, get_optional(node, "kspace", 10));
+  HYPRE_ParCSRGMRESSetPrintLevel(solver_, get_optional(node, "print_level", 4));
+  solverDestroyPtr_ = &HYPRE_ParCSRGMRESDestroy;
+  solverSetupPtr_ = &HYPRE_ParCSRGMRESSetup;
+  solverPrecondPtr_ = &HYPRE_ParCSRGMRESSetPrecond;
+  solverSolvePtr_ = &HYPRE_ParCSRGMRESSolve;
+  solverItersPtr_ = &HYPRE_ParCSRGMRESGetNumIterations;
+  solverResPtr_ = &HYPRE_ParCSRGMRESGetFinalRelativeResidualNorm;
+}
+
+// /root/reference/src/HypreSystem.cpp:423-438
+void HypreSystem::setup_bicg() {
+  YAML::Node node = inpfile_["solver_settings"];
+  HYPRE_ParCSRBiCGSTABCreate(comm_, &solver_);
+  HYPRE_ParCSRBiCGSTABSetTol(solver_, get_optional(node, "tolerance", 1.0e-5));
+  HYPRE_ParCSRBiCGSTABSetMaxIter(solver_, get_optional(node, "max_iterations", 1000));
+  HYPRE_ParCSRBiCGSTABSetPrintLevel(solver_, get_optional(node, "print_level", 4));
+  solverDestroyPtr_ = &HYPRE_ParCSRBiCGSTABDestroy;
+  solverSetupPtr_ = &HYPRE_ParCSRBiCGSTABSetup;
+  solverPrecondPtr_ = &HYPRE_ParCSRBiCGSTABSetPrecond;
+  solverSolvePtr_ = &HYPRE_ParCSRBiCGSTABSolve;
+  solverItersPtr_ = &HYPRE_ParCSRBiCGSTABGetNumIterations;
+  solverResPtr_ = &HYPRE_ParCSRBiCGSTABGetFinalRelativeResidualNorm;
+}
+
+// /root/reference/src/HypreSystem.cpp:372-388, :406-421, :440-455 -- stub families
+#define MI_SETUP_STUB(FUNC, NAME)                                                            \
+  void HypreSystem::FUNC() {                                                                 \
+    YAML::Node node = inpfile_["solver_settings"];                                           \
+    HYPRE_ParCSR##NAME##Create(comm_, &solver_);                                             \
+    HYPRE_ParCSR##NAME##SetTol(solver_, get_optional(node, "tolerance", 1.0e-5));            \
+    HYPRE_ParCSR##NAME##SetMaxIter(solver_, get_optional(node, "max_iterations", 1000));     \
+    HYPRE_ParCSR##NAME##SetPrintLevel(solver_, get_optional(node, "print_level", 4));        \
+    solverDestroyPtr_ = &HYPRE_ParCSR##NAME##Destroy;                                        \
+    solverSetupPtr_ = &HYPRE_ParCSR##NAME##Setup;                                            \
+    solverPrecondPtr_ = &HYPRE_ParCSR##NAME##SetPrecond;                                     \
+    solverSolvePtr_ = &HYPRE_ParCSR##NAME##Solve;                                            \
+  }
+MI_SETUP_STUB(setup_cogmres, COGMRES)
+MI_SETUP_STUB(setup_fgmres, FlexGMRES)
+MI_SETUP_STUB(setup_cg, PCG)
+#undef MI_SETUP_STUB
+
+// /root/reference/src/HypreSystem.cpp:499-523
+void HypreSystem::destroy_system() {
+  if (mat_) HYPRE_IJMatrixDestroy(mat_);
+  mat_ = NULL;
+  for (auto *vecs : {&rhs_, &sln_, &slnRef_}) {
+    for (auto &v : *vecs)
+      if (v) HYPRE_IJVectorDestroy(v);
+    vecs->clear();
+  }
+  if (solver_ && solverDestroyPtr_) solverDestroyPtr_(solver_);
+  if (precond_ && precondDestroyPtr_) precondDestroyPtr_(precond_);
+  solver_ = precond_ = NULL;
+}
+
+// /root/reference/src/HypreSystem.cpp:525-544: even contiguous split, remainder to the low ranks
+void HypreSystem::init_row_decomposition() {
+  if (iproc_ == 0) printf("\tComputing row decomposition\n");
+  const HYPRE_BigInt rowsPerProc = totalRows_ / nproc_;
+  const HYPRE_BigInt remainder = totalRows_ % nproc_;
+  iLower_ = rowsPerProc * iproc_ + std::min<HYPRE_BigInt>(iproc_, remainder);
+  iUpper_ = rowsPerProc * (iproc_ + 1) + std::min<HYPRE_BigInt>(iproc_ + 1, remainder) - 1;
+  numRows_ = iUpper_ - iLower_ + 1;
+  MPI_Barrier(comm_);
+  std::cout << "\tRank: " << std::setw(4) << iproc_ << " :: iLower = " << std::setw(9) << iLower_
+            << "; iUpper = " << std::setw(9) << iUpper_ << "; numRows = " << numRows_ << std::endl;
+  MPI_Barrier(comm_);
+  fflush(stdout);
+}
+
+// /root/reference/src/HypreSystem.cpp:546-598
+void HypreSystem::init_system() {
+  MPI_Barrier(comm_);
+  Stopwatch sw;
+  if (iproc_ == 0) printf("\tInitializing HYPRE data structures\n");
+  HYPRE_IJMatrixCreate(comm_, iLower_, iUpper_, iLower_, iUpper_, &mat_);
+  HYPRE_IJMatrixSetObjectType(mat_, HYPRE_PARCSR);
+  HYPRE_IJMatrixInitialize(mat_);
+  HYPRE_IJMatrixGetObject(mat_, (void **)&parMat_);
+  HYPRE_IJMatrixSetConstantValues(mat_, 0.0);
+
+  rhs_.assign((size_t)numSolves_, NULL);
+  sln_.assign((size_t)numSolves_, NULL);
+  parRhs_.assign((size_t)numSolves_, NULL);
+  parSln_.assign((size_t)numSolves_, NULL);
+  if (checkSolution_) {
+    slnRef_.assign((size_t)numSolves_, NULL);
+    parSlnRef_.assign((size_t)numSolves_, NULL);
+  }
+  auto make = [&](HYPRE_IJVector &v, HYPRE_ParVector &pv) {
+    HYPRE_IJVectorCreate(comm_, iLower_, iUpper_, &v);
+    HYPRE_IJVectorSetObjectType(v, HYPRE_PARCSR);
+    HYPRE_IJVectorSetNumComponents(v, numVectors_);
+    HYPRE_IJVectorInitialize(v);
+    HYPRE_IJVectorGetObject(v, (void **)&pv);
+    HYPRE_ParVectorSetConstantValues(pv, 0.0);
+  };
+  for (int i = 0; i < numSolves_; ++i) {
+    make(rhs_[(size_t)i], parRhs_[(size_t)i]);
+    make(sln_[(size_t)i], parSln_[(size_t)i]);
+    if (checkSolution_) make(slnRef_[(size_t)i], parSlnRef_[(size_t)i]);
+  }
+  MPI_Barrier(comm_);
+  push_timer("Initialize system", sw.seconds());
+  fflush(stdout);
+}
+
+// /root/reference/src/HypreSystem.cpp:600-636
+void HypreSystem::assemble_system() {
+  Stopwatch sw;
+  if (iproc_ == 0) printf("Assembling HYPRE data structures\n");
+  HYPRE_IJMatrixAssemble(mat_);
+  HYPRE_IJMatrixGetObject(mat_, (void **)&parMat_);
+  for (int i = 0; i < numSolves_; ++i) {
+    HYPRE_IJVectorAssemble(rhs_[(size_t)i]);
+    HYPRE_IJVectorAssemble(sln_[(size_t)i]);
+    HYPRE_IJVectorGetObject(rhs_[(size_t)i], (void **)&parRhs_[(size_t)i]);
+    HYPRE_IJVectorGetObject(sln_[(size_t)i], (void **)&parSln_[(size_t)i]);
+    if (checkSolution_) {
+      HYPRE_IJVectorAssemble(slnRef_[(size_t)i]);
+      HYPRE_IJVectorGetObject(slnRef_[(size_t)i], (void **)&parSlnRef_[(size_t)i]);
+    }
+  }
+  MPI_Barrier(comm_);
+  push_timer("Assemble system", sw.seconds());
+  std::vector<HYPRE_BigInt>().swap(rows_);
+  std::vector<HYPRE_BigInt>().swap(cols_);
+  std::vector<double>().swap(vals_);
+  checkMemory();
+}
+
+// /root/reference/src/HypreSystem.cpp:638-671
+void HypreSystem::checkMemory() {
+  int count = 0, device = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return;
+  (void)hipGetDevice(&device);
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  hipDeviceProp_t prop;
+  (void)hipGetDeviceProperties(&prop, device);
+  printf("rank=%d : %s : %s arch=%s : device=%d of %d : free memory=%1.8g GB, total memory=%1.8g GB\n", iproc_,
+         __FUNCTION__, prop.name, prop.gcnArchName, device, count, free_b / 1.e9, total_b / 1.e9);
+  fflush(stdout);
+}
+
+// /root/reference/src/HypreSystem.cpp:673-737 -- the call site of the hot path.
+// Timers as there: "Preconditioner setup" = SetPrecond + Setup, "Solve" = the
+// Solve calls only, all barrier-fenced.  The hierarchy is built once per matrix
+// (the reference rebuilds it for every component, :692 inside :681).
+void HypreSystem::solve() {
+  assemble_system();
+  double setup = 0.0, write_operators = 0.0, solve_t = 0.0;
+  iterations_.assign((size_t)numSolves_, 0);
+  relres_.assign((size_t)numSolves_, 0.0);
+
+  for (int i = 0; i < numSolves_; ++i) {
+    if (iproc_ == 0) printf("Setting up preconditioner\n");
+    MPI_Barrier(comm_);
+    Stopwatch s1;
+    if (i == 0) {
+      if (usePrecond_) solverPrecondPtr_(solver_, precondSolvePtr_, precondSetupPtr_, precond_);
+      if (iproc_ == 0) printf("Setting up solver\n");
+      solverSetupPtr_(solver_, parMat_, parRhs_[(size_t)i], parSln_[(size_t)i]);
+      checkMemory();
+    }
+    MPI_Barrier(comm_);
+    setup += s1.seconds();
+    fflush(stdout);
+
+    if (writeAmgMatrices_ && i == 0 && precond_) {
+      Stopwatch s2;
+      YAML::Node linsys = inpfile_["linear_system"];
+      std::string matfile = get_optional<std::string>(linsys, "matrix_file", "amg");
+      const std::string stem = matfile.substr(0, matfile.rfind("."));
+      hypre_ParAMGData *amg_data = (hypre_ParAMGData *)precond_;
+      hypre_ParCSRMatrix **A_array = hypre_ParAMGDataAArray(amg_data);
+      const int num_levels = hypre_ParAMGDataNumLevels(amg_data);
+      for (int l = 0; l < num_levels && A_array; ++l) {
+        const std::string fname = stem + "_level_" + std::to_string(l) + ".IJ";
+        hypre_ParCSRMatrixPrintIJ(A_array[l], 0, 0, fname.c_str());
+      }
+      MPI_Barrier(comm_);
+      write_operators += s2.seconds();
+    }
+
+    if (iproc_ == 0) printf("Solving the system\n");
+    MPI_Barrier(comm_);
+    Stopwatch s3;
+    solverSolvePtr_(solver_, parMat_, parRhs_[(size_t)i], parSln_[(size_t)i]);
+    MPI_Barrier(comm_);
+    solve_t += s3.seconds();
+    if (solverItersPtr_) solverItersPtr_(solver_, &iterations_[(size_t)i]);
+    if (solverResPtr_) solverResPtr_(solver_, &relres_[(size_t)i]);
+    if (iproc_ == 0)
+      printf("Solve %d : %d iterations, final relative residual %.6e\n", i, iterations_[(size_t)i],
+             relres_[(size_t)i]);
+    fflush(stdout);
+  }
+  push_timer("Preconditioner setup", setup);
+  if (writeAmgMatrices_) push_timer("Write AMG Matrices", write_operators);
+  push_timer("Solve", solve_t);
+  solveComplete_ = true;
+}
+
+// /root/reference/src/HypreSystem.cpp:739-769
+void HypreSystem::output_linear_system() {
+  if (!outputSystem_ && !outputSolution_) return;
+  Stopwatch sw;
+  if (outputSystem_) {
+    HYPRE_IJMatrixPrint(mat_, "IJM.mat");
+    for (int i = 0; i < numSolves_; ++i) {
+      HYPRE_IJVectorPrint(rhs_[(size_t)i], ("IJV" + std::to_string(i) + ".rhs").c_str());
+      HYPRE_IJVectorPrint(sln_[(size_t)i], ("IJV" + std::to_string(i) + ".sln").c_str());
+    }
+  }
+  if (outputSolution_)
+    for (int i = 0; i < numSolves_; ++i)
+      for (int j = 0; j < numVectors_; ++j) {
+        HYPRE_IJVectorSetComponent(sln_[(size_t)i], j);
+        HYPRE_IJVectorPrint(sln_[(size_t)i], ("IJV" + std::to_string(std::max(i, j)) + ".sln").c_str());
+      }
+  MPI_Barrier(comm_);
+  push_timer("Output system", sw.seconds());
+}
+
+// /root/reference/src/HypreSystem.cpp:771-845: |x - xref| < max(rtol*max(|x|,|xref|), atol)
+// per entry (:815-818); the verdict is reduced over ranks properly here.
+void HypreSystem::check_solution() {
+  if (!checkSolution_) {
+    if (syntheticOnes_ && solveComplete_) {
+      // the generators build b = A*1: the only known answer the reference holds
+      // (/root/reference/src/laplace_3d_weak_scaling.hpp:321)
+      const HYPRE_Int nloc = (HYPRE_Int)(iUpper_ - iLower_ + 1);
+      std::vector<double> h((size_t)nloc);
+      HYPRE_IJVectorSetComponent(sln_[0], 0);
+      HYPRE_IJVectorGetValues(sln_[0], nloc, NULL, h.data());
+      double err = 0.0;
+      for (double v : h) err = std::max(err, std::fabs(v - 1.0));
+      MPI_Allreduce(&err, &err, 1, MPI_DOUBLE, MPI_MAX, comm_);
+      if (iproc_ == 0) std::cout << "Synthetic system: max |x - 1| = " << err << std::endl;
+      return;
+    }
+    if (iproc_ == 0) std::cout << "Reference solution not provided; skipping error check." << std::endl;
+    return;
+  }
+  if (!solveComplete_) throw std::runtime_error("Solve was not called before check_solution");
+  Stopwatch sw;
+  const HYPRE_Int n = (HYPRE_Int)(iUpper_ - iLower_ + 1);
+  std::vector<double> hsln((size_t)n), href((size_t)n);
+  allClose_ = true;
+  for (int j = 0; j < numSolves_; ++j)
+    for (HYPRE_Int c = 0; c < numVectors_; c++) {
+      HYPRE_IJVectorSetComponent(sln_[(size_t)j], c);
+      HYPRE_IJVectorSetComponent(slnRef_[(size_t)j], c);
+      HYPRE_IJVectorGetValues(sln_[(size_t)j], n, NULL, hsln.data());
+      HYPRE_IJVectorGetValues(slnRef_[(size_t)j], n, NULL, href.data());
+      int printed = 0, close = 1;
+      double maxabs = 0.0, maxrel = 0.0;
+      for (HYPRE_Int k = 0; k < n; k++) {
+        const double diff = std::fabs(hsln[(size_t)k] - href[(size_t)k]);
+        const double scale = std::max(std::fabs(hsln[(size_t)k]), std::fabs(href[(size_t)k]));
+        const double bound = std::max(rtol_ * scale, atol_);
+        maxabs = std::max(maxabs, diff);
+        if (scale > 0) maxrel = std::max(maxrel, diff / scale);
+        if (diff >= bound) {
+          close = 0;
+          if (printed++ < 20)
+            std::cout << "rank " << iproc_ << " row " << k + iLower_ << ": " << hsln[(size_t)k] << " "
+                      << href[(size_t)k] << " " << diff << " " << bound << std::endl;
+        }
+      }
+      int all = close;
+      MPI_Allreduce(&close, &all, 1, MPI_INT, MPI_MIN, comm_);
+      MPI_Allreduce(&maxabs, &maxabs, 1, MPI_DOUBLE, MPI_MAX, comm_);
+      MPI_Allreduce(&maxrel, &maxrel, 1, MPI_DOUBLE, MPI_MAX, comm_);
+      if (!all) allClose_ = false;
+      if (iproc_ == 0)
+        std::cout << "Solve " << j << " comp " << c << " atol=" << atol_ << " rtol=" << rtol_
+                  << " max abs err=" << maxabs << " max rel err=" << maxrel << " allClose=" << all << std::endl;
+    }
+  MPI_Barrier(comm_);
+  push_timer("Check solution", sw.seconds());
+}
+
+// /root/reference/src/HypreSystem.cpp:847-889
+void HypreSystem::retrieve_timers(std::vector<std::string> &names, std::vector<std::vector<double>> &data) {
+  if (iproc_ != 0) return;
+  if (names.empty()) {
+    for (auto &t : timers_) names.push_back(t.first);
+    data.assign(names.size(), {});
+  }
+  for (auto &t : timers_) {
+    auto it = std::find(names.begin(), names.end(), t.first);
+    if (it != names.end()) data[(size_t)(it - names.begin())].push_back(t.second);
+  }
+}
+void HypreSystem::summarize_timers() {
+  if (iproc_ != 0) return;
+  std::cout << "\nTimer summary: " << std::endl;
+  for (auto &t : timers_)
+    std::cout << "    " << std::setw(25) << std::left << t.first << t.second << " seconds" << std::endl;
+}
+
+// /root/reference/src/HypreSystem.cpp:897-955: one entry per "row", ncols == NULL.
+// Host pointers go in; the library stages them itself.
+void HypreSystem::hypre_matrix_set_values() {
+  if (iproc_ == 0) printf("%s : loading matrix into HYPRE_IJMatrix\n", __FUNCTION__);
+  const size_t step = (size_t)1 << 30;  // HYPRE_Int nrows
+  for (size_t s = 0; s < vals_.size(); s += step) {
+    const size_t e = std::min(vals_.size(), s + step);
+    HYPRE_IJMatrixSetValues2(mat_, (HYPRE_Int)(e - s), NULL, rows_.data() + s, NULL, cols_.data() + s,
+                             vals_.data() + s);
+  }
+}
+
+// /root/reference/src/HypreSystem.cpp:957-1015
+void HypreSystem::hypre_vector_set_values(std::vector<HYPRE_IJVector> &vec, int component) {
+  HYPRE_IJVector v;
+  if (numSolves_ == 1) {
+    v = vec[0];
+    HYPRE_IJVectorSetComponent(v, component);
+  } else {
+    v = vec[(size_t)component];
+    HYPRE_IJVectorSetComponent(v, 0);
+  }
+  if (!vector_values_.empty())
+    HYPRE_IJVectorSetValues(v, (HYPRE_Int)vector_values_.size(), vector_indices_.data(), vector_values_.data());
+}
+
+void HypreSystem::read_vector_files(const YAML::Node &linsys, std::vector<std::string> &rhs,
+                                    std::vector<std::string> &sln) {
+  // /root/reference/src/HypreSystem.cpp:1040-1062, :1622-1644
+  rhs.assign((size_t)numComps_, "");
+  sln.assign((size_t)numComps_, "");
+  if (numComps_ == 1 && linsys["rhs_file"]) {
+    rhs[0] = linsys["rhs_file"].as<std::string>();
+    if (linsys["sln_file"]) {
+      sln[0] = linsys["sln_file"].as<std::string>();
+      checkSolution_ = true;
+    }
+  } else {
+    int count = 0;
+    for (int i = 0; i < numComps_; ++i) {
+      YAML::Node r = linsys["rhs_file" + std::to_string(i)];
+      if (!r) throw std::runtime_error("linear_system: rhs_file" + std::to_string(i) + " is missing");
+      rhs[(size_t)i] = r.as<std::string>();
+      YAML::Node s = linsys["sln_file" + std::to_string(i)];
+      if (s) {
+        sln[(size_t)i] = s.as<std::string>();
+        count++;
+      }
+    }
+    if (count == numComps_) checkSolution_ = true;
+  }
+}
+
+static void read_common_keys(const YAML::Node &linsys, HYPRE_Int &numComps, bool &segregated, HYPRE_Int &numSolves,
+                             HYPRE_Int &numVectors, double &rtol, double &atol) {
+  numComps = get_optional(linsys, "num_components", 1);
+  segregated = (bool)get_optional(linsys, "segregated_solve", 1);
+  numSolves = segregated ? numComps : 1;
+  numVectors = segregated ? 1 : numComps;
+  rtol = get_optional(linsys, "rtol", 1.0e-6);
+  atol = get_optional(linsys, "atol", 1.0e-8);
+}
+
+// ------------------------------------------------------------------ HYPRE IJ text files
+// /root/reference/src/HypreSystem.cpp:1021-1081 (the "native" reader there is dead code)
+void HypreSystem::load_hypre_format() {
+  YAML::Node linsys = inpfile_["linear_system"];
+  const int nfiles = get_optional(linsys, "num_partitions", nproc_);
+  read_common_keys(linsys, numComps_, segregatedSolve_, numSolves_, numVectors_, rtol_, atol_);
+  const std::string matfile = linsys["matrix_file"].as<std::string>();
+  std::vector<std::string> rhsfile, slnfile;
+  read_vector_files(linsys, rhsfile, slnfile);
+  determine_ij_system_sizes(matfile, nfiles);
+  init_row_decomposition();
+  init_system();
+  build_ij_matrix(matfile, nfiles);
+  build_ij_vector(rhsfile, nfiles, rhs_);
+  if (checkSolution_) build_ij_vector(slnfile, nfiles, slnRef_);
+}
+
+// /root/reference/src/HypreSystem.cpp:1138-1176: global size from the file headers
+void HypreSystem::determine_ij_system_sizes(const std::string &matfile, int nfiles) {
+  Stopwatch sw;
+  long long imin = 0, imax = 0;  // ids are 0-based (the reference starts both at 0 as well)
+  for (int ii = iproc_; ii < nfiles; ii += nproc_) {
+    const std::string fn = part_name(matfile, ii);
+    FILE *fh = fopen(fn.c_str(), "r");
+    if (!fh) throw std::runtime_error("Cannot open matrix file: " + fn);
+    long long il, iu, jl, ju;
+    if (fscanf(fh, "%lld %lld %lld %lld", &il, &iu, &jl, &ju) != 4) {
+      fclose(fh);
+      throw std::runtime_error("Cannot read IJ header of " + fn);
+    }
+    fclose(fh);
+    imin = std::min(imin, il);
+    imax = std::max(imax, iu);
+  }
+  long long gmin = imin, gmax = imax;
+  MPI_Allreduce(&imin, &gmin, 1, MPI_LONG_LONG_INT, MPI_MIN, comm_);
+  MPI_Allreduce(&imax, &gmax, 1, MPI_LONG_LONG_INT, MPI_MAX, comm_);
+  totalRows_ = (gmax - gmin) + 1;
+  M_ = N_ = (int)totalRows_;
+  MPI_Barrier(comm_);
+  push_timer("IJ : determine system size", sw.seconds());
+}
+
+// /root/reference/src/HypreSystem.cpp:1181-1247: every rank scans every file that
+// overlaps its row range and keeps its own rows
+void HypreSystem::build_ij_matrix(const std::string &matfile, int nfiles) {
+  MPI_Barrier(comm_);
+  Stopwatch sw;
+  if (iproc_ == 0) printf("%s : Reading %d HYPRE IJ Matrix files\n", __FUNCTION__, nfiles);
+  rows_.clear();
+  cols_.clear();
+  vals_.clear();
+  for (int ii = 0; ii < nfiles; ii++) {
+    const std::string fn = part_name(matfile, ii);
+    MappedFile mf(fn);
+    TextCursor cur(mf.data, mf.size);
+    auto ln = cur.line();
+    const char *b = ln.first;
+    long long il, iu, jl, ju;
+    if (!(next_ll(b, ln.second, il) && next_ll(b, ln.second, iu) && next_ll(b, ln.second, jl) &&
+          next_ll(b, ln.second, ju)))
+      throw std::runtime_error("Cannot read IJ header of " + fn);
+    if (std::min<long long>(iUpper_ + 1, iu + 1) - std::max<long long>(iLower_, il) <= 0) continue;
+    while (!cur.done()) {
+      ln = cur.line();
+      b = ln.first;
+      long long r, c;
+      double v;
+      if (!next_ll(b, ln.second, r)) continue;
+      if (!(next_ll(b, ln.second, c) && next_dbl(b, ln.second, v)))
+        throw std::runtime_error("Malformed IJ matrix line in " + fn);
+      if (r >= iLower_ && r <= iUpper_) {
+        rows_.push_back(r);
+        cols_.push_back(c);
+        vals_.push_back(v);
+      }
+    }
+  }
+  nnz_ = (long long)vals_.size();
+  hypre_matrix_set_values();
+  MPI_Barrier(comm_);
+  push_timer("IJ : read and build matrix", sw.seconds());
+  fflush(stdout);
+}
+
+// /root/reference/src/HypreSystem.cpp:1252-1318
+void HypreSystem::build_ij_vector(std::vector<std::string> &vecfiles, int nfiles, std::vector<HYPRE_IJVector> &vec) {
+  MPI_Barrier(comm_);
+  Stopwatch sw;
+  for (int i = 0; i < numComps_; ++i) {
+    const std::string &vecfile = vecfiles[(size_t)i];
+    if (iproc_ == 0)
+      printf("%s : Reading %d HYPRE IJ Vector files %s\n", __FUNCTION__, nfiles, vecfile.c_str());
+    vector_indices_.clear();
+    vector_values_.clear();
+    for (int ii = 0; ii < nfiles; ii++) {
+      const std::string fn = part_name(vecfile, ii);
+      MappedFile mf(fn);
+      TextCursor cur(mf.data, mf.size);
+      auto ln = cur.line();
+      const char *b = ln.first;
+      long long il, iu;
+      if (!(next_ll(b, ln.second, il) && next_ll(b, ln.second, iu)))
+        throw std::runtime_error("Cannot read IJ vector header of " + fn);
+      if (std::min<long long>(iUpper_ + 1, iu + 1) - std::max<long long>(iLower_, il) <= 0) continue;
+      while (!cur.done()) {
+        ln = cur.line();
+        b = ln.first;
+        long long r;
+        double v;
+        if (!next_ll(b, ln.second, r)) continue;
+        if (!next_dbl(b, ln.second, v)) throw std::runtime_error("Malformed IJ vector line in " + fn);
+        if (r >= iLower_ && r <= iUpper_) {
+          vector_indices_.push_back(r);
+          vector_values_.push_back(v);
+        }
+      }
+    }
+    hypre_vector_set_values(vec, i);
+  }
+  MPI_Barrier(comm_);
+  push_timer("IJ : read and build vector", sw.seconds());
+  fflush(stdout);
+}
+
+// ------------------------------------------------------------------ Matrix Market
+// /root/reference/src/HypreSystem.cpp:1613-1665
+void HypreSystem::load_matrix_market() {
+  YAML::Node linsys = inpfile_["linear_system"];
+  read_common_keys(linsys, numComps_, segregatedSolve_, numSolves_, numVectors_, rtol_, atol_);
+  const std::string matfile = linsys["matrix_file"].as<std::string>();
+  std::vector<std::string> rhsfile, slnfile;
+  read_vector_files(linsys, rhsfile, slnfile);
+  complexNumbers_ = get_optional(linsys, "complex_numbers", false);
+  determine_mm_system_sizes(matfile);
+  init_row_decomposition();
+  init_system();
+  build_mm_matrix(matfile);
+  build_mm_vector(rhsfile, rhs_);
+  if (checkSolution_) build_mm_vector(slnfile, slnRef_);
+}
+
+// /root/reference/src/HypreSystem.cpp:1670-1712
+void HypreSystem::determine_mm_system_sizes(const std::string &matfile) {
+  MPI_Barrier(comm_);
+  Stopwatch sw;
+  MappedFile mf(matfile);
+  TextCursor cur(mf.data, mf.size);
+  MMHeader h = read_mm_header(cur, matfile);
+  if (!h.coordinate) throw std::runtime_error("Invalid matrix market file encountered");
+  const int mult = complexNumbers_ ? 2 : 1;
+  totalRows_ = (HYPRE_BigInt)mult * h.m;
+  M_ = (int)totalRows_;
+  N_ = (int)(mult * h.n);
+  nnz_ = (long long)mult * mult * h.nnz;
+  MPI_Barrier(comm_);
+  push_timer("Matrix market : determine system size", sw.seconds());
+  fflush(stdout);
+}
+
+// /root/reference/src/HypreSystem.cpp:1717-1850: 1-based "i j v" lines, every rank
+// keeps its own rows; complex entries become 2x2 real blocks (:1810-1833); as in
+// the reference, symmetric files are NOT mirrored.
+void HypreSystem::build_mm_matrix(const std::string &matfile) {
+  MPI_Barrier(comm_);
+  Stopwatch sw;
+  if (iproc_ == 0) printf("%s : Reading from %s into HYPRE_IJMatrix\n", __FUNCTION__, matfile.c_str());
+  MappedFile mf(matfile);
+  TextCursor cur(mf.data, mf.size);
+  (void)read_mm_header(cur, matfile);
+  rows_.clear();
+  cols_.clear();
+  vals_.clear();
+  const long long lo = complexNumbers_ ? iLower_ / 2 : iLower_;
+  const long long hi = complexNumbers_ ? (iUpper_ - 1) / 2 : iUpper_;
+  while (!cur.done()) {
+    auto ln = cur.line();
+    const char *b = ln.first;
+    if (b < ln.second && *b == '%') continue;
+    long long r, c;
+    double v, vi = 0.0;
+    if (!next_ll(b, ln.second, r)) continue;
+    if (!(next_ll(b, ln.second, c) && next_dbl(b, ln.second, v)))
+      throw std::runtime_error("Malformed matrix market line in " + matfile);
+    if (complexNumbers_ && !next_dbl(b, ln.second, vi))
+      throw std::runtime_error("Complex matrix market line without imaginary part in " + matfile);
+    r--;
+    c--;
+    if (r < lo || r > hi) continue;
+    if (!complexNumbers_) {
+      rows_.push_back(r);
+      cols_.push_back(c);
+      vals_.push_back(v);
+    } else {
+      const long long rr[4] = {2 * r, 2 * r, 2 * r + 1, 2 * r + 1};
+      const long long cc[4] = {2 * c, 2 * c + 1, 2 * c, 2 * c + 1};
+      const double vv[4] = {v, -vi, vi, v};
+      for (int q = 0; q < 4; q++) {
+        rows_.push_back(rr[q]);
+        cols_.push_back(cc[q]);
+        vals_.push_back(vv[q]);
+      }
+    }
+  }
+  hypre_matrix_set_values();
+  MPI_Barrier(comm_);
+  push_timer("Matrix market : read and build matrix", sw.seconds());
+  fflush(stdout);
+}
+
+// /root/reference/src/HypreSystem.cpp:1855-1969: "array" files, one value per line,
+// line index = global row (two rows per line for complex)
+void HypreSystem::build_mm_vector(std::vector<std::string> &mmfiles, std::vector<HYPRE_IJVector> &vec) {
+  MPI_Barrier(comm_);
+  Stopwatch sw;
+  for (int j = 0; j < numComps_; j++) {
+    const std::string &mmfile = mmfiles[(size_t)j];
+    if (iproc_ == 0) printf("%s : Reading from %s into HYPRE_IJVector\n", __FUNCTION__, mmfile.c_str());
+    MappedFile mf(mmfile);
+    TextCursor cur(mf.data, mf.size);
+    MMHeader h = read_mm_header(cur, mmfile);
+    if (!h.array) throw std::runtime_error("Invalid matrix market file encountered: " + mmfile);
+    vector_indices_.clear();
+    vector_values_.clear();
+    long long i = 0;
+    while (!cur.done()) {
+      auto ln = cur.line();
+      const char *b = ln.first;
+      if (b < ln.second && *b == '%') continue;
+      double v, vi = 0.0;
+      if (!next_dbl(b, ln.second, v)) continue;
+      if (complexNumbers_) (void)next_dbl(b, ln.second, vi);
+      if (i >= iLower_ && i <= iUpper_) {
+        vector_indices_.push_back(i);
+        vector_values_.push_back(v);
+        if (complexNumbers_ && i + 1 <= iUpper_) {
+          vector_indices_.push_back(i + 1);
+          vector_values_.push_back(vi);
+        }
+      }
+      i += complexNumbers_ ? 2 : 1;
+    }
+    hypre_vector_set_values(vec, j);
+  }
+  MPI_Barrier(comm_);
+  push_timer("Matrix market : read and build vector", sw.seconds());
+  fflush(stdout);
+}
+
+// ------------------------------------------------------------------ synthetic problems
+// build_27pt_stencil: /root/reference/src/HypreSystem.cpp:1476-1607 +
+// laplace_3d_weak_scaling.hpp: nx,ny,nz are the PER-RANK
+// box, the process grid is the reference's factorisation, rows are numbered rank
+// by rank (x fastest inside a box), diag 26 / off -1, rhs = row sum so x* = 1.
+// Unlike the reference, off-rank columns are the TRUE neighbour ids (the
+// reference folds them onto rank 0/1) and one rank is allowed.
+// laplace_3d: nx,ny,nz are GLOBAL, lexicographic numbering, contiguous row
+// partition (z-slabs); stencil 7 (diag 6) unless `stencil: 27`.
+void HypreSystem::build_stencil(int default_stencil, bool per_rank_dims) {
+  Stopwatch sw;
+  YAML::Node linsys = inpfile_["linear_system"];
+  read_common_keys(linsys, numComps_, segregatedSolve_, numSolves_, numVectors_, rtol_, atol_);
+  nx_ = get_optional(linsys, "nx", 128);
+  ny_ = get_optional(linsys, "ny", 128);
+  nz_ = get_optional(linsys, "nz", 128);
+  const int stencil = get_optional(linsys, "stencil", default_stencil);
+  if (stencil != 7 && stencil != 27) throw std::runtime_error("linear_system: stencil must be 7 or 27");
+  if (numSolves_ != 1 || numVectors_ != 1)
+    throw std::runtime_error("synthetic stencil systems have one component");
+
+  HYPRE_BigInt nnz = 0;
+  HYPRE_BigInt *rows = nullptr, *cols = nullptr;
+  HYPRE_Complex *vals = nullptr, *rhs = nullptr;
+  if (!per_rank_dims) {
+    totalRows_ = (HYPRE_BigInt)nx_ * ny_ * nz_;
+    M_ = N_ = (int)totalRows_;
+    init_row_decomposition();
+    init_system();
+    if (HYPRE_MI_Laplace3D(nx_, ny_, nz_, stencil, iLower_, iUpper_, &nnz, &rows, &cols, &vals, &rhs))
+      throw std::runtime_error("synthetic generator failed");
+    const size_t step = (size_t)1 << 30;
+    for (size_t s = 0; s < (size_t)nnz; s += step) {
+      const size_t e = std::min<size_t>((size_t)nnz, s + step);
+      HYPRE_IJMatrixSetValues2(mat_, (HYPRE_Int)(e - s), NULL, rows + s, NULL, cols + s, vals + s);
+    }
+    vector_indices_.resize((size_t)numRows_);
+    for (HYPRE_BigInt i = 0; i < numRows_; i++) vector_indices_[(size_t)i] = iLower_ + i;
+    HYPRE_IJVectorSetComponent(rhs_[0], 0);
+    HYPRE_IJVectorSetValues(rhs_[0], (HYPRE_Int)numRows_, vector_indices_.data(), rhs);
+    HYPRE_MI_Free(rows), HYPRE_MI_Free(cols), HYPRE_MI_Free(vals), HYPRE_MI_Free(rhs);
+  } else {
+    int npx, npy, npz;
+    process_grid(nproc_, npx, npy, npz);
+    if (iproc_ == 0) printf("\tProcess distribution: %d x %d x %d\n", npx, npy, npz);
+    const long long nloc = (long long)nx_ * ny_ * nz_;
+    totalRows_ = nloc * nproc_;
+    M_ = N_ = (int)totalRows_;
+    init_row_decomposition();  // equals [rank*nloc, (rank+1)*nloc)
+    init_system();
+    const int pz = iproc_ / (npx * npy), py = (iproc_ - pz * npx * npy) / npx, px = iproc_ % npx;
+    const long long GX = (long long)npx * nx_, GY = (long long)npy * ny_, GZ = (long long)npz * nz_;
+    const double dv = (stencil == 27) ? 26.0 : 6.0;
+    rows_.clear(), cols_.clear(), vals_.clear();
+    rows_.reserve((size_t)nloc * (size_t)stencil);
+    cols_.reserve((size_t)nloc * (size_t)stencil);
+    vals_.reserve((size_t)nloc * (size_t)stencil);
+    vector_indices_.resize((size_t)nloc);
+    vector_values_.resize((size_t)nloc);
+    auto gid = [&](long long X, long long Y, long long Z) {
+      const int bx = (int)(X / nx_), by = (int)(Y / ny_), bz = (int)(Z / nz_);
+      const long long owner = bx + (long long)npx * (by + (long long)npy * bz);
+      return owner * nloc + (X % nx_) + (long long)nx_ * ((Y % ny_) + (long long)ny_ * (Z % nz_));
+    };
+    for (int lz = 0; lz < nz_; lz++)
+      for (int ly = 0; ly < ny_; ly++)
+        for (int lx = 0; lx < nx_; lx++) {
+          const long long X = (long long)px * nx_ + lx, Y = (long long)py * ny_ + ly, Z = (long long)pz * nz_ + lz;
+          const long long row = gid(X, Y, Z);
+          double sum = 0.0;
+          for (int dz = -1; dz <= 1; dz++)
+            for (int dy = -1; dy <= 1; dy++)
+              for (int dx = -1; dx <= 1; dx++) {
+                if (stencil == 7 && std::abs(dx) + std::abs(dy) + std::abs(dz) > 1) continue;
+                const long long XX = X + dx, YY = Y + dy, ZZ = Z + dz;
+                if (XX < 0 || XX >= GX || YY < 0 || YY >= GY || ZZ < 0 || ZZ >= GZ) continue;
+                const long long col = gid(XX, YY, ZZ);
+                const double v = (col == row) ? dv : -1.0;
+                rows_.push_back(row);
+                cols_.push_back(col);
+                vals_.push_back(v);
+                sum += v;
+              }
+          const long long li = row - iLower_;
+          vector_indices_[(size_t)li] = row;
+          vector_values_[(size_t)li] = sum;
+        }
+    nnz_ = (long long)vals_.size();
+    hypre_matrix_set_values();
+    hypre_vector_set_values(rhs_, 0);
+  }
+  syntheticOnes_ = true;
+  MPI_Barrier(comm_);
+  push_timer(per_rank_dims ? "Build 27Pt Stencil HYPRE matrix" : "Build laplace_3d HYPRE matrix", sw.seconds());
+  fflush(stdout);
+}
+
+}  // namespace nalu

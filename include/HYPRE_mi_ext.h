@@ -14,6 +14,8 @@ extern "C" {
 #define HYPRE_MI_UNIQUE_ID_BYTES 128
 HYPRE_Int HYPRE_MI_CommGetUniqueId(void *id128);               /* rank 0, then broadcast by the launcher */
 HYPRE_Int HYPRE_MI_CommInitRCCL(const void *id128, HYPRE_Int rank, HYPRE_Int size);
+/* RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun's env); the id travels over TCP */
+HYPRE_Int HYPRE_MI_CommInitFromEnv(void);
 /* host-staged transport supplied by the caller (tests: torch.distributed gloo) */
 typedef void (*HYPRE_MI_AllreduceFn)(void *ctx, void *buf, size_t count, int dtype /*0 f64,1 i64,2 i32,3 u8*/,
                                      int op /*0 sum,1 min,2 max*/);
@@ -23,6 +25,8 @@ typedef void (*HYPRE_MI_ExchangeFn)(void *ctx, int nsend, const int *send_peers,
                                     const size_t *recv_bytes);
 HYPRE_Int HYPRE_MI_CommInitCallbacks(void *ctx, HYPRE_MI_AllreduceFn ar, HYPRE_MI_AllgatherFn ag,
                                      HYPRE_MI_ExchangeFn ex, HYPRE_Int rank, HYPRE_Int size);
+/* one-rank exercise of the RCCL transport (dlopen, init, all-reduce, all-gather, send/recv) */
+HYPRE_Int HYPRE_MI_CommSelfTestRCCL(void);
 HYPRE_Int HYPRE_MI_CommFinalize(void);
 HYPRE_Int HYPRE_MI_CommRank(HYPRE_Int *rank);
 HYPRE_Int HYPRE_MI_CommSize(HYPRE_Int *size);

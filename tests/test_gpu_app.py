@@ -1,0 +1,195 @@
+"""The C++ driver (hypre_app = HypreSystem + main over the C ABI) end to end:
+YAML in, MatrixMarket / HYPRE-IJ / synthetic systems loaded, GMRES or BiCGSTAB +
+BoomerAMG solve on the GPU, solution checked with the reference's own closeness
+rule (/root/reference/src/HypreSystem.cpp:815-818) against scipy's direct solve."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spl
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+APP = os.path.join(ROOT, "hypre-mini-app_amd", "hypre_app")
+
+# the boomeramg_settings block of the upstream sample input (/root/reference/etc/hypre_app.yaml:33-42)
+UPSTREAM_AMG = """
+boomeramg_settings:
+  print_level: 1
+  max_iterations: 1
+  tolerance: 0.0
+  coarsen_type: 6
+  cycle_type: 1
+  relax_type: 6
+  relax_order: 1
+  num_sweeps: 2
+  max_levels: 20
+  interp_type: 0
+  strong_threshold: 0.57
+"""
+DEFAULT_AMG = """
+boomeramg_settings:
+  print_level: 1
+"""
+
+
+def _run(tmp_path, yaml_text):
+    inp = tmp_path / "input.yaml"
+    inp.write_text(yaml_text)
+    p = subprocess.run([APP, str(inp)], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:]
+    return p.stdout
+
+
+def _system(n, seed, nonsym=False):
+    """2-D 5-point convection-diffusion (M-matrix), random rhs, direct solution."""
+    rng = np.random.default_rng(seed)
+    T = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(n, n))
+    A = (sp.kron(sp.eye(n), T) + sp.kron(T, sp.eye(n))).tocsr()
+    if nonsym:
+        C = sp.diags([-0.3, 0.3], [-1, 0], shape=(n, n))
+        A = (A + sp.kron(sp.eye(n), C)).tocsr()
+    A.sort_indices()
+    x = rng.standard_normal(n * n)
+    b = A @ x
+    return A, b, spl.spsolve(A.tocsc(), b)
+
+
+def _write_mm_matrix(path, A):
+    coo = A.tocoo()
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n% written by tests/test_gpu_app.py\n")
+        f.write(f"{A.shape[0]} {A.shape[1]} {coo.nnz}\n")
+        for r, c, v in zip(coo.row, coo.col, coo.data):
+            f.write(f"{r + 1} {c + 1} {v:.17g}\n")
+
+
+def _write_mm_vector(path, v):
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix array real general\n% vector\n")
+        f.write(f"{len(v)} 1\n")
+        for x in v:
+            f.write(f"{x:.17g}\n")
+
+
+def _write_ij(base, A, vecs, nparts):
+    n = A.shape[0]
+    bounds = np.linspace(0, n, nparts + 1).astype(int)
+    A = A.tocsr()
+    for p in range(nparts):
+        lo, hi = bounds[p], bounds[p + 1] - 1
+        with open(f"{base}/mat.ij.{p:05d}", "w") as f:
+            f.write(f"{lo} {hi} {lo} {hi}\n")
+            for r in range(lo, hi + 1):
+                for k in range(A.indptr[r], A.indptr[r + 1]):
+                    f.write(f"{r} {A.indices[k]} {A.data[k]:.17g}\n")
+        for name, v in vecs.items():
+            with open(f"{base}/{name}.{p:05d}", "w") as f:
+                f.write(f"{lo} {hi}\n")
+                for r in range(lo, hi + 1):
+                    f.write(f"{r} {v[r]:.17g}\n")
+
+
+def test_matrix_market_upstream_sample_settings(tmp_path):
+    A, b, x = _system(40, 1)
+    _write_mm_matrix(tmp_path / "mat.mm", A)
+    _write_mm_vector(tmp_path / "rhs.mm", b)
+    _write_mm_vector(tmp_path / "sln.mm", x)
+    out = _run(tmp_path, """
+linear_system:
+  type: matrix_market
+  matrix_file: mat.mm
+  rhs_file: rhs.mm
+  sln_file: sln.mm
+  write_outputs: false
+  num_partitions: 2
+  rtol: 1.0e-5
+  atol: 1.0e-7
+
+solver_settings:
+  method: gmres
+  preconditioner: boomeramg
+  tolerance: 1.0e-12
+  max_iterations: 100
+  kspace: 10
+  print_level: 4
+  reuse_preconditioner: false
+""" + UPSTREAM_AMG)
+    assert "allClose=1" in out
+    assert "Timer summary" in out and "Preconditioner setup" in out and "Solve" in out
+
+
+def test_hypre_ij_partitions_bicgstab_csv(tmp_path):
+    A, b, x = _system(32, 2, nonsym=True)
+    _write_ij(str(tmp_path), A, {"rhs.ij": b, "sln.ij": x}, 3)
+    out = _run(tmp_path, """
+linear_system:
+  type: hypre_ij
+  matrix_file: mat.ij
+  rhs_file: rhs.ij
+  sln_file: sln.ij
+  num_partitions: 3
+  rtol: 1.0e-5
+  atol: 1.0e-7
+  write_solution: true
+
+solver_settings:
+  method: bicg
+  preconditioner: boomeramg
+  tolerance: 1.0e-12
+  max_iterations: 100
+  print_level: 0
+  num_tests: 2
+  csv_profile_file: timers.csv
+""" + DEFAULT_AMG)
+    assert out.count("allClose=1") == 2
+    rows = (tmp_path / "timers.csv").read_text().strip().splitlines()
+    assert rows[0].split(",")[-1] in ("Solve", "Check solution", "Output system") and len(rows) == 3
+    got = np.loadtxt(tmp_path / "IJV0.sln.00000", skiprows=1)
+    assert np.allclose(got[:, 1], x, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("typ,extra,n", [("laplace_3d", "stencil: 7", 24), ("laplace_3d", "stencil: 27", 12),
+                                         ("build_27pt_stencil", "", 14)])
+def test_synthetic_known_answer(tmp_path, typ, extra, n):
+    out = _run(tmp_path, f"""
+linear_system:
+  type: {typ}
+  nx: {n}
+  ny: {n}
+  nz: {n}
+  {extra}
+
+solver_settings:
+  method: gmres
+  preconditioner: boomeramg
+  tolerance: 1.0e-10
+  max_iterations: 100
+  kspace: 50
+  print_level: 2
+""" + DEFAULT_AMG)
+    m = re.search(r"max \|x - 1\| = ([0-9.eE+-]+)", out)
+    assert m and float(m.group(1)) < 1e-7, out[-2000:]
+    m = re.search(r"Solve 0 : (\d+) iterations, final relative residual ([0-9.eE+-]+)", out)
+    assert m and int(m.group(1)) < 40 and float(m.group(2)) <= 1e-10
+
+
+def test_unsupported_family_reports_error(tmp_path):
+    inp = tmp_path / "input.yaml"
+    inp.write_text("""
+linear_system:
+  type: laplace_3d
+  nx: 8
+  ny: 8
+  nz: 8
+solver_settings:
+  method: cg
+  preconditioner: none
+""")
+    p = subprocess.run([APP, str(inp)], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=300)
+    assert "not implemented" in p.stdout

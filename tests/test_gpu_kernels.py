@@ -127,3 +127,9 @@ def test_vector_get_set_indices(mi):
     with pytest.raises(mi.HypreError):
         mi.call("HYPRE_IJVectorGetValues", v.h, 1, bad, out)
     mi.call("HYPRE_ClearAllErrors")
+
+
+def test_rccl_transport_single_rank(mi):
+    """The RCCL transport cannot be run with two ranks on a one-GPU box (RCCL refuses a
+    duplicate device); this drives every RCCL entry point it uses in a world of one."""
+    mi.call("HYPRE_MI_CommSelfTestRCCL")
