@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.npz.
+
+The reference cannot run here (libHYPRE is absent: SURVEY.md 0.2, 8c), so these
+are NOT outputs of the reference.  They freeze (a) analytic / direct-solve known
+answers (x* = 1 for the generator systems, scipy spsolve for a random system)
+and (b) the oracle's own iteration histories and hierarchy shapes at the commit
+that produced them, so that a later change to oracle/ that alters its numerics is
+noticed.  Run from the repo root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spl
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import oracle_ctypes as oc  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+CASES = [
+    dict(name="lap7_8", n=8, stencil=7, kdim=50, tol=1e-8, nparts=1),
+    dict(name="lap7_16", n=16, stencil=7, kdim=50, tol=1e-8, nparts=1),
+    dict(name="lap7_16_k5", n=16, stencil=7, kdim=5, tol=1e-10, nparts=1),
+    dict(name="lap27_10", n=10, stencil=27, kdim=50, tol=1e-8, nparts=1),
+    dict(name="lap7_12_p2", n=12, stencil=7, kdim=50, tol=1e-8, nparts=2),
+]
+
+
+def run_case(c):
+    n = c["n"]
+    A, b = oc.Csr.laplace(n, n, n, c["stencil"])
+    N = n ** 3
+    kw = dict(gs_chunk=8)
+    if c["nparts"] > 1:
+        per, rem = divmod(N, c["nparts"])
+        kw["part_starts"] = [per * r + min(r, rem) for r in range(c["nparts"])] + [N]
+    amg = oc.Amg(A, oc.default_params(**kw))
+    x, info = oc.gmres(A, b, kdim=c["kdim"], tol=c["tol"], maxit=100, amg=amg)
+    sizes = np.array([amg.level_A(l).shape[0] for l in range(amg.num_levels)])
+    nnzs = np.array([amg.level_A(l).nnz for l in range(amg.num_levels)])
+    return dict(rhs=b, x=x, norms=info["norms"], iters=info["iters"], rel_res=info["rel_res"], level_rows=sizes,
+                level_nnz=nnzs, cf0=amg.level_cf(0).astype(np.int8))
+
+
+def main():
+    for c in CASES:
+        np.savez_compressed(os.path.join(HERE, c["name"] + ".npz"), **run_case(c))
+        print("wrote", c["name"])
+    # independent direct-solve fixture: random M-matrix, scipy spsolve
+    rng = np.random.default_rng(20260101)
+    n = 400
+    M = sp.random(n, n, density=0.02, random_state=rng, format="csr")
+    M = (M - sp.diags(M.diagonal())).tocsr()
+    M = (-abs(M) + sp.diags(abs(M).sum(axis=1).A1 + 0.25)).tocsr()
+    M.sort_indices()
+    xs = rng.standard_normal(n)
+    b = M @ xs
+    xd = spl.spsolve(M.tocsc(), b)
+    np.savez_compressed(os.path.join(HERE, "random_mmatrix_400.npz"), indptr=M.indptr, indices=M.indices, data=M.data,
+                        rhs=b, x_direct=xd)
+    print("wrote random_mmatrix_400")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,101 @@
+"""CPU: the C-ABI library loads, exports every symbol include/*.h declares, and the
+product path refuses to run without a GPU (no CPU fallback).  No compute calls."""
+import ctypes
+import glob
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    names = set()
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        text = open(h).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        # expand the stub-family macro
+        for fam in re.findall(r"^MI_HYPRE_DECLARE_KRYLOV_STUB\((\w+)\)", text, flags=re.M):
+            for f in ("Create", "Destroy", "Setup", "Solve", "SetPrecond", "SetTol", "SetMaxIter", "SetKDim",
+                      "SetPrintLevel"):
+                names.add(f"HYPRE_ParCSR{fam}{f}")
+        text = re.sub(r"#define MI_HYPRE_DECLARE_KRYLOV_STUB.*?\n\n", "\n", text, flags=re.S)
+        for m in re.finditer(r"^\s*(?:HYPRE_Int|void \*|void|const char \*|hypre_ParCSRMatrix \*\*)\s*((?:HYPRE|hypre)_\w+)\s*\(",
+                             text, flags=re.M):
+            names.add(m.group(1))
+    return names
+
+
+def test_every_declared_symbol_is_exported(mi_lib):
+    lib = mi_lib.lib()
+    names = _declared_symbols()
+    assert len(names) > 200
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+    # the entry points the reference driver binds into its function-pointer table
+    # (/root/reference/src/HypreSystem.cpp:323-325, :400-403)
+    for n in ("HYPRE_BoomerAMGSetup", "HYPRE_BoomerAMGSolve", "HYPRE_BoomerAMGDestroy", "HYPRE_ParCSRGMRESSetup",
+              "HYPRE_ParCSRGMRESSetPrecond", "HYPRE_ParCSRGMRESSolve", "HYPRE_ParCSRGMRESDestroy"):
+        assert n in names
+
+
+def test_no_cpu_fallback():
+    """Without a HIP device HYPRE_Init and every compute entry point fail loudly."""
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+import __graft_entry__ as ge
+mi = ge.load_binding()
+import ctypes as C
+n = C.c_int(0)
+try:
+    import torch
+    has = torch.cuda.is_available()
+except Exception:
+    has = False
+if has:
+    print("HAS_GPU")
+    sys.exit(0)
+rc = mi.lib().HYPRE_Init()
+msg = mi.lib().HYPRE_MI_LastErrorMessage().decode()
+assert rc != 0 and "no HIP device" in msg and "no CPU path" in msg, (rc, msg)
+A = mi.IJMatrix.__new__(mi.IJMatrix)
+A.h = mi.vp()
+mi.call("HYPRE_IJMatrixCreate", 0, mi.c_big(0), mi.c_big(9), mi.c_big(0), mi.c_big(9), C.byref(A.h))
+rc = mi.lib().HYPRE_IJMatrixAssemble(A.h)
+assert rc != 0
+v = mi.vp()
+mi.call("HYPRE_IJVectorCreate", 0, mi.c_big(0), mi.c_big(9), C.byref(v))
+assert mi.lib().HYPRE_IJVectorInitialize(v) != 0
+assert mi.lib().HYPRE_SetMemoryLocation(0) != 0     # HYPRE_MEMORY_HOST is refused
+assert mi.lib().HYPRE_SetExecutionPolicy(0) != 0
+print("REFUSED_OK")
+""" % ROOT
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=300)
+    assert p.returncode == 0, p.stdout
+    assert "REFUSED_OK" in p.stdout or "HAS_GPU" in p.stdout
+
+
+def test_library_does_not_link_the_oracle(mi_lib):
+    out = subprocess.run(["ldd", mi_lib.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
+    assert "oracle" not in out
+    syms = subprocess.run(["nm", "-D", mi_lib.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
+    assert "ogmres_solve" not in syms and "oamg_" not in syms
+
+
+def test_row_partition_matches_reference_rule(mi_lib):
+    # init_row_decomposition, /root/reference/src/HypreSystem.cpp:529-535
+    for total, nproc in ((10, 3), (134217728, 8), (7, 8), (1000, 1)):
+        prev = -1
+        for r in range(nproc):
+            lo, hi = mi_lib.row_partition(total, nproc, r)
+            assert lo == prev + 1
+            per, rem = divmod(total, nproc)
+            assert hi - lo + 1 == per + (1 if r < rem else 0)
+            prev = hi
+        assert prev == total - 1

@@ -1,0 +1,103 @@
+"""CPU: the product's host control plane (IJ assembly + BoomerAMG setup, C++ with
+threads) through the C ABI's host-only entry points, against the oracle.  The two
+are independent implementations of one specification: equal C/F
+splittings, interpolation and Galerkin operators mean both restate it the same way."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+
+def _host_amg(mi, n, stencil, **kw):
+    A, rhs = mi.build_laplace_system_host(n, n, n, stencil, 0, 1)
+    amg = mi.BoomerAMG(print_level=0, **kw)
+    mi.call("HYPRE_MI_BoomerAMGSetupHostOnly", amg.h, A.par)
+    return A, amg
+
+
+@pytest.mark.parametrize("n,stencil,kw", [(14, 7, {}), (9, 27, {}), (12, 7, dict(interp_type=3)),
+                                          (12, 7, dict(interp_type=0)), (12, 7, dict(strong_threshold=0.25)),
+                                          (12, 7, dict(max_coarse_size=100)), (12, 7, dict(max_levels=3))])
+def test_host_setup_equals_oracle(mi_lib, oc, n, stencil, kw):
+    mi = mi_lib
+    A, amg = _host_amg(mi, n, stencil, **kw)
+    Ao, bo = oc.Csr.laplace(n, n, n, stencil)
+    oamg = oc.Amg(Ao, oc.default_params(**kw))
+    assert amg.num_levels == oamg.num_levels
+    for l in range(amg.num_levels):
+        ia, ja, a, shape = amg.level_csr(l, 0)
+        oia, oja, oa = oamg.level_A(l).arrays()
+        assert np.array_equal(ia, oia) and np.array_equal(ja, oja) and np.array_equal(a, oa)  # bit-exact
+        if l < amg.num_levels - 1:
+            assert np.array_equal(amg.level_cf(l), oamg.level_cf(l))
+            pia, pja, pa, _ = amg.level_csr(l, 2)
+            qia, qja, qa = oamg.level_P(l).arrays()
+            assert np.array_equal(pia, qia) and np.array_equal(pja, qja) and np.array_equal(pa, qa)
+            ria, rja, ra, rshape = amg.level_csr(l, 3)
+            R = sp.csr_matrix((ra, rja, ria), shape=rshape)
+            P = sp.csr_matrix((pa, pja, pia), shape=(rshape[1], rshape[0]))
+            assert (abs(R - P.T)).nnz == 0
+
+
+def test_ij_assembly_semantics_host(mi_lib):
+    """Unsorted input, duplicates, Set-after-Add and Add-after-Set in submission order."""
+    mi = mi_lib
+    C = mi.C
+    n = 5
+    A = mi.IJMatrix.__new__(mi.IJMatrix)
+    A.h = mi.vp()
+    mi.call("HYPRE_IJMatrixCreate", 0, mi.c_big(0), mi.c_big(n - 1), mi.c_big(0), mi.c_big(n - 1), C.byref(A.h))
+    A.par = mi.vp()
+    mi.call("HYPRE_IJMatrixGetObject", A.h, C.byref(A.par))
+    # general SetValues2 form: ncols per row, explicit row_indexes
+    ncols = np.array([2, 1, 2], dtype=np.int32)
+    rows = np.array([4, 0, 2], dtype=np.int64)
+    row_indexes = np.array([3, 0, 1], dtype=np.int32)
+    cols = np.array([0, 2, 1, 4, 3], dtype=np.int64)          # row0:(0) row2:(2,1) row4:(4,3)
+    vals = np.array([10.0, 22.0, 21.0, 44.0, 43.0])
+    mi.call("HYPRE_IJMatrixSetValues2", A.h, 3, ncols, rows, row_indexes, cols, vals)
+    one = lambda r, c, v, add: A.set_values_coo(np.array([r], dtype=np.int64), np.array([c], dtype=np.int64),
+                                                np.array([v]), add=add)
+    one(2, 1, 1.0, True)     # 21 + 1
+    one(4, 4, 5.0, False)    # overwrite 44 -> 5
+    one(4, 4, 0.5, True)     # 5.5
+    one(1, 1, 7.0, True)     # AddTo on an empty slot creates it
+    one(3, 3, 1.0, False)
+    mi.call("HYPRE_MI_IJMatrixAssembleHostOnly", A.h)
+    amg = mi.BoomerAMG(print_level=0, max_levels=1)
+    mi.call("HYPRE_MI_BoomerAMGSetupHostOnly", amg.h, A.par)
+    ia, ja, a, shape = amg.level_csr(0, 0)
+    got = sp.csr_matrix((a, ja, ia), shape=shape).toarray()
+    want = np.zeros((n, n))
+    want[0, 0], want[1, 1], want[2, 1], want[2, 2], want[3, 3], want[4, 3], want[4, 4] = 10, 7, 22, 22, 1, 43, 5.5
+    assert np.array_equal(got, want)
+    assert np.all(np.diff(ja[ia[2]:ia[3]]) > 0)
+    # a row outside the owned range is an error (the driver never produces one)
+    B = mi.IJMatrix.__new__(mi.IJMatrix)
+    B.h = mi.vp()
+    mi.call("HYPRE_IJMatrixCreate", 0, mi.c_big(10), mi.c_big(19), mi.c_big(10), mi.c_big(19), C.byref(B.h))
+    B.set_values_coo(np.array([3], dtype=np.int64), np.array([3], dtype=np.int64), np.array([1.0]))
+    with pytest.raises(mi.HypreError):
+        mi.call("HYPRE_MI_IJMatrixAssembleHostOnly", B.h)
+    mi.call("HYPRE_ClearAllErrors")
+
+
+def test_empty_and_tiny_systems_host(mi_lib, oc):
+    mi = mi_lib
+    # 1x1x1 grid: one row, one level
+    A, amg = _host_amg(mi, 1, 7)
+    assert amg.num_levels == 1
+    ia, ja, a, shape = amg.level_csr(0, 0)
+    assert shape == (1, 1) and a.tolist() == [6.0]
+    # diagonal matrix: every row is isolated (no strong connections) -> no coarsening
+    n = 50
+    D = mi.IJMatrix.__new__(mi.IJMatrix)
+    D.h = mi.vp()
+    mi.call("HYPRE_IJMatrixCreate", 0, mi.c_big(0), mi.c_big(n - 1), mi.c_big(0), mi.c_big(n - 1), mi.C.byref(D.h))
+    D.par = mi.vp()
+    mi.call("HYPRE_IJMatrixGetObject", D.h, mi.C.byref(D.par))
+    idx = np.arange(n, dtype=np.int64)
+    D.set_values_coo(idx, idx, np.arange(1, n + 1, dtype=float))
+    mi.call("HYPRE_MI_IJMatrixAssembleHostOnly", D.h)
+    amg = mi.BoomerAMG(print_level=0)
+    mi.call("HYPRE_MI_BoomerAMGSetupHostOnly", amg.h, D.par)
+    assert amg.num_levels == 1

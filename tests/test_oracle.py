@@ -1,0 +1,181 @@
+"""CPU: the oracle against independent known answers and its frozen golden vectors.
+
+PARITY UNPINNED: the reference has no tests or vectors and libHYPRE is absent
+(SURVEY.md 0.2, 8c).  The pins available are analytic (generator systems have
+x* = 1), scipy (CSR kernels, direct solves, an independent GMRES) and algebraic
+invariants of the restated algorithms (Galerkin product, interpolation row sums,
+GMRES residual estimate = true residual, linearity of the V-cycle)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spl
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_generator_known_answer(oc):
+    for n, st, diag in ((5, 7, 6.0), (4, 27, 26.0)):
+        A, b = oc.Csr.laplace(n, n + 1, n + 2, st)
+        S = A.to_scipy()
+        assert np.all(S.diagonal() == diag)
+        off = S - sp.diags(S.diagonal())
+        assert set(np.unique(off.data)) == {-1.0}
+        assert np.array_equal(S @ np.ones(S.shape[0]), b)      # b = A*1 (laplace_3d_weak_scaling.hpp:321)
+        assert (abs(S - S.T)).nnz == 0
+        interior = np.flatnonzero(np.diff(S.indptr) == st)
+        assert len(interior) == (n - 2) * (n - 1) * n and np.all(b[interior] == 0.0)
+
+
+def test_csr_kernels_vs_scipy(oc):
+    rng = np.random.default_rng(0)
+    A = sp.random(60, 45, density=0.1, random_state=rng, format="csr")
+    B = sp.random(45, 70, density=0.1, random_state=rng, format="csr")
+    Ao, Bo = oc.Csr.from_scipy(A), oc.Csr.from_scipy(B)
+    x, y = rng.standard_normal(45), rng.standard_normal(60)
+    assert np.allclose(Ao.matvec(x, alpha=2.0, beta=-0.5, b=y), 2.0 * (A @ x) - 0.5 * y, rtol=1e-14, atol=1e-14)
+    T = oc.Csr(oc.lib().ocsr_transpose(Ao.h)).to_scipy()
+    assert (abs(T - A.T)).nnz == 0
+    C = oc.Csr(oc.lib().ocsr_matmul(Ao.h, Bo.h)).to_scipy()
+    assert abs(C - A @ B).max() < 1e-14
+    assert np.all(np.diff(C.indices[C.indptr[3]:C.indptr[4]]) > 0)  # columns ascending
+
+
+def test_park_miller_sequence(oc):
+    # minimal-standard generator: seed 1 -> 16807, 282475249, 1622650073 (Park & Miller 1988)
+    oc.lib().oracle_rand_seed(1)
+    got = [round(oc.lib().oracle_rand() * 2147483647) for _ in range(3)]
+    assert got == [16807, 282475249, 1622650073]
+
+
+@pytest.mark.parametrize("interp", [6, 3, 0])
+def test_hierarchy_invariants(oc, interp):
+    A, b = oc.Csr.laplace(10, 10, 10, 7)
+    amg = oc.Amg(A, oc.default_params(interp_type=interp))
+    assert amg.num_levels >= 3
+    for l in range(amg.num_levels - 1):
+        Al, P = amg.level_A(l).to_scipy(), amg.level_P(l).to_scipy()
+        cf = amg.level_cf(l)
+        assert set(np.unique(cf)) <= {1, -1}
+        assert P.shape == (Al.shape[0], int((cf == 1).sum()))
+        # C rows are identity rows; at most pmax = 4 entries per F row
+        assert np.all(np.diff(P.indptr)[cf == 1] == 1) and np.all(P.data[P.indptr[:-1][cf == 1]] == 1.0)
+        assert np.diff(P.indptr).max() <= 4
+        # PMIS: no two strongly connected C points (all couplings of this M-matrix are strong)
+        if l == 0:
+            S = Al - sp.diags(Al.diagonal())
+            cc = S[cf == 1][:, cf == 1]
+            assert cc.nnz == 0
+        # interpolation reproduces constants on zero-row-sum rows
+        rs = np.asarray(abs(Al @ np.ones(Al.shape[0]))).ravel()
+        zero_sum = (rs < 1e-12) & (np.diff(P.indptr) > 0)
+        assert np.allclose((P @ np.ones(P.shape[1]))[zero_sum], 1.0, atol=1e-12)
+        # Galerkin coarse operator
+        Ac = amg.level_A(l + 1).to_scipy()
+        assert abs(Ac - P.T @ Al @ P).max() < 1e-12
+
+
+def test_vcycle_is_linear_and_contracts(oc):
+    A, b = oc.Csr.laplace(12, 12, 12, 7)
+    amg = oc.Amg(A, oc.default_params())
+    rng = np.random.default_rng(1)
+    f, g = rng.standard_normal(12 ** 3), rng.standard_normal(12 ** 3)
+    Mf, Mg = amg.cycle(f), amg.cycle(g)
+    assert np.allclose(amg.cycle(2.0 * f - 3.0 * g), 2.0 * Mf - 3.0 * Mg, rtol=1e-11, atol=1e-12)
+    # stationary iteration x <- x + M(b - A x) converges
+    S = A.to_scipy()
+    x = np.zeros_like(b)
+    r0 = np.linalg.norm(b)
+    for _ in range(8):
+        x = x + amg.cycle(b - S @ x)
+    assert np.linalg.norm(b - S @ x) < 1e-3 * r0
+
+
+@pytest.mark.parametrize("rtype", [0, 7, 18, 3, 4, 6, 8, 13, 14])
+def test_relaxation_fixed_point_and_masks(oc, rtype):
+    """The exact solution is a fixed point of every smoother; C/F passes only touch their points."""
+    A, b = oc.Csr.laplace(8, 8, 8, 7)
+    amg = oc.Amg(A, oc.default_params())
+    x = np.ones(8 ** 3)
+    for points in (0, 1, -1):
+        assert np.allclose(amg.relax(0, rtype, points, b, x), x, atol=1e-13)
+    rng = np.random.default_rng(2)
+    u = rng.standard_normal(8 ** 3)
+    cf = amg.level_cf(0)
+    out = amg.relax(0, rtype, 1, b, u)
+    assert np.array_equal(out[cf != 1], u[cf != 1]) and not np.array_equal(out[cf == 1], u[cf == 1])
+
+
+def test_hybrid_gs_chunk_semantics(oc):
+    """chunk >= n is plain (symmetric) Gauss-Seidel; chunk 1 with l1 scaling is an l1-Jacobi step."""
+    A, b = oc.Csr.laplace(6, 6, 6, 7)
+    S = A.to_scipy().tocsr()
+    n = S.shape[0]
+    rng = np.random.default_rng(3)
+    u = rng.standard_normal(n)
+    amg = oc.Amg(A, oc.default_params(gs_chunk=10 ** 6, relax_order=0))
+    got = amg.relax(0, 3, 0, b, u)
+    ref = u.copy()
+    for i in range(n):
+        row = slice(S.indptr[i], S.indptr[i + 1])
+        ref[i] += (b[i] - S.data[row] @ ref[S.indices[row]]) / S[i, i]
+    assert np.allclose(got, ref, rtol=1e-13, atol=1e-13)
+    amg1 = oc.Amg(A, oc.default_params(gs_chunk=1, relax_order=0))
+    l1 = amg1.level_l1(0)
+    assert np.allclose(amg1.relax(0, 13, 0, b, u), u + (b - S @ u) / l1, rtol=1e-13, atol=1e-13)
+    # l1 option 4 with chunk 1: |a_ii| + 0.5 * sum over neighbours of the SAME C/F type, falling back to
+    # a_ii when <= 4/3 a_ii (Remark 6.2 truncation)
+    cf = amg1.level_cf(0)
+    want = np.empty(n)
+    for i in range(n):
+        row = slice(S.indptr[i], S.indptr[i + 1])
+        nb = S.indices[row]
+        v = 6.0 + 0.5 * np.abs(S.data[row][(nb != i) & (cf[nb] == cf[i])]).sum()
+        want[i] = 6.0 if v <= 8.0 else v
+    assert np.array_equal(l1, want) and l1.max() > 8.0 and l1.min() == 6.0
+
+
+@pytest.mark.parametrize("kdim", [50, 4])
+def test_gmres_against_scipy_and_true_residual(oc, kdim):
+    A, b = oc.Csr.laplace(9, 9, 9, 7)
+    S = A.to_scipy()
+    x, info = oc.gmres(A, b, kdim=kdim, tol=1e-9, maxit=400, amg=None)
+    assert info["converged"]
+    # the Givens estimate agrees with the true residual at the end (SURVEY 8c invariant)
+    assert abs(info["rel_res"] - info["true_rel_res"]) <= 1e-10
+    assert np.linalg.norm(b - S @ x) <= 1e-9 * np.linalg.norm(b) * (1 + 1e-6)
+    xs, flag = spl.gmres(S, b, rtol=1e-9, restart=kdim, maxiter=400)
+    assert flag == 0 and np.abs(x - xs).max() < 1e-6
+    assert np.abs(x - 1.0).max() < 1e-6
+    assert np.all(np.diff(info["norms"][: kdim + 1]) <= 1e-12)  # monotone inside a restart cycle
+
+
+def test_bicgstab_against_direct(oc):
+    d = np.load(os.path.join(GOLD, "random_mmatrix_400.npz"))
+    M = sp.csr_matrix((d["data"], d["indices"], d["indptr"]), shape=(400, 400))
+    A = oc.Csr.from_scipy(M)
+    amg = oc.Amg(A, oc.default_params())
+    for solver in (oc.bicgstab, oc.gmres):
+        x, info = solver(A, d["rhs"], tol=1e-12, maxit=200, amg=amg)
+        assert info["converged"]
+        assert np.abs(x - d["x_direct"]).max() <= 1e-8 * np.abs(d["x_direct"]).max()
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "lap*.npz"))))
+def test_golden_histories(oc, path):
+    """Frozen oracle outputs (tests/golden/make_golden.py): iteration counts, residual
+    histories, hierarchy shape, C/F split, solution; plus the analytic x* = 1."""
+    from tests.golden.make_golden import CASES, run_case
+
+    name = os.path.splitext(os.path.basename(path))[0]
+    case = next(c for c in CASES if c["name"] == name)
+    g = np.load(path)
+    r = run_case(case)
+    assert r["iters"] == int(g["iters"])
+    assert np.array_equal(r["level_rows"], g["level_rows"]) and np.array_equal(r["level_nnz"], g["level_nnz"])
+    assert np.array_equal(r["cf0"], g["cf0"])
+    assert np.allclose(r["norms"], g["norms"], rtol=1e-9, atol=0)
+    assert np.allclose(r["x"], g["x"], rtol=0, atol=1e-12)
+    assert np.abs(g["x"] - 1.0).max() < 100 * case["tol"]
