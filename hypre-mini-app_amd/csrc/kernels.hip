@@ -192,10 +192,26 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_hybrid_k(int n, int nchunks, int 
 //            butterfly over the group.
 // u_old is never written, so the result does not depend on scheduling.
 // ---------------------------------------------------------------------------
+// 64-bit DPP move (two dword moves); CTRL is a DPP control word
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// sum over an aligned group of LPC lanes, result in every lane of the group.
+// quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141,
+// row_mirror = 0x140: cross-lane moves in the VALU, no LDS crossbar; only the
+// 32- and 64-lane steps go through ds_bpermute.
 template <int LPC>
 __device__ __forceinline__ double group_sum(double v) {
-#pragma unroll
-  for (int m = LPC >> 1; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  if (LPC >= 16) v += dpp_mov<0x140>(v);
+  if (LPC >= 32) v += __shfl_xor(v, 16, 64);
+  if (LPC >= 64) v += __shfl_xor(v, 32, 64);
   return v;
 }
 
@@ -235,18 +251,18 @@ __global__ __launch_bounds__(256) void gs_group_k(int n, int nchunks, const int 
     my_k1 = rowsel ? a1 : my_k0;  // unselected rows load nothing
     mysel = rowsel && myd != 0.0;
   }
-  // phase A: three waves of independent loads (row pointers+marker, entries,
-  // gathers); no load waits on a branch
-  double val[R][E], uo[R][E];
-  int off[R][E];
+  // phase A: three waves of independent loads (row pointers + marker, entries,
+  // gathers).  Per entry one double survives: a_ij*u_old[j] for a column outside
+  // the chunk, a_ij itself for a column inside it; the in-chunk offset (or 15)
+  // of the 8 rows is packed 4 bits each into one register per strip.
   int k0s[R], k1s[R];
   unsigned longmask = 0;
 #pragma unroll
   for (int t = 0; t < R; t++) {
-    // row pointers travel from the owner lane by shuffle: one load round trip for all 8 rows
     k0s[t] = __shfl(my_k0, gbase + t, 64);
     k1s[t] = __shfl(my_k1, gbase + t, 64);
   }
+  double wv[R][E];
   int cols[R][E];
 #pragma unroll
   for (int t = 0; t < R; t++) {
@@ -255,10 +271,13 @@ __global__ __launch_bounds__(256) void gs_group_k(int n, int nchunks, const int 
     for (int e = 0; e < E; e++) {
       const int k = k0s[t] + g + e * LPC;
       const bool ok = k < k1s[t];
-      val[t][e] = ok ? av[k] : 0.0;
+      wv[t][e] = ok ? av[k] : 0.0;
       cols[t][e] = ok ? ja[k] : cs;
     }
   }
+  unsigned code[E];
+#pragma unroll
+  for (int e = 0; e < E; e++) code[e] = 0;
 #pragma unroll
   for (int t = 0; t < R; t++) {
 #pragma unroll
@@ -266,8 +285,9 @@ __global__ __launch_bounds__(256) void gs_group_k(int n, int nchunks, const int 
       const int j = cols[t][e];
       const unsigned oo = (unsigned)(j - cs);
       const bool inch = oo < (unsigned)len;
-      off[t][e] = inch ? (int)oo : -1;
-      uo[t][e] = u_old[j];  // unconditional: in-chunk values are simply not used
+      const double x = u_old[j];  // unconditional gather: no load waits on a branch
+      code[e] |= (inch ? oo : 15u) << (4 * t);
+      if (!inch) wv[t][e] *= x;
     }
   }
   // phase B
@@ -280,11 +300,11 @@ __global__ __launch_bounds__(256) void gs_group_k(int n, int nchunks, const int 
       double part = 0.0;
 #pragma unroll
       for (int e = 0; e < E; e++) {
-        const int o = off[t][e];
-        const double cur = __shfl(myu, gbase + (o < 0 ? 0 : o), 64);
-        part += val[t][e] * (o < 0 ? uo[t][e] : cur);
+        const unsigned o = (code[e] >> (4 * t)) & 15u;
+        const double cur = __shfl(myu, gbase + (int)(o & 7u), 64);
+        part += (o == 15u) ? wv[t][e] : wv[t][e] * cur;
       }
-      if (longmask & (1u << t)) {  // entries beyond the preloaded strip (group-uniform branch)
+      if (longmask & (1u << t)) {  // entries beyond the preloaded strips (group-uniform branch)
         const int i = cs + t;
         const int k1 = ia[i + 1];
         for (int k = ia[i] + LPC * E + g; k - g < k1; k += LPC) {
@@ -512,6 +532,7 @@ void gs_hybrid(const DevCSR &A, const double *u_old, double *u_new, const double
   prof_begin(prof, s);
   if (chunk == 8 && !gs_force_generic()) {
     const double avg = (double)A.nnz / (double)A.nrows;
+    const int p95 = A.rowlen_p95;
 #define GS_LAUNCH(LPC, E)                                                                                         \
   {                                                                                                               \
     const long long waves = (nchunks + (64 / LPC) - 1) / (64 / LPC);                                              \
@@ -519,16 +540,17 @@ void gs_hybrid(const DevCSR &A, const double *u_old, double *u_new, const double
                        (int)nchunks, A.ia.p, A.ja.p, A.a.p, cf, points, d, f, offc, u_old, u_new, fwd ? 1 : 0,     \
                        bwd ? 1 : 0, w);                                                                           \
   }
-    if (avg <= 8.0)
-      GS_LAUNCH(8, 1)
-    else if (avg <= 16.0)
-      GS_LAUNCH(16, 1)
-    else if (avg <= 32.0)
-      GS_LAUNCH(32, 1)
-    else if (avg <= 64.0)
-      GS_LAUNCH(64, 1)
-    else
-      GS_LAUNCH(64, 2)
+    // lanes per chunk from the mean row length, strips so that ~95 % of the rows
+    // are fully preloaded (the rest take the in-sweep path)
+    if (avg <= 8.0) {
+      if (p95 <= 8) GS_LAUNCH(8, 1) else GS_LAUNCH(8, 2)
+    } else if (avg <= 16.0) {
+      if (p95 <= 16) GS_LAUNCH(16, 1) else GS_LAUNCH(16, 2)
+    } else if (avg <= 32.0) {
+      if (p95 <= 32) GS_LAUNCH(32, 1) else GS_LAUNCH(32, 2)
+    } else {
+      if (p95 <= 64) GS_LAUNCH(64, 1) else if (p95 <= 128) GS_LAUNCH(64, 2) else GS_LAUNCH(64, 4)
+    }
 #undef GS_LAUNCH
   } else {
     const size_t lds = (size_t)chunk * GS_BLOCK * sizeof(double);

@@ -100,6 +100,7 @@ struct DevCSR {
   // row-block schedule of the LDS-staged SpMV (kernels.hip: spmv_stream)
   DVec<int> rb;
   int nblocks = 0;
+  int rowlen_p95 = 0;  // 95th percentile of the row lengths (GS kernel variant choice)
   bool empty() const { return nrows == 0 || nnz == 0; }
   void upload(const HostCSR &h);
 };

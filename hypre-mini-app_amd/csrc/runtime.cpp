@@ -1,5 +1,6 @@
 // Runtime context: device/stream ownership, scratch, device CSR upload,
 // event timers, the host thread helper.
+#include <algorithm>
 #include <chrono>
 #include <thread>
 
@@ -93,6 +94,15 @@ void DevCSR::upload(const HostCSR &h) {
   ia.upload(ia32);
   ja.upload(h.ja);
   a.upload(h.a);
+  {
+    std::vector<int> lens((size_t)nrows);
+    for (int i = 0; i < nrows; i++) lens[(size_t)i] = (int)(h.ia[(size_t)i + 1] - h.ia[(size_t)i]);
+    if (nrows) {
+      const size_t kth = (size_t)((double)(nrows - 1) * 0.95);
+      std::nth_element(lens.begin(), lens.begin() + (long)kth, lens.end());
+      rowlen_p95 = lens[kth];
+    }
+  }
   std::vector<int> blocks = k::build_row_blocks(nrows, h.ia.data());
   nblocks = (int)blocks.size() - 1;
   rb.upload(blocks);
