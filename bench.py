@@ -180,14 +180,14 @@ def main():
         roof = None
         if spmv_n:
             a = spmv_bytes / (spmv_ms / spmv_n * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "spmv_stream<0> (level-0 CSR SpMV, diag block)", "achieved": a,
+            roof = {"bound": "hbm", "kernel": "spmv_stream<0, 1> (level-0 CSR SpMV, diag block)", "achieved": a,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": traffic,
                     "launches": spmv_n, "avg_ms": spmv_ms / spmv_n, "min_ms": spmv_min,
                     "algorithmic_bytes_per_launch": spmv_bytes}
         roof_relax = None
         if rel_n:
             a = relax_bytes / (rel_ms / rel_n * 1e-3) / 1e9
-            roof_relax = {"bound": "hbm", "kernel": "gs_hybrid_k (level-0 l1 hybrid symmetric GS, one C or F pass)",
+            roof_relax = {"bound": "hbm", "kernel": "gs_group_k<8, 1> (level-0 l1 hybrid symmetric GS, one C or F pass)",
                           "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
                           "launches": rel_n, "avg_ms": rel_ms / rel_n, "min_ms": rel_min,
                           "algorithmic_bytes_per_launch": relax_bytes}
