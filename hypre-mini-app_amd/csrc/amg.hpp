@@ -37,6 +37,11 @@ struct AmgLevel {
   DevCSR dP, dR;
   std::vector<int> cf;  // +1 C, -1 F (empty on the coarsest level)
   DVec<signed char> d_cf;
+  // C-first ordering of this level: perm[new] = old local row;
+  // rows [0, nc) are the C points, [nc, n) the F points.  Empty = identity.
+  std::vector<int> perm;
+  DVec<int> d_perm;
+  int nc = 0;
   std::vector<double> diag, l1gs, l1jac;
   DVec<double> d_diag, d_l1gs, d_l1jac;
   DVec<double> u, f, tmp, snap;
@@ -70,10 +75,13 @@ struct BoomerAMG {
   // HYPRE_BoomerAMGSolve: x is the initial guess; up to max_iter cycles
   void solve(ParCSR &A, ParVector &b, ParVector &x);
 
-  // pieces (exposed for the parity tests)
-  void relax(int level, int type, int points, const double *f, DVec<double> &u);
-  void relax_sweeps(int level, int which, const double *f, DVec<double> &u);
-  void cycle(int level, const double *f, DVec<double> &u);
+  // pieces (exposed for the parity tests); vectors are in the level's own
+  // (C-first) ordering and are updated in place
+  void relax(int level, int type, int points, const double *f, double *u);
+  void relax_sweeps(int level, int which, const double *f, double *u);
+  void cycle(int level, const double *f, double *u);
+  // renumber every level C-first (host, collective); called at the end of setup_host
+  void apply_cf_ordering();
   double operator_complexity() const;
 };
 

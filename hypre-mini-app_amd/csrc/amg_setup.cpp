@@ -520,6 +520,125 @@ double BoomerAMG::operator_complexity() const {
   return base > 0 ? tot / base : 0.0;
 }
 
+// C-first ordering.  The hierarchy above is built in natural
+// order; here every level with a C/F splitting is renumbered inside its rank:
+// C points first (original order kept, so C point q IS coarse unknown q of the
+// rank), F points after.  Chunks of 8 rows are then all-C or all-F (bar one
+// mixed chunk per rank), a C or F relaxation pass touches one contiguous row
+// range, and the two passes of a sweep stream the level's matrix once instead of
+// twice.  Halo columns are renumbered by their owners (one halo exchange of the
+// new positions), so the level gets a fresh col_map_offd and halo plan.  Level 0
+// becomes a renumbered COPY of the caller's matrix, which stays untouched.
+void BoomerAMG::apply_cf_ordering() {
+  Comm &comm = current_comm();
+  const size_t nlev = L.size();
+  std::vector<std::vector<int>> pos(nlev);  // old -> new local row
+  for (size_t l = 0; l < nlev; l++) {
+    AmgLevel &Lv = L[l];
+    if (Lv.cf.empty()) continue;
+    const int n = Lv.A->nrows;
+    pos[l].resize((size_t)n);
+    Lv.perm.resize((size_t)n);
+    int q = 0;
+    for (int i = 0; i < n; i++)
+      if (Lv.cf[(size_t)i] == C_PT) pos[l][(size_t)i] = q++;
+    Lv.nc = q;
+    for (int i = 0; i < n; i++)
+      if (Lv.cf[(size_t)i] != C_PT) pos[l][(size_t)i] = q++;
+    for (int i = 0; i < n; i++) Lv.perm[(size_t)pos[l][(size_t)i]] = i;
+  }
+  auto sort_rows = [](HostCSR &M) {
+    parallel_for(M.nrows, [&](int64_t b, int64_t e, int) {
+      std::vector<std::pair<int, double>> row;
+      for (int64_t i = b; i < e; i++) {
+        const int64_t s = M.ia[(size_t)i], len = M.ia[(size_t)i + 1] - s;
+        bool sorted = true;
+        for (int64_t k = 1; k < len; k++)
+          if (M.ja[(size_t)(s + k)] < M.ja[(size_t)(s + k - 1)]) {
+            sorted = false;
+            break;
+          }
+        if (sorted) continue;
+        row.resize((size_t)len);
+        for (int64_t k = 0; k < len; k++) row[(size_t)k] = {M.ja[(size_t)(s + k)], M.a[(size_t)(s + k)]};
+        std::sort(row.begin(), row.end(), [](const std::pair<int, double> &x, const std::pair<int, double> &y) {
+          return x.first < y.first;
+        });
+        for (int64_t k = 0; k < len; k++) {
+          M.ja[(size_t)(s + k)] = row[(size_t)k].first;
+          M.a[(size_t)(s + k)] = row[(size_t)k].second;
+        }
+      }
+    });
+  };
+  // B = rows of M taken in perm order, columns mapped through colpos (may be null)
+  auto permute = [&](const HostCSR &M, const std::vector<int> &perm, const int *colpos, HostCSR &B) {
+    const int n = M.nrows;
+    B.nrows = n;
+    B.ncols = M.ncols;
+    B.ia.assign((size_t)n + 1, 0);
+    for (int q = 0; q < n; q++) {
+      const int i = perm.empty() ? q : perm[(size_t)q];
+      B.ia[(size_t)q + 1] = B.ia[(size_t)q] + (M.ia[(size_t)i + 1] - M.ia[(size_t)i]);
+    }
+    B.ja.resize((size_t)B.nnz());
+    B.a.resize((size_t)B.nnz());
+    parallel_for(n, [&](int64_t b, int64_t e, int) {
+      for (int64_t q = b; q < e; q++) {
+        const int i = perm.empty() ? (int)q : perm[(size_t)q];
+        int64_t w = B.ia[(size_t)q];
+        for (int64_t k = M.ia[(size_t)i]; k < M.ia[(size_t)i + 1]; k++, w++) {
+          B.ja[(size_t)w] = colpos ? colpos[M.ja[(size_t)k]] : M.ja[(size_t)k];
+          B.a[(size_t)w] = M.a[(size_t)k];
+        }
+      }
+    });
+    sort_rows(B);
+  };
+  for (size_t l = 0; l < nlev; l++) {
+    AmgLevel &Lv = L[l];
+    if (!pos[l].empty()) {
+      ParCSR &A = *Lv.A;
+      std::unique_ptr<ParCSR> An(new ParCSR());
+      An->nrows = A.nrows;
+      An->row_start = A.row_start;
+      An->row_end = A.row_end;
+      An->row_starts = A.row_starts;
+      permute(A.diag, Lv.perm, pos[l].data(), An->diag);
+      // halo columns: new global id = owner's start + owner's new position
+      std::vector<int> ext_pos = A.halo_exchange_host_int(comm, pos[l]);
+      const size_t next = A.col_map_offd.size();
+      std::vector<gidx> newgid(next);
+      for (size_t k = 0; k < next; k++) {
+        const gidx g = A.col_map_offd[k];
+        const size_t owner =
+            (size_t)(std::upper_bound(A.row_starts.begin(), A.row_starts.end(), g) - A.row_starts.begin()) - 1;
+        newgid[k] = A.row_starts[owner] + ext_pos[k];
+      }
+      std::vector<gidx> cm(newgid);
+      std::sort(cm.begin(), cm.end());
+      std::vector<int> colpos(next);
+      for (size_t k = 0; k < next; k++)
+        colpos[k] = (int)(std::lower_bound(cm.begin(), cm.end(), newgid[k]) - cm.begin());
+      permute(A.offd, Lv.perm, next ? colpos.data() : nullptr, An->offd);
+      An->offd.ncols = (int)next;
+      An->col_map_offd = cm;
+      An->build_halo_plan(comm);
+      Lv.A_own = std::move(An);
+      Lv.A = Lv.A_own.get();
+      std::vector<int> cf2(Lv.cf.size());
+      for (size_t q = 0; q < cf2.size(); q++) cf2[q] = Lv.cf[(size_t)Lv.perm[q]];
+      Lv.cf.swap(cf2);
+    }
+    if (Lv.P.nrows > 0 && (!pos[l].empty() || (l + 1 < nlev && !pos[l + 1].empty()))) {
+      HostCSR P2;
+      permute(Lv.P, Lv.perm, (l + 1 < nlev && !pos[l + 1].empty()) ? pos[l + 1].data() : nullptr, P2);
+      Lv.P = std::move(P2);
+      host_transpose(Lv.P, Lv.R);
+    }
+  }
+}
+
 void BoomerAMG::setup_host(ParCSR &A0) {
   Comm &comm = current_comm();
   t_setup_start = wall_time();
@@ -723,7 +842,9 @@ void BoomerAMG::setup_host(ParCSR &A0) {
     l++;
   }
 
-  // per-level norms (host)
+  apply_cf_ordering();
+
+  // per-level norms (host), on the C-first ordered operators
   const int ch = chunk();
   for (size_t li = 0; li < L.size(); li++) {
     AmgLevel &Lv = L[li];
@@ -815,6 +936,7 @@ void BoomerAMG::setup_device() {
       std::vector<signed char> c8(Lv.cf.size());
       for (size_t i = 0; i < c8.size(); i++) c8[i] = (signed char)Lv.cf[i];
       Lv.d_cf.upload(c8);
+      Lv.d_perm.upload(Lv.perm);
       Lv.dP.upload(Lv.P);
       Lv.dR.upload(Lv.R);
     }

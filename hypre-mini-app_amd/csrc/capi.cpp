@@ -1079,6 +1079,14 @@ HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCF(HYPRE_Solver solver, HYPRE_Int level, HYP
   for (size_t i = 0; i < v.size(); i++) cf[i] = v[i];
   API_END
 }
+HYPRE_Int HYPRE_MI_BoomerAMGGetLevelPerm(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int *perm) {
+  API_BEGIN
+  AmgSolver *a = AMG(solver);
+  if (level < 0 || level >= (int)a->amg.L.size()) fail(HYPRE_ERROR_ARG, "AMG level out of range");
+  const AmgLevel &Lv = a->amg.L[(size_t)level];
+  for (int i = 0; i < Lv.A->nrows; i++) perm[i] = Lv.perm.empty() ? i : Lv.perm[(size_t)i];
+  API_END
+}
 HYPRE_Int HYPRE_MI_BoomerAMGGetLevelColMap(HYPRE_Solver solver, HYPRE_Int level, HYPRE_BigInt *col_map_offd,
                                            HYPRE_BigInt *row_start) {
   API_BEGIN
@@ -1102,7 +1110,7 @@ HYPRE_Int HYPRE_MI_BoomerAMGRelaxLevel(HYPRE_Solver solver, HYPRE_Int level, HYP
     f.upload(f_host, (size_t)n);
     u.upload(u_host, (size_t)n);
   }
-  a->amg.relax(level, relax_type, points, f.p, u);
+  a->amg.relax(level, relax_type, points, f.p, u.p);
   MI_HIP(hipStreamSynchronize(ctx().stream));
   if (n) u.download(u_host, (size_t)n);
   API_END

@@ -5,6 +5,8 @@
 // streaming loads of the matrix, LDS staging of the per-entry products so that
 // short rows reduce without divergence, __shfl wave reductions, and a
 // workgroup->row-range map that keeps each XCD's L2 on its own slice of x.
+#include <algorithm>
+
 #include "kernels.hpp"
 #include "profile.hpp"
 
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256) void spmv_offd_k(int nrc, const int *__restric
 // threads/ranks (par_relax.c) and is bitwise independent of
 // scheduling because u_old is never written.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(GS_BLOCK) void gs_hybrid_k(int n, int nchunks, int chunk, const int *__restrict__ ia,
+__global__ __launch_bounds__(GS_BLOCK) void gs_hybrid_k(int n, int chunk0, int nchunks, int chunk, const int *__restrict__ ia,
                                                         const int *__restrict__ ja, const double *__restrict__ av,
                                                         const signed char *__restrict__ cf, int points,
                                                         const double *__restrict__ dd, const double *__restrict__ f,
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_hybrid_k(int n, int nchunks, int 
                                                         int fwd, int bwd, double w) {
   extern __shared__ double ucur[];  // [chunk][GS_BLOCK]
   const int tid = threadIdx.x;
-  const long long c = (long long)blockIdx.x * GS_BLOCK + tid;
+  const long long c = chunk0 + (long long)blockIdx.x * GS_BLOCK + tid;
   if (c >= nchunks) return;
   const int cs = (int)(c * chunk);
   const int len = min(chunk, n - cs);
@@ -218,7 +220,7 @@ __device__ __forceinline__ double group_sum(double v) {
 }
 
 template <int LPC, int E>
-__global__ __launch_bounds__(256) void gs_group_k(int n, int nchunks, const int *__restrict__ ia,
+__global__ __launch_bounds__(256) void gs_group_k(int n, int chunk0, int nchunks, const int *__restrict__ ia,
                                                   const int *__restrict__ ja, const double *__restrict__ av,
                                                   const signed char *__restrict__ cf, int points,
                                                   const double *__restrict__ dd, const double *__restrict__ f,
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(256) void gs_group_k(int n, int nchunks, const int 
   const int g = lane & (LPC - 1);
   const int gbase = lane & ~(LPC - 1);
   const long long wave = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
-  const long long c = wave * CPW + (lane / LPC);
+  const long long c = chunk0 + wave * CPW + (lane / LPC);
   const bool live = c < nchunks;
   const int cs = live ? (int)(c * R) : 0;
   const int len = live ? min(R, n - cs) : 0;
@@ -528,22 +530,27 @@ void spmv_offd_set(const DevOffd &B, const double *xext, double *out, hipStream_
   MI_HIP(hipGetLastError());
 }
 
-void gs_hybrid(const DevCSR &A, const double *u_old, double *u_new, const double *f, const double *offc,
-               const double *d, const signed char *cf, int points, int chunk, bool fwd, bool bwd, double w,
+void gs_hybrid(const DevCSR &A, double *u, double *tmp, const double *f, const double *offc, const double *d,
+               const signed char *cf, int points, int chunk, bool fwd, bool bwd, double w, int row_begin, int row_end,
                hipStream_t s, int prof) {
-  if (A.nrows == 0) return;
+  if (A.nrows == 0 || row_end <= row_begin) return;
   MI_REQUIRE(chunk >= 1 && chunk <= GS_MAX_CHUNK, "hybrid GS chunk out of range");
-  const long long nchunks = ((long long)A.nrows + chunk - 1) / chunk;
+  // chunks that intersect [row_begin, row_end); the kernel reads u everywhere
+  // (pre-sweep values) and writes the swept chunks into tmp, which is then
+  // copied back over the same rows
+  const long long c0 = row_begin / chunk;
+  const long long c1 = ((long long)row_end + chunk - 1) / chunk;
+  const long long nch = c1 - c0;
   prof_begin(prof, s);
   if (chunk == 8 && !gs_force_generic()) {
     const double avg = (double)A.nnz / (double)A.nrows;
     const int p95 = A.rowlen_p95;
-#define GS_LAUNCH(LPC, E)                                                                                         \
-  {                                                                                                               \
-    const long long waves = (nchunks + (64 / LPC) - 1) / (64 / LPC);                                              \
-    hipLaunchKernelGGL((gs_group_k<LPC, E>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, A.nrows,         \
-                       (int)nchunks, A.ia.p, A.ja.p, A.a.p, cf, points, d, f, offc, u_old, u_new, fwd ? 1 : 0,     \
-                       bwd ? 1 : 0, w);                                                                           \
+#define GS_LAUNCH(LPC, E)                                                                                       \
+  {                                                                                                             \
+    const long long waves = (nch + (64 / LPC) - 1) / (64 / LPC);                                                \
+    hipLaunchKernelGGL((gs_group_k<LPC, E>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, A.nrows,       \
+                       (int)c0, (int)c1, A.ia.p, A.ja.p, A.a.p, cf, points, d, f, offc, u, tmp, fwd ? 1 : 0,     \
+                       bwd ? 1 : 0, w);                                                                         \
   }
     // lanes per chunk from the mean row length, strips so that ~95 % of the rows
     // are fully preloaded (the rest take the in-sweep path)
@@ -559,12 +566,15 @@ void gs_hybrid(const DevCSR &A, const double *u_old, double *u_new, const double
 #undef GS_LAUNCH
   } else {
     const size_t lds = (size_t)chunk * GS_BLOCK * sizeof(double);
-    hipLaunchKernelGGL(gs_hybrid_k, dim3((unsigned)((nchunks + GS_BLOCK - 1) / GS_BLOCK)), dim3(GS_BLOCK), lds, s,
-                       A.nrows, (int)nchunks, chunk, A.ia.p, A.ja.p, A.a.p, cf, points, d, f, offc, u_old, u_new,
+    hipLaunchKernelGGL(gs_hybrid_k, dim3((unsigned)((nch + GS_BLOCK - 1) / GS_BLOCK)), dim3(GS_BLOCK), lds, s,
+                       A.nrows, (int)c0, (int)c1, chunk, A.ia.p, A.ja.p, A.a.p, cf, points, d, f, offc, u, tmp,
                        fwd ? 1 : 0, bwd ? 1 : 0, w);
   }
   MI_HIP(hipGetLastError());
   prof_end(prof, s);
+  const long long r0 = c0 * chunk;
+  const long long r1 = std::min<long long>(c1 * chunk, A.nrows);
+  MI_HIP(hipMemcpyAsync(u + r0, tmp + r0, (size_t)(r1 - r0) * sizeof(double), hipMemcpyDeviceToDevice, s));
 }
 
 void dot(const double *x, const double *y, int n, double *out_dev, hipStream_t s) {

@@ -31,10 +31,12 @@ void spmv_offd_set(const DevOffd &B, const double *xext, double *out, hipStream_
 void jacobi(const DevCSR &A, const double *u_old, double *u_new, const double *f, const double *offc, const double *d,
             const signed char *cf, int points, double w, hipStream_t s, int prof = PROF_NONE);
 // hybrid Gauss-Seidel family: chunks of `chunk` consecutive rows are swept
-// sequentially (forward and/or backward), chunks see each other's pre-sweep values
-void gs_hybrid(const DevCSR &A, const double *u_old, double *u_new, const double *f, const double *offc, const double *d,
-               const signed char *cf, int points, int chunk, bool fwd, bool bwd, double w, hipStream_t s,
-               int prof = PROF_NONE);
+// sequentially (forward and/or backward), chunks see each other's pre-sweep
+// values.  Only the chunks that intersect [row_begin, row_end) are swept (a C or
+// an F pass of a C-first ordered level); u is updated in place through tmp.
+void gs_hybrid(const DevCSR &A, double *u, double *tmp, const double *f, const double *offc, const double *d,
+               const signed char *cf, int points, int chunk, bool fwd, bool bwd, double w, int row_begin, int row_end,
+               hipStream_t s, int prof = PROF_NONE);
 
 // BLAS-1
 void dot(const double *x, const double *y, int n, double *out_dev, hipStream_t s);  // local sum, no collective

@@ -283,6 +283,14 @@ class BoomerAMG:
         call("HYPRE_MI_BoomerAMGGetLevelCF", self.h, level, cf)
         return cf
 
+    def level_perm(self, level):
+        """perm[new local row] = old local row of the level's C-first ordering."""
+        nr, nc, nnz = c_int(), c_int(), c_big()
+        call("HYPRE_MI_BoomerAMGGetLevelCSRSize", self.h, level, 0, C.byref(nr), C.byref(nc), C.byref(nnz))
+        perm = np.zeros(nr.value, dtype=np.int32)
+        call("HYPRE_MI_BoomerAMGGetLevelPerm", self.h, level, perm)
+        return perm
+
     def level_colmap(self, level):
         nr, nc, nnz = c_int(), c_int(), c_big()
         call("HYPRE_MI_BoomerAMGGetLevelCSRSize", self.h, level, 1, C.byref(nr), C.byref(nc), C.byref(nnz))

@@ -64,6 +64,9 @@ HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSRSize(HYPRE_Solver solver, HYPRE_Int level
 HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSR(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int which, HYPRE_BigInt *ia,
                                         HYPRE_Int *ja, HYPRE_Complex *a);
 HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCF(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int *cf);
+/* the level's C-first ordering: perm[new local row] = old local row (level matrices, P, R and the
+ * C/F marker are reported in the NEW ordering; level 0 is a renumbered copy of the caller's matrix) */
+HYPRE_Int HYPRE_MI_BoomerAMGGetLevelPerm(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int *perm);
 HYPRE_Int HYPRE_MI_BoomerAMGGetLevelColMap(HYPRE_Solver solver, HYPRE_Int level, HYPRE_BigInt *col_map_offd,
                                            HYPRE_BigInt *row_start);
 /* one relaxation call / one cycle on HOST arrays of the level's local length */

@@ -232,6 +232,7 @@ typedef struct olevel {
   double *l1gs;  /* l1 norm option 4, chunk/part/CF aware (relax 8,13,14) */
   double *l1jac; /* full row l1 norm (relax 18) */
   obig *part_starts;
+  int *perm; /* new -> old row of the C-first ordering (NULL = identity) */
   double *u, *f, *tmp, *old; /* work vectors (u,f unused on level 0) */
   double *Cinv;              /* dense inverse of the coarsest operator (relax 9) */
 } olevel;
@@ -714,6 +715,90 @@ static void finish_levels(oamg *h) {
   }
 }
 
+
+/* C-first ordering.  After the hierarchy is built in natural order, every level
+ * with a C/F splitting is renumbered inside each partition: C points first (in
+ * their original order, so that C point number q IS coarse unknown q of that
+ * partition), F points after.  The smoother's chunks of 8 rows are then all-C or
+ * all-F (bar one mixed chunk per partition), a C or F pass touches one contiguous
+ * row range, and the two passes of a sweep together read the matrix once.
+ * DESIGN.md section 3; the product applies the same renumbering. */
+static ocsr *permute_csr(const ocsr *A, const int *rowpos, const int *rowperm, const int *colpos) {
+  /* B[rowpos[i], colpos[j]] = A[i,j]; rowperm = inverse of rowpos; NULL maps = identity */
+  const int n = A->nrows;
+  ocsr *B = ocsr_new(n, A->ncols, ocsr_nnz(A));
+  for (int q = 0; q < n; q++) {
+    const int i = rowperm ? rowperm[q] : q;
+    B->ia[q + 1] = B->ia[q] + (A->ia[i + 1] - A->ia[i]);
+  }
+  for (int q = 0; q < n; q++) {
+    const int i = rowperm ? rowperm[q] : q;
+    const obig len = A->ia[i + 1] - A->ia[i];
+    obig w = B->ia[q];
+    for (obig k = A->ia[i]; k < A->ia[i + 1]; k++, w++) {
+      B->ja[w] = colpos ? colpos[A->ja[k]] : A->ja[k];
+      B->a[w] = A->a[k];
+    }
+    /* insertion sort of the row by new column (rows are short) */
+    for (obig a = B->ia[q] + 1; a < B->ia[q] + len; a++) {
+      int c = B->ja[a];
+      double v = B->a[a];
+      obig b = a - 1;
+      while (b >= B->ia[q] && B->ja[b] > c) {
+        B->ja[b + 1] = B->ja[b];
+        B->a[b + 1] = B->a[b];
+        b--;
+      }
+      B->ja[b + 1] = c;
+      B->a[b + 1] = v;
+    }
+  }
+  (void)rowpos;
+  return B;
+}
+
+static void apply_cf_ordering(oamg *h) {
+  const int nparts = h->p.nparts;
+  int **pos = (int **)xcalloc((size_t)h->nlev, sizeof(int *));
+  for (int l = 0; l < h->nlev; l++) {
+    olevel *L = &h->L[l];
+    if (!L->cf) continue;
+    const int n = L->A->nrows;
+    pos[l] = (int *)xmalloc(sizeof(int) * (size_t)n);
+    L->perm = (int *)xmalloc(sizeof(int) * (size_t)n);
+    for (int p = 0; p < nparts; p++) {
+      obig q = L->part_starts[p];
+      for (obig i = L->part_starts[p]; i < L->part_starts[p + 1]; i++)
+        if (L->cf[i] == C_PT) pos[l][i] = (int)q++;
+      for (obig i = L->part_starts[p]; i < L->part_starts[p + 1]; i++)
+        if (L->cf[i] != C_PT) pos[l][i] = (int)q++;
+    }
+    for (int i = 0; i < n; i++) L->perm[pos[l][i]] = i;
+  }
+  for (int l = 0; l < h->nlev; l++) {
+    olevel *L = &h->L[l];
+    if (pos[l]) {
+      ocsr *A2 = permute_csr(L->A, pos[l], L->perm, pos[l]);
+      if (L->own_A) ocsr_free(L->A);
+      L->A = A2;
+      L->own_A = 1;
+      const int n = A2->nrows;
+      int *cf2 = (int *)xmalloc(sizeof(int) * (size_t)n);
+      for (int q = 0; q < n; q++) cf2[q] = L->cf[L->perm[q]];
+      free(L->cf);
+      L->cf = cf2;
+    }
+    if (L->P && (pos[l] || (l + 1 < h->nlev && pos[l + 1]))) {
+      ocsr *P2 = permute_csr(L->P, pos[l], L->perm, (l + 1 < h->nlev) ? pos[l + 1] : NULL);
+      if (L->own_P) ocsr_free(L->P);
+      L->P = P2;
+      L->own_P = 1;
+    }
+  }
+  for (int l = 0; l < h->nlev; l++) free(pos[l]);
+  free(pos);
+}
+
 /* hypre_BoomerAMGSetup (par_amg_setup.c), reached from solverSetupPtr_
  * (src/HypreSystem.cpp:692) through HYPRE_ParCSRGMRESSetup -> precond setup. */
 oamg *oamg_setup(const ocsr *A0, const oamg_params *p) {
@@ -776,6 +861,7 @@ oamg *oamg_setup(const ocsr *A0, const oamg_params *p) {
     l++;
   }
   h->nlev = l + 1;
+  apply_cf_ordering(h);
   finish_levels(h);
   return h;
 }
@@ -822,6 +908,7 @@ void oamg_free(oamg *h) {
     free(L->l1gs);
     free(L->l1jac);
     free(L->part_starts);
+    free(L->perm);
     free(L->u);
     free(L->f);
     free(L->tmp);
@@ -837,6 +924,7 @@ const ocsr *oamg_P(const oamg *h, int l) { return h->L[l].P; }
 const int *oamg_cf(const oamg *h, int l) { return h->L[l].cf; }
 const double *oamg_l1(const oamg *h, int l) { return h->L[l].l1gs; }
 const obig *oamg_part_starts(const oamg *h, int l) { return h->L[l].part_starts; }
+const int *oamg_perm(const oamg *h, int l) { return h->L[l].perm; }
 
 /* ------------------------------------------------------------ AMG solve -- */
 
@@ -946,7 +1034,21 @@ static void cycle_level(const oamg *h, int l, const double *f, double *u) {
   relax_sweeps(h, l, 1, f, u);
 }
 
-void oamg_cycle(const oamg *h, const double *f, double *u) { cycle_level(h, 0, f, u); }
+/* f and u are in the caller's (natural) row order; level 0 works in its C-first order */
+void oamg_cycle(const oamg *h, const double *f, double *u) {
+  const olevel *L0 = &h->L[0];
+  if (!L0->perm) {
+    cycle_level(h, 0, f, u);
+    return;
+  }
+  const int n = L0->A->nrows;
+  for (int q = 0; q < n; q++) {
+    L0->f[q] = f[L0->perm[q]];
+    L0->u[q] = u[L0->perm[q]];
+  }
+  cycle_level(h, 0, L0->f, L0->u);
+  for (int q = 0; q < n; q++) u[L0->perm[q]] = L0->u[q];
+}
 
 static double vnorm(const double *x, int n) {
   double s = 0.0;

@@ -86,6 +86,8 @@ const ocsr *oamg_P(const oamg *h, int level);
 const int *oamg_cf(const oamg *h, int level);
 const double *oamg_l1(const oamg *h, int level);
 const obig *oamg_part_starts(const oamg *h, int level);
+/* C-first ordering of a level: perm[new] = old row (NULL when the level has no C/F split) */
+const int *oamg_perm(const oamg *h, int level);
 /* replace the hierarchy operators by externally supplied ones (used to run the
  * oracle's solve phase on the product's hierarchy) */
 oamg *oamg_from_levels(int nlev, const ocsr *const *A, const ocsr *const *P, const int *const *cf,

@@ -96,6 +96,8 @@ def lib():
         L.oamg_cf.argtypes = [C.c_void_p, C.c_int]
         L.oamg_l1.restype = P(C.c_double)
         L.oamg_l1.argtypes = [C.c_void_p, C.c_int]
+        L.oamg_perm.restype = P(C.c_int)
+        L.oamg_perm.argtypes = [C.c_void_p, C.c_int]
         L.oamg_part_starts.restype = P(C.c_longlong)
         L.oamg_part_starts.argtypes = [C.c_void_p, C.c_int]
         L.oamg_relax.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -232,6 +234,14 @@ class Amg:
     def level_l1(self, l):
         n = self.level_A(l).shape[0]
         return np.ctypeslib.as_array(lib().oamg_l1(self.h, l), shape=(n,)).copy()
+
+    def level_perm(self, l):
+        """perm[new] = old row of the level's C-first ordering (identity on the coarsest level)."""
+        n = self.level_A(l).shape[0]
+        p = lib().oamg_perm(self.h, l)
+        if not p:
+            return np.arange(n, dtype=np.int32)
+        return np.ctypeslib.as_array(p, shape=(n,)).copy()
 
     def level_part_starts(self, l):
         return np.ctypeslib.as_array(lib().oamg_part_starts(self.h, l), shape=(self.params.nparts + 1,)).copy()

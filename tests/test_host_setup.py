@@ -29,6 +29,7 @@ def test_host_setup_equals_oracle(mi_lib, oc, n, stencil, kw):
         assert np.array_equal(ia, oia) and np.array_equal(ja, oja) and np.array_equal(a, oa)  # bit-exact
         if l < amg.num_levels - 1:
             assert np.array_equal(amg.level_cf(l), oamg.level_cf(l))
+            assert np.array_equal(amg.level_perm(l), oamg.level_perm(l))
             pia, pja, pa, _ = amg.level_csr(l, 2)
             qia, qja, qa = oamg.level_P(l).arrays()
             assert np.array_equal(pia, qia) and np.array_equal(pja, qja) and np.array_equal(pa, qa)

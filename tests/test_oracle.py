@@ -99,11 +99,13 @@ def test_relaxation_fixed_point_and_masks(oc, rtype):
     A, b = oc.Csr.laplace(8, 8, 8, 7)
     amg = oc.Amg(A, oc.default_params())
     x = np.ones(8 ** 3)
+    b = b[amg.level_perm(0)]  # relaxation works in the level's C-first ordering
     for points in (0, 1, -1):
         assert np.allclose(amg.relax(0, rtype, points, b, x), x, atol=1e-13)
     rng = np.random.default_rng(2)
     u = rng.standard_normal(8 ** 3)
     cf = amg.level_cf(0)
+    assert np.all(cf[: (cf == 1).sum()] == 1) and np.all(cf[(cf == 1).sum():] == -1)  # C first
     out = amg.relax(0, rtype, 1, b, u)
     assert np.array_equal(out[cf != 1], u[cf != 1]) and not np.array_equal(out[cf == 1], u[cf == 1])
 
@@ -111,11 +113,13 @@ def test_relaxation_fixed_point_and_masks(oc, rtype):
 def test_hybrid_gs_chunk_semantics(oc):
     """chunk >= n is plain (symmetric) Gauss-Seidel; chunk 1 with l1 scaling is an l1-Jacobi step."""
     A, b = oc.Csr.laplace(6, 6, 6, 7)
-    S = A.to_scipy().tocsr()
-    n = S.shape[0]
     rng = np.random.default_rng(3)
-    u = rng.standard_normal(n)
     amg = oc.Amg(A, oc.default_params(gs_chunk=10 ** 6, relax_order=0))
+    S = amg.level_A(0).to_scipy().tocsr()  # level 0 in its C-first ordering
+    S.sort_indices()
+    n = S.shape[0]
+    b = b[amg.level_perm(0)]
+    u = rng.standard_normal(n)
     got = amg.relax(0, 3, 0, b, u)
     ref = u.copy()
     for i in range(n):
@@ -123,6 +127,7 @@ def test_hybrid_gs_chunk_semantics(oc):
         ref[i] += (b[i] - S.data[row] @ ref[S.indices[row]]) / S[i, i]
     assert np.allclose(got, ref, rtol=1e-13, atol=1e-13)
     amg1 = oc.Amg(A, oc.default_params(gs_chunk=1, relax_order=0))
+    assert np.array_equal(amg1.level_perm(0), amg.level_perm(0))
     l1 = amg1.level_l1(0)
     assert np.allclose(amg1.relax(0, 13, 0, b, u), u + (b - S @ u) / l1, rtol=1e-13, atol=1e-13)
     # l1 option 4 with chunk 1: |a_ii| + 0.5 * sum over neighbours of the SAME C/F type, falling back to
