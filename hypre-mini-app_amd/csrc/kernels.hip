@@ -45,6 +45,7 @@ struct EpiArgs {
   const double *d;         // EPI 1
   const signed char *cf;   // EPI 1 (nullable)
   int points;              // EPI 1
+  int exp_nogather;        // experiment knob (MI_HYPRE_EXP_NOGATHER): read x[0] instead of x[col]
 };
 
 template <int EPI>
@@ -97,13 +98,87 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream(int nb, int xchunk, co
     const int2 c = *reinterpret_cast<const int2 *>(ja + base_al + k);
     const bool ok0 = (base_al + k >= base);
     const bool ok1 = (base_al + k + 1 < end);
-    const double x0 = ok0 ? x[c.x] : 0.0;
-    const double x1 = ok1 ? x[c.y] : 0.0;
+    const double x0 = ok0 ? x[e.exp_nogather ? (c.x & 7) : c.x] : 0.0;
+    const double x1 = ok1 ? x[e.exp_nogather ? (c.y & 7) : c.y] : 0.0;
     prod[k] = v.x * x0;
     if (k + 1 < SPMV_TILE) prod[k + 1] = v.y * x1;
   }
   __syncthreads();
   // phase 2
+  const int nr = r1 - r0;
+  int G = 1;
+  while (G < 64 && nr * G * 2 <= SPMV_BLOCK) G <<= 1;
+  const int lane = tid & (G - 1);
+  for (int rr = tid / G; rr < nr; rr += SPMV_BLOCK / G) {
+    const int r = r0 + rr;
+    const int s0 = ia[r] - base_al, s1 = ia[r + 1] - base_al;
+    double s = 0.0;
+    for (int k = s0 + lane; k < s1; k += G) s += prod[k];
+    for (int off = G >> 1; off > 0; off >>= 1) s += __shfl_down(s, off, G);
+    if (lane == 0) epilogue<EPI>(r, s, x, y, e);
+  }
+}
+
+// Same kernel with an LDS x cache, for levels with long rows (coarse AMG levels).
+// There the plain version spends ~45 % of its time on the x gathers: 64
+// consecutive entries hit 30-60 different lines, neighbouring rows re-request
+// the same lines a moment later, and with 32 waves per CU the 32 KB L1 cannot
+// hold them, so every lane becomes an L2 transaction.  Here each workgroup first
+// gathers the sorted unique columns of its row block ONCE into LDS (adjacent
+// lanes -> ascending addresses, well coalesced) and the entries then carry
+// 16-bit block-local ids (which also shrinks the index stream from 4 to 2 B).
+template <int EPI>
+__global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream_xc(int nb, int xchunk, const int *__restrict__ rb,
+                                                             const int *__restrict__ ia, const int *__restrict__ ja,
+                                                             const double *__restrict__ av,
+                                                             const int *__restrict__ uptr, const int *__restrict__ ucols,
+                                                             const unsigned short *__restrict__ lcol,
+                                                             const double *__restrict__ x, double *__restrict__ y,
+                                                             EpiArgs e) {
+  __shared__ double prod[SPMV_TILE];
+  __shared__ double xs[SPMV_TILE];
+  const int blk = xcd_remap(blockIdx.x, xchunk);
+  if (blk >= nb) return;
+  const int tid = threadIdx.x;
+  const int r0 = rb[blk], r1 = rb[blk + 1];
+  const int base = ia[r0], end = ia[r1];
+  if (end - base >= SPMV_TILE) {
+    double s = 0.0;
+    for (int k = base + tid; k < end; k += SPMV_BLOCK) s += av[k] * x[ja[k]];
+    s = wave_sum(s);
+    if ((tid & 63) == 0) prod[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) epilogue<EPI>(r0, prod[0] + prod[1] + prod[2] + prod[3], x, y, e);
+    return;
+  }
+  // the matrix stream is issued first and waits in registers while the x cache fills
+  const int base_al = base & ~1;
+  const int cnt = end - base_al;
+  constexpr int NIT = SPMV_TILE / (2 * SPMV_BLOCK);
+  double2 vv[NIT];
+  ushort2 cc[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    const int k = 2 * tid + it * 2 * SPMV_BLOCK;
+    if (k < cnt) {
+      vv[it] = *reinterpret_cast<const double2 *>(av + base_al + k);
+      cc[it] = *reinterpret_cast<const ushort2 *>(lcol + base_al + k);
+    }
+  }
+  const int u0 = uptr[blk], nu = uptr[blk + 1] - u0;
+  for (int k = tid; k < nu; k += SPMV_BLOCK) xs[k] = x[ucols[u0 + k]];
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    const int k = 2 * tid + it * 2 * SPMV_BLOCK;
+    if (k < cnt) {
+      const bool ok0 = (base_al + k >= base);
+      const bool ok1 = (base_al + k + 1 < end);
+      prod[k] = ok0 ? vv[it].x * xs[cc[it].x] : 0.0;
+      prod[k + 1] = ok1 ? vv[it].y * xs[cc[it].y] : 0.0;
+    }
+  }
+  __syncthreads();
   const int nr = r1 - r0;
   int G = 1;
   while (G < 64 && nr * G * 2 <= SPMV_BLOCK) G <<= 1;
@@ -483,7 +558,14 @@ static void launch_stream(int epi, const DevCSR &A, const double *x, double *y, 
   const int nb = A.nblocks;
   const int xchunk = (nb + 7) / 8;
   const dim3 grid(xchunk * 8), block(SPMV_BLOCK);
-  if (epi == 0 && level0)
+  if (A.xcache) {
+    if (epi == 0)
+      hipLaunchKernelGGL(spmv_stream_xc<0>, grid, block, 0, s, nb, xchunk, A.rb.p, A.ia.p, A.ja.p, A.a.p, A.uptr.p,
+                         A.ucols.p, A.lcol.p, x, y, e);
+    else
+      hipLaunchKernelGGL(spmv_stream_xc<1>, grid, block, 0, s, nb, xchunk, A.rb.p, A.ia.p, A.ja.p, A.a.p, A.uptr.p,
+                         A.ucols.p, A.lcol.p, x, y, e);
+  } else if (epi == 0 && level0)
     hipLaunchKernelGGL((spmv_stream<0, 1>), grid, block, 0, s, nb, xchunk, A.rb.p, A.ia.p, A.ja.p, A.a.p, x, y, e);
   else if (epi == 0)
     hipLaunchKernelGGL((spmv_stream<0, 0>), grid, block, 0, s, nb, xchunk, A.rb.p, A.ia.p, A.ja.p, A.a.p, x, y, e);
@@ -498,6 +580,8 @@ void spmv(const DevCSR &A, const double *x, double alpha, double beta, const dou
   e.alpha = alpha;
   e.beta = beta;
   e.b = b;
+  static const int nog = getenv("MI_HYPRE_EXP_NOGATHER") ? atoi(getenv("MI_HYPRE_EXP_NOGATHER")) : 0;
+  e.exp_nogather = nog;
   prof_begin(prof, s);
   launch_stream(0, A, x, y, e, s, prof == PROF_SPMV_L0);
   prof_end(prof, s);

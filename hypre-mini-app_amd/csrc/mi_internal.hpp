@@ -101,6 +101,11 @@ struct DevCSR {
   DVec<int> rb;
   int nblocks = 0;
   int rowlen_p95 = 0;  // 95th percentile of the row lengths (GS kernel variant choice)
+  // x cache of the SpMV (levels with long rows): per row block the sorted unique
+  // columns (gathered once into LDS) and 16-bit block-local column ids per entry
+  bool xcache = false;
+  DVec<int> uptr, ucols;
+  DVec<unsigned short> lcol;
   bool empty() const { return nrows == 0 || nnz == 0; }
   void upload(const HostCSR &h);
 };

@@ -2,6 +2,7 @@
 // event timers, the host thread helper.
 #include <algorithm>
 #include <chrono>
+#include <cstring>
 #include <thread>
 
 #include "kernels.hpp"
@@ -106,6 +107,35 @@ void DevCSR::upload(const HostCSR &h) {
   std::vector<int> blocks = k::build_row_blocks(nrows, h.ia.data());
   nblocks = (int)blocks.size() - 1;
   rb.upload(blocks);
+  // x cache: worth it when a block's entries share columns (long rows); the fine
+  // level's short rows gather coalesced already
+  static const int xc_min = getenv("MI_HYPRE_XCACHE_MIN") ? atoi(getenv("MI_HYPRE_XCACHE_MIN")) : 12;
+  xcache = nrows > 0 && (double)nnz / (double)nrows >= (double)xc_min;
+  if (xcache) {
+    std::vector<int> up((size_t)nblocks + 1, 0);
+    std::vector<unsigned short> lc((size_t)nnz, 0);
+    std::vector<std::vector<int>> uniq((size_t)nblocks);
+    parallel_for(nblocks, [&](int64_t b0, int64_t b1, int) {
+      std::vector<int> tmp;
+      for (int64_t b = b0; b < b1; b++) {
+        const int64_t s = h.ia[(size_t)blocks[(size_t)b]], e = h.ia[(size_t)blocks[(size_t)b + 1]];
+        if (e - s >= k::SPMV_TILE) continue;  // single long row: direct gathers
+        tmp.assign(h.ja.begin() + s, h.ja.begin() + e);
+        std::sort(tmp.begin(), tmp.end());
+        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+        for (int64_t q = s; q < e; q++)
+          lc[(size_t)q] = (unsigned short)(std::lower_bound(tmp.begin(), tmp.end(), h.ja[(size_t)q]) - tmp.begin());
+        uniq[(size_t)b] = tmp;
+      }
+    });
+    for (int b = 0; b < nblocks; b++) up[(size_t)b + 1] = up[(size_t)b] + (int)uniq[(size_t)b].size();
+    std::vector<int> uc((size_t)up[(size_t)nblocks]);
+    for (int b = 0; b < nblocks; b++)
+      if (!uniq[(size_t)b].empty()) memcpy(uc.data() + up[(size_t)b], uniq[(size_t)b].data(), uniq[(size_t)b].size() * sizeof(int));
+    uptr.upload(up);
+    ucols.upload(uc);
+    lcol.upload(lc);
+  }
 }
 
 void DevOffd::upload(int nrows, const HostCSR &h) {
