@@ -77,13 +77,18 @@ struct BoomerAMG {
 
   // pieces (exposed for the parity tests); vectors are in the level's own
   // (C-first) ordering and are updated in place
-  void relax(int level, int type, int points, const double *f, double *u);
-  void relax_sweeps(int level, int which, const double *f, double *u);
-  void cycle(int level, const double *f, double *u);
+  // u_is_zero: the caller guarantees u == 0 on entry (its halo is then known to be zero)
+  void relax(int level, int type, int points, const double *f, double *u, bool u_is_zero = false);
+  void relax_sweeps(int level, int which, const double *f, double *u, bool u_is_zero = false);
+  void cycle(int level, const double *f, double *u, bool u_is_zero = false);
   // renumber every level C-first (host, collective); called at the end of setup_host
   void apply_cf_ordering();
   double operator_complexity() const;
 };
+
+// set by a Krylov solver right before it calls the preconditioner with x == 0,
+// consumed (and cleared) by BoomerAMG::solve
+bool &zero_guess_hint();
 
 // host algorithms (amg_setup.cpp), exposed for tests
 void host_transpose(const HostCSR &A, HostCSR &T);

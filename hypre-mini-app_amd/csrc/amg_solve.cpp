@@ -13,8 +13,13 @@
 
 namespace mi {
 
+bool &zero_guess_hint() {
+  static bool hint = false;
+  return hint;
+}
+
 // one relaxation call, u updated in place (level ordering)
-void BoomerAMG::relax(int level, int type, int points, const double *f, double *u) {
+void BoomerAMG::relax(int level, int type, int points, const double *f, double *u, bool u_is_zero) {
   AmgLevel &Lv = L[(size_t)level];
   ParCSR &A = *Lv.A;
   Comm &comm = current_comm();
@@ -37,7 +42,8 @@ void BoomerAMG::relax(int level, int type, int points, const double *f, double *
   const bool has_cf = !Lv.cf.empty();
   const signed char *cf = has_cf ? Lv.d_cf.p : nullptr;
   if (!has_cf) points = 0;
-  const double *offc = A.offd_contrib(comm, u, s);
+  // a zero vector has a zero halo: no exchange, no halo contribution
+  const double *offc = u_is_zero ? nullptr : A.offd_contrib(comm, u, s);
   if (type == 0 || type == 7 || type == 18) {
     const double *d = (type == 18) ? Lv.d_l1jac.p : Lv.d_diag.p;
     k::jacobi(A.d_diag, u, Lv.snap.p, f, offc, d, cf, points, w, s, prof);
@@ -56,14 +62,15 @@ void BoomerAMG::relax(int level, int type, int points, const double *f, double *
 
 // which: 0 down, 1 up, 2 coarsest.  relax_order 1: C then F going down, F then
 // C going up, all points on the coarsest level (hypre_BoomerAMGRelaxIF)
-void BoomerAMG::relax_sweeps(int level, int which, const double *f, double *u) {
+void BoomerAMG::relax_sweeps(int level, int which, const double *f, double *u, bool u_is_zero) {
   const int type = p.relax_type[which];
   const bool has_cf = !L[(size_t)level].cf.empty();
   for (int sw = 0; sw < p.num_sweeps[which]; sw++) {
+    const bool zero = u_is_zero && sw == 0;
     if (which == 2 || p.relax_order != 1 || !has_cf) {
-      relax(level, type, 0, f, u);
+      relax(level, type, 0, f, u, zero);
     } else if (which == 0) {
-      relax(level, type, 1, f, u);
+      relax(level, type, 1, f, u, zero);
       relax(level, type, -1, f, u);
     } else {
       relax(level, type, -1, f, u);
@@ -72,23 +79,23 @@ void BoomerAMG::relax_sweeps(int level, int which, const double *f, double *u) {
   }
 }
 
-void BoomerAMG::cycle(int level, const double *f, double *u) {
+void BoomerAMG::cycle(int level, const double *f, double *u, bool u_is_zero) {
   const int nlev = (int)L.size();
   if (level == nlev - 1) {
-    relax_sweeps(level, 2, f, u);
+    relax_sweeps(level, 2, f, u, u_is_zero);
     return;
   }
   AmgLevel &Lv = L[(size_t)level];
   AmgLevel &Ln = L[(size_t)level + 1];
   Comm &comm = current_comm();
   hipStream_t s = ctx().stream;
-  relax_sweeps(level, 0, f, u);
+  relax_sweeps(level, 0, f, u, u_is_zero && p.num_sweeps[0] > 0);
   // r = f - A u ; f_c = P^T r ; u_c = 0
   Lv.A->matvec(comm, -1.0, u, 1.0, f, Lv.tmp.p, s);
   k::spmv(Lv.dR, Lv.tmp.p, 1.0, 0.0, nullptr, Ln.f.p, s);
   k::fill(Ln.u.p, Ln.n, 0.0, s);
   const int ncyc = (p.cycle_type == 2 && level + 1 < nlev - 1) ? 2 : 1;
-  for (int c = 0; c < ncyc; c++) cycle(level + 1, Ln.f.p, Ln.u.p);
+  for (int c = 0; c < ncyc; c++) cycle(level + 1, Ln.f.p, Ln.u.p, c == 0);
   // u += P e
   k::spmv(Lv.dP, Ln.u.p, 1.0, 1.0, u, u, s);
   relax_sweeps(level, 1, f, u);
@@ -106,13 +113,21 @@ void BoomerAMG::solve(ParCSR &A, ParVector &b, ParVector &x) {
   double rel = 0.0, bn = 0.0;
   if (p.tol > 0.0) bn = std::sqrt(par_dot_host(comm, b.data(), b.data(), b.n, s));
   if (permuted) k::gather(b.data(), L0.d_perm.p, L0.f.p, L0.n, s);  // caller order -> C-first order
+  // a Krylov solver that has just zeroed x says so (krylov.cpp): the first cycle
+  // then needs neither x nor its halo
+  const bool zero_first = zero_guess_hint();
+  zero_guess_hint() = false;
   while (it < p.max_iter) {
+    const bool zero = zero_first && it == 0;
     if (permuted) {
-      k::gather(x.data(), L0.d_perm.p, L0.u.p, L0.n, s);
-      cycle(0, L0.f.p, L0.u.p);
+      if (zero)
+        k::fill(L0.u.p, L0.n, 0.0, s);
+      else
+        k::gather(x.data(), L0.d_perm.p, L0.u.p, L0.n, s);
+      cycle(0, L0.f.p, L0.u.p, zero);
       k::scatter_set(x.data(), L0.d_perm.p, L0.u.p, L0.n, s);
     } else {
-      cycle(0, b.data(), x.data());
+      cycle(0, b.data(), x.data(), zero);
     }
     it++;
     if (p.tol > 0.0) {

@@ -17,7 +17,9 @@ void KrylovSolver::apply_precond(ParCSR &A, ParVector &rhs, ParVector &out) {
   hipStream_t s = ctx().stream;
   if (precond_solve) {
     k::fill(out.data(), out.n, 0.0, s);
+    zero_guess_hint() = true;
     precond_solve(precond_data, &A, &rhs, &out);
+    zero_guess_hint() = false;
   } else {
     k::copy(rhs.data(), out.data(), out.n, s);
   }
