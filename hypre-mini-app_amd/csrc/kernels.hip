@@ -45,7 +45,6 @@ struct EpiArgs {
   const double *d;         // EPI 1
   const signed char *cf;   // EPI 1 (nullable)
   int points;              // EPI 1
-  int exp_nogather;        // experiment knob (MI_HYPRE_EXP_NOGATHER): read x[0] instead of x[col]
 };
 
 template <int EPI>
@@ -98,8 +97,8 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream(int nb, int xchunk, co
     const int2 c = *reinterpret_cast<const int2 *>(ja + base_al + k);
     const bool ok0 = (base_al + k >= base);
     const bool ok1 = (base_al + k + 1 < end);
-    const double x0 = ok0 ? x[e.exp_nogather ? (c.x & 7) : c.x] : 0.0;
-    const double x1 = ok1 ? x[e.exp_nogather ? (c.y & 7) : c.y] : 0.0;
+    const double x0 = ok0 ? x[c.x] : 0.0;
+    const double x1 = ok1 ? x[c.y] : 0.0;
     prod[k] = v.x * x0;
     if (k + 1 < SPMV_TILE) prod[k + 1] = v.y * x1;
   }
@@ -580,8 +579,6 @@ void spmv(const DevCSR &A, const double *x, double alpha, double beta, const dou
   e.alpha = alpha;
   e.beta = beta;
   e.b = b;
-  static const int nog = getenv("MI_HYPRE_EXP_NOGATHER") ? atoi(getenv("MI_HYPRE_EXP_NOGATHER")) : 0;
-  e.exp_nogather = nog;
   prof_begin(prof, s);
   launch_stream(0, A, x, y, e, s, prof == PROF_SPMV_L0);
   prof_end(prof, s);
