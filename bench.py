@@ -222,7 +222,7 @@ def main():
             "roofline": roof,
             "roofline_relax": roof_relax,
         }
-        if not args.no_cpu and args.cpu_n > 0:
+        if not args.no_cpu and args.cpu_n > 0 and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, chunk.value)
         else:
             out["cpu_baseline"] = None

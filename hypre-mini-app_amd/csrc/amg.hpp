@@ -59,6 +59,7 @@ struct BoomerAMG {
   std::vector<AmgLevel> L;
   bool is_setup = false, host_ready = false;
   double t_setup_start = 0.0;
+  double t_phase[6] = {0, 0, 0, 0, 0, 0};  // strength, pmis, interp, galerkin, ordering, host total
   int num_iterations = 0;
   double final_rel_res = 0.0;
   double setup_seconds = 0.0;

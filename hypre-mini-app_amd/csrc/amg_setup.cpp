@@ -642,6 +642,7 @@ void BoomerAMG::apply_cf_ordering() {
 void BoomerAMG::setup_host(ParCSR &A0) {
   Comm &comm = current_comm();
   t_setup_start = wall_time();
+  for (double &t : t_phase) t = 0.0;
   is_setup = false;
   L.clear();
   L.reserve((size_t)std::max(1, p.max_levels));
@@ -656,9 +657,13 @@ void BoomerAMG::setup_host(ParCSR &A0) {
     ParCSR &A = *L[(size_t)l].A;
     const int n = A.nrows;
     Strength S;
+    double tp0 = wall_time();
     strength(A, p.strong_threshold, p.max_row_sum, S);
+    t_phase[0] += wall_time() - tp0;
+    tp0 = wall_time();
     std::vector<int> cf;
     pmis(n, S, comm.rank, cf);
+    t_phase[1] += wall_time() - tp0;
     long long nc_loc = 0;
     for (int i = 0; i < n; i++) nc_loc += (cf[(size_t)i] == C_PT);
     long long nc_glob = nc_loc;
@@ -667,9 +672,12 @@ void BoomerAMG::setup_host(ParCSR &A0) {
 
     AmgLevel &Lv = L[(size_t)l];
     int nc = 0;
+    tp0 = wall_time();
     build_interp(A, S, cf, p.interp_type, p.trunc_factor, p.pmax_elmts, Lv.P, nc);
     Lv.cf = cf;
     host_transpose(Lv.P, Lv.R);
+    t_phase[2] += wall_time() - tp0;
+    tp0 = wall_time();
 
     // coarse partition
     std::vector<gidx> cstarts((size_t)comm.size + 1, 0);
@@ -836,13 +844,18 @@ void BoomerAMG::setup_host(ParCSR &A0) {
       An->col_map_offd = cm;
     }
     An->build_halo_plan(comm);
+    t_phase[3] += wall_time() - tp0;
     L.emplace_back();
     L[(size_t)l + 1].A_own = std::move(An);
     L[(size_t)l + 1].A = L[(size_t)l + 1].A_own.get();
     l++;
   }
 
-  apply_cf_ordering();
+  {
+    const double tp0 = wall_time();
+    apply_cf_ordering();
+    t_phase[4] += wall_time() - tp0;
+  }
 
   // per-level norms (host), on the C-first ordered operators
   const int ch = chunk();
@@ -918,6 +931,7 @@ void BoomerAMG::setup_host(ParCSR &A0) {
     Lc.Cinv_host.swap(Mp);
     Lc.dense = true;
   }
+  t_phase[5] = wall_time() - t_setup_start;
   host_ready = true;
 }
 
@@ -966,6 +980,8 @@ void BoomerAMG::setup_device() {
   if (p.print_level > 0 && comm.rank == 0) {
     printf("mi_hypre BoomerAMG setup: %zu levels, operator complexity %.3f, chunk %d, %.3f s\n", L.size(),
            operator_complexity(), ch, setup_seconds);
+    printf("   host phases: strength %.2f  pmis %.2f  interp %.2f  galerkin %.2f  C-first ordering %.2f  (host total %.2f) s\n",
+           t_phase[0], t_phase[1], t_phase[2], t_phase[3], t_phase[4], t_phase[5]);
     for (size_t li = 0; li < L.size(); li++)
       printf("   level %2zu: local rows %10d  global rows %12lld  local nnz %12lld\n", li, L[li].n,
              (long long)L[li].A->global_rows(), (long long)(L[li].A->diag.nnz() + L[li].A->offd.nnz()));
