@@ -76,12 +76,13 @@ struct BoomerAMG {
   // HYPRE_BoomerAMGSolve: x is the initial guess; up to max_iter cycles
   void solve(ParCSR &A, ParVector &b, ParVector &x);
 
-  // pieces (exposed for the parity tests); vectors are in the level's own
-  // (C-first) ordering and are updated in place
-  // u_is_zero: the caller guarantees u == 0 on entry (its halo is then known to be zero)
-  void relax(int level, int type, int points, const double *f, double *u, bool u_is_zero = false);
-  void relax_sweeps(int level, int which, const double *f, double *u, bool u_is_zero = false);
-  void cycle(int level, const double *f, double *u, bool u_is_zero = false);
+  // pieces (exposed for the parity tests).  Each level works on its own vectors
+  // Lv.u / Lv.f in the level's C-first ordering.
+  // u_is_zero: the caller guarantees Lv.u == 0 on entry (its halo is then known to be zero)
+  void relax(int level, int type, int points, const double *f, bool u_is_zero = false);
+  void relax_pair(int level, int type, int first, const double *f, bool u_is_zero = false);
+  void relax_sweeps(int level, int which, const double *f, bool u_is_zero = false);
+  void cycle(int level, bool u_is_zero = false);
   // renumber every level C-first (host, collective); called at the end of setup_host
   void apply_cf_ordering();
   double operator_complexity() const;

@@ -4,8 +4,12 @@
 // once per Arnoldi step from the GMRES loop.
 //
 // Every level works in its own C-first ordering (amg_setup.cpp,
-// apply_cf_ordering): a C pass sweeps rows [0, nc), an F pass rows [nc, n), so
-// the two passes of a sweep together stream the level's matrix once.
+// apply_cf_ordering) on its own vectors: a C pass sweeps rows [0, nc), an F pass
+// rows [nc, n), so the two passes of a sweep together stream the level's matrix
+// once.  The second pass of a C/F pair reads the first pass's rows straight
+// from the scratch vector (composite source), and the pair ends with a pointer
+// swap instead of a copy.
+#include <algorithm>
 #include <cmath>
 
 #include "amg.hpp"
@@ -18,87 +22,143 @@ bool &zero_guess_hint() {
   return hint;
 }
 
-// one relaxation call, u updated in place (level ordering)
-void BoomerAMG::relax(int level, int type, int points, const double *f, double *u, bool u_is_zero) {
+namespace {
+struct GsKind {
+  bool jacobi, l1, fwd, bwd;
+};
+GsKind classify(int type) {
+  GsKind g{};
+  g.jacobi = (type == 0 || type == 7 || type == 18);
+  g.l1 = (type == 8 || type == 13 || type == 14 || type == 18);
+  g.fwd = (type == 3 || type == 6 || type == 8 || type == 13);
+  g.bwd = (type == 4 || type == 6 || type == 8 || type == 14);
+  if (!g.jacobi && !g.fwd && !g.bwd) fail(4, "BoomerAMG: relax type " + std::to_string(type) + " is not supported");
+  return g;
+}
+
+// coarsest-level direct solve (relax type 9); false when the level is too large
+bool dense_solve(AmgLevel &Lv, Comm &comm, const double *f, double *u, hipStream_t s) {
+  if (!Lv.dense) return false;
+  if (comm.size == 1) {
+    k::dense_matvec(Lv.Cinv.p, f, u, Lv.n, Lv.n, s);
+  } else {
+    k::copy(f, Lv.fslot.p, Lv.n, s);
+    comm.allgather_dev(Lv.fslot.p, Lv.fgather.p, (size_t)Lv.slot * sizeof(double), s);
+    k::dense_matvec(Lv.Cinv.p, Lv.fgather.p, u, Lv.n, comm.size * Lv.slot, s);
+  }
+  return true;
+}
+}  // namespace
+
+// one relaxation call on the level's current vector Lv.u (level ordering), in place
+void BoomerAMG::relax(int level, int type, int points, const double *f, bool u_is_zero) {
   AmgLevel &Lv = L[(size_t)level];
   ParCSR &A = *Lv.A;
   Comm &comm = current_comm();
   hipStream_t s = ctx().stream;
   const int prof = (level == 0) ? k::PROF_RELAX_L0 : k::PROF_NONE;
+  double *u = Lv.u.p;
   if (type == 9) {
-    if (Lv.dense) {
-      if (comm.size == 1) {
-        k::dense_matvec(Lv.Cinv.p, f, u, Lv.n, Lv.n, s);
-      } else {
-        k::copy(f, Lv.fslot.p, Lv.n, s);
-        comm.allgather_dev(Lv.fslot.p, Lv.fgather.p, (size_t)Lv.slot * sizeof(double), s);
-        k::dense_matvec(Lv.Cinv.p, Lv.fgather.p, u, Lv.n, comm.size * Lv.slot, s);
-      }
-      return;
-    }
+    if (dense_solve(Lv, comm, f, u, s)) return;
     type = p.relax_type[0];  // coarsest level too large for a dense solve
   }
+  const GsKind g = classify(type);
   const double w = p.relax_weight * p.outer_weight;
   const bool has_cf = !Lv.cf.empty();
   const signed char *cf = has_cf ? Lv.d_cf.p : nullptr;
   if (!has_cf) points = 0;
   // a zero vector has a zero halo: no exchange, no halo contribution
   const double *offc = u_is_zero ? nullptr : A.offd_contrib(comm, u, s);
-  if (type == 0 || type == 7 || type == 18) {
-    const double *d = (type == 18) ? Lv.d_l1jac.p : Lv.d_diag.p;
-    k::jacobi(A.d_diag, u, Lv.snap.p, f, offc, d, cf, points, w, s, prof);
-    k::copy(Lv.snap.p, u, Lv.n, s);
+  if (g.jacobi) {
+    k::jacobi(A.d_diag, u, Lv.snap.p, f, offc, type == 18 ? Lv.d_l1jac.p : Lv.d_diag.p, cf, points, w, s, prof);
+    std::swap(Lv.u.p, Lv.snap.p);  // every row was written
     return;
   }
-  const bool l1 = (type == 8 || type == 13 || type == 14);
-  const bool fwd = (type == 3 || type == 6 || type == 8 || type == 13);
-  const bool bwd = (type == 4 || type == 6 || type == 8 || type == 14);
-  if (!fwd && !bwd) fail(4, "BoomerAMG: relax type " + std::to_string(type) + " is not supported");
   const int row_begin = (points == -1) ? Lv.nc : 0;
   const int row_end = (points == 1) ? Lv.nc : Lv.n;
-  k::gs_hybrid(A.d_diag, u, Lv.snap.p, f, offc, l1 ? Lv.d_l1gs.p : Lv.d_diag.p, cf, points, chunk(), fwd, bwd, w,
+  if (row_end <= row_begin) return;
+  const int ch = chunk();
+  k::gs_hybrid(A.d_diag, u, u, 0, Lv.snap.p, f, offc, g.l1 ? Lv.d_l1gs.p : Lv.d_diag.p, cf, points, ch, g.fwd, g.bwd, w,
                row_begin, row_end, s, prof);
+  if (row_begin == 0 && row_end == Lv.n) {
+    std::swap(Lv.u.p, Lv.snap.p);
+  } else {  // lone C or F pass: only the swept chunks were written
+    const long long r0 = (long long)(row_begin / ch) * ch;
+    const long long r1 = std::min<long long>(((long long)row_end + ch - 1) / ch * ch, Lv.n);
+    k::copy(Lv.snap.p + r0, u + r0, (int)(r1 - r0), s);
+  }
+}
+
+// a C/F pair of hybrid-GS passes (first = +1: C then F, first = -1: F then C)
+// without the intermediate copy
+void BoomerAMG::relax_pair(int level, int type, int first, const double *f, bool u_is_zero) {
+  AmgLevel &Lv = L[(size_t)level];
+  const GsKind g = classify(type);
+  if (g.jacobi || Lv.cf.empty() || Lv.nc == 0 || Lv.nc == Lv.n) {
+    relax(level, type, first, f, u_is_zero);
+    relax(level, type, -first, f, false);
+    return;
+  }
+  ParCSR &A = *Lv.A;
+  Comm &comm = current_comm();
+  hipStream_t s = ctx().stream;
+  const int prof = (level == 0) ? k::PROF_RELAX_L0 : k::PROF_NONE;
+  const double w = p.relax_weight * p.outer_weight;
+  const double *d = g.l1 ? Lv.d_l1gs.p : Lv.d_diag.p;
+  const int ch = chunk(), nc = Lv.nc, n = Lv.n;
+  double *u = Lv.u.p, *sn = Lv.snap.p;
+  // pass 1: everything is read from u; its swept rows land in snap
+  const double *offc = u_is_zero ? nullptr : A.offd_contrib(comm, u, s);
+  if (first == 1)
+    k::gs_hybrid(A.d_diag, u, u, 0, sn, f, offc, d, Lv.d_cf.p, 1, ch, g.fwd, g.bwd, w, 0, nc, s, prof);
+  else
+    k::gs_hybrid(A.d_diag, u, u, 0, sn, f, offc, d, Lv.d_cf.p, -1, ch, g.fwd, g.bwd, w, nc, n, s, prof);
+  // pass 2: the rows pass 1 updated are read from snap, the others from u
+  const double *lo = (first == 1) ? sn : u;
+  const double *hi = (first == 1) ? u : sn;
+  offc = A.offd_contrib(comm, lo, s, hi, nc);
+  if (first == 1)
+    k::gs_hybrid(A.d_diag, lo, hi, nc, sn, f, offc, d, Lv.d_cf.p, -1, ch, g.fwd, g.bwd, w, nc, n, s, prof);
+  else
+    k::gs_hybrid(A.d_diag, lo, hi, nc, sn, f, offc, d, Lv.d_cf.p, 1, ch, g.fwd, g.bwd, w, 0, nc, s, prof);
+  std::swap(Lv.u.p, Lv.snap.p);  // snap now holds every row
 }
 
 // which: 0 down, 1 up, 2 coarsest.  relax_order 1: C then F going down, F then
 // C going up, all points on the coarsest level (hypre_BoomerAMGRelaxIF)
-void BoomerAMG::relax_sweeps(int level, int which, const double *f, double *u, bool u_is_zero) {
+void BoomerAMG::relax_sweeps(int level, int which, const double *f, bool u_is_zero) {
   const int type = p.relax_type[which];
   const bool has_cf = !L[(size_t)level].cf.empty();
   for (int sw = 0; sw < p.num_sweeps[which]; sw++) {
     const bool zero = u_is_zero && sw == 0;
-    if (which == 2 || p.relax_order != 1 || !has_cf) {
-      relax(level, type, 0, f, u, zero);
-    } else if (which == 0) {
-      relax(level, type, 1, f, u, zero);
-      relax(level, type, -1, f, u);
-    } else {
-      relax(level, type, -1, f, u);
-      relax(level, type, 1, f, u);
-    }
+    if (which == 2 || p.relax_order != 1 || !has_cf)
+      relax(level, type, 0, f, zero);
+    else
+      relax_pair(level, type, which == 0 ? 1 : -1, f, zero);
   }
 }
 
-void BoomerAMG::cycle(int level, const double *f, double *u, bool u_is_zero) {
+// one cycle on the level's own f (Lv.f) and u (Lv.u)
+void BoomerAMG::cycle(int level, bool u_is_zero) {
   const int nlev = (int)L.size();
+  AmgLevel &Lv = L[(size_t)level];
   if (level == nlev - 1) {
-    relax_sweeps(level, 2, f, u, u_is_zero);
+    relax_sweeps(level, 2, Lv.f.p, u_is_zero);
     return;
   }
-  AmgLevel &Lv = L[(size_t)level];
   AmgLevel &Ln = L[(size_t)level + 1];
   Comm &comm = current_comm();
   hipStream_t s = ctx().stream;
-  relax_sweeps(level, 0, f, u, u_is_zero && p.num_sweeps[0] > 0);
+  relax_sweeps(level, 0, Lv.f.p, u_is_zero && p.num_sweeps[0] > 0);
   // r = f - A u ; f_c = P^T r ; u_c = 0
-  Lv.A->matvec(comm, -1.0, u, 1.0, f, Lv.tmp.p, s);
+  Lv.A->matvec(comm, -1.0, Lv.u.p, 1.0, Lv.f.p, Lv.tmp.p, s);
   k::spmv(Lv.dR, Lv.tmp.p, 1.0, 0.0, nullptr, Ln.f.p, s);
   k::fill(Ln.u.p, Ln.n, 0.0, s);
   const int ncyc = (p.cycle_type == 2 && level + 1 < nlev - 1) ? 2 : 1;
-  for (int c = 0; c < ncyc; c++) cycle(level + 1, Ln.f.p, Ln.u.p, c == 0);
+  for (int c = 0; c < ncyc; c++) cycle(level + 1, c == 0);
   // u += P e
-  k::spmv(Lv.dP, Ln.u.p, 1.0, 1.0, u, u, s);
-  relax_sweeps(level, 1, f, u);
+  k::spmv(Lv.dP, Ln.u.p, 1.0, 1.0, Lv.u.p, Lv.u.p, s);
+  relax_sweeps(level, 1, Lv.f.p, false);
 }
 
 void BoomerAMG::solve(ParCSR &A, ParVector &b, ParVector &x) {
@@ -112,23 +172,28 @@ void BoomerAMG::solve(ParCSR &A, ParVector &b, ParVector &x) {
   int it = 0;
   double rel = 0.0, bn = 0.0;
   if (p.tol > 0.0) bn = std::sqrt(par_dot_host(comm, b.data(), b.data(), b.n, s));
-  if (permuted) k::gather(b.data(), L0.d_perm.p, L0.f.p, L0.n, s);  // caller order -> C-first order
+  // caller order -> level-0 (C-first) order
+  if (permuted)
+    k::gather(b.data(), L0.d_perm.p, L0.f.p, L0.n, s);
+  else
+    k::copy(b.data(), L0.f.p, L0.n, s);
   // a Krylov solver that has just zeroed x says so (krylov.cpp): the first cycle
   // then needs neither x nor its halo
   const bool zero_first = zero_guess_hint();
   zero_guess_hint() = false;
   while (it < p.max_iter) {
     const bool zero = zero_first && it == 0;
-    if (permuted) {
-      if (zero)
-        k::fill(L0.u.p, L0.n, 0.0, s);
-      else
-        k::gather(x.data(), L0.d_perm.p, L0.u.p, L0.n, s);
-      cycle(0, L0.f.p, L0.u.p, zero);
+    if (zero)
+      k::fill(L0.u.p, L0.n, 0.0, s);
+    else if (permuted)
+      k::gather(x.data(), L0.d_perm.p, L0.u.p, L0.n, s);
+    else
+      k::copy(x.data(), L0.u.p, L0.n, s);
+    cycle(0, zero);
+    if (permuted)
       k::scatter_set(x.data(), L0.d_perm.p, L0.u.p, L0.n, s);
-    } else {
-      cycle(0, b.data(), x.data(), zero);
-    }
+    else
+      k::copy(L0.u.p, x.data(), L0.n, s);
     it++;
     if (p.tol > 0.0) {
       A.matvec(comm, -1.0, x.data(), 1.0, b.data(), L0.tmp.p, s);

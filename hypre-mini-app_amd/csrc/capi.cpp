@@ -1104,15 +1104,16 @@ HYPRE_Int HYPRE_MI_BoomerAMGRelaxLevel(HYPRE_Solver solver, HYPRE_Int level, HYP
   AmgSolver *a = AMG(solver);
   if (!a->amg.is_setup) fail(HYPRE_ERROR_GENERIC, "RelaxLevel: AMG is not set up");
   if (level < 0 || level >= (int)a->amg.L.size()) fail(HYPRE_ERROR_ARG, "AMG level out of range");
-  const int n = a->amg.L[(size_t)level].n;
-  DVec<double> f((size_t)n), u((size_t)n);
+  AmgLevel &Lv = a->amg.L[(size_t)level];
+  const int n = Lv.n;
+  DVec<double> f((size_t)n);
   if (n) {
     f.upload(f_host, (size_t)n);
-    u.upload(u_host, (size_t)n);
+    MI_HIP(hipMemcpy(Lv.u.p, u_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
   }
-  a->amg.relax(level, relax_type, points, f.p, u.p);
+  a->amg.relax(level, relax_type, points, f.p);
   MI_HIP(hipStreamSynchronize(ctx().stream));
-  if (n) u.download(u_host, (size_t)n);
+  if (n) MI_HIP(hipMemcpy(u_host, Lv.u.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
   API_END
 }
 HYPRE_Int HYPRE_MI_ProfileEnable(HYPRE_Int id, HYPRE_Int capacity) {

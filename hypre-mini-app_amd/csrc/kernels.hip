@@ -223,15 +223,17 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_hybrid_k(int n, int chunk0, int n
                                                         const signed char *__restrict__ cf, int points,
                                                         const double *__restrict__ dd, const double *__restrict__ f,
                                                         const double *__restrict__ offc,
-                                                        const double *__restrict__ u_old, double *__restrict__ u_new,
-                                                        int fwd, int bwd, double w) {
+                                                        const double *__restrict__ u_lo,
+                                                        const double *__restrict__ u_hi, int split,
+                                                        double *__restrict__ u_new, int fwd, int bwd, double w) {
+#define UOLD(j) (((j) < split ? u_lo : u_hi)[(j)])
   extern __shared__ double ucur[];  // [chunk][GS_BLOCK]
   const int tid = threadIdx.x;
   const long long c = chunk0 + (long long)blockIdx.x * GS_BLOCK + tid;
   if (c >= nchunks) return;
   const int cs = (int)(c * chunk);
   const int len = min(chunk, n - cs);
-  for (int t = 0; t < len; t++) ucur[t * GS_BLOCK + tid] = u_old[cs + t];
+  for (int t = 0; t < len; t++) ucur[t * GS_BLOCK + tid] = UOLD(cs + t);
   for (int dir = 0; dir < 2; dir++) {
     if (dir == 0 ? !fwd : !bwd) continue;
     for (int t = 0; t < len; t++) {
@@ -246,13 +248,14 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_hybrid_k(int n, int chunk0, int n
       for (int k = ia[i]; k < k1; k++) {
         const int j = ja[k];
         const unsigned o = (unsigned)(j - cs);
-        const double v = (o < (unsigned)len) ? ucur[o * GS_BLOCK + tid] : u_old[j];
+        const double v = (o < (unsigned)len) ? ucur[o * GS_BLOCK + tid] : UOLD(j);
         res -= av[k] * v;
       }
       ucur[tt * GS_BLOCK + tid] += w * res / d;
     }
   }
   for (int t = 0; t < len; t++) u_new[cs + t] = ucur[t * GS_BLOCK + tid];
+#undef UOLD
 }
 
 // ---------------------------------------------------------------------------
@@ -299,8 +302,10 @@ __global__ __launch_bounds__(256) void gs_group_k(int n, int chunk0, int nchunks
                                                   const signed char *__restrict__ cf, int points,
                                                   const double *__restrict__ dd, const double *__restrict__ f,
                                                   const double *__restrict__ offc,
-                                                  const double *__restrict__ u_old, double *__restrict__ u_new,
-                                                  int fwd, int bwd, double w) {
+                                                  const double *__restrict__ u_lo,
+                                                  const double *__restrict__ u_hi, int split,
+                                                  double *__restrict__ u_new, int fwd, int bwd, double w) {
+#define UOLD(j) (((j) < split ? u_lo : u_hi)[(j)])
   constexpr int R = 8;
   constexpr int CPW = 64 / LPC;
   const int lane = threadIdx.x & 63;
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(256) void gs_group_k(int n, int chunk0, int nchunks
     my_k0 = ia[i];
     const int a1 = ia[i + 1];
     const int mark = (points != 0 && cf != nullptr) ? (int)cf[i] : points;
-    myu = u_old[i];
+    myu = UOLD(i);
     myd = dd[i];
     myrhs = f[i];
     if (offc) myrhs -= offc[i];
@@ -363,7 +368,7 @@ __global__ __launch_bounds__(256) void gs_group_k(int n, int chunk0, int nchunks
       const int j = cols[t][e];
       const unsigned oo = (unsigned)(j - cs);
       const bool inch = oo < (unsigned)len;
-      const double x = u_old[j];  // unconditional gather: no load waits on a branch
+      const double x = UOLD(j);  // unconditional gather: no load waits on a branch
       code[e] |= (inch ? oo : 15u) << (4 * t);
       if (!inch) wv[t][e] *= x;
     }
@@ -395,7 +400,7 @@ __global__ __launch_bounds__(256) void gs_group_k(int n, int chunk0, int nchunks
             if (oo < (unsigned)len)
               o = (int)oo;
             else
-              x = u_old[j];
+              x = UOLD(j);
           }
           const double cur = __shfl(myu, gbase + (o < 0 ? 0 : o), 64);
           part += v * (o < 0 ? x : cur);
@@ -406,6 +411,7 @@ __global__ __launch_bounds__(256) void gs_group_k(int n, int chunk0, int nchunks
     }
   }
   if (g < len) u_new[cs + g] = myu;
+#undef UOLD
 }
 
 // ---------------------------------------------------------------------------
@@ -490,6 +496,15 @@ __global__ __launch_bounds__(256) void gather_k(const double *__restrict__ x, co
                                                 double *__restrict__ out, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) out[i] = x[map[i]];
+}
+
+__global__ __launch_bounds__(256) void gather2_k(const double *__restrict__ lo, const double *__restrict__ hi, int split,
+                                                 const int *__restrict__ map, double *__restrict__ out, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const int j = map[i];
+    out[i] = (j < split ? lo : hi)[j];
+  }
 }
 
 template <int ADD>
@@ -611,14 +626,13 @@ void spmv_offd_set(const DevOffd &B, const double *xext, double *out, hipStream_
   MI_HIP(hipGetLastError());
 }
 
-void gs_hybrid(const DevCSR &A, double *u, double *tmp, const double *f, const double *offc, const double *d,
-               const signed char *cf, int points, int chunk, bool fwd, bool bwd, double w, int row_begin, int row_end,
-               hipStream_t s, int prof) {
+void gs_hybrid(const DevCSR &A, const double *u_lo, const double *u_hi, int split, double *out, const double *f,
+               const double *offc, const double *d, const signed char *cf, int points, int chunk, bool fwd, bool bwd,
+               double w, int row_begin, int row_end, hipStream_t s, int prof) {
   if (A.nrows == 0 || row_end <= row_begin) return;
   MI_REQUIRE(chunk >= 1 && chunk <= GS_MAX_CHUNK, "hybrid GS chunk out of range");
-  // chunks that intersect [row_begin, row_end); the kernel reads u everywhere
-  // (pre-sweep values) and writes the swept chunks into tmp, which is then
-  // copied back over the same rows
+  // chunks that intersect [row_begin, row_end); pre-sweep values come from u_lo
+  // (rows < split) / u_hi (rows >= split), the swept chunks' rows go to out
   const long long c0 = row_begin / chunk;
   const long long c1 = ((long long)row_end + chunk - 1) / chunk;
   const long long nch = c1 - c0;
@@ -630,8 +644,8 @@ void gs_hybrid(const DevCSR &A, double *u, double *tmp, const double *f, const d
   {                                                                                                             \
     const long long waves = (nch + (64 / LPC) - 1) / (64 / LPC);                                                \
     hipLaunchKernelGGL((gs_group_k<LPC, E>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, A.nrows,       \
-                       (int)c0, (int)c1, A.ia.p, A.ja.p, A.a.p, cf, points, d, f, offc, u, tmp, fwd ? 1 : 0,     \
-                       bwd ? 1 : 0, w);                                                                         \
+                       (int)c0, (int)c1, A.ia.p, A.ja.p, A.a.p, cf, points, d, f, offc, u_lo, u_hi, split, out,  \
+                       fwd ? 1 : 0, bwd ? 1 : 0, w);                                                                         \
   }
     // lanes per chunk from the mean row length, strips so that ~95 % of the rows
     // are fully preloaded (the rest take the in-sweep path)
@@ -640,7 +654,7 @@ void gs_hybrid(const DevCSR &A, double *u, double *tmp, const double *f, const d
     } else if (avg <= 16.0) {
       if (p95 <= 16) GS_LAUNCH(16, 1) else GS_LAUNCH(16, 2)
     } else if (avg <= 32.0) {
-      if (p95 <= 32) GS_LAUNCH(32, 1) else GS_LAUNCH(32, 2)
+      if (p95 <= 32) GS_LAUNCH(32, 1) else GS_LAUNCH(64, 1)  // measured: <64,1> beats <32,2> by ~6 % on level 1
     } else {
       if (p95 <= 64) GS_LAUNCH(64, 1) else if (p95 <= 128) GS_LAUNCH(64, 2) else GS_LAUNCH(64, 4)
     }
@@ -648,14 +662,11 @@ void gs_hybrid(const DevCSR &A, double *u, double *tmp, const double *f, const d
   } else {
     const size_t lds = (size_t)chunk * GS_BLOCK * sizeof(double);
     hipLaunchKernelGGL(gs_hybrid_k, dim3((unsigned)((nch + GS_BLOCK - 1) / GS_BLOCK)), dim3(GS_BLOCK), lds, s,
-                       A.nrows, (int)c0, (int)c1, chunk, A.ia.p, A.ja.p, A.a.p, cf, points, d, f, offc, u, tmp,
-                       fwd ? 1 : 0, bwd ? 1 : 0, w);
+                       A.nrows, (int)c0, (int)c1, chunk, A.ia.p, A.ja.p, A.a.p, cf, points, d, f, offc, u_lo, u_hi,
+                       split, out, fwd ? 1 : 0, bwd ? 1 : 0, w);
   }
   MI_HIP(hipGetLastError());
   prof_end(prof, s);
-  const long long r0 = c0 * chunk;
-  const long long r1 = std::min<long long>(c1 * chunk, A.nrows);
-  MI_HIP(hipMemcpyAsync(u + r0, tmp + r0, (size_t)(r1 - r0) * sizeof(double), hipMemcpyDeviceToDevice, s));
 }
 
 void dot(const double *x, const double *y, int n, double *out_dev, hipStream_t s) {
@@ -700,6 +711,11 @@ void fill(double *x, int n, double v, hipStream_t s) {
 void copy(const double *x, double *y, int n, hipStream_t s) {
   if (n == 0 || x == y) return;
   MI_HIP(hipMemcpyAsync(y, x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+}
+void gather2(const double *lo, const double *hi, int split, const int *map, double *out, int n, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(gather2_k, dim3((n + 255) / 256), dim3(256), 0, s, lo, hi, split, map, out, n);
+  MI_HIP(hipGetLastError());
 }
 void gather(const double *x, const int *map, double *out, int n, hipStream_t s) {
   if (n == 0) return;

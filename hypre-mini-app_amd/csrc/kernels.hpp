@@ -33,10 +33,13 @@ void jacobi(const DevCSR &A, const double *u_old, double *u_new, const double *f
 // hybrid Gauss-Seidel family: chunks of `chunk` consecutive rows are swept
 // sequentially (forward and/or backward), chunks see each other's pre-sweep
 // values.  Only the chunks that intersect [row_begin, row_end) are swept (a C or
-// an F pass of a C-first ordered level); u is updated in place through tmp.
-void gs_hybrid(const DevCSR &A, double *u, double *tmp, const double *f, const double *offc, const double *d,
-               const signed char *cf, int points, int chunk, bool fwd, bool bwd, double w, int row_begin, int row_end,
-               hipStream_t s, int prof = PROF_NONE);
+// an F pass of a C-first ordered level).  Pre-sweep values are read from u_lo
+// for rows < split and from u_hi for rows >= split (the second pass of a C/F
+// pair reads the first pass's output without a copy); the swept chunks' rows are
+// written to out.
+void gs_hybrid(const DevCSR &A, const double *u_lo, const double *u_hi, int split, double *out, const double *f,
+               const double *offc, const double *d, const signed char *cf, int points, int chunk, bool fwd, bool bwd,
+               double w, int row_begin, int row_end, hipStream_t s, int prof = PROF_NONE);
 
 // BLAS-1
 void dot(const double *x, const double *y, int n, double *out_dev, hipStream_t s);  // local sum, no collective
@@ -47,6 +50,8 @@ void scale_inv_sqrt_dev(const double *sumsq_dev, double *x, int n, hipStream_t s
 void fill(double *x, int n, double v, hipStream_t s);
 void copy(const double *x, double *y, int n, hipStream_t s);
 void gather(const double *x, const int *map, double *out, int n, hipStream_t s);
+// out[i] = (map[i] < split ? lo : hi)[map[i]]
+void gather2(const double *lo, const double *hi, int split, const int *map, double *out, int n, hipStream_t s);
 // u = M f, M dense n x m row-major
 void dense_matvec(const double *M, const double *f, double *u, int n, int m, hipStream_t s);
 

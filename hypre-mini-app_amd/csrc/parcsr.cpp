@@ -225,10 +225,13 @@ void ParCSR::to_device() {
   on_device = true;
 }
 
-void ParCSR::halo_exchange(Comm &comm, const double *x, hipStream_t s) {
+void ParCSR::halo_exchange(Comm &comm, const double *x, hipStream_t s, const double *x_hi, int split) {
   if (comm.size == 1) return;
   if (halo.send_peers.empty() && halo.recv_peers.empty()) return;
-  k::gather(x, halo.d_send_map.p, halo.d_send_buf.p, halo.nsend(), s);
+  if (x_hi)
+    k::gather2(x, x_hi, split, halo.d_send_map.p, halo.d_send_buf.p, halo.nsend(), s);
+  else
+    k::gather(x, halo.d_send_map.p, halo.d_send_buf.p, halo.nsend(), s);
   std::vector<PeerBuf> sb, rb;
   for (size_t i = 0; i < halo.send_peers.size(); i++)
     sb.push_back({halo.send_peers[i], halo.d_send_buf.p + halo.send_starts[i],
@@ -272,9 +275,9 @@ void ParCSR::matvec(Comm &comm, double alpha, const double *x, double beta, cons
   if (halo_on) k::spmv_offd_add(d_offd, halo.d_xext.p, alpha, y, s);
 }
 
-const double *ParCSR::offd_contrib(Comm &comm, const double *x, hipStream_t s) {
+const double *ParCSR::offd_contrib(Comm &comm, const double *x, hipStream_t s, const double *x_hi, int split) {
   if (comm.size == 1) return nullptr;
-  halo_exchange(comm, x, s);
+  halo_exchange(comm, x, s, x_hi, split);
   if (d_offd.nrows_c == 0) return nullptr;
   k::spmv_offd_set(d_offd, halo.d_xext.p, d_offc.p, s);
   return d_offc.p;

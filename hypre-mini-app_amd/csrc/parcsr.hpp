@@ -49,14 +49,15 @@ struct ParCSR {
     to_device();
   }
   // x_ext <- halo values of x (pack + neighbour exchange), enqueued on stream
-  void halo_exchange(Comm &comm, const double *x, hipStream_t s);
+  // (optional composite source: rows < split from x, rows >= split from x_hi)
+  void halo_exchange(Comm &comm, const double *x, hipStream_t s, const double *x_hi = nullptr, int split = 0);
   // host-side halo exchange of an arbitrary per-row int array (setup only)
   std::vector<int> halo_exchange_host_int(Comm &comm, const std::vector<int> &local) const;
   // y = alpha*A*x + beta*b
   void matvec(Comm &comm, double alpha, const double *x, double beta, const double *b, double *y, hipStream_t s,
               int prof = -1);
   // offc[halo rows] = A_offd * x_ext(x)   (used by the smoothers)
-  const double *offd_contrib(Comm &comm, const double *x, hipStream_t s);
+  const double *offd_contrib(Comm &comm, const double *x, hipStream_t s, const double *x_hi = nullptr, int split = 0);
 };
 
 // global dot product: local two-stage reduction + one all-reduce; result stays on
