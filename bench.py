@@ -194,7 +194,7 @@ def main():
         chunk = C.c_int()
         mi.call("HYPRE_MI_GetGSChunk", C.byref(chunk))
         out = {
-            "metric": "GMRES+AMG solve GDOF/s (N_global * iterations / t_solve)",
+            "metric": "GMRES+AMG solve GDOF/s (N_global*iterations/t_solve; iterations/sec in iterations_per_s), %d^3 Laplacian" % n,
             "value": ndof * iters_total / elapsed / 1e9,
             "unit": "GDOF/s",
             "n_gpus": world,
