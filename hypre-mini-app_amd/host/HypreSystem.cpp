@@ -21,6 +21,7 @@
 #include <limits>
 #include <sstream>
 #include <stdexcept>
+#include <thread>
 
 namespace nalu {
 
@@ -101,6 +102,62 @@ inline bool next_dbl(const char *&b, const char *e, double &v) {
   char *q = nullptr;
   v = strtod(buf, &q);
   return q != buf;
+}
+
+// The big text files (a 10 M-row MatrixMarket dump is several GB) are parsed by a
+// pool of threads: the mapping is cut at line boundaries into one slice per thread,
+// every thread parses its slice into its own triples, and the slices are appended
+// in file order (so duplicate entries keep their submission order).
+struct Triples {
+  std::vector<HYPRE_BigInt> rows, cols;
+  std::vector<double> vals;
+};
+template <class LineFn>
+void parse_lines_parallel(const char *begin, const char *end, const LineFn &fn, std::vector<HYPRE_BigInt> &rows,
+                          std::vector<HYPRE_BigInt> &cols, std::vector<double> &vals) {
+  const size_t bytes = (size_t)(end - begin);
+  unsigned nt = std::thread::hardware_concurrency();
+  if (getenv("MI_HYPRE_HOST_THREADS")) nt = (unsigned)atoi(getenv("MI_HYPRE_HOST_THREADS"));
+  nt = std::max(1u, std::min(nt, 16u));
+  if (bytes < (size_t)(4 << 20)) nt = 1;
+  std::vector<const char *> cut(nt + 1, end);
+  cut[0] = begin;
+  for (unsigned t = 1; t < nt; t++) {
+    const char *p = begin + bytes * t / nt;
+    const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+    cut[t] = nl ? nl + 1 : end;
+  }
+  std::vector<Triples> part(nt);
+  std::vector<std::string> err(nt);
+  std::vector<std::thread> pool;
+  for (unsigned t = 0; t < nt; t++)
+    pool.emplace_back([&, t]() {
+      try {
+        TextCursor cur(cut[t], (size_t)(cut[t + 1] - cut[t]));
+        while (!cur.done()) {
+          auto ln = cur.line();
+          fn(ln.first, ln.second, part[t]);
+        }
+      } catch (const std::exception &e) {
+        err[t] = e.what();
+      }
+    });
+  for (auto &th : pool) th.join();
+  for (auto &e : err)
+    if (!e.empty()) throw std::runtime_error(e);
+  size_t total = rows.size();
+  for (auto &p : part) total += p.vals.size();
+  rows.reserve(total);
+  cols.reserve(total);
+  vals.reserve(total);
+  for (auto &p : part) {
+    rows.insert(rows.end(), p.rows.begin(), p.rows.end());
+    cols.insert(cols.end(), p.cols.begin(), p.cols.end());
+    vals.insert(vals.end(), p.vals.begin(), p.vals.end());
+    Triples().rows.swap(p.rows);
+    std::vector<HYPRE_BigInt>().swap(p.cols);
+    std::vector<double>().swap(p.vals);
+  }
 }
 
 // Matrix Market banner + size line (the part of mmio.c the driver uses,
@@ -803,20 +860,18 @@ void HypreSystem::build_ij_matrix(const std::string &matfile, int nfiles) {
           next_ll(b, ln.second, ju)))
       throw std::runtime_error("Cannot read IJ header of " + fn);
     if (std::min<long long>(iUpper_ + 1, iu + 1) - std::max<long long>(iLower_, il) <= 0) continue;
-    while (!cur.done()) {
-      ln = cur.line();
-      b = ln.first;
+    auto on_line = [&](const char *lb, const char *le, Triples &out) {
       long long r, c;
       double v;
-      if (!next_ll(b, ln.second, r)) continue;
-      if (!(next_ll(b, ln.second, c) && next_dbl(b, ln.second, v)))
-        throw std::runtime_error("Malformed IJ matrix line in " + fn);
+      if (!next_ll(lb, le, r)) return;
+      if (!(next_ll(lb, le, c) && next_dbl(lb, le, v))) throw std::runtime_error("Malformed IJ matrix line in " + fn);
       if (r >= iLower_ && r <= iUpper_) {
-        rows_.push_back(r);
-        cols_.push_back(c);
-        vals_.push_back(v);
+        out.rows.push_back(r);
+        out.cols.push_back(c);
+        out.vals.push_back(v);
       }
-    }
+    };
+    parse_lines_parallel(cur.p, cur.end, on_line, rows_, cols_, vals_);
   }
   nnz_ = (long long)vals_.size();
   hypre_matrix_set_values();
@@ -915,35 +970,34 @@ void HypreSystem::build_mm_matrix(const std::string &matfile) {
   vals_.clear();
   const long long lo = complexNumbers_ ? iLower_ / 2 : iLower_;
   const long long hi = complexNumbers_ ? (iUpper_ - 1) / 2 : iUpper_;
-  while (!cur.done()) {
-    auto ln = cur.line();
-    const char *b = ln.first;
-    if (b < ln.second && *b == '%') continue;
+  const bool cplx = complexNumbers_;
+  auto on_line = [&](const char *b, const char *e, Triples &out) {
+    if (b < e && *b == '%') return;
     long long r, c;
     double v, vi = 0.0;
-    if (!next_ll(b, ln.second, r)) continue;
-    if (!(next_ll(b, ln.second, c) && next_dbl(b, ln.second, v)))
-      throw std::runtime_error("Malformed matrix market line in " + matfile);
-    if (complexNumbers_ && !next_dbl(b, ln.second, vi))
+    if (!next_ll(b, e, r)) return;
+    if (!(next_ll(b, e, c) && next_dbl(b, e, v))) throw std::runtime_error("Malformed matrix market line in " + matfile);
+    if (cplx && !next_dbl(b, e, vi))
       throw std::runtime_error("Complex matrix market line without imaginary part in " + matfile);
     r--;
     c--;
-    if (r < lo || r > hi) continue;
-    if (!complexNumbers_) {
-      rows_.push_back(r);
-      cols_.push_back(c);
-      vals_.push_back(v);
+    if (r < lo || r > hi) return;
+    if (!cplx) {
+      out.rows.push_back(r);
+      out.cols.push_back(c);
+      out.vals.push_back(v);
     } else {
       const long long rr[4] = {2 * r, 2 * r, 2 * r + 1, 2 * r + 1};
       const long long cc[4] = {2 * c, 2 * c + 1, 2 * c, 2 * c + 1};
       const double vv[4] = {v, -vi, vi, v};
       for (int q = 0; q < 4; q++) {
-        rows_.push_back(rr[q]);
-        cols_.push_back(cc[q]);
-        vals_.push_back(vv[q]);
+        out.rows.push_back(rr[q]);
+        out.cols.push_back(cc[q]);
+        out.vals.push_back(vv[q]);
       }
     }
-  }
+  };
+  parse_lines_parallel(cur.p, cur.end, on_line, rows_, cols_, vals_);
   hypre_matrix_set_values();
   MPI_Barrier(comm_);
   push_timer("Matrix market : read and build matrix", sw.seconds());

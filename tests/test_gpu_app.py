@@ -193,3 +193,43 @@ solver_settings:
     p = subprocess.run([APP, str(inp)], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                        timeout=300)
     assert "not implemented" in p.stdout
+
+
+def test_matrix_market_parallel_parse(tmp_path):
+    """A file above the 4 MB threshold is cut at line boundaries and parsed by a thread pool;
+    entry order (and with it the duplicate-folding order) must survive."""
+    n = 56
+    T = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(n, n))
+    I = sp.eye(n)
+    A = (sp.kron(sp.kron(I, I), T) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(T, I), I)).tocsr()
+    A.sort_indices()
+    N = A.shape[0]
+    x = np.ones(N)
+    b = A @ x
+    coo = A.tocoo()
+    with open(tmp_path / "mat.mm", "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n% big enough for the threaded parser\n")
+        f.write(f"{N} {N} {coo.nnz + 1}\n")
+        np.savetxt(f, np.column_stack([coo.row + 1, coo.col + 1, coo.data]), fmt="%d %d %.17g")
+        f.write("1 1 6.0\n")  # duplicate of the first entry at the very end: Set semantics, last one wins
+    assert os.path.getsize(tmp_path / "mat.mm") > (4 << 20)
+    _write_mm_vector(tmp_path / "rhs.mm", b)
+    _write_mm_vector(tmp_path / "sln.mm", x)
+    out = _run(tmp_path, """
+linear_system:
+  type: matrix_market
+  matrix_file: mat.mm
+  rhs_file: rhs.mm
+  sln_file: sln.mm
+  rtol: 1.0e-6
+  atol: 1.0e-8
+
+solver_settings:
+  method: gmres
+  preconditioner: boomeramg
+  tolerance: 1.0e-11
+  max_iterations: 100
+  kspace: 50
+  print_level: 0
+""" + DEFAULT_AMG)
+    assert "allClose=1" in out
