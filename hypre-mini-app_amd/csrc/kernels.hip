@@ -436,6 +436,41 @@ __global__ __launch_bounds__(256) void dot_partial_k(const double *__restrict__ 
   if (tid == 0) partials[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
 }
 
+// fused modified-Gram-Schmidt step: y += a*xa (a = scale * *alpha_dev), then the
+// partial dot <xd, y_new> (xd == nullptr: <y_new, y_new>) in the same pass.
+// Same per-thread accumulation pattern as dot_partial_k, so the result is
+// bit-identical to axpy followed by dot.
+__global__ __launch_bounds__(256) void axpy_dot_partial_k(const double *__restrict__ alpha_dev, double scale,
+                                                          const double *__restrict__ xa, double *__restrict__ y,
+                                                          const double *__restrict__ xd, int n,
+                                                          double *__restrict__ partials) {
+  __shared__ double ws[4];
+  const int tid = threadIdx.x;
+  const double a = scale * alpha_dev[0];
+  double s = 0.0;
+  const long long stride = (long long)gridDim.x * 512;
+  long long i = ((long long)blockIdx.x * 256 + tid) * 2;
+  for (; i + 1 < n; i += stride) {
+    const double2 xv = *reinterpret_cast<const double2 *>(xa + i);
+    double2 yv = *reinterpret_cast<double2 *>(y + i);
+    yv.x += a * xv.x;
+    yv.y += a * xv.y;
+    *reinterpret_cast<double2 *>(y + i) = yv;
+    double2 dv = yv;
+    if (xd) dv = *reinterpret_cast<const double2 *>(xd + i);
+    s += dv.x * yv.x + dv.y * yv.y;
+  }
+  if (i < n) {
+    const double yn = y[i] + a * xa[i];
+    y[i] = yn;
+    s += (xd ? xd[i] : yn) * yn;
+  }
+  s = wave_sum(s);
+  if ((tid & 63) == 0) ws[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) partials[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
 __global__ __launch_bounds__(256) void reduce_final_k(const double *__restrict__ partials, int nb,
                                                       double *__restrict__ out) {
   __shared__ double ws[4];
@@ -674,6 +709,17 @@ void dot(const double *x, const double *y, int n, double *out_dev, hipStream_t s
   double *partials = ctx().red_partials.p;
   prof_begin(PROF_DOT, s);
   hipLaunchKernelGGL(dot_partial_k, dim3(g), dim3(256), 0, s, x, y, n, partials);
+  hipLaunchKernelGGL(reduce_final_k, dim3(1), dim3(256), 0, s, partials, g, out_dev);
+  prof_end(PROF_DOT, s);
+  MI_HIP(hipGetLastError());
+}
+
+void axpy_dot(const double *alpha_dev, double scale_, const double *xa, double *y, const double *xd, int n,
+              double *out_dev, hipStream_t s) {
+  const int g = vec_grid(n);
+  double *partials = ctx().red_partials.p;
+  prof_begin(PROF_DOT, s);
+  hipLaunchKernelGGL(axpy_dot_partial_k, dim3(g), dim3(256), 0, s, alpha_dev, scale_, xa, y, xd, n, partials);
   hipLaunchKernelGGL(reduce_final_k, dim3(1), dim3(256), 0, s, partials, g, out_dev);
   prof_end(PROF_DOT, s);
   MI_HIP(hipGetLastError());

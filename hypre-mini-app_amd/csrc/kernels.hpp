@@ -43,6 +43,9 @@ void gs_hybrid(const DevCSR &A, const double *u_lo, const double *u_hi, int spli
 
 // BLAS-1
 void dot(const double *x, const double *y, int n, double *out_dev, hipStream_t s);  // local sum, no collective
+// fused MGS step: y += scale*(*alpha_dev)*xa, then out_dev = <xd, y> (xd == nullptr: <y, y>), local sum
+void axpy_dot(const double *alpha_dev, double scale, const double *xa, double *y, const double *xd, int n,
+              double *out_dev, hipStream_t s);
 void axpy(double alpha, const double *x, double *y, int n, hipStream_t s);
 void axpy_dev(const double *alpha_dev, double scale, const double *x, double *y, int n, hipStream_t s);
 void scale(double alpha, double *x, int n, hipStream_t s);

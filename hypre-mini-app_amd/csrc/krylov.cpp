@@ -100,11 +100,14 @@ int GmresSolver::solve(ParCSR &A, ParVector &b, ParVector &x) {
       ParVector &pim1 = basis(i - 1);
       apply_precond(A, pim1, r);
       A.matvec(comm, 1.0, r.data(), 0.0, nullptr, pi.data(), s, k::PROF_SPMV_L0);
-      for (int j = 0; j < i; j++) {
-        par_dot(comm, basis(j).data(), pi.data(), n, slots + j, s);
-        k::axpy_dev(slots + j, -1.0, basis(j).data(), pi.data(), n, s);
+      // modified Gram-Schmidt with the axpy of step j-1 fused into the dot of step j
+      // (and the last axpy into the norm): h_j = <p_j, w>, w -= h_j p_j, one pass each
+      par_dot(comm, basis(0).data(), pi.data(), n, slots, s);
+      for (int j = 1; j <= i; j++) {
+        k::axpy_dot(slots + j - 1, -1.0, basis(j - 1).data(), pi.data(), j < i ? basis(j).data() : nullptr, n,
+                    slots + j, s);
+        if (comm.size > 1) comm.allreduce_dev(slots + j, 1, CommDType::F64, CommOp::SUM, s);
       }
-      par_dot(comm, pi.data(), pi.data(), n, slots + i, s);
       k::scale_inv_sqrt_dev(slots + i, pi.data(), n, s);
       MI_HIP(hipMemcpyAsync(c.h_pinned, slots, (size_t)(i + 1) * sizeof(double), hipMemcpyDeviceToHost, s));
       MI_HIP(hipStreamSynchronize(s));
