@@ -94,17 +94,34 @@ def main():
 
     mi = ge.load_binding()
     mi.init()
+    transport = "self"
     if world > 1:
         # ncclUniqueId from rank 0 to everyone, then the library opens its own RCCL communicator
-        idbuf = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            raw = (C.c_ubyte * 128)()
-            mi.call("HYPRE_MI_CommGetUniqueId", raw)
-            idbuf = torch.tensor(list(raw), dtype=torch.uint8)
-        idbuf = idbuf.cuda()
-        dist.broadcast(idbuf, src=0)
-        raw = (C.c_ubyte * 128)(*idbuf.cpu().tolist())
-        mi.call("HYPRE_MI_CommInitRCCL", raw, rank, world)
+        transport = "rccl (library communicator: ncclSend/ncclRecv halo groups, ncclAllReduce dots)"
+        ok = 1
+        try:
+            idbuf = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                raw = (C.c_ubyte * 128)()
+                mi.call("HYPRE_MI_CommGetUniqueId", raw)
+                idbuf = torch.tensor(list(raw), dtype=torch.uint8)
+            idbuf = idbuf.cuda()
+            dist.broadcast(idbuf, src=0)
+            raw = (C.c_ubyte * 128)(*idbuf.cpu().tolist())
+            mi.call("HYPRE_MI_CommInitRCCL", raw, rank, world)
+        except Exception as e:  # noqa: BLE001
+            ok = 0
+            print(f"[bench rank {rank}] library RCCL communicator failed: {e}", file=sys.stderr, flush=True)
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            # LOUD fallback, still RCCL: the same collectives through torch.distributed's
+            # communicator, staged through host callbacks (slower; reported in the JSON)
+            transport = "torch.distributed(nccl) callbacks -- library RCCL communicator FAILED, see stderr"
+            if rank == 0:
+                print("[bench] WARNING: falling back to the torch.distributed transport", file=sys.stderr, flush=True)
+            mi.call("HYPRE_MI_CommFinalize")
+            mi.init_comm_torch(dist, device="cuda")
 
     n = args.n
     ndof = n ** 3
@@ -210,6 +227,7 @@ def main():
                 "workload": f"laplace_3d {n}^3 {args.stencil}-pt (N={ndof}), GMRES({args.kdim})+BoomerAMG "
                             f"(PMIS, ext+i, C/F l1-hybrid-SGS chunk {chunk.value}, V(1,1)), tol {args.tol:g}, x0=0",
                 "row_partition": f"{world} contiguous block-row slab(s)",
+                "transport": transport,
             },
             "iterations_per_solve": iters,
             "iterations_per_s": iters_total / elapsed,

@@ -441,9 +441,12 @@ def profile_get(pid):
 _comm_keep = []
 
 
-def init_comm_torch(dist):
+def init_comm_torch(dist, device=None):
     """Bind the library's communicator to a torch.distributed process group through
-    host-buffer callbacks (several ranks may share one GPU this way)."""
+    host-buffer callbacks (several ranks may share one GPU this way).  With a gloo group
+    the buffers travel as CPU tensors; with an nccl group pass device="cuda" and they are
+    staged through device tensors (bench.py's loud fallback when the library's own RCCL
+    communicator cannot be created)."""
     import torch
 
     rank, size = dist.get_rank(), dist.get_world_size()
@@ -454,33 +457,43 @@ def init_comm_torch(dist):
         buf = (C.c_char * nbytes).from_address(ptr)
         return np.frombuffer(buf, dtype=dtype)
 
+    def _to(t):
+        return t.to(device) if device else t
+
     def allreduce(ctx, buf, count, dtype, op):
         dt = np_dt[dtype]
         a = _view(buf, count * np.dtype(dt).itemsize, dt)
-        t = torch.from_numpy(a)
-        dist.all_reduce(t, op=ops[op])
+        if device:
+            t = torch.from_numpy(a.copy()).to(device)
+            dist.all_reduce(t, op=ops[op])
+            a[:] = t.cpu().numpy()
+        else:
+            dist.all_reduce(torch.from_numpy(a), op=ops[op])
 
     def allgather(ctx, send, recv, nbytes):
-        s = torch.from_numpy(_view(send, nbytes).copy())
-        out = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(size)]
+        s = _to(torch.from_numpy(_view(send, nbytes).copy()))
+        out = [_to(torch.empty(nbytes, dtype=torch.uint8)) for _ in range(size)]
         dist.all_gather(out, s)
         r = _view(recv, nbytes * size)
         for i, o in enumerate(out):
-            r[i * nbytes:(i + 1) * nbytes] = o.numpy()
+            r[i * nbytes:(i + 1) * nbytes] = o.cpu().numpy()
 
     def exchange(ctx, nsend, speers, sptrs, sbytes, nrecv, rpeers, rptrs, rbytes):
-        reqs, rbufs = [], []
+        ops_, rbufs = [], []
         for i in range(nrecv):
-            t = torch.empty(rbytes[i], dtype=torch.uint8)
+            t = _to(torch.empty(rbytes[i], dtype=torch.uint8))
             rbufs.append(t)
-            reqs.append(dist.irecv(t, src=rpeers[i]))
+            ops_.append(dist.P2POp(dist.irecv, t, rpeers[i]))
+        keep = []
         for i in range(nsend):
-            t = torch.from_numpy(_view(sptrs[i], sbytes[i]).copy())
-            reqs.append(dist.isend(t, dst=speers[i]))
-        for r in reqs:
-            r.wait()
+            t = _to(torch.from_numpy(_view(sptrs[i], sbytes[i]).copy()))
+            keep.append(t)
+            ops_.append(dist.P2POp(dist.isend, t, speers[i]))
+        if ops_:
+            for r in dist.batch_isend_irecv(ops_):
+                r.wait()
         for i in range(nrecv):
-            _view(rptrs[i], rbytes[i])[:] = rbufs[i].numpy()
+            _view(rptrs[i], rbytes[i])[:] = rbufs[i].cpu().numpy()
 
     cbs = (ALLREDUCE_FN(allreduce), ALLGATHER_FN(allgather), EXCHANGE_FN(exchange))
     _comm_keep.append(cbs)

@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--mode", default="host")
     ap.add_argument("--grid", type=int, default=12)
     ap.add_argument("--stencil", type=int, default=7)
+    ap.add_argument("--staging", default="host", help="host | cuda (device-tensor staging of the callback transport)")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -48,7 +49,7 @@ def main():
     oc = ge.load_oracle()
     if args.mode == "solve":
         mi.init()
-    mi.init_comm_torch(dist)
+    mi.init_comm_torch(dist, device="cuda" if args.staging == "cuda" else None)
     n, st = args.grid, args.stencil
     N = n ** 3
     starts = [mi.row_partition(N, size, r)[0] for r in range(size)] + [N]
