@@ -72,9 +72,10 @@ T *as(HYPRE_Solver s, SolverBase::Kind k, const char *what) {
 AmgSolver *AMG(HYPRE_Solver s) { return as<AmgSolver>(s, SolverBase::K_AMG, "BoomerAMG"); }
 GmresSolver *GM(HYPRE_Solver s) { return as<GmresSolver>(s, SolverBase::K_GMRES, "GMRES"); }
 BicgstabSolver *BI(HYPRE_Solver s) { return as<BicgstabSolver>(s, SolverBase::K_BICGSTAB, "BiCGSTAB"); }
+PcgSolver *PC(HYPRE_Solver s) { return as<PcgSolver>(s, SolverBase::K_PCG, "PCG"); }
 KrylovSolver *KR(HYPRE_Solver s) {
   SolverBase *b = S(s);
-  if (!b || (b->kind != SolverBase::K_GMRES && b->kind != SolverBase::K_BICGSTAB))
+  if (!b || (b->kind != SolverBase::K_GMRES && b->kind != SolverBase::K_BICGSTAB && b->kind != SolverBase::K_PCG))
     fail(HYPRE_ERROR_ARG, "handle is not a Krylov solver");
   return static_cast<KrylovSolver *>(b);
 }
@@ -792,9 +793,50 @@ HYPRE_Int HYPRE_ParCSRGMRESSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPR
   }
 KRYLOV_COMMON(GMRES, GM)
 KRYLOV_COMMON(BiCGSTAB, BI)
+KRYLOV_COMMON(FlexGMRES, GM)
+KRYLOV_COMMON(PCG, PC)
 #undef KRYLOV_COMMON
 HYPRE_Int HYPRE_ParCSRGMRESSetCGS(HYPRE_Solver solver, HYPRE_Int) {
   API_BEGIN(void) GM(solver);
+  API_END
+}
+
+#define KRYLOV_LIFECYCLE(NAME, TYPE, GET, INIT)                                                                   \
+  HYPRE_Int HYPRE_ParCSR##NAME##Create(MPI_Comm, HYPRE_Solver *solver) {                                        \
+    API_BEGIN                                                                                                   \
+    if (!solver) fail(HYPRE_ERROR_ARG, #NAME "Create: NULL output");                                             \
+    TYPE *obj = new TYPE();                                                                                     \
+    INIT;                                                                                                       \
+    *solver = reinterpret_cast<HYPRE_Solver>(static_cast<SolverBase *>(obj));                                   \
+    API_END                                                                                                     \
+  }                                                                                                             \
+  HYPRE_Int HYPRE_ParCSR##NAME##Destroy(HYPRE_Solver solver) {                                                  \
+    API_BEGIN delete S(solver);                                                                                 \
+    API_END                                                                                                     \
+  }                                                                                                             \
+  HYPRE_Int HYPRE_ParCSR##NAME##Setup(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b,             \
+                                      HYPRE_ParVector x) {                                                      \
+    API_BEGIN                                                                                                   \
+    if (!A || !b || !x) fail(HYPRE_ERROR_ARG, #NAME "Setup: NULL argument");                                     \
+    GET(solver)->setup(*PM(A), *PV(b), *PV(x));                                                                 \
+    API_END                                                                                                     \
+  }                                                                                                             \
+  HYPRE_Int HYPRE_ParCSR##NAME##Solve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b,             \
+                                      HYPRE_ParVector x) {                                                      \
+    try {                                                                                                       \
+      if (!A || !b || !x) fail(HYPRE_ERROR_ARG, #NAME "Solve: NULL argument");                                   \
+      const int rc = GET(solver)->solve(*PM(A), *PV(b), *PV(x));                                                \
+      if (rc) g_error_flag |= rc;                                                                               \
+      return rc;                                                                                                \
+    } catch (const std::exception &e) {                                                                         \
+      return record_error(HYPRE_ERROR_GENERIC, e.what());                                                       \
+    }                                                                                                           \
+  }
+KRYLOV_LIFECYCLE(FlexGMRES, GmresSolver, GM, obj->flexible = true)
+KRYLOV_LIFECYCLE(PCG, PcgSolver, PC, (void)obj)
+#undef KRYLOV_LIFECYCLE
+HYPRE_Int HYPRE_ParCSRPCGSetTwoNorm(HYPRE_Solver solver, HYPRE_Int two_norm) {
+  API_BEGIN PC(solver)->two_norm = two_norm;
   API_END
 }
 
@@ -851,8 +893,6 @@ HYPRE_Int HYPRE_ParCSRBiCGSTABSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, H
   HYPRE_Int HYPRE_ParCSR##NAME##SetKDim(HYPRE_Solver, HYPRE_Int) { return 0; }                                  \
   HYPRE_Int HYPRE_ParCSR##NAME##SetPrintLevel(HYPRE_Solver, HYPRE_Int) { return 0; }
 KRYLOV_STUB(COGMRES)
-KRYLOV_STUB(FlexGMRES)
-KRYLOV_STUB(PCG)
 #undef KRYLOV_STUB
 HYPRE_Int HYPRE_ParCSRCOGMRESSetCGS(HYPRE_Solver, HYPRE_Int) { return 0; }
 

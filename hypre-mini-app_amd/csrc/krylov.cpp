@@ -54,6 +54,14 @@ int GmresSolver::solve(ParCSR &A, ParVector &b, ParVector &x) {
     }
     return *p[(size_t)i];
   };
+  auto zvec = [&](int i) -> ParVector & {
+    while ((int)z.size() <= i) {
+      std::unique_ptr<ParVector> v(new ParVector());
+      v->init(b.start, b.end, 1);
+      z.push_back(std::move(v));
+    }
+    return *z[(size_t)i];
+  };
   std::vector<double> cs((size_t)kd + 1, 0.0), sn((size_t)kd + 1, 0.0), rs((size_t)kd + 1, 0.0);
   std::vector<std::vector<double>> hh((size_t)kd + 1, std::vector<double>((size_t)kd, 0.0));
   double *slots = c.red_out.p;
@@ -98,8 +106,9 @@ int GmresSolver::solve(ParCSR &A, ParVector &b, ParVector &x) {
       iter++;
       ParVector &pi = basis(i);
       ParVector &pim1 = basis(i - 1);
-      apply_precond(A, pim1, r);
-      A.matvec(comm, 1.0, r.data(), 0.0, nullptr, pi.data(), s, k::PROF_SPMV_L0);
+      ParVector &dir = flexible ? zvec(i - 1) : r;  // M^-1 p_{i-1}
+      apply_precond(A, pim1, dir);
+      A.matvec(comm, 1.0, dir.data(), 0.0, nullptr, pi.data(), s, k::PROF_SPMV_L0);
       // modified Gram-Schmidt with the axpy of step j-1 fused into the dot of step j
       // (and the last axpy into the norm): h_j = <p_j, w>, w -= h_j p_j, one pass each
       par_dot(comm, basis(0).data(), pi.data(), n, slots, s);
@@ -146,12 +155,17 @@ int GmresSolver::solve(ParCSR &A, ParVector &b, ParVector &x) {
       t += y[(size_t)kk];
       y[(size_t)kk] = t / hh[(size_t)kk][(size_t)kk];
     }
-    // w = sum_j y_j p_j ; x += M^-1 w
-    k::copy(basis(i - 1).data(), w.data(), n, s);
-    k::scale(y[(size_t)i - 1], w.data(), n, s);
-    for (int j = i - 2; j >= 0; j--) k::axpy(y[(size_t)j], basis(j).data(), w.data(), n, s);
-    apply_precond(A, w, r);
-    k::axpy(1.0, r.data(), x.data(), n, s);
+    if (flexible) {
+      // x += sum_j y_j z_j
+      for (int j = i - 1; j >= 0; j--) k::axpy(y[(size_t)j], zvec(j).data(), x.data(), n, s);
+    } else {
+      // w = sum_j y_j p_j ; x += M^-1 w
+      k::copy(basis(i - 1).data(), w.data(), n, s);
+      k::scale(y[(size_t)i - 1], w.data(), n, s);
+      for (int j = i - 2; j >= 0; j--) k::axpy(y[(size_t)j], basis(j).data(), w.data(), n, s);
+      apply_precond(A, w, r);
+      k::axpy(1.0, r.data(), x.data(), n, s);
+    }
     if (r_norm <= eps && iter >= min_iter) {
       A.matvec(comm, -1.0, x.data(), 1.0, b.data(), r.data(), s, k::PROF_SPMV_L0);
       r_norm = std::sqrt(par_dot_host(comm, r.data(), r.data(), n, s));
@@ -162,6 +176,14 @@ int GmresSolver::solve(ParCSR &A, ParVector &b, ParVector &x) {
       if (chatty) printf("false convergence 2\n");
       k::copy(r.data(), basis(0).data(), n, s);
       i = 0;
+    }
+    if (flexible) {
+      // flexgmres.c restarts from the explicitly recomputed residual
+      if (i) {
+        A.matvec(comm, -1.0, x.data(), 1.0, b.data(), basis(0).data(), s, k::PROF_SPMV_L0);
+        r_norm = std::sqrt(par_dot_host(comm, basis(0).data(), basis(0).data(), n, s));
+      }
+      continue;
     }
     // residual vector for the restart, rebuilt from the Givens data
     for (int j = i; j > 0; j--) {
@@ -184,6 +206,78 @@ int GmresSolver::solve(ParCSR &A, ParVector &b, ParVector &x) {
     (void)r_norm_0;
   }
   return (iter >= max_iter && r_norm > eps) ? 256 : 0;  // HYPRE_ERROR_CONV
+}
+
+void PcgSolver::setup(ParCSR &A, ParVector &b, ParVector &x) {
+  ensure_init();
+  MI_REQUIRE(b.ncomp == 1 && x.ncomp == 1, "PCG: multi-component vectors are not supported");
+  for (ParVector *v : {&r, &pv, &sv}) v->init(b.start, b.end, 1);
+  if (precond_setup) precond_setup(precond_data, &A, &b, &x);
+}
+
+// hypre_PCGSolve (krylov/pcg.c), default options: two_norm 0 (the convergence
+// measure is <C r, r> / <C b, b> against tol^2), no residual recomputation
+int PcgSolver::solve(ParCSR &A, ParVector &b, ParVector &x) {
+  ensure_init();
+  Comm &comm = current_comm();
+  hipStream_t s = ctx().stream;
+  const double t_start = wall_time();
+  const int n = b.n;
+  if (r.n != n) setup(A, b, x);
+  double bi_prod;
+  if (two_norm) {
+    bi_prod = par_dot_host(comm, b.data(), b.data(), n, s);
+  } else {
+    apply_precond(A, b, pv);
+    bi_prod = par_dot_host(comm, pv.data(), b.data(), n, s);
+  }
+  double eps = tol * tol;
+  norms.clear();
+  converged = false;
+  num_iterations = 0;
+  if (!(bi_prod > 0.0)) {  // zero right-hand side: x = 0 (pcg.c)
+    k::fill(x.data(), n, 0.0, s);
+    MI_HIP(hipStreamSynchronize(s));
+    rel_residual_norm = 0.0;
+    converged = true;
+    solve_seconds = wall_time() - t_start;
+    return 0;
+  }
+  if (atol > 0.0) eps = std::max(eps, atol * atol / bi_prod);
+  A.matvec(comm, -1.0, x.data(), 1.0, b.data(), r.data(), s, k::PROF_SPMV_L0);
+  apply_precond(A, r, pv);
+  double gamma = par_dot_host(comm, r.data(), pv.data(), n, s);
+  double i_prod = two_norm ? par_dot_host(comm, r.data(), r.data(), n, s) : gamma;
+  norms.push_back(std::sqrt(std::fabs(i_prod) / bi_prod));
+  int i = 0;
+  const bool chatty = print_level > 1 && comm.rank == 0;
+  while (i + 1 <= max_iter) {
+    i++;
+    A.matvec(comm, 1.0, pv.data(), 0.0, nullptr, sv.data(), s, k::PROF_SPMV_L0);
+    const double sdotp = par_dot_host(comm, sv.data(), pv.data(), n, s);
+    if (sdotp == 0.0) break;
+    const double alpha = gamma / sdotp;
+    const double gamma_old = gamma;
+    k::axpy(alpha, pv.data(), x.data(), n, s);
+    k::axpy(-alpha, sv.data(), r.data(), n, s);
+    apply_precond(A, r, sv);
+    gamma = par_dot_host(comm, r.data(), sv.data(), n, s);
+    i_prod = two_norm ? par_dot_host(comm, r.data(), r.data(), n, s) : gamma;
+    norms.push_back(std::sqrt(std::fabs(i_prod) / bi_prod));
+    if (chatty) printf("% 5d    %e\n", i, norms.back());
+    if (i_prod / bi_prod < eps && i >= min_iter) {
+      converged = true;
+      break;
+    }
+    const double beta = gamma / gamma_old;
+    k::scale(beta, pv.data(), n, s);
+    k::axpy(1.0, sv.data(), pv.data(), n, s);
+  }
+  MI_HIP(hipStreamSynchronize(s));
+  num_iterations = i;
+  rel_residual_norm = std::sqrt(std::fabs(i_prod) / bi_prod);
+  solve_seconds = wall_time() - t_start;
+  return (!converged && i >= max_iter) ? 256 : 0;
 }
 
 void BicgstabSolver::setup(ParCSR &A, ParVector &b, ParVector &x) {

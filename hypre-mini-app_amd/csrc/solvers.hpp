@@ -5,7 +5,7 @@
 namespace mi {
 
 struct SolverBase {
-  enum Kind { K_GMRES, K_BICGSTAB, K_AMG, K_STUB } kind;
+  enum Kind { K_GMRES, K_BICGSTAB, K_PCG, K_AMG, K_STUB } kind;
   explicit SolverBase(Kind k) : kind(k) {}
   virtual ~SolverBase() {}
 };
@@ -34,6 +34,10 @@ struct KrylovSolver : SolverBase {
 
 struct GmresSolver : KrylovSolver {
   std::vector<std::unique_ptr<ParVector>> p;
+  // FlexGMRES (krylov/flexgmres.c): the preconditioned directions z_j = M^-1 p_j are kept and the
+  // update is x += sum y_j z_j (no extra preconditioner call); the restart residual is recomputed
+  bool flexible = false;
+  std::vector<std::unique_ptr<ParVector>> z;
   ParVector r, w;
   GmresSolver() : KrylovSolver(K_GMRES) {}
   void setup(ParCSR &A, ParVector &b, ParVector &x);
@@ -43,6 +47,15 @@ struct GmresSolver : KrylovSolver {
 struct BicgstabSolver : KrylovSolver {
   ParVector r0, r, pv, v, q, sv, t;
   BicgstabSolver() : KrylovSolver(K_BICGSTAB) {}
+  void setup(ParCSR &A, ParVector &b, ParVector &x);
+  int solve(ParCSR &A, ParVector &b, ParVector &x);
+};
+
+// preconditioned conjugate gradients (krylov/pcg.c; src/HypreSystem.cpp:440-455)
+struct PcgSolver : KrylovSolver {
+  ParVector r, pv, sv;
+  int two_norm = 0;
+  PcgSolver() : KrylovSolver(K_PCG) {}
   void setup(ParCSR &A, ParVector &b, ParVector &x);
   int solve(ParCSR &A, ParVector &b, ParVector &x);
 };

@@ -454,8 +454,8 @@ void HypreSystem::setup_bicg() {
   solverResPtr_ = &HYPRE_ParCSRBiCGSTABGetFinalRelativeResidualNorm;
 }
 
-// /root/reference/src/HypreSystem.cpp:372-388, :406-421, :440-455 -- stub families
-#define MI_SETUP_STUB(FUNC, NAME)                                                            \
+// /root/reference/src/HypreSystem.cpp:372-388 (COGMRES: stub family), :406-421 (FlexGMRES), :440-455 (PCG)
+#define MI_SETUP_STUB(FUNC, NAME, ITERS, RES)                                                \
   void HypreSystem::FUNC() {                                                                 \
     YAML::Node node = inpfile_["solver_settings"];                                           \
     HYPRE_ParCSR##NAME##Create(comm_, &solver_);                                             \
@@ -466,10 +466,12 @@ void HypreSystem::setup_bicg() {
     solverSetupPtr_ = &HYPRE_ParCSR##NAME##Setup;                                            \
     solverPrecondPtr_ = &HYPRE_ParCSR##NAME##SetPrecond;                                     \
     solverSolvePtr_ = &HYPRE_ParCSR##NAME##Solve;                                            \
+    solverItersPtr_ = ITERS;                                                                 \
+    solverResPtr_ = RES;                                                                     \
   }
-MI_SETUP_STUB(setup_cogmres, COGMRES)
-MI_SETUP_STUB(setup_fgmres, FlexGMRES)
-MI_SETUP_STUB(setup_cg, PCG)
+MI_SETUP_STUB(setup_cogmres, COGMRES, nullptr, nullptr)
+MI_SETUP_STUB(setup_fgmres, FlexGMRES, &HYPRE_ParCSRFlexGMRESGetNumIterations, &HYPRE_ParCSRFlexGMRESGetFinalRelativeResidualNorm)
+MI_SETUP_STUB(setup_cg, PCG, &HYPRE_ParCSRPCGGetNumIterations, &HYPRE_ParCSRPCGGetFinalRelativeResidualNorm)
 #undef MI_SETUP_STUB
 
 // /root/reference/src/HypreSystem.cpp:499-523

@@ -388,6 +388,14 @@ class BiCGSTAB(_Krylov):
     prefix = "HYPRE_ParCSRBiCGSTAB"
 
 
+class FlexGMRES(_Krylov):
+    prefix = "HYPRE_ParCSRFlexGMRES"
+
+
+class PCG(_Krylov):
+    prefix = "HYPRE_ParCSRPCG"
+
+
 def laplace3d(nx, ny, nz, stencil, ilower, iupper):
     """Synthetic COO triples + rhs for global rows [ilower, iupper] (library-side generator)."""
     nnz = c_big()

@@ -117,9 +117,22 @@ HYPRE_Int HYPRE_ParCSRBiCGSTABGetFinalRelativeResidualNorm(HYPRE_Solver solver, 
   HYPRE_Int HYPRE_ParCSR##NAME##SetMaxIter(HYPRE_Solver solver, HYPRE_Int max_iter);                                 \
   HYPRE_Int HYPRE_ParCSR##NAME##SetKDim(HYPRE_Solver solver, HYPRE_Int k_dim);                                       \
   HYPRE_Int HYPRE_ParCSR##NAME##SetPrintLevel(HYPRE_Solver solver, HYPRE_Int print_level);
-MI_HYPRE_DECLARE_KRYLOV_STUB(COGMRES)  /* src/HypreSystem.cpp:372-388 */
+MI_HYPRE_DECLARE_KRYLOV_STUB(COGMRES)  /* src/HypreSystem.cpp:372-388: stub */
+/* implemented: FlexGMRES = GMRES that keeps z_j = M^-1 p_j (krylov/flexgmres.c),
+ * PCG = preconditioned conjugate gradients (krylov/pcg.c) */
 MI_HYPRE_DECLARE_KRYLOV_STUB(FlexGMRES) /* :406-421 */
 MI_HYPRE_DECLARE_KRYLOV_STUB(PCG)      /* :440-455 */
+HYPRE_Int HYPRE_ParCSRFlexGMRESSetAbsoluteTol(HYPRE_Solver solver, HYPRE_Real a_tol);
+HYPRE_Int HYPRE_ParCSRFlexGMRESSetMinIter(HYPRE_Solver solver, HYPRE_Int min_iter);
+HYPRE_Int HYPRE_ParCSRFlexGMRESSetLogging(HYPRE_Solver solver, HYPRE_Int logging);
+HYPRE_Int HYPRE_ParCSRFlexGMRESGetNumIterations(HYPRE_Solver solver, HYPRE_Int *num_iterations);
+HYPRE_Int HYPRE_ParCSRFlexGMRESGetFinalRelativeResidualNorm(HYPRE_Solver solver, HYPRE_Real *norm);
+HYPRE_Int HYPRE_ParCSRPCGSetAbsoluteTol(HYPRE_Solver solver, HYPRE_Real a_tol);
+HYPRE_Int HYPRE_ParCSRPCGSetMinIter(HYPRE_Solver solver, HYPRE_Int min_iter);
+HYPRE_Int HYPRE_ParCSRPCGSetLogging(HYPRE_Solver solver, HYPRE_Int logging);
+HYPRE_Int HYPRE_ParCSRPCGSetTwoNorm(HYPRE_Solver solver, HYPRE_Int two_norm);
+HYPRE_Int HYPRE_ParCSRPCGGetNumIterations(HYPRE_Solver solver, HYPRE_Int *num_iterations);
+HYPRE_Int HYPRE_ParCSRPCGGetFinalRelativeResidualNorm(HYPRE_Solver solver, HYPRE_Real *norm);
 HYPRE_Int HYPRE_ParCSRCOGMRESSetCGS(HYPRE_Solver solver, HYPRE_Int cgs);                /* :382 */
 
 /* ILU (src/HypreSystem.cpp:328-370, :457-497) */

@@ -1108,14 +1108,19 @@ void oamg_precond(void *ctx, const double *r, double *z) {
 
 /* hypre_GMRESSolve (krylov/gmres.c); called through solverSolvePtr_
  * at src/HypreSystem.cpp:723 with tol/max_iter/k_dim from :393-397, x0 = 0 (:580). */
-void ogmres_solve(const ocsr *A, const double *b, double *x, int kdim, double tol, double atol, int maxit,
-                  oprecond_fn M, void *Mctx, okrylov_result *res, double *norms) {
+static void gmres_core(const ocsr *A, const double *b, double *x, int kdim, double tol, double atol, int maxit,
+                       oprecond_fn M, void *Mctx, okrylov_result *res, double *norms, int flexible) {
   const int n = A->nrows;
   const double epsmac = 1.e-16;
   double **p = (double **)xmalloc(sizeof(double *) * ((size_t)kdim + 1));
   for (int i = 0; i <= kdim; i++) p[i] = (double *)xcalloc((size_t)n, sizeof(double));
   double *r = (double *)xcalloc((size_t)n, sizeof(double));
   double *w = (double *)xcalloc((size_t)n, sizeof(double));
+  double **z = NULL; /* FlexGMRES keeps z_j = M^-1 p_j (krylov/flexgmres.c) */
+  if (flexible) {
+    z = (double **)xmalloc(sizeof(double *) * (size_t)kdim);
+    for (int i = 0; i < kdim; i++) z[i] = (double *)xcalloc((size_t)n, sizeof(double));
+  }
   double *c = (double *)xcalloc((size_t)kdim + 1, sizeof(double));
   double *s = (double *)xcalloc((size_t)kdim + 1, sizeof(double));
   double *rs = (double *)xcalloc((size_t)kdim + 1, sizeof(double));
@@ -1150,12 +1155,13 @@ void ogmres_solve(const ocsr *A, const double *b, double *x, int kdim, double to
     while (i < kdim && iter < maxit) {
       i++;
       iter++;
-      memset(r, 0, sizeof(double) * (size_t)n);
+      double *dir = flexible ? z[i - 1] : r;
+      memset(dir, 0, sizeof(double) * (size_t)n);
       if (M)
-        M(Mctx, p[i - 1], r);
+        M(Mctx, p[i - 1], dir);
       else
-        memcpy(r, p[i - 1], sizeof(double) * (size_t)n);
-      ocsr_matvec(1.0, A, r, 0.0, NULL, p[i]);
+        memcpy(dir, p[i - 1], sizeof(double) * (size_t)n);
+      ocsr_matvec(1.0, A, dir, 0.0, NULL, p[i]);
       for (int j = 0; j < i; j++) {
         hh[j][i - 1] = vdot(p[j], p[i], n);
         vaxpy(-hh[j][i - 1], p[j], p[i], n);
@@ -1190,17 +1196,22 @@ void ogmres_solve(const ocsr *A, const double *b, double *x, int kdim, double to
       t += y[k];
       y[k] = t / hh[k][k];
     }
-    /* w = sum y_j p_j ; x += M^-1 w */
-    memcpy(w, p[i - 1], sizeof(double) * (size_t)n);
-    vscale(y[i - 1], w, n);
-    for (int j = i - 2; j >= 0; j--) vaxpy(y[j], p[j], w, n);
-    free(y);
-    memset(r, 0, sizeof(double) * (size_t)n);
-    if (M)
-      M(Mctx, w, r);
-    else
-      memcpy(r, w, sizeof(double) * (size_t)n);
-    vaxpy(1.0, r, x, n);
+    if (flexible) {
+      for (int j = i - 1; j >= 0; j--) vaxpy(y[j], z[j], x, n);
+      free(y);
+    } else {
+      /* w = sum y_j p_j ; x += M^-1 w */
+      memcpy(w, p[i - 1], sizeof(double) * (size_t)n);
+      vscale(y[i - 1], w, n);
+      for (int j = i - 2; j >= 0; j--) vaxpy(y[j], p[j], w, n);
+      free(y);
+      memset(r, 0, sizeof(double) * (size_t)n);
+      if (M)
+        M(Mctx, w, r);
+      else
+        memcpy(r, w, sizeof(double) * (size_t)n);
+      vaxpy(1.0, r, x, n);
+    }
     if (r_norm <= eps) {
       ocsr_matvec(-1.0, A, x, 1.0, b, r);
       r_norm = vnorm(r, n);
@@ -1211,6 +1222,13 @@ void ogmres_solve(const ocsr *A, const double *b, double *x, int kdim, double to
       /* false convergence 2: restart from the true residual */
       memcpy(p[0], r, sizeof(double) * (size_t)n);
       i = 0;
+    }
+    if (flexible) { /* restart from the explicitly recomputed residual */
+      if (i) {
+        ocsr_matvec(-1.0, A, x, 1.0, b, p[0]);
+        r_norm = vnorm(p[0], n);
+      }
+      continue;
     }
     /* residual vector for the restart, rebuilt from the Givens data */
     for (int j = i; j > 0; j--) {
@@ -1236,6 +1254,10 @@ void ogmres_solve(const ocsr *A, const double *b, double *x, int kdim, double to
     free(p[i]);
     free(hh[i]);
   }
+  if (z) {
+    for (int i = 0; i < kdim; i++) free(z[i]);
+    free(z);
+  }
   free(p);
   free(hh);
   free(r);
@@ -1243,6 +1265,84 @@ void ogmres_solve(const ocsr *A, const double *b, double *x, int kdim, double to
   free(c);
   free(s);
   free(rs);
+}
+
+void ogmres_solve(const ocsr *A, const double *b, double *x, int kdim, double tol, double atol, int maxit,
+                  oprecond_fn M, void *Mctx, okrylov_result *res, double *norms) {
+  gmres_core(A, b, x, kdim, tol, atol, maxit, M, Mctx, res, norms, 0);
+}
+
+/* hypre_FlexGMRESSolve (krylov/flexgmres.c); bound at src/HypreSystem.cpp:406-421 */
+void ofgmres_solve(const ocsr *A, const double *b, double *x, int kdim, double tol, double atol, int maxit,
+                   oprecond_fn M, void *Mctx, okrylov_result *res, double *norms) {
+  gmres_core(A, b, x, kdim, tol, atol, maxit, M, Mctx, res, norms, 1);
+}
+
+/* hypre_PCGSolve (krylov/pcg.c), default options (two_norm 0: the measure is <C r,r>/<C b,b>
+ * against tol^2); bound at src/HypreSystem.cpp:440-455.  norms[i] = sqrt(i_prod/bi_prod). */
+void opcg_solve(const ocsr *A, const double *b, double *x, double tol, double atol, int maxit, oprecond_fn M,
+                void *Mctx, okrylov_result *res, double *norms) {
+  const int n = A->nrows;
+  double *r = (double *)xcalloc((size_t)n, sizeof(double));
+  double *p = (double *)xcalloc((size_t)n, sizeof(double));
+  double *s = (double *)xcalloc((size_t)n, sizeof(double));
+#define OPRECOND(in, out)                          \
+  do {                                             \
+    memset(out, 0, sizeof(double) * (size_t)n);    \
+    if (M)                                         \
+      M(Mctx, in, out);                            \
+    else                                           \
+      memcpy(out, in, sizeof(double) * (size_t)n); \
+  } while (0)
+  OPRECOND(b, p);
+  const double bi_prod = vdot(p, b, n);
+  double eps = tol * tol;
+  int i = 0, converged = 0;
+  double i_prod = 0.0;
+  if (!(bi_prod > 0.0)) {
+    memset(x, 0, sizeof(double) * (size_t)n);
+    converged = 1;
+  } else {
+    if (atol > 0.0 && atol * atol / bi_prod > eps) eps = atol * atol / bi_prod;
+    ocsr_matvec(-1.0, A, x, 1.0, b, r);
+    OPRECOND(r, p);
+    double gamma = vdot(r, p, n);
+    i_prod = gamma;
+    if (norms) norms[0] = sqrt(fabs(i_prod) / bi_prod);
+    while (i + 1 <= maxit) {
+      i++;
+      ocsr_matvec(1.0, A, p, 0.0, NULL, s);
+      const double sdotp = vdot(s, p, n);
+      if (sdotp == 0.0) break;
+      const double alpha = gamma / sdotp;
+      const double gamma_old = gamma;
+      vaxpy(alpha, p, x, n);
+      vaxpy(-alpha, s, r, n);
+      OPRECOND(r, s);
+      gamma = vdot(r, s, n);
+      i_prod = gamma;
+      if (norms) norms[i] = sqrt(fabs(i_prod) / bi_prod);
+      if (i_prod / bi_prod < eps) {
+        converged = 1;
+        break;
+      }
+      const double beta = gamma / gamma_old;
+      vscale(beta, p, n);
+      vaxpy(1.0, s, p, n);
+    }
+  }
+#undef OPRECOND
+  if (res) {
+    res->iters = i;
+    res->converged = converged;
+    res->rel_res = (bi_prod > 0.0) ? sqrt(fabs(i_prod) / bi_prod) : 0.0;
+    ocsr_matvec(-1.0, A, x, 1.0, b, r);
+    const double bn = vnorm(b, n);
+    res->true_rel_res = (bn > 0.0) ? vnorm(r, n) / bn : vnorm(r, n);
+  }
+  free(r);
+  free(p);
+  free(s);
 }
 
 /* ------------------------------------------------------------- BiCGSTAB -- */

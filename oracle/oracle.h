@@ -113,6 +113,12 @@ typedef struct okrylov_result {
 /* right-preconditioned restarted GMRES(k), MGS */
 void ogmres_solve(const ocsr *A, const double *b, double *x, int kdim, double tol, double atol, int maxit,
                   oprecond_fn M, void *Mctx, okrylov_result *res, double *norms /* maxit+1 or NULL */);
+/* FlexGMRES: GMRES that keeps z_j = M^-1 p_j, restart residual recomputed (krylov/flexgmres.c) */
+void ofgmres_solve(const ocsr *A, const double *b, double *x, int kdim, double tol, double atol, int maxit,
+                   oprecond_fn M, void *Mctx, okrylov_result *res, double *norms);
+/* preconditioned conjugate gradients, HYPRE default options (krylov/pcg.c) */
+void opcg_solve(const ocsr *A, const double *b, double *x, double tol, double atol, int maxit, oprecond_fn M,
+                void *Mctx, okrylov_result *res, double *norms);
 /* right-preconditioned BiCGSTAB */
 void obicgstab_solve(const ocsr *A, const double *b, double *x, double tol, double atol, int maxit, oprecond_fn M,
                      void *Mctx, okrylov_result *res, double *norms);

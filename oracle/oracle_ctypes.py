@@ -106,6 +106,9 @@ def lib():
         L.oamg_precond.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.ogmres_solve.argtypes = [P(_Csr), C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int,
                                    C.c_void_p, C.c_void_p, P(KrylovResult), C.c_void_p]
+        L.ofgmres_solve.argtypes = L.ogmres_solve.argtypes
+        L.opcg_solve.argtypes = [P(_Csr), C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int,
+                                 C.c_void_p, C.c_void_p, P(KrylovResult), C.c_void_p]
         L.obicgstab_solve.argtypes = [P(_Csr), C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int,
                                       C.c_void_p, C.c_void_p, P(KrylovResult), C.c_void_p]
         L.oracle_set_threads.argtypes = [C.c_int]
@@ -290,3 +293,11 @@ def gmres(A, b, x0=None, kdim=50, tol=1e-6, atol=0.0, maxit=100, amg=None):
 
 def bicgstab(A, b, x0=None, tol=1e-6, atol=0.0, maxit=100, amg=None):
     return _krylov(lib().obicgstab_solve, A, b, x0, (tol, atol, maxit), amg, maxit)
+
+
+def fgmres(A, b, x0=None, kdim=50, tol=1e-6, atol=0.0, maxit=100, amg=None):
+    return _krylov(lib().ofgmres_solve, A, b, x0, (kdim, tol, atol, maxit), amg, maxit)
+
+
+def pcg(A, b, x0=None, tol=1e-6, atol=0.0, maxit=100, amg=None):
+    return _krylov(lib().opcg_solve, A, b, x0, (tol, atol, maxit), amg, maxit)

@@ -218,6 +218,34 @@ def test_bicgstab_amg_matches_oracle(mi, oc):
     assert _allclose_ref(x.get(), xo)
 
 
+@pytest.mark.parametrize("kdim", [50, 4])
+def test_flexgmres_amg_matches_oracle(mi, oc, kdim):
+    A, b, x, amg, Ao, bo, oamg = _setup(mi, oc, 16)
+    fg = mi.FlexGMRES(tolerance=1e-9, max_iterations=60, kspace=kdim, print_level=0)
+    fg.set_precond(amg)
+    fg.setup(A, b, x)
+    assert fg.solve(A, b, x) == 0
+    xo, info = oc.fgmres(Ao, bo, kdim=kdim, tol=1e-9, maxit=60, amg=oamg)
+    assert fg.num_iterations == info["iters"]
+    assert np.allclose(fg.residual_history(), info["norms"], rtol=1e-7)
+    assert abs(fg.final_rel_res - info["rel_res"]) <= 1e-10
+    assert _allclose_ref(x.get(), xo)
+
+
+@pytest.mark.parametrize("precond", [True, False])
+def test_pcg_matches_oracle(mi, oc, precond):
+    A, b, x, amg, Ao, bo, oamg = _setup(mi, oc, 14)
+    cg = mi.PCG(tolerance=1e-9, max_iterations=200, print_level=0)
+    if precond:
+        cg.set_precond(amg)
+    cg.setup(A, b, x)
+    assert cg.solve(A, b, x) == 0
+    xo, info = oc.pcg(Ao, bo, tol=1e-9, maxit=200, amg=oamg if precond else None)
+    assert cg.num_iterations == info["iters"]
+    assert np.allclose(cg.residual_history(), info["norms"], rtol=1e-6)
+    assert _allclose_ref(x.get(), xo) and _allclose_ref(x.get(), np.ones(14 ** 3), rtol=1e-6)
+
+
 def test_against_direct_solve(mi):
     """Independent known answer: scipy's sparse direct solve of a non-symmetric system."""
     import scipy.sparse as sp

@@ -178,6 +178,29 @@ solver_settings:
     assert m and int(m.group(1)) < 40 and float(m.group(2)) <= 1e-10
 
 
+@pytest.mark.parametrize("method", ["cg", "fgmres", "boomeramg"])
+def test_other_methods_through_driver(tmp_path, method):
+    out = _run(tmp_path, f"""
+linear_system:
+  type: laplace_3d
+  nx: 20
+  ny: 20
+  nz: 20
+
+solver_settings:
+  method: {method}
+  preconditioner: {"none" if method == "boomeramg" else "boomeramg"}
+  tolerance: 1.0e-9
+  max_iterations: 100
+  kspace: 20
+  print_level: 0
+""" + DEFAULT_AMG)
+    m = re.search(r"max \|x - 1\| = ([0-9.eE+-]+)", out)
+    assert m and float(m.group(1)) < 1e-6, out[-1500:]
+    m = re.search(r"Solve 0 : (\d+) iterations", out)
+    assert m and 0 < int(m.group(1)) < 60
+
+
 def test_unsupported_family_reports_error(tmp_path):
     inp = tmp_path / "input.yaml"
     inp.write_text("""
@@ -187,7 +210,7 @@ linear_system:
   ny: 8
   nz: 8
 solver_settings:
-  method: cg
+  method: cogmres
   preconditioner: none
 """)
     p = subprocess.run([APP, str(inp)], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,

@@ -157,6 +157,24 @@ def test_gmres_against_scipy_and_true_residual(oc, kdim):
     assert np.all(np.diff(info["norms"][: kdim + 1]) <= 1e-12)  # monotone inside a restart cycle
 
 
+def test_pcg_and_flexgmres_against_scipy(oc):
+    A, b = oc.Csr.laplace(9, 9, 9, 7)
+    S = A.to_scipy()
+    x, info = oc.pcg(A, b, tol=1e-10, maxit=300, amg=None)
+    xs, flag = spl.cg(S, b, rtol=1e-10, maxiter=300)
+    assert info["converged"] and flag == 0 and np.abs(x - xs).max() < 1e-7
+    # unpreconditioned: the measure <r,r>/<b,b> is the plain relative residual
+    assert abs(info["rel_res"] - info["true_rel_res"]) <= 1e-12
+    # with a fixed preconditioner FlexGMRES and GMRES build the same Krylov space
+    amg = oc.Amg(A, oc.default_params())
+    xg, ig = oc.gmres(A, b, kdim=50, tol=1e-10, maxit=100, amg=amg)
+    xf, jf = oc.fgmres(A, b, kdim=50, tol=1e-10, maxit=100, amg=amg)
+    assert ig["iters"] == jf["iters"] and np.allclose(ig["norms"], jf["norms"], rtol=1e-8)
+    assert np.abs(xg - xf).max() < 1e-9
+    xc, ic = oc.pcg(A, b, tol=1e-10, maxit=100, amg=amg)
+    assert ic["converged"] and np.abs(xc - 1.0).max() < 1e-7
+
+
 def test_bicgstab_against_direct(oc):
     d = np.load(os.path.join(GOLD, "random_mmatrix_400.npz"))
     M = sp.csr_matrix((d["data"], d["indices"], d["indptr"]), shape=(400, 400))
