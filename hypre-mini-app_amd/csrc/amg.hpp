@@ -33,8 +33,10 @@ struct AmgLevel {
   ParCSR *A = nullptr;
   std::unique_ptr<ParCSR> A_own;
   int n = 0;
-  HostCSR P, R;  // rank-local interpolation and its transpose
-  DevCSR dP, dR;
+  HostCSR P, R;  // interpolation / restriction while the hierarchy is being built (moved into Pm / Rm)
+  // transfer operators of the finished hierarchy: rectangular ParCSR (rows: this
+  // level / next level, columns: next level / this level), diag + halo blocks
+  std::unique_ptr<ParCSR> Pm, Rm;
   std::vector<int> cf;  // +1 C, -1 F (empty on the coarsest level)
   DVec<signed char> d_cf;
   // C-first ordering of this level: perm[new] = old local row;
@@ -71,6 +73,10 @@ struct BoomerAMG {
   }
   // hierarchy construction: host only (threads + host collectives)
   void setup_host(ParCSR &A);
+  void build_natural(ParCSR &A);      // strength / PMIS / interpolation / Galerkin loop, natural ordering
+  void build_replicated(ParCSR &A);   // N > 1: global hierarchy on every rank, then this rank's row slices
+  void make_local_transfer_operators();
+  void finish_host();                 // l1 norms, coarsest-level dense inverse
   // device mirror of the hierarchy (needs a GPU)
   void setup_device();
   // HYPRE_BoomerAMGSolve: x is the initial guess; up to max_iter cycles

@@ -644,13 +644,33 @@ void BoomerAMG::setup_host(ParCSR &A0) {
   t_setup_start = wall_time();
   for (double &t : t_phase) t = 0.0;
   is_setup = false;
+  host_ready = false;
+  MI_REQUIRE(!A0.row_starts.empty(), "BoomerAMGSetup: matrix is not assembled");
+  if (p.print_level > 0 && comm.rank == 0 && p.coarsen_type != 8 && p.coarsen_type != 10)
+    printf("mi_hypre BoomerAMG: coarsen_type %d is not restated; using PMIS (8)\n", p.coarsen_type);
+  if (comm.size > 1) {
+    build_replicated(A0);
+  } else {
+    build_natural(A0);
+    const double tp0 = wall_time();
+    apply_cf_ordering();
+    make_local_transfer_operators();
+    t_phase[4] += wall_time() - tp0;
+  }
+  finish_host();
+  t_phase[5] = wall_time() - t_setup_start;
+  host_ready = true;
+}
+
+// the coarsening loop in natural ordering (single communicator rank, or the
+// global operator in the replicated multi-rank setup)
+void BoomerAMG::build_natural(ParCSR &A0) {
+  Comm &comm = current_comm();
+  MI_REQUIRE(comm.size == 1 && A0.col_map_offd.empty(), "build_natural expects a single-rank operator");
   L.clear();
   L.reserve((size_t)std::max(1, p.max_levels));
   L.emplace_back();
   L[0].A = &A0;
-  MI_REQUIRE(!A0.row_starts.empty(), "BoomerAMGSetup: matrix is not assembled");
-  if (p.print_level > 0 && comm.rank == 0 && p.coarsen_type != 8 && p.coarsen_type != 10)
-    printf("mi_hypre BoomerAMG: coarsen_type %d is not restated; using PMIS (8)\n", p.coarsen_type);
 
   int l = 0;
   while (l < p.max_levels - 1 && L[(size_t)l].A->global_rows() > p.max_coarse_size) {
@@ -679,170 +699,20 @@ void BoomerAMG::setup_host(ParCSR &A0) {
     t_phase[2] += wall_time() - tp0;
     tp0 = wall_time();
 
-    // coarse partition
-    std::vector<gidx> cstarts((size_t)comm.size + 1, 0);
-    {
-      std::vector<long long> all((size_t)comm.size);
-      comm.allgather_host(&nc_loc, all.data(), sizeof(long long));
-      for (int r = 0; r < comm.size; r++) cstarts[(size_t)r + 1] = cstarts[(size_t)r] + all[(size_t)r];
-    }
-    const gidx cstart = cstarts[(size_t)comm.rank];
-
-    // P rows of the halo columns, in coarse GLOBAL ids
-    const int next = (int)A.col_map_offd.size();
-    HostCSR B;  // [P ; P_ext] over columns [0,nc) local + nc.. extended
-    std::vector<gidx> ext_cgid;
-    if (comm.size > 1) {
-      std::vector<std::vector<char>> send(A.halo.send_peers.size());
-      for (size_t i = 0; i < A.halo.send_peers.size(); i++) {
-        std::vector<char> &buf = send[i];
-        for (int k = A.halo.send_starts[i]; k < A.halo.send_starts[i + 1]; k++) {
-          const int r = A.halo.send_map[(size_t)k];
-          const int len = (int)(Lv.P.ia[(size_t)r + 1] - Lv.P.ia[(size_t)r]);
-          const size_t off = buf.size();
-          buf.resize(off + sizeof(int) + (size_t)len * (sizeof(gidx) + sizeof(double)));
-          char *w = buf.data() + off;
-          memcpy(w, &len, sizeof(int));
-          w += sizeof(int);
-          for (int q = 0; q < len; q++) {
-            const gidx g = cstart + Lv.P.ja[(size_t)(Lv.P.ia[(size_t)r] + q)];
-            memcpy(w, &g, sizeof(gidx));
-            w += sizeof(gidx);
-            memcpy(w, &Lv.P.a[(size_t)(Lv.P.ia[(size_t)r] + q)], sizeof(double));
-            w += sizeof(double);
-          }
-        }
-      }
-      std::vector<int> from;
-      std::vector<std::vector<char>> got;
-      comm.exchange_host(A.halo.send_peers, send, from, got);
-      std::vector<std::vector<std::pair<gidx, double>>> ext_rows((size_t)next);
-      for (size_t i = 0; i < from.size(); i++) {
-        size_t pi = 0;
-        while (pi < A.halo.recv_peers.size() && A.halo.recv_peers[pi] != from[i]) pi++;
-        MI_REQUIRE(pi < A.halo.recv_peers.size(), "unexpected P-row sender");
-        const char *rp = got[i].data();
-        for (int k = A.halo.recv_starts[pi]; k < A.halo.recv_starts[pi + 1]; k++) {
-          int len;
-          memcpy(&len, rp, sizeof(int));
-          rp += sizeof(int);
-          for (int q = 0; q < len; q++) {
-            gidx g;
-            double v;
-            memcpy(&g, rp, sizeof(gidx));
-            rp += sizeof(gidx);
-            memcpy(&v, rp, sizeof(double));
-            rp += sizeof(double);
-            ext_rows[(size_t)k].push_back({g, v});
-            ext_cgid.push_back(g);
-          }
-        }
-      }
-      std::sort(ext_cgid.begin(), ext_cgid.end());
-      ext_cgid.erase(std::unique(ext_cgid.begin(), ext_cgid.end()), ext_cgid.end());
-      B.nrows = n + next;
-      B.ncols = nc + (int)ext_cgid.size();
-      B.ia.assign((size_t)B.nrows + 1, 0);
-      for (int i = 0; i < n; i++) B.ia[(size_t)i + 1] = Lv.P.ia[(size_t)i + 1];
-      for (int k = 0; k < next; k++) B.ia[(size_t)(n + k) + 1] = B.ia[(size_t)(n + k)] + (int64_t)ext_rows[(size_t)k].size();
-      B.ja = Lv.P.ja;
-      B.a = Lv.P.a;
-      B.ja.resize((size_t)B.nnz());
-      B.a.resize((size_t)B.nnz());
-      for (int k = 0; k < next; k++) {
-        int64_t q = B.ia[(size_t)(n + k)];
-        for (auto &pr : ext_rows[(size_t)k]) {
-          B.ja[(size_t)q] =
-              nc + (int)(std::lower_bound(ext_cgid.begin(), ext_cgid.end(), pr.first) - ext_cgid.begin());
-          B.a[(size_t)q] = pr.second;
-          q++;
-        }
-      }
-    }
-
-    HostCSR Ac;
+    // Galerkin product on the (single-rank) operator: A_c = R (A P)
+    std::unique_ptr<ParCSR> An(new ParCSR());
     {
       HostCSR AP;
-      if (comm.size > 1 && next > 0) {
-        // Afull = [A_diag | A_offd] over the extended column space
-        HostCSR Af;
-        Af.nrows = n;
-        Af.ncols = n + next;
-        Af.ia.assign((size_t)n + 1, 0);
-        for (int i = 0; i < n; i++)
-          Af.ia[(size_t)i + 1] = Af.ia[(size_t)i] + (A.diag.ia[(size_t)i + 1] - A.diag.ia[(size_t)i]) +
-                                 (A.offd.ia[(size_t)i + 1] - A.offd.ia[(size_t)i]);
-        Af.ja.resize((size_t)Af.nnz());
-        Af.a.resize((size_t)Af.nnz());
-        parallel_for(n, [&](int64_t b, int64_t e, int) {
-          for (int64_t i = b; i < e; i++) {
-            int64_t q = Af.ia[(size_t)i];
-            for (int64_t k = A.diag.ia[(size_t)i]; k < A.diag.ia[(size_t)i + 1]; k++, q++) {
-              Af.ja[(size_t)q] = A.diag.ja[(size_t)k];
-              Af.a[(size_t)q] = A.diag.a[(size_t)k];
-            }
-            for (int64_t k = A.offd.ia[(size_t)i]; k < A.offd.ia[(size_t)i + 1]; k++, q++) {
-              Af.ja[(size_t)q] = n + A.offd.ja[(size_t)k];
-              Af.a[(size_t)q] = A.offd.a[(size_t)k];
-            }
-          }
-        });
-        host_spgemm(Af, B, AP);
-      } else {
-        host_spgemm(A.diag, Lv.P, AP);
-      }
-      host_spgemm(Lv.R, AP, Ac);
+      host_spgemm(A.diag, Lv.P, AP);
+      host_spgemm(Lv.R, AP, An->diag);
     }
-
-    // next level ParCSR: split columns at nc
-    std::unique_ptr<ParCSR> An(new ParCSR());
     An->nrows = nc;
-    An->row_start = cstart;
-    An->row_end = cstart + nc;
-    An->row_starts = cstarts;
-    HostCSR &Dn = An->diag, &On = An->offd;
-    Dn.nrows = On.nrows = nc;
-    Dn.ncols = nc;
-    On.ncols = (int)ext_cgid.size();
-    Dn.ia.assign((size_t)nc + 1, 0);
-    On.ia.assign((size_t)nc + 1, 0);
-    for (int i = 0; i < nc; i++) {
-      int nd = 0;
-      for (int64_t k = Ac.ia[(size_t)i]; k < Ac.ia[(size_t)i + 1]; k++) nd += (Ac.ja[(size_t)k] < nc);
-      Dn.ia[(size_t)i + 1] = Dn.ia[(size_t)i] + nd;
-      On.ia[(size_t)i + 1] = On.ia[(size_t)i] + (Ac.ia[(size_t)i + 1] - Ac.ia[(size_t)i] - nd);
-    }
-    Dn.ja.resize((size_t)Dn.nnz());
-    Dn.a.resize((size_t)Dn.nnz());
-    On.ja.resize((size_t)On.nnz());
-    On.a.resize((size_t)On.nnz());
-    for (int i = 0; i < nc; i++) {
-      int64_t pd = Dn.ia[(size_t)i], po = On.ia[(size_t)i];
-      for (int64_t k = Ac.ia[(size_t)i]; k < Ac.ia[(size_t)i + 1]; k++) {
-        if (Ac.ja[(size_t)k] < nc) {
-          Dn.ja[(size_t)pd] = Ac.ja[(size_t)k];
-          Dn.a[(size_t)pd++] = Ac.a[(size_t)k];
-        } else {
-          On.ja[(size_t)po] = Ac.ja[(size_t)k] - nc;
-          On.a[(size_t)po++] = Ac.a[(size_t)k];
-        }
-      }
-    }
-    // drop halo columns that no longer appear (keeps col_map_offd tight)
-    {
-      std::vector<char> usedc(ext_cgid.size(), 0);
-      for (int v : On.ja) usedc[(size_t)v] = 1;
-      std::vector<int> remap(ext_cgid.size(), -1);
-      std::vector<gidx> cm;
-      for (size_t q = 0; q < ext_cgid.size(); q++)
-        if (usedc[q]) {
-          remap[q] = (int)cm.size();
-          cm.push_back(ext_cgid[q]);
-        }
-      for (int &v : On.ja) v = remap[(size_t)v];
-      On.ncols = (int)cm.size();
-      An->col_map_offd = cm;
-    }
+    An->row_start = 0;
+    An->row_end = nc;
+    An->row_starts = {0, (gidx)nc};
+    An->offd.nrows = nc;
+    An->offd.ncols = 0;
+    An->offd.ia.assign((size_t)nc + 1, 0);
     An->build_halo_plan(comm);
     t_phase[3] += wall_time() - tp0;
     L.emplace_back();
@@ -851,12 +721,11 @@ void BoomerAMG::setup_host(ParCSR &A0) {
     l++;
   }
 
-  {
-    const double tp0 = wall_time();
-    apply_cf_ordering();
-    t_phase[4] += wall_time() - tp0;
-  }
+}
 
+// l1 norms and the coarsest-level dense inverse, on the finished (C-first ordered, per-rank) levels
+void BoomerAMG::finish_host() {
+  Comm &comm = current_comm();
   // per-level norms (host), on the C-first ordered operators
   const int ch = chunk();
   for (size_t li = 0; li < L.size(); li++) {
@@ -931,8 +800,304 @@ void BoomerAMG::setup_host(ParCSR &A0) {
     Lc.Cinv_host.swap(Mp);
     Lc.dense = true;
   }
-  t_phase[5] = wall_time() - t_setup_start;
-  host_ready = true;
+}
+
+namespace {
+// wrap a local CSR block as a (possibly rectangular) ParCSR without halo columns
+std::unique_ptr<ParCSR> wrap_local(HostCSR &&M, const std::vector<gidx> &row_starts, const std::vector<gidx> &col_starts,
+                                   int rank) {
+  std::unique_ptr<ParCSR> Q(new ParCSR());
+  Q->nrows = M.nrows;
+  Q->row_starts = row_starts;
+  Q->col_starts = col_starts;
+  Q->row_start = row_starts[(size_t)rank];
+  Q->row_end = row_starts[(size_t)rank + 1];
+  Q->offd.nrows = M.nrows;
+  Q->offd.ncols = 0;
+  Q->offd.ia.assign((size_t)M.nrows + 1, 0);
+  Q->diag = std::move(M);
+  return Q;
+}
+
+// rows (given by their OLD global ids, in NEW order) of the global operator G, columns renumbered through
+// colpos (global old -> global new) and split at this rank's column range into diag / halo blocks
+std::unique_ptr<ParCSR> slice_rows(const HostCSR &G, const int *rows_old, int nloc, const int *colpos,
+                                   const std::vector<gidx> &row_starts, const std::vector<gidx> &col_starts,
+                                   int rank) {
+  std::unique_ptr<ParCSR> Q(new ParCSR());
+  const gidx c0 = col_starts[(size_t)rank], c1 = col_starts[(size_t)rank + 1];
+  Q->nrows = nloc;
+  Q->row_starts = row_starts;
+  Q->col_starts = col_starts;
+  Q->row_start = row_starts[(size_t)rank];
+  Q->row_end = row_starts[(size_t)rank + 1];
+  HostCSR &D = Q->diag, &O = Q->offd;
+  D.nrows = O.nrows = nloc;
+  D.ncols = (int)(c1 - c0);
+  D.ia.assign((size_t)nloc + 1, 0);
+  O.ia.assign((size_t)nloc + 1, 0);
+  for (int q = 0; q < nloc; q++) {
+    const int i = rows_old[q];
+    int nd = 0;
+    for (int64_t k = G.ia[(size_t)i]; k < G.ia[(size_t)i + 1]; k++) {
+      const gidx c = colpos ? colpos[G.ja[(size_t)k]] : G.ja[(size_t)k];
+      nd += (c >= c0 && c < c1);
+    }
+    D.ia[(size_t)q + 1] = D.ia[(size_t)q] + nd;
+    O.ia[(size_t)q + 1] = O.ia[(size_t)q] + (G.ia[(size_t)i + 1] - G.ia[(size_t)i] - nd);
+  }
+  D.ja.resize((size_t)D.nnz());
+  D.a.resize((size_t)D.nnz());
+  O.ja.resize((size_t)O.nnz());
+  O.a.resize((size_t)O.nnz());
+  std::vector<gidx> ogid((size_t)O.nnz());
+  parallel_for(nloc, [&](int64_t b, int64_t e, int) {
+    std::vector<std::pair<gidx, double>> row;
+    for (int64_t q = b; q < e; q++) {
+      const int i = rows_old[q];
+      row.clear();
+      for (int64_t k = G.ia[(size_t)i]; k < G.ia[(size_t)i + 1]; k++)
+        row.push_back({colpos ? (gidx)colpos[G.ja[(size_t)k]] : (gidx)G.ja[(size_t)k], G.a[(size_t)k]});
+      std::sort(row.begin(), row.end(),
+                [](const std::pair<gidx, double> &x, const std::pair<gidx, double> &y) { return x.first < y.first; });
+      int64_t pd = D.ia[(size_t)q], po = O.ia[(size_t)q];
+      for (auto &en : row) {
+        if (en.first >= c0 && en.first < c1) {
+          D.ja[(size_t)pd] = (int)(en.first - c0);
+          D.a[(size_t)pd++] = en.second;
+        } else {
+          ogid[(size_t)po] = en.first;
+          O.a[(size_t)po++] = en.second;
+        }
+      }
+    }
+  });
+  Q->col_map_offd = ogid;
+  std::sort(Q->col_map_offd.begin(), Q->col_map_offd.end());
+  Q->col_map_offd.erase(std::unique(Q->col_map_offd.begin(), Q->col_map_offd.end()), Q->col_map_offd.end());
+  for (size_t k = 0; k < ogid.size(); k++)
+    O.ja[k] = (int)(std::lower_bound(Q->col_map_offd.begin(), Q->col_map_offd.end(), ogid[k]) - Q->col_map_offd.begin());
+  O.ncols = (int)Q->col_map_offd.size();
+  return Q;
+}
+}  // namespace
+
+// single rank: the transfer operators have no halo block
+void BoomerAMG::make_local_transfer_operators() {
+  Comm &comm = current_comm();
+  for (size_t l = 0; l + 1 < L.size(); l++) {
+    AmgLevel &Lv = L[l];
+    if (Lv.P.nrows == 0 && Lv.cf.empty()) continue;
+    Lv.Pm = wrap_local(std::move(Lv.P), Lv.A->row_starts, L[l + 1].A->row_starts, comm.rank);
+    Lv.Rm = wrap_local(std::move(Lv.R), L[l + 1].A->row_starts, Lv.A->row_starts, comm.rank);
+    Lv.Pm->build_halo_plan(comm);
+    Lv.Rm->build_halo_plan(comm);
+    Lv.P = HostCSR();
+    Lv.R = HostCSR();
+  }
+}
+
+// More than one rank: coarsening, interpolation and the Galerkin products are
+// GLOBAL algorithms, so the hierarchy -- and with it the
+// iteration count -- does not depend on the number of ranks.  This first
+// implementation obtains that by replication: every rank gathers the global
+// operator, runs the single-rank setup on it and keeps its own rows of every
+// level (in the per-rank C-first ordering) as distributed ParCSR blocks.  The
+// solve phase is fully distributed; the setup is O(N_global) per rank and is
+// the piece to distribute next.
+void BoomerAMG::build_replicated(ParCSR &A0) {
+  Comm &comm = current_comm();
+  const int rank = comm.rank, size = comm.size;
+  // ---- 1. gather the global operator (CSR over global columns)
+  double tp0 = wall_time();
+  const gidx N = A0.global_rows();
+  MI_REQUIRE(N < (gidx)2147483000, "replicated setup: global row count exceeds int32");
+  std::vector<char> mine;
+  {
+    const int n = A0.nrows;
+    std::vector<int> len((size_t)n);
+    size_t tot = 0;
+    for (int i = 0; i < n; i++) {
+      len[(size_t)i] = (int)((A0.diag.ia[(size_t)i + 1] - A0.diag.ia[(size_t)i]) +
+                             (A0.offd.ia[(size_t)i + 1] - A0.offd.ia[(size_t)i]));
+      tot += (size_t)len[(size_t)i];
+    }
+    mine.resize(sizeof(int) * (size_t)n + tot * (sizeof(int) + sizeof(double)));
+    char *w = mine.data();
+    memcpy(w, len.data(), sizeof(int) * (size_t)n);
+    int *cj = reinterpret_cast<int *>(w + sizeof(int) * (size_t)n);
+    double *cv = reinterpret_cast<double *>(w + sizeof(int) * (size_t)n + tot * sizeof(int));
+    size_t q = 0;
+    for (int i = 0; i < n; i++) {
+      for (int64_t k = A0.diag.ia[(size_t)i]; k < A0.diag.ia[(size_t)i + 1]; k++, q++) {
+        cj[q] = (int)(A0.row_start + A0.diag.ja[(size_t)k]);
+        cv[q] = A0.diag.a[(size_t)k];
+      }
+      for (int64_t k = A0.offd.ia[(size_t)i]; k < A0.offd.ia[(size_t)i + 1]; k++, q++) {
+        cj[q] = (int)A0.col_map_offd[(size_t)A0.offd.ja[(size_t)k]];
+        cv[q] = A0.offd.a[(size_t)k];
+      }
+    }
+  }
+  std::vector<int> peers;
+  std::vector<std::vector<char>> send;
+  for (int r = 0; r < size; r++)
+    if (r != rank) {
+      peers.push_back(r);
+      send.push_back(mine);
+    }
+  std::vector<int> from;
+  std::vector<std::vector<char>> got;
+  comm.exchange_host(peers, send, from, got);
+  std::unique_ptr<ParCSR> Ag(new ParCSR());
+  {
+    HostCSR &G = Ag->diag;
+    G.nrows = G.ncols = (int)N;
+    G.ia.assign((size_t)N + 1, 0);
+    std::vector<const char *> blob((size_t)size, nullptr);
+    blob[(size_t)rank] = mine.data();
+    for (size_t i = 0; i < from.size(); i++) blob[(size_t)from[i]] = got[i].data();
+    for (int r = 0; r < size; r++) {
+      const gidx rs = A0.row_starts[(size_t)r], re = A0.row_starts[(size_t)r + 1];
+      if (re > rs) MI_REQUIRE(blob[(size_t)r] != nullptr, "replicated setup: a rank's rows did not arrive");
+      const int *len = reinterpret_cast<const int *>(blob[(size_t)r]);
+      for (gidx g = rs; g < re; g++) G.ia[(size_t)g + 1] = G.ia[(size_t)g] + len[(size_t)(g - rs)];
+    }
+    G.ja.resize((size_t)G.nnz());
+    G.a.resize((size_t)G.nnz());
+    for (int r = 0; r < size; r++) {
+      const gidx rs = A0.row_starts[(size_t)r], re = A0.row_starts[(size_t)r + 1];
+      if (re == rs) continue;
+      const size_t nr = (size_t)(re - rs);
+      const size_t tot = (size_t)(G.ia[(size_t)re] - G.ia[(size_t)rs]);
+      const char *base = blob[(size_t)r];
+      memcpy(G.ja.data() + G.ia[(size_t)rs], base + sizeof(int) * nr, tot * sizeof(int));
+      memcpy(G.a.data() + G.ia[(size_t)rs], base + sizeof(int) * nr + tot * sizeof(int), tot * sizeof(double));
+    }
+    // rows arrive as [diag | halo]: sort every row by global column
+    parallel_for((int64_t)N, [&](int64_t b, int64_t e, int) {
+      std::vector<std::pair<int, double>> row;
+      for (int64_t i = b; i < e; i++) {
+        const int64_t s0 = G.ia[(size_t)i], len = G.ia[(size_t)i + 1] - s0;
+        bool sorted = true;
+        for (int64_t k = 1; k < len; k++)
+          if (G.ja[(size_t)(s0 + k)] < G.ja[(size_t)(s0 + k - 1)]) {
+            sorted = false;
+            break;
+          }
+        if (sorted) continue;
+        row.resize((size_t)len);
+        for (int64_t k = 0; k < len; k++) row[(size_t)k] = {G.ja[(size_t)(s0 + k)], G.a[(size_t)(s0 + k)]};
+        std::sort(row.begin(), row.end(),
+                  [](const std::pair<int, double> &x, const std::pair<int, double> &y) { return x.first < y.first; });
+        for (int64_t k = 0; k < len; k++) {
+          G.ja[(size_t)(s0 + k)] = row[(size_t)k].first;
+          G.a[(size_t)(s0 + k)] = row[(size_t)k].second;
+        }
+      }
+    });
+    Ag->nrows = (int)N;
+    Ag->row_start = 0;
+    Ag->row_end = N;
+    Ag->row_starts = {0, N};
+    Ag->offd.nrows = (int)N;
+    Ag->offd.ncols = 0;
+    Ag->offd.ia.assign((size_t)N + 1, 0);
+  }
+  std::vector<char>().swap(mine);
+  got.clear();
+  send.clear();
+  const double t_gather = wall_time() - tp0;
+
+  // ---- 2. the global hierarchy, natural ordering, through the single-rank code path
+  BoomerAMG g;
+  g.p = p;
+  g.p.print_level = 0;
+  {
+    std::unique_ptr<Comm> real = std::move(ctx().comm);
+    ctx().comm = make_self_comm();
+    try {
+      g.build_natural(*Ag);
+    } catch (...) {
+      ctx().comm = std::move(real);
+      throw;
+    }
+    ctx().comm = std::move(real);
+  }
+  for (int q = 0; q < 4; q++) t_phase[q] = g.t_phase[q];
+  tp0 = wall_time();
+  const size_t nlev = g.L.size();
+
+  // ---- 3. row partition of every level (coarse ownership = owner of the C point) and
+  //         the per-rank C-first ordering: pos (old -> new), perm (new -> old), both global
+  std::vector<std::vector<gidx>> starts(nlev);
+  starts[0] = A0.row_starts;
+  std::vector<std::vector<int>> pos(nlev), perm(nlev);
+  for (size_t l = 0; l < nlev; l++) {
+    const AmgLevel &G = g.L[l];
+    const int n = G.A->nrows;
+    if (l + 1 < nlev) {
+      starts[l + 1].assign((size_t)size + 1, 0);
+      for (int r = 0; r < size; r++) {
+        gidx c = 0;
+        for (gidx i = starts[l][(size_t)r]; i < starts[l][(size_t)r + 1]; i++) c += (G.cf[(size_t)i] == C_PT);
+        starts[l + 1][(size_t)r + 1] = starts[l + 1][(size_t)r] + c;
+      }
+    }
+    pos[l].resize((size_t)n);
+    perm[l].resize((size_t)n);
+    if (G.cf.empty()) {
+      for (int i = 0; i < n; i++) pos[l][(size_t)i] = perm[l][(size_t)i] = i;
+    } else {
+      for (int r = 0; r < size; r++) {
+        gidx q = starts[l][(size_t)r];
+        for (gidx i = starts[l][(size_t)r]; i < starts[l][(size_t)r + 1]; i++)
+          if (G.cf[(size_t)i] == C_PT) pos[l][(size_t)i] = (int)q++;
+        for (gidx i = starts[l][(size_t)r]; i < starts[l][(size_t)r + 1]; i++)
+          if (G.cf[(size_t)i] != C_PT) pos[l][(size_t)i] = (int)q++;
+      }
+      for (int i = 0; i < n; i++) perm[l][(size_t)pos[l][(size_t)i]] = i;
+    }
+  }
+
+  // ---- 4. this rank's slices
+  L.clear();
+  L.resize(nlev);
+  for (size_t l = 0; l < nlev; l++) {
+    AmgLevel &G = g.L[l];
+    AmgLevel &Lv = L[l];
+    const gidx r0 = starts[l][(size_t)rank], r1 = starts[l][(size_t)rank + 1];
+    const int nloc = (int)(r1 - r0);
+    const int *rows_old = perm[l].data() + r0;
+    Lv.A_own = slice_rows(G.A->diag, rows_old, nloc, pos[l].data(), starts[l], starts[l], rank);
+    Lv.A = Lv.A_own.get();
+    Lv.A->build_halo_plan(comm);
+    if (!G.cf.empty()) {
+      Lv.cf.resize((size_t)nloc);
+      Lv.perm.resize((size_t)nloc);
+      Lv.nc = 0;
+      for (int q = 0; q < nloc; q++) {
+        Lv.cf[(size_t)q] = G.cf[(size_t)rows_old[q]];
+        Lv.perm[(size_t)q] = (int)(rows_old[q] - r0);
+        Lv.nc += (Lv.cf[(size_t)q] == C_PT);
+      }
+      // P: my fine rows x coarse columns; R = P^T: my coarse rows x fine columns
+      Lv.Pm = slice_rows(G.P, rows_old, nloc, pos[l + 1].data(), starts[l], starts[l + 1], rank);
+      Lv.Pm->build_halo_plan(comm);
+      const gidx c0 = starts[l + 1][(size_t)rank], c1 = starts[l + 1][(size_t)rank + 1];
+      Lv.Rm = slice_rows(G.R, perm[l + 1].data() + c0, (int)(c1 - c0), pos[l].data(), starts[l + 1], starts[l], rank);
+      Lv.Rm->build_halo_plan(comm);
+    }
+    // the global level is not needed any more
+    if (G.A_own) G.A_own.reset();
+    G.P = HostCSR();
+    G.R = HostCSR();
+  }
+  Ag.reset();
+  t_phase[4] = wall_time() - tp0;
+  if (p.print_level > 0 && rank == 0)
+    printf("mi_hypre BoomerAMG: replicated setup on %d ranks (global gather %.2f s, slicing %.2f s)\n", size, t_gather,
+           t_phase[4]);
 }
 
 void BoomerAMG::setup_device() {
@@ -943,6 +1108,8 @@ void BoomerAMG::setup_device() {
   for (size_t li = 0; li < L.size(); li++) {
     AmgLevel &Lv = L[li];
     if (li > 0 || !Lv.A->on_device) Lv.A->to_device();
+    if (Lv.Pm) Lv.Pm->to_device();
+    if (Lv.Rm) Lv.Rm->to_device();
     Lv.d_diag.upload(Lv.diag);
     Lv.d_l1gs.upload(Lv.l1gs);
     Lv.d_l1jac.upload(Lv.l1jac);
@@ -951,8 +1118,6 @@ void BoomerAMG::setup_device() {
       for (size_t i = 0; i < c8.size(); i++) c8[i] = (signed char)Lv.cf[i];
       Lv.d_cf.upload(c8);
       Lv.d_perm.upload(Lv.perm);
-      Lv.dP.upload(Lv.P);
-      Lv.dR.upload(Lv.R);
     }
     Lv.u.alloc((size_t)Lv.n);
     Lv.f.alloc((size_t)Lv.n);

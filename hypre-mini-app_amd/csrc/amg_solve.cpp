@@ -152,12 +152,12 @@ void BoomerAMG::cycle(int level, bool u_is_zero) {
   relax_sweeps(level, 0, Lv.f.p, u_is_zero && p.num_sweeps[0] > 0);
   // r = f - A u ; f_c = P^T r ; u_c = 0
   Lv.A->matvec(comm, -1.0, Lv.u.p, 1.0, Lv.f.p, Lv.tmp.p, s);
-  k::spmv(Lv.dR, Lv.tmp.p, 1.0, 0.0, nullptr, Ln.f.p, s);
+  Lv.Rm->matvec(comm, 1.0, Lv.tmp.p, 0.0, nullptr, Ln.f.p, s);
   k::fill(Ln.u.p, Ln.n, 0.0, s);
   const int ncyc = (p.cycle_type == 2 && level + 1 < nlev - 1) ? 2 : 1;
   for (int c = 0; c < ncyc; c++) cycle(level + 1, c == 0);
   // u += P e
-  k::spmv(Lv.dP, Ln.u.p, 1.0, 1.0, Lv.u.p, Lv.u.p, s);
+  Lv.Pm->matvec(comm, 1.0, Ln.u.p, 1.0, Lv.u.p, Lv.u.p, s);
   relax_sweeps(level, 1, Lv.f.p, false);
 }
 

@@ -1084,9 +1084,16 @@ static const HostCSR &level_csr(AmgSolver *a, int level, int which) {
   switch (which) {
     case 0: return L.A->diag;
     case 1: return L.A->offd;
-    case 2: return L.P;
-    case 3: return L.R;
-    default: fail(HYPRE_ERROR_ARG, "which must be 0..3");
+    case 2:
+    case 3:
+    case 4:
+    case 5: {
+      const ParCSR *M = (which == 2 || which == 4) ? L.Pm.get() : L.Rm.get();
+      static const HostCSR empty;
+      if (!M) return empty;  // coarsest level has no transfer operators
+      return which <= 3 ? M->diag : M->offd;
+    }
+    default: fail(HYPRE_ERROR_ARG, "which must be 0..5");
   }
 }
 HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSRSize(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int which, HYPRE_Int *nrows,
@@ -1136,6 +1143,23 @@ HYPRE_Int HYPRE_MI_BoomerAMGGetLevelColMap(HYPRE_Solver solver, HYPRE_Int level,
   if (col_map_offd)
     for (size_t i = 0; i < A.col_map_offd.size(); i++) col_map_offd[i] = A.col_map_offd[i];
   if (row_start) *row_start = A.row_start;
+  API_END
+}
+HYPRE_Int HYPRE_MI_BoomerAMGGetLevelOffdColMap(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int which,
+                                               HYPRE_BigInt *col_map_offd) {
+  API_BEGIN
+  AmgSolver *a = AMG(solver);
+  if (level < 0 || level >= (int)a->amg.L.size()) fail(HYPRE_ERROR_ARG, "AMG level out of range");
+  const AmgLevel &Lv = a->amg.L[(size_t)level];
+  const ParCSR *M = nullptr;
+  switch (which) {
+    case 1: M = Lv.A; break;
+    case 4: M = Lv.Pm.get(); break;
+    case 5: M = Lv.Rm.get(); break;
+    default: fail(HYPRE_ERROR_ARG, "which must be 1 (A), 4 (P) or 5 (R)");
+  }
+  if (M)
+    for (size_t i = 0; i < M->col_map_offd.size(); i++) col_map_offd[i] = M->col_map_offd[i];
   API_END
 }
 HYPRE_Int HYPRE_MI_BoomerAMGRelaxLevel(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int relax_type, HYPRE_Int points,

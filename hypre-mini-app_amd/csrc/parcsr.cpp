@@ -176,10 +176,12 @@ void ParCSR::build_halo_plan(Comm &comm) {
   } else {
     // receive side: col_map_offd is sorted and the partition is contiguous, so
     // the halo columns of one owner are contiguous in x_ext
+    const std::vector<gidx> &cpart = col_partition();
+    const gidx my_c0 = cpart[(size_t)comm.rank], my_c1 = cpart[(size_t)comm.rank + 1];
     halo.recv_starts.push_back(0);
     for (size_t k = 0; k < col_map_offd.size(); k++) {
       const gidx g = col_map_offd[k];
-      const int owner = (int)(std::upper_bound(row_starts.begin(), row_starts.end(), g) - row_starts.begin()) - 1;
+      const int owner = (int)(std::upper_bound(cpart.begin(), cpart.end(), g) - cpart.begin()) - 1;
       MI_REQUIRE(owner >= 0 && owner < comm.size && owner != comm.rank, "halo column without an owner");
       if (halo.recv_peers.empty() || halo.recv_peers.back() != owner) {
         if (!halo.recv_peers.empty()) halo.recv_starts.push_back((int)k);
@@ -202,8 +204,8 @@ void ParCSR::build_halo_plan(Comm &comm) {
       const size_t cnt = got[i].size() / sizeof(gidx);
       const gidx *g = reinterpret_cast<const gidx *>(got[i].data());
       for (size_t k = 0; k < cnt; k++) {
-        MI_REQUIRE(g[k] >= row_start && g[k] < row_end, "peer requested a row this rank does not own");
-        halo.send_map.push_back((int)(g[k] - row_start));
+        MI_REQUIRE(g[k] >= my_c0 && g[k] < my_c1, "peer requested an entry this rank does not own");
+        halo.send_map.push_back((int)(g[k] - my_c0));
       }
       halo.send_peers.push_back(from[i]);
       halo.send_starts.push_back((int)halo.send_map.size());

@@ -30,7 +30,9 @@ struct HaloPlan {
 struct ParCSR {
   gidx row_start = 0, row_end = 0;  // [start, end)
   int nrows = 0;
-  std::vector<gidx> row_starts;  // size+1 global partition (square matrices: also the column partition)
+  std::vector<gidx> row_starts;  // size+1 global row partition (square matrices: also the column partition)
+  std::vector<gidx> col_starts;  // size+1 global COLUMN partition of a rectangular operator (P, R); empty = row_starts
+  const std::vector<gidx> &col_partition() const { return col_starts.empty() ? row_starts : col_starts; }
   HostCSR diag, offd;
   std::vector<gidx> col_map_offd;
   HaloPlan halo;

@@ -267,7 +267,7 @@ class BoomerAMG:
         return v.value
 
     def level_csr(self, level, which):
-        """which: 0 A diag, 1 A offd, 2 P, 3 R -> (ia int64, ja int32, a f64, shape)."""
+        """which: 0 A diag, 1 A offd, 2 P diag, 3 R diag, 4 P offd, 5 R offd -> (ia int64, ja int32, a f64, shape)."""
         nr, nc, nnz = c_int(), c_int(), c_big()
         call("HYPRE_MI_BoomerAMGGetLevelCSRSize", self.h, level, which, C.byref(nr), C.byref(nc), C.byref(nnz))
         ia = np.zeros(nr.value + 1, dtype=np.int64)
@@ -298,6 +298,14 @@ class BoomerAMG:
         rs = c_big()
         call("HYPRE_MI_BoomerAMGGetLevelColMap", self.h, level, cm, C.byref(rs))
         return cm[: nc.value], rs.value
+
+    def level_offd_colmap(self, level, which):
+        """sorted global column ids of an offd block (which: 1 A, 4 P, 5 R)."""
+        nr, nc, nnz = c_int(), c_int(), c_big()
+        call("HYPRE_MI_BoomerAMGGetLevelCSRSize", self.h, level, which, C.byref(nr), C.byref(nc), C.byref(nnz))
+        cm = np.zeros(max(nc.value, 1), dtype=np.int64)
+        call("HYPRE_MI_BoomerAMGGetLevelOffdColMap", self.h, level, which, cm)
+        return cm[: nc.value]
 
     def relax_level(self, level, relax_type, points, f, u):
         f = dbl(f)

@@ -58,7 +58,8 @@ HYPRE_Int HYPRE_MI_KrylovGetSolveSeconds(HYPRE_Solver solver, HYPRE_Real *second
 HYPRE_Int HYPRE_MI_BoomerAMGGetNumLevels(HYPRE_Solver solver, HYPRE_Int *num_levels);
 HYPRE_Int HYPRE_MI_BoomerAMGGetOperatorComplexity(HYPRE_Solver solver, HYPRE_Real *cx);
 HYPRE_Int HYPRE_MI_BoomerAMGGetSetupSeconds(HYPRE_Solver solver, HYPRE_Real *seconds);
-/* which: 0 A diag block, 1 A offd block, 2 P (local), 3 R (local) */
+/* which: 0 A diag block, 1 A offd block, 2 P diag, 3 R diag, 4 P offd (halo columns), 5 R offd.
+ * P (rows: this level, columns: next level) and R = P^T are rectangular ParCSR operators. */
 HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSRSize(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int which, HYPRE_Int *nrows,
                                             HYPRE_Int *ncols, HYPRE_BigInt *nnz);
 HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSR(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int which, HYPRE_BigInt *ia,
@@ -69,6 +70,9 @@ HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCF(HYPRE_Solver solver, HYPRE_Int level, HYP
 HYPRE_Int HYPRE_MI_BoomerAMGGetLevelPerm(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int *perm);
 HYPRE_Int HYPRE_MI_BoomerAMGGetLevelColMap(HYPRE_Solver solver, HYPRE_Int level, HYPRE_BigInt *col_map_offd,
                                            HYPRE_BigInt *row_start);
+/* sorted global column ids of an offd block (which: 1 A, 4 P, 5 R; length = that block's ncols) */
+HYPRE_Int HYPRE_MI_BoomerAMGGetLevelOffdColMap(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int which,
+                                               HYPRE_BigInt *col_map_offd);
 /* one relaxation call / one cycle on HOST arrays of the level's local length */
 HYPRE_Int HYPRE_MI_BoomerAMGRelaxLevel(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int relax_type, HYPRE_Int points,
                                        const HYPRE_Real *f_host, HYPRE_Real *u_host);

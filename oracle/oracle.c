@@ -208,7 +208,7 @@ ocsr *oracle_laplace(int nx, int ny, int nz, int stencil, double *rhs) {
 
 /* ------------------------------------------------------------------ RNG -- */
 /* hypre_SeedRand / hypre_Rand (utilities/random.c): Park-Miller, a = 16807,
- * m = 2^31-1, q = 127773, r = 2836.  PMIS seeds it with 2747 + rank. */
+ * m = 2^31-1, q = 127773, r = 2836.  PMIS seeds it with 2747 (one global stream). */
 static int g_seed = 13579;
 void oracle_rand_seed(int seed) {
   if (seed == 0) seed = 13579;
@@ -311,17 +311,19 @@ static void strength(const ocsr *A, double theta, double max_row_sum, obig **Sia
 }
 
 /* PMIS (par_coarsen.c hypre_BoomerAMGCoarsenPMIS; coarsen_type 8,
- * HypreSystem.cpp:126).  Rank-local variant: only strong connections inside the
- * row's own partition take part; measure = |S^T row| + rand, seed 2747+part. */
+ * HypreSystem.cpp:126).  The graph is the GLOBAL strength graph whatever the row
+ * partition; measure = |S^T row| + rand, one Park-Miller stream seeded 2747 and
+ * drawn in global row order (HYPRE's "seq_rand" mode), so the splitting does
+ * not depend on the number of ranks. */
 static void pmis(int n, const obig *Sia, const int *Sja, const int *part_of, int nparts, const obig *ps, int *cf) {
   double *measure = (double *)xcalloc((size_t)n, sizeof(double));
+  (void)nparts;
+  (void)ps;
   for (int i = 0; i < n; i++)
     for (obig k = Sia[i]; k < Sia[i + 1]; k++)
       if (part_of[Sja[k]] == part_of[i]) measure[Sja[k]] += 1.0;
-  for (int p = 0; p < nparts; p++) {
-    oracle_rand_seed(2747 + p);
-    for (obig i = ps[p]; i < ps[p + 1]; i++) measure[i] += oracle_rand();
-  }
+  oracle_rand_seed(2747);
+  for (int i = 0; i < n; i++) measure[i] += oracle_rand();
   int *graph = (int *)xmalloc(sizeof(int) * (size_t)n);
   int *tmp = (int *)xmalloc(sizeof(int) * (size_t)n);
   int ng = 0;
@@ -422,8 +424,7 @@ static int truncate_row(int len, int *cols, double *vals, double trunc_factor, i
  * hypre_BoomerAMGBuildExtPIInterp, De Sterck/Falgout/Nolting/Yang 2008);
  * 3: direct (par_interp.c hypre_BoomerAMGBuildDirInterp);
  * 0: classical modified (par_interp.c hypre_BoomerAMGBuildInterp).
- * Rank-local variant: neighbours outside the row's partition are treated as
- * weak (lumped into the diagonal), so P has no off-partition columns.
+ * (Called with a single partition: interpolation is a global algorithm.)
  * Columns of P are coarse indices (fine_to_coarse = running count of C points). */
 static ocsr *build_interp(const ocsr *A, const obig *Sia, const int *Sja, int *cf, const int *part_of, int interp_type,
                           double trunc_factor, int pmax, int *ncoarse_out) {
@@ -828,18 +829,22 @@ oamg *oamg_setup(const ocsr *A0, const oamg_params *p) {
     strength(A, p->strong_threshold, p->max_row_sum, &Sia, &Sja);
     int *part_of = part_of_rows(n, nparts, L->part_starts);
     int *cf = (int *)xmalloc(sizeof(int) * (size_t)n);
-    pmis(n, Sia, Sja, part_of, nparts, L->part_starts, cf);
+    /* coarsening and interpolation are GLOBAL algorithms (independent of the row partition) */
+    int *one_part = (int *)xcalloc((size_t)n, sizeof(int));
+    pmis(n, Sia, Sja, one_part, nparts, L->part_starts, cf);
     int nc = 0;
     for (int i = 0; i < n; i++) nc += (cf[i] == C_PT);
     if (nc == 0 || nc == n || nc < p->min_coarse_size) {
       free(Sia);
       free(Sja);
       free(part_of);
+      free(one_part);
       free(cf);
       break;
     }
     int nc2;
-    ocsr *P = build_interp(A, Sia, Sja, cf, part_of, p->interp_type, p->trunc_factor, p->pmax_elmts, &nc2);
+    ocsr *P = build_interp(A, Sia, Sja, cf, one_part, p->interp_type, p->trunc_factor, p->pmax_elmts, &nc2);
+    free(one_part);
     L->cf = cf;
     L->P = P;
     L->own_P = 1;

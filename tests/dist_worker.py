@@ -1,9 +1,9 @@
 """One rank of a multi-process parity run (launched by torch.distributed.run).
 
   --mode host   CPU only: IJ assembly, halo plan and the whole multi-rank AMG setup
-                (rank-local coarsening, P-row exchange, Galerkin product) through the
-                C ABI with a gloo transport, checked against the oracle's emulation
-                of the same row partition.
+                (global hierarchy, this rank's C-first ordered row slices of A, P and R
+                with their halo blocks) through the C ABI with a gloo transport, checked
+                against the oracle's emulation of the same row partition.
   --mode solve  GPU: the same plus the device solve (ranks share the visible GPU;
                 the transport is still gloo -- RCCL refuses two ranks on one device).
 Exit code 0 = every rank's checks passed.
@@ -20,17 +20,28 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
 
-def local_rows_global(amg, level, which_cols_global_n, rank):
-    """This rank's rows of level `level` as a scipy CSR over GLOBAL columns."""
-    ia, ja, a, shape = amg.level_csr(level, 0)
-    oia, oja, oa, oshape = amg.level_csr(level, 1)
-    cm, row_start = amg.level_colmap(level)
+def local_rows_global(amg, level, which_cols_global_n, rank, diag=0, offd=1, col_start=None):
+    """This rank's rows of a level operator (A: 0/1, P: 2/4, R: 3/5) as a scipy CSR over GLOBAL columns."""
+    ia, ja, a, shape = amg.level_csr(level, diag)
+    oia, oja, oa, oshape = amg.level_csr(level, offd)
+    cm = amg.level_offd_colmap(level, offd)
+    _, row_start = amg.level_colmap(level)
+    if col_start is None:
+        col_start = row_start
     n = shape[0]
-    D = sp.csr_matrix((a, ja + row_start, ia), shape=(n, which_cols_global_n))
+    D = sp.csr_matrix((a, ja.astype(np.int64) + col_start, ia), shape=(n, which_cols_global_n))
     if oshape[1] > 0 and len(oa):
+        assert np.all(np.diff(cm) > 0)
+        assert np.all((cm < col_start) | (cm >= col_start + shape[1]))  # halo columns are off-rank
         O = sp.csr_matrix((oa, cm[oja], oia), shape=(n, which_cols_global_n))
         return (D + O).tocsr(), row_start
     return D, row_start
+
+
+def same_matrix(mine, ref, tol):
+    diff = abs(mine - ref)
+    scale = abs(ref).max() if ref.nnz else 1.0
+    return (diff.max() if diff.nnz else 0.0) <= tol * scale and (mine != 0).nnz == (ref != 0).nnz
 
 
 def main():
@@ -95,22 +106,19 @@ def main():
         ps = oamg.level_part_starts(l)
         mine, row_start = local_rows_global(amg, l, OA.shape[1], rank)
         assert row_start == ps[rank] and mine.shape[0] == ps[rank + 1] - ps[rank], (l, rank)
-        ref = OA[ps[rank]:ps[rank + 1]]
-        diff = abs(mine - ref)
-        scale = abs(ref).max() if ref.nnz else 1.0
-        assert (diff.max() if diff.nnz else 0.0) <= 1e-12 * scale, (l, rank, diff.max())
-        assert (mine != 0).nnz == (ref != 0).nnz
+        assert same_matrix(mine, OA[ps[rank]:ps[rank + 1]], 1e-12), (l, rank)
         if l < amg.num_levels - 1:
             cf = amg.level_cf(l)
             assert np.array_equal(cf, oamg.level_cf(l)[ps[rank]:ps[rank + 1]]), (l, rank)
-            pia, pja, pa, pshape = amg.level_csr(l, 2)
+            perm = amg.level_perm(l)
+            assert np.array_equal(perm + ps[rank], oamg.level_perm(l)[ps[rank]:ps[rank + 1]]), (l, rank)
+            # interpolation reaches C points of other ranks: P and R = P^T carry halo blocks
             OP = oamg.level_P(l).to_scipy()
             psn = oamg.level_part_starts(l + 1)
-            refP = OP[ps[rank]:ps[rank + 1], psn[rank]:psn[rank + 1]]
-            assert OP[ps[rank]:ps[rank + 1]].nnz == refP.nnz  # P has no off-rank columns
-            Pm = sp.csr_matrix((pa, pja, pia), shape=pshape)
-            d = abs(Pm - refP)
-            assert (d.max() if d.nnz else 0.0) <= 1e-13
+            Pm, _ = local_rows_global(amg, l, OP.shape[1], rank, 2, 4, col_start=psn[rank])
+            assert same_matrix(Pm, OP[ps[rank]:ps[rank + 1]], 1e-13), (l, rank)
+            Rm, _ = local_rows_global(amg, l, OP.shape[0], rank, 3, 5, col_start=ps[rank])
+            assert same_matrix(Rm, OP.T.tocsr()[psn[rank]:psn[rank + 1]], 1e-13), (l, rank)
 
     if args.mode == "solve":
         gm = mi.GMRES(tolerance=1e-8, max_iterations=60, kspace=20, print_level=0)

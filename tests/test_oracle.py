@@ -202,3 +202,28 @@ def test_golden_histories(oc, path):
     assert np.allclose(r["norms"], g["norms"], rtol=1e-9, atol=0)
     assert np.allclose(r["x"], g["x"], rtol=0, atol=1e-12)
     assert np.abs(g["x"] - 1.0).max() < 100 * case["tol"]
+
+
+def test_hierarchy_does_not_depend_on_the_row_partition(oc):
+    """Coarsening and interpolation are global algorithms: every partition yields the same
+    hierarchy up to the per-part C-first renumbering, so the iteration count stays put."""
+    n = 20
+    A, b = oc.Csr.laplace(n, n, n, 7)
+    N = n ** 3
+    base = None
+    for parts in (1, 2, 3, 8):
+        starts = [N * r // parts for r in range(parts)] + [N]
+        amg = oc.Amg(A, oc.default_params(part_starts=starts))
+        sizes = [amg.level_A(l).shape[0] for l in range(amg.num_levels)]
+        nnzs = [amg.level_A(l).to_scipy().nnz for l in range(amg.num_levels)]
+        # undo the ordering on level 1: the operator itself is identical
+        perm0 = amg.level_perm(0)
+        cf0 = amg.level_cf(0)
+        cpts = np.sort(perm0[cf0 == 1])  # natural ids of the C points
+        _, info = oc.gmres(A, b, kdim=30, tol=1e-8, maxit=60, amg=amg)
+        if base is None:
+            base = (sizes, nnzs, cpts, info["iters"])
+        else:
+            assert sizes == base[0] and nnzs == base[1]
+            assert np.array_equal(cpts, base[2])
+            assert abs(info["iters"] - base[3]) <= 1, (parts, info["iters"], base[3])
