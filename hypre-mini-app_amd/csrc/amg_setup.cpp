@@ -660,6 +660,9 @@ void BoomerAMG::setup_host(ParCSR &A0) {
   finish_host();
   t_phase[5] = wall_time() - t_setup_start;
   host_ready = true;
+  if (getenv("MI_HYPRE_SETUP_TIMING") && comm.rank == 0)
+    printf("mi_hypre host setup: strength %.2f  pmis %.2f  interp %.2f  galerkin %.2f  ordering/slicing %.2f  total %.2f s\n",
+           t_phase[0], t_phase[1], t_phase[2], t_phase[3], t_phase[4], t_phase[5]);
 }
 
 // the coarsening loop in natural ordering (single communicator rank, or the
@@ -703,8 +706,13 @@ void BoomerAMG::build_natural(ParCSR &A0) {
     std::unique_ptr<ParCSR> An(new ParCSR());
     {
       HostCSR AP;
+      const double ta = wall_time();
       host_spgemm(A.diag, Lv.P, AP);
+      const double tb = wall_time();
       host_spgemm(Lv.R, AP, An->diag);
+      if (getenv("MI_HYPRE_SETUP_TIMING"))
+        printf("   level %d: n %d  A*P %.2f s (nnz %lld)  R*(AP) %.2f s (nnz %lld)\n", l, n, tb - ta, (long long)AP.nnz(),
+               wall_time() - tb, (long long)An->diag.nnz());
     }
     An->nrows = nc;
     An->row_start = 0;
@@ -939,24 +947,18 @@ void BoomerAMG::build_replicated(ParCSR &A0) {
       }
     }
   }
-  std::vector<int> peers;
-  std::vector<std::vector<char>> send;
-  for (int r = 0; r < size; r++)
-    if (r != rank) {
-      peers.push_back(r);
-      send.push_back(mine);
-    }
-  std::vector<int> from;
-  std::vector<std::vector<char>> got;
-  comm.exchange_host(peers, send, from, got);
+  std::vector<size_t> offs;
+  std::vector<char> everyone;
+  comm.allgatherv_host(mine.data(), mine.size(), offs, everyone);
+  std::vector<char>().swap(mine);
   std::unique_ptr<ParCSR> Ag(new ParCSR());
   {
     HostCSR &G = Ag->diag;
     G.nrows = G.ncols = (int)N;
     G.ia.assign((size_t)N + 1, 0);
     std::vector<const char *> blob((size_t)size, nullptr);
-    blob[(size_t)rank] = mine.data();
-    for (size_t i = 0; i < from.size(); i++) blob[(size_t)from[i]] = got[i].data();
+    for (int r = 0; r < size; r++)
+      if (offs[(size_t)r + 1] > offs[(size_t)r]) blob[(size_t)r] = everyone.data() + offs[(size_t)r];
     for (int r = 0; r < size; r++) {
       const gidx rs = A0.row_starts[(size_t)r], re = A0.row_starts[(size_t)r + 1];
       if (re > rs) MI_REQUIRE(blob[(size_t)r] != nullptr, "replicated setup: a rank's rows did not arrive");
@@ -1004,9 +1006,7 @@ void BoomerAMG::build_replicated(ParCSR &A0) {
     Ag->offd.ncols = 0;
     Ag->offd.ia.assign((size_t)N + 1, 0);
   }
-  std::vector<char>().swap(mine);
-  got.clear();
-  send.clear();
+  std::vector<char>().swap(everyone);
   const double t_gather = wall_time() - tp0;
 
   // ---- 2. the global hierarchy, natural ordering, through the single-rank code path

@@ -111,6 +111,43 @@ void Comm::exchange_host(const std::vector<int> &peers_send, const std::vector<s
   exchange_host_fixed(sb, rb);
 }
 
+void Comm::allgatherv_host(const void *mine, size_t bytes, std::vector<size_t> &offs, std::vector<char> &out) {
+  std::vector<long long> cnt((size_t)size, 0);
+  long long b = (long long)bytes;
+  allgather_host(&b, cnt.data(), sizeof(long long));
+  offs.assign((size_t)size + 1, 0);
+  for (int r = 0; r < size; r++) offs[(size_t)r + 1] = offs[(size_t)r] + (size_t)cnt[(size_t)r];
+  out.resize(offs[(size_t)size]);
+  if (bytes) memcpy(out.data() + offs[(size_t)rank], mine, bytes);
+  if (size == 1) return;
+  std::vector<PeerBuf> sb, rb;
+  if (host_transport()) {
+    for (int r = 0; r < size; r++) {
+      if (r == rank) continue;
+      if (bytes) sb.push_back({r, const_cast<void *>(mine), bytes});
+      if (cnt[(size_t)r]) rb.push_back({r, out.data() + offs[(size_t)r], (size_t)cnt[(size_t)r]});
+    }
+    exchange_host_fixed(sb, rb);
+    return;
+  }
+  // device transport: one upload of this rank's string, one download of everybody's
+  ensure_init();
+  hipStream_t s = ctx().stream;
+  DVec<char> ds(bytes), dr(out.size());
+  if (bytes) MI_HIP(hipMemcpyAsync(ds.p, mine, bytes, hipMemcpyHostToDevice, s));
+  for (int r = 0; r < size; r++) {
+    if (r == rank) continue;
+    if (bytes) sb.push_back({r, ds.p, bytes});
+    if (cnt[(size_t)r]) rb.push_back({r, dr.p + offs[(size_t)r], (size_t)cnt[(size_t)r]});
+  }
+  exchange_dev(sb, rb, s);
+  for (int r = 0; r < size; r++)
+    if (r != rank && cnt[(size_t)r])
+      MI_HIP(hipMemcpyAsync(out.data() + offs[(size_t)r], dr.p + offs[(size_t)r], (size_t)cnt[(size_t)r],
+                            hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+}
+
 // ------------------------------------------------------------------ self
 namespace {
 struct SelfComm : Comm {
@@ -217,6 +254,7 @@ struct CallbackComm : Comm {
     size = size_;
   }
   const char *name() const override { return "callback"; }
+  bool host_transport() const override { return true; }
   // the transport is a host transport: host collectives go straight through
   void allreduce_host(void *buf, size_t count, CommDType t, CommOp o) override {
     if (size == 1 || count == 0) return;

@@ -151,6 +151,9 @@ struct Comm {
   // through an all-gather of the size matrix
   void exchange_host(const std::vector<int> &peers_send, const std::vector<std::vector<char>> &send,
                      std::vector<int> &peers_recv, std::vector<std::vector<char>> &recv);
+  // every rank's byte string on every rank: out = rank 0's | rank 1's | ..., offs[r] = start of rank r's (size+1 entries)
+  void allgatherv_host(const void *mine, size_t bytes, std::vector<size_t> &offs, std::vector<char> &out);
+  virtual bool host_transport() const { return false; }
   void barrier();
 };
 
