@@ -1,6 +1,7 @@
 // BoomerAMG-shaped preconditioner/solver object: parameters, hierarchy, V-cycle.
 #pragma once
 #include "parcsr.hpp"
+#include "setup_kernels.hpp"
 
 namespace mi {
 
@@ -37,6 +38,8 @@ struct AmgLevel {
   // transfer operators of the finished hierarchy: rectangular ParCSR (rows: this
   // level / next level, columns: next level / this level), diag + halo blocks
   std::unique_ptr<ParCSR> Pm, Rm;
+  // device copies (natural ordering) kept between the Galerkin product and the C-first renumbering
+  sk::DCsr sA, sP;
   std::vector<int> cf;  // +1 C, -1 F (empty on the coarsest level)
   DVec<signed char> d_cf;
   // C-first ordering of this level: perm[new] = old local row;
@@ -60,14 +63,20 @@ struct BoomerAMG {
   AmgParams p;
   std::vector<AmgLevel> L;
   bool is_setup = false, host_ready = false;
+  // levels with at least this many rows run their sparse products / transposes / renumbering on the
+  // device; -1 = everything on host threads (HYPRE_MI_BoomerAMGSetupHostOnly)
+  long long device_min_rows = -1;
+  bool keep_natural_R = false;  // the replicated multi-rank setup slices R in natural ordering
   double t_setup_start = 0.0;
   double t_phase[6] = {0, 0, 0, 0, 0, 0};  // strength, pmis, interp, galerkin, ordering, host total
   int num_iterations = 0;
   double final_rel_res = 0.0;
   double setup_seconds = 0.0;
   int chunk() const;
+  static long long default_device_min_rows();
 
   void setup(ParCSR &A) {
+    device_min_rows = default_device_min_rows();
     setup_host(A);
     setup_device();
   }

@@ -510,6 +510,11 @@ void host_spgemm(const HostCSR &A, const HostCSR &B, HostCSR &C) {
   }, 16);
 }
 
+long long BoomerAMG::default_device_min_rows() {
+  const char *e = getenv("MI_HYPRE_DEVICE_SETUP_MIN_ROWS");
+  return e ? atoll(e) : 20000;
+}
+
 int BoomerAMG::chunk() const { return p.gs_chunk > 0 ? p.gs_chunk : ctx().gs_chunk; }
 
 double BoomerAMG::operator_complexity() const {
@@ -604,7 +609,18 @@ void BoomerAMG::apply_cf_ordering() {
       An->row_start = A.row_start;
       An->row_end = A.row_end;
       An->row_starts = A.row_starts;
-      permute(A.diag, Lv.perm, pos[l].data(), An->diag);
+      if (Lv.sA.nnz > 0 && Lv.sA.nrows == A.nrows) {
+        hipStream_t s = ctx().stream;
+        DVec<int> dperm, dpos;
+        dperm.upload(Lv.perm);
+        dpos.upload(pos[l]);
+        sk::DCsr dB;
+        sk::permute(Lv.sA, dperm.p, dpos.p, dB, s);
+        dB.download(An->diag, s);
+      } else {
+        permute(A.diag, Lv.perm, pos[l].data(), An->diag);
+      }
+      Lv.sA.release();
       // halo columns: new global id = owner's start + owner's new position
       std::vector<int> ext_pos = A.halo_exchange_host_int(comm, pos[l]);
       const size_t next = A.col_map_offd.size();
@@ -631,11 +647,29 @@ void BoomerAMG::apply_cf_ordering() {
       Lv.cf.swap(cf2);
     }
     if (Lv.P.nrows > 0 && (!pos[l].empty() || (l + 1 < nlev && !pos[l + 1].empty()))) {
-      HostCSR P2;
-      permute(Lv.P, Lv.perm, (l + 1 < nlev && !pos[l + 1].empty()) ? pos[l + 1].data() : nullptr, P2);
-      Lv.P = std::move(P2);
-      host_transpose(Lv.P, Lv.R);
+      const bool map_cols = l + 1 < nlev && !pos[l + 1].empty();
+      if (Lv.sP.nnz > 0 && Lv.sP.nrows == Lv.P.nrows) {
+        hipStream_t s = ctx().stream;
+        DVec<int> dperm, dpos;
+        if (!Lv.perm.empty()) dperm.upload(Lv.perm);
+        if (map_cols) dpos.upload(pos[l + 1]);
+        sk::DCsr dP2, dR2;
+        sk::permute(Lv.sP, Lv.perm.empty() ? nullptr : dperm.p, map_cols ? dpos.p : nullptr, dP2, s);
+        Lv.sP.release();
+        dP2.download(Lv.P, s);
+        sk::transpose(dP2, dR2, s);
+        dR2.download(Lv.R, s);
+      } else {
+        HostCSR P2;
+        permute(Lv.P, Lv.perm, map_cols ? pos[l + 1].data() : nullptr, P2);
+        Lv.P = std::move(P2);
+        host_transpose(Lv.P, Lv.R);
+      }
+    } else if (Lv.P.nrows > 0 && Lv.R.nrows == 0) {
+      host_transpose(Lv.P, Lv.R);  // no renumbering on either side: R was not built yet on the device path
     }
+    Lv.sA.release();
+    Lv.sP.release();
   }
 }
 
@@ -698,21 +732,34 @@ void BoomerAMG::build_natural(ParCSR &A0) {
     tp0 = wall_time();
     build_interp(A, S, cf, p.interp_type, p.trunc_factor, p.pmax_elmts, Lv.P, nc);
     Lv.cf = cf;
-    host_transpose(Lv.P, Lv.R);
+    const bool on_device = device_min_rows >= 0 && n >= device_min_rows;
+    if (!on_device) host_transpose(Lv.P, Lv.R);
     t_phase[2] += wall_time() - tp0;
     tp0 = wall_time();
 
     // Galerkin product on the (single-rank) operator: A_c = R (A P)
     std::unique_ptr<ParCSR> An(new ParCSR());
-    {
-      HostCSR AP;
-      const double ta = wall_time();
-      host_spgemm(A.diag, Lv.P, AP);
-      const double tb = wall_time();
-      host_spgemm(Lv.R, AP, An->diag);
+    if (on_device) {
+      // same arithmetic, same order (setup_kernels.hip); the natural-order device copies stay for the
+      // C-first renumbering
+      hipStream_t s = ctx().stream;
+      if (Lv.sA.nrows != n || Lv.sA.nnz != A.diag.nnz()) Lv.sA.upload(A.diag, s);
+      Lv.sP.upload(Lv.P, s);
+      sk::DCsr dR, dAP;
+      sk::transpose(Lv.sP, dR, s);
+      if (keep_natural_R) dR.download(Lv.R, s);
+      sk::spgemm(Lv.sA, Lv.sP, dAP, s);
+      L.emplace_back();  // the coarse operator is born on the device (L was reserved: references stay valid)
+      sk::spgemm(dR, dAP, L[(size_t)l + 1].sA, s);
+      L[(size_t)l + 1].sA.download(An->diag, s);
       if (getenv("MI_HYPRE_SETUP_TIMING"))
-        printf("   level %d: n %d  A*P %.2f s (nnz %lld)  R*(AP) %.2f s (nnz %lld)\n", l, n, tb - ta, (long long)AP.nnz(),
-               wall_time() - tb, (long long)An->diag.nnz());
+        printf("   level %d: n %d  device Galerkin %.2f s (nnz AP %lld, A_c %lld)\n", l, n, wall_time() - tp0,
+               (long long)dAP.nnz, (long long)An->diag.nnz());
+    } else {
+      HostCSR AP;
+      host_spgemm(A.diag, Lv.P, AP);
+      host_spgemm(Lv.R, AP, An->diag);
+      L.emplace_back();
     }
     An->nrows = nc;
     An->row_start = 0;
@@ -723,7 +770,6 @@ void BoomerAMG::build_natural(ParCSR &A0) {
     An->offd.ia.assign((size_t)nc + 1, 0);
     An->build_halo_plan(comm);
     t_phase[3] += wall_time() - tp0;
-    L.emplace_back();
     L[(size_t)l + 1].A_own = std::move(An);
     L[(size_t)l + 1].A = L[(size_t)l + 1].A_own.get();
     l++;
@@ -1013,6 +1059,8 @@ void BoomerAMG::build_replicated(ParCSR &A0) {
   BoomerAMG g;
   g.p = p;
   g.p.print_level = 0;
+  g.device_min_rows = device_min_rows;
+  g.keep_natural_R = true;
   {
     std::unique_ptr<Comm> real = std::move(ctx().comm);
     ctx().comm = make_self_comm();

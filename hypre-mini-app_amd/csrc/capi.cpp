@@ -382,7 +382,58 @@ HYPRE_Int HYPRE_MI_IJMatrixAssembleHostOnly(HYPRE_IJMatrix matrix) {
 HYPRE_Int HYPRE_MI_BoomerAMGSetupHostOnly(HYPRE_Solver solver, HYPRE_ParCSRMatrix A) {
   API_BEGIN
   if (!A) fail(HYPRE_ERROR_ARG, "BoomerAMGSetupHostOnly: NULL matrix");
+  AMG(solver)->amg.device_min_rows = -1;  // host threads only
   AMG(solver)->amg.setup_host(*PM(A));
+  API_END
+}
+// setup-phase sparse kernels on caller (host) CSR arrays; results are malloc'ed (HYPRE_MI_Free)
+HYPRE_Int HYPRE_MI_CSRDeviceOp(HYPRE_Int op, HYPRE_Int a_nrows, HYPRE_Int a_ncols, const HYPRE_BigInt *a_ia,
+                               const HYPRE_Int *a_ja, const HYPRE_Complex *a_a, HYPRE_Int b_nrows, HYPRE_Int b_ncols,
+                               const HYPRE_BigInt *b_ia, const HYPRE_Int *b_ja, const HYPRE_Complex *b_a,
+                               const HYPRE_Int *perm, const HYPRE_Int *colpos, HYPRE_Int *c_nrows, HYPRE_Int *c_ncols,
+                               HYPRE_BigInt **c_ia, HYPRE_Int **c_ja, HYPRE_Complex **c_a) {
+  API_BEGIN
+  ensure_init();
+  hipStream_t s = ctx().stream;
+  auto to_host = [](HYPRE_Int nr, HYPRE_Int nc, const HYPRE_BigInt *ia, const HYPRE_Int *ja, const HYPRE_Complex *a) {
+    HostCSR h;
+    h.nrows = nr;
+    h.ncols = nc;
+    h.ia.assign(ia, ia + nr + 1);
+    h.ja.assign(ja, ja + ia[nr]);
+    h.a.assign(a, a + ia[nr]);
+    return h;
+  };
+  sk::DCsr dA, dB, dC;
+  dA.upload(to_host(a_nrows, a_ncols, a_ia, a_ja, a_a), s);
+  switch (op) {
+    case 0:
+      if (!b_ia) fail(HYPRE_ERROR_ARG, "CSRDeviceOp: product needs B");
+      dB.upload(to_host(b_nrows, b_ncols, b_ia, b_ja, b_a), s);
+      sk::spgemm(dA, dB, dC, s);
+      break;
+    case 1: sk::transpose(dA, dC, s); break;
+    case 2: {
+      DVec<int> dperm, dpos;
+      if (perm) dperm.upload(std::vector<int>(perm, perm + a_nrows));
+      if (colpos) dpos.upload(std::vector<int>(colpos, colpos + a_ncols));
+      sk::permute(dA, perm ? dperm.p : nullptr, colpos ? dpos.p : nullptr, dC, s);
+      break;
+    }
+    default: fail(HYPRE_ERROR_ARG, "CSRDeviceOp: op must be 0 (A*B), 1 (A^T) or 2 (row permutation)");
+  }
+  HostCSR hc;
+  dC.download(hc, s);
+  *c_nrows = hc.nrows;
+  *c_ncols = hc.ncols;
+  *c_ia = (HYPRE_BigInt *)malloc(sizeof(HYPRE_BigInt) * ((size_t)hc.nrows + 1));
+  *c_ja = (HYPRE_Int *)malloc(sizeof(HYPRE_Int) * std::max<size_t>(1, hc.ja.size()));
+  *c_a = (HYPRE_Complex *)malloc(sizeof(HYPRE_Complex) * std::max<size_t>(1, hc.a.size()));
+  for (int i = 0; i <= hc.nrows; i++) (*c_ia)[i] = hc.ia[(size_t)i];
+  if (!hc.ja.empty()) {
+    memcpy(*c_ja, hc.ja.data(), hc.ja.size() * sizeof(int));
+    memcpy(*c_a, hc.a.data(), hc.a.size() * sizeof(double));
+  }
   API_END
 }
 HYPRE_Int HYPRE_MI_ParCSRGetHaloPlan(HYPRE_ParCSRMatrix A, HYPRE_Int *nsend_peers, HYPRE_Int *send_peers,

@@ -1,0 +1,561 @@
+// Device kernels of the AMG setup phase: sparse matrix products (Galerkin
+// operator), transposes, row permutations.  See setup_kernels.hpp.
+//
+// Bit-exactness contract: every floating-point result equals what the host
+// code / the oracle computes -- products and sums are individually rounded
+// (this file is built with -ffp-contract=off) and each output entry is summed
+// by ONE thread in the reference order.  Everything else is integer work.
+//
+// SpGEMM layout: one sub-wave group (8 / 16 / 64 lanes, by the row's product
+// count T) or one 256-thread block per output row.  The distinct output
+// columns of the row are collected in an LDS hash set, ranked (counting sort by
+// comparison), and then every lane owns output entries: it walks A's row in
+// stored order and finds its column in B's sorted rows by binary search, so the
+// sum is taken in exactly the reference order without any atomics on doubles.
+#include "setup_kernels.hpp"
+
+#include <algorithm>
+
+namespace mi {
+namespace sk {
+namespace {
+
+constexpr int EMPTY = 0x7fffffff;
+constexpr int BLK = 256;
+
+__device__ __forceinline__ bool hs_insert(int *tab, int log_h, int j) {
+  const unsigned mask = (1u << log_h) - 1u;
+  unsigned s = ((unsigned)j * 2654435761u) >> (32 - log_h);
+  while (true) {
+    const int old = atomicCAS(&tab[s], EMPTY, j);
+    if (old == EMPTY) return true;
+    if (old == j) return false;
+    s = (s + 1u) & mask;
+  }
+}
+
+// value of C(i, j): products in the stored order of A's row, first assigned, rest added
+__device__ __forceinline__ double row_dot(long long a0, long long a1, const int *__restrict__ Aja,
+                                          const double *__restrict__ Aa, const long long *__restrict__ Bia,
+                                          const int *__restrict__ Bja, const double *__restrict__ Ba, int j) {
+  double acc = 0.0;
+  bool first = true;
+  for (long long ka = a0; ka < a1; ka++) {
+    const int kr = Aja[ka];
+    long long lo = Bia[kr];
+    const long long end = Bia[kr + 1];
+    long long hi = end;
+    while (lo < hi) {
+      const long long mid = (lo + hi) >> 1;
+      if (Bja[mid] < j)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    if (lo < end && Bja[lo] == j) {
+      const double prod = Aa[ka] * Ba[lo];
+      acc = first ? prod : acc + prod;
+      first = false;
+    }
+  }
+  return acc;
+}
+
+// ---------------------------------------------------------------- product counts and row bins
+__global__ __launch_bounds__(BLK) void row_products_k(int n, const long long *__restrict__ Aia,
+                                                      const int *__restrict__ Aja, const long long *__restrict__ Bia,
+                                                      int *__restrict__ T, int *__restrict__ bin_count,
+                                                      int *__restrict__ tmax) {
+  __shared__ int hist[4];
+  __shared__ int smax;
+  if (threadIdx.x < 4) hist[threadIdx.x] = 0;
+  if (threadIdx.x == 0) smax = 0;
+  __syncthreads();
+  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (i < n) {
+    long long t = 0;
+    for (long long ka = Aia[i]; ka < Aia[i + 1]; ka++) {
+      const int kr = Aja[ka];
+      t += Bia[kr + 1] - Bia[kr];
+    }
+    const int ti = t > 0x3fffffff ? 0x3fffffff : (int)t;
+    T[i] = ti;
+    const int b = ti <= 32 ? 0 : ti <= 128 ? 1 : ti <= 512 ? 2 : 3;
+    atomicAdd(&hist[b], 1);
+    atomicMax(&smax, ti);
+  }
+  __syncthreads();
+  if (threadIdx.x < 4 && hist[threadIdx.x]) atomicAdd(&bin_count[threadIdx.x], hist[threadIdx.x]);
+  if (threadIdx.x == 0) atomicMax(tmax, smax);
+}
+
+// rows of every bin, contiguous per bin (order inside a bin is irrelevant: a row writes only its own output)
+__global__ __launch_bounds__(BLK) void bin_fill_k(int n, const int *__restrict__ T, const int *__restrict__ bin_start,
+                                                  int *__restrict__ bin_cursor, int *__restrict__ rows) {
+  __shared__ int hist[4], base[4];
+  if (threadIdx.x < 4) hist[threadIdx.x] = 0;
+  __syncthreads();
+  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  int b = -1, off = 0;
+  if (i < n) {
+    const int ti = T[i];
+    b = ti <= 32 ? 0 : ti <= 128 ? 1 : ti <= 512 ? 2 : 3;
+    off = atomicAdd(&hist[b], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) base[threadIdx.x] = hist[threadIdx.x] ? atomicAdd(&bin_cursor[threadIdx.x], hist[threadIdx.x]) : 0;
+  __syncthreads();
+  if (b >= 0) rows[bin_start[b] + base[b] + off] = (int)i;
+}
+
+// ---------------------------------------------------------------- SpGEMM, one group of G lanes per row
+// S = lanes that share one row of B during the hash phase (power of two <= G)
+template <int G, int CAP, bool NUMERIC>
+__global__ __launch_bounds__(BLK) void spgemm_group_k(int nlist, const int *__restrict__ rows, int S,
+                                                      const long long *__restrict__ Aia, const int *__restrict__ Aja,
+                                                      const double *__restrict__ Aa, const long long *__restrict__ Bia,
+                                                      const int *__restrict__ Bja, const double *__restrict__ Ba,
+                                                      int *__restrict__ nout, const long long *__restrict__ Cia,
+                                                      int *__restrict__ Cja, double *__restrict__ Ca) {
+  constexpr int H = 2 * CAP;
+  constexpr int LOGH = (H == 64) ? 6 : (H == 256) ? 8 : 10;
+  static_assert(H == 64 || H == 256 || H == 1024, "table size");
+  constexpr int GP = BLK / G;
+  __shared__ int tab[GP][H];
+  __shared__ int list[GP][CAP];
+  __shared__ int cnt[GP];
+  const int g = threadIdx.x / G, lane = threadIdx.x % G;
+  const long long gi = (long long)blockIdx.x * GP + g;
+  const bool active = gi < nlist;
+  const int row = active ? rows[gi] : 0;
+  for (int t = lane; t < H; t += G) tab[g][t] = EMPTY;
+  if (lane == 0) cnt[g] = 0;
+  __syncthreads();
+  long long a0 = 0, a1 = 0;
+  if (active) {
+    a0 = Aia[row];
+    a1 = Aia[row + 1];
+    const int sub = lane / S, sl = lane % S, nsub = G / S;
+    for (long long ka = a0 + sub; ka < a1; ka += nsub) {
+      const int kr = Aja[ka];
+      const long long b1 = Bia[kr + 1];
+      for (long long kb = Bia[kr] + sl; kb < b1; kb += S) {
+        const int j = Bja[kb];
+        if (hs_insert(tab[g], LOGH, j)) list[g][atomicAdd(&cnt[g], 1)] = j;
+      }
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+  const int no = cnt[g];
+  if (!NUMERIC) {
+    if (lane == 0) nout[row] = no;
+    return;
+  }
+  const long long c0 = Cia[row];
+  for (int r = lane; r < no; r += G) {
+    const int j = list[g][r];
+    int rank = 0;
+    for (int t = 0; t < no; t++) rank += (list[g][t] < j);
+    Cja[c0 + rank] = j;
+    Ca[c0 + rank] = row_dot(a0, a1, Aja, Aa, Bia, Bja, Ba, j);
+  }
+}
+
+// ---------------------------------------------------------------- SpGEMM, one block per (long) row
+// Hash set and column list live in LDS when the row's bound fits, otherwise in this block's slice of gscratch.
+constexpr int BLK_LDS_CAP = 4096;
+template <bool NUMERIC>
+__global__ __launch_bounds__(BLK) void spgemm_block_k(int nlist, const int *__restrict__ rows,
+                                                      const int *__restrict__ T, int m, int S, int *gscratch,
+                                                      long long scratch_per_block, const long long *__restrict__ Aia,
+                                                      const int *__restrict__ Aja, const double *__restrict__ Aa,
+                                                      const long long *__restrict__ Bia, const int *__restrict__ Bja,
+                                                      const double *__restrict__ Ba, int *__restrict__ nout,
+                                                      const long long *__restrict__ Cia, int *__restrict__ Cja,
+                                                      double *__restrict__ Ca) {
+  __shared__ int s_tab[2 * BLK_LDS_CAP];
+  __shared__ int s_list[BLK_LDS_CAP];
+  __shared__ int s_cnt;
+  const int tid = threadIdx.x;
+  for (int li = blockIdx.x; li < nlist; li += gridDim.x) {
+    const int row = rows[li];
+    const int bound = min(T[row], m);  // distinct output columns of this row <= bound
+    int log_h = 6;
+    while ((1 << log_h) < 2 * bound) log_h++;
+    const int H = 1 << log_h;
+    int *tab, *list;
+    if (bound <= BLK_LDS_CAP) {
+      tab = s_tab;
+      list = s_list;
+    } else {
+      tab = gscratch + (long long)blockIdx.x * scratch_per_block;
+      list = tab + H;
+    }
+    for (int t = tid; t < H; t += BLK) tab[t] = EMPTY;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    const long long a0 = Aia[row], a1 = Aia[row + 1];
+    {
+      const int sub = tid / S, sl = tid % S, nsub = BLK / S;
+      for (long long ka = a0 + sub; ka < a1; ka += nsub) {
+        const int kr = Aja[ka];
+        const long long b1 = Bia[kr + 1];
+        for (long long kb = Bia[kr] + sl; kb < b1; kb += S) {
+          const int j = Bja[kb];
+          if (hs_insert(tab, log_h, j)) list[atomicAdd(&s_cnt, 1)] = j;
+        }
+      }
+    }
+    __syncthreads();
+    const int no = s_cnt;
+    if (!NUMERIC) {
+      if (tid == 0) nout[row] = no;
+    } else {
+      const long long c0 = Cia[row];
+      for (int r = tid; r < no; r += BLK) {
+        const int j = list[r];
+        int rank = 0;
+        for (int t = 0; t < no; t++) rank += (list[t] < j);
+        Cja[c0 + rank] = j;
+        Ca[c0 + rank] = row_dot(a0, a1, Aja, Aa, Bia, Bja, Ba, j);
+      }
+    }
+    __syncthreads();  // table and counter are reused by the next row
+  }
+}
+
+// ---------------------------------------------------------------- exclusive scan (int counts -> 64-bit offsets)
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = BLK * SCAN_ITEMS;
+
+__global__ __launch_bounds__(BLK) void scan_tile_k(long long n, const int *__restrict__ in, long long *__restrict__ out,
+                                                   long long *__restrict__ tile_sum) {
+  __shared__ long long sh[BLK];
+  const long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
+  long long v[SCAN_ITEMS], tot = 0;
+  for (int q = 0; q < SCAN_ITEMS; q++) {
+    v[q] = (base + q < n) ? in[base + q] : 0;
+    tot += v[q];
+  }
+  sh[threadIdx.x] = tot;
+  __syncthreads();
+  for (int d = 1; d < BLK; d <<= 1) {
+    const long long add = (threadIdx.x >= d) ? sh[threadIdx.x - d] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += add;
+    __syncthreads();
+  }
+  long long run = sh[threadIdx.x] - tot;  // exclusive prefix of this thread inside the tile
+  for (int q = 0; q < SCAN_ITEMS; q++) {
+    if (base + q < n) out[base + q] = run;
+    run += v[q];
+  }
+  if (threadIdx.x == BLK - 1) tile_sum[blockIdx.x] = sh[BLK - 1];
+}
+
+// single block: exclusive scan of the tile sums in place; total -> tile_sum[ntiles]
+__global__ __launch_bounds__(BLK) void scan_sums_k(long long ntiles, long long *__restrict__ tile_sum) {
+  __shared__ long long sh[BLK];
+  __shared__ long long carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (long long b0 = 0; b0 < ntiles; b0 += BLK) {
+    const long long i = b0 + threadIdx.x;
+    const long long v = (i < ntiles) ? tile_sum[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < BLK; d <<= 1) {
+      const long long add = (threadIdx.x >= d) ? sh[threadIdx.x - d] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (i < ntiles) tile_sum[i] = carry + sh[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 0) carry += sh[BLK - 1];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) tile_sum[ntiles] = carry;
+}
+
+__global__ __launch_bounds__(BLK) void scan_add_k(long long n, long long *__restrict__ out,
+                                                  const long long *__restrict__ tile_sum, long long ntiles) {
+  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (i < n) out[i] += tile_sum[i / SCAN_TILE];
+  if (i == n) out[n] = tile_sum[ntiles];
+}
+
+// out[0..n] = exclusive scan of in[0..n); returns nothing (out[n] holds the total on the device)
+void exclusive_scan(const int *in, long long *out, long long n, hipStream_t s) {
+  const long long ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+  DVec<long long> sums((size_t)ntiles + 1);
+  if (ntiles > 0) {
+    scan_tile_k<<<(unsigned)ntiles, BLK, 0, s>>>(n, in, out, sums.p);
+    scan_sums_k<<<1, BLK, 0, s>>>(ntiles, sums.p);
+  } else {
+    MI_HIP(hipMemsetAsync(sums.p, 0, sizeof(long long), s));
+  }
+  scan_add_k<<<(unsigned)((n + 1 + BLK - 1) / BLK), BLK, 0, s>>>(n, out, sums.p, ntiles);
+  MI_HIP(hipStreamSynchronize(s));  // sums is released on return
+}
+
+int pow2_at_most(double v, int cap) {
+  int s = 1;
+  while (s * 2 <= cap && (double)(s * 2) <= v) s *= 2;
+  return s;
+}
+
+// ---------------------------------------------------------------- row sort / transpose / permute
+// dst row = src row sorted by column (columns are unique inside a row); group of G lanes per row
+template <int G>
+__global__ __launch_bounds__(BLK) void sort_rows_k(int n, const long long *__restrict__ ia, const int *__restrict__ sj,
+                                                   const double *__restrict__ sa, int *__restrict__ dj,
+                                                   double *__restrict__ da) {
+  const long long row = ((long long)blockIdx.x * BLK + threadIdx.x) / G;
+  const int lane = threadIdx.x % G;
+  if (row >= n) return;
+  const long long b = ia[row];
+  const int len = (int)(ia[row + 1] - b);
+  for (int e = lane; e < len; e += G) {
+    const int c = sj[b + e];
+    int rank = 0;
+    for (int t = 0; t < len; t++) rank += (sj[b + t] < c);
+    dj[b + rank] = c;
+    da[b + rank] = sa[b + e];
+  }
+}
+
+void sort_rows(int n, int64_t nnz, const long long *ia, const int *sj, const double *sa, int *dj, double *da,
+               hipStream_t s) {
+  if (n == 0 || nnz == 0) return;
+  const double avg = (double)nnz / (double)n;
+  const long long threads_needed = (long long)n * (avg <= 16 ? 8 : avg <= 48 ? 16 : 64);
+  const unsigned grid = (unsigned)((threads_needed + BLK - 1) / BLK);
+  if (avg <= 16)
+    sort_rows_k<8><<<grid, BLK, 0, s>>>(n, ia, sj, sa, dj, da);
+  else if (avg <= 48)
+    sort_rows_k<16><<<grid, BLK, 0, s>>>(n, ia, sj, sa, dj, da);
+  else
+    sort_rows_k<64><<<grid, BLK, 0, s>>>(n, ia, sj, sa, dj, da);
+}
+
+__global__ __launch_bounds__(BLK) void col_count_k(long long nnz, const int *__restrict__ ja, int *__restrict__ cnt) {
+  const long long k = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (k < nnz) atomicAdd(&cnt[ja[k]], 1);
+}
+
+__global__ __launch_bounds__(BLK) void transpose_fill_k(int n, const long long *__restrict__ ia,
+                                                        const int *__restrict__ ja, const double *__restrict__ a,
+                                                        const long long *__restrict__ tia, int *__restrict__ cursor,
+                                                        int *__restrict__ tj, double *__restrict__ ta) {
+  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  for (long long k = ia[i]; k < ia[i + 1]; k++) {
+    const int j = ja[k];
+    const long long p = tia[j] + atomicAdd(&cursor[j], 1);
+    tj[p] = (int)i;
+    ta[p] = a[k];
+  }
+}
+
+__global__ __launch_bounds__(BLK) void perm_len_k(int n, const long long *__restrict__ ia, const int *__restrict__ perm,
+                                                  int *__restrict__ len) {
+  const long long q = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (q >= n) return;
+  const int i = perm ? perm[q] : (int)q;
+  len[q] = (int)(ia[i + 1] - ia[i]);
+}
+
+__global__ __launch_bounds__(BLK) void perm_copy_k(int n, const long long *__restrict__ ia, const int *__restrict__ ja,
+                                                   const double *__restrict__ a, const int *__restrict__ perm,
+                                                   const int *__restrict__ colpos, const long long *__restrict__ bia,
+                                                   int *__restrict__ bj, double *__restrict__ ba) {
+  const long long q = ((long long)blockIdx.x * BLK + threadIdx.x) / 8;
+  const int lane = threadIdx.x % 8;
+  if (q >= n) return;
+  const int i = perm ? perm[q] : (int)q;
+  const long long s0 = ia[i], d0 = bia[q];
+  const int len = (int)(ia[i + 1] - s0);
+  for (int e = lane; e < len; e += 8) {
+    const int c = ja[s0 + e];
+    bj[d0 + e] = colpos ? colpos[c] : c;
+    ba[d0 + e] = a[s0 + e];
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- host-facing entry points
+void DCsr::upload(const HostCSR &h, hipStream_t s) {
+  ensure_init();
+  nrows = h.nrows;
+  ncols = h.ncols;
+  nnz = h.nnz();
+  ia.alloc((size_t)nrows + 1);
+  ja.alloc((size_t)nnz);
+  a.alloc((size_t)nnz);
+  static_assert(sizeof(long long) == sizeof(int64_t), "row pointer width");
+  if (h.ia.empty()) {
+    MI_HIP(hipMemsetAsync(ia.p, 0, ((size_t)nrows + 1) * sizeof(long long), s));
+  } else {
+    MI_HIP(hipMemcpyAsync(ia.p, h.ia.data(), ((size_t)nrows + 1) * sizeof(long long), hipMemcpyHostToDevice, s));
+  }
+  if (nnz) {
+    MI_HIP(hipMemcpyAsync(ja.p, h.ja.data(), (size_t)nnz * sizeof(int), hipMemcpyHostToDevice, s));
+    MI_HIP(hipMemcpyAsync(a.p, h.a.data(), (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, s));
+  }
+  MI_HIP(hipStreamSynchronize(s));
+}
+
+void DCsr::download(HostCSR &h, hipStream_t s) const {
+  h.nrows = nrows;
+  h.ncols = ncols;
+  h.ia.resize((size_t)nrows + 1);
+  h.ja.resize((size_t)nnz);
+  h.a.resize((size_t)nnz);
+  MI_HIP(hipMemcpyAsync(h.ia.data(), ia.p, ((size_t)nrows + 1) * sizeof(long long), hipMemcpyDeviceToHost, s));
+  if (nnz) {
+    MI_HIP(hipMemcpyAsync(h.ja.data(), ja.p, (size_t)nnz * sizeof(int), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipMemcpyAsync(h.a.data(), a.p, (size_t)nnz * sizeof(double), hipMemcpyDeviceToHost, s));
+  }
+  MI_HIP(hipStreamSynchronize(s));
+}
+
+namespace {
+struct Bins {
+  int start[5] = {0, 0, 0, 0, 0};
+  int tmax = 0;
+};
+
+template <bool NUMERIC>
+void launch_bins(const Bins &bins, const int *rows, const int *T, int S_hint, const DCsr &A, const DCsr &B, int *nout,
+                 const long long *Cia, int *Cja, double *Ca, int *gscratch, long long scratch_per_block, int block_grid,
+                 hipStream_t s) {
+  const int n0 = bins.start[1] - bins.start[0], n1 = bins.start[2] - bins.start[1], n2 = bins.start[3] - bins.start[2],
+            n3 = bins.start[4] - bins.start[3];
+  if (n0)
+    spgemm_group_k<8, 32, NUMERIC><<<(unsigned)((n0 + 31) / 32), BLK, 0, s>>>(
+        n0, rows + bins.start[0], std::min(S_hint, 8), A.ia.p, A.ja.p, A.a.p, B.ia.p, B.ja.p, B.a.p, nout, Cia, Cja, Ca);
+  if (n1)
+    spgemm_group_k<16, 128, NUMERIC><<<(unsigned)((n1 + 15) / 16), BLK, 0, s>>>(
+        n1, rows + bins.start[1], std::min(S_hint, 16), A.ia.p, A.ja.p, A.a.p, B.ia.p, B.ja.p, B.a.p, nout, Cia, Cja, Ca);
+  if (n2)
+    spgemm_group_k<64, 512, NUMERIC><<<(unsigned)((n2 + 3) / 4), BLK, 0, s>>>(
+        n2, rows + bins.start[2], std::min(S_hint, 64), A.ia.p, A.ja.p, A.a.p, B.ia.p, B.ja.p, B.a.p, nout, Cia, Cja, Ca);
+  if (n3)
+    spgemm_block_k<NUMERIC><<<(unsigned)std::min(n3, block_grid), BLK, 0, s>>>(
+        n3, rows + bins.start[3], T, B.ncols, S_hint, gscratch, scratch_per_block, A.ia.p, A.ja.p, A.a.p, B.ia.p,
+        B.ja.p, B.a.p, nout, Cia, Cja, Ca);
+  MI_HIP(hipGetLastError());
+}
+}  // namespace
+
+void spgemm(const DCsr &A, const DCsr &B, DCsr &C, hipStream_t s) {
+  MI_REQUIRE(A.ncols == B.nrows, "spgemm: inner dimensions differ");
+  const int n = A.nrows;
+  C.release();
+  C.nrows = n;
+  C.ncols = B.ncols;
+  C.ia.alloc((size_t)n + 1);
+  if (n == 0 || A.nnz == 0 || B.nnz == 0) {
+    MI_HIP(hipMemsetAsync(C.ia.p, 0, ((size_t)n + 1) * sizeof(long long), s));
+    C.ja.alloc(0);
+    C.a.alloc(0);
+    MI_HIP(hipStreamSynchronize(s));
+    return;
+  }
+  const unsigned grid_rows = (unsigned)((n + BLK - 1) / BLK);
+  DVec<int> T((size_t)n), rows((size_t)n), nout((size_t)n), meta(16);
+  MI_HIP(hipMemsetAsync(meta.p, 0, 16 * sizeof(int), s));
+  // meta: [0..3] bin counts, [4] max T, [8..11] bin starts, [12..15] fill cursors
+  row_products_k<<<grid_rows, BLK, 0, s>>>(n, A.ia.p, A.ja.p, B.ia.p, T.p, meta.p, meta.p + 4);
+  int hmeta[16];
+  MI_HIP(hipMemcpyAsync(hmeta, meta.p, sizeof(hmeta), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+  Bins bins;
+  for (int b = 0; b < 4; b++) bins.start[b + 1] = bins.start[b] + hmeta[b];
+  bins.tmax = hmeta[4];
+  for (int b = 0; b < 4; b++) hmeta[8 + b] = bins.start[b], hmeta[12 + b] = 0;
+  MI_HIP(hipMemcpyAsync(meta.p + 8, hmeta + 8, 8 * sizeof(int), hipMemcpyHostToDevice, s));
+  bin_fill_k<<<grid_rows, BLK, 0, s>>>(n, T.p, meta.p + 8, meta.p + 12, rows.p);
+  // lanes per B row in the hash phase ~ B's mean row length
+  const int S_hint = pow2_at_most((double)B.nnz / std::max(1, B.nrows), 64);
+  // long rows whose bound exceeds the LDS table use a per-block slice of global scratch
+  DVec<int> gscratch;
+  long long per_block = 0;
+  int block_grid = 2048;
+  const int n3 = bins.start[4] - bins.start[3];
+  if (n3) {
+    const long long bound = std::min<long long>(bins.tmax, B.ncols);
+    if (bound > BLK_LDS_CAP) {
+      long long H = 64;
+      while (H < 2 * bound) H *= 2;
+      per_block = H + bound;
+      const long long budget = 1LL << 29;  // ints (2 GiB)
+      block_grid = (int)std::max<long long>(32, std::min<long long>(2048, budget / per_block));
+      block_grid = std::min(block_grid, n3);
+      gscratch.alloc((size_t)(per_block * block_grid));
+    }
+  }
+  launch_bins<false>(bins, rows.p, T.p, S_hint, A, B, nout.p, nullptr, nullptr, nullptr, gscratch.p, per_block,
+                     block_grid, s);
+  exclusive_scan(nout.p, C.ia.p, n, s);
+  long long total = 0;
+  MI_HIP(hipMemcpyAsync(&total, C.ia.p + n, sizeof(long long), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+  C.nnz = total;
+  C.ja.alloc((size_t)total);
+  C.a.alloc((size_t)total);
+  launch_bins<true>(bins, rows.p, T.p, S_hint, A, B, nout.p, C.ia.p, C.ja.p, C.a.p, gscratch.p, per_block, block_grid,
+                    s);
+  MI_HIP(hipStreamSynchronize(s));
+}
+
+void transpose(const DCsr &A, DCsr &T, hipStream_t s) {
+  T.release();
+  T.nrows = A.ncols;
+  T.ncols = A.nrows;
+  T.nnz = A.nnz;
+  T.ia.alloc((size_t)T.nrows + 1);
+  T.ja.alloc((size_t)A.nnz);
+  T.a.alloc((size_t)A.nnz);
+  DVec<int> cnt((size_t)T.nrows);
+  if (T.nrows) MI_HIP(hipMemsetAsync(cnt.p, 0, (size_t)T.nrows * sizeof(int), s));
+  if (A.nnz) col_count_k<<<(unsigned)((A.nnz + BLK - 1) / BLK), BLK, 0, s>>>(A.nnz, A.ja.p, cnt.p);
+  exclusive_scan(cnt.p, T.ia.p, T.nrows, s);
+  if (A.nnz == 0) return;
+  MI_HIP(hipMemsetAsync(cnt.p, 0, (size_t)T.nrows * sizeof(int), s));
+  DVec<int> tj((size_t)A.nnz);
+  DVec<double> ta((size_t)A.nnz);
+  transpose_fill_k<<<(unsigned)((A.nrows + BLK - 1) / BLK), BLK, 0, s>>>(A.nrows, A.ia.p, A.ja.p, A.a.p, T.ia.p, cnt.p,
+                                                                         tj.p, ta.p);
+  sort_rows(T.nrows, T.nnz, T.ia.p, tj.p, ta.p, T.ja.p, T.a.p, s);
+  MI_HIP(hipGetLastError());
+  MI_HIP(hipStreamSynchronize(s));
+}
+
+void permute(const DCsr &A, const int *perm, const int *colpos, DCsr &B, hipStream_t s) {
+  B.release();
+  const int n = A.nrows;
+  B.nrows = n;
+  B.ncols = A.ncols;
+  B.nnz = A.nnz;
+  B.ia.alloc((size_t)n + 1);
+  B.ja.alloc((size_t)A.nnz);
+  B.a.alloc((size_t)A.nnz);
+  DVec<int> len((size_t)n);
+  if (n) perm_len_k<<<(unsigned)((n + BLK - 1) / BLK), BLK, 0, s>>>(n, A.ia.p, perm, len.p);
+  exclusive_scan(len.p, B.ia.p, n, s);
+  if (A.nnz == 0) return;
+  DVec<int> tj((size_t)A.nnz);
+  DVec<double> ta((size_t)A.nnz);
+  perm_copy_k<<<(unsigned)(((long long)n * 8 + BLK - 1) / BLK), BLK, 0, s>>>(n, A.ia.p, A.ja.p, A.a.p, perm, colpos,
+                                                                             B.ia.p, tj.p, ta.p);
+  sort_rows(n, A.nnz, B.ia.p, tj.p, ta.p, B.ja.p, B.a.p, s);
+  MI_HIP(hipGetLastError());
+  MI_HIP(hipStreamSynchronize(s));
+}
+
+}  // namespace sk
+}  // namespace mi

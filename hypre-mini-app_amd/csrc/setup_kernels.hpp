@@ -1,0 +1,45 @@
+// Device kernels of the AMG setup phase (hypre_BoomerAMGSetup side of
+// src/HypreSystem.cpp:692): sparse products of the Galerkin operator, transposes
+// and the C-first renumbering.  Every kernel reproduces the host/oracle
+// arithmetic bit for bit (same accumulation order, no fused multiply-add): this
+// file is compiled with -ffp-contract=off.
+#pragma once
+#include "mi_internal.hpp"
+
+namespace mi {
+namespace sk {
+
+// device CSR of the setup phase: 64-bit row pointers, columns ascending inside a row
+struct DCsr {
+  int nrows = 0, ncols = 0;
+  int64_t nnz = 0;
+  DVec<long long> ia;
+  DVec<int> ja;
+  DVec<double> a;
+  void upload(const HostCSR &h, hipStream_t s);
+  void download(HostCSR &h, hipStream_t s) const;
+  void release() {
+    ia.release();
+    ja.release();
+    a.release();
+    nrows = ncols = 0;
+    nnz = 0;
+  }
+};
+
+// C = A * B.  Rows of B must have ascending columns.  Entry (i, j) is the sum of
+// a_ik * b_kj taken in the stored order of A's row i (first product assigned,
+// the others added one by one) -- exactly host_spgemm (amg_setup.cpp) and the
+// oracle's ocsr_matmul; output columns ascending.
+void spgemm(const DCsr &A, const DCsr &B, DCsr &C, hipStream_t s);
+
+// T = A^T with ascending columns in every row (entries of one output row keep
+// the order of A's rows)
+void transpose(const DCsr &A, DCsr &T, hipStream_t s);
+
+// B = rows of A taken in `perm` order (perm[new] = old; null = identity) with
+// columns mapped through colpos (null = identity) and re-sorted ascending
+void permute(const DCsr &A, const int *perm, const int *colpos, DCsr &B, hipStream_t s);
+
+}  // namespace sk
+}  // namespace mi

@@ -548,3 +548,31 @@ def halo_plan(A):
     call("HYPRE_MI_ParCSRGetHaloPlan", A.par, C.byref(ns), sp, ss, sm, C.byref(nr), rp, rs)
     return dict(send_peers=sp[: ns.value], send_starts=ss, send_map=sm[: int(ss[-1])], recv_peers=rp[: nr.value],
                 recv_starts=rs)
+
+
+def csr_device_op(op, A, B=None, perm=None, colpos=None):
+    """Setup-phase device kernels on scipy CSR matrices: op 0 A@B, 1 A.T, 2 rows of A in perm order with
+    columns mapped through colpos.  Returns (ia int64, ja int32, a f64, shape) exactly as the library stores it."""
+    def parts(M):
+        return (np.ascontiguousarray(M.indptr, dtype=np.int64), np.ascontiguousarray(M.indices, dtype=np.int32),
+                np.ascontiguousarray(M.data, dtype=np.float64))
+    aia, aja, aa = parts(A)
+    if B is not None:
+        bia, bja, ba = parts(B)
+        bn, bm = B.shape
+    else:
+        bia = bja = ba = None
+        bn = bm = 0
+    pp = None if perm is None else np.ascontiguousarray(perm, dtype=np.int32)
+    cp = None if colpos is None else np.ascontiguousarray(colpos, dtype=np.int32)
+    nr, nc = c_int(), c_int()
+    cia, cja, ca = vp(), vp(), vp()
+    call("HYPRE_MI_CSRDeviceOp", op, A.shape[0], A.shape[1], aia, aja, aa, bn, bm, bia, bja, ba, pp, cp,
+         C.byref(nr), C.byref(nc), C.byref(cia), C.byref(cja), C.byref(ca))
+    ia = np.ctypeslib.as_array(C.cast(cia, C.POINTER(c_big)), shape=(nr.value + 1,)).copy()
+    nnz = int(ia[-1])
+    ja = np.ctypeslib.as_array(C.cast(cja, C.POINTER(c_int)), shape=(max(nnz, 1),)).copy()[:nnz]
+    a = np.ctypeslib.as_array(C.cast(ca, C.POINTER(c_dbl)), shape=(max(nnz, 1),)).copy()[:nnz]
+    for ptr in (cia, cja, ca):
+        lib().HYPRE_MI_Free(ptr)
+    return ia, ja, a, (nr.value, nc.value)

@@ -54,6 +54,16 @@ HYPRE_Int HYPRE_MI_GetGSChunk(HYPRE_Int *rows_per_chunk);
 HYPRE_Int HYPRE_MI_KrylovGetResidualHistory(HYPRE_Solver solver, HYPRE_Real *norms, HYPRE_Int max_n, HYPRE_Int *n);
 HYPRE_Int HYPRE_MI_KrylovGetSolveSeconds(HYPRE_Solver solver, HYPRE_Real *seconds);
 
+/* ---- the setup phase's device sparse kernels on caller (host) CSR arrays: op 0 C = A*B (B rows sorted),
+ * 1 C = A^T, 2 C = rows of A in perm order (perm[new] = old, NULL = identity) with columns mapped through
+ * colpos (NULL = identity) and re-sorted.  Bit-identical to the host/oracle arithmetic.  Results are
+ * malloc'ed: release with HYPRE_MI_Free. */
+HYPRE_Int HYPRE_MI_CSRDeviceOp(HYPRE_Int op, HYPRE_Int a_nrows, HYPRE_Int a_ncols, const HYPRE_BigInt *a_ia,
+                               const HYPRE_Int *a_ja, const HYPRE_Complex *a_a, HYPRE_Int b_nrows, HYPRE_Int b_ncols,
+                               const HYPRE_BigInt *b_ia, const HYPRE_Int *b_ja, const HYPRE_Complex *b_a,
+                               const HYPRE_Int *perm, const HYPRE_Int *colpos, HYPRE_Int *c_nrows, HYPRE_Int *c_ncols,
+                               HYPRE_BigInt **c_ia, HYPRE_Int **c_ja, HYPRE_Complex **c_a);
+
 /* ---- hierarchy inspection (parity tests; mirrors hypre_ParAMGDataAArray) */
 HYPRE_Int HYPRE_MI_BoomerAMGGetNumLevels(HYPRE_Solver solver, HYPRE_Int *num_levels);
 HYPRE_Int HYPRE_MI_BoomerAMGGetOperatorComplexity(HYPRE_Solver solver, HYPRE_Real *cx);
