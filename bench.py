@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=int(os.environ.get("MI_BENCH_N", "512")), help="grid points per side")
+    ap.add_argument("--n", "--grid", dest="n", type=int, default=int(os.environ.get("MI_BENCH_N", "512")), help="grid points per side")
     ap.add_argument("--stencil", type=int, default=7)
     ap.add_argument("--tol", type=float, default=1e-8)
     ap.add_argument("--kdim", type=int, default=50)
@@ -84,18 +84,29 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
-    torch.cuda.set_device(local_rank)
+    # MI_BENCH_SHARED_GPU=1: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (ranks
+    # share devices, gloo transport through host callbacks -- RCCL refuses two ranks on one device).
+    # The line it prints carries "rehearsal": true and is not a measurement.
+    rehearsal = world > 1 and os.environ.get("MI_BENCH_SHARED_GPU") == "1"
+    device_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
+    torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist_
 
         dist = dist_
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     mi = ge.load_binding()
     mi.init()
     transport = "self"
-    if world > 1:
+    if rehearsal:
+        transport = "REHEARSAL: gloo host callbacks, ranks share a GPU"
+        mi.init_comm_torch(dist, device=None)
+    elif world > 1:
         # ncclUniqueId from rank 0 to everyone, then the library opens its own RCCL communicator
         transport = "rccl (library communicator: ncclSend/ncclRecv halo groups, ncclAllReduce dots)"
         ok = 1
@@ -159,7 +170,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -240,6 +251,8 @@ def main():
             "roofline": roof,
             "roofline_relax": roof_relax,
         }
+        if rehearsal:
+            out["rehearsal"] = True
         if not args.no_cpu and args.cpu_n > 0 and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, chunk.value)
         else:
