@@ -713,26 +713,46 @@ void BoomerAMG::build_natural(ParCSR &A0) {
   while (l < p.max_levels - 1 && L[(size_t)l].A->global_rows() > p.max_coarse_size) {
     ParCSR &A = *L[(size_t)l].A;
     const int n = A.nrows;
+    AmgLevel &Lv = L[(size_t)l];
+    const bool on_device = device_min_rows >= 0 && n >= device_min_rows;
     Strength S;
-    double tp0 = wall_time();
-    strength(A, p.strong_threshold, p.max_row_sum, S);
-    t_phase[0] += wall_time() - tp0;
-    tp0 = wall_time();
     std::vector<int> cf;
-    pmis(n, S, comm.rank, cf);
-    t_phase[1] += wall_time() - tp0;
+    double tp0 = wall_time();
+    if (on_device) {
+      // strength graph and PMIS splitting on the device (integer/compare work, identical results)
+      hipStream_t s = ctx().stream;
+      if (Lv.sA.nrows != n || Lv.sA.nnz != A.diag.nnz()) Lv.sA.upload(A.diag, s);
+      sk::DCsr dS;
+      sk::strength(Lv.sA, p.strong_threshold, p.max_row_sum, dS, s);
+      t_phase[0] += wall_time() - tp0;
+      tp0 = wall_time();
+      DVec<int> dcf;
+      sk::pmis(dS, 2747, dcf, s);
+      S.ia.resize((size_t)n + 1);
+      S.ja.resize((size_t)dS.nnz);
+      cf.resize((size_t)n);
+      MI_HIP(hipMemcpyAsync(S.ia.data(), dS.ia.p, ((size_t)n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+      if (dS.nnz) MI_HIP(hipMemcpyAsync(S.ja.data(), dS.ja.p, (size_t)dS.nnz * sizeof(int), hipMemcpyDeviceToHost, s));
+      MI_HIP(hipMemcpyAsync(cf.data(), dcf.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+      MI_HIP(hipStreamSynchronize(s));
+      t_phase[1] += wall_time() - tp0;
+    } else {
+      strength(A, p.strong_threshold, p.max_row_sum, S);
+      t_phase[0] += wall_time() - tp0;
+      tp0 = wall_time();
+      pmis(n, S, comm.rank, cf);
+      t_phase[1] += wall_time() - tp0;
+    }
     long long nc_loc = 0;
     for (int i = 0; i < n; i++) nc_loc += (cf[(size_t)i] == C_PT);
     long long nc_glob = nc_loc;
     comm.allreduce_host(&nc_glob, 1, CommDType::I64, CommOp::SUM);
     if (nc_glob == 0 || nc_glob == A.global_rows() || nc_glob < p.min_coarse_size) break;
 
-    AmgLevel &Lv = L[(size_t)l];
     int nc = 0;
     tp0 = wall_time();
     build_interp(A, S, cf, p.interp_type, p.trunc_factor, p.pmax_elmts, Lv.P, nc);
     Lv.cf = cf;
-    const bool on_device = device_min_rows >= 0 && n >= device_min_rows;
     if (!on_device) host_transpose(Lv.P, Lv.R);
     t_phase[2] += wall_time() - tp0;
     tp0 = wall_time();

@@ -306,6 +306,124 @@ int pow2_at_most(double v, int cap) {
   return s;
 }
 
+
+// ---------------------------------------------------------------- strength of connection
+// FILL = false: count per row; FILL = true: write the kept columns (stored order)
+template <bool FILL>
+__global__ __launch_bounds__(BLK) void strength_k(int n, const long long *__restrict__ ia, const int *__restrict__ ja,
+                                                  const double *__restrict__ a, double theta, double max_row_sum,
+                                                  int *__restrict__ cnt, const long long *__restrict__ sia,
+                                                  int *__restrict__ sja) {
+  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  const long long k0 = ia[i], k1 = ia[i + 1];
+  double diag = 0.0, row_sum = 0.0;
+  for (long long k = k0; k < k1; k++) {
+    row_sum += a[k];
+    if (ja[k] == i) diag = a[k];
+  }
+  double scale = 0.0;
+  for (long long k = k0; k < k1; k++) {
+    if (ja[k] == i) continue;
+    const double v = a[k];
+    if (diag < 0) {
+      if (v > scale) scale = v;
+    } else {
+      if (v < scale) scale = v;
+    }
+  }
+  const bool all_weak = (fabs(row_sum) > fabs(diag) * max_row_sum) && (max_row_sum < 1.0);
+  int c = 0;
+  if (!all_weak) {
+    const double thr = theta * scale;
+    long long q = FILL ? sia[i] : 0;
+    for (long long k = k0; k < k1; k++) {
+      if (ja[k] == i) continue;
+      const double v = a[k];
+      if ((diag < 0) ? (v > thr) : (v < thr)) {
+        if (FILL) sja[q++] = ja[k];
+        c++;
+      }
+    }
+  }
+  if (!FILL) cnt[i] = c;
+}
+
+// ---------------------------------------------------------------- PMIS
+constexpr int C_PT = 1, F_PT = -1, SF_PT = -3;
+
+__device__ __forceinline__ unsigned long long mulmod31(unsigned long long x, unsigned long long y) {
+  return (x * y) % 2147483647ULL;  // both < 2^31: the product fits 64 bits
+}
+
+__global__ __launch_bounds__(BLK) void pmis_init_k(int n, const long long *__restrict__ sia,
+                                                   const int *__restrict__ incoming, int seed0,
+                                                   double *__restrict__ measure, int *__restrict__ cf,
+                                                   int *__restrict__ undecided) {
+  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  // element i of the Park-Miller stream: seed0 * 16807^(i+1) mod (2^31 - 1)
+  unsigned long long base = 16807ULL, acc = (unsigned long long)seed0, e = (unsigned long long)i + 1ULL;
+  while (e) {
+    if (e & 1ULL) acc = mulmod31(acc, base);
+    base = mulmod31(base, base);
+    e >>= 1;
+  }
+  const double m = (double)incoming[i] + (double)(int)acc / 2147483647;
+  int c = 0;
+  if (sia[i + 1] == sia[i])
+    c = SF_PT;
+  else if (m < 1.0)
+    c = F_PT;
+  cf[i] = c;
+  measure[i] = c ? 0.0 : m;
+  if (c == 0) atomicAdd(undecided, 1);
+}
+
+__global__ __launch_bounds__(BLK) void pmis_mark_k(int n, const int *__restrict__ cf, signed char *__restrict__ tmp) {
+  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (i < n) tmp[i] = (cf[i] == 0);
+}
+
+__global__ __launch_bounds__(BLK) void pmis_compare_k(int n, const long long *__restrict__ sia,
+                                                      const int *__restrict__ sja, const int *__restrict__ cf,
+                                                      const double *__restrict__ measure,
+                                                      signed char *__restrict__ tmp) {
+  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (i >= n || cf[i] != 0) return;
+  const double mi = measure[i];
+  bool lose = false;
+  for (long long k = sia[i]; k < sia[i + 1]; k++) {
+    const int j = sja[k];
+    if (cf[j] != 0) continue;
+    const double mj = measure[j];
+    if (mi > mj)
+      tmp[j] = 0;
+    else if (mj > mi)
+      lose = true;
+  }
+  if (lose) tmp[i] = 0;
+}
+
+__global__ __launch_bounds__(BLK) void pmis_select_k(int n, int *__restrict__ cf, const signed char *__restrict__ tmp) {
+  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (i < n && cf[i] == 0 && tmp[i]) cf[i] = C_PT;
+}
+
+// undecided rows that depend on a C point become F; the others are counted for the next round
+__global__ __launch_bounds__(BLK) void pmis_fpoints_k(int n, const long long *__restrict__ sia,
+                                                      const int *__restrict__ sja, int *__restrict__ cf,
+                                                      int *__restrict__ undecided) {
+  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (i >= n || cf[i] != 0) return;
+  for (long long k = sia[i]; k < sia[i + 1]; k++)
+    if (cf[sja[k]] == C_PT) {  // other rows only ever switch 0 -> F here, never to or from C
+      cf[i] = F_PT;
+      return;
+    }
+  atomicAdd(undecided, 1);
+}
+
 // ---------------------------------------------------------------- row sort / transpose / permute
 // dst row = src row sorted by column (columns are unique inside a row); group of G lanes per row
 template <int G>
@@ -450,6 +568,57 @@ void launch_bins(const Bins &bins, const int *rows, const int *T, int S_hint, co
   MI_HIP(hipGetLastError());
 }
 }  // namespace
+
+
+void strength(const DCsr &A, double theta, double max_row_sum, DCsr &S, hipStream_t s) {
+  const int n = A.nrows;
+  S.release();
+  S.nrows = n;
+  S.ncols = A.ncols;
+  S.ia.alloc((size_t)n + 1);
+  DVec<int> cnt((size_t)n);
+  const unsigned grid = (unsigned)((n + BLK - 1) / BLK);
+  if (n) strength_k<false><<<grid, BLK, 0, s>>>(n, A.ia.p, A.ja.p, A.a.p, theta, max_row_sum, cnt.p, nullptr, nullptr);
+  exclusive_scan(cnt.p, S.ia.p, n, s);
+  long long total = 0;
+  MI_HIP(hipMemcpyAsync(&total, S.ia.p + n, sizeof(long long), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+  S.nnz = total;
+  S.ja.alloc((size_t)total);
+  if (n && total)
+    strength_k<true><<<grid, BLK, 0, s>>>(n, A.ia.p, A.ja.p, A.a.p, theta, max_row_sum, nullptr, S.ia.p, S.ja.p);
+  MI_HIP(hipGetLastError());
+  MI_HIP(hipStreamSynchronize(s));
+}
+
+void pmis(const DCsr &S, int seed, DVec<int> &cf, hipStream_t s) {
+  const int n = S.nrows;
+  cf.alloc((size_t)n);
+  if (n == 0) return;
+  const unsigned grid = (unsigned)((n + BLK - 1) / BLK);
+  DVec<int> incoming((size_t)n), counter(1);
+  DVec<double> measure((size_t)n);
+  DVec<signed char> tmp((size_t)n);
+  MI_HIP(hipMemsetAsync(incoming.p, 0, (size_t)n * sizeof(int), s));
+  MI_HIP(hipMemsetAsync(counter.p, 0, sizeof(int), s));
+  if (S.nnz) col_count_k<<<(unsigned)((S.nnz + BLK - 1) / BLK), BLK, 0, s>>>(S.nnz, S.ja.p, incoming.p);
+  pmis_init_k<<<grid, BLK, 0, s>>>(n, S.ia.p, incoming.p, seed ? seed : 13579, measure.p, cf.p, counter.p);
+  int undecided = 0;
+  MI_HIP(hipMemcpyAsync(&undecided, counter.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+  int rounds = 0;
+  while (undecided > 0) {
+    MI_REQUIRE(++rounds <= 10000, "PMIS does not terminate");
+    pmis_mark_k<<<grid, BLK, 0, s>>>(n, cf.p, tmp.p);
+    pmis_compare_k<<<grid, BLK, 0, s>>>(n, S.ia.p, S.ja.p, cf.p, measure.p, tmp.p);
+    pmis_select_k<<<grid, BLK, 0, s>>>(n, cf.p, tmp.p);
+    MI_HIP(hipMemsetAsync(counter.p, 0, sizeof(int), s));
+    pmis_fpoints_k<<<grid, BLK, 0, s>>>(n, S.ia.p, S.ja.p, cf.p, counter.p);
+    MI_HIP(hipMemcpyAsync(&undecided, counter.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+  }
+  MI_HIP(hipGetLastError());
+}
 
 void spgemm(const DCsr &A, const DCsr &B, DCsr &C, hipStream_t s) {
   MI_REQUIRE(A.ncols == B.nrows, "spgemm: inner dimensions differ");

@@ -27,6 +27,15 @@ struct DCsr {
   }
 };
 
+// strength-of-connection graph of a single-rank operator (no halo block): row i keeps column j != i iff
+// a_ij < theta * min_k a_ik (a_ii >= 0; mirrored for a_ii < 0); rows with |sum_j a_ij| > max_row_sum |a_ii|
+// keep nothing.  S has no values (S.a stays empty).
+void strength(const DCsr &A, double theta, double max_row_sum, DCsr &S, hipStream_t s);
+
+// PMIS on the graph S: measure = |S^T row| + Park-Miller(seed) drawn in row order (hypre_Rand; element i is
+// computed directly as seed * 16807^(i+1) mod 2^31-1).  cf: +1 C, -1 F, -3 F without strong connections.
+void pmis(const DCsr &S, int seed, DVec<int> &cf, hipStream_t s);
+
 // C = A * B.  Rows of B must have ascending columns.  Entry (i, j) is the sum of
 // a_ik * b_kj taken in the stored order of A's row i (first product assigned,
 // the others added one by one) -- exactly host_spgemm (amg_setup.cpp) and the
