@@ -717,22 +717,18 @@ void BoomerAMG::build_natural(ParCSR &A0) {
     const bool on_device = device_min_rows >= 0 && n >= device_min_rows;
     Strength S;
     std::vector<int> cf;
+    sk::DCsr dS;
+    DVec<int> dcf;
     double tp0 = wall_time();
     if (on_device) {
       // strength graph and PMIS splitting on the device (integer/compare work, identical results)
       hipStream_t s = ctx().stream;
       if (Lv.sA.nrows != n || Lv.sA.nnz != A.diag.nnz()) Lv.sA.upload(A.diag, s);
-      sk::DCsr dS;
       sk::strength(Lv.sA, p.strong_threshold, p.max_row_sum, dS, s);
       t_phase[0] += wall_time() - tp0;
       tp0 = wall_time();
-      DVec<int> dcf;
       sk::pmis(dS, 2747, dcf, s);
-      S.ia.resize((size_t)n + 1);
-      S.ja.resize((size_t)dS.nnz);
       cf.resize((size_t)n);
-      MI_HIP(hipMemcpyAsync(S.ia.data(), dS.ia.p, ((size_t)n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-      if (dS.nnz) MI_HIP(hipMemcpyAsync(S.ja.data(), dS.ja.p, (size_t)dS.nnz * sizeof(int), hipMemcpyDeviceToHost, s));
       MI_HIP(hipMemcpyAsync(cf.data(), dcf.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
       MI_HIP(hipStreamSynchronize(s));
       t_phase[1] += wall_time() - tp0;
@@ -751,7 +747,28 @@ void BoomerAMG::build_natural(ParCSR &A0) {
 
     int nc = 0;
     tp0 = wall_time();
-    build_interp(A, S, cf, p.interp_type, p.trunc_factor, p.pmax_elmts, Lv.P, nc);
+    bool p_on_device = false;
+    if (on_device) {
+      hipStream_t s = ctx().stream;
+      if (p.interp_type == 6 || p.interp_type == 0)
+        p_on_device = sk::interp(Lv.sA, dS, dcf, p.interp_type, p.trunc_factor, p.pmax_elmts, Lv.sP, nc, s);
+      if (p_on_device) {
+        Lv.sP.download(Lv.P, s);
+        MI_HIP(hipMemcpyAsync(cf.data(), dcf.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+        MI_HIP(hipStreamSynchronize(s));
+      } else {
+        // direct interpolation, or a row whose interpolatory set outgrows the kernels' tables: host routine
+        S.ia.resize((size_t)n + 1);
+        S.ja.resize((size_t)dS.nnz);
+        MI_HIP(hipMemcpyAsync(S.ia.data(), dS.ia.p, ((size_t)n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        if (dS.nnz)
+          MI_HIP(hipMemcpyAsync(S.ja.data(), dS.ja.p, (size_t)dS.nnz * sizeof(int), hipMemcpyDeviceToHost, s));
+        MI_HIP(hipStreamSynchronize(s));
+      }
+      dS.release();
+      dcf.release();
+    }
+    if (!p_on_device) build_interp(A, S, cf, p.interp_type, p.trunc_factor, p.pmax_elmts, Lv.P, nc);
     Lv.cf = cf;
     if (!on_device) host_transpose(Lv.P, Lv.R);
     t_phase[2] += wall_time() - tp0;
@@ -763,8 +780,7 @@ void BoomerAMG::build_natural(ParCSR &A0) {
       // same arithmetic, same order (setup_kernels.hip); the natural-order device copies stay for the
       // C-first renumbering
       hipStream_t s = ctx().stream;
-      if (Lv.sA.nrows != n || Lv.sA.nnz != A.diag.nnz()) Lv.sA.upload(A.diag, s);
-      Lv.sP.upload(Lv.P, s);
+      if (!p_on_device) Lv.sP.upload(Lv.P, s);
       sk::DCsr dR, dAP;
       sk::transpose(Lv.sP, dR, s);
       if (keep_natural_R) dR.download(Lv.R, s);

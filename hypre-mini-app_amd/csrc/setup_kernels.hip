@@ -424,6 +424,346 @@ __global__ __launch_bounds__(BLK) void pmis_fpoints_k(int n, const long long *__
   atomicAdd(undecided, 1);
 }
 
+// ---------------------------------------------------------------- interpolation (ext+i / classical modified)
+// One group of G lanes per row.  The interpolatory set of an F row (strong C neighbours, plus for ext+i the
+// strong C neighbours of its strong F neighbours) is collected in an LDS hash keyed by the fine id with the
+// DISCOVERY position of the host loop as value (atomicMin), ranked by that position, and from then on lane q
+// owns entry q: it walks A's row in stored order and adds the same terms in the same order as the host loop.
+constexpr int INTERP_SEQ = 65536;
+
+// bound on the interpolatory set (T) and on the stored row of P (cap); bins on max(T, |S row|)
+__global__ __launch_bounds__(BLK) void interp_bound_k(int n, const long long *__restrict__ sia,
+                                                      const int *__restrict__ sja, const int *__restrict__ cf,
+                                                      int ext, int pmax, int *__restrict__ T, int *__restrict__ cap,
+                                                      int *__restrict__ is_c, int *__restrict__ bin_count,
+                                                      int *__restrict__ tmax) {
+  __shared__ int hist[4];
+  __shared__ int smax;
+  if (threadIdx.x < 4) hist[threadIdx.x] = 0;
+  if (threadIdx.x == 0) smax = 0;
+  __syncthreads();
+  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (i < n) {
+    const int c = cf[i];
+    long long t = 0;
+    int cp = 0;
+    if (c == C_PT) {
+      cp = 1;
+    } else if (c == F_PT) {
+      long long trc = 0;
+      for (long long k = sia[i]; k < sia[i + 1]; k++) {
+        const int i1 = sja[k];
+        const int c1 = cf[i1];
+        if (c1 == C_PT)
+          trc++;
+        else if (c1 == F_PT && ext)
+          trc += sia[i1 + 1] - sia[i1];
+      }
+      t = max(trc, sia[i + 1] - sia[i]);
+      const long long rowcap = pmax > 0 ? min(trc, (long long)pmax) : trc;
+      cp = rowcap > 0x3fffffff ? 0x3fffffff : (int)rowcap;
+    }
+    const int ti = t > 0x3fffffff ? 0x3fffffff : (int)t;
+    T[i] = ti;
+    cap[i] = cp;
+    is_c[i] = (c == C_PT);
+    const int b = ti <= 32 ? 0 : ti <= 128 ? 1 : ti <= 512 ? 2 : 3;
+    atomicAdd(&hist[b], 1);
+    atomicMax(&smax, ti);
+  }
+  __syncthreads();
+  if (threadIdx.x < 4 && hist[threadIdx.x]) atomicAdd(&bin_count[threadIdx.x], hist[threadIdx.x]);
+  if (threadIdx.x == 0) atomicMax(tmax, smax);
+}
+
+template <int CAP>
+struct InterpGroup {
+  int hkey[2 * CAP];
+  int hval[2 * CAP];  // discovery position, later the entry's index q
+  int ckey[CAP];
+  int cseq[CAP];  // discovery positions of the compacted entries, later the keep flags
+  int ord[CAP];   // fine ids in discovery order
+  double rv[CAP];
+  double sfsum[CAP];
+  signed char sfsgn[CAP];
+  int cnt, nkept;
+  double diag, scale;
+};
+
+template <int LOGH>
+__device__ __forceinline__ int ig_find(const int *hkey, int key) {
+  const unsigned mask = (1u << LOGH) - 1u;
+  unsigned s = ((unsigned)key * 2654435761u) >> (32 - LOGH);
+  while (true) {
+    const int kk = hkey[s];
+    if (kk == key) return (int)s;
+    if (kk == EMPTY) return -1;
+    s = (s + 1u) & mask;
+  }
+}
+
+template <int G, int CAP, int BT>
+__global__ __launch_bounds__(BT) void interp_group_k(int nlist, const int *__restrict__ rows, int ext,
+                                                     const long long *__restrict__ Aia, const int *__restrict__ Aja,
+                                                     const double *__restrict__ Aa, const long long *__restrict__ Sia,
+                                                     const int *__restrict__ Sja, const int *__restrict__ cf,
+                                                     const long long *__restrict__ f2c, double trunc_factor, int pmax,
+                                                     const long long *__restrict__ slack_ia, int *__restrict__ Pj,
+                                                     double *__restrict__ Pa, int *__restrict__ len_out) {
+  constexpr int H = 2 * CAP;
+  constexpr int LOGH = (H == 64) ? 6 : (H == 256) ? 8 : 10;
+  constexpr int GP = BT / G;
+  __shared__ InterpGroup<CAP> grp[GP];
+  InterpGroup<CAP> &L = grp[threadIdx.x / G];
+  const int lane = threadIdx.x % G;
+  const long long gi = (long long)blockIdx.x * GP + threadIdx.x / G;
+  const bool active = gi < nlist;
+  const int i = active ? rows[gi] : 0;
+  const int mycf = active ? cf[i] : SF_PT;
+  const bool work = active && mycf == F_PT;
+  // trivial rows: C point -> (coarse id, 1.0); F without strong connections -> empty
+  if (active && !work && lane == 0) {
+    if (mycf == C_PT) {
+      const long long o = slack_ia[i];
+      Pj[o] = (int)f2c[i];
+      Pa[o] = 1.0;
+      len_out[i] = 1;
+    } else {
+      len_out[i] = 0;
+    }
+  }
+  for (int t = lane; t < H; t += G) {
+    L.hkey[t] = EMPTY;
+    L.hval[t] = 0x7fffffff;
+  }
+  if (lane == 0) L.cnt = 0;
+  __syncthreads();
+  const long long s0 = work ? Sia[i] : 0, s1 = work ? Sia[i + 1] : 0;
+  // ---- 1. interpolatory set with discovery positions
+  if (work) {
+    for (long long k = s0 + lane; k < s1; k += G) {
+      const int i1 = Sja[k];
+      const int c1 = cf[i1];
+      const int kl = (int)(k - s0);
+      auto put = [&](int key, int seq) {
+        const unsigned mask = (1u << LOGH) - 1u;
+        unsigned sl = ((unsigned)key * 2654435761u) >> (32 - LOGH);
+        while (true) {
+          const int old = atomicCAS(&L.hkey[sl], EMPTY, key);
+          if (old == EMPTY || old == key) break;
+          sl = (sl + 1u) & mask;
+        }
+        atomicMin(&L.hval[sl], seq);
+      };
+      if (c1 == C_PT) {
+        put(i1, kl * INTERP_SEQ);
+      } else if (c1 == F_PT && ext) {
+        const long long t0 = Sia[i1], t1 = Sia[i1 + 1];
+        for (long long kk = t0; kk < t1; kk++) {
+          const int k1 = Sja[kk];
+          if (cf[k1] == C_PT) put(k1, kl * INTERP_SEQ + 1 + (int)(kk - t0));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- 2. compaction
+  if (work)
+    for (int t = lane; t < H; t += G)
+      if (L.hkey[t] != EMPTY) {
+        const int p = atomicAdd(&L.cnt, 1);
+        L.ckey[p] = L.hkey[t];
+        L.cseq[p] = L.hval[t];
+      }
+  __syncthreads();
+  const int len = work ? L.cnt : 0;
+  // ---- 3. discovery order: ord[rank] = key, hash value = rank
+  if (work)
+    for (int p = lane; p < len; p += G) {
+      const int sq = L.cseq[p];
+      int rank = 0;
+      for (int u = 0; u < len; u++) rank += (L.cseq[u] < sq);
+      L.ord[rank] = L.ckey[p];
+      L.hval[ig_find<LOGH>(L.hkey, L.ckey[p])] = rank;
+    }
+  __syncthreads();
+  // ---- 4. per strong F neighbour: sign of its diagonal and the sum its connection is distributed over
+  if (work)
+    for (long long k = s0 + lane; k < s1; k += G) {
+      const int i1 = Sja[k];
+      const int kl = (int)(k - s0);
+      double sum = 0.0;
+      signed char sg = 1;
+      if (cf[i1] == F_PT) {
+        const long long r0 = Aia[i1], r1 = Aia[i1 + 1];
+        double dk = 0.0;
+        for (long long kk = r0; kk < r1; kk++)
+          if (Aja[kk] == i1) dk = Aa[kk];
+        const double sgn = (dk < 0) ? -1.0 : 1.0;
+        sg = (dk < 0) ? -1 : 1;
+        for (long long kk = r0; kk < r1; kk++) {
+          const int i2 = Aja[kk];
+          if (i2 == i1) continue;
+          const double v = Aa[kk];
+          if (!(sgn * v < 0)) continue;
+          if ((ext && i2 == i) || (cf[i2] == C_PT && ig_find<LOGH>(L.hkey, i2) >= 0)) sum += v;
+        }
+      }
+      L.sfsum[kl] = sum;
+      L.sfsgn[kl] = sg;
+    }
+  __syncthreads();
+  // ---- 5. weights: lane q accumulates entry q; the last lane accumulates the diagonal
+  if (work) {
+    const long long r0 = Aia[i], r1 = Aia[i + 1];
+    for (int q = lane; q < len; q += G) {
+      const int myid = L.ord[q];
+      double acc = 0.0;
+      long long sp = s0;
+      for (long long k = r0; k < r1; k++) {
+        const int i1 = Aja[k];
+        const bool strong = (sp < s1 && Sja[sp] == i1);
+        const int kl = (int)(sp - s0);
+        if (strong) sp++;
+        if (i1 == i) continue;
+        const double aik = Aa[k];
+        if (i1 == myid) {
+          acc += aik;
+        } else if (strong && cf[i1] == F_PT) {
+          const double sum = L.sfsum[kl];
+          if (sum != 0.0) {
+            const double distribute = aik / sum;
+            long long lo = Aia[i1];
+            const long long end = Aia[i1 + 1];
+            long long hi = end;
+            while (lo < hi) {
+              const long long mid = (lo + hi) >> 1;
+              if (Aja[mid] < myid)
+                lo = mid + 1;
+              else
+                hi = mid;
+            }
+            if (lo < end && Aja[lo] == myid) {
+              const double v = Aa[lo];
+              if ((double)L.sfsgn[kl] * v < 0) acc += distribute * v;
+            }
+          }
+        }
+      }
+      L.rv[q] = acc;
+    }
+    if (lane == G - 1) {
+      double diagonal = 0.0;
+      for (long long k = r0; k < r1; k++)
+        if (Aja[k] == i) diagonal = Aa[k];
+      long long sp = s0;
+      for (long long k = r0; k < r1; k++) {
+        const int i1 = Aja[k];
+        const bool strong = (sp < s1 && Sja[sp] == i1);
+        const int kl = (int)(sp - s0);
+        if (strong) sp++;
+        if (i1 == i) continue;
+        const double aik = Aa[k];
+        const int c1 = cf[i1];
+        if (c1 == C_PT && ig_find<LOGH>(L.hkey, i1) >= 0) continue;  // interpolatory point
+        if (strong && c1 == F_PT) {
+          const double sum = L.sfsum[kl];
+          if (sum != 0.0) {
+            if (ext) {
+              const double distribute = aik / sum;
+              const long long q0 = Aia[i1], q1 = Aia[i1 + 1];
+              for (long long kk = q0; kk < q1; kk++)
+                if (Aja[kk] == i) {
+                  const double v = Aa[kk];
+                  if ((double)L.sfsgn[kl] * v < 0) diagonal += distribute * v;
+                }
+            }
+          } else {
+            diagonal += aik;
+          }
+        } else {
+          diagonal += aik;
+        }
+      }
+      L.diag = diagonal;
+    }
+  }
+  __syncthreads();
+  if (work) {
+    const double diagonal = L.diag;
+    if (diagonal != 0.0)
+      for (int q = lane; q < len; q += G) L.rv[q] = L.rv[q] / -diagonal;
+  }
+  __syncthreads();
+  // ---- 6. truncation: keep the pmax largest by (|p| descending, position ascending) among those >= factor*max
+  if (work) {
+    double maxabs = 0.0;
+    if (trunc_factor > 0.0)
+      for (int t = 0; t < len; t++) maxabs = fmax(maxabs, fabs(L.rv[t]));
+    for (int q = lane; q < len; q += G) {
+      const double aq = fabs(L.rv[q]);
+      bool keep = (trunc_factor > 0.0) ? (aq >= trunc_factor * maxabs) : true;
+      if (keep && pmax > 0) {
+        int rank = 0;
+        for (int t = 0; t < len; t++) {
+          const double at = fabs(L.rv[t]);
+          const bool kt = (trunc_factor > 0.0) ? (at >= trunc_factor * maxabs) : true;
+          rank += (kt && (at > aq || (at == aq && t < q)));
+        }
+        keep = rank < pmax;
+      }
+      L.cseq[q] = keep;
+    }
+  }
+  __syncthreads();
+  if (work && lane == 0) {
+    double row_sum = 0.0, kept = 0.0;
+    int nk = 0;
+    for (int t = 0; t < len; t++) {
+      row_sum += L.rv[t];
+      if (L.cseq[t]) {
+        kept += L.rv[t];
+        nk++;
+      }
+    }
+    L.scale = (kept != 0.0) ? row_sum / kept : 1.0;
+    L.nkept = nk;
+    len_out[i] = nk;
+  }
+  __syncthreads();
+  if (work) {
+    const long long o = slack_ia[i];
+    const double scale = L.scale;
+    for (int q = lane; q < len; q += G) {
+      if (!L.cseq[q]) continue;
+      const int id = L.ord[q];
+      int pos = 0;
+      for (int t = 0; t < len; t++) pos += (L.cseq[t] && L.ord[t] < id);
+      Pj[o + pos] = (int)f2c[id];
+      Pa[o + pos] = L.rv[q] * scale;
+    }
+  }
+}
+
+__global__ __launch_bounds__(BLK) void compact_rows_k(int n, const long long *__restrict__ slack_ia,
+                                                      const int *__restrict__ sj, const double *__restrict__ sa,
+                                                      const long long *__restrict__ ia, int *__restrict__ dj,
+                                                      double *__restrict__ da) {
+  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  const long long s0 = slack_ia[i], d0 = ia[i];
+  const int len = (int)(ia[i + 1] - d0);
+  for (int e = 0; e < len; e++) {
+    dj[d0 + e] = sj[s0 + e];
+    da[d0 + e] = sa[s0 + e];
+  }
+}
+
+__global__ __launch_bounds__(BLK) void sf_to_f_k(int n, int *__restrict__ cf) {
+  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (i < n && cf[i] == SF_PT) cf[i] = F_PT;
+}
+
 // ---------------------------------------------------------------- row sort / transpose / permute
 // dst row = src row sorted by column (columns are unique inside a row); group of G lanes per row
 template <int G>
@@ -618,6 +958,68 @@ void pmis(const DCsr &S, int seed, DVec<int> &cf, hipStream_t s) {
     MI_HIP(hipStreamSynchronize(s));
   }
   MI_HIP(hipGetLastError());
+}
+
+bool interp(const DCsr &A, const DCsr &S, DVec<int> &cf, int interp_type, double trunc_factor, int pmax, DCsr &P,
+            int &nc, hipStream_t s) {
+  MI_REQUIRE(interp_type == 6 || interp_type == 0, "device interpolation: type 6 (ext+i) or 0 (classical modified)");
+  const int n = A.nrows;
+  const int ext = interp_type == 6;
+  P.release();
+  if (n == 0) return false;
+  const unsigned grid_rows = (unsigned)((n + BLK - 1) / BLK);
+  DVec<int> T((size_t)n), cap((size_t)n), is_c((size_t)n), rows((size_t)n), len((size_t)n), meta(16);
+  MI_HIP(hipMemsetAsync(meta.p, 0, 16 * sizeof(int), s));
+  interp_bound_k<<<grid_rows, BLK, 0, s>>>(n, S.ia.p, S.ja.p, cf.p, ext, pmax, T.p, cap.p, is_c.p, meta.p, meta.p + 4);
+  int hmeta[16];
+  MI_HIP(hipMemcpyAsync(hmeta, meta.p, sizeof(hmeta), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+  if (hmeta[3] > 0) return false;  // a row may exceed the largest LDS table
+  Bins bins;
+  for (int b = 0; b < 4; b++) bins.start[b + 1] = bins.start[b] + hmeta[b];
+  for (int b = 0; b < 4; b++) hmeta[8 + b] = bins.start[b], hmeta[12 + b] = 0;
+  MI_HIP(hipMemcpyAsync(meta.p + 8, hmeta + 8, 8 * sizeof(int), hipMemcpyHostToDevice, s));
+  bin_fill_k<<<grid_rows, BLK, 0, s>>>(n, T.p, meta.p + 8, meta.p + 12, rows.p);
+  // coarse numbering and the slack row pointers
+  DVec<long long> f2c((size_t)n + 1), slack_ia((size_t)n + 1);
+  exclusive_scan(is_c.p, f2c.p, n, s);
+  exclusive_scan(cap.p, slack_ia.p, n, s);
+  long long tot[2];
+  MI_HIP(hipMemcpyAsync(&tot[0], f2c.p + n, sizeof(long long), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipMemcpyAsync(&tot[1], slack_ia.p + n, sizeof(long long), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+  nc = (int)tot[0];
+  DVec<int> sj((size_t)tot[1]);
+  DVec<double> sa((size_t)tot[1]);
+  const int n0 = bins.start[1] - bins.start[0], n1 = bins.start[2] - bins.start[1], n2 = bins.start[3] - bins.start[2];
+  if (n0)
+    interp_group_k<8, 32, 256><<<(unsigned)((n0 + 31) / 32), 256, 0, s>>>(
+        n0, rows.p + bins.start[0], ext, A.ia.p, A.ja.p, A.a.p, S.ia.p, S.ja.p, cf.p, f2c.p, trunc_factor, pmax,
+        slack_ia.p, sj.p, sa.p, len.p);
+  if (n1)
+    interp_group_k<16, 128, 128><<<(unsigned)((n1 + 7) / 8), 128, 0, s>>>(
+        n1, rows.p + bins.start[1], ext, A.ia.p, A.ja.p, A.a.p, S.ia.p, S.ja.p, cf.p, f2c.p, trunc_factor, pmax,
+        slack_ia.p, sj.p, sa.p, len.p);
+  if (n2)
+    interp_group_k<64, 512, 128><<<(unsigned)((n2 + 1) / 2), 128, 0, s>>>(
+        n2, rows.p + bins.start[2], ext, A.ia.p, A.ja.p, A.a.p, S.ia.p, S.ja.p, cf.p, f2c.p, trunc_factor, pmax,
+        slack_ia.p, sj.p, sa.p, len.p);
+  MI_HIP(hipGetLastError());
+  P.nrows = n;
+  P.ncols = nc;
+  P.ia.alloc((size_t)n + 1);
+  exclusive_scan(len.p, P.ia.p, n, s);
+  long long total = 0;
+  MI_HIP(hipMemcpyAsync(&total, P.ia.p + n, sizeof(long long), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+  P.nnz = total;
+  P.ja.alloc((size_t)total);
+  P.a.alloc((size_t)total);
+  compact_rows_k<<<grid_rows, BLK, 0, s>>>(n, slack_ia.p, sj.p, sa.p, P.ia.p, P.ja.p, P.a.p);
+  sf_to_f_k<<<grid_rows, BLK, 0, s>>>(n, cf.p);
+  MI_HIP(hipGetLastError());
+  MI_HIP(hipStreamSynchronize(s));
+  return true;
 }
 
 void spgemm(const DCsr &A, const DCsr &B, DCsr &C, hipStream_t s) {

@@ -36,6 +36,13 @@ void strength(const DCsr &A, double theta, double max_row_sum, DCsr &S, hipStrea
 // computed directly as seed * 16807^(i+1) mod 2^31-1).  cf: +1 C, -1 F, -3 F without strong connections.
 void pmis(const DCsr &S, int seed, DVec<int> &cf, hipStream_t s);
 
+// Interpolation (interp_type 6 extended+i or 0 classical modified) with truncation to pmax entries /
+// trunc_factor, rows of A and S in ascending column order.  cf is updated like the host code does (-3 -> -1).
+// Returns false -- and builds nothing -- when a row's interpolatory set may exceed the kernels' LDS capacity
+// (the caller then runs the host routine for this level).  nc = number of C points.
+bool interp(const DCsr &A, const DCsr &S, DVec<int> &cf, int interp_type, double trunc_factor, int pmax, DCsr &P,
+            int &nc, hipStream_t s);
+
 // C = A * B.  Rows of B must have ascending columns.  Entry (i, j) is the sum of
 // a_ik * b_kj taken in the stored order of A's row i (first product assigned,
 // the others added one by one) -- exactly host_spgemm (amg_setup.cpp) and the

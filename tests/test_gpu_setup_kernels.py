@@ -93,17 +93,7 @@ def test_transpose_and_permute(mi):
             assert np.array_equal(a.view(np.int64), R.data.view(np.int64))
 
 
-@pytest.mark.parametrize("n,stencil", [(16, 7), (14, 27)])
-def test_device_setup_hierarchy_is_bit_identical(mi, oc, n, stencil, monkeypatch):
-    """The whole hierarchy with every level's products/transposes/renumbering on the device."""
-    monkeypatch.setenv("MI_HYPRE_DEVICE_SETUP_MIN_ROWS", "0")
-    A, b, x, rhs = mi.build_laplace_system(n, n, n, stencil)
-    amg = mi.BoomerAMG(print_level=0)
-    amg.setup(A)
-    Ao, bo = oc.Csr.laplace(n, n, n, stencil)
-    chunk = mi.c_int()
-    mi.call("HYPRE_MI_GetGSChunk", mi.C.byref(chunk))
-    oamg = oc.Amg(Ao, oc.default_params(gs_chunk=chunk.value))
+def _assert_same_hierarchy(amg, oamg):
     assert amg.num_levels == oamg.num_levels
     for l in range(amg.num_levels):
         ia, ja, a, _ = amg.level_csr(l, 0)
@@ -111,6 +101,7 @@ def test_device_setup_hierarchy_is_bit_identical(mi, oc, n, stencil, monkeypatch
         assert np.array_equal(ia, oia) and np.array_equal(ja, oja), l
         assert np.array_equal(a.view(np.int64), oa.view(np.int64)), l
         if l < amg.num_levels - 1:
+            assert np.array_equal(amg.level_cf(l), oamg.level_cf(l)), l
             pia, pja, pa, _ = amg.level_csr(l, 2)
             oia, oja, oa = oamg.level_P(l).arrays()
             assert np.array_equal(pia, oia) and np.array_equal(pja, oja), l
@@ -120,3 +111,52 @@ def test_device_setup_hierarchy_is_bit_identical(mi, oc, n, stencil, monkeypatch
             PT.sort_indices()
             assert np.array_equal(ria, PT.indptr) and np.array_equal(rja, PT.indices), l
             assert np.array_equal(ra.view(np.int64), PT.data.view(np.int64)), l
+
+
+@pytest.mark.parametrize("n,stencil,kw", [
+    (16, 7, {}),
+    (14, 27, {}),
+    (14, 7, dict(interp_type=0)),                                  # classical modified
+    (12, 27, dict(trunc_factor=0.2, true_pmax_elmts=0)),           # relative truncation only
+    (16, 7, dict(strong_threshold=0.25, true_pmax_elmts=6)),
+    (12, 7, dict(interp_type=3)),                                  # direct: host routine inside the device setup
+])
+def test_device_setup_hierarchy_is_bit_identical(mi, oc, n, stencil, kw, monkeypatch):
+    """Strength, PMIS, interpolation, Galerkin products, transposes and the C-first renumbering of EVERY level on
+    the device: the hierarchy equals the oracle's bit for bit."""
+    monkeypatch.setenv("MI_HYPRE_DEVICE_SETUP_MIN_ROWS", "0")
+    A, b, x, rhs = mi.build_laplace_system(n, n, n, stencil)
+    amg = mi.BoomerAMG(print_level=0, **kw)
+    amg.setup(A)
+    Ao, bo = oc.Csr.laplace(n, n, n, stencil)
+    chunk = mi.c_int()
+    mi.call("HYPRE_MI_GetGSChunk", mi.C.byref(chunk))
+    okw = {("pmax_elmts" if k == "true_pmax_elmts" else k): v for k, v in kw.items()}
+    oamg = oc.Amg(Ao, oc.default_params(gs_chunk=chunk.value, **okw))
+    _assert_same_hierarchy(amg, oamg)
+
+
+def test_device_setup_random_mmatrix(mi, oc, monkeypatch):
+    """Irregular rows (the interpolation kernel's larger group sizes) on a random M-matrix."""
+    monkeypatch.setenv("MI_HYPRE_DEVICE_SETUP_MIN_ROWS", "0")
+    rng = np.random.default_rng(21)
+    n = 3000
+    B = _rand_csr(rng, n, n, 14)
+    B = (B + B.T).tocsr()
+    B.data = -np.abs(B.data)
+    B.setdiag(0)
+    B.eliminate_zeros()
+    d = -np.asarray(B.sum(axis=1)).ravel() * (1.0 + 0.05 * rng.random(n)) + 1e-3
+    M = (B + sp.diags(d)).tocsr()
+    M.sort_indices()
+    A = mi.IJMatrix(0, n - 1)
+    coo = M.tocoo()
+    A.set_values_coo(coo.row.astype(np.int64), coo.col.astype(np.int64), coo.data.astype(np.float64))
+    A.assemble()
+    amg = mi.BoomerAMG(print_level=0, strong_threshold=0.25)
+    amg.setup(A)
+    chunk = mi.c_int()
+    mi.call("HYPRE_MI_GetGSChunk", mi.C.byref(chunk))
+    oamg = oc.Amg(oc.Csr.from_scipy(M), oc.default_params(gs_chunk=chunk.value, strong_threshold=0.25))
+    assert amg.num_levels > 2
+    _assert_same_hierarchy(amg, oamg)
