@@ -40,6 +40,9 @@ struct AmgLevel {
   std::unique_ptr<ParCSR> Pm, Rm;
   // device copies (natural ordering) kept between the Galerkin product and the C-first renumbering
   sk::DCsr sA, sP;
+  // C-first ordered operators of a level built on the device, until setup_device moves them into the
+  // solve-phase format (A->d_diag, Pm->d_diag, Rm->d_diag)
+  sk::DCsr oA, oP, oR;
   std::vector<int> cf;  // +1 C, -1 F (empty on the coarsest level)
   DVec<signed char> d_cf;
   // C-first ordering of this level: perm[new] = old local row;
@@ -101,6 +104,8 @@ struct BoomerAMG {
   // renumber every level C-first (host, collective); called at the end of setup_host
   void apply_cf_ordering();
   double operator_complexity() const;
+  // fill the host arrays of a level's A / P / R from the device (inspection API, coarse solve)
+  void ensure_host(int level);
 };
 
 // set by a Krylov solver right before it calls the preconditioner with x == 0,

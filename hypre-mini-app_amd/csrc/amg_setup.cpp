@@ -515,13 +515,33 @@ long long BoomerAMG::default_device_min_rows() {
   return e ? atoll(e) : 20000;
 }
 
+void BoomerAMG::ensure_host(int level) {
+  if (level < 0 || level >= (int)L.size()) return;
+  AmgLevel &Lv = L[(size_t)level];
+  auto fetch = [&](ParCSR *M, sk::DCsr &dev) {
+    if (!M || !M->host_diag_stale) return;
+    hipStream_t s = ctx().stream;
+    const int nr = M->diag.nrows, ncl = M->diag.ncols;
+    if (dev.nrows == M->nrows && dev.ia.p)
+      dev.download(M->diag, s);
+    else
+      sk::solve_format_to_host(M->d_diag, M->diag, s);
+    M->diag.nrows = nr;
+    M->diag.ncols = ncl;
+    M->host_diag_stale = false;
+  };
+  fetch(Lv.A, Lv.oA);
+  fetch(Lv.Pm.get(), Lv.oP);
+  fetch(Lv.Rm.get(), Lv.oR);
+}
+
 int BoomerAMG::chunk() const { return p.gs_chunk > 0 ? p.gs_chunk : ctx().gs_chunk; }
 
 double BoomerAMG::operator_complexity() const {
   if (L.empty()) return 0.0;
   double tot = 0.0;
-  for (const auto &l : L) tot += (double)(l.A->diag.nnz() + l.A->offd.nnz());
-  const double base = (double)(L[0].A->diag.nnz() + L[0].A->offd.nnz());
+  for (const auto &l : L) tot += (double)(l.A->diag_nnz() + l.A->offd.nnz());
+  const double base = (double)(L[0].A->diag_nnz() + L[0].A->offd.nnz());
   return base > 0 ? tot / base : 0.0;
 }
 
@@ -602,6 +622,14 @@ void BoomerAMG::apply_cf_ordering() {
   };
   for (size_t l = 0; l < nlev; l++) {
     AmgLevel &Lv = L[l];
+    if (pos[l].empty() && Lv.A->host_diag_stale && Lv.sA.nrows == Lv.A->nrows) {
+      // a level without C/F splitting (the coarsest) keeps its ordering: fetch it before sA goes away
+      const int nr = Lv.A->diag.nrows, ncl = Lv.A->diag.ncols;
+      Lv.sA.download(Lv.A->diag, ctx().stream);
+      Lv.A->diag.nrows = nr;
+      Lv.A->diag.ncols = ncl;
+      Lv.A->host_diag_stale = false;
+    }
     if (!pos[l].empty()) {
       ParCSR &A = *Lv.A;
       std::unique_ptr<ParCSR> An(new ParCSR());
@@ -614,10 +642,12 @@ void BoomerAMG::apply_cf_ordering() {
         DVec<int> dperm, dpos;
         dperm.upload(Lv.perm);
         dpos.upload(pos[l]);
-        sk::DCsr dB;
-        sk::permute(Lv.sA, dperm.p, dpos.p, dB, s);
-        dB.download(An->diag, s);
+        sk::permute(Lv.sA, dperm.p, dpos.p, Lv.oA, s);
+        An->diag.nrows = An->diag.ncols = A.nrows;
+        An->host_diag_stale = true;
+        An->dev_diag_nnz = Lv.oA.nnz;
       } else {
+        if (A.host_diag_stale) fail(1, "C-first ordering: a level has neither host nor device arrays");
         permute(A.diag, Lv.perm, pos[l].data(), An->diag);
       }
       Lv.sA.release();
@@ -653,19 +683,21 @@ void BoomerAMG::apply_cf_ordering() {
         DVec<int> dperm, dpos;
         if (!Lv.perm.empty()) dperm.upload(Lv.perm);
         if (map_cols) dpos.upload(pos[l + 1]);
-        sk::DCsr dP2, dR2;
-        sk::permute(Lv.sP, Lv.perm.empty() ? nullptr : dperm.p, map_cols ? dpos.p : nullptr, dP2, s);
+        sk::permute(Lv.sP, Lv.perm.empty() ? nullptr : dperm.p, map_cols ? dpos.p : nullptr, Lv.oP, s);
         Lv.sP.release();
-        dP2.download(Lv.P, s);
-        sk::transpose(dP2, dR2, s);
-        dR2.download(Lv.R, s);
+        sk::transpose(Lv.oP, Lv.oR, s);
+        const int pr = Lv.P.nrows, pc = Lv.P.ncols;
+        Lv.P = HostCSR();
+        Lv.R = HostCSR();
+        Lv.P.nrows = Lv.R.ncols = pr;
+        Lv.P.ncols = Lv.R.nrows = pc;
       } else {
         HostCSR P2;
         permute(Lv.P, Lv.perm, map_cols ? pos[l + 1].data() : nullptr, P2);
         Lv.P = std::move(P2);
         host_transpose(Lv.P, Lv.R);
       }
-    } else if (Lv.P.nrows > 0 && Lv.R.nrows == 0) {
+    } else if (Lv.P.nrows > 0 && !Lv.P.ia.empty() && Lv.R.nrows == 0) {
       host_transpose(Lv.P, Lv.R);  // no renumbering on either side: R was not built yet on the device path
     }
     Lv.sA.release();
@@ -723,7 +755,7 @@ void BoomerAMG::build_natural(ParCSR &A0) {
     if (on_device) {
       // strength graph and PMIS splitting on the device (integer/compare work, identical results)
       hipStream_t s = ctx().stream;
-      if (Lv.sA.nrows != n || Lv.sA.nnz != A.diag.nnz()) Lv.sA.upload(A.diag, s);
+      if (Lv.sA.nrows != n) Lv.sA.upload(A.diag, s);
       sk::strength(Lv.sA, p.strong_threshold, p.max_row_sum, dS, s);
       t_phase[0] += wall_time() - tp0;
       tp0 = wall_time();
@@ -753,11 +785,21 @@ void BoomerAMG::build_natural(ParCSR &A0) {
       if (p.interp_type == 6 || p.interp_type == 0)
         p_on_device = sk::interp(Lv.sA, dS, dcf, p.interp_type, p.trunc_factor, p.pmax_elmts, Lv.sP, nc, s);
       if (p_on_device) {
-        Lv.sP.download(Lv.P, s);
+        if (keep_natural_R) {
+          Lv.sP.download(Lv.P, s);
+        } else {  // stays on the device; the dimensions are all the host needs
+          Lv.P = HostCSR();
+          Lv.P.nrows = n;
+          Lv.P.ncols = nc;
+        }
         MI_HIP(hipMemcpyAsync(cf.data(), dcf.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
         MI_HIP(hipStreamSynchronize(s));
       } else {
         // direct interpolation, or a row whose interpolatory set outgrows the kernels' tables: host routine
+        if (A.host_diag_stale) {
+          Lv.sA.download(A.diag, s);
+          A.host_diag_stale = false;
+        }
         S.ia.resize((size_t)n + 1);
         S.ja.resize((size_t)dS.nnz);
         MI_HIP(hipMemcpyAsync(S.ia.data(), dS.ia.p, ((size_t)n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, s));
@@ -786,11 +828,18 @@ void BoomerAMG::build_natural(ParCSR &A0) {
       if (keep_natural_R) dR.download(Lv.R, s);
       sk::spgemm(Lv.sA, Lv.sP, dAP, s);
       L.emplace_back();  // the coarse operator is born on the device (L was reserved: references stay valid)
-      sk::spgemm(dR, dAP, L[(size_t)l + 1].sA, s);
-      L[(size_t)l + 1].sA.download(An->diag, s);
+      sk::DCsr &dAc = L[(size_t)l + 1].sA;
+      sk::spgemm(dR, dAP, dAc, s);
+      if (keep_natural_R || nc < device_min_rows) {
+        dAc.download(An->diag, s);  // the next level (or the multi-rank slicing) works on host arrays
+      } else {
+        An->diag.nrows = An->diag.ncols = nc;
+        An->host_diag_stale = true;
+        An->dev_diag_nnz = dAc.nnz;
+      }
       if (getenv("MI_HYPRE_SETUP_TIMING"))
         printf("   level %d: n %d  device Galerkin %.2f s (nnz AP %lld, A_c %lld)\n", l, n, wall_time() - tp0,
-               (long long)dAP.nnz, (long long)An->diag.nnz());
+               (long long)dAP.nnz, (long long)dAc.nnz);
     } else {
       HostCSR AP;
       host_spgemm(A.diag, Lv.P, AP);
@@ -822,10 +871,23 @@ void BoomerAMG::finish_host() {
     AmgLevel &Lv = L[li];
     ParCSR &A = *Lv.A;
     Lv.n = A.nrows;
+    if (A.host_diag_stale && Lv.oA.nrows == A.nrows) {
+      // the level lives on the device: norms straight into the solve-phase vectors
+      hipStream_t s = ctx().stream;
+      DVec<int> dcf;
+      if (!Lv.cf.empty()) dcf.upload(Lv.cf);
+      Lv.d_diag.alloc((size_t)Lv.n);
+      Lv.d_l1gs.alloc((size_t)Lv.n);
+      Lv.d_l1jac.alloc((size_t)Lv.n);
+      sk::level_norms(Lv.oA, Lv.cf.empty() ? nullptr : dcf.p, ch, Lv.d_diag.p, Lv.d_l1gs.p, Lv.d_l1jac.p, s);
+      MI_HIP(hipStreamSynchronize(s));
+      continue;
+    }
     std::vector<int> cf_ext;
     if (!Lv.cf.empty()) cf_ext = A.halo_exchange_host_int(comm, Lv.cf);
     level_norms(A, Lv.cf, cf_ext, ch, Lv.diag, Lv.l1gs, Lv.l1jac);
   }
+  ensure_host((int)L.size() - 1);
 
   // coarsest level: dense inverse (relax type 9), every rank holds its own rows
   AmgLevel &Lc = L.back();
@@ -980,6 +1042,11 @@ void BoomerAMG::make_local_transfer_operators() {
     if (Lv.P.nrows == 0 && Lv.cf.empty()) continue;
     Lv.Pm = wrap_local(std::move(Lv.P), Lv.A->row_starts, L[l + 1].A->row_starts, comm.rank);
     Lv.Rm = wrap_local(std::move(Lv.R), L[l + 1].A->row_starts, Lv.A->row_starts, comm.rank);
+    if (Lv.oP.nrows > 0) {  // built on the device: host arrays on demand
+      Lv.Pm->host_diag_stale = Lv.Rm->host_diag_stale = true;
+      Lv.Pm->dev_diag_nnz = Lv.oP.nnz;
+      Lv.Rm->dev_diag_nnz = Lv.oR.nnz;
+    }
     Lv.Pm->build_halo_plan(comm);
     Lv.Rm->build_halo_plan(comm);
     Lv.P = HostCSR();
@@ -1191,12 +1258,23 @@ void BoomerAMG::setup_device() {
   const int ch = chunk();
   for (size_t li = 0; li < L.size(); li++) {
     AmgLevel &Lv = L[li];
-    if (li > 0 || !Lv.A->on_device) Lv.A->to_device();
-    if (Lv.Pm) Lv.Pm->to_device();
-    if (Lv.Rm) Lv.Rm->to_device();
-    Lv.d_diag.upload(Lv.diag);
-    Lv.d_l1gs.upload(Lv.l1gs);
-    Lv.d_l1jac.upload(Lv.l1jac);
+    hipStream_t s = ctx().stream;
+    auto place = [&](ParCSR &M, sk::DCsr &dev) {
+      if (dev.nrows == M.nrows && M.host_diag_stale) {  // built on the device: no host round trip
+        sk::to_solve_format(dev, M.d_diag, s);
+        M.to_device_halo();
+      } else {
+        M.to_device();
+      }
+    };
+    if (li > 0 || !Lv.A->on_device) place(*Lv.A, Lv.oA);
+    if (Lv.Pm) place(*Lv.Pm, Lv.oP);
+    if (Lv.Rm) place(*Lv.Rm, Lv.oR);
+    if (!Lv.d_diag.p || Lv.d_diag.n != (size_t)Lv.n) {
+      Lv.d_diag.upload(Lv.diag);
+      Lv.d_l1gs.upload(Lv.l1gs);
+      Lv.d_l1jac.upload(Lv.l1jac);
+    }
     if (!Lv.cf.empty()) {
       std::vector<signed char> c8(Lv.cf.size());
       for (size_t i = 0; i < c8.size(); i++) c8[i] = (signed char)Lv.cf[i];
@@ -1233,7 +1311,7 @@ void BoomerAMG::setup_device() {
            t_phase[0], t_phase[1], t_phase[2], t_phase[3], t_phase[4], t_phase[5]);
     for (size_t li = 0; li < L.size(); li++)
       printf("   level %2zu: local rows %10d  global rows %12lld  local nnz %12lld\n", li, L[li].n,
-             (long long)L[li].A->global_rows(), (long long)(L[li].A->diag.nnz() + L[li].A->offd.nnz()));
+             (long long)L[li].A->global_rows(), (long long)(L[li].A->diag_nnz() + L[li].A->offd.nnz()));
   }
 }
 

@@ -1131,6 +1131,7 @@ HYPRE_Int HYPRE_MI_BoomerAMGGetSetupSeconds(HYPRE_Solver solver, HYPRE_Real *sec
 }
 static const HostCSR &level_csr(AmgSolver *a, int level, int which) {
   if (level < 0 || level >= (int)a->amg.L.size()) fail(HYPRE_ERROR_ARG, "AMG level out of range");
+  a->amg.ensure_host(level);
   AmgLevel &L = a->amg.L[(size_t)level];
   switch (which) {
     case 0: return L.A->diag;

@@ -215,7 +215,13 @@ void ParCSR::build_halo_plan(Comm &comm) {
 
 void ParCSR::to_device() {
   ensure_init();
+  MI_REQUIRE(!host_diag_stale, "to_device: the host copy of the diag block was not built");
   d_diag.upload(diag);
+  to_device_halo();
+}
+
+void ParCSR::to_device_halo() {
+  ensure_init();
   d_offd.upload(nrows, offd);
   halo.d_send_map.upload(halo.send_map);
   halo.d_send_buf.alloc(halo.send_map.size());

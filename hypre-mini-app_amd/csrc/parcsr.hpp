@@ -40,12 +40,19 @@ struct ParCSR {
   DevOffd d_offd;
   DVec<double> d_offc;  // per-row halo contribution scratch (zero outside halo rows)
   bool on_device = false;
+  // A level built by the device setup keeps its diag block on the device only: the host arrays of `diag`
+  // are filled on demand (BoomerAMG::ensure_host); nrows / ncols of `diag` are always valid.
+  bool host_diag_stale = false;
+  int64_t dev_diag_nnz = 0;
+  int64_t diag_nnz() const { return host_diag_stale ? dev_diag_nnz : diag.nnz(); }
   gidx global_rows() const { return row_starts.empty() ? nrows : row_starts.back(); }
 
   // build the halo plan from col_map_offd (collective, host only)
   void build_halo_plan(Comm &comm);
   // mirror matrix + plan to the device (needs a GPU)
   void to_device();
+  // the same without the diag block (already built on the device: d_diag is set)
+  void to_device_halo();
   void finalize(Comm &comm) {
     build_halo_plan(comm);
     to_device();

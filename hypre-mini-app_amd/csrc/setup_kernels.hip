@@ -16,6 +16,8 @@
 
 #include <algorithm>
 
+#include "kernels.hpp"
+
 namespace mi {
 namespace sk {
 namespace {
@@ -842,6 +844,147 @@ __global__ __launch_bounds__(BLK) void perm_copy_k(int n, const long long *__res
   }
 }
 
+// ---------------------------------------------------------------- solve-phase format on the device
+__global__ __launch_bounds__(BLK) void ia_to_32_k(long long n1, const long long *__restrict__ ia, int *__restrict__ ia32) {
+  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (i < n1) ia32[i] = (int)ia[i];
+}
+__global__ __launch_bounds__(BLK) void ia_to_64_k(long long n1, const int *__restrict__ ia32, long long *__restrict__ ia) {
+  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (i < n1) ia[i] = ia32[i];
+}
+
+constexpr int LEN_BINS = 4096;
+__global__ __launch_bounds__(BLK) void rowlen_hist_k(int n, const long long *__restrict__ ia, int *__restrict__ hist) {
+  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  const long long len = ia[i + 1] - ia[i];
+  atomicAdd(&hist[len >= LEN_BINS ? LEN_BINS - 1 : (int)len], 1);
+}
+
+// x cache of one row block (spmv_stream_xc): sorted unique columns of the block's entries and the
+// block-local id of every entry.  One workgroup per block, bitonic sort in LDS.
+__global__ __launch_bounds__(BLK) void xcache_block_k(int nb, const int *__restrict__ rb, const int *__restrict__ ia,
+                                                      const int *__restrict__ ja, int *__restrict__ ucnt,
+                                                      int *__restrict__ uslack, unsigned short *__restrict__ lcol) {
+  constexpr int TILE = k::SPMV_TILE;
+  __shared__ int key[TILE];
+  __shared__ int uniq[TILE];
+  __shared__ int wsum[BLK];
+  const int b = blockIdx.x;
+  if (b >= nb) return;
+  const int tid = threadIdx.x;
+  const int s0 = ia[rb[b]], e0 = ia[rb[b + 1]];
+  const int cnt = e0 - s0;
+  if (cnt >= TILE) {  // a single long row: direct gathers in the SpMV
+    if (tid == 0) ucnt[b] = 0;
+    return;
+  }
+  for (int t = tid; t < TILE; t += BLK) key[t] = (t < cnt) ? ja[s0 + t] : EMPTY;
+  __syncthreads();
+  for (int size = 2; size <= TILE; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < TILE / 2; t += BLK) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool up = ((lo & size) == 0);
+        const int a = key[lo], c = key[hi];
+        if ((a > c) == up) {
+          key[lo] = c;
+          key[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  // unique: every thread owns TILE/BLK consecutive sorted keys
+  constexpr int PER = TILE / BLK;
+  int flags[PER], local = 0;
+  for (int q = 0; q < PER; q++) {
+    const int t = tid * PER + q;
+    const int v = key[t];
+    flags[q] = (v != EMPTY) && (t == 0 || key[t - 1] != v);
+    local += flags[q];
+  }
+  wsum[tid] = local;
+  __syncthreads();
+  for (int d = 1; d < BLK; d <<= 1) {
+    const int add = (tid >= d) ? wsum[tid - d] : 0;
+    __syncthreads();
+    wsum[tid] += add;
+    __syncthreads();
+  }
+  int pos = wsum[tid] - local;
+  for (int q = 0; q < PER; q++)
+    if (flags[q]) {
+      const int v = key[tid * PER + q];
+      uniq[pos] = v;
+      uslack[s0 + pos] = v;
+      pos++;
+    }
+  const int nu = wsum[BLK - 1];
+  __syncthreads();
+  if (tid == 0) ucnt[b] = nu;
+  for (int t = tid; t < cnt; t += BLK) {
+    const int c = ja[s0 + t];
+    int lo = 0, hi = nu;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (uniq[mid] < c)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    lcol[s0 + t] = (unsigned short)lo;
+  }
+}
+
+__global__ __launch_bounds__(BLK) void xcache_compact_k(int nb, const int *__restrict__ rb, const int *__restrict__ ia,
+                                                        const long long *__restrict__ uptr64,
+                                                        const int *__restrict__ uslack, int *__restrict__ uptr,
+                                                        int *__restrict__ ucols) {
+  const int b = blockIdx.x;
+  if (b >= nb) return;
+  const long long u0 = uptr64[b];
+  const int nu = (int)(uptr64[b + 1] - u0);
+  const int s0 = ia[rb[b]];
+  for (int t = threadIdx.x; t < nu; t += BLK) ucols[u0 + t] = uslack[s0 + t];
+  if (threadIdx.x == 0) {
+    uptr[b] = (int)u0;
+    if (b == nb - 1) uptr[nb] = (int)uptr64[nb];
+  }
+}
+
+// ---------------------------------------------------------------- l1 norms
+__global__ __launch_bounds__(BLK) void level_norms_k(int n, const long long *__restrict__ ia, const int *__restrict__ ja,
+                                                     const double *__restrict__ a, const int *__restrict__ cf, int chunk,
+                                                     double *__restrict__ diag, double *__restrict__ l1gs,
+                                                     double *__restrict__ l1jac) {
+  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  const long long cs = (i / chunk) * chunk, ce = cs + chunk;
+  const int mycf = cf ? cf[i] : 0;
+  double d = 0.0, l1 = 0.0, full = 0.0;
+  for (long long k = ia[i]; k < ia[i + 1]; k++) {
+    const int j = ja[k];
+    const double av = fabs(a[k]);
+    full += av;
+    if (j == i) {
+      d = a[k];
+      l1 += av;
+    } else if (j < cs || j >= ce) {
+      if (!cf || cf[j] == mycf) l1 += 0.5 * av;
+    }
+  }
+  if (l1 <= 4.0 / 3.0 * fabs(d)) l1 = fabs(d);
+  if (d < 0) {
+    l1 = -l1;
+    full = -full;
+  }
+  diag[i] = d;
+  l1gs[i] = l1;
+  l1jac[i] = full;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------- host-facing entry points
@@ -909,6 +1052,92 @@ void launch_bins(const Bins &bins, const int *rows, const int *T, int S_hint, co
 }
 }  // namespace
 
+
+void to_solve_format(DCsr &src, DevCSR &dst, hipStream_t s) {
+  const int n = src.nrows;
+  MI_REQUIRE(src.nnz < (int64_t)2147483000, "per-rank matrix block exceeds int32 row pointers");
+  dst.nrows = n;
+  dst.ncols = src.ncols;
+  dst.nnz = src.nnz;
+  dst.ia.alloc((size_t)n + 1);
+  ia_to_32_k<<<(unsigned)((n + 1 + BLK - 1) / BLK), BLK, 0, s>>>((long long)n + 1, src.ia.p, dst.ia.p);
+  // row-length percentile (GS kernel variant choice) from a device histogram
+  dst.rowlen_p95 = 0;
+  if (n) {
+    DVec<int> hist(LEN_BINS);
+    MI_HIP(hipMemsetAsync(hist.p, 0, LEN_BINS * sizeof(int), s));
+    rowlen_hist_k<<<(unsigned)((n + BLK - 1) / BLK), BLK, 0, s>>>(n, src.ia.p, hist.p);
+    std::vector<int> hh(LEN_BINS);
+    MI_HIP(hipMemcpyAsync(hh.data(), hist.p, LEN_BINS * sizeof(int), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    const long long kth = (long long)((double)(n - 1) * 0.95);
+    long long run = 0;
+    for (int b = 0; b < LEN_BINS; b++) {
+      run += hh[(size_t)b];
+      if (run > kth) {
+        dst.rowlen_p95 = b;
+        break;
+      }
+    }
+  }
+  // greedy row-block schedule: sequential over the row pointers, on the host
+  std::vector<int64_t> hia((size_t)n + 1);
+  MI_HIP(hipMemcpyAsync(hia.data(), src.ia.p, ((size_t)n + 1) * sizeof(long long), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+  std::vector<int> blocks = k::build_row_blocks(n, hia.data());
+  std::vector<int64_t>().swap(hia);
+  dst.nblocks = (int)blocks.size() - 1;
+  dst.rb.upload(blocks);
+  dst.ja = std::move(src.ja);
+  dst.a = std::move(src.a);
+  static const int xc_min = getenv("MI_HYPRE_XCACHE_MIN") ? atoi(getenv("MI_HYPRE_XCACHE_MIN")) : 12;
+  dst.xcache = n > 0 && (double)dst.nnz / (double)n >= (double)xc_min;
+  if (dst.xcache) {
+    const int nb = dst.nblocks;
+    DVec<int> ucnt((size_t)nb), uslack((size_t)dst.nnz);
+    dst.lcol.alloc((size_t)dst.nnz);
+    MI_HIP(hipMemsetAsync(dst.lcol.p, 0, (size_t)dst.nnz * sizeof(unsigned short), s));
+    xcache_block_k<<<(unsigned)nb, BLK, 0, s>>>(nb, dst.rb.p, dst.ia.p, dst.ja.p, ucnt.p, uslack.p, dst.lcol.p);
+    DVec<long long> uptr64((size_t)nb + 1);
+    exclusive_scan(ucnt.p, uptr64.p, nb, s);
+    long long tot = 0;
+    MI_HIP(hipMemcpyAsync(&tot, uptr64.p + nb, sizeof(long long), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    dst.uptr.alloc((size_t)nb + 1);
+    dst.ucols.alloc((size_t)tot);
+    xcache_compact_k<<<(unsigned)nb, BLK, 0, s>>>(nb, dst.rb.p, dst.ia.p, uptr64.p, uslack.p, dst.uptr.p, dst.ucols.p);
+    MI_HIP(hipGetLastError());
+    MI_HIP(hipStreamSynchronize(s));
+  }
+  src.release();
+  MI_HIP(hipGetLastError());
+}
+
+void solve_format_to_host(const DevCSR &src, HostCSR &h, hipStream_t s) {
+  const int n = src.nrows;
+  h.nrows = n;
+  h.ncols = src.ncols;
+  h.ia.assign((size_t)n + 1, 0);
+  h.ja.resize((size_t)src.nnz);
+  h.a.resize((size_t)src.nnz);
+  if (src.ia.p) {
+    DVec<long long> ia64((size_t)n + 1);
+    ia_to_64_k<<<(unsigned)((n + 1 + BLK - 1) / BLK), BLK, 0, s>>>((long long)n + 1, src.ia.p, ia64.p);
+    MI_HIP(hipMemcpyAsync(h.ia.data(), ia64.p, ((size_t)n + 1) * sizeof(long long), hipMemcpyDeviceToHost, s));
+    if (src.nnz) {
+      MI_HIP(hipMemcpyAsync(h.ja.data(), src.ja.p, (size_t)src.nnz * sizeof(int), hipMemcpyDeviceToHost, s));
+      MI_HIP(hipMemcpyAsync(h.a.data(), src.a.p, (size_t)src.nnz * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    MI_HIP(hipStreamSynchronize(s));
+  }
+}
+
+void level_norms(const DCsr &A, const int *cf, int chunk, double *diag, double *l1gs, double *l1jac, hipStream_t s) {
+  const int n = A.nrows;
+  if (n == 0) return;
+  level_norms_k<<<(unsigned)((n + BLK - 1) / BLK), BLK, 0, s>>>(n, A.ia.p, A.ja.p, A.a.p, cf, chunk, diag, l1gs, l1jac);
+  MI_HIP(hipGetLastError());
+}
 
 void strength(const DCsr &A, double theta, double max_row_sum, DCsr &S, hipStream_t s) {
   const int n = A.nrows;

@@ -57,5 +57,16 @@ void transpose(const DCsr &A, DCsr &T, hipStream_t s);
 // columns mapped through colpos (null = identity) and re-sorted ascending
 void permute(const DCsr &A, const int *perm, const int *colpos, DCsr &B, hipStream_t s);
 
+// Solve-phase format of a setup-phase matrix, built on the device: 32-bit row pointers, the row-block
+// schedule and x cache of the SpMV (DevCSR::upload builds the same from host arrays).  src's column and
+// value arrays are MOVED into dst; only the row pointers travel to the host (for the greedy block schedule).
+void to_solve_format(DCsr &src, DevCSR &dst, hipStream_t s);
+// back to host arrays (lazy host copies for the inspection API)
+void solve_format_to_host(const DevCSR &src, HostCSR &h, hipStream_t s);
+
+// diagonal, l1 norm of the hybrid-GS chunks (option 4, C/F aware) and full l1 norm per row (level_norms in
+// amg_setup.cpp) of a single-rank operator; cf may be null
+void level_norms(const DCsr &A, const int *cf, int chunk, double *diag, double *l1gs, double *l1jac, hipStream_t s);
+
 }  // namespace sk
 }  // namespace mi
