@@ -855,11 +855,30 @@ __global__ __launch_bounds__(BLK) void ia_to_64_k(long long n1, const int *__res
 }
 
 constexpr int LEN_BINS = 4096;
+// every thread walks RUN consecutive rows and merges equal neighbours before it touches the (LDS) histogram:
+// uniform row lengths (stencil matrices) would otherwise serialise on one counter
+constexpr int HIST_RUN = 32;
 __global__ __launch_bounds__(BLK) void rowlen_hist_k(int n, const long long *__restrict__ ia, int *__restrict__ hist) {
-  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
-  if (i >= n) return;
-  const long long len = ia[i + 1] - ia[i];
-  atomicAdd(&hist[len >= LEN_BINS ? LEN_BINS - 1 : (int)len], 1);
+  __shared__ int sh[LEN_BINS];
+  for (int t = threadIdx.x; t < LEN_BINS; t += BLK) sh[t] = 0;
+  __syncthreads();
+  const long long r0 = ((long long)blockIdx.x * BLK + threadIdx.x) * HIST_RUN;
+  int cur = -1, cnt = 0;
+  for (long long i = r0; i < r0 + HIST_RUN && i < n; i++) {
+    const long long len = ia[i + 1] - ia[i];
+    const int b = len >= LEN_BINS ? LEN_BINS - 1 : (int)len;
+    if (b == cur) {
+      cnt++;
+    } else {
+      if (cnt) atomicAdd(&sh[cur], cnt);
+      cur = b;
+      cnt = 1;
+    }
+  }
+  if (cnt) atomicAdd(&sh[cur], cnt);
+  __syncthreads();
+  for (int t = threadIdx.x; t < LEN_BINS; t += BLK)
+    if (sh[t]) atomicAdd(&hist[t], sh[t]);
 }
 
 // x cache of one row block (spmv_stream_xc): sorted unique columns of the block's entries and the
@@ -1066,7 +1085,8 @@ void to_solve_format(DCsr &src, DevCSR &dst, hipStream_t s) {
   if (n) {
     DVec<int> hist(LEN_BINS);
     MI_HIP(hipMemsetAsync(hist.p, 0, LEN_BINS * sizeof(int), s));
-    rowlen_hist_k<<<(unsigned)((n + BLK - 1) / BLK), BLK, 0, s>>>(n, src.ia.p, hist.p);
+    rowlen_hist_k<<<(unsigned)(((long long)n + (long long)BLK * HIST_RUN - 1) / ((long long)BLK * HIST_RUN)), BLK, 0, s>>>(
+        n, src.ia.p, hist.p);
     std::vector<int> hh(LEN_BINS);
     MI_HIP(hipMemcpyAsync(hh.data(), hist.p, LEN_BINS * sizeof(int), hipMemcpyDeviceToHost, s));
     MI_HIP(hipStreamSynchronize(s));

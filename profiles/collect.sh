@@ -1,0 +1,23 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (through gpurun): kernel-trace statistics and, in separate passes, the two HBM
+# counters for the default bench workload (512^3).  Raw output lands in gpurun_out/prof_*; the summaries
+# under profiles/ are made afterwards by profiles/summarize.py.
+#   gpurun --timeout 1100 -- 'bash profiles/collect.sh stats'      (or: pmc)
+set -e
+cd "${GRAFT_REPO_ROOT:-.}"
+REPO=$(pwd)
+mkdir -p "$REPO/gpurun_out"
+export TMPDIR=/tmp
+mode=${1:-stats}
+cd /tmp
+if [ "$mode" = stats ]; then
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof_stats" -- \
+    python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu > "$REPO/gpurun_out/prof_stats.log" 2>&1
+else
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$REPO/gpurun_out/prof_fetch" -- \
+    python3 "$REPO/bench.py" --steps 1 --warmup 0 --no-cpu > "$REPO/gpurun_out/prof_fetch.log" 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$REPO/gpurun_out/prof_write" -- \
+    python3 "$REPO/bench.py" --steps 1 --warmup 0 --no-cpu > "$REPO/gpurun_out/prof_write.log" 2>&1
+fi
+find "$REPO/gpurun_out" -name "*.csv" -size +60M -delete   # keep the merge-back small
+ls -la "$REPO"/gpurun_out/prof_*/*/ 2>/dev/null | tail -20

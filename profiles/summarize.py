@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Summaries of the rocprofv3 output collected by profiles/collect.sh (run HERE, after gpurun merged the raw
+csv files back under gpurun_out/).
+
+  python profiles/summarize.py stats gpurun_out/prof_stats  profiles/rNN   -> rNN_bench512_kernel_stats.csv,
+                                                                              rNN_bench512_by_kernel_and_grid.txt
+  python profiles/summarize.py pmc gpurun_out/prof_fetch gpurun_out/prof_write profiles/rNN
+                                                                           -> rNN_pmc512_fetch_write.txt, traffic_rNN.json
+"""
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    m = re.search(r"namespace\)::([A-Za-z0-9_]+(<[^>]*>)?)", name)
+    if m:
+        return m.group(1)
+    return name.split("(")[0].replace("void ", "")
+
+
+def find(d, suffix):
+    f = sorted(glob.glob(os.path.join(d, "*", "*" + suffix)))
+    if not f:
+        raise SystemExit(f"no {suffix} under {d}")
+    return f[-1]
+
+
+def stats(src, out):
+    shutil.copy(find(src, "_kernel_stats.csv"), out + "_bench512_kernel_stats.csv")
+    rows = list(csv.DictReader(open(find(src, "_kernel_trace.csv"))))
+    agg = defaultdict(lambda: [0, 0.0])
+    total = 0.0
+    for r in rows:
+        dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        key = (short(r["Kernel_Name"]), int(r["Grid_Size"]) if "Grid_Size" in r else int(r["Grid_Size_X"]))
+        agg[key][0] += 1
+        agg[key][1] += dur
+        total += dur
+    with open(out + "_bench512_by_kernel_and_grid.txt", "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu\n")
+        f.write("#   (laplace_3d 512^3 7-pt, GMRES(50)+BoomerAMG, 1x MI355X; setup kernels + 3 solves in the trace)\n")
+        f.write("# per (kernel, grid size) = per AMG level: calls, mean us, total ms, share of GPU time\n")
+        f.write("# spmv_stream<0, 1> = the level-0 operator in the caller ordering (GMRES matvec): the kernel bench.py reports as \"roofline\"\n")
+        for (name, grid), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            if us / total < 2e-4:
+                continue
+            f.write(f"{name:28s} grid {grid:<10d} calls {n:5d}  mean {us / n:10.1f} us  total {us / 1e3:9.1f} ms  {100 * us / total:5.1f}%\n")
+    print("wrote", out + "_bench512_kernel_stats.csv", out + "_bench512_by_kernel_and_grid.txt")
+
+
+def counter_means(src, counter):
+    rows = list(csv.DictReader(open(find(src, "_counter_collection.csv"))))
+    agg = defaultdict(lambda: [0, 0.0])
+    for r in rows:
+        if r["Counter_Name"] != counter:
+            continue
+        key = (short(r["Kernel_Name"]), int(r["Grid_Size"]))
+        agg[key][0] += 1
+        agg[key][1] += float(r["Counter_Value"])
+    return {k: (n, v / n) for k, (n, v) in agg.items()}
+
+
+def pmc(fetch_dir, write_dir, out):
+    fe = counter_means(fetch_dir, "FETCH_SIZE")
+    wr = counter_means(write_dir, "WRITE_SIZE")
+    tag = os.path.basename(out)
+    lines = []
+    for key, (n, kb) in sorted(fe.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+        f_gb = kb * 1024 / 1e9
+        w_gb = wr.get(key, (0, 0.0))[1] * 1024 / 1e9
+        if n * f_gb < 0.5:
+            continue
+        lines.append(f"{key[0]:28s} grid {key[1]:<10d} n={n:4d}  FETCH_raw {f_gb:8.3f} GB  x2 {2 * f_gb:8.3f} GB  WRITE {w_gb:7.3f} GB")
+    with open(out + "_pmc512_fetch_write.txt", "w") as f:
+        f.write("# separate passes: rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv ... and --pmc WRITE_SIZE ...\n")
+        f.write("#   -- python3 bench.py --steps 1 --warmup 0 --no-cpu   (512^3 7-pt, 1x MI355X)\n")
+        f.write("# raw counter means per launch (KB*1024 -> GB).  gfx950: FETCH_SIZE reports 1/2 of a wide coalesced read\n")
+        f.write("# (MI355X_MICROARCH.md, HBM section): check it on axpy/scale kernels of known traffic below; WRITE_SIZE is exact.\n")
+        f.write("\n".join(lines) + "\n")
+    key = next(k for k in fe if k[0] == "spmv_stream<0, 1>")
+    fetch_raw = fe[key][1] * 1024
+    write = wr[key][1] * 1024
+    js = {"512^3/7pt/1gpu": {
+        "spmv_hbm_bytes_per_launch": 2 * fetch_raw + write,
+        "fetch_size_raw_bytes": fetch_raw,
+        "write_size_bytes": write,
+        "kernel": "spmv_stream<0, 1>",
+        "note": "FETCH_SIZE doubled per the gfx950 correction; separate --pmc passes; see profiles/%s_pmc512_fetch_write.txt" % tag}}
+    path = os.path.join(os.path.dirname(out), "traffic_%s.json" % tag)
+    json.dump(js, open(path, "w"), indent=1)
+    print("wrote", out + "_pmc512_fetch_write.txt", path)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3])
+    else:
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4])
