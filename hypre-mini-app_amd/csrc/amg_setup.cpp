@@ -1286,10 +1286,10 @@ void BoomerAMG::setup_device() {
     Lv.tmp.alloc((size_t)Lv.n);
     Lv.snap.alloc((size_t)Lv.n);
     if (Lv.n) {
-      MI_HIP(hipMemset(Lv.u.p, 0, (size_t)Lv.n * sizeof(double)));
-      MI_HIP(hipMemset(Lv.f.p, 0, (size_t)Lv.n * sizeof(double)));
-      MI_HIP(hipMemset(Lv.tmp.p, 0, (size_t)Lv.n * sizeof(double)));
-      MI_HIP(hipMemset(Lv.snap.p, 0, (size_t)Lv.n * sizeof(double)));
+      zero_on_stream(Lv.u.p, (size_t)Lv.n * sizeof(double));
+      zero_on_stream(Lv.f.p, (size_t)Lv.n * sizeof(double));
+      zero_on_stream(Lv.tmp.p, (size_t)Lv.n * sizeof(double));
+      zero_on_stream(Lv.snap.p, (size_t)Lv.n * sizeof(double));
     }
   }
   AmgLevel &Lc = L.back();
@@ -1298,8 +1298,8 @@ void BoomerAMG::setup_device() {
     Lc.Cinv.upload(Lc.Cinv_host);
     Lc.fgather.alloc(width);
     Lc.fslot.alloc((size_t)Lc.slot);
-    MI_HIP(hipMemset(Lc.fslot.p, 0, ((size_t)Lc.slot + 2) * sizeof(double)));
-    MI_HIP(hipMemset(Lc.fgather.p, 0, (width + 2) * sizeof(double)));
+    zero_on_stream(Lc.fslot.p, ((size_t)Lc.slot + 2) * sizeof(double));
+    zero_on_stream(Lc.fgather.p, (width + 2) * sizeof(double));
   }
   MI_HIP(hipDeviceSynchronize());
   is_setup = true;

@@ -267,9 +267,10 @@ void *hypre_MAlloc(size_t bytes, HYPRE_MemoryLocation loc) {
 void *hypre_CAlloc(size_t count, size_t elt, HYPRE_MemoryLocation loc) {
   void *p = hypre_MAlloc(count * elt, loc);
   if (!p) return p;
-  if (loc == HYPRE_MEMORY_DEVICE)
+  if (loc == HYPRE_MEMORY_DEVICE) {
     (void)hipMemset(p, 0, count * elt);
-  else
+    (void)hipDeviceSynchronize();  // the caller may hand the buffer to any stream next
+  } else
     memset(p, 0, count * elt);
   return p;
 }
@@ -282,6 +283,7 @@ void hypre_Free(void *ptr, HYPRE_MemoryLocation loc) {
 }
 void hypre_Memcpy(void *dst, const void *src, size_t bytes, HYPRE_MemoryLocation, HYPRE_MemoryLocation) {
   if (!bytes) return;
+  if (ctx().inited) (void)hipStreamSynchronize(ctx().stream);  // library kernels may still be producing src
   if (hipMemcpy(dst, src, bytes, hipMemcpyDefault) != hipSuccess)
     record_error(HYPRE_ERROR_GENERIC, "hypre_Memcpy failed");
 }
@@ -579,7 +581,10 @@ HYPRE_Int HYPRE_IJVectorPrint(HYPRE_IJVector vector, const char *filename) {
   IJVectorObj *v = V(vector);
   if (!v || !v->initialized) fail(HYPRE_ERROR_GENERIC, "IJVectorPrint: vector not initialised");
   std::vector<double> h((size_t)v->par.n);
-  if (v->par.n) MI_HIP(hipMemcpy(h.data(), v->par.data(), h.size() * sizeof(double), hipMemcpyDeviceToHost));
+  if (v->par.n) {
+    MI_HIP(hipStreamSynchronize(ctx().stream));  // blocking copies are not ordered against the library stream
+    MI_HIP(hipMemcpy(h.data(), v->par.data(), h.size() * sizeof(double), hipMemcpyDeviceToHost));
+  }
   char fn[2048];
   snprintf(fn, sizeof(fn), "%s.%05d", filename, current_comm().rank);
   FILE *fp = fopen(fn, "w");
@@ -1225,6 +1230,7 @@ HYPRE_Int HYPRE_MI_BoomerAMGRelaxLevel(HYPRE_Solver solver, HYPRE_Int level, HYP
   DVec<double> f((size_t)n);
   if (n) {
     f.upload(f_host, (size_t)n);
+    MI_HIP(hipStreamSynchronize(ctx().stream));
     MI_HIP(hipMemcpy(Lv.u.p, u_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
   }
   a->amg.relax(level, relax_type, points, f.p);

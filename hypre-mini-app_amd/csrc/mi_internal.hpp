@@ -65,7 +65,10 @@ struct DVec {
     release();
     n = n_;
     MI_HIP(hipMalloc((void **)&p, (n + pad) * sizeof(T)));
-    if (pad) MI_HIP(hipMemset((void *)(p + n), 0, pad * sizeof(T)));
+    if (pad) {  // finished before any stream can touch the allocation
+      MI_HIP(hipMemsetAsync((void *)(p + n), 0, pad * sizeof(T), nullptr));
+      MI_HIP(hipStreamSynchronize(nullptr));
+    }
   }
   void upload(const T *h, size_t cnt) { MI_HIP(hipMemcpy(p, h, cnt * sizeof(T), hipMemcpyHostToDevice)); }
   void upload(const std::vector<T> &h) {
@@ -193,6 +196,9 @@ struct Ctx {
 };
 Ctx &ctx();
 void ensure_init();
+// zero device memory in order with the library stream (hipMemset on the null stream is not: the library
+// stream is non-blocking)
+void zero_on_stream(void *p, size_t bytes);
 Comm &current_comm();  // never needs a device (self comm by default)
 
 // ---------------------------------------------------------------- small helpers

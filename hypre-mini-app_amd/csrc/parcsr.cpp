@@ -25,7 +25,9 @@ void ParVector::init(gidx s, gidx e, int nc) {
   ncomp = nc < 1 ? 1 : nc;
   cur = 0;
   d.alloc((size_t)n * ncomp);
-  if (n) MI_HIP(hipMemset(d.p, 0, (size_t)n * ncomp * sizeof(double)));
+  // stream-ordered: a null-stream memset is NOT ordered against the library's non-blocking stream and could
+  // land after the first kernel that writes this vector (GMRES creates its basis vectors inside the solve)
+  if (n) zero_on_stream(d.p, (size_t)n * ncomp * sizeof(double));
 }
 
 // ------------------------------------------------------------------ IJ assembly
@@ -228,7 +230,7 @@ void ParCSR::to_device_halo() {
   halo.d_xext.alloc(col_map_offd.size());
   if (!col_map_offd.empty()) {
     d_offc.alloc((size_t)nrows);
-    MI_HIP(hipMemset(d_offc.p, 0, (size_t)nrows * sizeof(double)));
+    zero_on_stream(d_offc.p, (size_t)nrows * sizeof(double));
   }
   on_device = true;
 }

@@ -61,6 +61,12 @@ void parallel_for(int64_t n, const std::function<void(int64_t, int64_t, int)> &f
     if (e) std::rethrow_exception(e);
 }
 
+void zero_on_stream(void *p, size_t bytes) {
+  if (!p || !bytes) return;
+  ensure_init();
+  MI_HIP(hipMemsetAsync(p, 0, bytes, ctx().stream));
+}
+
 // The product path has no CPU fallback: without a HIP device every entry point
 // fails loudly here.
 void ensure_init() {
