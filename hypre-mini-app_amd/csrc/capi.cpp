@@ -851,6 +851,7 @@ KRYLOV_COMMON(GMRES, GM)
 KRYLOV_COMMON(BiCGSTAB, BI)
 KRYLOV_COMMON(FlexGMRES, GM)
 KRYLOV_COMMON(PCG, PC)
+KRYLOV_COMMON(COGMRES, GM)
 #undef KRYLOV_COMMON
 HYPRE_Int HYPRE_ParCSRGMRESSetCGS(HYPRE_Solver solver, HYPRE_Int) {
   API_BEGIN(void) GM(solver);
@@ -890,7 +891,13 @@ HYPRE_Int HYPRE_ParCSRGMRESSetCGS(HYPRE_Solver solver, HYPRE_Int) {
   }
 KRYLOV_LIFECYCLE(FlexGMRES, GmresSolver, GM, obj->flexible = true)
 KRYLOV_LIFECYCLE(PCG, PcgSolver, PC, (void)obj)
+KRYLOV_LIFECYCLE(COGMRES, GmresSolver, GM, obj->ortho = 1)
 #undef KRYLOV_LIFECYCLE
+// cgs <= 1: one classical Gram-Schmidt pass per Arnoldi step, cgs >= 2: two
+HYPRE_Int HYPRE_ParCSRCOGMRESSetCGS(HYPRE_Solver solver, HYPRE_Int cgs) {
+  API_BEGIN GM(solver)->ortho = (cgs >= 2) ? 2 : 1;
+  API_END
+}
 HYPRE_Int HYPRE_ParCSRPCGSetTwoNorm(HYPRE_Solver solver, HYPRE_Int two_norm) {
   API_BEGIN PC(solver)->two_norm = two_norm;
   API_END
@@ -925,33 +932,6 @@ HYPRE_Int HYPRE_ParCSRBiCGSTABSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, H
 }
 
 // ------------------------------------------------------------------ stubs
-#define KRYLOV_STUB(NAME)                                                                                       \
-  HYPRE_Int HYPRE_ParCSR##NAME##Create(MPI_Comm, HYPRE_Solver *solver) {                                        \
-    API_BEGIN *solver = reinterpret_cast<HYPRE_Solver>(static_cast<SolverBase *>(new StubSolver(#NAME)));       \
-    API_END                                                                                                     \
-  }                                                                                                             \
-  HYPRE_Int HYPRE_ParCSR##NAME##Destroy(HYPRE_Solver solver) {                                                  \
-    API_BEGIN delete S(solver);                                                                                 \
-    API_END                                                                                                     \
-  }                                                                                                             \
-  HYPRE_Int HYPRE_ParCSR##NAME##Setup(HYPRE_Solver, HYPRE_ParCSRMatrix, HYPRE_ParVector, HYPRE_ParVector) {     \
-    return stub_fail("HYPRE_ParCSR" #NAME);                                                                     \
-  }                                                                                                             \
-  HYPRE_Int HYPRE_ParCSR##NAME##Solve(HYPRE_Solver, HYPRE_ParCSRMatrix, HYPRE_ParVector, HYPRE_ParVector) {     \
-    return stub_fail("HYPRE_ParCSR" #NAME);                                                                     \
-  }                                                                                                             \
-  HYPRE_Int HYPRE_ParCSR##NAME##SetPrecond(HYPRE_Solver, HYPRE_PtrToParSolverFcn, HYPRE_PtrToParSolverFcn,      \
-                                           HYPRE_Solver) {                                                      \
-    return 0;                                                                                                   \
-  }                                                                                                             \
-  HYPRE_Int HYPRE_ParCSR##NAME##SetTol(HYPRE_Solver, HYPRE_Real) { return 0; }                                  \
-  HYPRE_Int HYPRE_ParCSR##NAME##SetMaxIter(HYPRE_Solver, HYPRE_Int) { return 0; }                               \
-  HYPRE_Int HYPRE_ParCSR##NAME##SetKDim(HYPRE_Solver, HYPRE_Int) { return 0; }                                  \
-  HYPRE_Int HYPRE_ParCSR##NAME##SetPrintLevel(HYPRE_Solver, HYPRE_Int) { return 0; }
-KRYLOV_STUB(COGMRES)
-#undef KRYLOV_STUB
-HYPRE_Int HYPRE_ParCSRCOGMRESSetCGS(HYPRE_Solver, HYPRE_Int) { return 0; }
-
 HYPRE_Int HYPRE_ILUCreate(HYPRE_Solver *solver) {
   API_BEGIN *solver = reinterpret_cast<HYPRE_Solver>(static_cast<SolverBase *>(new StubSolver("ILU")));
   API_END

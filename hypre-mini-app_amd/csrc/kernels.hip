@@ -495,6 +495,87 @@ __global__ __launch_bounds__(256) void reduce_final_k(const double *__restrict__
   if (tid == 0) out[0] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
 }
 
+
+// ---- block Gram-Schmidt pieces of COGMRES: up to MASS_NV inner products off one vector in one pass, and the
+// matching block update.  The per-thread accumulation pattern is dot_partial_k's, so every result equals the
+// separate dot's bit for bit; the update adds the terms in ascending j like repeated axpys.
+struct MassPtrs {
+  const double *p[MASS_NV];
+};
+
+__global__ __launch_bounds__(256) void mass_dot_partial_k(MassPtrs P, int m, const double *__restrict__ w, int n,
+                                                          double *__restrict__ partials) {
+  __shared__ double ws[MASS_NV][4];
+  const int tid = threadIdx.x;
+  double acc[MASS_NV];
+#pragma unroll
+  for (int j = 0; j < MASS_NV; j++) acc[j] = 0.0;
+  const long long stride = (long long)gridDim.x * 512;
+  long long i = ((long long)blockIdx.x * 256 + tid) * 2;
+  for (; i + 1 < n; i += stride) {
+    const double2 b = *reinterpret_cast<const double2 *>(w + i);
+#pragma unroll
+    for (int j = 0; j < MASS_NV; j++)
+      if (j < m) {
+        const double2 a = *reinterpret_cast<const double2 *>(P.p[j] + i);
+        acc[j] += a.x * b.x + a.y * b.y;
+      }
+  }
+  if (i < n) {
+#pragma unroll
+    for (int j = 0; j < MASS_NV; j++)
+      if (j < m) acc[j] += P.p[j][i] * w[i];
+  }
+#pragma unroll
+  for (int j = 0; j < MASS_NV; j++) {
+    const double v = wave_sum(acc[j]);
+    if ((tid & 63) == 0) ws[j][tid >> 6] = v;
+  }
+  __syncthreads();
+  if (tid < m) partials[(size_t)tid * RED_MAX_BLOCKS + blockIdx.x] = (ws[tid][0] + ws[tid][1]) + (ws[tid][2] + ws[tid][3]);
+}
+
+__global__ __launch_bounds__(256) void reduce_final_multi_k(const double *__restrict__ partials, int nb,
+                                                            double *__restrict__ out) {
+  __shared__ double ws[4];
+  const int tid = threadIdx.x;
+  const double *mine = partials + (size_t)blockIdx.x * RED_MAX_BLOCKS;
+  double s = 0.0;
+  for (int i = tid; i < nb; i += 256) s += mine[i];
+  s = wave_sum(s);
+  if ((tid & 63) == 0) ws[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) out[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+// w += sum_j (scale * coef[j]) * p_j, terms added in ascending j
+__global__ __launch_bounds__(256) void mass_axpy_k(MassPtrs P, int m, const double *__restrict__ coef, double scale,
+                                                   double *__restrict__ w, int n) {
+  double c[MASS_NV];
+#pragma unroll
+  for (int j = 0; j < MASS_NV; j++) c[j] = (j < m) ? scale * coef[j] : 0.0;
+  const long long stride = (long long)gridDim.x * 512;
+  long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 2;
+  for (; i + 1 < n; i += stride) {
+    double2 wv = *reinterpret_cast<double2 *>(w + i);
+#pragma unroll
+    for (int j = 0; j < MASS_NV; j++)
+      if (j < m) {
+        const double2 a = *reinterpret_cast<const double2 *>(P.p[j] + i);
+        wv.x += c[j] * a.x;
+        wv.y += c[j] * a.y;
+      }
+    *reinterpret_cast<double2 *>(w + i) = wv;
+  }
+  if (i < n) {
+    double v = w[i];
+#pragma unroll
+    for (int j = 0; j < MASS_NV; j++)
+      if (j < m) v += c[j] * P.p[j][i];
+    w[i] = v;
+  }
+}
+
 // y += (scale * (alpha_dev ? *alpha_dev : 1)) * x
 __global__ __launch_bounds__(256) void axpy_k(const double *__restrict__ alpha_dev, double scale,
                                               const double *__restrict__ x, double *__restrict__ y, int n) {
@@ -734,6 +815,35 @@ void axpy_dot(const double *alpha_dev, double scale_, const double *xa, double *
   hipLaunchKernelGGL(axpy_dot_partial_k, dim3(g), dim3(256), 0, s, alpha_dev, scale_, xa, y, xd, n, partials);
   hipLaunchKernelGGL(reduce_final_k, dim3(1), dim3(256), 0, s, partials, g, out_dev);
   prof_end(PROF_DOT, s);
+  MI_HIP(hipGetLastError());
+}
+
+void mass_dot(const double *const *vecs, int m, const double *w, int n, double *out_dev, hipStream_t s) {
+  const int g = vec_grid(n);
+  double *partials = ctx().red_partials.p;
+  prof_begin(PROF_DOT, s);
+  for (int j0 = 0; j0 < m; j0 += MASS_NV) {
+    const int mm = std::min(MASS_NV, m - j0);
+    MassPtrs P;
+    for (int j = 0; j < MASS_NV; j++) P.p[j] = vecs[j0 + (j < mm ? j : 0)];
+    hipLaunchKernelGGL(mass_dot_partial_k, dim3(g), dim3(256), 0, s, P, mm, w, n, partials);
+    hipLaunchKernelGGL(reduce_final_multi_k, dim3(mm), dim3(256), 0, s, partials, g, out_dev + j0);
+  }
+  prof_end(PROF_DOT, s);
+  MI_HIP(hipGetLastError());
+}
+
+void mass_axpy(const double *const *vecs, int m, const double *coef_dev, double scale_, double *w, int n,
+               hipStream_t s) {
+  if (n == 0) return;
+  prof_begin(PROF_AXPY, s);
+  for (int j0 = 0; j0 < m; j0 += MASS_NV) {
+    const int mm = std::min(MASS_NV, m - j0);
+    MassPtrs P;
+    for (int j = 0; j < MASS_NV; j++) P.p[j] = vecs[j0 + (j < mm ? j : 0)];
+    hipLaunchKernelGGL(mass_axpy_k, dim3(vec_grid(n)), dim3(256), 0, s, P, mm, coef_dev + j0, scale_, w, n);
+  }
+  prof_end(PROF_AXPY, s);
   MI_HIP(hipGetLastError());
 }
 

@@ -9,6 +9,7 @@ namespace k {
 constexpr int SPMV_BLOCK = 256;   // threads per workgroup (4 wave64)
 constexpr int SPMV_TILE = 2048;   // LDS-staged products per workgroup
 constexpr int RED_MAX_BLOCKS = 2048;
+constexpr int MASS_NV = 8;        // vectors per pass of the block inner product / block update
 constexpr int GS_BLOCK = 256;     // chunks (lanes) per workgroup
 constexpr int GS_MAX_CHUNK = 32;
 
@@ -46,6 +47,9 @@ void dot(const double *x, const double *y, int n, double *out_dev, hipStream_t s
 // fused MGS step: y += scale*(*alpha_dev)*xa, then out_dev = <xd, y> (xd == nullptr: <y, y>), local sum
 void axpy_dot(const double *alpha_dev, double scale, const double *xa, double *y, const double *xd, int n,
               double *out_dev, hipStream_t s);
+// block Gram-Schmidt (COGMRES): out_dev[j] = <vecs[j], w> for j < m (local sums), and w += scale * sum_j coef_dev[j] vecs[j]
+void mass_dot(const double *const *vecs, int m, const double *w, int n, double *out_dev, hipStream_t s);
+void mass_axpy(const double *const *vecs, int m, const double *coef_dev, double scale, double *w, int n, hipStream_t s);
 void axpy(double alpha, const double *x, double *y, int n, hipStream_t s);
 void axpy_dev(const double *alpha_dev, double scale, const double *x, double *y, int n, hipStream_t s);
 void scale(double alpha, double *x, int n, hipStream_t s);

@@ -43,7 +43,8 @@ int GmresSolver::solve(ParCSR &A, ParVector &b, ParVector &x) {
   const double t_start = wall_time();
   const int n = b.n;
   const int kd = k_dim < 1 ? 1 : k_dim;
-  MI_REQUIRE(kd + 2 <= 250, "GMRES: k_dim too large for the device scalar slots");
+  MI_REQUIRE(kd + 2 <= (ortho > 1 ? 120 : 250), "GMRES: k_dim too large for the device scalar slots");
+  MI_REQUIRE(ortho >= 0 && ortho <= 2, "GMRES: orthogonalisation must be 0 (MGS), 1 or 2 (classical passes)");
   if (r.n != n) setup(A, b, x);
   const double epsmac = 1.e-16;
   auto basis = [&](int i) -> ParVector & {
@@ -109,18 +110,43 @@ int GmresSolver::solve(ParCSR &A, ParVector &b, ParVector &x) {
       ParVector &dir = flexible ? zvec(i - 1) : r;  // M^-1 p_{i-1}
       apply_precond(A, pim1, dir);
       A.matvec(comm, 1.0, dir.data(), 0.0, nullptr, pi.data(), s, k::PROF_SPMV_L0);
-      // modified Gram-Schmidt with the axpy of step j-1 fused into the dot of step j
-      // (and the last axpy into the norm): h_j = <p_j, w>, w -= h_j p_j, one pass each
-      par_dot(comm, basis(0).data(), pi.data(), n, slots, s);
-      for (int j = 1; j <= i; j++) {
-        k::axpy_dot(slots + j - 1, -1.0, basis(j - 1).data(), pi.data(), j < i ? basis(j).data() : nullptr, n,
-                    slots + j, s);
-        if (comm.size > 1) comm.allreduce_dev(slots + j, 1, CommDType::F64, CommOp::SUM, s);
+      if (ortho == 0) {
+        // modified Gram-Schmidt with the axpy of step j-1 fused into the dot of step j
+        // (and the last axpy into the norm): h_j = <p_j, w>, w -= h_j p_j, one pass each
+        par_dot(comm, basis(0).data(), pi.data(), n, slots, s);
+        for (int j = 1; j <= i; j++) {
+          k::axpy_dot(slots + j - 1, -1.0, basis(j - 1).data(), pi.data(), j < i ? basis(j).data() : nullptr, n,
+                      slots + j, s);
+          if (comm.size > 1) comm.allreduce_dev(slots + j, 1, CommDType::F64, CommOp::SUM, s);
+        }
+        k::scale_inv_sqrt_dev(slots + i, pi.data(), n, s);
+        MI_HIP(hipMemcpyAsync(c.h_pinned, slots, (size_t)(i + 1) * sizeof(double), hipMemcpyDeviceToHost, s));
+        MI_HIP(hipStreamSynchronize(s));
+        for (int j = 0; j < i; j++) hh[(size_t)j][(size_t)i - 1] = c.h_pinned[j];
+      } else {
+        // classical Gram-Schmidt: per pass ONE block of inner products (one all-reduce of i values) and one
+        // block update; coefficients of the passes add up.  Slots: pass q at [128 q, 128 q + i), norm^2 at [i].
+        std::vector<const double *> vecs((size_t)i);
+        for (int j = 0; j < i; j++) vecs[(size_t)j] = basis(j).data();
+        for (int q = 0; q < ortho; q++) {
+          double *cs_dev = slots + 128 * q;
+          k::mass_dot(vecs.data(), i, pi.data(), n, cs_dev, s);
+          if (comm.size > 1) comm.allreduce_dev(cs_dev, (size_t)i, CommDType::F64, CommOp::SUM, s);
+          k::mass_axpy(vecs.data(), i, cs_dev, -1.0, pi.data(), n, s);
+        }
+        double *nrm = (ortho == 1) ? slots + i : slots + 128 + i;  // adjacent to the last pass: one copy below
+        par_dot(comm, pi.data(), pi.data(), n, nrm, s);
+        k::scale_inv_sqrt_dev(nrm, pi.data(), n, s);
+        MI_HIP(hipMemcpyAsync(c.h_pinned, slots, (size_t)(128 * (ortho - 1) + i + 1) * sizeof(double),
+                              hipMemcpyDeviceToHost, s));
+        MI_HIP(hipStreamSynchronize(s));
+        for (int j = 0; j < i; j++) {
+          double hsum = c.h_pinned[j];
+          if (ortho > 1) hsum += c.h_pinned[128 + j];
+          hh[(size_t)j][(size_t)i - 1] = hsum;
+        }
+        c.h_pinned[i] = c.h_pinned[128 * (ortho - 1) + i];
       }
-      k::scale_inv_sqrt_dev(slots + i, pi.data(), n, s);
-      MI_HIP(hipMemcpyAsync(c.h_pinned, slots, (size_t)(i + 1) * sizeof(double), hipMemcpyDeviceToHost, s));
-      MI_HIP(hipStreamSynchronize(s));
-      for (int j = 0; j < i; j++) hh[(size_t)j][(size_t)i - 1] = c.h_pinned[j];
       const double t = std::sqrt(c.h_pinned[i] > 0.0 ? c.h_pinned[i] : 0.0);
       hh[(size_t)i][(size_t)i - 1] = t;
       for (int j = 1; j < i; j++) {

@@ -78,7 +78,7 @@ void ensure_init() {
     fail(1, "mi_hypre: no HIP device available (this library has no CPU path; it needs an MI355X/gfx950 GPU)");
   MI_HIP(hipGetDevice(&c.device));
   MI_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-  c.red_partials.alloc((size_t)k::RED_MAX_BLOCKS);
+  c.red_partials.alloc((size_t)k::RED_MAX_BLOCKS * k::MASS_NV);
   c.red_out.alloc(256);
   MI_HIP(hipHostMalloc((void **)&c.h_pinned, 256 * sizeof(double), hipHostMallocDefault));
   if (!c.comm) c.comm = make_self_comm();

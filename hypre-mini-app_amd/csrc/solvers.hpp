@@ -37,6 +37,10 @@ struct GmresSolver : KrylovSolver {
   // FlexGMRES (krylov/flexgmres.c): the preconditioned directions z_j = M^-1 p_j are kept and the
   // update is x += sum y_j z_j (no extra preconditioner call); the restart residual is recomputed
   bool flexible = false;
+  // orthogonalisation: 0 modified Gram-Schmidt (GMRES, FlexGMRES); 1 / 2 = classical Gram-Schmidt with one /
+  // two passes, every pass one block of inner products (ONE all-reduce) and one block update (COGMRES,
+  // krylov/cogmres.c; src/HypreSystem.cpp:372-388)
+  int ortho = 0;
   std::vector<std::unique_ptr<ParVector>> z;
   ParVector r, w;
   GmresSolver() : KrylovSolver(K_GMRES) {}
@@ -60,8 +64,7 @@ struct PcgSolver : KrylovSolver {
   int solve(ParCSR &A, ParVector &b, ParVector &x);
 };
 
-// placeholder for solver families outside the north-star path (ILU, PCG,
-// FlexGMRES, COGMRES): every call reports HYPRE_ERROR_GENERIC
+// placeholder for solver families outside the north-star path (ILU): every call reports HYPRE_ERROR_GENERIC
 struct StubSolver : SolverBase {
   std::string family;
   explicit StubSolver(const char *f) : SolverBase(K_STUB), family(f) {}

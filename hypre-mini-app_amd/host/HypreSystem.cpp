@@ -454,7 +454,7 @@ void HypreSystem::setup_bicg() {
   solverResPtr_ = &HYPRE_ParCSRBiCGSTABGetFinalRelativeResidualNorm;
 }
 
-// /root/reference/src/HypreSystem.cpp:372-388 (COGMRES: stub family), :406-421 (FlexGMRES), :440-455 (PCG)
+// /root/reference/src/HypreSystem.cpp:372-388 (COGMRES), :406-421 (FlexGMRES), :440-455 (PCG)
 #define MI_SETUP_STUB(FUNC, NAME, ITERS, RES)                                                \
   void HypreSystem::FUNC() {                                                                 \
     YAML::Node node = inpfile_["solver_settings"];                                           \
@@ -469,10 +469,25 @@ void HypreSystem::setup_bicg() {
     solverItersPtr_ = ITERS;                                                                 \
     solverResPtr_ = RES;                                                                     \
   }
-MI_SETUP_STUB(setup_cogmres, COGMRES, nullptr, nullptr)
 MI_SETUP_STUB(setup_fgmres, FlexGMRES, &HYPRE_ParCSRFlexGMRESGetNumIterations, &HYPRE_ParCSRFlexGMRESGetFinalRelativeResidualNorm)
 MI_SETUP_STUB(setup_cg, PCG, &HYPRE_ParCSRPCGGetNumIterations, &HYPRE_ParCSRPCGGetFinalRelativeResidualNorm)
 #undef MI_SETUP_STUB
+
+void HypreSystem::setup_cogmres() {
+  YAML::Node node = inpfile_["solver_settings"];
+  HYPRE_ParCSRCOGMRESCreate(comm_, &solver_);
+  HYPRE_ParCSRCOGMRESSetTol(solver_, get_optional(node, "tolerance", 1.0e-5));
+  HYPRE_ParCSRCOGMRESSetMaxIter(solver_, get_optional(node, "max_iterations", 1000));
+  HYPRE_ParCSRCOGMRESSetKDim(solver_, get_optional(node, "kspace", 10));
+  HYPRE_ParCSRCOGMRESSetPrintLevel(solver_, get_optional(node, "print_level", 4));
+  HYPRE_ParCSRCOGMRESSetCGS(solver_, get_optional(node, "cgs", 0));
+  solverDestroyPtr_ = &HYPRE_ParCSRCOGMRESDestroy;
+  solverSetupPtr_ = &HYPRE_ParCSRCOGMRESSetup;
+  solverPrecondPtr_ = &HYPRE_ParCSRCOGMRESSetPrecond;
+  solverSolvePtr_ = &HYPRE_ParCSRCOGMRESSolve;
+  solverItersPtr_ = &HYPRE_ParCSRCOGMRESGetNumIterations;
+  solverResPtr_ = &HYPRE_ParCSRCOGMRESGetFinalRelativeResidualNorm;
+}
 
 // /root/reference/src/HypreSystem.cpp:499-523
 void HypreSystem::destroy_system() {

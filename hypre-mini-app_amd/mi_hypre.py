@@ -404,6 +404,10 @@ class PCG(_Krylov):
     prefix = "HYPRE_ParCSRPCG"
 
 
+class COGMRES(_Krylov):
+    prefix = "HYPRE_ParCSRCOGMRES"
+
+
 def laplace3d(nx, ny, nz, stencil, ilower, iupper):
     """Synthetic COO triples + rhs for global rows [ilower, iupper] (library-side generator)."""
     nnz = c_big()

@@ -103,9 +103,8 @@ HYPRE_Int HYPRE_ParCSRBiCGSTABSetLogging(HYPRE_Solver solver, HYPRE_Int logging)
 HYPRE_Int HYPRE_ParCSRBiCGSTABGetNumIterations(HYPRE_Solver solver, HYPRE_Int *num_iterations);
 HYPRE_Int HYPRE_ParCSRBiCGSTABGetFinalRelativeResidualNorm(HYPRE_Solver solver, HYPRE_Real *norm);
 
-/* ---------------------------------------------------------------- out-of-scope families
- * (SURVEY.md 2.1 row 3, 8f rank f4): exported so the driver links; Create hands
- * back a handle, Set* are accepted, Setup/Solve return HYPRE_ERROR_GENERIC. */
+/* ---------------------------------------------------------------- further Krylov families;
+ * ILU further down is the one family that is still a stub (Setup/Solve return HYPRE_ERROR_GENERIC) */
 #define MI_HYPRE_DECLARE_KRYLOV_STUB(NAME)                                                                           \
   HYPRE_Int HYPRE_ParCSR##NAME##Create(MPI_Comm comm, HYPRE_Solver *solver);                                         \
   HYPRE_Int HYPRE_ParCSR##NAME##Destroy(HYPRE_Solver solver);                                                        \
@@ -117,9 +116,11 @@ HYPRE_Int HYPRE_ParCSRBiCGSTABGetFinalRelativeResidualNorm(HYPRE_Solver solver, 
   HYPRE_Int HYPRE_ParCSR##NAME##SetMaxIter(HYPRE_Solver solver, HYPRE_Int max_iter);                                 \
   HYPRE_Int HYPRE_ParCSR##NAME##SetKDim(HYPRE_Solver solver, HYPRE_Int k_dim);                                       \
   HYPRE_Int HYPRE_ParCSR##NAME##SetPrintLevel(HYPRE_Solver solver, HYPRE_Int print_level);
-MI_HYPRE_DECLARE_KRYLOV_STUB(COGMRES)  /* src/HypreSystem.cpp:372-388: stub */
 /* implemented: FlexGMRES = GMRES that keeps z_j = M^-1 p_j (krylov/flexgmres.c),
- * PCG = preconditioned conjugate gradients (krylov/pcg.c) */
+ * PCG = preconditioned conjugate gradients (krylov/pcg.c), COGMRES = the GMRES skeleton with classical
+ * Gram-Schmidt in block form: one block of inner products (one all-reduce) + one block update per pass
+ * (krylov/cogmres.c); SetCGS(cgs): cgs <= 1 one pass, cgs >= 2 two passes */
+MI_HYPRE_DECLARE_KRYLOV_STUB(COGMRES)  /* src/HypreSystem.cpp:372-388 */
 MI_HYPRE_DECLARE_KRYLOV_STUB(FlexGMRES) /* :406-421 */
 MI_HYPRE_DECLARE_KRYLOV_STUB(PCG)      /* :440-455 */
 HYPRE_Int HYPRE_ParCSRFlexGMRESSetAbsoluteTol(HYPRE_Solver solver, HYPRE_Real a_tol);
@@ -134,6 +135,11 @@ HYPRE_Int HYPRE_ParCSRPCGSetTwoNorm(HYPRE_Solver solver, HYPRE_Int two_norm);
 HYPRE_Int HYPRE_ParCSRPCGGetNumIterations(HYPRE_Solver solver, HYPRE_Int *num_iterations);
 HYPRE_Int HYPRE_ParCSRPCGGetFinalRelativeResidualNorm(HYPRE_Solver solver, HYPRE_Real *norm);
 HYPRE_Int HYPRE_ParCSRCOGMRESSetCGS(HYPRE_Solver solver, HYPRE_Int cgs);                /* :382 */
+HYPRE_Int HYPRE_ParCSRCOGMRESSetAbsoluteTol(HYPRE_Solver solver, HYPRE_Real a_tol);
+HYPRE_Int HYPRE_ParCSRCOGMRESSetMinIter(HYPRE_Solver solver, HYPRE_Int min_iter);
+HYPRE_Int HYPRE_ParCSRCOGMRESSetLogging(HYPRE_Solver solver, HYPRE_Int logging);
+HYPRE_Int HYPRE_ParCSRCOGMRESGetNumIterations(HYPRE_Solver solver, HYPRE_Int *num_iterations);
+HYPRE_Int HYPRE_ParCSRCOGMRESGetFinalRelativeResidualNorm(HYPRE_Solver solver, HYPRE_Real *norm);
 
 /* ILU (src/HypreSystem.cpp:328-370, :457-497) */
 HYPRE_Int HYPRE_ILUCreate(HYPRE_Solver *solver);

@@ -1114,7 +1114,7 @@ void oamg_precond(void *ctx, const double *r, double *z) {
 /* hypre_GMRESSolve (krylov/gmres.c); called through solverSolvePtr_
  * at src/HypreSystem.cpp:723 with tol/max_iter/k_dim from :393-397, x0 = 0 (:580). */
 static void gmres_core(const ocsr *A, const double *b, double *x, int kdim, double tol, double atol, int maxit,
-                       oprecond_fn M, void *Mctx, okrylov_result *res, double *norms, int flexible) {
+                       oprecond_fn M, void *Mctx, okrylov_result *res, double *norms, int flexible, int ortho) {
   const int n = A->nrows;
   const double epsmac = 1.e-16;
   double **p = (double **)xmalloc(sizeof(double *) * ((size_t)kdim + 1));
@@ -1167,9 +1167,20 @@ static void gmres_core(const ocsr *A, const double *b, double *x, int kdim, doub
       else
         memcpy(dir, p[i - 1], sizeof(double) * (size_t)n);
       ocsr_matvec(1.0, A, dir, 0.0, NULL, p[i]);
-      for (int j = 0; j < i; j++) {
-        hh[j][i - 1] = vdot(p[j], p[i], n);
-        vaxpy(-hh[j][i - 1], p[j], p[i], n);
+      if (ortho == 0) { /* modified Gram-Schmidt (krylov/gmres.c) */
+        for (int j = 0; j < i; j++) {
+          hh[j][i - 1] = vdot(p[j], p[i], n);
+          vaxpy(-hh[j][i - 1], p[j], p[i], n);
+        }
+      } else { /* classical Gram-Schmidt, ortho passes: all inner products off the same vector, then the update */
+        double *hv = (double *)xcalloc((size_t)i, sizeof(double));
+        for (int j = 0; j < i; j++) hh[j][i - 1] = 0.0;
+        for (int pass = 0; pass < ortho; pass++) {
+          for (int j = 0; j < i; j++) hv[j] = vdot(p[j], p[i], n);
+          for (int j = 0; j < i; j++) vaxpy(-hv[j], p[j], p[i], n);
+          for (int j = 0; j < i; j++) hh[j][i - 1] = (pass == 0) ? hv[j] : hh[j][i - 1] + hv[j];
+        }
+        free(hv);
       }
       double t = vnorm(p[i], n);
       hh[i][i - 1] = t;
@@ -1274,13 +1285,22 @@ static void gmres_core(const ocsr *A, const double *b, double *x, int kdim, doub
 
 void ogmres_solve(const ocsr *A, const double *b, double *x, int kdim, double tol, double atol, int maxit,
                   oprecond_fn M, void *Mctx, okrylov_result *res, double *norms) {
-  gmres_core(A, b, x, kdim, tol, atol, maxit, M, Mctx, res, norms, 0);
+  gmres_core(A, b, x, kdim, tol, atol, maxit, M, Mctx, res, norms, 0, 0);
 }
 
 /* hypre_FlexGMRESSolve (krylov/flexgmres.c); bound at src/HypreSystem.cpp:406-421 */
 void ofgmres_solve(const ocsr *A, const double *b, double *x, int kdim, double tol, double atol, int maxit,
                    oprecond_fn M, void *Mctx, okrylov_result *res, double *norms) {
-  gmres_core(A, b, x, kdim, tol, atol, maxit, M, Mctx, res, norms, 1);
+  gmres_core(A, b, x, kdim, tol, atol, maxit, M, Mctx, res, norms, 1, 0);
+}
+
+/* hypre_COGMRESSolve (krylov/cogmres.c), bound at src/HypreSystem.cpp:372-388: the GMRES skeleton with
+ * CLASSICAL Gram-Schmidt -- one block of inner products and one block update per pass, cgs <= 1: one pass,
+ * cgs >= 2: two passes (coefficients added).  Restated from the published low-synchronisation GMRES
+ * algorithm; like everything HYPRE-side: parity unpinned. */
+void ocogmres_solve(const ocsr *A, const double *b, double *x, int kdim, int cgs, double tol, double atol, int maxit,
+                    oprecond_fn M, void *Mctx, okrylov_result *res, double *norms) {
+  gmres_core(A, b, x, kdim, tol, atol, maxit, M, Mctx, res, norms, 0, cgs >= 2 ? 2 : 1);
 }
 
 /* hypre_PCGSolve (krylov/pcg.c), default options (two_norm 0: the measure is <C r,r>/<C b,b>

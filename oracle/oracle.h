@@ -116,6 +116,8 @@ void ogmres_solve(const ocsr *A, const double *b, double *x, int kdim, double to
 /* FlexGMRES: GMRES that keeps z_j = M^-1 p_j, restart residual recomputed (krylov/flexgmres.c) */
 void ofgmres_solve(const ocsr *A, const double *b, double *x, int kdim, double tol, double atol, int maxit,
                    oprecond_fn M, void *Mctx, okrylov_result *res, double *norms);
+void ocogmres_solve(const ocsr *A, const double *b, double *x, int kdim, int cgs, double tol, double atol, int maxit,
+                    oprecond_fn M, void *Mctx, okrylov_result *res, double *norms);
 /* preconditioned conjugate gradients, HYPRE default options (krylov/pcg.c) */
 void opcg_solve(const ocsr *A, const double *b, double *x, double tol, double atol, int maxit, oprecond_fn M,
                 void *Mctx, okrylov_result *res, double *norms);

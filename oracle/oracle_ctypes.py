@@ -107,6 +107,8 @@ def lib():
         L.ogmres_solve.argtypes = [P(_Csr), C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int,
                                    C.c_void_p, C.c_void_p, P(KrylovResult), C.c_void_p]
         L.ofgmres_solve.argtypes = L.ogmres_solve.argtypes
+        L.ocogmres_solve.argtypes = [P(_Csr), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
+                                     C.c_void_p, C.c_void_p, P(KrylovResult), C.c_void_p]
         L.opcg_solve.argtypes = [P(_Csr), C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int,
                                  C.c_void_p, C.c_void_p, P(KrylovResult), C.c_void_p]
         L.obicgstab_solve.argtypes = [P(_Csr), C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int,
@@ -297,6 +299,10 @@ def bicgstab(A, b, x0=None, tol=1e-6, atol=0.0, maxit=100, amg=None):
 
 def fgmres(A, b, x0=None, kdim=50, tol=1e-6, atol=0.0, maxit=100, amg=None):
     return _krylov(lib().ofgmres_solve, A, b, x0, (kdim, tol, atol, maxit), amg, maxit)
+
+
+def cogmres(A, b, x0=None, kdim=50, cgs=0, tol=1e-6, atol=0.0, maxit=100, amg=None):
+    return _krylov(lib().ocogmres_solve, A, b, x0, (kdim, cgs, tol, atol, maxit), amg, maxit)
 
 
 def pcg(A, b, x0=None, tol=1e-6, atol=0.0, maxit=100, amg=None):

@@ -232,6 +232,26 @@ def test_flexgmres_amg_matches_oracle(mi, oc, kdim):
     assert _allclose_ref(x.get(), xo)
 
 
+@pytest.mark.parametrize("kdim,cgs", [(50, 0), (12, 0), (50, 2), (5, 2)])
+def test_cogmres_amg_matches_oracle(mi, oc, kdim, cgs):
+    """GMRES skeleton with classical Gram-Schmidt in block form (one block of inner products + one block
+    update per pass; kdim 12 crosses the 8-vector block of the kernels, kdim 5 restarts)."""
+    A, b, x, amg, Ao, bo, oamg = _setup(mi, oc, 16)
+    cg = mi.COGMRES(tolerance=1e-9, max_iterations=60, kspace=kdim, print_level=0)
+    mi.call("HYPRE_ParCSRCOGMRESSetCGS", cg.h, cgs)
+    cg.set_precond(amg)
+    cg.setup(A, b, x)
+    assert cg.solve(A, b, x) == 0
+    xo, info = oc.cogmres(Ao, bo, kdim=kdim, cgs=cgs, tol=1e-9, maxit=60, amg=oamg)
+    assert cg.num_iterations == info["iters"]
+    assert np.allclose(cg.residual_history(), info["norms"], rtol=1e-6)
+    assert abs(cg.final_rel_res - info["rel_res"]) <= 1e-10
+    assert _allclose_ref(x.get(), xo)
+    # same Krylov space as GMRES: the counts agree while orthogonality holds
+    _, ginfo = oc.gmres(Ao, bo, kdim=kdim, tol=1e-9, maxit=60, amg=oamg)
+    assert abs(info["iters"] - ginfo["iters"]) <= 1
+
+
 @pytest.mark.parametrize("precond", [True, False])
 def test_pcg_matches_oracle(mi, oc, precond):
     A, b, x, amg, Ao, bo, oamg = _setup(mi, oc, 14)

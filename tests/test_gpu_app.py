@@ -178,7 +178,7 @@ solver_settings:
     assert m and int(m.group(1)) < 40 and float(m.group(2)) <= 1e-10
 
 
-@pytest.mark.parametrize("method", ["cg", "fgmres", "boomeramg"])
+@pytest.mark.parametrize("method", ["cg", "fgmres", "cogmres", "boomeramg"])
 def test_other_methods_through_driver(tmp_path, method):
     out = _run(tmp_path, f"""
 linear_system:
@@ -210,7 +210,7 @@ linear_system:
   ny: 8
   nz: 8
 solver_settings:
-  method: cogmres
+  method: ilu
   preconditioner: none
 """)
     p = subprocess.run([APP, str(inp)], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,

@@ -175,6 +175,18 @@ def test_pcg_and_flexgmres_against_scipy(oc):
     assert ic["converged"] and np.abs(xc - 1.0).max() < 1e-7
 
 
+def test_cogmres_builds_the_gmres_space(oc):
+    A, b = oc.Csr.laplace(12, 12, 12, 7)
+    amg = oc.Amg(A)
+    xg, jg = oc.gmres(A, b, kdim=30, tol=1e-10, maxit=80, amg=amg)
+    for cgs in (0, 2):
+        xc, jc = oc.cogmres(A, b, kdim=30, cgs=cgs, tol=1e-10, maxit=80, amg=amg)
+        assert jc["converged"] and abs(jc["iters"] - jg["iters"]) <= 1
+        assert jc["true_rel_res"] <= 2e-10
+        assert np.allclose(jc["norms"][:8], jg["norms"][:8], rtol=1e-6)
+        assert np.allclose(xc, np.ones_like(xc), atol=1e-7)
+
+
 def test_bicgstab_against_direct(oc):
     d = np.load(os.path.join(GOLD, "random_mmatrix_400.npz"))
     M = sp.csr_matrix((d["data"], d["indices"], d["indptr"]), shape=(400, 400))
