@@ -120,3 +120,33 @@ def test_first_solve_after_setup_equals_the_next(mi):
         hist.append(np.array(gm.residual_history()))
     assert len(hist[0]) == len(hist[1]) == len(hist[2])
     assert np.array_equal(hist[0], hist[1]) and np.array_equal(hist[1], hist[2])
+
+
+def test_benchmark_size_512(mi):
+    """BASELINE.json's own configuration (laplace_3d 512^3 7-pt, GMRES(50)+BoomerAMG, tol 1e-8) end to end:
+    exact solution, true residual, agreement of the first and the second solve (the benchmark size is where an
+    ordering bug between streams showed), hierarchy shape."""
+    n = 512
+    ndof = n ** 3
+    A, b, x, rhs = mi.build_laplace_system(n, n, n, 7)
+    amg = mi.BoomerAMG(print_level=0)
+    gm = mi.GMRES(tolerance=1e-8, max_iterations=100, kspace=50, print_level=0)
+    gm.set_precond(amg)
+    gm.setup(A, b, x)
+    assert 8 <= amg.num_levels <= 20 and 2.0 < amg.operator_complexity < 5.0
+    hists = []
+    for _ in range(2):
+        x.fill(0.0)
+        assert gm.solve(A, b, x) == 0
+        hists.append(np.array(gm.residual_history()))
+    assert np.array_equal(hists[0], hists[1])
+    assert 12 <= gm.num_iterations <= 30
+    xs = x.get()
+    assert np.all(np.abs(xs - 1.0) < 1e-5)
+    del xs
+    r = mi.IJVector(0, ndof - 1, rhs)
+    mi.call("HYPRE_ParCSRMatrixMatvec", -1.0, A.par, x.par, 1.0, r.par)
+    dot = mi.c_dbl()
+    mi.call("HYPRE_ParVectorInnerProd", r.par, r.par, mi.C.byref(dot))
+    rn = np.sqrt(dot.value) / np.linalg.norm(rhs)
+    assert rn <= 1e-8 and abs(rn - gm.final_rel_res) <= 1e-10
