@@ -28,6 +28,9 @@ struct AmgParams {
   int gs_chunk = 0;  // 0 => runtime default (ctx().gs_chunk)
   int agg_num_levels = 0, agg_interp_type = 4, agg_pmax_elmts = 0, keep_transpose = 0, rap2 = 0;
   int smooth_num_sweeps = 1;
+  // N > 1 ranks: levels >= 1 with at most this many global rows are kept whole on every rank and cycled
+  // redundantly, without halo exchanges (HYPRE_BoomerAMGSetSeqThreshold); -1 = MI_HYPRE_REDUNDANT_ROWS or 200000
+  long long redundant_rows = -1;
 };
 
 struct AmgLevel {
@@ -76,6 +79,39 @@ struct BoomerAMG {
   double final_rel_res = 0.0;
   double setup_seconds = 0.0;
   int chunk() const;
+  // the communicator this hierarchy works on: the process communicator, or a private single-rank one
+  // (global hierarchy of the replicated setup, redundant coarse tail)
+  Comm *forced_comm = nullptr;
+  std::unique_ptr<Comm> own_comm;
+  Comm &my_comm() const { return forced_comm ? *forced_comm : current_comm(); }
+  void use_private_self_comm();
+
+  // ---- redundant coarse tail (N > 1): the last entry of L is a stub that only carries this rank's slice of
+  // the first redundant level (natural ordering); the level itself and everything below it live in `tail`, a
+  // single-rank hierarchy every rank holds and cycles for itself
+  std::unique_ptr<BoomerAMG> tail;
+  std::unique_ptr<ParCSR> tail_A;   // the first redundant level, global, natural ordering (tail's fine level)
+  long long stop_rows = 0;          // build_natural: stop coarsening at the first level >= 1 this small
+  bool stopped_by_rows = false;
+  int tail_slot = 0;                // max rows of the stub over the ranks (all-gather slot)
+  gidx tail_start = 0;              // this rank's first row of the redundant level
+  DVec<double> tail_fslot, tail_fgather, tail_f, tail_e;
+  std::vector<int> tail_map_host;
+  DVec<int> tail_map, tail_pcol;    // natural id -> all-gather position; halo columns of the last P
+  void tail_cycle(bool zero_guess);
+  void apply_global(const double *f, double *e, bool zero_guess);  // one cycle, caller (natural) ordering
+  long long effective_redundant_rows() const;
+  // levels of the whole hierarchy (the stub counts once, as the tail's fine level) and the owner of one
+  int total_levels() const { return (int)L.size() + (tail ? (int)tail->L.size() - 1 : 0); }
+  BoomerAMG &owner_of(int level, int &local) {
+    const int own = tail ? (int)L.size() - 1 : (int)L.size();
+    if (level < own || !tail) {
+      local = level;
+      return *this;
+    }
+    local = level - own;
+    return *tail;
+  }
   static long long default_device_min_rows();
 
   void setup(ParCSR &A) {

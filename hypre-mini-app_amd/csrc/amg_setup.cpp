@@ -515,6 +515,17 @@ long long BoomerAMG::default_device_min_rows() {
   return e ? atoll(e) : 20000;
 }
 
+void BoomerAMG::use_private_self_comm() {
+  own_comm = make_self_comm();
+  forced_comm = own_comm.get();
+}
+
+long long BoomerAMG::effective_redundant_rows() const {
+  if (p.redundant_rows >= 0) return p.redundant_rows;
+  const char *e = getenv("MI_HYPRE_REDUNDANT_ROWS");
+  return e ? atoll(e) : 200000;
+}
+
 void BoomerAMG::ensure_host(int level) {
   if (level < 0 || level >= (int)L.size()) return;
   AmgLevel &Lv = L[(size_t)level];
@@ -540,7 +551,13 @@ int BoomerAMG::chunk() const { return p.gs_chunk > 0 ? p.gs_chunk : ctx().gs_chu
 double BoomerAMG::operator_complexity() const {
   if (L.empty()) return 0.0;
   double tot = 0.0;
-  for (const auto &l : L) tot += (double)(l.A->diag_nnz() + l.A->offd.nnz());
+  const size_t own = tail ? L.size() - 1 : L.size();  // the stub's operator is the tail's fine level
+  for (size_t l = 0; l < own; l++) tot += (double)(L[l].A->diag_nnz() + L[l].A->offd.nnz());
+  if (tail) {
+    double t = 0.0;
+    for (const auto &l : tail->L) t += (double)(l.A->diag_nnz() + l.A->offd.nnz());
+    tot += t / (double)std::max(1, my_comm().size);  // this rank's share of the redundant levels
+  }
   const double base = (double)(L[0].A->diag_nnz() + L[0].A->offd.nnz());
   return base > 0 ? tot / base : 0.0;
 }
@@ -555,7 +572,7 @@ double BoomerAMG::operator_complexity() const {
 // new positions), so the level gets a fresh col_map_offd and halo plan.  Level 0
 // becomes a renumbered COPY of the caller's matrix, which stays untouched.
 void BoomerAMG::apply_cf_ordering() {
-  Comm &comm = current_comm();
+  Comm &comm = my_comm();
   const size_t nlev = L.size();
   std::vector<std::vector<int>> pos(nlev);  // old -> new local row
   for (size_t l = 0; l < nlev; l++) {
@@ -706,7 +723,7 @@ void BoomerAMG::apply_cf_ordering() {
 }
 
 void BoomerAMG::setup_host(ParCSR &A0) {
-  Comm &comm = current_comm();
+  Comm &comm = my_comm();
   t_setup_start = wall_time();
   for (double &t : t_phase) t = 0.0;
   is_setup = false;
@@ -717,6 +734,8 @@ void BoomerAMG::setup_host(ParCSR &A0) {
   if (comm.size > 1) {
     build_replicated(A0);
   } else {
+    tail.reset();
+    tail_A.reset();
     build_natural(A0);
     const double tp0 = wall_time();
     apply_cf_ordering();
@@ -734,7 +753,7 @@ void BoomerAMG::setup_host(ParCSR &A0) {
 // the coarsening loop in natural ordering (single communicator rank, or the
 // global operator in the replicated multi-rank setup)
 void BoomerAMG::build_natural(ParCSR &A0) {
-  Comm &comm = current_comm();
+  Comm &comm = my_comm();
   MI_REQUIRE(comm.size == 1 && A0.col_map_offd.empty(), "build_natural expects a single-rank operator");
   L.clear();
   L.reserve((size_t)std::max(1, p.max_levels));
@@ -742,7 +761,12 @@ void BoomerAMG::build_natural(ParCSR &A0) {
   L[0].A = &A0;
 
   int l = 0;
+  stopped_by_rows = false;
   while (l < p.max_levels - 1 && L[(size_t)l].A->global_rows() > p.max_coarse_size) {
+    if (stop_rows > 0 && l >= 1 && L[(size_t)l].A->global_rows() <= stop_rows) {
+      stopped_by_rows = true;  // the caller continues from here with a redundant hierarchy
+      break;
+    }
     ParCSR &A = *L[(size_t)l].A;
     const int n = A.nrows;
     AmgLevel &Lv = L[(size_t)l];
@@ -864,7 +888,7 @@ void BoomerAMG::build_natural(ParCSR &A0) {
 
 // l1 norms and the coarsest-level dense inverse, on the finished (C-first ordered, per-rank) levels
 void BoomerAMG::finish_host() {
-  Comm &comm = current_comm();
+  Comm &comm = my_comm();
   // per-level norms (host), on the C-first ordered operators
   const int ch = chunk();
   for (size_t li = 0; li < L.size(); li++) {
@@ -892,7 +916,7 @@ void BoomerAMG::finish_host() {
   // coarsest level: dense inverse (relax type 9), every rank holds its own rows
   AmgLevel &Lc = L.back();
   const gidx ng = Lc.A->global_rows();
-  if (p.relax_type[2] == 9 && ng <= MAX_DENSE && ng > 0) {
+  if (!tail && p.relax_type[2] == 9 && ng <= MAX_DENSE && ng > 0) {
     ParCSR &A = *Lc.A;
     const int n = A.nrows;
     int maxloc = n;
@@ -1036,7 +1060,7 @@ std::unique_ptr<ParCSR> slice_rows(const HostCSR &G, const int *rows_old, int nl
 
 // single rank: the transfer operators have no halo block
 void BoomerAMG::make_local_transfer_operators() {
-  Comm &comm = current_comm();
+  Comm &comm = my_comm();
   for (size_t l = 0; l + 1 < L.size(); l++) {
     AmgLevel &Lv = L[l];
     if (Lv.P.nrows == 0 && Lv.cf.empty()) continue;
@@ -1063,7 +1087,7 @@ void BoomerAMG::make_local_transfer_operators() {
 // solve phase is fully distributed; the setup is O(N_global) per rank and is
 // the piece to distribute next.
 void BoomerAMG::build_replicated(ParCSR &A0) {
-  Comm &comm = current_comm();
+  Comm &comm = my_comm();
   const int rank = comm.rank, size = comm.size;
   // ---- 1. gather the global operator (CSR over global columns)
   double tp0 = wall_time();
@@ -1164,17 +1188,10 @@ void BoomerAMG::build_replicated(ParCSR &A0) {
   g.p.print_level = 0;
   g.device_min_rows = device_min_rows;
   g.keep_natural_R = true;
-  {
-    std::unique_ptr<Comm> real = std::move(ctx().comm);
-    ctx().comm = make_self_comm();
-    try {
-      g.build_natural(*Ag);
-    } catch (...) {
-      ctx().comm = std::move(real);
-      throw;
-    }
-    ctx().comm = std::move(real);
-  }
+  g.stop_rows = effective_redundant_rows();
+  g.use_private_self_comm();
+  g.build_natural(*Ag);
+  const bool has_tail = g.stopped_by_rows && g.L.size() >= 2;
   for (int q = 0; q < 4; q++) t_phase[q] = g.t_phase[q];
   tp0 = wall_time();
   const size_t nlev = g.L.size();
@@ -1234,15 +1251,45 @@ void BoomerAMG::build_replicated(ParCSR &A0) {
       }
       // P: my fine rows x coarse columns; R = P^T: my coarse rows x fine columns
       Lv.Pm = slice_rows(G.P, rows_old, nloc, pos[l + 1].data(), starts[l], starts[l + 1], rank);
-      Lv.Pm->build_halo_plan(comm);
+      // with a redundant tail the coarse correction is whole on every rank: no exchange for the last P
+      if (!(has_tail && l + 2 == nlev)) Lv.Pm->build_halo_plan(comm);
       const gidx c0 = starts[l + 1][(size_t)rank], c1 = starts[l + 1][(size_t)rank + 1];
       Lv.Rm = slice_rows(G.R, perm[l + 1].data() + c0, (int)(c1 - c0), pos[l].data(), starts[l + 1], starts[l], rank);
       Lv.Rm->build_halo_plan(comm);
     }
-    // the global level is not needed any more
-    if (G.A_own) G.A_own.reset();
+    // the global level is not needed any more (the tail's fine level is)
+    if (has_tail && l + 1 == nlev && G.A_own)
+      tail_A = std::move(G.A_own);
+    else if (G.A_own)
+      G.A_own.reset();
     G.P = HostCSR();
     G.R = HostCSR();
+  }
+  tail.reset();
+  if (has_tail) {
+    MI_REQUIRE(tail_A != nullptr, "replicated setup: the redundant level was not kept");
+    // levels nlev-1 .. : one single-rank hierarchy per rank, built by the ordinary pipeline on the
+    // (global, natural-order) operator of the first redundant level
+    if (tail_A->host_diag_stale) fail(1, "replicated setup: the redundant level has no host arrays");
+    tail.reset(new BoomerAMG());
+    tail->p = p;
+    tail->p.print_level = 0;
+    tail->p.max_levels = std::max(1, p.max_levels - (int)(nlev - 1));
+    tail->device_min_rows = device_min_rows;
+    tail->use_private_self_comm();
+    tail->setup_host(*tail_A);
+    tail_start = starts[nlev - 1][(size_t)rank];
+    int slot = 0;
+    for (int r = 0; r < size; r++)
+      slot = std::max(slot, (int)(starts[nlev - 1][(size_t)r + 1] - starts[nlev - 1][(size_t)r]));
+    tail_slot = slot;
+    std::vector<int> map((size_t)tail_A->nrows);
+    for (int r = 0; r < size; r++)
+      for (gidx i = starts[nlev - 1][(size_t)r]; i < starts[nlev - 1][(size_t)r + 1]; i++)
+        map[(size_t)i] = r * slot + (int)(i - starts[nlev - 1][(size_t)r]);
+    tail_map_host.swap(map);
+  } else {
+    tail_A.reset();
   }
   Ag.reset();
   t_phase[4] = wall_time() - tp0;
@@ -1254,7 +1301,7 @@ void BoomerAMG::build_replicated(ParCSR &A0) {
 void BoomerAMG::setup_device() {
   MI_REQUIRE(host_ready, "BoomerAMG: setup_device before setup_host");
   ensure_init();
-  Comm &comm = current_comm();
+  Comm &comm = my_comm();
   const int ch = chunk();
   for (size_t li = 0; li < L.size(); li++) {
     AmgLevel &Lv = L[li];
@@ -1301,17 +1348,38 @@ void BoomerAMG::setup_device() {
     zero_on_stream(Lc.fslot.p, ((size_t)Lc.slot + 2) * sizeof(double));
     zero_on_stream(Lc.fgather.p, (width + 2) * sizeof(double));
   }
+  if (tail) {
+    tail->setup_device();
+    const size_t ng = (size_t)tail_A->nrows;
+    tail_fslot.alloc((size_t)tail_slot);
+    tail_fgather.alloc((size_t)tail_slot * (size_t)comm.size);
+    tail_f.alloc(ng);
+    tail_e.alloc(ng);
+    zero_on_stream(tail_fslot.p, ((size_t)tail_slot + 2) * sizeof(double));
+    zero_on_stream(tail_fgather.p, ((size_t)tail_slot * (size_t)comm.size + 2) * sizeof(double));
+    zero_on_stream(tail_e.p, (ng + 2) * sizeof(double));
+    tail_map.upload(tail_map_host);
+    AmgLevel &Lp = L[L.size() - 2];
+    std::vector<int> pcol(Lp.Pm->col_map_offd.size());
+    for (size_t q = 0; q < pcol.size(); q++) pcol[q] = (int)Lp.Pm->col_map_offd[q];
+    tail_pcol.upload(pcol);
+  }
   MI_HIP(hipDeviceSynchronize());
   is_setup = true;
   setup_seconds = wall_time() - t_setup_start;
   if (p.print_level > 0 && comm.rank == 0) {
-    printf("mi_hypre BoomerAMG setup: %zu levels, operator complexity %.3f, chunk %d, %.3f s\n", L.size(),
+    printf("mi_hypre BoomerAMG setup: %d levels, operator complexity %.3f, chunk %d, %.3f s\n", total_levels(),
            operator_complexity(), ch, setup_seconds);
     printf("   host phases: strength %.2f  pmis %.2f  interp %.2f  galerkin %.2f  C-first ordering %.2f  (host total %.2f) s\n",
            t_phase[0], t_phase[1], t_phase[2], t_phase[3], t_phase[4], t_phase[5]);
-    for (size_t li = 0; li < L.size(); li++)
-      printf("   level %2zu: local rows %10d  global rows %12lld  local nnz %12lld\n", li, L[li].n,
-             (long long)L[li].A->global_rows(), (long long)(L[li].A->diag_nnz() + L[li].A->offd.nnz()));
+    for (int li = 0; li < total_levels(); li++) {
+      int loc = 0;
+      BoomerAMG &o = owner_of(li, loc);
+      const AmgLevel &Lv = o.L[(size_t)loc];
+      printf("   level %2d: local rows %10d  global rows %12lld  local nnz %12lld%s\n", li, Lv.n,
+             (long long)Lv.A->global_rows(), (long long)(Lv.A->diag_nnz() + Lv.A->offd.nnz()),
+             &o != this ? "  (whole level on every rank)" : "");
+    }
   }
 }
 

@@ -54,7 +54,7 @@ bool dense_solve(AmgLevel &Lv, Comm &comm, const double *f, double *u, hipStream
 void BoomerAMG::relax(int level, int type, int points, const double *f, bool u_is_zero) {
   AmgLevel &Lv = L[(size_t)level];
   ParCSR &A = *Lv.A;
-  Comm &comm = current_comm();
+  Comm &comm = my_comm();
   hipStream_t s = ctx().stream;
   const int prof = (level == 0) ? k::PROF_RELAX_L0 : k::PROF_NONE;
   double *u = Lv.u.p;
@@ -100,7 +100,7 @@ void BoomerAMG::relax_pair(int level, int type, int first, const double *f, bool
     return;
   }
   ParCSR &A = *Lv.A;
-  Comm &comm = current_comm();
+  Comm &comm = my_comm();
   hipStream_t s = ctx().stream;
   const int prof = (level == 0) ? k::PROF_RELAX_L0 : k::PROF_NONE;
   const double w = p.relax_weight * p.outer_weight;
@@ -143,29 +143,78 @@ void BoomerAMG::cycle(int level, bool u_is_zero) {
   const int nlev = (int)L.size();
   AmgLevel &Lv = L[(size_t)level];
   if (level == nlev - 1) {
-    relax_sweeps(level, 2, Lv.f.p, u_is_zero);
+    if (tail)
+      tail_cycle(u_is_zero);
+    else
+      relax_sweeps(level, 2, Lv.f.p, u_is_zero);
     return;
   }
   AmgLevel &Ln = L[(size_t)level + 1];
-  Comm &comm = current_comm();
+  Comm &comm = my_comm();
   hipStream_t s = ctx().stream;
   relax_sweeps(level, 0, Lv.f.p, u_is_zero && p.num_sweeps[0] > 0);
   // r = f - A u ; f_c = P^T r ; u_c = 0
   Lv.A->matvec(comm, -1.0, Lv.u.p, 1.0, Lv.f.p, Lv.tmp.p, s);
   Lv.Rm->matvec(comm, 1.0, Lv.tmp.p, 0.0, nullptr, Ln.f.p, s);
   k::fill(Ln.u.p, Ln.n, 0.0, s);
-  const int ncyc = (p.cycle_type == 2 && level + 1 < nlev - 1) ? 2 : 1;
+  // the coarsest level is visited once per cycle; with a redundant tail the count continues into the tail
+  const bool tail_next = tail && level + 1 == nlev - 1;
+  const bool next_is_coarsest = tail_next ? tail->L.size() == 1 : level + 1 == nlev - 1;
+  const int ncyc = (p.cycle_type == 2 && !next_is_coarsest) ? 2 : 1;
   for (int c = 0; c < ncyc; c++) cycle(level + 1, c == 0);
   // u += P e
-  Lv.Pm->matvec(comm, 1.0, Ln.u.p, 1.0, Lv.u.p, Lv.u.p, s);
+  if (tail_next) {  // every rank holds the whole coarse correction: halo values without an exchange
+    const int next = (int)Lv.Pm->col_map_offd.size();
+    if (next) k::gather(tail_e.p, tail_pcol.p, Lv.Pm->halo.d_xext.p, next, s);
+    Lv.Pm->matvec_ext_ready(1.0, Ln.u.p, 1.0, Lv.u.p, Lv.u.p, s);
+  } else {
+    Lv.Pm->matvec(comm, 1.0, Ln.u.p, 1.0, Lv.u.p, Lv.u.p, s);
+  }
   relax_sweeps(level, 1, Lv.f.p, false);
+}
+
+// the stub level's right-hand side (this rank's slice) -> whole level on every rank -> one cycle of the
+// redundant hierarchy -> this rank's slice of the correction
+void BoomerAMG::tail_cycle(bool zero_guess) {
+  AmgLevel &Lv = L.back();
+  Comm &comm = my_comm();
+  hipStream_t s = ctx().stream;
+  const int ng = tail_A->nrows;
+  if (Lv.n) k::copy(Lv.f.p, tail_fslot.p, Lv.n, s);
+  comm.allgather_dev(tail_fslot.p, tail_fgather.p, (size_t)tail_slot * sizeof(double), s);
+  k::gather(tail_fgather.p, tail_map.p, tail_f.p, ng, s);
+  tail->apply_global(tail_f.p, tail_e.p, zero_guess);
+  if (Lv.n) k::copy(tail_e.p + tail_start, Lv.u.p, Lv.n, s);
+}
+
+// one cycle on vectors in the caller's (natural) ordering of this hierarchy's fine level; e is the initial
+// guess unless zero_guess
+void BoomerAMG::apply_global(const double *f, double *e, bool zero_guess) {
+  hipStream_t s = ctx().stream;
+  AmgLevel &L0 = L[0];
+  const bool permuted = !L0.perm.empty();
+  if (permuted)
+    k::gather(f, L0.d_perm.p, L0.f.p, L0.n, s);
+  else
+    k::copy(f, L0.f.p, L0.n, s);
+  if (zero_guess)
+    k::fill(L0.u.p, L0.n, 0.0, s);
+  else if (permuted)
+    k::gather(e, L0.d_perm.p, L0.u.p, L0.n, s);
+  else
+    k::copy(e, L0.u.p, L0.n, s);
+  cycle(0, zero_guess);
+  if (permuted)
+    k::scatter_set(e, L0.d_perm.p, L0.u.p, L0.n, s);
+  else
+    k::copy(L0.u.p, e, L0.n, s);
 }
 
 void BoomerAMG::solve(ParCSR &A, ParVector &b, ParVector &x) {
   if (!is_setup) setup(A);
   MI_REQUIRE(x.ncomp == 1 && b.ncomp == 1, "BoomerAMGSolve: multi-component vectors are not supported");
   MI_REQUIRE(x.n == L[0].n && b.n == L[0].n, "BoomerAMGSolve: vector size does not match the matrix");
-  Comm &comm = current_comm();
+  Comm &comm = my_comm();
   hipStream_t s = ctx().stream;
   AmgLevel &L0 = L[0];
   const bool permuted = !L0.perm.empty();

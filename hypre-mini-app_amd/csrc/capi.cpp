@@ -718,6 +718,7 @@ AMG_SET(TruncFactor, HYPRE_Real, p.trunc_factor = v)
 AMG_SET(PMaxElmts, HYPRE_Int, p.pmax_elmts = v)
 AMG_SET(MinCoarseSize, HYPRE_Int, p.min_coarse_size = v)
 AMG_SET(MaxCoarseSize, HYPRE_Int, p.max_coarse_size = v)
+AMG_SET(SeqThreshold, HYPRE_Int, p.redundant_rows = (v < 0 ? 0 : v))
 AMG_SET(RelaxWt, HYPRE_Real, p.relax_weight = v)
 AMG_SET(OuterWt, HYPRE_Real, p.outer_weight = v)
 AMG_SET(AggNumLevels, HYPRE_Int, p.agg_num_levels = v)
@@ -967,7 +968,12 @@ hypre_ParCSRMatrix **hypre_ParAMGDataAArray(hypre_ParAMGData *amg_data) {
   try {
     AmgSolver *a = AMG(reinterpret_cast<HYPRE_Solver>(amg_data));
     g_level_ptrs.clear();
-    for (auto &l : a->amg.L) g_level_ptrs.push_back(reinterpret_cast<hypre_ParCSRMatrix *>(l.A));
+    for (int l = 0; l < a->amg.total_levels(); l++) {
+      int loc = 0;
+      BoomerAMG &o = a->amg.owner_of(l, loc);
+      o.ensure_host(loc);
+      g_level_ptrs.push_back(reinterpret_cast<hypre_ParCSRMatrix *>(o.L[(size_t)loc].A));
+    }
     return g_level_ptrs.data();
   } catch (const std::exception &e) {
     record_error(HYPRE_ERROR_ARG, e.what());
@@ -976,7 +982,7 @@ hypre_ParCSRMatrix **hypre_ParAMGDataAArray(hypre_ParAMGData *amg_data) {
 }
 HYPRE_Int hypre_ParAMGDataNumLevels(hypre_ParAMGData *amg_data) {
   try {
-    return (HYPRE_Int)AMG(reinterpret_cast<HYPRE_Solver>(amg_data))->amg.L.size();
+    return (HYPRE_Int)AMG(reinterpret_cast<HYPRE_Solver>(amg_data))->amg.total_levels();
   } catch (const std::exception &e) {
     record_error(HYPRE_ERROR_ARG, e.what());
     return 0;
@@ -1101,7 +1107,7 @@ HYPRE_Int HYPRE_MI_KrylovGetSolveSeconds(HYPRE_Solver solver, HYPRE_Real *second
 }
 HYPRE_Int HYPRE_MI_BoomerAMGGetNumLevels(HYPRE_Solver solver, HYPRE_Int *n) {
   API_BEGIN
-  *n = (HYPRE_Int)AMG(solver)->amg.L.size();
+  *n = (HYPRE_Int)AMG(solver)->amg.total_levels();
   API_END
 }
 HYPRE_Int HYPRE_MI_BoomerAMGGetOperatorComplexity(HYPRE_Solver solver, HYPRE_Real *cx) {
@@ -1114,10 +1120,20 @@ HYPRE_Int HYPRE_MI_BoomerAMGGetSetupSeconds(HYPRE_Solver solver, HYPRE_Real *sec
   *seconds = AMG(solver)->amg.setup_seconds;
   API_END
 }
+// level of the whole hierarchy: the distributed levels, then the redundant tail's (its fine level replaces the stub)
+static AmgLevel &level_ref(AmgSolver *a, int level, BoomerAMG **owner = nullptr, int *local = nullptr) {
+  if (level < 0 || level >= a->amg.total_levels()) fail(HYPRE_ERROR_ARG, "AMG level out of range");
+  int loc = 0;
+  BoomerAMG &o = a->amg.owner_of(level, loc);
+  if (owner) *owner = &o;
+  if (local) *local = loc;
+  return o.L[(size_t)loc];
+}
 static const HostCSR &level_csr(AmgSolver *a, int level, int which) {
-  if (level < 0 || level >= (int)a->amg.L.size()) fail(HYPRE_ERROR_ARG, "AMG level out of range");
-  a->amg.ensure_host(level);
-  AmgLevel &L = a->amg.L[(size_t)level];
+  BoomerAMG *o = nullptr;
+  int loc = 0;
+  AmgLevel &L = level_ref(a, level, &o, &loc);
+  o->ensure_host(loc);
   switch (which) {
     case 0: return L.A->diag;
     case 1: return L.A->offd;
@@ -1158,16 +1174,14 @@ HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSR(HYPRE_Solver solver, HYPRE_Int level, HY
 HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCF(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int *cf) {
   API_BEGIN
   AmgSolver *a = AMG(solver);
-  if (level < 0 || level >= (int)a->amg.L.size()) fail(HYPRE_ERROR_ARG, "AMG level out of range");
-  const auto &v = a->amg.L[(size_t)level].cf;
+  const auto &v = level_ref(a, level).cf;
   for (size_t i = 0; i < v.size(); i++) cf[i] = v[i];
   API_END
 }
 HYPRE_Int HYPRE_MI_BoomerAMGGetLevelPerm(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int *perm) {
   API_BEGIN
   AmgSolver *a = AMG(solver);
-  if (level < 0 || level >= (int)a->amg.L.size()) fail(HYPRE_ERROR_ARG, "AMG level out of range");
-  const AmgLevel &Lv = a->amg.L[(size_t)level];
+  const AmgLevel &Lv = level_ref(a, level);
   for (int i = 0; i < Lv.A->nrows; i++) perm[i] = Lv.perm.empty() ? i : Lv.perm[(size_t)i];
   API_END
 }
@@ -1175,8 +1189,7 @@ HYPRE_Int HYPRE_MI_BoomerAMGGetLevelColMap(HYPRE_Solver solver, HYPRE_Int level,
                                            HYPRE_BigInt *row_start) {
   API_BEGIN
   AmgSolver *a = AMG(solver);
-  if (level < 0 || level >= (int)a->amg.L.size()) fail(HYPRE_ERROR_ARG, "AMG level out of range");
-  const ParCSR &A = *a->amg.L[(size_t)level].A;
+  const ParCSR &A = *level_ref(a, level).A;
   if (col_map_offd)
     for (size_t i = 0; i < A.col_map_offd.size(); i++) col_map_offd[i] = A.col_map_offd[i];
   if (row_start) *row_start = A.row_start;
@@ -1186,8 +1199,7 @@ HYPRE_Int HYPRE_MI_BoomerAMGGetLevelOffdColMap(HYPRE_Solver solver, HYPRE_Int le
                                                HYPRE_BigInt *col_map_offd) {
   API_BEGIN
   AmgSolver *a = AMG(solver);
-  if (level < 0 || level >= (int)a->amg.L.size()) fail(HYPRE_ERROR_ARG, "AMG level out of range");
-  const AmgLevel &Lv = a->amg.L[(size_t)level];
+  const AmgLevel &Lv = level_ref(a, level);
   const ParCSR *M = nullptr;
   switch (which) {
     case 1: M = Lv.A; break;

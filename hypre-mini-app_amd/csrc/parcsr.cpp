@@ -285,6 +285,12 @@ void ParCSR::matvec(Comm &comm, double alpha, const double *x, double beta, cons
   if (halo_on) k::spmv_offd_add(d_offd, halo.d_xext.p, alpha, y, s);
 }
 
+void ParCSR::matvec_ext_ready(double alpha, const double *x, double beta, const double *b, double *y, hipStream_t s) {
+  MI_REQUIRE(on_device, "matrix not assembled");
+  k::spmv(d_diag, x, alpha, beta, b, y, s, -1);
+  if (d_offd.nrows_c > 0) k::spmv_offd_add(d_offd, halo.d_xext.p, alpha, y, s);
+}
+
 const double *ParCSR::offd_contrib(Comm &comm, const double *x, hipStream_t s, const double *x_hi, int split) {
   if (comm.size == 1) return nullptr;
   halo_exchange(comm, x, s, x_hi, split);

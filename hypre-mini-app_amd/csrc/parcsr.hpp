@@ -65,6 +65,8 @@ struct ParCSR {
   // y = alpha*A*x + beta*b
   void matvec(Comm &comm, double alpha, const double *x, double beta, const double *b, double *y, hipStream_t s,
               int prof = -1);
+  // the same with the halo values already in halo.d_xext (no exchange)
+  void matvec_ext_ready(double alpha, const double *x, double beta, const double *b, double *y, hipStream_t s);
   // offc[halo rows] = A_offd * x_ext(x)   (used by the smoothers)
   const double *offd_contrib(Comm &comm, const double *x, hipStream_t s, const double *x_hi = nullptr, int split = 0);
 };

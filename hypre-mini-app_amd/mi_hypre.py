@@ -234,6 +234,7 @@ class BoomerAMG:
         for key, fn, conv in (("interp_type", "HYPRE_BoomerAMGSetInterpType", int),
                               ("min_coarse_size", "HYPRE_BoomerAMGSetMinCoarseSize", int),
                               ("max_coarse_size", "HYPRE_BoomerAMGSetMaxCoarseSize", int),
+                              ("seq_threshold", "HYPRE_BoomerAMGSetSeqThreshold", int),
                               ("agg_num_levels", "HYPRE_BoomerAMGSetAggNumLevels", int),
                               ("trunc_factor", "HYPRE_BoomerAMGSetTruncFactor", float),
                               ("keep_transpose", "HYPRE_BoomerAMGSetKeepTranspose", int),

@@ -266,6 +266,7 @@ void oamg_default_params(oamg_params *p) {
   p->part_starts = NULL;
   p->max_iter = 1;
   p->tol = 0.0;
+  p->redundant_rows = 0;
 }
 
 static int *part_of_rows(int n, int nparts, const obig *ps) {
@@ -860,6 +861,11 @@ oamg *oamg_setup(const ocsr *A0, const oamg_params *p) {
     for (int i = 0; i < n; i++)
       if (cf[i] == C_PT) Ln->part_starts[part_of[i] + 1]++;
     for (int q = 0; q < nparts; q++) Ln->part_starts[q + 1] += Ln->part_starts[q];
+    if (p->redundant_rows > 0 && Ln->part_starts[nparts] <= p->redundant_rows) {
+      /* small level: every rank holds all of it (one part; the others are empty) */
+      const obig all = Ln->part_starts[nparts];
+      for (int q = 1; q <= nparts; q++) Ln->part_starts[q] = all;
+    }
     free(Sia);
     free(Sja);
     free(part_of);

@@ -73,6 +73,8 @@ typedef struct oamg_params {
   const obig *part_starts; /* nparts+1 row starts of level 0 (NULL => 1 part) */
   int max_iter;            /* 1 as preconditioner (HypreSystem.cpp:155) */
   double tol;              /* 0 as preconditioner (HypreSystem.cpp:154) */
+  obig redundant_rows;     /* nparts > 1: levels >= 1 with at most this many rows are solved redundantly by every
+                            * rank (one part: HYPRE's seq_threshold idea); 0 = every level distributed */
 } oamg_params;
 
 void oamg_default_params(oamg_params *p);

@@ -43,6 +43,7 @@ class AmgParams(C.Structure):
         ("part_starts", C.POINTER(C.c_longlong)),
         ("max_iter", C.c_int),
         ("tol", C.c_double),
+        ("redundant_rows", C.c_longlong),
     ]
 
 

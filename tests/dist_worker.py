@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--grid", type=int, default=12)
     ap.add_argument("--stencil", type=int, default=7)
     ap.add_argument("--staging", default="host", help="host | cuda (device-tensor staging of the callback transport)")
+    ap.add_argument("--seq", type=int, default=-1, help="redundant-level threshold (HYPRE seq_threshold); -1 = library default")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -69,7 +70,8 @@ def main():
     Ao, bo = oc.Csr.laplace(n, n, n, st)
     chunk = mi.c_int()
     mi.call("HYPRE_MI_GetGSChunk", mi.C.byref(chunk))
-    oamg = oc.Amg(Ao, oc.default_params(gs_chunk=chunk.value, part_starts=starts))
+    seq = args.seq if args.seq >= 0 else 200000
+    oamg = oc.Amg(Ao, oc.default_params(gs_chunk=chunk.value, part_starts=starts, redundant_rows=seq))
 
     if args.mode == "host":
         A, rhs = mi.build_laplace_system_host(n, n, n, st, rank, size)
@@ -95,19 +97,40 @@ def main():
         assert np.array_equal(np.sort(got), need), (rank, p)
 
     # ---- hierarchy
-    amg = mi.BoomerAMG(print_level=0)
+    amg = mi.BoomerAMG(print_level=0, **({"seq_threshold": args.seq} if args.seq >= 0 else {}))
     if args.mode == "host":
         mi.call("HYPRE_MI_BoomerAMGSetupHostOnly", amg.h, A.par)
     else:
         amg.setup(A)
     assert amg.num_levels == oamg.num_levels, (amg.num_levels, oamg.num_levels)
+    def coarse_partition(l):
+        """Row partition of level l+1 as the product builds it: owner of the C point."""
+        ps = oamg.level_part_starts(l)
+        ocf = oamg.level_cf(l)
+        return np.concatenate([[0], np.cumsum([int((ocf[ps[r]:ps[r + 1]] == 1).sum()) for r in range(size)])])
+
+    n_redundant = 0
     for l in range(amg.num_levels):
         OA = oamg.level_A(l).to_scipy()
         ps = oamg.level_part_starts(l)
+        redundant = size > 1 and l >= 1 and ps[1] == ps[-1]  # the oracle keeps a redundant level whole in part 0
+        last = l == amg.num_levels - 1
+        if redundant:
+            # every rank holds the whole level in the single-part C-first ordering
+            n_redundant += 1
+            ia, ja, a, shape = amg.level_csr(l, 0)
+            assert shape == OA.shape and amg.level_csr(l, 1)[3][1] == 0
+            assert same_matrix(sp.csr_matrix((a, ja, ia), shape=shape), OA, 1e-12), (l, rank)
+            if not last:
+                assert np.array_equal(amg.level_cf(l), oamg.level_cf(l)), (l, rank)
+                assert np.array_equal(amg.level_perm(l), oamg.level_perm(l)), (l, rank)
+                pia, pja, pa, pshape = amg.level_csr(l, 2)
+                assert same_matrix(sp.csr_matrix((pa, pja, pia), shape=pshape), oamg.level_P(l).to_scipy(), 1e-13), (l, rank)
+            continue
         mine, row_start = local_rows_global(amg, l, OA.shape[1], rank)
         assert row_start == ps[rank] and mine.shape[0] == ps[rank + 1] - ps[rank], (l, rank)
         assert same_matrix(mine, OA[ps[rank]:ps[rank + 1]], 1e-12), (l, rank)
-        if l < amg.num_levels - 1:
+        if not last:
             cf = amg.level_cf(l)
             assert np.array_equal(cf, oamg.level_cf(l)[ps[rank]:ps[rank + 1]]), (l, rank)
             perm = amg.level_perm(l)
@@ -115,10 +138,21 @@ def main():
             # interpolation reaches C points of other ranks: P and R = P^T carry halo blocks
             OP = oamg.level_P(l).to_scipy()
             psn = oamg.level_part_starts(l + 1)
+            if size > 1 and psn[1] == psn[-1]:
+                # the next level is redundant: the product numbers it naturally (rank slices = owners of the
+                # C points), the oracle in its single-part C-first ordering
+                pos = np.empty(OP.shape[1], dtype=np.int64)
+                pos[oamg.level_perm(l + 1)] = np.arange(OP.shape[1])
+                OP = OP[:, pos].tocsr()
+                psn = coarse_partition(l)
             Pm, _ = local_rows_global(amg, l, OP.shape[1], rank, 2, 4, col_start=psn[rank])
             assert same_matrix(Pm, OP[ps[rank]:ps[rank + 1]], 1e-13), (l, rank)
             Rm, _ = local_rows_global(amg, l, OP.shape[0], rank, 3, 5, col_start=ps[rank])
             assert same_matrix(Rm, OP.T.tocsr()[psn[rank]:psn[rank + 1]], 1e-13), (l, rank)
+    if size > 1 and seq > 0 and amg.num_levels > 1 and oamg.level_A(1).shape[0] <= seq:
+        assert n_redundant == amg.num_levels - 1
+    if seq == 0:
+        assert n_redundant == 0
 
     if args.mode == "solve":
         gm = mi.GMRES(tolerance=1e-8, max_iterations=60, kspace=20, print_level=0)
@@ -145,9 +179,10 @@ def main():
         mi.call("HYPRE_ParVectorInnerProd", xv.par, xv.par, mi.C.byref(prod))
         assert abs(prod.value - float(v @ v)) <= 1e-12 * float(v @ v)
         if rank == 0:
-            print(f"dist solve ok: {size} ranks, {gm.num_iterations} iterations, rel res {gm.final_rel_res:.3e}")
+            print(f"dist solve ok: {size} ranks, {gm.num_iterations} iterations, rel res {gm.final_rel_res:.3e}, "
+                  f"{n_redundant} redundant levels")
     elif rank == 0:
-        print(f"dist host setup ok: {size} ranks, {amg.num_levels} levels")
+        print(f"dist host setup ok: {size} ranks, {amg.num_levels} levels, {n_redundant} redundant")
     dist.barrier()
     mi.call("HYPRE_MI_CommFinalize")
     dist.destroy_process_group()

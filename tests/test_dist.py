@@ -1,9 +1,11 @@
 """N>1 path: world_size-2/3 runs of tests/dist_worker.py.
 
 CPU (gloo): the host half of the distributed path -- partition, IJ assembly, halo
-plan, rank-local coarsening, P-row exchange, Galerkin product -- against the
-oracle's emulation of the same partition.
+plan, global hierarchy, this rank's slices of A / P / R with their halo blocks, the
+redundant coarse tail -- against the oracle's emulation of the same partition.
 GPU: the same plus the device solve with several ranks sharing the GPU.
+seq = threshold of the redundant coarse levels (-1 library default: every level >= 1
+of these small grids; 0 off: all levels distributed; in between: a switch mid-hierarchy).
 """
 import os
 import subprocess
@@ -15,29 +17,30 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
 
 
-def _run(nproc, mode, n, stencil, port, staging="host"):
+def _run(nproc, mode, n, stencil, port, staging="host", seq=-1):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["MI_HYPRE_HOST_THREADS"] = "2"
     env["OMP_NUM_THREADS"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), WORKER, "--mode", mode, "--grid", str(n),
-           "--stencil", str(stencil), "--staging", staging]
+           "--stencil", str(stencil), "--staging", staging, "--seq", str(seq)]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-4000:]
     return p.stdout
 
 
-@pytest.mark.parametrize("nproc,n,stencil", [(2, 12, 7), (3, 10, 27)])
-def test_host_setup_world_size_n_gloo(nproc, n, stencil):
-    out = _run(nproc, "host", n, stencil, 29611 + nproc)
+@pytest.mark.parametrize("nproc,n,stencil,seq", [(2, 12, 7, -1), (3, 10, 27, 0), (2, 14, 7, 300)])
+def test_host_setup_world_size_n_gloo(nproc, n, stencil, seq):
+    out = _run(nproc, "host", n, stencil, 29611 + nproc + (7 if seq > 0 else 0), seq=seq)
     assert "dist host setup ok" in out
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nproc,n,stencil", [(2, 16, 7), (4, 12, 7), (3, 10, 27)])
-def test_device_solve_shared_gpu(nproc, n, stencil):
-    out = _run(nproc, "solve", n, stencil, 29631 + nproc)
+@pytest.mark.parametrize("nproc,n,stencil,seq", [(2, 16, 7, -1), (4, 12, 7, 0), (3, 10, 27, 0), (3, 14, 7, 300),
+                                                  (4, 16, 7, 1000)])
+def test_device_solve_shared_gpu(nproc, n, stencil, seq):
+    out = _run(nproc, "solve", n, stencil, 29631 + nproc + (11 if seq > 0 else 0), seq=seq)
     assert "dist solve ok" in out
 
 
