@@ -1,5 +1,5 @@
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
 import __graft_entry__ as ge
 mi = ge.load_binding(); mi.init()
 n = int(sys.argv[1])
