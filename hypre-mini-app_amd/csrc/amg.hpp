@@ -47,6 +47,7 @@ struct AmgLevel {
   // solve-phase format (A->d_diag, Pm->d_diag, Rm->d_diag)
   sk::DCsr oA, oP, oR;
   std::vector<int> cf;  // +1 C, -1 F (empty on the coarsest level)
+  bool has_cf = false;  // the level has a C/F splitting -- a GLOBAL fact (cf itself is empty on a rank without rows)
   DVec<signed char> d_cf;
   // C-first ordering of this level: perm[new] = old local row;
   // rows [0, nc) are the C points, [nc, n) the F points.  Empty = identity.

@@ -836,6 +836,7 @@ void BoomerAMG::build_natural(ParCSR &A0) {
     }
     if (!p_on_device) build_interp(A, S, cf, p.interp_type, p.trunc_factor, p.pmax_elmts, Lv.P, nc);
     Lv.cf = cf;
+    Lv.has_cf = true;
     if (!on_device) host_transpose(Lv.P, Lv.R);
     t_phase[2] += wall_time() - tp0;
     tp0 = wall_time();
@@ -908,7 +909,7 @@ void BoomerAMG::finish_host() {
       continue;
     }
     std::vector<int> cf_ext;
-    if (!Lv.cf.empty()) cf_ext = A.halo_exchange_host_int(comm, Lv.cf);
+    if (Lv.has_cf) cf_ext = A.halo_exchange_host_int(comm, Lv.cf);  // collective: gated by the global flag
     level_norms(A, Lv.cf, cf_ext, ch, Lv.diag, Lv.l1gs, Lv.l1jac);
   }
   ensure_host((int)L.size() - 1);
@@ -1240,7 +1241,8 @@ void BoomerAMG::build_replicated(ParCSR &A0) {
     Lv.A_own = slice_rows(G.A->diag, rows_old, nloc, pos[l].data(), starts[l], starts[l], rank);
     Lv.A = Lv.A_own.get();
     Lv.A->build_halo_plan(comm);
-    if (!G.cf.empty()) {
+    Lv.has_cf = !G.cf.empty();
+    if (Lv.has_cf) {
       Lv.cf.resize((size_t)nloc);
       Lv.perm.resize((size_t)nloc);
       Lv.nc = 0;

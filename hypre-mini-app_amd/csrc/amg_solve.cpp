@@ -64,7 +64,7 @@ void BoomerAMG::relax(int level, int type, int points, const double *f, bool u_i
   }
   const GsKind g = classify(type);
   const double w = p.relax_weight * p.outer_weight;
-  const bool has_cf = !Lv.cf.empty();
+  const bool has_cf = Lv.has_cf && !Lv.cf.empty();
   const signed char *cf = has_cf ? Lv.d_cf.p : nullptr;
   if (!has_cf) points = 0;
   // a zero vector has a zero halo: no exchange, no halo contribution
@@ -128,7 +128,7 @@ void BoomerAMG::relax_pair(int level, int type, int first, const double *f, bool
 // C going up, all points on the coarsest level (hypre_BoomerAMGRelaxIF)
 void BoomerAMG::relax_sweeps(int level, int which, const double *f, bool u_is_zero) {
   const int type = p.relax_type[which];
-  const bool has_cf = !L[(size_t)level].cf.empty();
+  const bool has_cf = L[(size_t)level].has_cf;
   for (int sw = 0; sw < p.num_sweeps[which]; sw++) {
     const bool zero = u_is_zero && sw == 0;
     if (which == 2 || p.relax_order != 1 || !has_cf)

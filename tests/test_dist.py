@@ -30,17 +30,18 @@ def _run(nproc, mode, n, stencil, port, staging="host", seq=-1):
     return p.stdout
 
 
-@pytest.mark.parametrize("nproc,n,stencil,seq", [(2, 12, 7, -1), (3, 10, 27, 0), (2, 14, 7, 300)])
+@pytest.mark.parametrize("nproc,n,stencil,seq", [(2, 12, 7, -1), (3, 10, 27, 0), (2, 14, 7, 300),
+                                                  (4, 6, 7, 0)])  # last: coarse levels leave ranks without rows
 def test_host_setup_world_size_n_gloo(nproc, n, stencil, seq):
-    out = _run(nproc, "host", n, stencil, 29611 + nproc + (7 if seq > 0 else 0), seq=seq)
+    out = _run(nproc, "host", n, stencil, 29611 + nproc + (7 if seq > 0 else 0) + n, seq=seq)
     assert "dist host setup ok" in out
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("nproc,n,stencil,seq", [(2, 16, 7, -1), (4, 12, 7, 0), (3, 10, 27, 0), (3, 14, 7, 300),
-                                                  (4, 16, 7, 1000)])
+                                                  (4, 16, 7, 1000), (4, 6, 7, 0)])
 def test_device_solve_shared_gpu(nproc, n, stencil, seq):
-    out = _run(nproc, "solve", n, stencil, 29631 + nproc + (11 if seq > 0 else 0), seq=seq)
+    out = _run(nproc, "solve", n, stencil, 29651 + nproc + (11 if seq > 0 else 0) + n, seq=seq)
     assert "dist solve ok" in out
 
 
@@ -48,5 +49,5 @@ def test_device_solve_shared_gpu(nproc, n, stencil, seq):
 def test_device_solve_cuda_staged_transport():
     """bench.py's fallback transport (torch.distributed collectives on device tensors behind the callback
     interface), exercised here over gloo because two nccl ranks cannot share the one GPU of the test box."""
-    out = _run(2, "solve", 12, 7, 29651, staging="cuda")
+    out = _run(2, "solve", 12, 7, 29699, staging="cuda")
     assert "dist solve ok" in out
