@@ -426,6 +426,193 @@ __global__ __launch_bounds__(256) void gs_group_k(int n, int chunk0, int nchunks
 #undef UOLD
 }
 
+
+// ---------------------------------------------------------------------------
+// Hybrid Gauss-Seidel, dense-chunk formulation (the default for chunk = 8).
+//
+// gs_group_k above sweeps the 8 rows of a chunk with one cross-lane reduction and
+// one division per row and direction; counters showed its VALU pipes saturated
+// (955 VALU instructions per wave, 100 % busy) while HBM idled at ~2 TB/s.  Here
+// everything that does not depend on the sweep order leaves the serial part:
+//   * entries with a column outside the chunk multiply the snapshot of u: their
+//     8 row sums are reduced ONCE over the group by a reduce-scatter butterfly
+//     (8 -> 4 -> 2 -> 1 values per lane while the lane count halves) and serve the
+//     forward and the backward sweep;
+//   * entries inside the chunk (diagonal included) are scattered into a dense
+//     8x8 block in LDS, one block per chunk; owner lane t then holds row t of the
+//     block in registers;
+//   * rows longer than the preloaded strips are finished in the same pre-sweep
+//     phase (no slow path inside the sweep);
+//   * the sweep itself is 8 fused multiply-adds per row on the owner lanes, one
+//     multiplication by the precomputed w/d, and one broadcast of the new value.
+// ---------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_xchg(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// value of the partner lane for the exchange step with distance M inside an aligned group:
+// M = 1, 2: xor; 4: mirror inside 8 lanes; 8: mirror inside 16 lanes (both pair the two halves); 16, 32: xor
+template <int M>
+__device__ __forceinline__ double partner(double v) {
+  if (M == 1) return dpp_xchg<0xB1>(v);
+  if (M == 2) return dpp_xchg<0x4E>(v);
+  if (M == 4) return dpp_xchg<0x141>(v);
+  if (M == 8) return dpp_xchg<0x140>(v);
+  return __shfl_xor(v, M, 64);
+}
+
+// reduce-scatter step: NV values per lane -> NV/2; lanes whose bit M is clear keep the lower half of the rows
+template <int M, int NV>
+__device__ __forceinline__ void rs_step(double *p, int g) {
+  const bool hi = (g & M) != 0;
+#pragma unroll
+  for (int q = 0; q < NV / 2; q++) {
+    const double keep = hi ? p[NV / 2 + q] : p[q];
+    const double send = hi ? p[q] : p[NV / 2 + q];
+    p[q] = keep + partner<M>(send);
+  }
+}
+
+template <int LPC, int E>
+__global__ __launch_bounds__(256) void gs_dense_k(int n, int chunk0, int nchunks, const int *__restrict__ ia,
+                                                  const int *__restrict__ ja, const double *__restrict__ av,
+                                                  const signed char *__restrict__ cf, int points,
+                                                  const double *__restrict__ dd, const double *__restrict__ f,
+                                                  const double *__restrict__ offc,
+                                                  const double *__restrict__ u_lo,
+                                                  const double *__restrict__ u_hi, int split,
+                                                  double *__restrict__ u_new, int fwd, int bwd, double w) {
+#define UOLD(j) (((j) < split ? u_lo : u_hi)[(j)])
+  constexpr int R = 8;
+  constexpr int CPW = 64 / LPC;
+  constexpr int GPB = 256 / LPC;
+  __shared__ double Cs[GPB][R][R];
+  const int lane = threadIdx.x & 63;
+  const int g = lane & (LPC - 1);
+  const int gbase = lane & ~(LPC - 1);
+  const int grp = threadIdx.x / LPC;
+  const long long wave = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const long long c = chunk0 + wave * CPW + (lane / LPC);
+  const bool live = c < nchunks;
+  const int cs = live ? (int)(c * R) : 0;
+  const int len = live ? min(R, n - cs) : 0;
+
+  // owner lane g < len holds the state of row cs+g
+  double myu = 0.0, myrhs = 0.0, wd = 0.0;
+  int my_k0 = 0, my_k1 = 0;
+  if (g < len) {
+    const int i = cs + g;
+    my_k0 = ia[i];
+    const int a1 = ia[i + 1];
+    const int mark = (points != 0 && cf != nullptr) ? (int)cf[i] : points;
+    myu = UOLD(i);
+    const double myd = dd[i];
+    myrhs = f[i];
+    if (offc) myrhs -= offc[i];
+    const bool rowsel = (mark == points);
+    my_k1 = rowsel ? a1 : my_k0;  // unselected rows load nothing
+    if (rowsel && myd != 0.0) wd = w / myd;
+  }
+  {
+    double *blk = &Cs[grp][0][0];
+#pragma unroll
+    for (int q = g; q < R * R; q += LPC) blk[q] = 0.0;
+  }
+  int k0s[R], k1s[R];
+#pragma unroll
+  for (int t = 0; t < R; t++) {
+    k0s[t] = __shfl(my_k0, gbase + t, 64);
+    k1s[t] = __shfl(my_k1, gbase + t, 64);
+  }
+  double wv[R][E];
+  int cols[R][E];
+#pragma unroll
+  for (int t = 0; t < R; t++) {
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int k = k0s[t] + g + e * LPC;
+      const bool ok = k < k1s[t];
+      wv[t][e] = ok ? av[k] : 0.0;
+      cols[t][e] = ok ? ja[k] : -1;
+    }
+  }
+  __syncthreads();  // the blocks are zero before the scatter below
+  double p[R];
+#pragma unroll
+  for (int t = 0; t < R; t++) {
+    p[t] = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int j = cols[t][e];
+      const unsigned oo = (unsigned)(j - cs);
+      const bool inch = (j >= 0) && oo < (unsigned)len;
+      const double x = UOLD(j < 0 ? cs : j);  // unconditional gather: no load waits on a branch
+      if (inch)
+        Cs[grp][t][oo] = wv[t][e];
+      else
+        p[t] += wv[t][e] * x;
+    }
+    if (k1s[t] - k0s[t] > LPC * E) {  // the rest of a long row (uniform inside the group)
+      for (int k = k0s[t] + LPC * E + g; k < k1s[t]; k += LPC) {
+        const double a = av[k];
+        const int j = ja[k];
+        const unsigned oo = (unsigned)(j - cs);
+        if (oo < (unsigned)len)
+          Cs[grp][t][oo] = a;
+        else
+          p[t] += a * UOLD(j);
+      }
+    }
+  }
+  // row sums of the out-of-chunk part: reduce-scatter over the group, then the owners fetch theirs
+  rs_step<LPC / 2, 8>(p, g);
+  if (LPC >= 16) rs_step<(LPC >= 16 ? LPC / 4 : 1), 4>(p, g); else rs_step<2, 4>(p, g);
+  if (LPC >= 32) rs_step<(LPC >= 32 ? LPC / 8 : 1), 2>(p, g); else if (LPC == 16) rs_step<2, 2>(p, g); else rs_step<1, 2>(p, g);
+  double S = p[0];  // full sum of row g / (LPC / 8) once the low bits are folded in
+  if (LPC >= 16) {
+    S += partner<1>(S);
+    if (LPC >= 32) S += partner<2>(S);
+    if (LPC >= 64) S += partner<4>(S);
+  }
+  if (LPC > 8) S = __shfl(S, gbase + (g & 7) * (LPC / 8), 64);
+  __syncthreads();  // the dense blocks are complete
+  double crow[R], uc[R];
+  {
+    const int r = g & 7;
+#pragma unroll
+    for (int j = 0; j < R; j++) crow[j] = Cs[grp][r][j];
+  }
+#pragma unroll
+  for (int j = 0; j < R; j++) uc[j] = __shfl(myu, gbase + j, 64);
+#pragma unroll
+  for (int dir = 0; dir < 2; dir++) {
+    if (dir == 0 ? !fwd : !bwd) continue;
+#pragma unroll
+    for (int tt = 0; tt < R; tt++) {
+      const int t = (dir == 0) ? tt : R - 1 - tt;
+      double s = S;
+#pragma unroll
+      for (int j = 0; j < R; j++) s += crow[j] * uc[j];
+      const double nu = myu + (myrhs - s) * wd;  // unselected rows: wd == 0
+      double b;
+      if (LPC == 64) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(nu), t);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(nu), t);
+        b = __hiloint2double(hi, lo);
+      } else {
+        b = __shfl(nu, gbase + t, 64);
+      }
+      uc[t] = b;
+      if (g == t) myu = b;
+    }
+  }
+  if (g < len) u_new[cs + g] = myu;
+#undef UOLD
+}
+
 // ---------------------------------------------------------------------------
 // BLAS-1
 // ---------------------------------------------------------------------------
@@ -685,6 +872,14 @@ std::vector<int> build_row_blocks(int nrows, const int64_t *ia) {
   return rb;
 }
 
+static bool gs_use_old() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("MI_HYPRE_GS_OLD");
+    v = (e && atoi(e)) ? 1 : 0;
+  }
+  return v == 1;
+}
 static bool gs_force_generic() {
   static int v = -1;
   if (v < 0) {
@@ -768,24 +963,34 @@ void gs_hybrid(const DevCSR &A, const double *u_lo, const double *u_hi, int spli
   if (chunk == 8 && !gs_force_generic()) {
     const double avg = (double)A.nnz / (double)A.nrows;
     const int p95 = A.rowlen_p95;
-#define GS_LAUNCH(LPC, E)                                                                                       \
+#define GS_LAUNCH_K(KERNEL, LPC, E)                                                                             \
   {                                                                                                             \
     const long long waves = (nch + (64 / LPC) - 1) / (64 / LPC);                                                \
-    hipLaunchKernelGGL((gs_group_k<LPC, E>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, A.nrows,       \
-                       (int)c0, (int)c1, A.ia.p, A.ja.p, A.a.p, cf, points, d, f, offc, u_lo, u_hi, split, out,  \
-                       fwd ? 1 : 0, bwd ? 1 : 0, w);                                                                         \
+    hipLaunchKernelGGL((KERNEL<LPC, E>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, A.nrows, (int)c0,   \
+                       (int)c1, A.ia.p, A.ja.p, A.a.p, cf, points, d, f, offc, u_lo, u_hi, split, out,          \
+                       fwd ? 1 : 0, bwd ? 1 : 0, w);                                                            \
   }
-    // lanes per chunk from the mean row length, strips so that ~95 % of the rows
-    // are fully preloaded (the rest take the in-sweep path)
+#define GS_LAUNCH(LPC, E) \
+  if (gs_use_old()) GS_LAUNCH_K(gs_group_k, LPC, E) else GS_LAUNCH_K(gs_dense_k, LPC, E)
+    // Measured per level (256^3 / 512^3 Laplacian hierarchies, profiles/compare_gs.*):
+    //   mean row length <= 8 (the fine level): the shuffle kernel with 8 lanes per chunk is memory-bound
+    //   already (3.9 TB/s) and beats the dense-chunk kernel, whose barriers and LDS block it does not need;
+    //   longer rows: the dense-chunk kernel wins 10-18 %; for means up to 32 two chunks per wave (32 lanes
+    //   each, rows beyond 32 entries finished in the pre-sweep loop) beat one chunk per wave.
     if (avg <= 8.0) {
-      if (p95 <= 8) GS_LAUNCH(8, 1) else GS_LAUNCH(8, 2)
+      if (p95 <= 8) GS_LAUNCH_K(gs_group_k, 8, 1) else GS_LAUNCH_K(gs_group_k, 8, 2)
     } else if (avg <= 16.0) {
       if (p95 <= 16) GS_LAUNCH(16, 1) else GS_LAUNCH(16, 2)
     } else if (avg <= 32.0) {
-      if (p95 <= 32) GS_LAUNCH(32, 1) else GS_LAUNCH(64, 1)  // measured: <64,1> beats <32,2> by ~6 % on level 1
+      if (gs_use_old()) {
+        if (p95 <= 32) GS_LAUNCH_K(gs_group_k, 32, 1) else GS_LAUNCH_K(gs_group_k, 64, 1)
+      } else {
+        if (p95 <= 64) GS_LAUNCH_K(gs_dense_k, 32, 1) else GS_LAUNCH_K(gs_dense_k, 32, 2)
+      }
     } else {
       if (p95 <= 64) GS_LAUNCH(64, 1) else if (p95 <= 128) GS_LAUNCH(64, 2) else GS_LAUNCH(64, 4)
     }
+#undef GS_LAUNCH_K
 #undef GS_LAUNCH
   } else {
     const size_t lds = (size_t)chunk * GS_BLOCK * sizeof(double);
