@@ -446,6 +446,13 @@ __global__ __launch_bounds__(256) void gs_group_k(int n, int chunk0, int nchunks
 //   * the sweep itself is 8 fused multiply-adds per row on the owner lanes, one
 //     multiplication by the precomputed w/d, and one broadcast of the new value.
 // ---------------------------------------------------------------------------
+// LDS accesses of one wave are processed in issue order; this only keeps the compiler from moving them
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int CTRL>
 __device__ __forceinline__ double dpp_xchg(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -539,7 +546,7 @@ __global__ __launch_bounds__(256) void gs_dense_k(int n, int chunk0, int nchunks
       cols[t][e] = ok ? ja[k] : -1;
     }
   }
-  __syncthreads();  // the blocks are zero before the scatter below
+  wave_sync_lds();  // the block is zero before the scatter below (a chunk's block is private to its wave)
   double p[R];
 #pragma unroll
   for (int t = 0; t < R; t++) {
@@ -578,7 +585,7 @@ __global__ __launch_bounds__(256) void gs_dense_k(int n, int chunk0, int nchunks
     if (LPC >= 64) S += partner<4>(S);
   }
   if (LPC > 8) S = __shfl(S, gbase + (g & 7) * (LPC / 8), 64);
-  __syncthreads();  // the dense blocks are complete
+  wave_sync_lds();  // the dense block is complete
   double crow[R], uc[R];
   {
     const int r = g & 7;
