@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstring>
 
+#include "HYPRE_parcsr_ls.h"
 #include "kernels.hpp"
 #include "solvers.hpp"
 
@@ -25,6 +26,25 @@ void KrylovSolver::apply_precond(ParCSR &A, ParVector &rhs, ParVector &out) {
   }
 }
 
+// The BoomerAMG preconditioner works in its own (C-first) ordering of level 0 and gathers / scatters its
+// argument on every call.  When GMRES is bound to it in the usual way (solverPrecondPtr_ with
+// HYPRE_BoomerAMGSolve, one cycle, zero tolerance -- src/HypreSystem.cpp:687, :154-155) the Krylov loop runs
+// in that ordering instead: b and x are permuted once per solve, the matvec uses the level-0 copy of the
+// operator, and a preconditioner application is one cycle on the Krylov vector itself -- no gather, no
+// scatter, no copy.  Inner products only change their summation order.  MI_HYPRE_GMRES_PERMUTED=0 disables it.
+BoomerAMG *KrylovSolver::amg_in_level_order(ParCSR &A, int n) const {
+  static const bool enabled = !(getenv("MI_HYPRE_GMRES_PERMUTED") && atoi(getenv("MI_HYPRE_GMRES_PERMUTED")) == 0);
+  if (!enabled || !precond_data) return nullptr;
+  if (precond_solve != reinterpret_cast<ParSolverFcn>(&HYPRE_BoomerAMGSolve)) return nullptr;
+  SolverBase *sb = static_cast<SolverBase *>(precond_data);
+  if (sb->kind != SolverBase::K_AMG) return nullptr;
+  BoomerAMG &amg = static_cast<AmgSolver *>(sb)->amg;
+  if (!amg.is_setup || amg.p.max_iter != 1 || amg.p.tol != 0.0 || amg.L.empty()) return nullptr;
+  AmgLevel &L0 = amg.L[0];
+  if (L0.perm.empty() || L0.A == &A || L0.n != n || !L0.A->on_device) return nullptr;
+  return &amg;
+}
+
 void GmresSolver::setup(ParCSR &A, ParVector &b, ParVector &x) {
   ensure_init();
   MI_REQUIRE(b.ncomp == 1 && x.ncomp == 1, "GMRES: multi-component vectors are not supported");
@@ -35,22 +55,22 @@ void GmresSolver::setup(ParCSR &A, ParVector &b, ParVector &x) {
   if (precond_setup) precond_setup(precond_data, &A, &b, &x);
 }
 
-int GmresSolver::solve(ParCSR &A, ParVector &b, ParVector &x) {
+int GmresSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
   ensure_init();
   Ctx &c = ctx();
   Comm &comm = current_comm();
   hipStream_t s = c.stream;
   const double t_start = wall_time();
-  const int n = b.n;
+  const int n = b_in.n;
   const int kd = k_dim < 1 ? 1 : k_dim;
   MI_REQUIRE(kd + 2 <= (ortho > 1 ? 120 : 250), "GMRES: k_dim too large for the device scalar slots");
   MI_REQUIRE(ortho >= 0 && ortho <= 2, "GMRES: orthogonalisation must be 0 (MGS), 1 or 2 (classical passes)");
-  if (r.n != n) setup(A, b, x);
+  if (r.n != n) setup(A_in, b_in, x_in);
   const double epsmac = 1.e-16;
   auto basis = [&](int i) -> ParVector & {
     while ((int)p.size() <= i) {
       std::unique_ptr<ParVector> v(new ParVector());
-      v->init(b.start, b.end, 1);
+      v->init(b_in.start, b_in.end, 1);
       p.push_back(std::move(v));
     }
     return *p[(size_t)i];
@@ -58,7 +78,7 @@ int GmresSolver::solve(ParCSR &A, ParVector &b, ParVector &x) {
   auto zvec = [&](int i) -> ParVector & {
     while ((int)z.size() <= i) {
       std::unique_ptr<ParVector> v(new ParVector());
-      v->init(b.start, b.end, 1);
+      v->init(b_in.start, b_in.end, 1);
       z.push_back(std::move(v));
     }
     return *z[(size_t)i];
@@ -66,6 +86,42 @@ int GmresSolver::solve(ParCSR &A, ParVector &b, ParVector &x) {
   std::vector<double> cs((size_t)kd + 1, 0.0), sn((size_t)kd + 1, 0.0), rs((size_t)kd + 1, 0.0);
   std::vector<std::vector<double>> hh((size_t)kd + 1, std::vector<double>((size_t)kd, 0.0));
   double *slots = c.red_out.p;
+
+  // level ordering of the AMG preconditioner (see amg_in_level_order)
+  BoomerAMG *amg = amg_in_level_order(A_in, n);
+  if (amg) {
+    if (bp.n != n) {
+      bp.init(b_in.start, b_in.end, 1);
+      xp.init(b_in.start, b_in.end, 1);
+    }
+    k::gather(b_in.data(), amg->L[0].d_perm.p, bp.data(), n, s);
+    k::gather(x_in.data(), amg->L[0].d_perm.p, xp.data(), n, s);
+  }
+  ParCSR &A = amg ? *amg->L[0].A : A_in;
+  ParVector &b = amg ? bp : b_in;
+  ParVector &x = amg ? xp : x_in;
+  // out = M^-1 rhs; returns where the result lives (the AMG's own level vector on the fast path unless a
+  // copy is asked for)
+  auto precond = [&](ParVector &rhs, ParVector &out, bool need_copy) -> const double * {
+    if (!amg) {
+      apply_precond(A, rhs, out);
+      return out.data();
+    }
+    AmgLevel &L0 = amg->L[0];
+    double *own_f = L0.f.p;
+    L0.f.p = rhs.data();  // read-only inside the cycle
+    k::fill(L0.u.p, n, 0.0, s);
+    try {
+      amg->cycle(0, true);
+    } catch (...) {
+      L0.f.p = own_f;
+      throw;
+    }
+    L0.f.p = own_f;
+    if (!need_copy) return L0.u.p;
+    k::copy(L0.u.p, out.data(), n, s);
+    return out.data();
+  };
 
   ParVector &p0 = basis(0);
   A.matvec(comm, -1.0, x.data(), 1.0, b.data(), p0.data(), s, k::PROF_SPMV_L0);
@@ -108,8 +164,8 @@ int GmresSolver::solve(ParCSR &A, ParVector &b, ParVector &x) {
       ParVector &pi = basis(i);
       ParVector &pim1 = basis(i - 1);
       ParVector &dir = flexible ? zvec(i - 1) : r;  // M^-1 p_{i-1}
-      apply_precond(A, pim1, dir);
-      A.matvec(comm, 1.0, dir.data(), 0.0, nullptr, pi.data(), s, k::PROF_SPMV_L0);
+      const double *mp = precond(pim1, dir, flexible);
+      A.matvec(comm, 1.0, mp, 0.0, nullptr, pi.data(), s, k::PROF_SPMV_L0);
       if (ortho == 0) {
         // modified Gram-Schmidt with the axpy of step j-1 fused into the dot of step j
         // (and the last axpy into the norm): h_j = <p_j, w>, w -= h_j p_j, one pass each
@@ -189,8 +245,8 @@ int GmresSolver::solve(ParCSR &A, ParVector &b, ParVector &x) {
       k::copy(basis(i - 1).data(), w.data(), n, s);
       k::scale(y[(size_t)i - 1], w.data(), n, s);
       for (int j = i - 2; j >= 0; j--) k::axpy(y[(size_t)j], basis(j).data(), w.data(), n, s);
-      apply_precond(A, w, r);
-      k::axpy(1.0, r.data(), x.data(), n, s);
+      const double *mw = precond(w, r, false);
+      k::axpy(1.0, mw, x.data(), n, s);
     }
     if (r_norm <= eps && iter >= min_iter) {
       A.matvec(comm, -1.0, x.data(), 1.0, b.data(), r.data(), s, k::PROF_SPMV_L0);
@@ -223,6 +279,7 @@ int GmresSolver::solve(ParCSR &A, ParVector &b, ParVector &x) {
       k::axpy(1.0, basis(i).data(), basis(0).data(), n, s);
     }
   }
+  if (amg) k::scatter_set(x_in.data(), amg->L[0].d_perm.p, xp.data(), n, s);
   MI_HIP(hipStreamSynchronize(s));
   num_iterations = iter;
   rel_residual_norm = (b_norm > 0.0) ? r_norm / b_norm : r_norm;

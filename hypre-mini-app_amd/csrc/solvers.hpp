@@ -30,6 +30,8 @@ struct KrylovSolver : SolverBase {
   double solve_seconds = 0.0;
   explicit KrylovSolver(Kind k) : SolverBase(k) {}
   void apply_precond(ParCSR &A, ParVector &rhs, ParVector &out);
+  // the BoomerAMG behind precond_solve when the Krylov loop may run in its level-0 ordering (krylov.cpp)
+  BoomerAMG *amg_in_level_order(ParCSR &A, int n) const;
 };
 
 struct GmresSolver : KrylovSolver {
@@ -43,6 +45,7 @@ struct GmresSolver : KrylovSolver {
   int ortho = 0;
   std::vector<std::unique_ptr<ParVector>> z;
   ParVector r, w;
+  ParVector bp, xp;  // b and x in the preconditioner's level-0 ordering (fast path)
   GmresSolver() : KrylovSolver(K_GMRES) {}
   void setup(ParCSR &A, ParVector &b, ParVector &x);
   int solve(ParCSR &A, ParVector &b, ParVector &x);
