@@ -46,7 +46,7 @@ def stats(src, out):
         f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu\n")
         f.write("#   (laplace_3d 512^3 7-pt, GMRES(50)+BoomerAMG, 1x MI355X; setup kernels + 3 solves in the trace)\n")
         f.write("# per (kernel, grid size) = per AMG level: calls, mean us, total ms, share of GPU time\n")
-        f.write("# spmv_stream<0, 1> = the level-0 operator in the caller ordering (GMRES matvec): the kernel bench.py reports as \"roofline\"\n")
+        f.write("# spmv_stream<0, 1> = the level-0 operator of the GMRES loop (C-first ordering of level 0): the kernel bench.py reports as \"roofline\"\n")
         for (name, grid), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             if us / total < 2e-4:
                 continue
