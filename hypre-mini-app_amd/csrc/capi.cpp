@@ -1152,10 +1152,30 @@ static const HostCSR &level_csr(AmgSolver *a, int level, int which) {
 HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSRSize(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int which, HYPRE_Int *nrows,
                                             HYPRE_Int *ncols, HYPRE_BigInt *nnz) {
   API_BEGIN
-  const HostCSR &c = level_csr(AMG(solver), level, which);
-  *nrows = c.nrows;
-  *ncols = c.ncols;
-  *nnz = c.nnz();
+  // sizes come from the level's metadata: no host copy of a device-resident level is made for them
+  AmgLevel &L = level_ref(AMG(solver), level);
+  const ParCSR *M = nullptr;
+  switch (which) {
+    case 0:
+    case 1: M = L.A; break;
+    case 2:
+    case 4: M = L.Pm.get(); break;
+    case 3:
+    case 5: M = L.Rm.get(); break;
+    default: fail(HYPRE_ERROR_ARG, "which must be 0..5");
+  }
+  if (!M) {
+    *nrows = *ncols = 0;
+    *nnz = 0;
+  } else if (which == 0 || which == 2 || which == 3) {
+    *nrows = M->diag.nrows;
+    *ncols = M->diag.ncols;
+    *nnz = M->diag_nnz();
+  } else {
+    *nrows = M->offd.nrows;
+    *ncols = M->offd.ncols;
+    *nnz = M->offd.nnz();
+  }
   API_END
 }
 HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSR(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int which, HYPRE_BigInt *ia,
