@@ -25,10 +25,10 @@ def short(name):
 
 
 def find(d, suffix):
-    f = sorted(glob.glob(os.path.join(d, "*", "*" + suffix)))
+    f = sorted(glob.glob(os.path.join(d, "*", "*" + suffix)), key=os.path.getmtime)
     if not f:
         raise SystemExit(f"no {suffix} under {d}")
-    return f[-1]
+    return f[-1]  # the most recent run
 
 
 def stats(src, out):
