@@ -42,7 +42,7 @@ struct AmgLevel {
   // level / next level, columns: next level / this level), diag + halo blocks
   std::unique_ptr<ParCSR> Pm, Rm;
   // device copies (natural ordering) kept between the Galerkin product and the C-first renumbering
-  sk::DCsr sA, sP;
+  sk::DCsr sA, sP, sR;  // sR: only in the global hierarchy of the replicated setup (sliced on the device)
   // C-first ordered operators of a level built on the device, until setup_device moves them into the
   // solve-phase format (A->d_diag, Pm->d_diag, Rm->d_diag)
   sk::DCsr oA, oP, oR;
@@ -73,7 +73,8 @@ struct BoomerAMG {
   // levels with at least this many rows run their sparse products / transposes / renumbering on the
   // device; -1 = everything on host threads (HYPRE_MI_BoomerAMGSetupHostOnly)
   long long device_min_rows = -1;
-  bool keep_natural_R = false;  // the replicated multi-rank setup slices R in natural ordering
+  bool keep_natural_R = false;  // the replicated multi-rank setup slices A, P and R = P^T in natural ordering:
+                                // device-built levels keep them on the device (sA, sP, sR), host-built ones on the host
   double t_setup_start = 0.0;
   double t_phase[6] = {0, 0, 0, 0, 0, 0};  // strength, pmis, interp, galerkin, ordering, host total
   int num_iterations = 0;

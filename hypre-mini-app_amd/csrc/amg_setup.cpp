@@ -809,13 +809,10 @@ void BoomerAMG::build_natural(ParCSR &A0) {
       if (p.interp_type == 6 || p.interp_type == 0)
         p_on_device = sk::interp(Lv.sA, dS, dcf, p.interp_type, p.trunc_factor, p.pmax_elmts, Lv.sP, nc, s);
       if (p_on_device) {
-        if (keep_natural_R) {
-          Lv.sP.download(Lv.P, s);
-        } else {  // stays on the device; the dimensions are all the host needs
-          Lv.P = HostCSR();
-          Lv.P.nrows = n;
-          Lv.P.ncols = nc;
-        }
+        // stays on the device; the dimensions are all the host needs
+        Lv.P = HostCSR();
+        Lv.P.nrows = n;
+        Lv.P.ncols = nc;
         MI_HIP(hipMemcpyAsync(cf.data(), dcf.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
         MI_HIP(hipStreamSynchronize(s));
       } else {
@@ -848,15 +845,15 @@ void BoomerAMG::build_natural(ParCSR &A0) {
       // C-first renumbering
       hipStream_t s = ctx().stream;
       if (!p_on_device) Lv.sP.upload(Lv.P, s);
-      sk::DCsr dR, dAP;
+      sk::DCsr dR_local, dAP;
+      sk::DCsr &dR = keep_natural_R ? Lv.sR : dR_local;  // the replicated setup slices R on the device later
       sk::transpose(Lv.sP, dR, s);
-      if (keep_natural_R) dR.download(Lv.R, s);
       sk::spgemm(Lv.sA, Lv.sP, dAP, s);
       L.emplace_back();  // the coarse operator is born on the device (L was reserved: references stay valid)
       sk::DCsr &dAc = L[(size_t)l + 1].sA;
       sk::spgemm(dR, dAP, dAc, s);
-      if (keep_natural_R || nc < device_min_rows) {
-        dAc.download(An->diag, s);  // the next level (or the multi-rank slicing) works on host arrays
+      if (nc < device_min_rows) {
+        dAc.download(An->diag, s);  // the next level is built by the host routines
       } else {
         An->diag.nrows = An->diag.ncols = nc;
         An->host_diag_stale = true;
@@ -1193,6 +1190,13 @@ void BoomerAMG::build_replicated(ParCSR &A0) {
   g.use_private_self_comm();
   g.build_natural(*Ag);
   const bool has_tail = g.stopped_by_rows && g.L.size() >= 2;
+  if (g.L[0].sA.ia.p && g.L[0].sA.nrows == (int)N) {  // level 0 lives on the device: drop the host copy
+    HostCSR &G0 = Ag->diag;
+    std::vector<int64_t>().swap(G0.ia);
+    std::vector<int>().swap(G0.ja);
+    std::vector<double>().swap(G0.a);
+    Ag->host_diag_stale = true;
+  }
   for (int q = 0; q < 4; q++) t_phase[q] = g.t_phase[q];
   tp0 = wall_time();
   const size_t nlev = g.L.size();
@@ -1238,7 +1242,28 @@ void BoomerAMG::build_replicated(ParCSR &A0) {
     const gidx r0 = starts[l][(size_t)rank], r1 = starts[l][(size_t)rank + 1];
     const int nloc = (int)(r1 - r0);
     const int *rows_old = perm[l].data() + r0;
-    Lv.A_own = slice_rows(G.A->diag, rows_old, nloc, pos[l].data(), starts[l], starts[l], rank);
+    hipStream_t s = ctx().stream;
+    // a level the device built is sliced there (this rank's rows, columns renumbered, re-sorted) and only the
+    // slice comes to the host; host-built levels are sliced from their host arrays
+    auto slice = [&](sk::DCsr &dev, const HostCSR &host, bool host_ok, const int *rows, int nrows_loc,
+                     const std::vector<int> &colpos, const std::vector<gidx> &rstarts,
+                     const std::vector<gidx> &cstarts) -> std::unique_ptr<ParCSR> {
+      if (dev.ia.p && dev.nnz > 0) {
+        DVec<int> d_rows, d_pos;
+        d_rows.upload(std::vector<int>(rows, rows + nrows_loc));
+        d_pos.upload(colpos);
+        sk::DCsr mine;
+        sk::extract_rows(dev, d_rows.p, nrows_loc, d_pos.p, mine, s);
+        HostCSR local;
+        mine.download(local, s);
+        std::vector<int> iota((size_t)nrows_loc);
+        for (int q = 0; q < nrows_loc; q++) iota[(size_t)q] = q;
+        return slice_rows(local, iota.data(), nrows_loc, nullptr, rstarts, cstarts, rank);
+      }
+      MI_REQUIRE(host_ok, "replicated setup: a level has neither device nor host arrays");
+      return slice_rows(host, rows, nrows_loc, colpos.data(), rstarts, cstarts, rank);
+    };
+    Lv.A_own = slice(G.sA, G.A->diag, !G.A->host_diag_stale, rows_old, nloc, pos[l], starts[l], starts[l]);
     Lv.A = Lv.A_own.get();
     Lv.A->build_halo_plan(comm);
     Lv.has_cf = !G.cf.empty();
@@ -1252,13 +1277,16 @@ void BoomerAMG::build_replicated(ParCSR &A0) {
         Lv.nc += (Lv.cf[(size_t)q] == C_PT);
       }
       // P: my fine rows x coarse columns; R = P^T: my coarse rows x fine columns
-      Lv.Pm = slice_rows(G.P, rows_old, nloc, pos[l + 1].data(), starts[l], starts[l + 1], rank);
+      Lv.Pm = slice(G.sP, G.P, !G.P.ia.empty(), rows_old, nloc, pos[l + 1], starts[l], starts[l + 1]);
       // with a redundant tail the coarse correction is whole on every rank: no exchange for the last P
       if (!(has_tail && l + 2 == nlev)) Lv.Pm->build_halo_plan(comm);
       const gidx c0 = starts[l + 1][(size_t)rank], c1 = starts[l + 1][(size_t)rank + 1];
-      Lv.Rm = slice_rows(G.R, perm[l + 1].data() + c0, (int)(c1 - c0), pos[l].data(), starts[l + 1], starts[l], rank);
+      Lv.Rm = slice(G.sR, G.R, !G.R.ia.empty(), perm[l + 1].data() + c0, (int)(c1 - c0), pos[l], starts[l + 1], starts[l]);
       Lv.Rm->build_halo_plan(comm);
     }
+    G.sP.release();
+    G.sR.release();
+    if (!(has_tail && l + 1 == nlev)) G.sA.release();
     // the global level is not needed any more (the tail's fine level is)
     if (has_tail && l + 1 == nlev && G.A_own)
       tail_A = std::move(G.A_own);
@@ -1272,7 +1300,14 @@ void BoomerAMG::build_replicated(ParCSR &A0) {
     MI_REQUIRE(tail_A != nullptr, "replicated setup: the redundant level was not kept");
     // levels nlev-1 .. : one single-rank hierarchy per rank, built by the ordinary pipeline on the
     // (global, natural-order) operator of the first redundant level
-    if (tail_A->host_diag_stale) fail(1, "replicated setup: the redundant level has no host arrays");
+    if (tail_A->host_diag_stale) {
+      const int nr = tail_A->diag.nrows, ncl = tail_A->diag.ncols;
+      g.L.back().sA.download(tail_A->diag, ctx().stream);
+      tail_A->diag.nrows = nr;
+      tail_A->diag.ncols = ncl;
+      tail_A->host_diag_stale = false;
+    }
+    g.L.back().sA.release();
     tail.reset(new BoomerAMG());
     tail->p = p;
     tail->p.print_level = 0;

@@ -1377,5 +1377,29 @@ void permute(const DCsr &A, const int *perm, const int *colpos, DCsr &B, hipStre
   MI_HIP(hipStreamSynchronize(s));
 }
 
+void extract_rows(const DCsr &A, const int *rows, int nout, const int *colpos, DCsr &B, hipStream_t s) {
+  B.release();
+  B.nrows = nout;
+  B.ncols = A.ncols;
+  B.ia.alloc((size_t)nout + 1);
+  DVec<int> len((size_t)nout);
+  if (nout) perm_len_k<<<(unsigned)((nout + BLK - 1) / BLK), BLK, 0, s>>>(nout, A.ia.p, rows, len.p);
+  exclusive_scan(len.p, B.ia.p, nout, s);
+  long long total = 0;
+  MI_HIP(hipMemcpyAsync(&total, B.ia.p + nout, sizeof(long long), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+  B.nnz = total;
+  B.ja.alloc((size_t)total);
+  B.a.alloc((size_t)total);
+  if (total == 0) return;
+  DVec<int> tj((size_t)total);
+  DVec<double> ta((size_t)total);
+  perm_copy_k<<<(unsigned)(((long long)nout * 8 + BLK - 1) / BLK), BLK, 0, s>>>(nout, A.ia.p, A.ja.p, A.a.p, rows, colpos,
+                                                                                B.ia.p, tj.p, ta.p);
+  sort_rows(nout, total, B.ia.p, tj.p, ta.p, B.ja.p, B.a.p, s);
+  MI_HIP(hipGetLastError());
+  MI_HIP(hipStreamSynchronize(s));
+}
+
 }  // namespace sk
 }  // namespace mi

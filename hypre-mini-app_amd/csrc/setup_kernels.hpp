@@ -57,6 +57,10 @@ void transpose(const DCsr &A, DCsr &T, hipStream_t s);
 // columns mapped through colpos (null = identity) and re-sorted ascending
 void permute(const DCsr &A, const int *perm, const int *colpos, DCsr &B, hipStream_t s);
 
+// B = the nout rows rows[0..nout) of A (any subset, any order) with columns mapped through colpos (null =
+// identity) and re-sorted ascending -- this rank's slice of a global level in the replicated multi-rank setup
+void extract_rows(const DCsr &A, const int *rows, int nout, const int *colpos, DCsr &B, hipStream_t s);
+
 // Solve-phase format of a setup-phase matrix, built on the device: 32-bit row pointers, the row-block
 // schedule and x cache of the SpMV (DevCSR::upload builds the same from host arrays).  src's column and
 // value arrays are MOVED into dst; only the row pointers travel to the host (for the greedy block schedule).

@@ -17,8 +17,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
 
 
-def _run(nproc, mode, n, stencil, port, staging="host", seq=-1):
+def _run(nproc, mode, n, stencil, port, staging="host", seq=-1, devmin=None):
     env = dict(os.environ)
+    if devmin is not None:  # levels with at least this many rows are built (and sliced) on the device
+        env["MI_HYPRE_DEVICE_SETUP_MIN_ROWS"] = str(devmin)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["MI_HYPRE_HOST_THREADS"] = "2"
     env["OMP_NUM_THREADS"] = "1"
@@ -42,6 +44,15 @@ def test_host_setup_world_size_n_gloo(nproc, n, stencil, seq):
                                                   (4, 16, 7, 1000), (4, 6, 7, 0)])
 def test_device_solve_shared_gpu(nproc, n, stencil, seq):
     out = _run(nproc, "solve", n, stencil, 29651 + nproc + (11 if seq > 0 else 0) + n, seq=seq)
+    assert "dist solve ok" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,n,stencil,seq", [(2, 16, 7, -1), (3, 14, 7, 300), (4, 12, 27, 0)])
+def test_device_setup_and_slicing_shared_gpu(nproc, n, stencil, seq):
+    """Every level of the global hierarchy built on the device and sliced there (the production path for
+    large problems; the small grids of the other tests stay below the device threshold)."""
+    out = _run(nproc, "solve", n, stencil, 29731 + nproc + n, seq=seq, devmin=0)
     assert "dist solve ok" in out
 
 
