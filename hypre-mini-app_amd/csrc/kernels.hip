@@ -146,8 +146,10 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream_xc(int nb, int xchunk,
                                                              const unsigned short *__restrict__ lcol,
                                                              const double *__restrict__ x, double *__restrict__ y,
                                                              EpiArgs e) {
+  // one 16 KB array serves first as the x cache and then as the product buffer (the products wait in
+  // registers across the barrier in between): twice the workgroups per CU of two separate arrays
   __shared__ double prod[SPMV_TILE];
-  __shared__ double xs[SPMV_TILE];
+  double *xs = prod;
   const int blk = xcd_remap(blockIdx.x, xchunk);
   if (blk >= nb) return;
   const int tid = threadIdx.x;
@@ -185,8 +187,17 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream_xc(int nb, int xchunk,
     if (k < cnt) {
       const bool ok0 = (base_al + k >= base);
       const bool ok1 = (base_al + k + 1 < end);
-      prod[k] = ok0 ? vv[it].x * xs[cc[it].x] : 0.0;
-      prod[k + 1] = ok1 ? vv[it].y * xs[cc[it].y] : 0.0;
+      vv[it].x = ok0 ? vv[it].x * xs[cc[it].x] : 0.0;
+      vv[it].y = ok1 ? vv[it].y * xs[cc[it].y] : 0.0;
+    }
+  }
+  __syncthreads();  // every x-cache read is done: the array becomes the product buffer
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    const int k = 2 * tid + it * 2 * SPMV_BLOCK;
+    if (k < cnt) {
+      prod[k] = vv[it].x;
+      prod[k + 1] = vv[it].y;
     }
   }
   __syncthreads();
