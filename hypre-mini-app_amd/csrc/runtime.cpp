@@ -115,7 +115,7 @@ void DevCSR::upload(const HostCSR &h) {
   rb.upload(blocks);
   // x cache: worth it when a block's entries share columns (long rows); the fine
   // level's short rows gather coalesced already
-  static const int xc_min = getenv("MI_HYPRE_XCACHE_MIN") ? atoi(getenv("MI_HYPRE_XCACHE_MIN")) : 12;
+  static const int xc_min = getenv("MI_HYPRE_XCACHE_MIN") ? atoi(getenv("MI_HYPRE_XCACHE_MIN")) : 3;
   xcache = nrows > 0 && (double)nnz / (double)nrows >= (double)xc_min;
   if (xcache) {
     std::vector<int> up((size_t)nblocks + 1, 0);

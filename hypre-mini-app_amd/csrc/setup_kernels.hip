@@ -1110,7 +1110,7 @@ void to_solve_format(DCsr &src, DevCSR &dst, hipStream_t s) {
   dst.rb.upload(blocks);
   dst.ja = std::move(src.ja);
   dst.a = std::move(src.a);
-  static const int xc_min = getenv("MI_HYPRE_XCACHE_MIN") ? atoi(getenv("MI_HYPRE_XCACHE_MIN")) : 12;
+  static const int xc_min = getenv("MI_HYPRE_XCACHE_MIN") ? atoi(getenv("MI_HYPRE_XCACHE_MIN")) : 3;
   dst.xcache = n > 0 && (double)dst.nnz / (double)n >= (double)xc_min;
   if (dst.xcache) {
     const int nb = dst.nblocks;
