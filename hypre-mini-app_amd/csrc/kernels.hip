@@ -187,8 +187,8 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream_xc(int nb, int xchunk,
     if (k < cnt) {
       const bool ok0 = (base_al + k >= base);
       const bool ok1 = (base_al + k + 1 < end);
-      vv[it].x = ok0 ? vv[it].x * xs[cc[it].x] : 0.0;
-      vv[it].y = ok1 ? vv[it].y * xs[cc[it].y] : 0.0;
+      vv[it].x = ok0 ? vv[it].x * xs[cc[it].x & XC_ID_MASK] : 0.0;
+      vv[it].y = ok1 ? vv[it].y * xs[cc[it].y & XC_ID_MASK] : 0.0;
     }
   }
   __syncthreads();  // every x-cache read is done: the array becomes the product buffer
@@ -631,6 +631,149 @@ __global__ __launch_bounds__(256) void gs_dense_k(int n, int chunk0, int nchunks
 #undef UOLD
 }
 
+
+// ---------------------------------------------------------------------------
+// Hybrid Gauss-Seidel on the SpMV tiles (levels with an x cache).
+//
+// The chunk kernels above read the matrix row by row and gather u through L1;
+// on the coarse levels they wait on memory most of the time (53 % L1 misses,
+// 2 TB/s).  This kernel reads like spmv_stream_xc -- one workgroup per tile of
+// <= 256 rows / < 2048 entries, matrix stream in aligned pairs, the tile's
+// unique columns gathered once (coalesced) into LDS -- and then sweeps the
+// tile's chunks: 8 lanes per chunk, lane g owns row g, sums its out-of-chunk
+// products out of LDS, picks its in-chunk coefficients by the code bits of the
+// 16-bit column entries, and runs the dense 8x8 sweep of gs_dense_k.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(SPMV_BLOCK) void gs_tile_k(int blk0, int nblk, const int *__restrict__ rb,
+                                                        const int *__restrict__ ia, const double *__restrict__ av,
+                                                        const int *__restrict__ uptr, const int *__restrict__ ucols,
+                                                        const unsigned short *__restrict__ lcol,
+                                                        const signed char *__restrict__ cf, int points,
+                                                        const double *__restrict__ dd, const double *__restrict__ f,
+                                                        const double *__restrict__ offc,
+                                                        const double *__restrict__ u_lo,
+                                                        const double *__restrict__ u_hi, int split,
+                                                        double *__restrict__ u_new, int fwd, int bwd, double w,
+                                                        int row_begin, int row_end) {
+#define UOLD(j) (((j) < split ? u_lo : u_hi)[(j)])
+  __shared__ double buf[SPMV_TILE];           // x cache, then products / in-chunk coefficients
+  __shared__ unsigned short code[SPMV_TILE];  // the entries' lcol words
+  if ((int)blockIdx.x >= nblk) return;
+  const int blk = blk0 + blockIdx.x;
+  const int tid = threadIdx.x;
+  const int r0 = rb[blk], r1 = rb[blk + 1];
+  const int base = ia[r0], end = ia[r1];
+  const int base_al = base & ~1;
+  const int cnt = end - base_al;
+  constexpr int NIT = SPMV_TILE / (2 * SPMV_BLOCK);
+  d2_t vv[NIT];
+  us2_t cc[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    const int k = 2 * tid + it * 2 * SPMV_BLOCK;
+    if (k < cnt) {
+      vv[it] = *reinterpret_cast<const d2_t *>(av + base_al + k);
+      cc[it] = *reinterpret_cast<const us2_t *>(lcol + base_al + k);
+    }
+  }
+  // LPR lanes per row, as many as this tile's row count leaves room for (uniform in the workgroup);
+  // 8 * LPR consecutive lanes = one chunk; all lanes of a row carry its state, the first one writes it back
+  const int nr = r1 - r0;
+  const int LPR = nr <= 32 ? 8 : nr <= 64 ? 4 : nr <= 128 ? 2 : 1;
+  const int rl = tid / LPR, sub = tid % LPR;
+  const int i = r0 + rl;
+  double myu = 0.0, myrhs = 0.0, wd = 0.0;
+  bool rowsel = false;
+  if (rl < nr) {
+    const int mark = (points != 0 && cf != nullptr) ? (int)cf[i] : points;
+    myu = UOLD(i);
+    rowsel = (mark == points) && i >= row_begin && i < row_end;
+    if (rowsel) {
+      const double myd = dd[i];
+      myrhs = f[i];
+      if (offc) myrhs -= offc[i];
+      if (myd != 0.0) wd = w / myd;
+    }
+  }
+  const int u0 = uptr[blk], nu = uptr[blk + 1] - u0;
+  for (int k = tid; k < nu; k += SPMV_BLOCK) {
+    const int j = ucols[u0 + k];
+    buf[k] = UOLD(j);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    const int k = 2 * tid + it * 2 * SPMV_BLOCK;
+    if (k < cnt) {
+      const bool ok0 = (base_al + k >= base);
+      const bool ok1 = (base_al + k + 1 < end);
+      const unsigned c0 = cc[it].x, c1 = cc[it].y;
+      // out-of-chunk: product with the snapshot value; in-chunk: the coefficient itself
+      vv[it].x = ok0 ? ((c0 & XC_INCH) ? vv[it].x : vv[it].x * buf[c0 & XC_ID_MASK]) : 0.0;
+      vv[it].y = ok1 ? ((c1 & XC_INCH) ? vv[it].y : vv[it].y * buf[c1 & XC_ID_MASK]) : 0.0;
+    }
+  }
+  __syncthreads();  // every x-cache read is done
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    const int k = 2 * tid + it * 2 * SPMV_BLOCK;
+    if (k < cnt) {
+      buf[k] = vv[it].x;
+      buf[k + 1] = vv[it].y;
+      code[k] = cc[it].x;
+      code[k + 1] = cc[it].y;
+    }
+  }
+  __syncthreads();
+  // per row: out-of-chunk sum and the row of the dense 8x8 chunk block (the row's lanes share the entries)
+  double S = 0.0, crow[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) crow[j] = 0.0;
+  if (rowsel) {
+    const int s0 = ia[i] - base_al, s1 = ia[i + 1] - base_al;
+    for (int k = s0 + sub; k < s1; k += LPR) {
+      const unsigned c = code[k];
+      const double v = buf[k];
+      if (c & XC_INCH) {
+        const int o = (c >> XC_OFF_SHIFT) & 7;
+#pragma unroll
+        for (int j = 0; j < 8; j++) crow[j] = (o == j) ? v : crow[j];
+      } else {
+        S += v;
+      }
+    }
+  }
+  for (int m = 1; m < LPR; m <<= 1) {
+    S += __shfl_xor(S, m, 64);
+#pragma unroll
+    for (int j = 0; j < 8; j++) crow[j] += __shfl_xor(crow[j], m, 64);
+  }
+  // the sweep: a chunk = 8 rows = 8 * LPR consecutive lanes (tiles start on a multiple of 8 rows)
+  const int lane = tid & 63;
+  const int g = (lane / LPR) & 7;
+  const int gbase = lane & ~(8 * LPR - 1);
+  double uc[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) uc[j] = __shfl(myu, gbase + j * LPR, 64);
+#pragma unroll
+  for (int dir = 0; dir < 2; dir++) {
+    if (dir == 0 ? !fwd : !bwd) continue;
+#pragma unroll
+    for (int tt = 0; tt < 8; tt++) {
+      const int t = (dir == 0) ? tt : 7 - tt;
+      double sacc = S;
+#pragma unroll
+      for (int j = 0; j < 8; j++) sacc += crow[j] * uc[j];
+      const double nu2 = myu + (myrhs - sacc) * wd;  // unselected rows: wd == 0
+      const double b = __shfl(nu2, gbase + t * LPR, 64);
+      uc[t] = b;
+      if (g == t) myu = b;
+    }
+  }
+  if (rl < nr && sub == 0) u_new[i] = myu;
+#undef UOLD
+}
+
 // ---------------------------------------------------------------------------
 // BLAS-1
 // ---------------------------------------------------------------------------
@@ -873,23 +1016,49 @@ inline int vec_grid(int n) {
 
 // ---------------------------------------------------------------- host side
 
-std::vector<int> build_row_blocks(int nrows, const int64_t *ia) {
+// Tiles of the SpMV / tile Gauss-Seidel kernels: <= 256 rows and < SPMV_TILE entries.  Whenever no 8-row
+// chunk exceeds a tile the blocks begin and end on multiples of 8 rows (the hybrid-GS chunks), which the
+// tile Gauss-Seidel kernel needs; *chunk_aligned says whether that held for the whole matrix.
+std::vector<int> build_row_blocks(int nrows, const int64_t *ia, bool *chunk_aligned) {
   std::vector<int> rb;
   rb.reserve((size_t)nrows / 200 + 2);
   rb.push_back(0);
+  bool aligned = true;
   int r = 0;
   while (r < nrows) {
     const int64_t start = ia[r];
     int e = r;
-    // keep one slot of slack for the aligned-pair start
-    while (e < nrows && e - r < SPMV_BLOCK && ia[e + 1] - start <= SPMV_TILE - 1) e++;
-    if (e == r) e = r + 1;  // a single row longer than the tile
+    if ((r & 7) == 0) {  // whole chunks while they fit
+      while (e < nrows && e - r < SPMV_BLOCK) {
+        const int e2 = std::min(nrows, e + 8);
+        if (ia[e2] - start > SPMV_TILE - 1) break;
+        e = e2;
+      }
+    }
+    if (e == r) {  // not even one chunk fits (or an unaligned start after such a chunk): row granularity
+      aligned = false;
+      // keep one slot of slack for the aligned-pair start
+      while (e < nrows && e - r < SPMV_BLOCK && ia[e + 1] - start <= SPMV_TILE - 1) e++;
+      if (e == r) e = r + 1;  // a single row longer than the tile
+    }
     rb.push_back(e);
     r = e;
   }
+  if (chunk_aligned) *chunk_aligned = aligned;
   return rb;
 }
 
+// MI_HYPRE_GS_TILE: 0 never, 1 every level with tiles, unset: levels with mean row length > 8
+static bool gs_tile_mode(const DevCSR &A) {
+  static int v = -2;
+  if (v == -2) {
+    const char *e = getenv("MI_HYPRE_GS_TILE");
+    v = e ? atoi(e) : -1;
+  }
+  if (v == 0) return false;
+  if (v == 1) return true;
+  return (double)A.nnz / (double)std::max(1, A.nrows) > 8.0;
+}
 static bool gs_use_old() {
   static int v = -1;
   if (v < 0) {
@@ -978,7 +1147,17 @@ void gs_hybrid(const DevCSR &A, const double *u_lo, const double *u_hi, int spli
   const long long c1 = ((long long)row_end + chunk - 1) / chunk;
   const long long nch = c1 - c0;
   prof_begin(prof, s);
-  if (chunk == 8 && !gs_force_generic()) {
+  if (chunk == 8 && A.gs_tiles && A.xcache && gs_tile_mode(A) && !gs_force_generic() && !gs_use_old()) {
+    // tiles that hold the chunks [c0, c1): first tile with rb[b+1] > c0*8, last tile with rb[b] < c1*8
+    const std::vector<int> &rbh = A.rb_host;
+    const int first_row = (int)(c0 * 8), last_row = (int)std::min<long long>(c1 * 8, A.nrows);
+    const int b0 = (int)(std::upper_bound(rbh.begin(), rbh.end(), first_row) - rbh.begin()) - 1;
+    const int b1 = (int)(std::lower_bound(rbh.begin(), rbh.end(), last_row) - rbh.begin());
+    if (b1 > b0)
+      hipLaunchKernelGGL(gs_tile_k, dim3((unsigned)(b1 - b0)), dim3(SPMV_BLOCK), 0, s, b0, b1 - b0, A.rb.p, A.ia.p,
+                         A.a.p, A.uptr.p, A.ucols.p, A.lcol.p, cf, points, d, f, offc, u_lo, u_hi, split, out,
+                         fwd ? 1 : 0, bwd ? 1 : 0, w, first_row, last_row);
+  } else if (chunk == 8 && !gs_force_generic()) {
     const double avg = (double)A.nnz / (double)A.nrows;
     const int p95 = A.rowlen_p95;
 #define GS_LAUNCH_K(KERNEL, LPC, E)                                                                             \

@@ -18,7 +18,10 @@ enum ProfId { PROF_NONE = -1, PROF_SPMV_L0 = 0, PROF_RELAX_L0 = 1, PROF_DOT = 2,
 
 // host: row-block schedule for spmv_stream (<= 256 rows and < SPMV_TILE entries
 // per block, or exactly one longer row)
-std::vector<int> build_row_blocks(int nrows, const int64_t *ia);
+std::vector<int> build_row_blocks(int nrows, const int64_t *ia, bool *chunk_aligned = nullptr);
+constexpr int XC_ID_MASK = 0x7FF;   // block-local column id inside an lcol entry (SPMV_TILE <= 2048 ids)
+constexpr int XC_INCH = 0x8000;     // the column lies in the row's own 8-row chunk ...
+constexpr int XC_OFF_SHIFT = 12;    // ... at this offset (3 bits)
 
 // y = alpha*A*x + beta*b   (b may alias y)
 void spmv(const DevCSR &A, const double *x, double alpha, double beta, const double *b, double *y, hipStream_t s,

@@ -107,6 +107,12 @@ struct DevCSR {
   // x cache of the SpMV (levels with long rows): per row block the sorted unique
   // columns (gathered once into LDS) and 16-bit block-local column ids per entry
   bool xcache = false;
+  // Gauss-Seidel on the SpMV tiles (gs_tile_k): the row blocks start and end on multiples of 8 rows, no
+  // 8-row chunk exceeds a tile, and every lcol entry carries the in-chunk code in its upper bits
+  // (bit 15: the column lies in the row's own chunk of 8 rows, bits 12-14: which of the 8)
+  bool gs_tiles = false;
+  std::vector<int> rb_host;  // host copy of rb (row ranges -> tile ranges)
+  int max_tile_rows = 256;   // rows of the largest tile
   DVec<int> uptr, ucols;
   DVec<unsigned short> lcol;
   bool empty() const { return nrows == 0 || nnz == 0; }

@@ -110,9 +110,14 @@ void DevCSR::upload(const HostCSR &h) {
       rowlen_p95 = lens[kth];
     }
   }
-  std::vector<int> blocks = k::build_row_blocks(nrows, h.ia.data());
+  bool aligned = false;
+  std::vector<int> blocks = k::build_row_blocks(nrows, h.ia.data(), &aligned);
   nblocks = (int)blocks.size() - 1;
   rb.upload(blocks);
+  rb_host = blocks;
+  gs_tiles = false;
+  max_tile_rows = 1;
+  for (size_t b = 0; b + 1 < blocks.size(); b++) max_tile_rows = std::max(max_tile_rows, blocks[b + 1] - blocks[b]);
   // x cache: worth it when a block's entries share columns (long rows); the fine
   // level's short rows gather coalesced already
   static const int xc_min = getenv("MI_HYPRE_XCACHE_MIN") ? atoi(getenv("MI_HYPRE_XCACHE_MIN")) : 3;
@@ -131,6 +136,12 @@ void DevCSR::upload(const HostCSR &h) {
         tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
         for (int64_t q = s; q < e; q++)
           lc[(size_t)q] = (unsigned short)(std::lower_bound(tmp.begin(), tmp.end(), h.ja[(size_t)q]) - tmp.begin());
+        // in-chunk code bits for the tile Gauss-Seidel kernel
+        for (int i = blocks[(size_t)b]; i < blocks[(size_t)b + 1]; i++)
+          for (int64_t q = h.ia[(size_t)i]; q < h.ia[(size_t)i + 1]; q++) {
+            const int j = h.ja[(size_t)q];
+            if ((j >> 3) == (i >> 3)) lc[(size_t)q] |= (unsigned short)(k::XC_INCH | ((j & 7) << k::XC_OFF_SHIFT));
+          }
         uniq[(size_t)b] = tmp;
       }
     });
@@ -141,6 +152,7 @@ void DevCSR::upload(const HostCSR &h) {
     uptr.upload(up);
     ucols.upload(uc);
     lcol.upload(lc);
+    gs_tiles = aligned && nrows == ncols;
   }
 }
 

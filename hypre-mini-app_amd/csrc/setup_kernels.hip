@@ -957,6 +957,17 @@ __global__ __launch_bounds__(BLK) void xcache_block_k(int nb, const int *__restr
   }
 }
 
+// in-chunk code bits of the lcol entries (tile Gauss-Seidel kernel): thread per row
+__global__ __launch_bounds__(BLK) void lcol_code_k(int n, const int *__restrict__ ia, const int *__restrict__ ja,
+                                                   unsigned short *__restrict__ lcol) {
+  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  for (int q = ia[i]; q < ia[i + 1]; q++) {
+    const int j = ja[q];
+    if ((j >> 3) == (int)(i >> 3)) lcol[q] |= (unsigned short)(k::XC_INCH | ((j & 7) << k::XC_OFF_SHIFT));
+  }
+}
+
 __global__ __launch_bounds__(BLK) void xcache_compact_k(int nb, const int *__restrict__ rb, const int *__restrict__ ia,
                                                         const long long *__restrict__ uptr64,
                                                         const int *__restrict__ uslack, int *__restrict__ uptr,
@@ -1104,10 +1115,15 @@ void to_solve_format(DCsr &src, DevCSR &dst, hipStream_t s) {
   std::vector<int64_t> hia((size_t)n + 1);
   MI_HIP(hipMemcpyAsync(hia.data(), src.ia.p, ((size_t)n + 1) * sizeof(long long), hipMemcpyDeviceToHost, s));
   MI_HIP(hipStreamSynchronize(s));
-  std::vector<int> blocks = k::build_row_blocks(n, hia.data());
+  bool aligned = false;
+  std::vector<int> blocks = k::build_row_blocks(n, hia.data(), &aligned);
   std::vector<int64_t>().swap(hia);
   dst.nblocks = (int)blocks.size() - 1;
   dst.rb.upload(blocks);
+  dst.rb_host = blocks;
+  dst.gs_tiles = false;
+  dst.max_tile_rows = 1;
+  for (size_t b = 0; b + 1 < blocks.size(); b++) dst.max_tile_rows = std::max(dst.max_tile_rows, blocks[b + 1] - blocks[b]);
   dst.ja = std::move(src.ja);
   dst.a = std::move(src.a);
   static const int xc_min = getenv("MI_HYPRE_XCACHE_MIN") ? atoi(getenv("MI_HYPRE_XCACHE_MIN")) : 3;
@@ -1126,6 +1142,10 @@ void to_solve_format(DCsr &src, DevCSR &dst, hipStream_t s) {
     dst.uptr.alloc((size_t)nb + 1);
     dst.ucols.alloc((size_t)tot);
     xcache_compact_k<<<(unsigned)nb, BLK, 0, s>>>(nb, dst.rb.p, dst.ia.p, uptr64.p, uslack.p, dst.uptr.p, dst.ucols.p);
+    if (aligned && dst.nrows == dst.ncols) {
+      lcol_code_k<<<(unsigned)((n + BLK - 1) / BLK), BLK, 0, s>>>(n, dst.ia.p, dst.ja.p, dst.lcol.p);
+      dst.gs_tiles = true;
+    }
     MI_HIP(hipGetLastError());
     MI_HIP(hipStreamSynchronize(s));
   }
