@@ -208,9 +208,9 @@ def main():
         roof = None
         if spmv_n:
             a = spmv_bytes / (spmv_ms / spmv_n * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "spmv_stream<0, 1> (level-0 CSR SpMV of the GMRES loop; the loop runs in the preconditioner's "
-                              "C-first ordering of level 0, whose x gathers are less local than the caller's "
-                              "lexicographic ordering: 3.0 ms there, but no gather/scatter per V-cycle)", "achieved": a,
+            roof = {"bound": "hbm", "kernel": "spmv_stream_xc<0, 1> (level-0 CSR SpMV of the GMRES loop, LDS x-cache variant; the loop "
+                              "runs in the preconditioner's C-first ordering of level 0, whose x gathers are less local "
+                              "than the caller's lexicographic ordering -- 3.0 ms there -- but no gather/scatter per V-cycle)", "achieved": a,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": traffic,
                     "launches": spmv_n, "avg_ms": spmv_ms / spmv_n, "min_ms": spmv_min,
                     "algorithmic_bytes_per_launch": spmv_bytes}

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream(int nb, int xchunk, co
 // gathers the sorted unique columns of its row block ONCE into LDS (adjacent
 // lanes -> ascending addresses, well coalesced) and the entries then carry
 // 16-bit block-local ids (which also shrinks the index stream from 4 to 2 B).
-template <int EPI>
+template <int EPI, int TAG>
 __global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream_xc(int nb, int xchunk, const int *__restrict__ rb,
                                                              const int *__restrict__ ia, const int *__restrict__ ja,
                                                              const double *__restrict__ av,
@@ -1083,12 +1083,15 @@ static void launch_stream(int epi, const DevCSR &A, const double *x, double *y, 
   const int xchunk = (nb + 7) / 8;
   const dim3 grid(xchunk * 8), block(SPMV_BLOCK);
   if (A.xcache) {
-    if (epi == 0)
-      hipLaunchKernelGGL(spmv_stream_xc<0>, grid, block, 0, s, nb, xchunk, A.rb.p, A.ia.p, A.ja.p, A.a.p, A.uptr.p,
-                         A.ucols.p, A.lcol.p, x, y, e);
+    if (epi == 0 && level0)
+      hipLaunchKernelGGL((spmv_stream_xc<0, 1>), grid, block, 0, s, nb, xchunk, A.rb.p, A.ia.p, A.ja.p, A.a.p,
+                         A.uptr.p, A.ucols.p, A.lcol.p, x, y, e);
+    else if (epi == 0)
+      hipLaunchKernelGGL((spmv_stream_xc<0, 0>), grid, block, 0, s, nb, xchunk, A.rb.p, A.ia.p, A.ja.p, A.a.p,
+                         A.uptr.p, A.ucols.p, A.lcol.p, x, y, e);
     else
-      hipLaunchKernelGGL(spmv_stream_xc<1>, grid, block, 0, s, nb, xchunk, A.rb.p, A.ia.p, A.ja.p, A.a.p, A.uptr.p,
-                         A.ucols.p, A.lcol.p, x, y, e);
+      hipLaunchKernelGGL((spmv_stream_xc<1, 0>), grid, block, 0, s, nb, xchunk, A.rb.p, A.ia.p, A.ja.p, A.a.p,
+                         A.uptr.p, A.ucols.p, A.lcol.p, x, y, e);
   } else if (epi == 0 && level0)
     hipLaunchKernelGGL((spmv_stream<0, 1>), grid, block, 0, s, nb, xchunk, A.rb.p, A.ia.p, A.ja.p, A.a.p, x, y, e);
   else if (epi == 0)
