@@ -513,7 +513,8 @@ __global__ __launch_bounds__(BT) void interp_group_k(int nlist, const int *__res
                                                      const long long *__restrict__ slack_ia, int *__restrict__ Pj,
                                                      double *__restrict__ Pa, int *__restrict__ len_out) {
   constexpr int H = 2 * CAP;
-  constexpr int LOGH = (H == 64) ? 6 : (H == 256) ? 8 : 10;
+  constexpr int LOGH = (H == 64) ? 6 : (H == 256) ? 8 : (H == 1024) ? 10 : 11;
+  static_assert(H == 64 || H == 256 || H == 1024 || H == 2048, "table size");
   constexpr int GP = BT / G;
   __shared__ InterpGroup<CAP> grp[GP];
   InterpGroup<CAP> &L = grp[threadIdx.x / G];
@@ -1243,7 +1244,7 @@ bool interp(const DCsr &A, const DCsr &S, DVec<int> &cf, int interp_type, double
   int hmeta[16];
   MI_HIP(hipMemcpyAsync(hmeta, meta.p, sizeof(hmeta), hipMemcpyDeviceToHost, s));
   MI_HIP(hipStreamSynchronize(s));
-  if (hmeta[3] > 0) return false;  // a row may exceed the largest LDS table
+  if (hmeta[3] > 0 && hmeta[4] > 1024) return false;  // a row may exceed the largest LDS table
   Bins bins;
   for (int b = 0; b < 4; b++) bins.start[b + 1] = bins.start[b] + hmeta[b];
   for (int b = 0; b < 4; b++) hmeta[8 + b] = bins.start[b], hmeta[12 + b] = 0;
@@ -1260,7 +1261,12 @@ bool interp(const DCsr &A, const DCsr &S, DVec<int> &cf, int interp_type, double
   nc = (int)tot[0];
   DVec<int> sj((size_t)tot[1]);
   DVec<double> sa((size_t)tot[1]);
-  const int n0 = bins.start[1] - bins.start[0], n1 = bins.start[2] - bins.start[1], n2 = bins.start[3] - bins.start[2];
+  const int n0 = bins.start[1] - bins.start[0], n1 = bins.start[2] - bins.start[1], n2 = bins.start[3] - bins.start[2],
+            n3 = bins.start[4] - bins.start[3];
+  if (n3)  // up to 1024 candidates: one workgroup per row
+    interp_group_k<256, 1024, 256><<<(unsigned)n3, 256, 0, s>>>(
+        n3, rows.p + bins.start[3], ext, A.ia.p, A.ja.p, A.a.p, S.ia.p, S.ja.p, cf.p, f2c.p, trunc_factor, pmax,
+        slack_ia.p, sj.p, sa.p, len.p);
   if (n0)
     interp_group_k<8, 32, 256><<<(unsigned)((n0 + 31) / 32), 256, 0, s>>>(
         n0, rows.p + bins.start[0], ext, A.ia.p, A.ja.p, A.a.p, S.ia.p, S.ja.p, cf.p, f2c.p, trunc_factor, pmax,
