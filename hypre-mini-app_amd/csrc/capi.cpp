@@ -933,34 +933,69 @@ HYPRE_Int HYPRE_ParCSRBiCGSTABSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, H
 }
 
 // ------------------------------------------------------------------ stubs
+static IluSolver *ILU(HYPRE_Solver s) {
+  SolverBase *b = S(s);
+  if (b->kind != SolverBase::K_ILU) fail(HYPRE_ERROR_ARG, "handle is not an ILU solver");
+  return static_cast<IluSolver *>(b);
+}
 HYPRE_Int HYPRE_ILUCreate(HYPRE_Solver *solver) {
-  API_BEGIN *solver = reinterpret_cast<HYPRE_Solver>(static_cast<SolverBase *>(new StubSolver("ILU")));
+  API_BEGIN
+  if (!solver) fail(HYPRE_ERROR_ARG, "ILUCreate: NULL output");
+  *solver = reinterpret_cast<HYPRE_Solver>(static_cast<SolverBase *>(new IluSolver()));
   API_END
 }
 HYPRE_Int HYPRE_ILUDestroy(HYPRE_Solver solver) {
   API_BEGIN delete S(solver);
   API_END
 }
-HYPRE_Int HYPRE_ILUSetup(HYPRE_Solver, HYPRE_ParCSRMatrix, HYPRE_ParVector, HYPRE_ParVector) { return stub_fail("HYPRE_ILU"); }
-HYPRE_Int HYPRE_ILUSolve(HYPRE_Solver, HYPRE_ParCSRMatrix, HYPRE_ParVector, HYPRE_ParVector) { return stub_fail("HYPRE_ILU"); }
-#define ILU_SET(NAME, TYPE) \
-  HYPRE_Int HYPRE_ILUSet##NAME(HYPRE_Solver, TYPE) { return 0; }
-ILU_SET(Type, HYPRE_Int)
-ILU_SET(MaxIter, HYPRE_Int)
-ILU_SET(Tol, HYPRE_Real)
-ILU_SET(LocalReordering, HYPRE_Int)
-ILU_SET(PrintLevel, HYPRE_Int)
-ILU_SET(LevelOfFill, HYPRE_Int)
-ILU_SET(MaxNnzPerRow, HYPRE_Int)
-ILU_SET(DropThreshold, HYPRE_Real)
-ILU_SET(IterativeSetupType, HYPRE_Int)
-ILU_SET(IterativeSetupOption, HYPRE_Int)
-ILU_SET(IterativeSetupMaxIter, HYPRE_Int)
-ILU_SET(IterativeSetupTolerance, HYPRE_Real)
-ILU_SET(TriSolve, HYPRE_Int)
-ILU_SET(LowerJacobiIters, HYPRE_Int)
-ILU_SET(UpperJacobiIters, HYPRE_Int)
+HYPRE_Int HYPRE_ILUSetup(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector, HYPRE_ParVector) {
+  API_BEGIN
+  if (!A) fail(HYPRE_ERROR_ARG, "ILUSetup: NULL matrix");
+  ILU(solver)->setup(*PM(A));
+  API_END
+}
+HYPRE_Int HYPRE_ILUSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x) {
+  API_BEGIN
+  if (!A || !b || !x) fail(HYPRE_ERROR_ARG, "ILUSolve: NULL argument");
+  ILU(solver)->solve(*PM(A), *PV(b), *PV(x));
+  API_END
+}
+HYPRE_Int HYPRE_ILUGetNumIterations(HYPRE_Solver solver, HYPRE_Int *n) {
+  API_BEGIN *n = ILU(solver)->num_iterations;
+  API_END
+}
+HYPRE_Int HYPRE_ILUGetFinalRelativeResidualNorm(HYPRE_Solver solver, HYPRE_Real *r) {
+  API_BEGIN *r = ILU(solver)->final_rel_res;
+  API_END
+}
+#define ILU_SET(NAME, TYPE, STMT)                           \
+  HYPRE_Int HYPRE_ILUSet##NAME(HYPRE_Solver solver, TYPE v) { \
+    API_BEGIN IluSolver *o = ILU(solver);                   \
+    (void)o;                                                \
+    STMT;                                                   \
+    API_END                                                 \
+  }
+ILU_SET(Type, HYPRE_Int, o->ilu_type = v)
+ILU_SET(MaxIter, HYPRE_Int, o->max_iter = v)
+ILU_SET(Tol, HYPRE_Real, o->tol = v)
+ILU_SET(LocalReordering, HYPRE_Int, (void)v)
+ILU_SET(PrintLevel, HYPRE_Int, o->print_level = v)
+ILU_SET(LevelOfFill, HYPRE_Int, o->level_of_fill = v)
+ILU_SET(MaxNnzPerRow, HYPRE_Int, (void)v)        /* ILUT only */
+ILU_SET(DropThreshold, HYPRE_Real, (void)v)      /* ILUT only */
+ILU_SET(IterativeSetupType, HYPRE_Int, if (v != 0) fail(HYPRE_ERROR_ARG, "ILU: iterative setup is not implemented"))
+ILU_SET(IterativeSetupOption, HYPRE_Int, (void)v)
+ILU_SET(IterativeSetupMaxIter, HYPRE_Int, (void)v)
+ILU_SET(IterativeSetupTolerance, HYPRE_Real, (void)v)
+ILU_SET(LowerJacobiIters, HYPRE_Int, o->lower_it = v)
+ILU_SET(UpperJacobiIters, HYPRE_Int, o->upper_it = v)
 #undef ILU_SET
+// the driver also calls this one on a BoomerAMG handle (src/HypreSystem.cpp:306): accepted and ignored there
+HYPRE_Int HYPRE_ILUSetTriSolve(HYPRE_Solver solver, HYPRE_Int v) {
+  API_BEGIN
+  if (S(solver)->kind == SolverBase::K_ILU) ILU(solver)->tri_solve = v ? 1 : 0;
+  API_END
+}
 
 // ------------------------------------------------------------------ AMG internals used by the driver's level dump
 static thread_local std::vector<hypre_ParCSRMatrix *> g_level_ptrs;

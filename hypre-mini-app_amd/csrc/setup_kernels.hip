@@ -1016,6 +1016,94 @@ __global__ __launch_bounds__(BLK) void level_norms_k(int n, const long long *__r
   l1jac[i] = full;
 }
 
+// ---------------------------------------------------------------- ILU(0)
+__global__ __launch_bounds__(BLK) void ilu_dpos_k(int n, const long long *__restrict__ ia, const int *__restrict__ ja,
+                                                  long long *__restrict__ dpos) {
+  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  long long d = -1;
+  for (long long k = ia[i]; k < ia[i + 1]; k++)
+    if (ja[k] == i) d = k;
+  dpos[i] = d;
+}
+
+// one thread per row of the level: the oracle's IKJ loop, same operation order
+__global__ __launch_bounds__(BLK) void ilu_factor_k(int nrows, const int *__restrict__ rows,
+                                                    const long long *__restrict__ ia, const int *__restrict__ ja,
+                                                    double *__restrict__ a, const long long *__restrict__ dpos) {
+  const long long t = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (t >= nrows) return;
+  const int i = rows[t];
+  const long long e = ia[i + 1];
+  for (long long kk = ia[i]; kk < e; kk++) {
+    const int k = ja[kk];
+    if (k >= i) break;
+    const long long dk = dpos[k];
+    if (dk < 0) continue;
+    const double l = a[kk] / a[dk];
+    a[kk] = l;
+    long long pk = dk + 1;
+    const long long ek = ia[k + 1];
+    for (long long jj = kk + 1; jj < e; jj++) {
+      const int j = ja[jj];
+      while (pk < ek && ja[pk] < j) pk++;
+      if (pk < ek && ja[pk] == j) a[jj] -= l * a[pk];
+    }
+  }
+}
+
+__global__ __launch_bounds__(BLK) void ilu_lower_k(int nrows, const int *__restrict__ rows,
+                                                   const long long *__restrict__ ia, const int *__restrict__ ja,
+                                                   const double *__restrict__ a, const double *__restrict__ b,
+                                                   double *__restrict__ y) {
+  const long long t = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (t >= nrows) return;
+  const int i = rows ? rows[t] : (int)t;
+  double s = b[i];
+  for (long long k = ia[i]; k < ia[i + 1] && ja[k] < i; k++) s -= a[k] * y[ja[k]];
+  y[i] = s;
+}
+
+__global__ __launch_bounds__(BLK) void ilu_upper_k(int nrows, const int *__restrict__ rows,
+                                                   const long long *__restrict__ ia, const int *__restrict__ ja,
+                                                   const double *__restrict__ a, const long long *__restrict__ dpos,
+                                                   const double *__restrict__ y, double *__restrict__ x) {
+  const long long t = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (t >= nrows) return;
+  const int i = rows ? rows[t] : (int)t;
+  double s = y[i];
+  const long long d = dpos[i];
+  for (long long k = d + 1; k < ia[i + 1]; k++) s -= a[k] * x[ja[k]];
+  x[i] = (d >= 0) ? s / a[d] : s;
+}
+
+// Jacobi sweeps: every row reads the previous iterate
+__global__ __launch_bounds__(BLK) void ilu_lower_jac_k(int n, const long long *__restrict__ ia,
+                                                       const int *__restrict__ ja, const double *__restrict__ a,
+                                                       const double *__restrict__ b, const double *__restrict__ in,
+                                                       double *__restrict__ out) {
+  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  double s = b[i];
+  if (in)
+    for (long long k = ia[i]; k < ia[i + 1] && ja[k] < i; k++) s -= a[k] * in[ja[k]];
+  out[i] = s;
+}
+
+__global__ __launch_bounds__(BLK) void ilu_upper_jac_k(int n, const long long *__restrict__ ia,
+                                                       const int *__restrict__ ja, const double *__restrict__ a,
+                                                       const long long *__restrict__ dpos,
+                                                       const double *__restrict__ b, const double *__restrict__ in,
+                                                       double *__restrict__ out) {
+  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  double s = b[i];
+  const long long d = dpos[i];
+  if (in)
+    for (long long k = d + 1; k < ia[i + 1]; k++) s -= a[k] * in[ja[k]];
+  out[i] = (d >= 0) ? s / a[d] : s;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------- host-facing entry points
@@ -1425,6 +1513,35 @@ void extract_rows(const DCsr &A, const int *rows, int nout, const int *colpos, D
   sort_rows(nout, total, B.ia.p, tj.p, ta.p, B.ja.p, B.a.p, s);
   MI_HIP(hipGetLastError());
   MI_HIP(hipStreamSynchronize(s));
+}
+
+void ilu_diag_positions(const DCsr &A, long long *dpos, hipStream_t s) {
+  if (A.nrows) ilu_dpos_k<<<(unsigned)((A.nrows + BLK - 1) / BLK), BLK, 0, s>>>(A.nrows, A.ia.p, A.ja.p, dpos);
+  MI_HIP(hipGetLastError());
+}
+void ilu_factor_level(DCsr &LU, const long long *dpos, const int *rows, int nrows, hipStream_t s) {
+  if (nrows) ilu_factor_k<<<(unsigned)((nrows + BLK - 1) / BLK), BLK, 0, s>>>(nrows, rows, LU.ia.p, LU.ja.p, LU.a.p, dpos);
+}
+void ilu_lower_level(const DCsr &LU, const long long *dpos, const int *rows, int nrows, const double *b, double *y,
+                     hipStream_t s) {
+  (void)dpos;
+  if (nrows) ilu_lower_k<<<(unsigned)((nrows + BLK - 1) / BLK), BLK, 0, s>>>(nrows, rows, LU.ia.p, LU.ja.p, LU.a.p, b, y);
+}
+void ilu_upper_level(const DCsr &LU, const long long *dpos, const int *rows, int nrows, const double *y, double *x,
+                     hipStream_t s) {
+  if (nrows)
+    ilu_upper_k<<<(unsigned)((nrows + BLK - 1) / BLK), BLK, 0, s>>>(nrows, rows, LU.ia.p, LU.ja.p, LU.a.p, dpos, y, x);
+}
+void ilu_lower_jacobi(const DCsr &LU, const long long *dpos, const double *b, const double *in, double *out,
+                      hipStream_t s) {
+  (void)dpos;
+  const int n = LU.nrows;
+  if (n) ilu_lower_jac_k<<<(unsigned)((n + BLK - 1) / BLK), BLK, 0, s>>>(n, LU.ia.p, LU.ja.p, LU.a.p, b, in, out);
+}
+void ilu_upper_jacobi(const DCsr &LU, const long long *dpos, const double *b, const double *in, double *out,
+                      hipStream_t s) {
+  const int n = LU.nrows;
+  if (n) ilu_upper_jac_k<<<(unsigned)((n + BLK - 1) / BLK), BLK, 0, s>>>(n, LU.ia.p, LU.ja.p, LU.a.p, dpos, b, in, out);
 }
 
 }  // namespace sk

@@ -72,5 +72,21 @@ void solve_format_to_host(const DevCSR &src, HostCSR &h, hipStream_t s);
 // amg_setup.cpp) of a single-rank operator; cf may be null
 void level_norms(const DCsr &A, const int *cf, int chunk, double *diag, double *l1gs, double *l1jac, hipStream_t s);
 
+// ---- ILU(0) of a single-rank block (HYPRE_ILU type 0, fill 0), level-scheduled
+// position of the diagonal entry of every row (-1: none)
+void ilu_diag_positions(const DCsr &A, long long *dpos, hipStream_t s);
+// in-place IKJ factorisation of the rows rows[0..nrows) -- one level set: every row they depend on is final
+void ilu_factor_level(DCsr &LU, const long long *dpos, const int *rows, int nrows, hipStream_t s);
+// forward / backward substitution for one level set: y[i] = b[i] - sum_{k<i} l_ik y_k ;
+// x[i] = (y[i] - sum_{j>i} u_ij x_j) / u_ii
+void ilu_lower_level(const DCsr &LU, const long long *dpos, const int *rows, int nrows, const double *b, double *y,
+                     hipStream_t s);
+void ilu_upper_level(const DCsr &LU, const long long *dpos, const int *rows, int nrows, const double *y, double *x,
+                     hipStream_t s);
+// Jacobi sweeps on the triangular factors (HYPRE's iterative triangular solve):
+// out = b - L_strict in   /   out = D^-1 (b - U_strict in) ; in == nullptr: out = b resp. D^-1 b
+void ilu_lower_jacobi(const DCsr &LU, const long long *dpos, const double *b, const double *in, double *out, hipStream_t s);
+void ilu_upper_jacobi(const DCsr &LU, const long long *dpos, const double *b, const double *in, double *out, hipStream_t s);
+
 }  // namespace sk
 }  // namespace mi

@@ -5,7 +5,7 @@
 namespace mi {
 
 struct SolverBase {
-  enum Kind { K_GMRES, K_BICGSTAB, K_PCG, K_AMG, K_STUB } kind;
+  enum Kind { K_GMRES, K_BICGSTAB, K_PCG, K_AMG, K_ILU, K_STUB } kind;
   explicit SolverBase(Kind k) : kind(k) {}
   virtual ~SolverBase() {}
 };
@@ -67,7 +67,28 @@ struct PcgSolver : KrylovSolver {
   int solve(ParCSR &A, ParVector &b, ParVector &x);
 };
 
-// placeholder for solver families outside the north-star path (ILU): every call reports HYPRE_ERROR_GENERIC
+// HYPRE_ILU, type 0 (block Jacobi) with level of fill 0: ILU(0) of this rank's diagonal block, factorised and
+// applied on the device by level sets (src/HypreSystem.cpp:328-370 as preconditioner, :457-497 as solver).
+// tri_solve 1: exact substitutions (one launch per level set); 0: lower/upper Jacobi sweeps (HYPRE's GPU option)
+struct IluSolver : SolverBase {
+  int ilu_type = 0, level_of_fill = 0, max_iter = 20, print_level = 0, tri_solve = 1, lower_it = 5, upper_it = 5;
+  double tol = 1e-7;
+  bool is_setup = false;
+  int n = 0;
+  sk::DCsr LU;
+  DVec<long long> dpos;
+  DVec<int> order_l, order_u;            // rows sorted by level set
+  std::vector<int> lptr, uptr;           // level set boundaries in order_l / order_u
+  DVec<double> y, t, r, z;
+  int num_iterations = 0;
+  double final_rel_res = 0.0;
+  IluSolver() : SolverBase(K_ILU) {}
+  void setup(ParCSR &A);
+  void apply(const double *rhs, double *out);           // out = U^-1 L^-1 rhs
+  int solve(ParCSR &A, ParVector &b, ParVector &x);     // x += M^-1 (b - A x), max_iter times or to tol
+};
+
+// placeholder for entry points that stay unimplemented: every call reports HYPRE_ERROR_GENERIC
 struct StubSolver : SolverBase {
   std::string family;
   explicit StubSolver(const char *f) : SolverBase(K_STUB), family(f) {}

@@ -406,20 +406,41 @@ void HypreSystem::setup_boomeramg_precond() {
   precondDestroyPtr_ = &HYPRE_BoomerAMGDestroy;
 }
 
-// /root/reference/src/HypreSystem.cpp:328-370 -- outside the north-star path: the
-// handle exists, Setup/Solve report HYPRE_ERROR_GENERIC
+// /root/reference/src/HypreSystem.cpp:328-370 (preconditioner) and :457-497 (solver): HYPRE_ILU with the
+// reference's keys and defaults; the library implements type 0 / fill 0 (block-Jacobi ILU(0))
+static void ilu_settings(HYPRE_Solver h, YAML::Node node, int default_max_iter, double default_tol) {
+  HYPRE_ILUSetType(h, get_optional(node, "ilu_type", 0));
+  HYPRE_ILUSetMaxIter(h, get_optional(node, "max_iterations", default_max_iter));
+  HYPRE_ILUSetTol(h, get_optional(node, "tolerance", default_tol));
+  HYPRE_ILUSetLocalReordering(h, get_optional(node, "local_reordering", 0));
+  HYPRE_ILUSetPrintLevel(h, get_optional(node, "print_level", 1));
+  HYPRE_ILUSetLevelOfFill(h, get_optional(node, "fill", 0));
+  HYPRE_ILUSetMaxNnzPerRow(h, get_optional(node, "max_nnz_per_row", 1000));
+  HYPRE_ILUSetDropThreshold(h, get_optional(node, "drop_threshold", 1.0e-2));
+  HYPRE_ILUSetIterativeSetupType(h, get_optional(node, "iterative_algorithm_type", 0));
+  HYPRE_ILUSetIterativeSetupOption(h, get_optional(node, "iterative_setup_option", 2));
+  HYPRE_ILUSetIterativeSetupMaxIter(h, get_optional(node, "iterative_ilu_max_iterations", 1));
+  HYPRE_ILUSetIterativeSetupTolerance(h, get_optional(node, "iterative_ilu_tolerance", 1e-5));
+  HYPRE_ILUSetTriSolve(h, get_optional(node, "trisolve", 1));
+  HYPRE_ILUSetLowerJacobiIters(h, get_optional(node, "lower_jacobi_iters", 5));
+  HYPRE_ILUSetUpperJacobiIters(h, get_optional(node, "upper_jacobi_iters", 5));
+}
 void HypreSystem::setup_ilu_precond() {
   HYPRE_ILUCreate(&precond_);
+  ilu_settings(precond_, inpfile_["ilu_preconditioner_settings"], 1, 0.0);
   precondSetupPtr_ = &HYPRE_ILUSetup;
   precondSolvePtr_ = &HYPRE_ILUSolve;
   precondDestroyPtr_ = &HYPRE_ILUDestroy;
 }
 void HypreSystem::setup_ilu() {
   HYPRE_ILUCreate(&solver_);
+  ilu_settings(solver_, inpfile_["solver_settings"], 20, 1.0e-7);
   solverDestroyPtr_ = &HYPRE_ILUDestroy;
   solverSetupPtr_ = &HYPRE_ILUSetup;
   solverPrecondPtr_ = nullptr;
   solverSolvePtr_ = &HYPRE_ILUSolve;
+  solverItersPtr_ = &HYPRE_ILUGetNumIterations;
+  solverResPtr_ = &HYPRE_ILUGetFinalRelativeResidualNorm;
   usePrecond_ = false;
 }
 

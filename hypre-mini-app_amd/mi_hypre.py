@@ -326,6 +326,53 @@ class BoomerAMG:
             pass
 
 
+class ILU:
+    """HYPRE_ILU: block-Jacobi ILU(0) (type 0, fill 0); usable as a preconditioner (set_precond) or a solver."""
+
+    def __init__(self, max_iterations=1, tolerance=0.0, trisolve=1, lower_jacobi_iters=5, upper_jacobi_iters=5,
+                 print_level=0, ilu_type=0, fill=0):
+        self.h = vp()
+        call("HYPRE_ILUCreate", C.byref(self.h))
+        call("HYPRE_ILUSetType", self.h, ilu_type)
+        call("HYPRE_ILUSetLevelOfFill", self.h, fill)
+        call("HYPRE_ILUSetMaxIter", self.h, max_iterations)
+        call("HYPRE_ILUSetTol", self.h, float(tolerance))
+        call("HYPRE_ILUSetTriSolve", self.h, trisolve)
+        call("HYPRE_ILUSetLowerJacobiIters", self.h, lower_jacobi_iters)
+        call("HYPRE_ILUSetUpperJacobiIters", self.h, upper_jacobi_iters)
+        call("HYPRE_ILUSetPrintLevel", self.h, print_level)
+        self.solve_fn, self.setup_fn = "HYPRE_ILUSolve", "HYPRE_ILUSetup"
+
+    def setup(self, A):
+        call("HYPRE_ILUSetup", self.h, A.par, None, None)
+
+    def solve(self, A, b, x):
+        return call("HYPRE_ILUSolve", self.h, A.par, b.par, x.par)
+
+    @property
+    def num_iterations(self):
+        n = c_int()
+        call("HYPRE_ILUGetNumIterations", self.h, C.byref(n))
+        return n.value
+
+    @property
+    def final_rel_res(self):
+        v = c_dbl()
+        call("HYPRE_ILUGetFinalRelativeResidualNorm", self.h, C.byref(v))
+        return v.value
+
+    def destroy(self):
+        if self.h:
+            call("HYPRE_ILUDestroy", self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:  # noqa: BLE001
+            pass
+
+
 class _Krylov:
     prefix = None
 
@@ -343,8 +390,9 @@ class _Krylov:
     def set_precond(self, amg):
         """solverPrecondPtr_(solver_, precondSolvePtr_, precondSetupPtr_, precond_), HypreSystem.cpp:687."""
         L = lib()
-        call(f"{self.prefix}SetPrecond", self.h, C.cast(L.HYPRE_BoomerAMGSolve, vp), C.cast(L.HYPRE_BoomerAMGSetup, vp),
-             amg.h)
+        solve_fn = getattr(amg, "solve_fn", "HYPRE_BoomerAMGSolve")
+        setup_fn = getattr(amg, "setup_fn", "HYPRE_BoomerAMGSetup")
+        call(f"{self.prefix}SetPrecond", self.h, C.cast(getattr(L, solve_fn), vp), C.cast(getattr(L, setup_fn), vp), amg.h)
         self.precond = amg
 
     def setup(self, A, b, x):

@@ -1117,6 +1117,156 @@ void oamg_precond(void *ctx, const double *r, double *z) {
 
 /* ---------------------------------------------------------------- GMRES -- */
 
+
+/* ------------------------------------------------------------------ ILU(0) -- */
+struct oilu {
+  int n;
+  ocsr *LU;
+  obig *dpos; /* position of the diagonal entry of every row */
+  int tri_solve, lower_it, upper_it;
+};
+
+oilu *oilu_setup(const ocsr *A, int nparts, const obig *part_starts, int tri_solve, int lower_it, int upper_it) {
+  const int n = A->nrows;
+  oilu *h = (oilu *)xcalloc(1, sizeof(oilu));
+  h->n = n;
+  h->tri_solve = tri_solve;
+  h->lower_it = lower_it;
+  h->upper_it = upper_it;
+  obig one_part[2] = {0, n};
+  if (nparts < 1 || !part_starts) {
+    nparts = 1;
+    part_starts = one_part;
+  }
+  /* the block-diagonal part of A */
+  obig *cia = (obig *)xcalloc((size_t)n + 1, sizeof(obig));
+  for (int p = 0; p < nparts; p++)
+    for (obig i = part_starts[p]; i < part_starts[p + 1]; i++) {
+      obig c = 0;
+      for (obig k = A->ia[i]; k < A->ia[i + 1]; k++)
+        if (A->ja[k] >= part_starts[p] && A->ja[k] < part_starts[p + 1]) c++;
+      cia[i + 1] = c;
+    }
+  for (int i = 0; i < n; i++) cia[i + 1] += cia[i];
+  ocsr *LU = ocsr_new(n, n, cia[n]);
+  memcpy(LU->ia, cia, sizeof(obig) * ((size_t)n + 1));
+  free(cia);
+  h->dpos = (obig *)xcalloc((size_t)n, sizeof(obig));
+  for (int p = 0; p < nparts; p++)
+    for (obig i = part_starts[p]; i < part_starts[p + 1]; i++) {
+      obig q = LU->ia[i];
+      h->dpos[i] = -1;
+      for (obig k = A->ia[i]; k < A->ia[i + 1]; k++)
+        if (A->ja[k] >= part_starts[p] && A->ja[k] < part_starts[p + 1]) {
+          LU->ja[q] = A->ja[k];
+          LU->a[q] = A->a[k];
+          if (A->ja[k] == i) h->dpos[i] = q;
+          q++;
+        }
+    }
+  /* IKJ: for k < i in row i (ascending): l_ik = a_ik / u_kk ; a_ij -= l_ik u_kj for j > k in both patterns */
+  for (int i = 0; i < n; i++) {
+    for (obig kk = LU->ia[i]; kk < LU->ia[i + 1]; kk++) {
+      const int k = LU->ja[kk];
+      if (k >= i) break;
+      if (h->dpos[k] < 0) continue;
+      const double l = LU->a[kk] / LU->a[h->dpos[k]];
+      LU->a[kk] = l;
+      obig pk = h->dpos[k] + 1; /* entries of row k right of its diagonal */
+      const obig ek = LU->ia[k + 1];
+      for (obig jj = kk + 1; jj < LU->ia[i + 1]; jj++) {
+        const int j = LU->ja[jj];
+        while (pk < ek && LU->ja[pk] < j) pk++;
+        if (pk < ek && LU->ja[pk] == j) LU->a[jj] -= l * LU->a[pk];
+      }
+    }
+  }
+  h->LU = LU;
+  return h;
+}
+
+void oilu_free(oilu *h) {
+  if (!h) return;
+  ocsr_free(h->LU);
+  free(h->dpos);
+  free(h);
+}
+
+const ocsr *oilu_factor(const oilu *h) { return h->LU; }
+
+void oilu_apply(const oilu *h, const double *r, double *z) {
+  const int n = h->n;
+  const ocsr *LU = h->LU;
+  double *y = (double *)xmalloc(sizeof(double) * (size_t)n);
+  if (h->tri_solve) {
+    for (int i = 0; i < n; i++) {
+      double s = r[i];
+      for (obig k = LU->ia[i]; k < LU->ia[i + 1] && LU->ja[k] < i; k++) s -= LU->a[k] * y[LU->ja[k]];
+      y[i] = s;
+    }
+    for (int i = n - 1; i >= 0; i--) {
+      double s = y[i];
+      const obig d = h->dpos[i];
+      for (obig k = d + 1; k < LU->ia[i + 1]; k++) s -= LU->a[k] * z[LU->ja[k]];
+      z[i] = (d >= 0) ? s / LU->a[d] : s;
+    }
+  } else {
+    /* Jacobi iterations on the triangular systems: y <- r - L_strict y ;  z <- D^-1 (y - U_strict z) */
+    double *t = (double *)xmalloc(sizeof(double) * (size_t)n);
+    memcpy(y, r, sizeof(double) * (size_t)n);
+    for (int it = 0; it < h->lower_it; it++) {
+      for (int i = 0; i < n; i++) {
+        double s = r[i];
+        for (obig k = LU->ia[i]; k < LU->ia[i + 1] && LU->ja[k] < i; k++) s -= LU->a[k] * y[LU->ja[k]];
+        t[i] = s;
+      }
+      memcpy(y, t, sizeof(double) * (size_t)n);
+    }
+    for (int i = 0; i < n; i++) z[i] = (h->dpos[i] >= 0) ? y[i] / LU->a[h->dpos[i]] : y[i];
+    for (int it = 0; it < h->upper_it; it++) {
+      for (int i = 0; i < n; i++) {
+        double s = y[i];
+        const obig d = h->dpos[i];
+        for (obig k = d + 1; k < LU->ia[i + 1]; k++) s -= LU->a[k] * z[LU->ja[k]];
+        t[i] = (d >= 0) ? s / LU->a[d] : s;
+      }
+      memcpy(z, t, sizeof(double) * (size_t)n);
+    }
+    free(t);
+  }
+  free(y);
+}
+
+void oilu_precond(void *ctx, const double *r, double *z) { oilu_apply((const oilu *)ctx, r, z); }
+
+int oilu_solve(const oilu *h, const ocsr *A, const double *b, double *x, int max_iter, double tol, double *rel_res) {
+  const int n = h->n;
+  double *r = (double *)xmalloc(sizeof(double) * (size_t)n);
+  double *z = (double *)xmalloc(sizeof(double) * (size_t)n);
+  const double bn = vnorm(b, n);
+  int it = 0;
+  double rel = 0.0;
+  while (it < max_iter) {
+    ocsr_matvec(-1.0, A, x, 1.0, b, r);
+    if (tol > 0.0) {
+      const double rn = vnorm(r, n);
+      rel = (bn > 0.0) ? rn / bn : rn;
+      if (rel <= tol) break;
+    }
+    oilu_apply(h, r, z);
+    vaxpy(1.0, z, x, n);
+    it++;
+  }
+  if (rel_res) {
+    ocsr_matvec(-1.0, A, x, 1.0, b, r);
+    const double rn = vnorm(r, n);
+    *rel_res = (bn > 0.0) ? rn / bn : rn;
+  }
+  free(r);
+  free(z);
+  return it;
+}
+
 /* hypre_GMRESSolve (krylov/gmres.c); called through solverSolvePtr_
  * at src/HypreSystem.cpp:723 with tol/max_iter/k_dim from :393-397, x0 = 0 (:580). */
 static void gmres_core(const ocsr *A, const double *b, double *x, int kdim, double tol, double atol, int maxit,

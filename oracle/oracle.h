@@ -105,6 +105,19 @@ int oamg_solve(const oamg *h, const double *b, double *x, int *iters, double *re
 typedef void (*oprecond_fn)(void *ctx, const double *r, double *z); /* z = M^-1 r, z arrives zeroed */
 void oamg_precond(void *ctx, const double *r, double *z);
 
+/* Block-Jacobi ILU(0) (HYPRE_ILU, ilu_type 0, level of fill 0; src/HypreSystem.cpp:328-370, :457-497):
+ * every part factorises its own diagonal block in place (IKJ order, entries outside the block dropped).
+ * tri_solve 1: exact forward/backward substitution; tri_solve 0: lower_it / upper_it Jacobi iterations per
+ * triangular factor (HYPRE's GPU option).  HYPRE's ILU source is not available here: parity unpinned. */
+typedef struct oilu oilu;
+oilu *oilu_setup(const ocsr *A, int nparts, const obig *part_starts, int tri_solve, int lower_it, int upper_it);
+void oilu_free(oilu *h);
+const ocsr *oilu_factor(const oilu *h);                 /* L (unit, strictly lower part) and U in A's pattern */
+void oilu_apply(const oilu *h, const double *r, double *z); /* z = U^-1 L^-1 r */
+void oilu_precond(void *ctx, const double *r, double *z);
+/* Richardson iteration x += M^-1 (b - A x) (HYPRE_ILUSolve as a solver), returns the iteration count */
+int oilu_solve(const oilu *h, const ocsr *A, const double *b, double *x, int max_iter, double tol, double *rel_res);
+
 typedef struct okrylov_result {
   int iters;
   int converged;

@@ -114,6 +114,14 @@ def lib():
                                  C.c_void_p, C.c_void_p, P(KrylovResult), C.c_void_p]
         L.obicgstab_solve.argtypes = [P(_Csr), C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int,
                                       C.c_void_p, C.c_void_p, P(KrylovResult), C.c_void_p]
+        L.oilu_setup.restype = C.c_void_p
+        L.oilu_setup.argtypes = [P(_Csr), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.oilu_free.argtypes = [C.c_void_p]
+        L.oilu_factor.restype = P(_Csr)
+        L.oilu_factor.argtypes = [C.c_void_p]
+        L.oilu_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oilu_solve.restype = C.c_int
+        L.oilu_solve.argtypes = [C.c_void_p, P(_Csr), C.c_void_p, C.c_void_p, C.c_int, C.c_double, P(C.c_double)]
         L.oracle_set_threads.argtypes = [C.c_int]
         _LIB = L
     return _LIB
@@ -278,12 +286,47 @@ class Amg:
             self.h = None
 
 
+class Ilu:
+    """Block-Jacobi ILU(0) of the oracle (part_starts: emulated rank partition)."""
+
+    def __init__(self, A, part_starts=None, tri_solve=1, lower_it=5, upper_it=5):
+        self.A = A
+        ps = None if part_starts is None else np.ascontiguousarray(part_starts, dtype=np.int64)
+        self._ps = ps
+        self.h = lib().oilu_setup(A.h, 0 if ps is None else len(ps) - 1, _ptr(ps), tri_solve, lower_it, upper_it)
+        self.is_ilu = True
+
+    def factor(self):
+        return Csr(lib().oilu_factor(self.h), own=False)
+
+    def apply(self, r):
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        z = np.zeros_like(r)
+        lib().oilu_apply(self.h, _ptr(r), _ptr(z))
+        return z
+
+    def solve(self, b, x0=None, max_iter=20, tol=1e-7):
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.zeros_like(b) if x0 is None else np.array(x0, dtype=np.float64)
+        rel = C.c_double()
+        it = lib().oilu_solve(self.h, self.A.h, _ptr(b), _ptr(x), max_iter, tol, C.byref(rel))
+        return x, dict(iters=it, rel_res=rel.value)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().oilu_free(self.h)
+            self.h = None
+
+
 def _krylov(fn, A, b, x0, args, amg, maxit):
     b = np.ascontiguousarray(b, dtype=np.float64)
     x = np.zeros_like(b) if x0 is None else np.array(x0, dtype=np.float64)
     res = KrylovResult()
     norms = np.full(maxit + 2, np.nan)
-    M = C.cast(lib().oamg_precond, C.c_void_p) if amg is not None else None
+    if amg is not None and getattr(amg, "is_ilu", False):
+        M = C.cast(lib().oilu_precond, C.c_void_p)
+    else:
+        M = C.cast(lib().oamg_precond, C.c_void_p) if amg is not None else None
     ctx = amg.h if amg is not None else None
     fn(A.h, _ptr(b), _ptr(x), *args, M, ctx, C.byref(res), _ptr(norms))
     return x, dict(iters=res.iters, converged=bool(res.converged), rel_res=res.rel_res,

@@ -292,3 +292,52 @@ def test_against_direct_solve(mi):
     assert gm.solve(A, b, x) == 0
     xd = spl.spsolve(M.tocsc(), rhs)
     assert np.abs(x.get() - xd).max() <= 1e-8 * np.abs(xd).max()
+
+
+@pytest.mark.parametrize("n,stencil,trisolve", [(12, 7, 1), (9, 27, 1), (12, 7, 0)])
+def test_ilu0_matches_oracle(mi, oc, n, stencil, trisolve):
+    """HYPRE_ILU type 0 / fill 0: application, GMRES preconditioning and the Richardson solver against the oracle.
+    The device factorisation and substitutions repeat the oracle's operation order (no FMA): applications agree
+    to rounding of the final division only."""
+    A, b, x, rhs = mi.build_laplace_system(n, n, n, stencil)
+    Ao, bo = oc.Csr.laplace(n, n, n, stencil)
+    ilu = mi.ILU(max_iterations=1, tolerance=0.0, trisolve=trisolve, lower_jacobi_iters=4, upper_jacobi_iters=3)
+    oilu = oc.Ilu(Ao, tri_solve=trisolve, lower_it=4, upper_it=3)
+    ilu.setup(A)
+    # one application on a zero guess: x = M^-1 b (through the solver entry point)
+    rng = np.random.default_rng(4)
+    v = rng.standard_normal(n ** 3)
+    bv = mi.IJVector(0, n ** 3 - 1, v)
+    xv = mi.IJVector(0, n ** 3 - 1, np.zeros(n ** 3))
+    ilu.solve(A, bv, xv)
+    ref = oilu.apply(v)
+    assert np.allclose(xv.get(), ref, rtol=1e-13, atol=1e-13 * np.abs(ref).max())
+    # as the preconditioner of GMRES
+    gm = mi.GMRES(tolerance=1e-9, max_iterations=200, kspace=40, print_level=0)
+    gm.set_precond(ilu)
+    gm.setup(A, b, x)
+    assert gm.solve(A, b, x) == 0
+    xo, info = oc.gmres(Ao, bo, kdim=40, tol=1e-9, maxit=200, amg=oilu)
+    assert gm.num_iterations == info["iters"]
+    assert np.allclose(gm.residual_history(), info["norms"], rtol=1e-7)
+    assert _allclose_ref(x.get(), xo)
+    # as a solver: Richardson iteration to a tolerance
+    if trisolve:
+        sol = mi.ILU(max_iterations=300, tolerance=1e-6)
+        sol.setup(A)
+        x.fill(0.0)
+        sol.solve(A, b, x)
+        xs, si = oilu.solve(bo, max_iter=300, tol=1e-6)
+        assert sol.num_iterations == si["iters"] and _allclose_ref(x.get(), xs)
+
+
+def test_ilu_unsupported_variants_report_errors(mi):
+    A, b, x, rhs = mi.build_laplace_system(6, 6, 6, 7)
+    ilu = mi.ILU(ilu_type=1)
+    with pytest.raises(mi.HypreError):
+        ilu.setup(A)
+    mi.call("HYPRE_ClearAllErrors")
+    ilu = mi.ILU(fill=2)
+    with pytest.raises(mi.HypreError):
+        ilu.setup(A)
+    mi.call("HYPRE_ClearAllErrors")

@@ -201,6 +201,31 @@ solver_settings:
     assert m and 0 < int(m.group(1)) < 60
 
 
+def test_ilu_preconditioner_and_solver_through_driver(tmp_path):
+    for method, precond, extra in (("gmres", "ilu", "ilu_preconditioner_settings:\n  trisolve: 1\n"),
+                                   ("ilu", "none", "")):
+        out = _run(tmp_path, f"""
+linear_system:
+  type: laplace_3d
+  nx: 14
+  ny: 14
+  nz: 14
+
+solver_settings:
+  method: {method}
+  preconditioner: {precond}
+  tolerance: 1.0e-8
+  max_iterations: 600
+  kspace: 50
+  print_level: 0
+
+""" + extra)
+        m = re.search(r"max \|x - 1\| = ([0-9.eE+-]+)", out)
+        assert m and float(m.group(1)) < 1e-5, out[-1500:]
+        m = re.search(r"Solve 0 : (\d+) iterations", out)
+        assert m and 0 < int(m.group(1)) < 600, out[-1500:]
+
+
 def test_unsupported_family_reports_error(tmp_path):
     inp = tmp_path / "input.yaml"
     inp.write_text("""
@@ -210,8 +235,10 @@ linear_system:
   ny: 8
   nz: 8
 solver_settings:
-  method: ilu
-  preconditioner: none
+  method: gmres
+  preconditioner: ilu
+ilu_preconditioner_settings:
+  ilu_type: 10
 """)
     p = subprocess.run([APP, str(inp)], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                        timeout=300)

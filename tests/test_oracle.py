@@ -239,3 +239,32 @@ def test_hierarchy_does_not_depend_on_the_row_partition(oc):
             assert sizes == base[0] and nnzs == base[1]
             assert np.array_equal(cpts, base[2])
             assert abs(info["iters"] - base[3]) <= 1, (parts, info["iters"], base[3])
+
+
+def test_ilu0_factor_reproduces_the_pattern_entries(oc):
+    """ILU(0): (L U)_ij == a_ij on the sparsity pattern of A; block Jacobi drops the couplings between parts;
+    the Jacobi-iterated triangular solves converge to the exact substitution."""
+    n = 7
+    A, b = oc.Csr.laplace(n, n, n, 27)
+    S = A.to_scipy()
+    ilu = oc.Ilu(A)
+    F = ilu.factor().to_scipy()
+    L = sp.tril(F, -1) + sp.eye(F.shape[0])
+    U = sp.triu(F, 0)
+    R = (L @ U - S).tocsr()
+    mask = S.copy()
+    mask.data[:] = 1.0
+    assert abs(R.multiply(mask)).max() <= 1e-13 * abs(S).max()
+    z = ilu.apply(b)
+    assert np.allclose(spl.spsolve_triangular(U.tocsr(), spl.spsolve_triangular(L.tocsr(), b, lower=True), lower=False), z,
+                       rtol=1e-12, atol=1e-12)
+    it = oc.Ilu(A, tri_solve=0, lower_it=60, upper_it=60)
+    assert np.allclose(it.apply(b), z, rtol=1e-8, atol=1e-10)
+    N = n ** 3
+    bj = oc.Ilu(A, part_starts=[0, N // 2, N])
+    Fb = bj.factor().to_scipy().tocoo()
+    assert not np.any((Fb.row < N // 2) != (Fb.col < N // 2))
+    x, info = oc.gmres(A, b, kdim=30, tol=1e-9, maxit=100, amg=ilu)
+    assert info["converged"] and np.allclose(x, 1.0, atol=1e-7)
+    xs, si = ilu.solve(b, max_iter=400, tol=1e-8)
+    assert si["rel_res"] <= 1e-8 and np.allclose(xs, 1.0, atol=1e-6)
