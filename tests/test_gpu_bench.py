@@ -1,0 +1,50 @@
+"""bench.py contract: one JSON line with the agreed keys at N = 1, and the N > 1 code path (rehearsed with
+ranks sharing the one GPU of the test box over gloo callbacks -- RCCL refuses two ranks on one device)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _json_line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-3000:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_contract():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--grid", "64", "--cpu-n", "32"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-3000:]
+    j = _json_line(p.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["unit"] == "GDOF/s"
+    assert j["vs_baseline"] is None and j["dtype"] == "f64" and j["data"] == "synthetic" and "workload" in j["config"]
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert 5 <= j["iterations_per_solve"] <= 30 and j["final_rel_residual"] <= 1e-8
+
+
+def test_bench_two_ranks_rehearsal():
+    env = dict(os.environ)
+    env["MI_BENCH_SHARED_GPU"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29791", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--grid", "64", "--no-cpu"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-3000:]
+    j = _json_line(p.stdout)
+    assert j["n_gpus"] == 2 and j.get("rehearsal") is True and j["cpu_baseline"] is None
+    assert 5 <= j["iterations_per_solve"] <= 30 and j["final_rel_residual"] <= 1e-8
+    assert j["max_abs_error_vs_ones"] < 1e-5
