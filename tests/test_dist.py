@@ -33,7 +33,8 @@ def _run(nproc, mode, n, stencil, port, staging="host", seq=-1, devmin=None):
 
 
 @pytest.mark.parametrize("nproc,n,stencil,seq", [(2, 12, 7, -1), (3, 10, 27, 0), (2, 14, 7, 300),
-                                                  (4, 6, 7, 0)])  # last: coarse levels leave ranks without rows
+                                                  (4, 6, 7, 0),    # coarse levels leave ranks without rows
+                                                  (8, 8, 7, 0), (8, 10, 7, -1)])  # the node size of the benchmark
 def test_host_setup_world_size_n_gloo(nproc, n, stencil, seq):
     out = _run(nproc, "host", n, stencil, 29611 + nproc + (7 if seq > 0 else 0) + n, seq=seq)
     assert "dist host setup ok" in out
