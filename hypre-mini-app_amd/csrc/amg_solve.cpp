@@ -14,6 +14,7 @@
 
 #include "amg.hpp"
 #include "kernels.hpp"
+#include "profile.hpp"
 
 namespace mi {
 
@@ -23,6 +24,12 @@ bool &zero_guess_hint() {
 }
 
 namespace {
+// level 0 is timed under bench.py's id when that one is enabled, else under the per-level id
+int relax_prof_id(int level) {
+  KernelTimer *t = ctx().timer;
+  if (level == 0 && t && t->enabled[k::PROF_RELAX_L0]) return k::PROF_RELAX_L0;
+  return k::prof_level(k::PROF_LVL_RELAX, level);
+}
 struct GsKind {
   bool jacobi, l1, fwd, bwd;
 };
@@ -56,7 +63,7 @@ void BoomerAMG::relax(int level, int type, int points, const double *f, bool u_i
   ParCSR &A = *Lv.A;
   Comm &comm = my_comm();
   hipStream_t s = ctx().stream;
-  const int prof = (level == 0) ? k::PROF_RELAX_L0 : k::PROF_NONE;
+  const int prof = relax_prof_id(level);
   double *u = Lv.u.p;
   if (type == 9) {
     if (dense_solve(Lv, comm, f, u, s)) return;
@@ -102,7 +109,7 @@ void BoomerAMG::relax_pair(int level, int type, int first, const double *f, bool
   ParCSR &A = *Lv.A;
   Comm &comm = my_comm();
   hipStream_t s = ctx().stream;
-  const int prof = (level == 0) ? k::PROF_RELAX_L0 : k::PROF_NONE;
+  const int prof = relax_prof_id(level);
   const double w = p.relax_weight * p.outer_weight;
   const double *d = g.l1 ? Lv.d_l1gs.p : Lv.d_diag.p;
   const int ch = chunk(), nc = Lv.nc, n = Lv.n;
@@ -154,8 +161,8 @@ void BoomerAMG::cycle(int level, bool u_is_zero) {
   hipStream_t s = ctx().stream;
   relax_sweeps(level, 0, Lv.f.p, u_is_zero && p.num_sweeps[0] > 0);
   // r = f - A u ; f_c = P^T r ; u_c = 0
-  Lv.A->matvec(comm, -1.0, Lv.u.p, 1.0, Lv.f.p, Lv.tmp.p, s);
-  Lv.Rm->matvec(comm, 1.0, Lv.tmp.p, 0.0, nullptr, Ln.f.p, s);
+  Lv.A->matvec(comm, -1.0, Lv.u.p, 1.0, Lv.f.p, Lv.tmp.p, s, k::prof_level(k::PROF_LVL_RESID, level));
+  Lv.Rm->matvec(comm, 1.0, Lv.tmp.p, 0.0, nullptr, Ln.f.p, s, k::prof_level(k::PROF_LVL_RESTRICT, level));
   k::fill(Ln.u.p, Ln.n, 0.0, s);
   // the coarsest level is visited once per cycle; with a redundant tail the count continues into the tail
   const bool tail_next = tail && level + 1 == nlev - 1;
@@ -168,7 +175,7 @@ void BoomerAMG::cycle(int level, bool u_is_zero) {
     if (next) k::gather(tail_e.p, tail_pcol.p, Lv.Pm->halo.d_xext.p, next, s);
     Lv.Pm->matvec_ext_ready(1.0, Ln.u.p, 1.0, Lv.u.p, Lv.u.p, s);
   } else {
-    Lv.Pm->matvec(comm, 1.0, Ln.u.p, 1.0, Lv.u.p, Lv.u.p, s);
+    Lv.Pm->matvec(comm, 1.0, Ln.u.p, 1.0, Lv.u.p, Lv.u.p, s, k::prof_level(k::PROF_LVL_PROLONG, level));
   }
   relax_sweeps(level, 1, Lv.f.p, false);
 }

@@ -14,7 +14,22 @@ constexpr int GS_BLOCK = 256;     // chunks (lanes) per workgroup
 constexpr int GS_MAX_CHUNK = 32;
 
 // kernel classes that can be timed with HIP events (profile.cpp)
-enum ProfId { PROF_NONE = -1, PROF_SPMV_L0 = 0, PROF_RELAX_L0 = 1, PROF_DOT = 2, PROF_AXPY = 3, PROF_COUNT = 4 };
+// 0..3: the classes bench.py times; then per AMG level l < PROF_LEVELS: the residual SpMV of the cycle, the
+// relaxation passes, restriction and prolongation (profiles/roofline_table.py)
+constexpr int PROF_LEVELS = 16;
+enum ProfId {
+  PROF_NONE = -1,
+  PROF_SPMV_L0 = 0,
+  PROF_RELAX_L0 = 1,
+  PROF_DOT = 2,
+  PROF_AXPY = 3,
+  PROF_LVL_RESID = 4,
+  PROF_LVL_RELAX = PROF_LVL_RESID + PROF_LEVELS,
+  PROF_LVL_RESTRICT = PROF_LVL_RELAX + PROF_LEVELS,
+  PROF_LVL_PROLONG = PROF_LVL_RESTRICT + PROF_LEVELS,
+  PROF_COUNT = PROF_LVL_PROLONG + PROF_LEVELS
+};
+inline int prof_level(int base, int level) { return level < PROF_LEVELS ? base + level : PROF_NONE; }
 
 // host: row-block schedule for spmv_stream (<= 256 rows and < SPMV_TILE entries
 // per block, or exactly one longer row)

@@ -25,6 +25,8 @@ c_dbl = C.c_double
 vp = C.c_void_p
 
 PROF_SPMV_L0, PROF_RELAX_L0, PROF_DOT, PROF_AXPY = 0, 1, 2, 3
+PROF_LEVELS = 16
+PROF_LVL_RESID, PROF_LVL_RELAX, PROF_LVL_RESTRICT, PROF_LVL_PROLONG = 4, 4 + 16, 4 + 32, 4 + 48
 
 ALLREDUCE_FN = C.CFUNCTYPE(None, vp, vp, C.c_size_t, c_int, c_int)
 ALLGATHER_FN = C.CFUNCTYPE(None, vp, vp, vp, C.c_size_t)

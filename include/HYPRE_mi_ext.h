@@ -88,7 +88,8 @@ HYPRE_Int HYPRE_MI_BoomerAMGRelaxLevel(HYPRE_Solver solver, HYPRE_Int level, HYP
                                        const HYPRE_Real *f_host, HYPRE_Real *u_host);
 
 /* ---- HIP-event timing of kernel classes on the library stream.
- * id: 0 level-0 SpMV, 1 level-0 relaxation, 2 dot, 3 axpy */
+ * id: 0 level-0 SpMV of the Krylov loop, 1 level-0 relaxation, 2 dot, 3 axpy; per AMG level l < 16:
+ * 4 + l residual SpMV of the cycle, 20 + l relaxation passes, 36 + l restriction, 52 + l prolongation */
 HYPRE_Int HYPRE_MI_ProfileEnable(HYPRE_Int id, HYPRE_Int capacity);
 HYPRE_Int HYPRE_MI_ProfileReset(void);
 HYPRE_Int HYPRE_MI_ProfileGet(HYPRE_Int id, long long *launches, double *total_ms, double *min_ms);
