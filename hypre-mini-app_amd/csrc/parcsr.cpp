@@ -1,4 +1,5 @@
 #include "parcsr.hpp"
+#include "setup_kernels.hpp"
 
 #include <algorithm>
 #include <cstring>
@@ -218,7 +219,16 @@ void ParCSR::build_halo_plan(Comm &comm) {
 void ParCSR::to_device() {
   ensure_init();
   MI_REQUIRE(!host_diag_stale, "to_device: the host copy of the diag block was not built");
-  d_diag.upload(diag);
+  // large blocks: raw upload, then row-block schedule inputs, x cache and Gauss-Seidel code bits on the device
+  // (sk::to_solve_format); small ones through the host builder (DevCSR::upload) -- same result
+  static const long long dev_min = getenv("MI_HYPRE_DEVICE_FORMAT_MIN_NNZ") ? atoll(getenv("MI_HYPRE_DEVICE_FORMAT_MIN_NNZ")) : 4000000;
+  if (diag.nnz() >= dev_min) {
+    sk::DCsr raw;
+    raw.upload(diag, ctx().stream);
+    sk::to_solve_format(raw, d_diag, ctx().stream);
+  } else {
+    d_diag.upload(diag);
+  }
   to_device_halo();
 }
 
