@@ -40,18 +40,97 @@ void assemble_parcsr(Comm &comm, gidx ilower, gidx iupper, gidx jlower, gidx jup
   const int nrows = (int)(iupper - ilower + 1);
   const int ncols_loc = (int)(jupper - jlower + 1);
   std::vector<int64_t> ia((size_t)nrows + 1, 0);
-  for (auto &b : batches)
-    for (size_t k = 0; k < b.rows.size(); k++) {
-      const gidx r = b.rows[k] - ilower;
-      if (r < 0 || r >= nrows) fail(4, "IJMatrix: row " + std::to_string(b.rows[k]) + " is not owned by this rank");
-      ia[(size_t)r + 1]++;
-    }
-  for (int i = 0; i < nrows; i++) ia[(size_t)i + 1] += ia[(size_t)i];
-  const int64_t total = ia[(size_t)nrows];
-  std::vector<gidx> cj((size_t)total);
-  std::vector<double> cv((size_t)total);
-  std::vector<char> cadd((size_t)total);
+  int64_t total = 0;
+  for (auto &b : batches) total += (int64_t)b.rows.size();
+  std::vector<gidx> cj;
+  std::vector<double> cv;
+  std::vector<char> cadd;
+  // Fast path: the entries arrive in row order (generators, row-sorted files) -- they already are the CSR
+  // entry arrays, only the row pointers have to be found.  Checked in parallel; anything else takes the
+  // counting sort below.
+  bool in_row_order = total > 0;
   {
+    gidx prev_last = ilower;
+    for (auto &b : batches) {
+      if (b.rows.empty()) continue;
+      if (b.rows.front() < prev_last) in_row_order = false;
+      prev_last = b.rows.back();
+    }
+    if (in_row_order)
+      for (auto &b : batches) {
+        const int64_t m = (int64_t)b.rows.size();
+        std::vector<char> bad((size_t)host_threads() + 1, 0);
+        parallel_for(m, [&](int64_t k0, int64_t k1, int t) {
+          for (int64_t k = k0; k < k1; k++) {
+            const gidx r = b.rows[(size_t)k];
+            if (r < ilower || r > iupper || (k > 0 && b.rows[(size_t)k - 1] > r)) {
+              bad[(size_t)t] = 1;
+              return;
+            }
+          }
+        });
+        for (char f : bad) in_row_order = in_row_order && !f;
+        if (!in_row_order) break;
+      }
+  }
+  if (in_row_order) {
+    // row pointers: ia[r + 1] = one past the last entry of row r
+    std::vector<int64_t> last((size_t)nrows, -1);
+    int64_t off = 0;
+    for (auto &b : batches) {
+      const int64_t m = (int64_t)b.rows.size();
+      parallel_for(m, [&](int64_t k0, int64_t k1, int) {
+        for (int64_t k = k0; k < k1; k++)
+          if (k + 1 == m || b.rows[(size_t)k + 1] != b.rows[(size_t)k]) {
+            int64_t &slot = last[(size_t)(b.rows[(size_t)k] - ilower)];
+            slot = std::max(slot, off + k + 1);  // a row may continue in a later batch: batches are visited in order
+          }
+      });
+      off += m;
+    }
+    for (int i = 0; i < nrows; i++) ia[(size_t)i + 1] = (last[(size_t)i] >= 0) ? last[(size_t)i] : ia[(size_t)i];
+    bool same_add = true;
+    for (auto &b : batches) same_add = same_add && (b.add == batches.front().add);
+    if (batches.size() == 1) {
+      cj.swap(batches[0].cols);
+      cv.swap(batches[0].vals);
+    } else {
+      cj.resize((size_t)total);
+      cv.resize((size_t)total);
+      int64_t o = 0;
+      for (auto &b : batches) {
+        std::copy(b.cols.begin(), b.cols.end(), cj.begin() + o);
+        std::copy(b.vals.begin(), b.vals.end(), cv.begin() + o);
+        o += (int64_t)b.rows.size();
+      }
+    }
+    cadd.resize((size_t)total);
+    {
+      int64_t o = 0;
+      for (auto &b : batches) {
+        const int64_t m = (int64_t)b.rows.size();
+        const char f = b.add ? 1 : 0;
+        parallel_for(m, [&](int64_t k0, int64_t k1, int) { memset(cadd.data() + o + k0, f, (size_t)(k1 - k0)); });
+        o += m;
+      }
+    }
+    (void)same_add;
+    for (auto &b : batches) {
+      std::vector<gidx>().swap(b.rows);
+      std::vector<gidx>().swap(b.cols);
+      std::vector<double>().swap(b.vals);
+    }
+  } else {
+    for (auto &b : batches)
+      for (size_t k = 0; k < b.rows.size(); k++) {
+        const gidx r = b.rows[k] - ilower;
+        if (r < 0 || r >= nrows) fail(4, "IJMatrix: row " + std::to_string(b.rows[k]) + " is not owned by this rank");
+        ia[(size_t)r + 1]++;
+      }
+    for (int i = 0; i < nrows; i++) ia[(size_t)i + 1] += ia[(size_t)i];
+    cj.resize((size_t)total);
+    cv.resize((size_t)total);
+    cadd.resize((size_t)total);
     std::vector<int64_t> pos(ia.begin(), ia.end() - 1);
     for (auto &b : batches) {
       for (size_t k = 0; k < b.rows.size(); k++) {
