@@ -45,6 +45,54 @@ BoomerAMG *KrylovSolver::amg_in_level_order(ParCSR &A, int n) const {
   return &amg;
 }
 
+BoomerAMG *KrylovSolver::enter_level_order(ParCSR &A_in, ParVector &b_in, ParVector &x_in, ParCSR *&A, ParVector *&b,
+                                           ParVector *&x) {
+  const int n = b_in.n;
+  BoomerAMG *amg = amg_in_level_order(A_in, n);
+  A = &A_in;
+  b = &b_in;
+  x = &x_in;
+  if (!amg) return nullptr;
+  hipStream_t s = ctx().stream;
+  if (bp.n != n) {
+    bp.init(b_in.start, b_in.end, 1);
+    xp.init(b_in.start, b_in.end, 1);
+  }
+  k::gather(b_in.data(), amg->L[0].d_perm.p, bp.data(), n, s);
+  k::gather(x_in.data(), amg->L[0].d_perm.p, xp.data(), n, s);
+  A = amg->L[0].A;
+  b = &bp;
+  x = &xp;
+  return amg;
+}
+
+void KrylovSolver::leave_level_order(BoomerAMG *amg, ParVector &x_in) {
+  if (amg) k::scatter_set(x_in.data(), amg->L[0].d_perm.p, xp.data(), x_in.n, ctx().stream);
+}
+
+const double *KrylovSolver::precond_in_order(BoomerAMG *amg, ParCSR &A, ParVector &rhs, ParVector &out, bool need_copy) {
+  if (!amg) {
+    apply_precond(A, rhs, out);
+    return out.data();
+  }
+  hipStream_t s = ctx().stream;
+  AmgLevel &L0 = amg->L[0];
+  const int n = L0.n;
+  double *own_f = L0.f.p;
+  L0.f.p = rhs.data();  // read-only inside the cycle
+  k::fill(L0.u.p, n, 0.0, s);
+  try {
+    amg->cycle(0, true);
+  } catch (...) {
+    L0.f.p = own_f;
+    throw;
+  }
+  L0.f.p = own_f;
+  if (!need_copy) return L0.u.p;
+  k::copy(L0.u.p, out.data(), n, s);
+  return out.data();
+}
+
 void GmresSolver::setup(ParCSR &A, ParVector &b, ParVector &x) {
   ensure_init();
   MI_REQUIRE(b.ncomp == 1 && x.ncomp == 1, "GMRES: multi-component vectors are not supported");
@@ -88,39 +136,14 @@ int GmresSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
   double *slots = c.red_out.p;
 
   // level ordering of the AMG preconditioner (see amg_in_level_order)
-  BoomerAMG *amg = amg_in_level_order(A_in, n);
-  if (amg) {
-    if (bp.n != n) {
-      bp.init(b_in.start, b_in.end, 1);
-      xp.init(b_in.start, b_in.end, 1);
-    }
-    k::gather(b_in.data(), amg->L[0].d_perm.p, bp.data(), n, s);
-    k::gather(x_in.data(), amg->L[0].d_perm.p, xp.data(), n, s);
-  }
-  ParCSR &A = amg ? *amg->L[0].A : A_in;
-  ParVector &b = amg ? bp : b_in;
-  ParVector &x = amg ? xp : x_in;
-  // out = M^-1 rhs; returns where the result lives (the AMG's own level vector on the fast path unless a
-  // copy is asked for)
+  ParCSR *Ap;
+  ParVector *bq, *xq;
+  BoomerAMG *amg = enter_level_order(A_in, b_in, x_in, Ap, bq, xq);
+  ParCSR &A = *Ap;
+  ParVector &b = *bq;
+  ParVector &x = *xq;
   auto precond = [&](ParVector &rhs, ParVector &out, bool need_copy) -> const double * {
-    if (!amg) {
-      apply_precond(A, rhs, out);
-      return out.data();
-    }
-    AmgLevel &L0 = amg->L[0];
-    double *own_f = L0.f.p;
-    L0.f.p = rhs.data();  // read-only inside the cycle
-    k::fill(L0.u.p, n, 0.0, s);
-    try {
-      amg->cycle(0, true);
-    } catch (...) {
-      L0.f.p = own_f;
-      throw;
-    }
-    L0.f.p = own_f;
-    if (!need_copy) return L0.u.p;
-    k::copy(L0.u.p, out.data(), n, s);
-    return out.data();
+    return precond_in_order(amg, A, rhs, out, need_copy);
   };
 
   ParVector &p0 = basis(0);
@@ -279,7 +302,7 @@ int GmresSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
       k::axpy(1.0, basis(i).data(), basis(0).data(), n, s);
     }
   }
-  if (amg) k::scatter_set(x_in.data(), amg->L[0].d_perm.p, xp.data(), n, s);
+  leave_level_order(amg, x_in);
   MI_HIP(hipStreamSynchronize(s));
   num_iterations = iter;
   rel_residual_norm = (b_norm > 0.0) ? r_norm / b_norm : r_norm;
@@ -300,18 +323,24 @@ void PcgSolver::setup(ParCSR &A, ParVector &b, ParVector &x) {
 
 // hypre_PCGSolve (krylov/pcg.c), default options: two_norm 0 (the convergence
 // measure is <C r, r> / <C b, b> against tol^2), no residual recomputation
-int PcgSolver::solve(ParCSR &A, ParVector &b, ParVector &x) {
+int PcgSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
   ensure_init();
   Comm &comm = current_comm();
   hipStream_t s = ctx().stream;
   const double t_start = wall_time();
-  const int n = b.n;
-  if (r.n != n) setup(A, b, x);
+  const int n = b_in.n;
+  if (r.n != n) setup(A_in, b_in, x_in);
+  ParCSR *Ap;
+  ParVector *bq, *xq;
+  BoomerAMG *amg = enter_level_order(A_in, b_in, x_in, Ap, bq, xq);
+  ParCSR &A = *Ap;
+  ParVector &b = *bq;
+  ParVector &x = *xq;
   double bi_prod;
   if (two_norm) {
     bi_prod = par_dot_host(comm, b.data(), b.data(), n, s);
   } else {
-    apply_precond(A, b, pv);
+    precond_in_order(amg, A, b, pv, true);
     bi_prod = par_dot_host(comm, pv.data(), b.data(), n, s);
   }
   double eps = tol * tol;
@@ -320,6 +349,7 @@ int PcgSolver::solve(ParCSR &A, ParVector &b, ParVector &x) {
   num_iterations = 0;
   if (!(bi_prod > 0.0)) {  // zero right-hand side: x = 0 (pcg.c)
     k::fill(x.data(), n, 0.0, s);
+    leave_level_order(amg, x_in);
     MI_HIP(hipStreamSynchronize(s));
     rel_residual_norm = 0.0;
     converged = true;
@@ -328,7 +358,7 @@ int PcgSolver::solve(ParCSR &A, ParVector &b, ParVector &x) {
   }
   if (atol > 0.0) eps = std::max(eps, atol * atol / bi_prod);
   A.matvec(comm, -1.0, x.data(), 1.0, b.data(), r.data(), s, k::PROF_SPMV_L0);
-  apply_precond(A, r, pv);
+  precond_in_order(amg, A, r, pv, true);
   double gamma = par_dot_host(comm, r.data(), pv.data(), n, s);
   double i_prod = two_norm ? par_dot_host(comm, r.data(), r.data(), n, s) : gamma;
   norms.push_back(std::sqrt(std::fabs(i_prod) / bi_prod));
@@ -343,7 +373,7 @@ int PcgSolver::solve(ParCSR &A, ParVector &b, ParVector &x) {
     const double gamma_old = gamma;
     k::axpy(alpha, pv.data(), x.data(), n, s);
     k::axpy(-alpha, sv.data(), r.data(), n, s);
-    apply_precond(A, r, sv);
+    precond_in_order(amg, A, r, sv, true);
     gamma = par_dot_host(comm, r.data(), sv.data(), n, s);
     i_prod = two_norm ? par_dot_host(comm, r.data(), r.data(), n, s) : gamma;
     norms.push_back(std::sqrt(std::fabs(i_prod) / bi_prod));
@@ -356,6 +386,7 @@ int PcgSolver::solve(ParCSR &A, ParVector &b, ParVector &x) {
     k::scale(beta, pv.data(), n, s);
     k::axpy(1.0, sv.data(), pv.data(), n, s);
   }
+  leave_level_order(amg, x_in);
   MI_HIP(hipStreamSynchronize(s));
   num_iterations = i;
   rel_residual_norm = std::sqrt(std::fabs(i_prod) / bi_prod);
@@ -370,14 +401,20 @@ void BicgstabSolver::setup(ParCSR &A, ParVector &b, ParVector &x) {
   if (precond_setup) precond_setup(precond_data, &A, &b, &x);
 }
 
-int BicgstabSolver::solve(ParCSR &A, ParVector &b, ParVector &x) {
+int BicgstabSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
   ensure_init();
   Ctx &c = ctx();
   Comm &comm = current_comm();
   hipStream_t s = c.stream;
   const double t_start = wall_time();
-  const int n = b.n;
-  if (r.n != n) setup(A, b, x);
+  const int n = b_in.n;
+  if (r.n != n) setup(A_in, b_in, x_in);
+  ParCSR *Ap;
+  ParVector *bq, *xq;
+  BoomerAMG *amg = enter_level_order(A_in, b_in, x_in, Ap, bq, xq);
+  ParCSR &A = *Ap;
+  ParVector &b = *bq;
+  ParVector &x = *xq;
   const double epsmac = 1.e-128;
   A.matvec(comm, -1.0, x.data(), 1.0, b.data(), r0.data(), s, k::PROF_SPMV_L0);
   k::copy(r0.data(), r.data(), n, s);
@@ -403,7 +440,7 @@ int BicgstabSolver::solve(ParCSR &A, ParVector &b, ParVector &x) {
   };
   while (!converged && iter < max_iter) {
     iter++;
-    apply_precond(A, pv, v);
+    precond_in_order(amg, A, pv, v, true);
     A.matvec(comm, 1.0, v.data(), 0.0, nullptr, q.data(), s, k::PROF_SPMV_L0);
     const double temp = par_dot_host(comm, r0.data(), q.data(), n, s);
     if (std::fabs(temp) < epsmac) break;
@@ -416,7 +453,7 @@ int BicgstabSolver::solve(ParCSR &A, ParVector &b, ParVector &x) {
       converged = true;
       break;
     }
-    apply_precond(A, r, v);
+    precond_in_order(amg, A, r, v, true);
     A.matvec(comm, 1.0, v.data(), 0.0, nullptr, sv.data(), s, k::PROF_SPMV_L0);
     const double ss = par_dot_host(comm, sv.data(), sv.data(), n, s);
     const double gamma = (ss != 0.0) ? par_dot_host(comm, r.data(), sv.data(), n, s) / ss : 0.0;
@@ -438,6 +475,7 @@ int BicgstabSolver::solve(ParCSR &A, ParVector &b, ParVector &x) {
     k::scale(beta * alpha / gamma, pv.data(), n, s);
     k::axpy(1.0, r.data(), pv.data(), n, s);
   }
+  leave_level_order(amg, x_in);
   MI_HIP(hipStreamSynchronize(s));
   num_iterations = iter;
   rel_residual_norm = (b_norm > 0.0) ? r_norm / b_norm : r_norm;

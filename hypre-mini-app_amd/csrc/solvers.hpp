@@ -32,6 +32,14 @@ struct KrylovSolver : SolverBase {
   void apply_precond(ParCSR &A, ParVector &rhs, ParVector &out);
   // the BoomerAMG behind precond_solve when the Krylov loop may run in its level-0 ordering (krylov.cpp)
   BoomerAMG *amg_in_level_order(ParCSR &A, int n) const;
+  // the loop's view of the system: the caller's objects, or (fast path) the level-0 operator of the AMG with
+  // b and x permuted into bp / xp; leave_level_order scatters xp back into the caller's x
+  ParVector bp, xp;
+  BoomerAMG *enter_level_order(ParCSR &A_in, ParVector &b_in, ParVector &x_in, ParCSR *&A, ParVector *&b, ParVector *&x);
+  void leave_level_order(BoomerAMG *amg, ParVector &x_in);
+  // out = M^-1 rhs; returns where the result lives (the AMG's own level vector on the fast path unless a copy
+  // into `out` is asked for)
+  const double *precond_in_order(BoomerAMG *amg, ParCSR &A, ParVector &rhs, ParVector &out, bool need_copy);
 };
 
 struct GmresSolver : KrylovSolver {
@@ -45,7 +53,6 @@ struct GmresSolver : KrylovSolver {
   int ortho = 0;
   std::vector<std::unique_ptr<ParVector>> z;
   ParVector r, w;
-  ParVector bp, xp;  // b and x in the preconditioner's level-0 ordering (fast path)
   GmresSolver() : KrylovSolver(K_GMRES) {}
   void setup(ParCSR &A, ParVector &b, ParVector &x);
   int solve(ParCSR &A, ParVector &b, ParVector &x);
