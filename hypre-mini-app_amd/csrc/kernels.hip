@@ -785,8 +785,8 @@ __global__ __launch_bounds__(256) void dot_partial_k(const double *__restrict__ 
   const long long stride = (long long)gridDim.x * 512;
   long long i = ((long long)blockIdx.x * 256 + tid) * 2;
   for (; i + 1 < n; i += stride) {
-    const double2 a = *reinterpret_cast<const double2 *>(x + i);
-    const double2 b = *reinterpret_cast<const double2 *>(y + i);
+    const d2_t a = nt_load(reinterpret_cast<const d2_t *>(x + i));
+    const d2_t b = nt_load(reinterpret_cast<const d2_t *>(y + i));
     s += a.x * b.x + a.y * b.y;
   }
   if (i < n) s += x[i] * y[i];
@@ -811,13 +811,14 @@ __global__ __launch_bounds__(256) void axpy_dot_partial_k(const double *__restri
   const long long stride = (long long)gridDim.x * 512;
   long long i = ((long long)blockIdx.x * 256 + tid) * 2;
   for (; i + 1 < n; i += stride) {
-    const double2 xv = *reinterpret_cast<const double2 *>(xa + i);
-    double2 yv = *reinterpret_cast<double2 *>(y + i);
+    // every operand is streamed exactly once: non-temporal accesses keep them out of L2's way
+    const d2_t xv = nt_load(reinterpret_cast<const d2_t *>(xa + i));
+    d2_t yv = nt_load(reinterpret_cast<const d2_t *>(y + i));
     yv.x += a * xv.x;
     yv.y += a * xv.y;
-    *reinterpret_cast<double2 *>(y + i) = yv;
-    double2 dv = yv;
-    if (xd) dv = *reinterpret_cast<const double2 *>(xd + i);
+    __builtin_nontemporal_store(yv, reinterpret_cast<d2_t *>(y + i));
+    d2_t dv = yv;
+    if (xd) dv = nt_load(reinterpret_cast<const d2_t *>(xd + i));
     s += dv.x * yv.x + dv.y * yv.y;
   }
   if (i < n) {
