@@ -63,7 +63,8 @@ template <int EPI>
 __device__ __forceinline__ void epilogue(int r, double s, const double *__restrict__ x, double *__restrict__ y,
                                          const EpiArgs &e) {
   if (EPI == 0) {
-    y[r] = (e.beta == 0.0) ? e.alpha * s : e.alpha * s + e.beta * e.b[r];
+    // y is written once and next read by another kernel: keep it out of L2's way
+    __builtin_nontemporal_store((e.beta == 0.0) ? e.alpha * s : e.alpha * s + e.beta * e.b[r], y + r);
   } else {
     const double xi = x[r];
     double out = xi;
