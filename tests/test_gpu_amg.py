@@ -341,3 +341,50 @@ def test_ilu_unsupported_variants_report_errors(mi):
     with pytest.raises(mi.HypreError):
         ilu.setup(A)
     mi.call("HYPRE_ClearAllErrors")
+
+
+def _ij_from_scipy(mi, M):
+    M = M.tocsr()
+    A = mi.IJMatrix(0, M.shape[0] - 1)
+    coo = M.tocoo()
+    A.set_values_coo(coo.row.astype(np.int64), coo.col.astype(np.int64), coo.data.astype(np.float64))
+    A.assemble()
+    return A
+
+
+@pytest.mark.parametrize("case", ["one_by_one", "diagonal", "zero_rhs", "tiny_dense"])
+def test_degenerate_systems(mi, case):
+    """Edge cases of the solve path: a 1x1 system, a diagonal operator (empty strength graph: single level),
+    a zero right-hand side (zero iterations, x = 0), a small dense block (coarsest-level direct solve only)."""
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(8)
+    if case == "one_by_one":
+        M, rhs = sp.csr_matrix(np.array([[4.0]])), np.array([2.0])
+    elif case == "diagonal":
+        d = 1.0 + rng.random(300)
+        M, rhs = sp.diags(d).tocsr(), rng.standard_normal(300)
+    elif case == "zero_rhs":
+        T = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(200, 200))
+        M, rhs = T.tocsr(), np.zeros(200)
+    else:
+        B = rng.random((7, 7))
+        M, rhs = sp.csr_matrix(B @ B.T + 7 * np.eye(7)), rng.standard_normal(7)
+    n = M.shape[0]
+    A = _ij_from_scipy(mi, M)
+    b = mi.IJVector(0, n - 1, rhs)
+    x = mi.IJVector(0, n - 1, np.zeros(n))
+    amg = mi.BoomerAMG(print_level=0)
+    gm = mi.GMRES(tolerance=1e-12, max_iterations=50, kspace=20, print_level=0)
+    gm.set_precond(amg)
+    gm.setup(A, b, x)
+    assert gm.solve(A, b, x) == 0
+    xs = x.get()
+    if case == "zero_rhs":
+        assert gm.num_iterations == 0 and np.all(xs == 0.0)
+    else:
+        ref = np.linalg.solve(M.toarray(), rhs)
+        assert np.allclose(xs, ref, rtol=1e-9, atol=1e-12)
+        assert gm.num_iterations <= 10
+    if case in ("one_by_one", "diagonal", "tiny_dense"):
+        assert amg.num_levels == 1
