@@ -59,6 +59,20 @@ def cpu_baseline(args, chunk):
     x, info = oc.gmres(A, b, kdim=args.kdim, tol=args.tol, maxit=args.max_iter, amg=amg)
     t_solve = time.time() - t0
     ndof = n ** 3
+    cpu_model = "unknown CPU"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    # the same solve on ONE thread, for the per-core figure
+    oc.lib().oracle_set_threads(1)
+    t0 = time.time()
+    _, info1 = oc.gmres(A, b, kdim=args.kdim, tol=args.tol, maxit=args.max_iter, amg=amg)
+    t_solve1 = time.time() - t0
+    oc.lib().oracle_set_threads(cores)
     return {
         "value": ndof * info["iters"] / t_solve / 1e9,
         "unit": "GDOF/s",
@@ -66,7 +80,9 @@ def cpu_baseline(args, chunk):
         "kind": "port",
         "sample": f"laplace_3d {n}^3 {args.stencil}-pt, GMRES({args.kdim})+AMG tol {args.tol:g}: "
                   f"{info['iters']} iterations in {t_solve:.2f} s solve (+{t_setup:.2f} s setup, 1 thread), "
-                  f"rel res {info['rel_res']:.2e}; HYPRE-algorithm CPU restatement (oracle/), OpenMP {cores} threads",
+                  f"rel res {info['rel_res']:.2e}; HYPRE-algorithm CPU restatement (oracle/), OpenMP {cores} threads of "
+                  f"{os.cpu_count()} visible on {cpu_model}; on 1 thread: {t_solve1:.2f} s = "
+                  f"{ndof * info1['iters'] / t_solve1 / 1e9:.4f} GDOF/s",
         "iterations": info["iters"],
         "iterations_per_s": info["iters"] / t_solve,
     }
