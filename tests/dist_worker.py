@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--stencil", type=int, default=7)
     ap.add_argument("--staging", default="host", help="host | cuda (device-tensor staging of the callback transport)")
     ap.add_argument("--seq", type=int, default=-1, help="redundant-level threshold (HYPRE seq_threshold); -1 = library default")
+    ap.add_argument("--golden", default="", help="name of a multi-part fixture of tests/golden to replay after the oracle checks")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -178,6 +179,24 @@ def main():
         prod = mi.c_dbl()
         mi.call("HYPRE_ParVectorInnerProd", xv.par, xv.par, mi.C.byref(prod))
         assert abs(prod.value - float(v @ v)) <= 1e-12 * float(v @ v)
+        if args.golden:
+            # the committed fixture of this partition (tests/golden/make_golden.py: GMRES(50), tol 1e-8)
+            g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", args.golden + ".npz"))
+            assert chunk.value == 8 and len(g["rhs"]) == N
+            x.fill(0.0)
+            g2 = mi.GMRES(tolerance=1e-8, max_iterations=100, kspace=50, print_level=0)
+            g2.set_precond(amg)
+            g2.setup(A, b, x)
+            assert g2.solve(A, b, x) == 0
+            assert g2.num_iterations == int(g["iters"]), (g2.num_iterations, int(g["iters"]))
+            assert np.allclose(g2.residual_history(), g["norms"], rtol=1e-7)
+            assert abs(g2.final_rel_res - float(g["rel_res"])) <= 1e-10
+            xs, ref = x.get(), g["x"][starts[rank]:starts[rank + 1]]
+            assert np.all(np.abs(xs - ref) < np.maximum(1e-6 * np.maximum(np.abs(xs), np.abs(ref)), 1e-8))
+            assert amg.num_levels == len(g["level_rows"])
+            assert np.array_equal(np.asarray(amg.level_cf(0), dtype=np.int8), g["cf0"][starts[rank]:starts[rank + 1]])
+            if rank == 0:
+                print(f"golden {args.golden} ok")
         if rank == 0:
             print(f"dist solve ok: {size} ranks, {gm.num_iterations} iterations, rel res {gm.final_rel_res:.3e}, "
                   f"{n_redundant} redundant levels")

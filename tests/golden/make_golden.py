@@ -26,7 +26,14 @@ CASES = [
     dict(name="lap7_16", n=16, stencil=7, kdim=50, tol=1e-8, nparts=1),
     dict(name="lap7_16_k5", n=16, stencil=7, kdim=5, tol=1e-10, nparts=1),
     dict(name="lap27_10", n=10, stencil=27, kdim=50, tol=1e-8, nparts=1),
-    dict(name="lap7_12_p2", n=12, stencil=7, kdim=50, tol=1e-8, nparts=2),
+    dict(name="lap7_12_p2", n=12, stencil=7, kdim=50, tol=1e-8, nparts=2),  # no redundant levels (seq_threshold 0)
+    # the other solver families (method: cogmres / pcg / bicgstab with AMG; gmres with ILU(0); redundant
+    # coarse levels on 3 parts)
+    dict(name="lap7_12_cogmres", n=12, stencil=7, kdim=50, tol=1e-8, nparts=1, method="cogmres"),
+    dict(name="lap7_12_pcg", n=12, stencil=7, kdim=50, tol=1e-8, nparts=1, method="pcg"),
+    dict(name="lap7_12_bicgstab", n=12, stencil=7, kdim=50, tol=1e-8, nparts=1, method="bicgstab"),
+    dict(name="lap7_10_ilu", n=10, stencil=7, kdim=50, tol=1e-8, nparts=1, method="gmres_ilu"),
+    dict(name="lap7_14_p3_seq", n=14, stencil=7, kdim=50, tol=1e-8, nparts=3, redundant_rows=300),
 ]
 
 
@@ -38,8 +45,22 @@ def run_case(c):
     if c["nparts"] > 1:
         per, rem = divmod(N, c["nparts"])
         kw["part_starts"] = [per * r + min(r, rem) for r in range(c["nparts"])] + [N]
+    if "redundant_rows" in c:
+        kw["redundant_rows"] = c["redundant_rows"]
     amg = oc.Amg(A, oc.default_params(**kw))
-    x, info = oc.gmres(A, b, kdim=c["kdim"], tol=c["tol"], maxit=100, amg=amg)
+    method = c.get("method", "gmres")
+    if method == "gmres":
+        x, info = oc.gmres(A, b, kdim=c["kdim"], tol=c["tol"], maxit=100, amg=amg)
+    elif method == "cogmres":
+        x, info = oc.cogmres(A, b, kdim=c["kdim"], cgs=0, tol=c["tol"], maxit=100, amg=amg)
+    elif method == "pcg":
+        x, info = oc.pcg(A, b, tol=c["tol"], maxit=100, amg=amg)
+    elif method == "bicgstab":
+        x, info = oc.bicgstab(A, b, tol=c["tol"], maxit=100, amg=amg)
+    elif method == "gmres_ilu":
+        x, info = oc.gmres(A, b, kdim=c["kdim"], tol=c["tol"], maxit=200, amg=oc.Ilu(A))
+    else:
+        raise ValueError(method)
     sizes = np.array([amg.level_A(l).shape[0] for l in range(amg.num_levels)])
     nnzs = np.array([amg.level_A(l).nnz for l in range(amg.num_levels)])
     return dict(rhs=b, x=x, norms=info["norms"], iters=info["iters"], rel_res=info["rel_res"], level_rows=sizes,

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
 
 
-def _run(nproc, mode, n, stencil, port, staging="host", seq=-1, devmin=None):
+def _run(nproc, mode, n, stencil, port, staging="host", seq=-1, devmin=None, golden=""):
     env = dict(os.environ)
     if devmin is not None:  # levels with at least this many rows are built (and sliced) on the device
         env["MI_HYPRE_DEVICE_SETUP_MIN_ROWS"] = str(devmin)
@@ -27,6 +27,8 @@ def _run(nproc, mode, n, stencil, port, staging="host", seq=-1, devmin=None):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), WORKER, "--mode", mode, "--grid", str(n),
            "--stencil", str(stencil), "--staging", staging, "--seq", str(seq)]
+    if golden:
+        cmd += ["--golden", golden]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-4000:]
     return p.stdout
@@ -63,3 +65,11 @@ def test_device_solve_cuda_staged_transport():
     interface), exercised here over gloo because two nccl ranks cannot share the one GPU of the test box."""
     out = _run(2, "solve", 12, 7, 29699, staging="cuda")
     assert "dist solve ok" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,nproc,n,seq", [("lap7_12_p2", 2, 12, 0), ("lap7_14_p3_seq", 3, 14, 300)])
+def test_multi_part_golden_fixtures(name, nproc, n, seq):
+    """The committed multi-part fixtures (tests/golden), replayed with one rank per part."""
+    out = _run(nproc, "solve", n, 7, 29771 + nproc + n, seq=seq, golden=name)
+    assert f"golden {name} ok" in out
