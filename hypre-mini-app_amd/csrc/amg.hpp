@@ -46,6 +46,10 @@ struct AmgLevel {
   // C-first ordered operators of a level built on the device, until setup_device moves them into the
   // solve-phase format (A->d_diag, Pm->d_diag, Rm->d_diag)
   sk::DCsr oA, oP, oR;
+  // sub-operator of A for the first sweep on a zero guess (sk::zero_guess_operator): the down leg of every
+  // cycle starts from u = 0, where most of A multiplies zeros
+  DevCSR Az;
+  bool has_Az = false;
   std::vector<int> cf;  // +1 C, -1 F (empty on the coarsest level)
   bool has_cf = false;  // the level has a C/F splitting -- a GLOBAL fact (cf itself is empty on a rank without rows)
   DVec<signed char> d_cf;
@@ -145,6 +149,11 @@ struct BoomerAMG {
   // fill the host arrays of a level's A / P / R from the device (inspection API, coarse solve)
   void ensure_host(int level);
 };
+
+// MI_HYPRE_GS_ZERO_SKIP: 0 = sweeps on a zero guess read like any other sweep, 1 = they skip the gathers of
+// known zeros, 2 (default) = they also run on the zero-guess sub-operator (AmgLevel::Az)
+int zero_skip_mode();
+void set_zero_skip_mode(int mode);  // applies to hierarchies set up afterwards (mode 2) / to every later sweep (0, 1)
 
 // set by a Krylov solver right before it calls the preconditioner with x == 0,
 // consumed (and cleared) by BoomerAMG::solve

@@ -1354,6 +1354,18 @@ void BoomerAMG::setup_device() {
     if (li > 0 || !Lv.A->on_device) place(*Lv.A, Lv.oA);
     if (Lv.Pm) place(*Lv.Pm, Lv.oP);
     if (Lv.Rm) place(*Lv.Rm, Lv.oR);
+    // the down leg starts every level from u = 0: its sweep runs on the entries that can see non-zeros
+    Lv.has_Az = false;
+    Lv.Az = DevCSR();
+    const int t0 = p.relax_type[0];
+    const bool down_gs = t0 == 3 || t0 == 4 || t0 == 6 || t0 == 8 || t0 == 13 || t0 == 14;  // hybrid GS family
+    if (zero_skip_mode() > 1 && down_gs && Lv.has_cf && !Lv.cf.empty() && Lv.n > 0 && Lv.nc > 0 &&
+        Lv.A->d_diag.nrows == Lv.n && Lv.A->d_diag.ncols == Lv.n) {
+      sk::DCsr Z;
+      sk::zero_guess_operator(Lv.A->d_diag, Lv.nc, ch, Z, s);
+      sk::to_solve_format(Z, Lv.Az, s);
+      Lv.has_Az = true;
+    }
     if (!Lv.d_diag.p || Lv.d_diag.n != (size_t)Lv.n) {
       Lv.d_diag.upload(Lv.diag);
       Lv.d_l1gs.upload(Lv.l1gs);

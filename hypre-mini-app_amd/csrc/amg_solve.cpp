@@ -23,9 +23,20 @@ bool &zero_guess_hint() {
   return hint;
 }
 
+static int g_zero_skip = -1;
+int zero_skip_mode() {
+  if (g_zero_skip < 0) {
+    const char *e = getenv("MI_HYPRE_GS_ZERO_SKIP");
+    g_zero_skip = e ? std::max(0, std::min(2, atoi(e))) : 2;
+  }
+  return g_zero_skip;
+}
+void set_zero_skip_mode(int mode) { g_zero_skip = std::max(0, std::min(2, mode)); }
+
 namespace {
 // level 0 is timed under bench.py's id when that one is enabled, else under the per-level id
-int relax_prof_id(int level) {
+int relax_prof_id(int level, bool zero_guess) {
+  if (zero_guess) return k::prof_level(k::PROF_LVL_RELAX0, level);  // not a full-operator sweep: own class
   KernelTimer *t = ctx().timer;
   if (level == 0 && t && t->enabled[k::PROF_RELAX_L0]) return k::PROF_RELAX_L0;
   return k::prof_level(k::PROF_LVL_RELAX, level);
@@ -63,7 +74,7 @@ void BoomerAMG::relax(int level, int type, int points, const double *f, bool u_i
   ParCSR &A = *Lv.A;
   Comm &comm = my_comm();
   hipStream_t s = ctx().stream;
-  const int prof = relax_prof_id(level);
+  const int prof = relax_prof_id(level, u_is_zero && zero_skip_mode() > 0);
   double *u = Lv.u.p;
   if (type == 9) {
     if (dense_solve(Lv, comm, f, u, s)) return;
@@ -85,8 +96,9 @@ void BoomerAMG::relax(int level, int type, int points, const double *f, bool u_i
   const int row_end = (points == 1) ? Lv.nc : Lv.n;
   if (row_end <= row_begin) return;
   const int ch = chunk();
-  k::gs_hybrid(A.d_diag, u, u, 0, Lv.snap.p, f, offc, g.l1 ? Lv.d_l1gs.p : Lv.d_diag.p, cf, points, ch, g.fwd, g.bwd, w,
-               row_begin, row_end, s, prof);
+  const bool zs = u_is_zero && zero_skip_mode() > 0;
+  k::gs_hybrid((zs && Lv.has_Az) ? Lv.Az : A.d_diag, u, u, 0, Lv.snap.p, f, offc, g.l1 ? Lv.d_l1gs.p : Lv.d_diag.p, cf,
+               points, ch, g.fwd, g.bwd, w, row_begin, row_end, s, prof, zs ? 0 : k::GS_NO_ZEROS);
   if (row_begin == 0 && row_end == Lv.n) {
     std::swap(Lv.u.p, Lv.snap.p);
   } else {  // lone C or F pass: only the swept chunks were written
@@ -109,25 +121,31 @@ void BoomerAMG::relax_pair(int level, int type, int first, const double *f, bool
   ParCSR &A = *Lv.A;
   Comm &comm = my_comm();
   hipStream_t s = ctx().stream;
-  const int prof = relax_prof_id(level);
+  const int prof = relax_prof_id(level, u_is_zero && zero_skip_mode() > 0);
   const double w = p.relax_weight * p.outer_weight;
   const double *d = g.l1 ? Lv.d_l1gs.p : Lv.d_diag.p;
   const int ch = chunk(), nc = Lv.nc, n = Lv.n;
   double *u = Lv.u.p, *sn = Lv.snap.p;
   // pass 1: everything is read from u; its swept rows land in snap
   const double *offc = u_is_zero ? nullptr : A.offd_contrib(comm, u, s);
+  // on a zero guess pass 1 gathers nothing, and pass 2 of a C-then-F pair only the C columns pass 1 wrote
+  // (and both run on the level's zero-guess sub-operator, which leaves out what multiplies zeros)
+  const bool zs = u_is_zero && zero_skip_mode() > 0;
+  const int z1 = zs ? 0 : k::GS_NO_ZEROS, z2 = (zs && first == 1) ? nc : k::GS_NO_ZEROS;
+  const DevCSR &A1 = (zs && Lv.has_Az) ? Lv.Az : A.d_diag;
+  const DevCSR &A2 = (zs && Lv.has_Az && first == 1) ? Lv.Az : A.d_diag;
   if (first == 1)
-    k::gs_hybrid(A.d_diag, u, u, 0, sn, f, offc, d, Lv.d_cf.p, 1, ch, g.fwd, g.bwd, w, 0, nc, s, prof);
+    k::gs_hybrid(A1, u, u, 0, sn, f, offc, d, Lv.d_cf.p, 1, ch, g.fwd, g.bwd, w, 0, nc, s, prof, z1);
   else
-    k::gs_hybrid(A.d_diag, u, u, 0, sn, f, offc, d, Lv.d_cf.p, -1, ch, g.fwd, g.bwd, w, nc, n, s, prof);
+    k::gs_hybrid(A1, u, u, 0, sn, f, offc, d, Lv.d_cf.p, -1, ch, g.fwd, g.bwd, w, nc, n, s, prof, z1);
   // pass 2: the rows pass 1 updated are read from snap, the others from u
   const double *lo = (first == 1) ? sn : u;
   const double *hi = (first == 1) ? u : sn;
   offc = A.offd_contrib(comm, lo, s, hi, nc);
   if (first == 1)
-    k::gs_hybrid(A.d_diag, lo, hi, nc, sn, f, offc, d, Lv.d_cf.p, -1, ch, g.fwd, g.bwd, w, nc, n, s, prof);
+    k::gs_hybrid(A2, lo, hi, nc, sn, f, offc, d, Lv.d_cf.p, -1, ch, g.fwd, g.bwd, w, nc, n, s, prof, z2);
   else
-    k::gs_hybrid(A.d_diag, lo, hi, nc, sn, f, offc, d, Lv.d_cf.p, 1, ch, g.fwd, g.bwd, w, 0, nc, s, prof);
+    k::gs_hybrid(A2, lo, hi, nc, sn, f, offc, d, Lv.d_cf.p, 1, ch, g.fwd, g.bwd, w, 0, nc, s, prof, z2);
   std::swap(Lv.u.p, Lv.snap.p);  // snap now holds every row
 }
 

@@ -1123,6 +1123,12 @@ HYPRE_Int HYPRE_MI_SetGSChunk(HYPRE_Int rows) {
   ctx().gs_chunk = rows;
   API_END
 }
+HYPRE_Int HYPRE_MI_SetZeroGuessMode(HYPRE_Int mode) {
+  API_BEGIN
+  if (mode < 0 || mode > 2) fail(HYPRE_ERROR_ARG, "SetZeroGuessMode: 0, 1 or 2");
+  set_zero_skip_mode(mode);
+  API_END
+}
 HYPRE_Int HYPRE_MI_GetGSChunk(HYPRE_Int *rows) {
   *rows = ctx().gs_chunk;
   return 0;
@@ -1189,6 +1195,12 @@ HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSRSize(HYPRE_Solver solver, HYPRE_Int level
   API_BEGIN
   // sizes come from the level's metadata: no host copy of a device-resident level is made for them
   AmgLevel &L = level_ref(AMG(solver), level);
+  if (which == 6) {  // the level's zero-guess sub-operator (0 x 0 when the level has none)
+    *nrows = L.has_Az ? L.Az.nrows : 0;
+    *ncols = L.has_Az ? L.Az.ncols : 0;
+    *nnz = L.has_Az ? L.Az.nnz : 0;
+    return 0;
+  }
   const ParCSR *M = nullptr;
   switch (which) {
     case 0:
@@ -1197,7 +1209,7 @@ HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSRSize(HYPRE_Solver solver, HYPRE_Int level
     case 4: M = L.Pm.get(); break;
     case 3:
     case 5: M = L.Rm.get(); break;
-    default: fail(HYPRE_ERROR_ARG, "which must be 0..5");
+    default: fail(HYPRE_ERROR_ARG, "which must be 0..6");
   }
   if (!M) {
     *nrows = *ncols = 0;

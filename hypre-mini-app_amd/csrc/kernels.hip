@@ -328,7 +328,8 @@ __global__ __launch_bounds__(256) void gs_group_k(int n, int chunk0, int nchunks
                                                   const double *__restrict__ offc,
                                                   const double *__restrict__ u_lo,
                                                   const double *__restrict__ u_hi, int split,
-                                                  double *__restrict__ u_new, int fwd, int bwd, double w) {
+                                                  double *__restrict__ u_new, int fwd, int bwd, double w,
+                                                  int zero_from) {
 #define UOLD(j) (((j) < split ? u_lo : u_hi)[(j)])
   constexpr int R = 8;
   constexpr int CPW = 64 / LPC;
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(256) void gs_group_k(int n, int chunk0, int nchunks
     my_k0 = ia[i];
     const int a1 = ia[i + 1];
     const int mark = (points != 0 && cf != nullptr) ? (int)cf[i] : points;
-    myu = UOLD(i);
+    myu = (i >= zero_from) ? 0.0 : UOLD(i);
     myd = dd[i];
     myrhs = f[i];
     if (offc) myrhs -= offc[i];
@@ -392,7 +393,8 @@ __global__ __launch_bounds__(256) void gs_group_k(int n, int chunk0, int nchunks
       const int j = cols[t][e];
       const unsigned oo = (unsigned)(j - cs);
       const bool inch = oo < (unsigned)len;
-      const double x = UOLD(j);  // unconditional gather: no load waits on a branch
+      // gather issued without waiting on the in-chunk test; columns >= zero_from hold zeros by contract
+      const double x = (j >= zero_from) ? 0.0 : UOLD(j);
       code[e] |= (inch ? oo : 15u) << (4 * t);
       if (!inch) wv[t][e] *= x;
     }
@@ -423,7 +425,7 @@ __global__ __launch_bounds__(256) void gs_group_k(int n, int chunk0, int nchunks
             const unsigned oo = (unsigned)(j - cs);
             if (oo < (unsigned)len)
               o = (int)oo;
-            else
+            else if (j < zero_from)
               x = UOLD(j);
           }
           const double cur = __shfl(myu, gbase + (o < 0 ? 0 : o), 64);
@@ -503,7 +505,8 @@ __global__ __launch_bounds__(256) void gs_dense_k(int n, int chunk0, int nchunks
                                                   const double *__restrict__ offc,
                                                   const double *__restrict__ u_lo,
                                                   const double *__restrict__ u_hi, int split,
-                                                  double *__restrict__ u_new, int fwd, int bwd, double w) {
+                                                  double *__restrict__ u_new, int fwd, int bwd, double w,
+                                                  int /*zero_from: not used, the vector holds real zeros*/) {
 #define UOLD(j) (((j) < split ? u_lo : u_hi)[(j)])
   constexpr int R = 8;
   constexpr int CPW = 64 / LPC;
@@ -655,7 +658,7 @@ __global__ __launch_bounds__(SPMV_BLOCK) void gs_tile_k(int blk0, int nblk, cons
                                                         const double *__restrict__ u_lo,
                                                         const double *__restrict__ u_hi, int split,
                                                         double *__restrict__ u_new, int fwd, int bwd, double w,
-                                                        int row_begin, int row_end) {
+                                                        int row_begin, int row_end, int zero_from) {
 #define UOLD(j) (((j) < split ? u_lo : u_hi)[(j)])
   __shared__ double buf[SPMV_TILE];           // x cache, then products / in-chunk coefficients
   __shared__ unsigned short code[SPMV_TILE];  // the entries' lcol words
@@ -687,7 +690,7 @@ __global__ __launch_bounds__(SPMV_BLOCK) void gs_tile_k(int blk0, int nblk, cons
   bool rowsel = false;
   if (rl < nr) {
     const int mark = (points != 0 && cf != nullptr) ? (int)cf[i] : points;
-    myu = UOLD(i);
+    myu = (i >= zero_from) ? 0.0 : UOLD(i);
     rowsel = (mark == points) && i >= row_begin && i < row_end;
     if (rowsel) {
       const double myd = dd[i];
@@ -697,9 +700,14 @@ __global__ __launch_bounds__(SPMV_BLOCK) void gs_tile_k(int blk0, int nblk, cons
     }
   }
   const int u0 = uptr[blk], nu = uptr[blk + 1] - u0;
-  for (int k = tid; k < nu; k += SPMV_BLOCK) {
-    const int j = ucols[u0 + k];
-    buf[k] = UOLD(j);
+  // columns >= zero_from hold zeros by contract (first sweep on a zero guess): nothing to gather there --
+  // the unique columns ascend, so for zero_from == 0 not even the ids are read
+  const bool all_zero = zero_from <= 0;
+  if (!all_zero) {
+    for (int k = tid; k < nu; k += SPMV_BLOCK) {
+      const int j = ucols[u0 + k];
+      buf[k] = (j >= zero_from) ? 0.0 : UOLD(j);
+    }
   }
   __syncthreads();
 #pragma unroll
@@ -710,8 +718,9 @@ __global__ __launch_bounds__(SPMV_BLOCK) void gs_tile_k(int blk0, int nblk, cons
       const bool ok1 = (base_al + k + 1 < end);
       const unsigned c0 = cc[it].x, c1 = cc[it].y;
       // out-of-chunk: product with the snapshot value; in-chunk: the coefficient itself
-      vv[it].x = ok0 ? ((c0 & XC_INCH) ? vv[it].x : vv[it].x * buf[c0 & XC_ID_MASK]) : 0.0;
-      vv[it].y = ok1 ? ((c1 & XC_INCH) ? vv[it].y : vv[it].y * buf[c1 & XC_ID_MASK]) : 0.0;
+      const double x0 = all_zero ? 0.0 : buf[c0 & XC_ID_MASK], x1 = all_zero ? 0.0 : buf[c1 & XC_ID_MASK];
+      vv[it].x = ok0 ? ((c0 & XC_INCH) ? vv[it].x : vv[it].x * x0) : 0.0;
+      vv[it].y = ok1 ? ((c1 & XC_INCH) ? vv[it].y : vv[it].y * x1) : 0.0;
     }
   }
   __syncthreads();  // every x-cache read is done
@@ -1143,7 +1152,7 @@ void spmv_offd_set(const DevOffd &B, const double *xext, double *out, hipStream_
 
 void gs_hybrid(const DevCSR &A, const double *u_lo, const double *u_hi, int split, double *out, const double *f,
                const double *offc, const double *d, const signed char *cf, int points, int chunk, bool fwd, bool bwd,
-               double w, int row_begin, int row_end, hipStream_t s, int prof) {
+               double w, int row_begin, int row_end, hipStream_t s, int prof, int zero_from) {
   if (A.nrows == 0 || row_end <= row_begin) return;
   MI_REQUIRE(chunk >= 1 && chunk <= GS_MAX_CHUNK, "hybrid GS chunk out of range");
   // chunks that intersect [row_begin, row_end); pre-sweep values come from u_lo
@@ -1161,7 +1170,7 @@ void gs_hybrid(const DevCSR &A, const double *u_lo, const double *u_hi, int spli
     if (b1 > b0)
       hipLaunchKernelGGL(gs_tile_k, dim3((unsigned)(b1 - b0)), dim3(SPMV_BLOCK), 0, s, b0, b1 - b0, A.rb.p, A.ia.p,
                          A.a.p, A.uptr.p, A.ucols.p, A.lcol.p, cf, points, d, f, offc, u_lo, u_hi, split, out,
-                         fwd ? 1 : 0, bwd ? 1 : 0, w, first_row, last_row);
+                         fwd ? 1 : 0, bwd ? 1 : 0, w, first_row, last_row, zero_from);
   } else if (chunk == 8 && !gs_force_generic()) {
     const double avg = (double)A.nnz / (double)A.nrows;
     const int p95 = A.rowlen_p95;
@@ -1170,7 +1179,7 @@ void gs_hybrid(const DevCSR &A, const double *u_lo, const double *u_hi, int spli
     const long long waves = (nch + (64 / LPC) - 1) / (64 / LPC);                                                \
     hipLaunchKernelGGL((KERNEL<LPC, E>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, A.nrows, (int)c0,   \
                        (int)c1, A.ia.p, A.ja.p, A.a.p, cf, points, d, f, offc, u_lo, u_hi, split, out,          \
-                       fwd ? 1 : 0, bwd ? 1 : 0, w);                                                            \
+                       fwd ? 1 : 0, bwd ? 1 : 0, w, zero_from);                                                 \
   }
 #define GS_LAUNCH(LPC, E) \
   if (gs_use_old()) GS_LAUNCH_K(gs_group_k, LPC, E) else GS_LAUNCH_K(gs_dense_k, LPC, E)

@@ -27,7 +27,8 @@ enum ProfId {
   PROF_LVL_RELAX = PROF_LVL_RESID + PROF_LEVELS,
   PROF_LVL_RESTRICT = PROF_LVL_RELAX + PROF_LEVELS,
   PROF_LVL_PROLONG = PROF_LVL_RESTRICT + PROF_LEVELS,
-  PROF_COUNT = PROF_LVL_PROLONG + PROF_LEVELS
+  PROF_LVL_RELAX0 = PROF_LVL_PROLONG + PROF_LEVELS,  // first sweep on a zero guess (runs on the sub-operator)
+  PROF_COUNT = PROF_LVL_RELAX0 + PROF_LEVELS
 };
 inline int prof_level(int base, int level) { return level < PROF_LEVELS ? base + level : PROF_NONE; }
 
@@ -55,10 +56,12 @@ void jacobi(const DevCSR &A, const double *u_old, double *u_new, const double *f
 // an F pass of a C-first ordered level).  Pre-sweep values are read from u_lo
 // for rows < split and from u_hi for rows >= split (the second pass of a C/F
 // pair reads the first pass's output without a copy); the swept chunks' rows are
-// written to out.
+// written to out.  zero_from: the caller guarantees that every pre-sweep value with index >= zero_from is
+// zero (first sweep on a zero guess); kernels may then skip those gathers -- same result, less traffic.
+constexpr int GS_NO_ZEROS = 0x7fffffff;
 void gs_hybrid(const DevCSR &A, const double *u_lo, const double *u_hi, int split, double *out, const double *f,
                const double *offc, const double *d, const signed char *cf, int points, int chunk, bool fwd, bool bwd,
-               double w, int row_begin, int row_end, hipStream_t s, int prof = PROF_NONE);
+               double w, int row_begin, int row_end, hipStream_t s, int prof = PROF_NONE, int zero_from = GS_NO_ZEROS);
 
 // BLAS-1
 void dot(const double *x, const double *y, int n, double *out_dev, hipStream_t s);  // local sum, no collective

@@ -1104,6 +1104,35 @@ __global__ __launch_bounds__(BLK) void ilu_upper_jac_k(int n, const long long *_
   out[i] = (d >= 0) ? s / a[d] : s;
 }
 
+// ---------------------------------------------------------------- zero-guess sub-operator
+// which entries of row i a first sweep on a zero guess can touch: the row's own chunk, and for an F row
+// (i >= nc) the C columns (< nc) the preceding C pass has just written
+template <bool FILL>
+__global__ __launch_bounds__(BLK) void zero_guess_rows_k(int n, int nc, int chunk, const int *__restrict__ ia,
+                                                         const int *__restrict__ ja, const double *__restrict__ a,
+                                                         int *__restrict__ cnt, const long long *__restrict__ zia,
+                                                         int *__restrict__ zja, double *__restrict__ za) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  const int c0 = (i / chunk) * chunk, c1 = c0 + chunk;
+  const bool frow = i >= nc;
+  long long o = FILL ? zia[i] : 0;
+  int c = 0;
+  for (int k = ia[i]; k < ia[i + 1]; k++) {
+    const int j = ja[k];
+    if ((j >= c0 && j < c1) || (frow && j < nc)) {
+      if (FILL) {
+        zja[o] = j;
+        za[o] = a[k];
+        o++;
+      } else {
+        c++;
+      }
+    }
+  }
+  if (!FILL) cnt[i] = c;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------- host-facing entry points
@@ -1240,6 +1269,29 @@ void to_solve_format(DCsr &src, DevCSR &dst, hipStream_t s) {
   }
   src.release();
   MI_HIP(hipGetLastError());
+}
+
+void zero_guess_operator(const DevCSR &A, int nc, int chunk, DCsr &Z, hipStream_t s) {
+  const int n = A.nrows;
+  Z.release();
+  Z.nrows = n;
+  Z.ncols = A.ncols;
+  Z.ia.alloc((size_t)n + 1);
+  DVec<int> cnt((size_t)n);
+  const unsigned grid = (unsigned)((n + BLK - 1) / BLK);
+  if (n)
+    zero_guess_rows_k<false><<<grid, BLK, 0, s>>>(n, nc, chunk, A.ia.p, A.ja.p, A.a.p, cnt.p, nullptr, nullptr, nullptr);
+  exclusive_scan(cnt.p, Z.ia.p, n, s);
+  long long total = 0;
+  MI_HIP(hipMemcpyAsync(&total, Z.ia.p + n, sizeof(long long), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+  Z.nnz = total;
+  Z.ja.alloc((size_t)total);
+  Z.a.alloc((size_t)total);
+  if (n && total)
+    zero_guess_rows_k<true><<<grid, BLK, 0, s>>>(n, nc, chunk, A.ia.p, A.ja.p, A.a.p, nullptr, Z.ia.p, Z.ja.p, Z.a.p);
+  MI_HIP(hipGetLastError());
+  MI_HIP(hipStreamSynchronize(s));
 }
 
 void solve_format_to_host(const DevCSR &src, HostCSR &h, hipStream_t s) {

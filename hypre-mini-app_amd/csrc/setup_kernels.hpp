@@ -65,6 +65,11 @@ void extract_rows(const DCsr &A, const int *rows, int nout, const int *colpos, D
 // schedule and x cache of the SpMV (DevCSR::upload builds the same from host arrays).  src's column and
 // value arrays are MOVED into dst; only the row pointers travel to the host (for the greedy block schedule).
 void to_solve_format(DCsr &src, DevCSR &dst, hipStream_t s);
+// The part of a C-first ordered square block (C points = indices < nc) that a FIRST relaxation sweep on a
+// zero guess can touch: every row keeps the entries inside its own chunk of `chunk` rows, F rows also their C
+// columns (written by the C pass that precedes the F pass).  Everything else multiplies zeros.  Columns stay
+// ascending; Z goes through to_solve_format like any operator.
+void zero_guess_operator(const DevCSR &A, int nc, int chunk, DCsr &Z, hipStream_t s);
 // back to host arrays (lazy host copies for the inspection API)
 void solve_format_to_host(const DevCSR &src, HostCSR &h, hipStream_t s);
 

@@ -27,6 +27,7 @@ vp = C.c_void_p
 PROF_SPMV_L0, PROF_RELAX_L0, PROF_DOT, PROF_AXPY = 0, 1, 2, 3
 PROF_LEVELS = 16
 PROF_LVL_RESID, PROF_LVL_RELAX, PROF_LVL_RESTRICT, PROF_LVL_PROLONG = 4, 4 + 16, 4 + 32, 4 + 48
+PROF_LVL_RELAX0 = 4 + 64  # first sweep on a zero guess (runs on the level's zero-guess sub-operator)
 
 ALLREDUCE_FN = C.CFUNCTYPE(None, vp, vp, C.c_size_t, c_int, c_int)
 ALLGATHER_FN = C.CFUNCTYPE(None, vp, vp, vp, C.c_size_t)

@@ -49,6 +49,11 @@ HYPRE_Int HYPRE_MI_GetStream(void **hip_stream);
 HYPRE_Int HYPRE_MI_StreamSynchronize(void);
 HYPRE_Int HYPRE_MI_SetGSChunk(HYPRE_Int rows_per_chunk);   /* hybrid-GS "thread" size, default 8 */
 HYPRE_Int HYPRE_MI_GetGSChunk(HYPRE_Int *rows_per_chunk);
+/* How the first relaxation sweep of a cycle's down leg (zero guess on every level) is run: 0 like any other
+ * sweep, 1 without gathering the known zeros, 2 (default, env MI_HYPRE_GS_ZERO_SKIP) also on the level's
+ * zero-guess sub-operator, built by BoomerAMGSetup: the rows' in-chunk entries plus the F rows' C columns --
+ * everything else multiplies zeros.  Same result up to summation order. */
+HYPRE_Int HYPRE_MI_SetZeroGuessMode(HYPRE_Int mode);
 
 /* ---- results the driver never asks HYPRE for */
 HYPRE_Int HYPRE_MI_KrylovGetResidualHistory(HYPRE_Solver solver, HYPRE_Real *norms, HYPRE_Int max_n, HYPRE_Int *n);
@@ -69,7 +74,9 @@ HYPRE_Int HYPRE_MI_BoomerAMGGetNumLevels(HYPRE_Solver solver, HYPRE_Int *num_lev
 HYPRE_Int HYPRE_MI_BoomerAMGGetOperatorComplexity(HYPRE_Solver solver, HYPRE_Real *cx);
 HYPRE_Int HYPRE_MI_BoomerAMGGetSetupSeconds(HYPRE_Solver solver, HYPRE_Real *seconds);
 /* which: 0 A diag block, 1 A offd block, 2 P diag, 3 R diag, 4 P offd (halo columns), 5 R offd.
- * P (rows: this level, columns: next level) and R = P^T are rectangular ParCSR operators. */
+ * P (rows: this level, columns: next level) and R = P^T are rectangular ParCSR operators.
+ * GetLevelCSRSize also takes which = 6: the level's zero-guess sub-operator (the entries of the diag block a
+ * first sweep on a zero guess can meet with a non-zero; 0 x 0 when the level has none). */
 HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSRSize(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int which, HYPRE_Int *nrows,
                                             HYPRE_Int *ncols, HYPRE_BigInt *nnz);
 HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSR(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int which, HYPRE_BigInt *ia,

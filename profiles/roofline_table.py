@@ -2,7 +2,9 @@
 kernel class) for the benchmark configuration.   gpurun -- python3 profiles/roofline_table.py 512 > table.txt
 
 Algorithmic bytes as in DESIGN.md section 5 / SURVEY 8(d): SpMV 12 nnz + 20 n; one relaxation sweep (C pass + F
-pass) 12 nnz + 48 n + n; restriction 12 nnz(R) + 20 n_c; prolongation 12 nnz(P) + 28 n."""
+pass) 12 nnz + 48 n + n; restriction 12 nnz(R) + 20 n_c; prolongation 12 nnz(P) + 28 n.  The first sweep of the
+down leg starts from a zero guess and runs on the level's zero-guess sub-operator (only the entries that can meet
+a non-zero): its row is priced with THAT operator's entries, 12 nnz(Az) + 48 n + n."""
 import ctypes as C
 import os
 import sys
@@ -31,7 +33,8 @@ x.fill(0.0)
 gm.solve(A, b, x)  # warm-up: basis vectors are allocated here
 ids = [mi.PROF_SPMV_L0, mi.PROF_DOT, mi.PROF_AXPY]
 for l in range(min(nlev, mi.PROF_LEVELS)):
-    ids += [mi.PROF_LVL_RESID + l, mi.PROF_LVL_RELAX + l, mi.PROF_LVL_RESTRICT + l, mi.PROF_LVL_PROLONG + l]
+    ids += [mi.PROF_LVL_RESID + l, mi.PROF_LVL_RELAX + l, mi.PROF_LVL_RESTRICT + l, mi.PROF_LVL_PROLONG + l,
+            mi.PROF_LVL_RELAX0 + l]
 for i in ids:
     mi.profile_enable(i, 8192)
 mi.profile_reset()
@@ -56,6 +59,9 @@ n0, nnz0 = size(0, 0)
 row("GMRES matvec (level 0, C-first)", mi.PROF_SPMV_L0, 12.0 * nnz0 + 20.0 * n0)
 for l in range(min(nlev, mi.PROF_LEVELS)):
     nl, nnzl = size(l, 0)
+    nz, nnzz = size(l, 6)
+    if nz:
+        row(f"level {l:2d} zero-guess sweep (sub-op.)", mi.PROF_LVL_RELAX0 + l, 12.0 * nnzz + 49.0 * nl, per=2)
     row(f"level {l:2d} relaxation sweep (C+F)", mi.PROF_LVL_RELAX + l, 12.0 * nnzl + 49.0 * nl, per=2)
     if l + 1 < nlev:
         row(f"level {l:2d} residual SpMV", mi.PROF_LVL_RESID + l, 12.0 * nnzl + 20.0 * nl)

@@ -151,6 +151,44 @@ def _allclose_ref(x, xref, rtol=1e-6, atol=1e-8):
     return np.all(diff < np.maximum(rtol * np.maximum(np.abs(x), np.abs(xref)), atol))
 
 
+@pytest.mark.parametrize("n,stencil", [(16, 7), (10, 27)])
+def test_zero_guess_sub_operator(mi, n, stencil):
+    """The first sweep of every down leg starts from u = 0 and runs on the level's zero-guess sub-operator (rows'
+    in-chunk entries + the F rows' C columns; everything else multiplies zeros): the operator has exactly those
+    entries, and the solve agrees with the one that sweeps the full operator (mode 0) up to summation order."""
+    runs = {}
+    try:
+        for mode in (0, 1, 2):
+            mi.call("HYPRE_MI_SetZeroGuessMode", mode)
+            A, b, x, rhs = mi.build_laplace_system(n, n, n, stencil)
+            amg = mi.BoomerAMG(print_level=0)
+            gm = mi.GMRES(tolerance=1e-10, max_iterations=100, kspace=50, print_level=0)
+            gm.set_precond(amg)
+            gm.setup(A, b, x)
+            assert gm.solve(A, b, x) == 0
+            runs[mode] = (gm.num_iterations, np.asarray(gm.residual_history()), x.get())
+            checked = 0
+            for l in range(amg.num_levels - 1):
+                nr, nc_, nnz = mi.c_int(), mi.c_int(), mi.C.c_longlong()
+                mi.call("HYPRE_MI_BoomerAMGGetLevelCSRSize", amg.h, l, 6, mi.C.byref(nr), mi.C.byref(nc_), mi.C.byref(nnz))
+                if mode < 2:
+                    assert nr.value == 0 and nnz.value == 0
+                    continue
+                ia, ja, a, shape = amg.level_csr(l, 0)
+                ncoarse = int((np.asarray(amg.level_cf(l)) == 1).sum())
+                rows = np.repeat(np.arange(shape[0]), np.diff(ia))
+                keep = (ja // 8 == rows // 8) | ((rows >= ncoarse) & (ja < ncoarse))
+                assert nr.value == shape[0] and nnz.value == int(keep.sum()) and nnz.value < len(ja)
+                checked += 1
+            assert mode < 2 or checked >= 2
+    finally:
+        mi.call("HYPRE_MI_SetZeroGuessMode", 2)
+    for mode in (1, 2):
+        assert runs[mode][0] == runs[0][0]
+        assert np.allclose(runs[mode][1], runs[0][1], rtol=1e-9, atol=0.0)
+        assert np.abs(runs[mode][2] - runs[0][2]).max() <= 1e-12
+
+
 @pytest.mark.parametrize("n,stencil,kdim,tol", [(16, 7, 50, 1e-8), (24, 7, 5, 1e-10), (12, 27, 50, 1e-8),
                                                   (32, 7, 50, 1e-6)])
 def test_gmres_amg_matches_oracle(mi, oc, n, stencil, kdim, tol):
