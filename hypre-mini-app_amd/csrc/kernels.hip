@@ -359,6 +359,8 @@ __global__ __launch_bounds__(256) void gs_group_k(int n, int chunk0, int nchunks
     my_k1 = rowsel ? a1 : my_k0;  // unselected rows load nothing
     mysel = rowsel && myd != 0.0;
   }
+  // one division per row, outside the sweep (the sweep's VALU work is what bounds this kernel)
+  const double mywd = mysel ? w / myd : 0.0;
   // phase A: three waves of independent loads (row pointers + marker, entries,
   // gathers).  Per entry one double survives: a_ij*u_old[j] for a column outside
   // the chunk, a_ij itself for a column inside it; the in-chunk offset (or 15)
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(256) void gs_group_k(int n, int chunk0, int nchunks
         }
       }
       const double sum = group_sum<LPC>(part);
-      if (g == t && mysel) myu += w * (myrhs - sum) / myd;
+      if (g == t && mysel) myu += (myrhs - sum) * mywd;
     }
   }
   if (g < len) u_new[cs + g] = myu;
@@ -735,28 +737,35 @@ __global__ __launch_bounds__(SPMV_BLOCK) void gs_tile_k(int blk0, int nblk, cons
     }
   }
   __syncthreads();
-  // per row: out-of-chunk sum and the row of the dense 8x8 chunk block (the row's lanes share the entries)
-  double S = 0.0, crow[8];
-#pragma unroll
-  for (int j = 0; j < 8; j++) crow[j] = 0.0;
+  // per row: out-of-chunk sum (the row's LPR lanes share the entries) and the row of the dense 8x8 chunk
+  // block.  Columns ascend and a chunk is 8 consecutive ids, so the in-chunk entries of a row are ONE run
+  // [kin, kin + popcount(mask)) of its entries, in ascending in-chunk offset: the loop only notes where the
+  // run starts and which offsets occur; the coefficients are then read straight from the product buffer.
+  double S = 0.0;
+  unsigned inmask = 0;
+  int kin = SPMV_TILE;
   if (rowsel) {
     const int s0 = ia[i] - base_al, s1 = ia[i + 1] - base_al;
     for (int k = s0 + sub; k < s1; k += LPR) {
       const unsigned c = code[k];
       const double v = buf[k];
-      if (c & XC_INCH) {
-        const int o = (c >> XC_OFF_SHIFT) & 7;
-#pragma unroll
-        for (int j = 0; j < 8; j++) crow[j] = (o == j) ? v : crow[j];
-      } else {
-        S += v;
-      }
+      const bool in = (c & XC_INCH) != 0;
+      S += in ? 0.0 : v;
+      inmask |= in ? (1u << ((c >> XC_OFF_SHIFT) & 7)) : 0u;
+      kin = in ? min(kin, k) : kin;
     }
   }
   for (int m = 1; m < LPR; m <<= 1) {
     S += __shfl_xor(S, m, 64);
+    inmask |= (unsigned)__shfl_xor((int)inmask, m, 64);
+    kin = min(kin, __shfl_xor(kin, m, 64));
+  }
+  double crow[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) crow[j] += __shfl_xor(crow[j], m, 64);
+  for (int j = 0; j < 8; j++) {
+    const bool has = (inmask >> j) & 1u;
+    const int pos = kin + __popc(inmask & ((1u << j) - 1u));
+    crow[j] = has ? buf[has ? pos : 0] : 0.0;
   }
   // the sweep: a chunk = 8 rows = 8 * LPR consecutive lanes (tiles start on a multiple of 8 rows)
   const int lane = tid & 63;
