@@ -233,7 +233,7 @@ def main():
         roof_relax = None
         if rel_n:
             a = relax_bytes / (rel_ms / rel_n * 1e-3) / 1e9
-            roof_relax = {"bound": "hbm", "kernel": "gs_group_k<8, 1> (level-0 l1 hybrid GS, one C or F pass over the full operator = the up-leg "
+            roof_relax = {"bound": "hbm", "kernel": "gs_tile_k (level-0 l1 hybrid GS, one C or F pass over the full operator = the up-leg "
                                     "sweeps; the down leg's sweep starts from a zero guess, runs on the zero-guess "
                                     "sub-operator and is not counted here)",
                           "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
