@@ -50,6 +50,7 @@ struct AmgLevel {
   // cycle starts from u = 0, where most of A multiplies zeros
   DevCSR Az;
   bool has_Az = false;
+  int Az_chunk = 0;  // the hybrid-GS chunk size Az was cut for (its "in-chunk" entries)
   std::vector<int> cf;  // +1 C, -1 F (empty on the coarsest level)
   bool has_cf = false;  // the level has a C/F splitting -- a GLOBAL fact (cf itself is empty on a rank without rows)
   DVec<signed char> d_cf;

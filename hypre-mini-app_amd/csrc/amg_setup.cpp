@@ -1365,6 +1365,7 @@ void BoomerAMG::setup_device() {
       sk::zero_guess_operator(Lv.A->d_diag, Lv.nc, ch, Z, s);
       sk::to_solve_format(Z, Lv.Az, s);
       Lv.has_Az = true;
+      Lv.Az_chunk = ch;
     }
     if (!Lv.d_diag.p || Lv.d_diag.n != (size_t)Lv.n) {
       Lv.d_diag.upload(Lv.diag);

@@ -97,7 +97,7 @@ void BoomerAMG::relax(int level, int type, int points, const double *f, bool u_i
   if (row_end <= row_begin) return;
   const int ch = chunk();
   const bool zs = u_is_zero && zero_skip_mode() > 0;
-  k::gs_hybrid((zs && Lv.has_Az) ? Lv.Az : A.d_diag, u, u, 0, Lv.snap.p, f, offc, g.l1 ? Lv.d_l1gs.p : Lv.d_diag.p, cf,
+  k::gs_hybrid((zs && Lv.has_Az && Lv.Az_chunk == ch) ? Lv.Az : A.d_diag, u, u, 0, Lv.snap.p, f, offc, g.l1 ? Lv.d_l1gs.p : Lv.d_diag.p, cf,
                points, ch, g.fwd, g.bwd, w, row_begin, row_end, s, prof, zs ? 0 : k::GS_NO_ZEROS);
   if (row_begin == 0 && row_end == Lv.n) {
     std::swap(Lv.u.p, Lv.snap.p);
@@ -132,8 +132,9 @@ void BoomerAMG::relax_pair(int level, int type, int first, const double *f, bool
   // (and both run on the level's zero-guess sub-operator, which leaves out what multiplies zeros)
   const bool zs = u_is_zero && zero_skip_mode() > 0;
   const int z1 = zs ? 0 : k::GS_NO_ZEROS, z2 = (zs && first == 1) ? nc : k::GS_NO_ZEROS;
-  const DevCSR &A1 = (zs && Lv.has_Az) ? Lv.Az : A.d_diag;
-  const DevCSR &A2 = (zs && Lv.has_Az && first == 1) ? Lv.Az : A.d_diag;
+  const bool use_Az = zs && Lv.has_Az && Lv.Az_chunk == ch;
+  const DevCSR &A1 = use_Az ? Lv.Az : A.d_diag;
+  const DevCSR &A2 = (use_Az && first == 1) ? Lv.Az : A.d_diag;
   if (first == 1)
     k::gs_hybrid(A1, u, u, 0, sn, f, offc, d, Lv.d_cf.p, 1, ch, g.fwd, g.bwd, w, 0, nc, s, prof, z1);
   else

@@ -139,23 +139,31 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream(int nb, int xchunk, co
 // gathers the sorted unique columns of its row block ONCE into LDS (adjacent
 // lanes -> ascending addresses, well coalesced) and the entries then carry
 // 16-bit block-local ids (which also shrinks the index stream from 4 to 2 B).
+//
+// Load order: the waves of this kernel wait ~84 % of their cycles with ~7 tiles resident per CU, i.e. a tile
+// lives ~12 us, most of it in dependent round trips.  Vector-memory results are counted in issue order, so
+// waiting for a LATE-issued short load also waits for every stream load issued before it.  The tile's row
+// range, entry range and column-list range therefore arrive in one 32-byte (scalar) descriptor load, the
+// column list is requested FIRST (its gathers are the longest chain), then the matrix stream and the row
+// pointers of the row sums; the x gathers start as soon as the column ids are back, while the stream is still
+// in flight.  (Worth ~0.5 % of the 512^3 solve over the rb -> ia -> stream / uptr -> ucols -> x order: the
+// kernel is not bound by this chain alone -- VALU, LDS and the L1 gather path are each 25-30 % busy.)
 template <int EPI, int TAG>
-__global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream_xc(int nb, int xchunk, const int *__restrict__ rb,
+__global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream_xc(int nb, int xchunk, const int *__restrict__ tdesc,
                                                              const int *__restrict__ ia, const int *__restrict__ ja,
                                                              const double *__restrict__ av,
-                                                             const int *__restrict__ uptr, const int *__restrict__ ucols,
+                                                             const int *__restrict__ ucols,
                                                              const unsigned short *__restrict__ lcol,
                                                              const double *__restrict__ x, double *__restrict__ y,
                                                              EpiArgs e) {
-  // one 16 KB array serves first as the x cache and then as the product buffer (the products wait in
-  // registers across the barrier in between): twice the workgroups per CU of two separate arrays
   __shared__ double prod[SPMV_TILE];
   double *xs = prod;
   const int blk = xcd_remap(blockIdx.x, xchunk);
   if (blk >= nb) return;
   const int tid = threadIdx.x;
-  const int r0 = rb[blk], r1 = rb[blk + 1];
-  const int base = ia[r0], end = ia[r1];
+  const int4 d0 = reinterpret_cast<const int4 *>(tdesc)[2 * blk];
+  const int4 d1 = reinterpret_cast<const int4 *>(tdesc)[2 * blk + 1];
+  const int r0 = d0.x, r1 = d0.y, base = d0.z, end = d0.w, u0 = d1.x, nu = d1.y;
   if (end - base >= SPMV_TILE) {
     double s = 0.0;
     for (int k = base + tid; k < end; k += SPMV_BLOCK) s += av[k] * x[ja[k]];
@@ -165,7 +173,13 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream_xc(int nb, int xchunk,
     if (tid == 0) epilogue<EPI>(r0, prod[0] + prod[1] + prod[2] + prod[3], x, y, e);
     return;
   }
-  // the matrix stream is issued first and waits in registers while the x cache fills
+  constexpr int NU = SPMV_TILE / SPMV_BLOCK;
+  int uc[NU];
+#pragma unroll
+  for (int q = 0; q < NU; q++) {
+    const int k = tid + q * SPMV_BLOCK;
+    uc[q] = (k < nu) ? ucols[u0 + k] : 0;
+  }
   const int base_al = base & ~1;
   const int cnt = end - base_al;
   constexpr int NIT = SPMV_TILE / (2 * SPMV_BLOCK);
@@ -179,8 +193,22 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream_xc(int nb, int xchunk,
       cc[it] = *reinterpret_cast<const us2_t *>(lcol + base_al + k);
     }
   }
-  const int u0 = uptr[blk], nu = uptr[blk + 1] - u0;
-  for (int k = tid; k < nu; k += SPMV_BLOCK) xs[k] = x[ucols[u0 + k]];
+  // every thread sums at most one row (nr * G <= SPMV_BLOCK): its entry range travels with the other loads
+  const int nr = r1 - r0;
+  int G = 1;
+  while (G < 64 && nr * G * 2 <= SPMV_BLOCK) G <<= 1;
+  const int lane = tid & (G - 1);
+  const int rr = tid / G;
+  int s0 = 0, s1 = 0;
+  if (rr < nr) {
+    s0 = ia[r0 + rr] - base_al;
+    s1 = ia[r0 + rr + 1] - base_al;
+  }
+#pragma unroll
+  for (int q = 0; q < NU; q++) {
+    const int k = tid + q * SPMV_BLOCK;
+    if (k < nu) xs[k] = x[uc[q]];
+  }
   __syncthreads();
 #pragma unroll
   for (int it = 0; it < NIT; it++) {
@@ -202,18 +230,23 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream_xc(int nb, int xchunk,
     }
   }
   __syncthreads();
-  const int nr = r1 - r0;
-  int G = 1;
-  while (G < 64 && nr * G * 2 <= SPMV_BLOCK) G <<= 1;
-  const int lane = tid & (G - 1);
-  for (int rr = tid / G; rr < nr; rr += SPMV_BLOCK / G) {
-    const int r = r0 + rr;
-    const int s0 = ia[r] - base_al, s1 = ia[r + 1] - base_al;
+  if (rr < nr) {
     double s = 0.0;
     for (int k = s0 + lane; k < s1; k += G) s += prod[k];
     for (int off = G >> 1; off > 0; off >>= 1) s += __shfl_down(s, off, G);
-    if (lane == 0) epilogue<EPI>(r, s, x, y, e);
+    if (lane == 0) epilogue<EPI>(r0 + rr, s, x, y, e);
   }
+}
+
+__global__ __launch_bounds__(256) void tile_desc_k(int nb, const int *__restrict__ rb, const int *__restrict__ ia,
+                                                   const int *__restrict__ uptr, int *__restrict__ desc) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= nb) return;
+  const int r0 = rb[b], r1 = rb[b + 1];
+  int4 *d = reinterpret_cast<int4 *>(desc) + 2 * (size_t)b;
+  const int u0 = uptr ? uptr[b] : 0, u1 = uptr ? uptr[b + 1] : 0;
+  d[0] = make_int4(r0, r1, ia[r0], ia[r1]);
+  d[1] = make_int4(u0, u1 - u0, 0, 0);
 }
 
 // compressed-row off-diagonal block: one lane per stored row (halo rows are few
@@ -1107,20 +1140,29 @@ static void launch_stream(int epi, const DevCSR &A, const double *x, double *y, 
   const dim3 grid(xchunk * 8), block(SPMV_BLOCK);
   if (A.xcache) {
     if (epi == 0 && level0)
-      hipLaunchKernelGGL((spmv_stream_xc<0, 1>), grid, block, 0, s, nb, xchunk, A.rb.p, A.ia.p, A.ja.p, A.a.p,
-                         A.uptr.p, A.ucols.p, A.lcol.p, x, y, e);
+      hipLaunchKernelGGL((spmv_stream_xc<0, 1>), grid, block, 0, s, nb, xchunk, A.tdesc.p, A.ia.p, A.ja.p, A.a.p,
+                         A.ucols.p, A.lcol.p, x, y, e);
     else if (epi == 0)
-      hipLaunchKernelGGL((spmv_stream_xc<0, 0>), grid, block, 0, s, nb, xchunk, A.rb.p, A.ia.p, A.ja.p, A.a.p,
-                         A.uptr.p, A.ucols.p, A.lcol.p, x, y, e);
+      hipLaunchKernelGGL((spmv_stream_xc<0, 0>), grid, block, 0, s, nb, xchunk, A.tdesc.p, A.ia.p, A.ja.p, A.a.p,
+                         A.ucols.p, A.lcol.p, x, y, e);
     else
-      hipLaunchKernelGGL((spmv_stream_xc<1, 0>), grid, block, 0, s, nb, xchunk, A.rb.p, A.ia.p, A.ja.p, A.a.p,
-                         A.uptr.p, A.ucols.p, A.lcol.p, x, y, e);
+      hipLaunchKernelGGL((spmv_stream_xc<1, 0>), grid, block, 0, s, nb, xchunk, A.tdesc.p, A.ia.p, A.ja.p, A.a.p,
+                         A.ucols.p, A.lcol.p, x, y, e);
   } else if (epi == 0 && level0)
     hipLaunchKernelGGL((spmv_stream<0, 1>), grid, block, 0, s, nb, xchunk, A.rb.p, A.ia.p, A.ja.p, A.a.p, x, y, e);
   else if (epi == 0)
     hipLaunchKernelGGL((spmv_stream<0, 0>), grid, block, 0, s, nb, xchunk, A.rb.p, A.ia.p, A.ja.p, A.a.p, x, y, e);
   else
     hipLaunchKernelGGL((spmv_stream<1, 0>), grid, block, 0, s, nb, xchunk, A.rb.p, A.ia.p, A.ja.p, A.a.p, x, y, e);
+  MI_HIP(hipGetLastError());
+}
+
+void build_tile_desc(DevCSR &A, hipStream_t s) {
+  A.tdesc.release();
+  if (A.nblocks <= 0 || !A.rb.p) return;
+  A.tdesc.alloc((size_t)A.nblocks * 8);
+  hipLaunchKernelGGL(tile_desc_k, dim3((unsigned)((A.nblocks + 255) / 256)), dim3(256), 0, s, A.nblocks, A.rb.p, A.ia.p,
+                     A.xcache ? A.uptr.p : nullptr, A.tdesc.p);
   MI_HIP(hipGetLastError());
 }
 

@@ -39,6 +39,9 @@ constexpr int XC_ID_MASK = 0x7FF;   // block-local column id inside an lcol entr
 constexpr int XC_INCH = 0x8000;     // the column lies in the row's own 8-row chunk ...
 constexpr int XC_OFF_SHIFT = 12;    // ... at this offset (3 bits)
 
+// per-tile descriptors of the SpMV / tile-GS kernels (row range, entry range, column-list range: 8 ints per
+// tile); call after rb, ia and (x cache) uptr are in place
+void build_tile_desc(DevCSR &A, hipStream_t s);
 // y = alpha*A*x + beta*b   (b may alias y)
 void spmv(const DevCSR &A, const double *x, double alpha, double beta, const double *b, double *y, hipStream_t s,
           int prof = PROF_NONE);

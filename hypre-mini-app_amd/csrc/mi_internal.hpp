@@ -115,6 +115,7 @@ struct DevCSR {
   int max_tile_rows = 256;   // rows of the largest tile
   DVec<int> uptr, ucols;
   DVec<unsigned short> lcol;
+  DVec<int> tdesc;  // 8 ints per tile: r0, r1, ia[r0], ia[r1], uptr[b], #unique columns, 0, 0 (k::build_tile_desc)
   bool empty() const { return nrows == 0 || nnz == 0; }
   void upload(const HostCSR &h);
 };

@@ -154,6 +154,8 @@ void DevCSR::upload(const HostCSR &h) {
     lcol.upload(lc);
     gs_tiles = aligned && nrows == ncols;
   }
+  k::build_tile_desc(*this, ctx().stream);
+  MI_HIP(hipStreamSynchronize(ctx().stream));
 }
 
 void DevOffd::upload(int nrows, const HostCSR &h) {

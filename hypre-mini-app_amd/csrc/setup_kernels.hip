@@ -1267,6 +1267,8 @@ void to_solve_format(DCsr &src, DevCSR &dst, hipStream_t s) {
     MI_HIP(hipGetLastError());
     MI_HIP(hipStreamSynchronize(s));
   }
+  k::build_tile_desc(dst, s);
+  MI_HIP(hipStreamSynchronize(s));
   src.release();
   MI_HIP(hipGetLastError());
 }
