@@ -192,6 +192,10 @@ struct Ctx {
   bool inited = false;
   int device = 0;
   hipStream_t stream = nullptr;
+  // side stream of the halo exchanges that overlap with the diag-block SpMV (ParCSR::matvec), and the two
+  // events that order it against `stream`
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_packed = nullptr, ev_halo = nullptr;
   std::unique_ptr<Comm> comm;
   // scratch for two-stage reductions
   DVec<double> red_partials;  // MAX_RED_BLOCKS * MAX_RED_SLOTS

@@ -324,13 +324,15 @@ void ParCSR::to_device_halo() {
   on_device = true;
 }
 
-void ParCSR::halo_exchange(Comm &comm, const double *x, hipStream_t s, const double *x_hi, int split) {
-  if (comm.size == 1) return;
-  if (halo.send_peers.empty() && halo.recv_peers.empty()) return;
+void ParCSR::halo_pack(const double *x, hipStream_t s, const double *x_hi, int split) {
+  if (halo.nsend() == 0) return;
   if (x_hi)
     k::gather2(x, x_hi, split, halo.d_send_map.p, halo.d_send_buf.p, halo.nsend(), s);
   else
     k::gather(x, halo.d_send_map.p, halo.d_send_buf.p, halo.nsend(), s);
+}
+
+void ParCSR::halo_transfer(Comm &comm, hipStream_t s) {
   std::vector<PeerBuf> sb, rb;
   for (size_t i = 0; i < halo.send_peers.size(); i++)
     sb.push_back({halo.send_peers[i], halo.d_send_buf.p + halo.send_starts[i],
@@ -339,6 +341,13 @@ void ParCSR::halo_exchange(Comm &comm, const double *x, hipStream_t s, const dou
     rb.push_back({halo.recv_peers[i], halo.d_xext.p + halo.recv_starts[i],
                   (size_t)(halo.recv_starts[i + 1] - halo.recv_starts[i]) * sizeof(double)});
   comm.exchange_dev(sb, rb, s);
+}
+
+void ParCSR::halo_exchange(Comm &comm, const double *x, hipStream_t s, const double *x_hi, int split) {
+  if (comm.size == 1) return;
+  if (halo.send_peers.empty() && halo.recv_peers.empty()) return;
+  halo_pack(x, s, x_hi, split);
+  halo_transfer(comm, s);
 }
 
 std::vector<int> ParCSR::halo_exchange_host_int(Comm &comm, const std::vector<int> &local) const {
@@ -369,8 +378,24 @@ void ParCSR::matvec(Comm &comm, double alpha, const double *x, double beta, cons
                     hipStream_t s, int prof) {
   MI_REQUIRE(on_device, "matrix not assembled");
   const bool halo_on = comm.size > 1 && d_offd.nrows_c > 0;
-  if (comm.size > 1) halo_exchange(comm, x, s);
+  // The diag-block product does not need the halo: the neighbour exchange runs beside it on the side stream
+  // (pack on s -> event -> exchange on comm_stream -> event -> halo-block product on s).
+  // MI_HYPRE_OVERLAP_HALO=0: everything in order on s.
+  static const bool overlap = !(getenv("MI_HYPRE_OVERLAP_HALO") && atoi(getenv("MI_HYPRE_OVERLAP_HALO")) == 0);
+  const bool mine = comm.size > 1 && !(halo.send_peers.empty() && halo.recv_peers.empty());
+  if (mine && !overlap) halo_exchange(comm, x, s);
+  if (mine && overlap) {
+    halo_pack(x, s, nullptr, 0);
+    MI_HIP(hipEventRecord(ctx().ev_packed, s));
+  }
   k::spmv(d_diag, x, alpha, beta, b, y, s, prof);
+  if (mine && overlap) {
+    hipStream_t cs = ctx().comm_stream;
+    MI_HIP(hipStreamWaitEvent(cs, ctx().ev_packed, 0));
+    halo_transfer(comm, cs);
+    MI_HIP(hipEventRecord(ctx().ev_halo, cs));
+    MI_HIP(hipStreamWaitEvent(s, ctx().ev_halo, 0));
+  }
   if (halo_on) k::spmv_offd_add(d_offd, halo.d_xext.p, alpha, y, s);
 }
 

@@ -60,6 +60,10 @@ struct ParCSR {
   // x_ext <- halo values of x (pack + neighbour exchange), enqueued on stream
   // (optional composite source: rows < split from x, rows >= split from x_hi)
   void halo_exchange(Comm &comm, const double *x, hipStream_t s, const double *x_hi = nullptr, int split = 0);
+  // its two halves: gather the send buffer / neighbour transfer into x_ext (matvec runs the transfer on a side
+  // stream, beside the diag-block product)
+  void halo_pack(const double *x, hipStream_t s, const double *x_hi, int split);
+  void halo_transfer(Comm &comm, hipStream_t s);
   // host-side halo exchange of an arbitrary per-row int array (setup only)
   std::vector<int> halo_exchange_host_int(Comm &comm, const std::vector<int> &local) const;
   // y = alpha*A*x + beta*b

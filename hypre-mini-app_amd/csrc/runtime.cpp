@@ -78,6 +78,9 @@ void ensure_init() {
     fail(1, "mi_hypre: no HIP device available (this library has no CPU path; it needs an MI355X/gfx950 GPU)");
   MI_HIP(hipGetDevice(&c.device));
   MI_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  MI_HIP(hipStreamCreateWithFlags(&c.comm_stream, hipStreamNonBlocking));
+  MI_HIP(hipEventCreateWithFlags(&c.ev_packed, hipEventDisableTiming));
+  MI_HIP(hipEventCreateWithFlags(&c.ev_halo, hipEventDisableTiming));
   c.red_partials.alloc((size_t)k::RED_MAX_BLOCKS * k::MASS_NV);
   c.red_out.alloc(256);
   MI_HIP(hipHostMalloc((void **)&c.h_pinned, 256 * sizeof(double), hipHostMallocDefault));
