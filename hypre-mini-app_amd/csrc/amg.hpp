@@ -51,6 +51,17 @@ struct AmgLevel {
   DevCSR Az;
   bool has_Az = false;
   int Az_chunk = 0;  // the hybrid-GS chunk size Az was cut for (its "in-chunk" entries)
+  // N > 1: rows with halo entries (ascending) and, per swept row range and operator, the largest halo-free
+  // stretch, cut at the units the GS kernels write back -- a pass sweeps it while the halo is still travelling
+  struct InteriorRange {
+    int row_begin, row_end;
+    const void *op;
+    int ib, ie;
+    bool ok;
+  };
+  std::vector<int> halo_rows;
+  bool halo_rows_ready = false;
+  std::vector<InteriorRange> interior_cache;
   std::vector<int> cf;  // +1 C, -1 F (empty on the coarsest level)
   bool has_cf = false;  // the level has a C/F splitting -- a GLOBAL fact (cf itself is empty on a rank without rows)
   DVec<signed char> d_cf;

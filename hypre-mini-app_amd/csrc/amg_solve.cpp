@@ -66,6 +66,101 @@ bool dense_solve(AmgLevel &Lv, Comm &comm, const double *f, double *u, hipStream
   }
   return true;
 }
+// largest stretch of [row_begin, row_end) without halo entries, cut at the write-back units of the GS kernel
+// that will sweep M; false when it is less than half of the range (not worth three launches)
+bool interior_range(AmgLevel &Lv, const DevCSR &M, int ch, int row_begin, int row_end, int &ib, int &ie) {
+  for (const auto &c : Lv.interior_cache)
+    if (c.row_begin == row_begin && c.row_end == row_end && c.op == (const void *)&M) {
+      ib = c.ib;
+      ie = c.ie;
+      return c.ok;
+    }
+  if (!Lv.halo_rows_ready) {
+    const HostCSR &B = Lv.A->offd;
+    Lv.halo_rows.clear();
+    for (int i = 0; i < B.nrows && (size_t)i + 1 < B.ia.size(); i++)
+      if (B.ia[(size_t)i + 1] > B.ia[(size_t)i]) Lv.halo_rows.push_back(i);
+    Lv.halo_rows_ready = true;
+  }
+  const std::vector<int> &hr = Lv.halo_rows;
+  const auto lo = std::lower_bound(hr.begin(), hr.end(), row_begin), hi = std::lower_bound(hr.begin(), hr.end(), row_end);
+  // gaps between consecutive halo rows of the range (open interval (a, b) = rows a+1 .. b-1)
+  int ga = row_begin - 1, gb = row_end;
+  if (lo != hi) {
+    int best = -1, prev = row_begin - 1;
+    for (auto it = lo; it != hi; ++it) {
+      if (*it - prev - 1 > best) best = *it - prev - 1, ga = prev, gb = *it;
+      prev = *it;
+    }
+    if (row_end - prev - 1 > best) ga = prev, gb = row_end;
+  }
+  int b = ga + 1, e = gb;  // rows [b, e) have no halo entries
+  const bool tiles = k::gs_uses_tiles(M, ch);
+  if (b > row_begin) {
+    if (tiles) {
+      const auto t = std::lower_bound(M.rb_host.begin(), M.rb_host.end(), b);
+      b = (t == M.rb_host.end()) ? e : *t;
+    } else {
+      b = (b + ch - 1) / ch * ch;
+    }
+  }
+  if (e < row_end) {
+    if (tiles) {
+      const auto t = std::upper_bound(M.rb_host.begin(), M.rb_host.end(), e);
+      e = (t == M.rb_host.begin()) ? b : *(t - 1);
+    } else {
+      e = e / ch * ch;
+    }
+  }
+  const bool ok = e > b && (long long)(e - b) * 2 >= (long long)(row_end - row_begin);
+  Lv.interior_cache.push_back({row_begin, row_end, (const void *)&M, b, e, ok});
+  ib = b;
+  ie = e;
+  return ok;
+}
+
+// One hybrid-GS pass over rows [row_begin, row_end) with pre-sweep values lo (rows < split) / hi.  On N > 1
+// ranks the pass needs the halo of those values: the neighbour exchange and the per-row halo contribution run on
+// the side stream while the rows without halo entries are swept, the rest follows (MI_HYPRE_OVERLAP_HALO=0: in
+// order).  zero_halo: the values are all zero -- no exchange at all.
+void gs_pass(BoomerAMG &amg, AmgLevel &Lv, const DevCSR &M, bool zero_halo, const double *lo, const double *hi, int split,
+             double *out, const double *f, const double *d, const signed char *cf, int points, int ch, const GsKind &g,
+             double w, int row_begin, int row_end, int prof, int zero_from) {
+  ParCSR &A = *Lv.A;
+  Comm &comm = amg.my_comm();
+  hipStream_t s = ctx().stream;
+  if (zero_halo || comm.size == 1) {
+    k::gs_hybrid(M, lo, hi, split, out, f, nullptr, d, cf, points, ch, g.fwd, g.bwd, w, row_begin, row_end, s, prof,
+                 zero_from);
+    return;
+  }
+  static const bool overlap = !(getenv("MI_HYPRE_OVERLAP_HALO") && atoi(getenv("MI_HYPRE_OVERLAP_HALO")) == 0);
+  const bool peers = !(A.halo.send_peers.empty() && A.halo.recv_peers.empty());
+  int ib = 0, ie = 0;
+  if (!overlap || !peers || !interior_range(Lv, M, ch, row_begin, row_end, ib, ie)) {
+    const double *offc = A.offd_contrib(comm, lo, s, hi, split);
+    k::gs_hybrid(M, lo, hi, split, out, f, offc, d, cf, points, ch, g.fwd, g.bwd, w, row_begin, row_end, s, prof,
+                 zero_from);
+    ctx().n_gs_in_order++;
+    return;
+  }
+  ctx().n_gs_overlapped++;
+  hipStream_t cs = ctx().comm_stream;
+  A.halo_pack(lo, s, hi, split);
+  MI_HIP(hipEventRecord(ctx().ev_packed, s));
+  // d_offc is zero outside the rows with halo entries, which the interior launch does not touch
+  const double *offc = A.d_offd.nrows_c > 0 ? A.d_offc.p : nullptr;
+  k::gs_hybrid(M, lo, hi, split, out, f, offc, d, cf, points, ch, g.fwd, g.bwd, w, ib, ie, s, prof, zero_from);
+  MI_HIP(hipStreamWaitEvent(cs, ctx().ev_packed, 0));
+  A.halo_transfer(comm, cs);
+  if (A.d_offd.nrows_c > 0) k::spmv_offd_set(A.d_offd, A.halo.d_xext.p, A.d_offc.p, cs);
+  MI_HIP(hipEventRecord(ctx().ev_halo, cs));
+  MI_HIP(hipStreamWaitEvent(s, ctx().ev_halo, 0));
+  if (ib > row_begin)
+    k::gs_hybrid(M, lo, hi, split, out, f, offc, d, cf, points, ch, g.fwd, g.bwd, w, row_begin, ib, s, prof, zero_from);
+  if (row_end > ie)
+    k::gs_hybrid(M, lo, hi, split, out, f, offc, d, cf, points, ch, g.fwd, g.bwd, w, ie, row_end, s, prof, zero_from);
+}
 }  // namespace
 
 // one relaxation call on the level's current vector Lv.u (level ordering), in place
@@ -85,20 +180,24 @@ void BoomerAMG::relax(int level, int type, int points, const double *f, bool u_i
   const bool has_cf = Lv.has_cf && !Lv.cf.empty();
   const signed char *cf = has_cf ? Lv.d_cf.p : nullptr;
   if (!has_cf) points = 0;
-  // a zero vector has a zero halo: no exchange, no halo contribution
-  const double *offc = u_is_zero ? nullptr : A.offd_contrib(comm, u, s);
   if (g.jacobi) {
+    // a zero vector has a zero halo: no exchange, no halo contribution
+    const double *offc = u_is_zero ? nullptr : A.offd_contrib(comm, u, s);
     k::jacobi(A.d_diag, u, Lv.snap.p, f, offc, type == 18 ? Lv.d_l1jac.p : Lv.d_diag.p, cf, points, w, s, prof);
     std::swap(Lv.u.p, Lv.snap.p);  // every row was written
     return;
   }
   const int row_begin = (points == -1) ? Lv.nc : 0;
   const int row_end = (points == 1) ? Lv.nc : Lv.n;
-  if (row_end <= row_begin) return;
+  if (row_end <= row_begin) {
+    // nothing to sweep HERE, but the neighbours' passes still expect this rank's values
+    if (!u_is_zero) A.halo_exchange(comm, u, s);
+    return;
+  }
   const int ch = chunk();
   const bool zs = u_is_zero && zero_skip_mode() > 0;
-  k::gs_hybrid((zs && Lv.has_Az && Lv.Az_chunk == ch) ? Lv.Az : A.d_diag, u, u, 0, Lv.snap.p, f, offc, g.l1 ? Lv.d_l1gs.p : Lv.d_diag.p, cf,
-               points, ch, g.fwd, g.bwd, w, row_begin, row_end, s, prof, zs ? 0 : k::GS_NO_ZEROS);
+  gs_pass(*this, Lv, (zs && Lv.has_Az && Lv.Az_chunk == ch) ? Lv.Az : A.d_diag, u_is_zero, u, u, 0, Lv.snap.p, f,
+          g.l1 ? Lv.d_l1gs.p : Lv.d_diag.p, cf, points, ch, g, w, row_begin, row_end, prof, zs ? 0 : k::GS_NO_ZEROS);
   if (row_begin == 0 && row_end == Lv.n) {
     std::swap(Lv.u.p, Lv.snap.p);
   } else {  // lone C or F pass: only the swept chunks were written
@@ -119,15 +218,12 @@ void BoomerAMG::relax_pair(int level, int type, int first, const double *f, bool
     return;
   }
   ParCSR &A = *Lv.A;
-  Comm &comm = my_comm();
-  hipStream_t s = ctx().stream;
   const int prof = relax_prof_id(level, u_is_zero && zero_skip_mode() > 0);
   const double w = p.relax_weight * p.outer_weight;
   const double *d = g.l1 ? Lv.d_l1gs.p : Lv.d_diag.p;
   const int ch = chunk(), nc = Lv.nc, n = Lv.n;
   double *u = Lv.u.p, *sn = Lv.snap.p;
   // pass 1: everything is read from u; its swept rows land in snap
-  const double *offc = u_is_zero ? nullptr : A.offd_contrib(comm, u, s);
   // on a zero guess pass 1 gathers nothing, and pass 2 of a C-then-F pair only the C columns pass 1 wrote
   // (and both run on the level's zero-guess sub-operator, which leaves out what multiplies zeros)
   const bool zs = u_is_zero && zero_skip_mode() > 0;
@@ -136,17 +232,16 @@ void BoomerAMG::relax_pair(int level, int type, int first, const double *f, bool
   const DevCSR &A1 = use_Az ? Lv.Az : A.d_diag;
   const DevCSR &A2 = (use_Az && first == 1) ? Lv.Az : A.d_diag;
   if (first == 1)
-    k::gs_hybrid(A1, u, u, 0, sn, f, offc, d, Lv.d_cf.p, 1, ch, g.fwd, g.bwd, w, 0, nc, s, prof, z1);
+    gs_pass(*this, Lv, A1, u_is_zero, u, u, 0, sn, f, d, Lv.d_cf.p, 1, ch, g, w, 0, nc, prof, z1);
   else
-    k::gs_hybrid(A1, u, u, 0, sn, f, offc, d, Lv.d_cf.p, -1, ch, g.fwd, g.bwd, w, nc, n, s, prof, z1);
+    gs_pass(*this, Lv, A1, u_is_zero, u, u, 0, sn, f, d, Lv.d_cf.p, -1, ch, g, w, nc, n, prof, z1);
   // pass 2: the rows pass 1 updated are read from snap, the others from u
   const double *lo = (first == 1) ? sn : u;
   const double *hi = (first == 1) ? u : sn;
-  offc = A.offd_contrib(comm, lo, s, hi, nc);
   if (first == 1)
-    k::gs_hybrid(A2, lo, hi, nc, sn, f, offc, d, Lv.d_cf.p, -1, ch, g.fwd, g.bwd, w, nc, n, s, prof, z2);
+    gs_pass(*this, Lv, A2, false, lo, hi, nc, sn, f, d, Lv.d_cf.p, -1, ch, g, w, nc, n, prof, z2);
   else
-    k::gs_hybrid(A2, lo, hi, nc, sn, f, offc, d, Lv.d_cf.p, 1, ch, g.fwd, g.bwd, w, 0, nc, s, prof, z2);
+    gs_pass(*this, Lv, A2, false, lo, hi, nc, sn, f, d, Lv.d_cf.p, 1, ch, g, w, 0, nc, prof, z2);
   std::swap(Lv.u.p, Lv.snap.p);  // snap now holds every row
 }
 

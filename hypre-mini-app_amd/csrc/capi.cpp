@@ -1123,6 +1123,19 @@ HYPRE_Int HYPRE_MI_SetGSChunk(HYPRE_Int rows) {
   ctx().gs_chunk = rows;
   API_END
 }
+HYPRE_Int HYPRE_MI_GetCounter(const char *name, long long *value) {
+  API_BEGIN
+  const std::string n(name ? name : "");
+  if (n == "matvec_overlapped")
+    *value = ctx().n_matvec_overlapped;
+  else if (n == "gs_overlapped")
+    *value = ctx().n_gs_overlapped;
+  else if (n == "gs_in_order")
+    *value = ctx().n_gs_in_order;
+  else
+    fail(HYPRE_ERROR_ARG, "GetCounter: unknown counter " + n);
+  API_END
+}
 HYPRE_Int HYPRE_MI_SetZeroGuessMode(HYPRE_Int mode) {
   API_BEGIN
   if (mode < 0 || mode > 2) fail(HYPRE_ERROR_ARG, "SetZeroGuessMode: 0, 1 or 2");

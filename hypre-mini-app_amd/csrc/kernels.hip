@@ -1204,6 +1204,10 @@ void spmv_offd_set(const DevOffd &B, const double *xext, double *out, hipStream_
   MI_HIP(hipGetLastError());
 }
 
+bool gs_uses_tiles(const DevCSR &A, int chunk) {
+  return chunk == 8 && A.gs_tiles && A.xcache && gs_tile_mode(A) && !gs_force_generic() && !gs_use_old();
+}
+
 void gs_hybrid(const DevCSR &A, const double *u_lo, const double *u_hi, int split, double *out, const double *f,
                const double *offc, const double *d, const signed char *cf, int points, int chunk, bool fwd, bool bwd,
                double w, int row_begin, int row_end, hipStream_t s, int prof, int zero_from) {
@@ -1215,7 +1219,7 @@ void gs_hybrid(const DevCSR &A, const double *u_lo, const double *u_hi, int spli
   const long long c1 = ((long long)row_end + chunk - 1) / chunk;
   const long long nch = c1 - c0;
   prof_begin(prof, s);
-  if (chunk == 8 && A.gs_tiles && A.xcache && gs_tile_mode(A) && !gs_force_generic() && !gs_use_old()) {
+  if (gs_uses_tiles(A, chunk)) {
     // tiles that hold the chunks [c0, c1): first tile with rb[b+1] > c0*8, last tile with rb[b] < c1*8
     const std::vector<int> &rbh = A.rb_host;
     const int first_row = (int)(c0 * 8), last_row = (int)std::min<long long>(c1 * 8, A.nrows);

@@ -62,6 +62,9 @@ void jacobi(const DevCSR &A, const double *u_old, double *u_new, const double *f
 // written to out.  zero_from: the caller guarantees that every pre-sweep value with index >= zero_from is
 // zero (first sweep on a zero guess); kernels may then skip those gathers -- same result, less traffic.
 constexpr int GS_NO_ZEROS = 0x7fffffff;
+// whether gs_hybrid sweeps A tile by tile (A.rb_host boundaries) rather than chunk by chunk: a caller that
+// splits one pass into several launches must cut at the unit the kernel writes back
+bool gs_uses_tiles(const DevCSR &A, int chunk);
 void gs_hybrid(const DevCSR &A, const double *u_lo, const double *u_hi, int split, double *out, const double *f,
                const double *offc, const double *d, const signed char *cf, int points, int chunk, bool fwd, bool bwd,
                double w, int row_begin, int row_end, hipStream_t s, int prof = PROF_NONE, int zero_from = GS_NO_ZEROS);

@@ -204,6 +204,9 @@ struct Ctx {
   int gs_chunk = 8;
   int verbose = 0;
   KernelTimer *timer = nullptr;
+  // event counters of the multi-rank choreography (HYPRE_MI_GetCounter; the distributed tests check that the
+  // overlapped paths are the ones that ran)
+  long long n_matvec_overlapped = 0, n_gs_overlapped = 0, n_gs_in_order = 0;
 };
 Ctx &ctx();
 void ensure_init();

@@ -385,6 +385,7 @@ void ParCSR::matvec(Comm &comm, double alpha, const double *x, double beta, cons
   const bool mine = comm.size > 1 && !(halo.send_peers.empty() && halo.recv_peers.empty());
   if (mine && !overlap) halo_exchange(comm, x, s);
   if (mine && overlap) {
+    ctx().n_matvec_overlapped++;
     halo_pack(x, s, nullptr, 0);
     MI_HIP(hipEventRecord(ctx().ev_packed, s));
   }

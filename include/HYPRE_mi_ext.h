@@ -54,6 +54,10 @@ HYPRE_Int HYPRE_MI_GetGSChunk(HYPRE_Int *rows_per_chunk);
  * zero-guess sub-operator, built by BoomerAMGSetup: the rows' in-chunk entries plus the F rows' C columns --
  * everything else multiplies zeros.  Same result up to summation order. */
 HYPRE_Int HYPRE_MI_SetZeroGuessMode(HYPRE_Int mode);
+/* Counters of the multi-rank choreography since the library was loaded: "matvec_overlapped" (SpMVs whose
+ * neighbour exchange ran beside the diag-block product), "gs_overlapped" / "gs_in_order" (relaxation passes that
+ * swept their halo-free rows while the halo travelled / that waited for it first). */
+HYPRE_Int HYPRE_MI_GetCounter(const char *name, long long *value);
 
 /* ---- results the driver never asks HYPRE for */
 HYPRE_Int HYPRE_MI_KrylovGetResidualHistory(HYPRE_Solver solver, HYPRE_Real *norms, HYPRE_Int max_n, HYPRE_Int *n);

@@ -197,6 +197,20 @@ def main():
             assert np.array_equal(np.asarray(amg.level_cf(0), dtype=np.int8), g["cf0"][starts[rank]:starts[rank + 1]])
             if rank == 0:
                 print(f"golden {args.golden} ok")
+        # the overlapped choreography is what ran (ranks with neighbours; a pass whose halo-free stretch is less
+        # than half of its rows stays in order)
+        cnt = {}
+        for name in ("matvec_overlapped", "gs_overlapped", "gs_in_order"):
+            v = mi.C.c_longlong()
+            mi.call("HYPRE_MI_GetCounter", name.encode(), mi.C.byref(v))
+            cnt[name] = v.value
+        if size > 1 and os.environ.get("MI_HYPRE_OVERLAP_HALO", "1") != "0":
+            assert cnt["matvec_overlapped"] > 0, cnt
+            assert cnt["gs_overlapped"] + cnt["gs_in_order"] > 0, cnt
+            if size == 2 and n >= 12:  # slabs of >= 6 planes with one neighbour: most rows are halo-free
+                assert cnt["gs_overlapped"] > 0, cnt
+        if rank == 0:
+            print(f"overlap counters rank 0: {cnt}")
         if rank == 0:
             print(f"dist solve ok: {size} ranks, {gm.num_iterations} iterations, rel res {gm.final_rel_res:.3e}, "
                   f"{n_redundant} redundant levels")
