@@ -231,7 +231,7 @@ def main():
                     "launches": spmv_n, "avg_ms": spmv_ms / spmv_n, "min_ms": spmv_min,
                     "algorithmic_bytes_per_launch": spmv_bytes}
         roof_relax = None
-        if rel_n:
+        if rel_n and world == 1:  # N > 1 cuts a pass into up to three launches (halo overlap): no per-launch figure
             a = relax_bytes / (rel_ms / rel_n * 1e-3) / 1e9
             roof_relax = {"bound": "hbm", "kernel": "gs_tile_k (level-0 l1 hybrid GS, one C or F pass over the full operator = the up-leg "
                                     "sweeps; the down leg's sweep starts from a zero guess, runs on the zero-guess "
