@@ -683,9 +683,9 @@ __global__ __launch_bounds__(256) void gs_dense_k(int n, int chunk0, int nchunks
 // products out of LDS, picks its in-chunk coefficients by the code bits of the
 // 16-bit column entries, and runs the dense 8x8 sweep of gs_dense_k.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(SPMV_BLOCK) void gs_tile_k(int blk0, int nblk, const int *__restrict__ rb,
+__global__ __launch_bounds__(SPMV_BLOCK) void gs_tile_k(int blk0, int nblk, const int *__restrict__ tdesc,
                                                         const int *__restrict__ ia, const double *__restrict__ av,
-                                                        const int *__restrict__ uptr, const int *__restrict__ ucols,
+                                                        const int *__restrict__ ucols,
                                                         const unsigned short *__restrict__ lcol,
                                                         const signed char *__restrict__ cf, int points,
                                                         const double *__restrict__ dd, const double *__restrict__ f,
@@ -700,8 +700,23 @@ __global__ __launch_bounds__(SPMV_BLOCK) void gs_tile_k(int blk0, int nblk, cons
   if ((int)blockIdx.x >= nblk) return;
   const int blk = blk0 + blockIdx.x;
   const int tid = threadIdx.x;
-  const int r0 = rb[blk], r1 = rb[blk + 1];
-  const int base = ia[r0], end = ia[r1];
+  // one descriptor load, then the loads in the order of their dependent chains (see spmv_stream_xc): column
+  // list, matrix stream, per-row data; the gathers start when the column ids are back
+  const int4 d0 = reinterpret_cast<const int4 *>(tdesc)[2 * blk];
+  const int4 d1 = reinterpret_cast<const int4 *>(tdesc)[2 * blk + 1];
+  const int r0 = d0.x, r1 = d0.y, base = d0.z, end = d0.w, u0 = d1.x, nu = d1.y;
+  // columns >= zero_from hold zeros by contract (first sweep on a zero guess): nothing to gather there --
+  // the unique columns ascend, so for zero_from == 0 not even the ids are read
+  const bool all_zero = zero_from <= 0;
+  constexpr int NU = SPMV_TILE / SPMV_BLOCK;
+  int ucid[NU];
+  if (!all_zero) {
+#pragma unroll
+    for (int q = 0; q < NU; q++) {
+      const int k = tid + q * SPMV_BLOCK;
+      ucid[q] = (k < nu) ? ucols[u0 + k] : 0;
+    }
+  }
   const int base_al = base & ~1;
   const int cnt = end - base_al;
   constexpr int NIT = SPMV_TILE / (2 * SPMV_BLOCK);
@@ -723,6 +738,7 @@ __global__ __launch_bounds__(SPMV_BLOCK) void gs_tile_k(int blk0, int nblk, cons
   const int i = r0 + rl;
   double myu = 0.0, myrhs = 0.0, wd = 0.0;
   bool rowsel = false;
+  int s0 = 0, s1 = 0;
   if (rl < nr) {
     const int mark = (points != 0 && cf != nullptr) ? (int)cf[i] : points;
     myu = (i >= zero_from) ? 0.0 : UOLD(i);
@@ -732,16 +748,18 @@ __global__ __launch_bounds__(SPMV_BLOCK) void gs_tile_k(int blk0, int nblk, cons
       myrhs = f[i];
       if (offc) myrhs -= offc[i];
       if (myd != 0.0) wd = w / myd;
+      s0 = ia[i] - base_al;
+      s1 = ia[i + 1] - base_al;
     }
   }
-  const int u0 = uptr[blk], nu = uptr[blk + 1] - u0;
-  // columns >= zero_from hold zeros by contract (first sweep on a zero guess): nothing to gather there --
-  // the unique columns ascend, so for zero_from == 0 not even the ids are read
-  const bool all_zero = zero_from <= 0;
   if (!all_zero) {
-    for (int k = tid; k < nu; k += SPMV_BLOCK) {
-      const int j = ucols[u0 + k];
-      buf[k] = (j >= zero_from) ? 0.0 : UOLD(j);
+#pragma unroll
+    for (int q = 0; q < NU; q++) {
+      const int k = tid + q * SPMV_BLOCK;
+      if (k < nu) {
+        const int j = ucid[q];
+        buf[k] = (j >= zero_from) ? 0.0 : UOLD(j);
+      }
     }
   }
   __syncthreads();
@@ -778,7 +796,6 @@ __global__ __launch_bounds__(SPMV_BLOCK) void gs_tile_k(int blk0, int nblk, cons
   unsigned inmask = 0;
   int kin = SPMV_TILE;
   if (rowsel) {
-    const int s0 = ia[i] - base_al, s1 = ia[i + 1] - base_al;
     for (int k = s0 + sub; k < s1; k += LPR) {
       const unsigned c = code[k];
       const double v = buf[k];
@@ -1226,8 +1243,8 @@ void gs_hybrid(const DevCSR &A, const double *u_lo, const double *u_hi, int spli
     const int b0 = (int)(std::upper_bound(rbh.begin(), rbh.end(), first_row) - rbh.begin()) - 1;
     const int b1 = (int)(std::lower_bound(rbh.begin(), rbh.end(), last_row) - rbh.begin());
     if (b1 > b0)
-      hipLaunchKernelGGL(gs_tile_k, dim3((unsigned)(b1 - b0)), dim3(SPMV_BLOCK), 0, s, b0, b1 - b0, A.rb.p, A.ia.p,
-                         A.a.p, A.uptr.p, A.ucols.p, A.lcol.p, cf, points, d, f, offc, u_lo, u_hi, split, out,
+      hipLaunchKernelGGL(gs_tile_k, dim3((unsigned)(b1 - b0)), dim3(SPMV_BLOCK), 0, s, b0, b1 - b0, A.tdesc.p, A.ia.p,
+                         A.a.p, A.ucols.p, A.lcol.p, cf, points, d, f, offc, u_lo, u_hi, split, out,
                          fwd ? 1 : 0, bwd ? 1 : 0, w, first_row, last_row, zero_from);
   } else if (chunk == 8 && !gs_force_generic()) {
     const double avg = (double)A.nnz / (double)A.nrows;
