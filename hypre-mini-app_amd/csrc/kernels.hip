@@ -200,9 +200,11 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream_xc(int nb, int xchunk,
   const int lane = tid & (G - 1);
   const int rr = tid / G;
   int s0 = 0, s1 = 0;
+  double bpre = 0.0;  // EPI 0 with beta != 0: the b entry of this thread's row, requested with the other loads
   if (rr < nr) {
     s0 = ia[r0 + rr] - base_al;
     s1 = ia[r0 + rr + 1] - base_al;
+    if (EPI == 0 && e.beta != 0.0 && lane == 0) bpre = e.b[r0 + rr];
   }
 #pragma unroll
   for (int q = 0; q < NU; q++) {
@@ -234,7 +236,12 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream_xc(int nb, int xchunk,
     double s = 0.0;
     for (int k = s0 + lane; k < s1; k += G) s += prod[k];
     for (int off = G >> 1; off > 0; off >>= 1) s += __shfl_down(s, off, G);
-    if (lane == 0) epilogue<EPI>(r0 + rr, s, x, y, e);
+    if (lane == 0) {
+      if (EPI == 0)
+        __builtin_nontemporal_store((e.beta == 0.0) ? e.alpha * s : e.alpha * s + e.beta * bpre, y + r0 + rr);
+      else
+        epilogue<EPI>(r0 + rr, s, x, y, e);
+    }
   }
 }
 
