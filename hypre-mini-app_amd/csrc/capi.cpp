@@ -1214,6 +1214,12 @@ HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSRSize(HYPRE_Solver solver, HYPRE_Int level
     *nnz = L.has_Az ? L.Az.nnz : 0;
     return 0;
   }
+  if (which == 7) {  // x cache of the level operator: tiles, 0, total unique columns over the tiles
+    *nrows = L.A->d_diag.nblocks;
+    *ncols = 0;
+    *nnz = (HYPRE_BigInt)L.A->d_diag.ucols.n;
+    return 0;
+  }
   const ParCSR *M = nullptr;
   switch (which) {
     case 0:
@@ -1222,7 +1228,7 @@ HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSRSize(HYPRE_Solver solver, HYPRE_Int level
     case 4: M = L.Pm.get(); break;
     case 3:
     case 5: M = L.Rm.get(); break;
-    default: fail(HYPRE_ERROR_ARG, "which must be 0..6");
+    default: fail(HYPRE_ERROR_ARG, "which must be 0..7");
   }
   if (!M) {
     *nrows = *ncols = 0;

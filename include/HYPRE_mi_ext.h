@@ -80,7 +80,8 @@ HYPRE_Int HYPRE_MI_BoomerAMGGetSetupSeconds(HYPRE_Solver solver, HYPRE_Real *sec
 /* which: 0 A diag block, 1 A offd block, 2 P diag, 3 R diag, 4 P offd (halo columns), 5 R offd.
  * P (rows: this level, columns: next level) and R = P^T are rectangular ParCSR operators.
  * GetLevelCSRSize also takes which = 6: the level's zero-guess sub-operator (the entries of the diag block a
- * first sweep on a zero guess can meet with a non-zero; 0 x 0 when the level has none). */
+ * first sweep on a zero guess can meet with a non-zero; 0 x 0 when the level has none), and which = 7: the x cache
+ * of the level's diag block (nrows = number of tiles, nnz = unique columns summed over the tiles). */
 HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSRSize(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int which, HYPRE_Int *nrows,
                                             HYPRE_Int *ncols, HYPRE_BigInt *nnz);
 HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSR(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int which, HYPRE_BigInt *ia,
