@@ -51,6 +51,13 @@ struct AmgLevel {
   DevCSR Az;
   bool has_Az = false;
   int Az_chunk = 0;  // the hybrid-GS chunk size Az was cut for (its "in-chunk" entries)
+  // operator of the residual that follows a zero-guess C-then-F sweep (sk::zero_guess_operator mode 1): the F
+  // pass leaves tvec = f - A_FC u_C for the F rows from t_from on (f itself before), so those rows need only
+  // their F columns; t_valid: tvec belongs to the current u
+  DevCSR Ar;
+  bool has_Ar = false, t_valid = false;
+  int t_from = 0;
+  DVec<double> tvec;
   // N > 1: rows with halo entries (ascending) and, per swept row range and operator, the largest halo-free
   // stretch, cut at the units the GS kernels write back -- a pass sweeps it while the halo is still travelling
   struct InteriorRange {
@@ -163,7 +170,8 @@ struct BoomerAMG {
 };
 
 // MI_HYPRE_GS_ZERO_SKIP: 0 = sweeps on a zero guess read like any other sweep, 1 = they skip the gathers of
-// known zeros, 2 (default) = they also run on the zero-guess sub-operator (AmgLevel::Az)
+// known zeros, 2 = they also run on the zero-guess sub-operator (AmgLevel::Az), 3 (default) = and the residual
+// that follows reuses the F pass's product with the C values (AmgLevel::Ar)
 int zero_skip_mode();
 void set_zero_skip_mode(int mode);  // applies to hierarchies set up afterwards (mode 2) / to every later sweep (0, 1)
 

@@ -1366,6 +1366,19 @@ void BoomerAMG::setup_device() {
       sk::to_solve_format(Z, Lv.Az, s);
       Lv.has_Az = true;
       Lv.Az_chunk = ch;
+      Lv.has_Ar = false;
+      Lv.Ar = DevCSR();
+      Lv.t_valid = false;
+      if (zero_skip_mode() > 2 && ch == 8 && li + 1 < L.size()) {  // a residual follows the down sweep
+        sk::DCsr R;
+        sk::zero_guess_operator(Lv.A->d_diag, Lv.nc, ch, R, s, 1);
+        sk::to_solve_format(R, Lv.Ar, s);
+        Lv.t_from = (Lv.nc + ch - 1) / ch * ch;
+        Lv.tvec.alloc((size_t)Lv.n);
+        zero_on_stream(Lv.tvec.p, (size_t)Lv.n * sizeof(double));
+        Lv.has_Ar = true;
+        Lv.Az.prefer_gs_tiles = true;  // only the tile kernel hands the F pass's C-column product over
+      }
     }
     if (!Lv.d_diag.p || Lv.d_diag.n != (size_t)Lv.n) {
       Lv.d_diag.upload(Lv.diag);

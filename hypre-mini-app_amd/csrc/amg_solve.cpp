@@ -27,11 +27,11 @@ static int g_zero_skip = -1;
 int zero_skip_mode() {
   if (g_zero_skip < 0) {
     const char *e = getenv("MI_HYPRE_GS_ZERO_SKIP");
-    g_zero_skip = e ? std::max(0, std::min(2, atoi(e))) : 2;
+    g_zero_skip = e ? std::max(0, std::min(3, atoi(e))) : 3;
   }
   return g_zero_skip;
 }
-void set_zero_skip_mode(int mode) { g_zero_skip = std::max(0, std::min(2, mode)); }
+void set_zero_skip_mode(int mode) { g_zero_skip = std::max(0, std::min(3, mode)); }
 
 namespace {
 // level 0 is timed under bench.py's id when that one is enabled, else under the per-level id
@@ -125,13 +125,13 @@ bool interior_range(AmgLevel &Lv, const DevCSR &M, int ch, int row_begin, int ro
 // order).  zero_halo: the values are all zero -- no exchange at all.
 void gs_pass(BoomerAMG &amg, AmgLevel &Lv, const DevCSR &M, bool zero_halo, const double *lo, const double *hi, int split,
              double *out, const double *f, const double *d, const signed char *cf, int points, int ch, const GsKind &g,
-             double w, int row_begin, int row_end, int prof, int zero_from) {
+             double w, int row_begin, int row_end, int prof, int zero_from, double *tout = nullptr, int t_from = 0) {
   ParCSR &A = *Lv.A;
   Comm &comm = amg.my_comm();
   hipStream_t s = ctx().stream;
   if (zero_halo || comm.size == 1) {
     k::gs_hybrid(M, lo, hi, split, out, f, nullptr, d, cf, points, ch, g.fwd, g.bwd, w, row_begin, row_end, s, prof,
-                 zero_from);
+                 zero_from, tout, t_from);
     return;
   }
   static const bool overlap = !(getenv("MI_HYPRE_OVERLAP_HALO") && atoi(getenv("MI_HYPRE_OVERLAP_HALO")) == 0);
@@ -140,7 +140,7 @@ void gs_pass(BoomerAMG &amg, AmgLevel &Lv, const DevCSR &M, bool zero_halo, cons
   if (!overlap || !peers || !interior_range(Lv, M, ch, row_begin, row_end, ib, ie)) {
     const double *offc = A.offd_contrib(comm, lo, s, hi, split);
     k::gs_hybrid(M, lo, hi, split, out, f, offc, d, cf, points, ch, g.fwd, g.bwd, w, row_begin, row_end, s, prof,
-                 zero_from);
+                 zero_from, tout, t_from);
     ctx().n_gs_in_order++;
     return;
   }
@@ -150,16 +150,18 @@ void gs_pass(BoomerAMG &amg, AmgLevel &Lv, const DevCSR &M, bool zero_halo, cons
   MI_HIP(hipEventRecord(ctx().ev_packed, s));
   // d_offc is zero outside the rows with halo entries, which the interior launch does not touch
   const double *offc = A.d_offd.nrows_c > 0 ? A.d_offc.p : nullptr;
-  k::gs_hybrid(M, lo, hi, split, out, f, offc, d, cf, points, ch, g.fwd, g.bwd, w, ib, ie, s, prof, zero_from);
+  k::gs_hybrid(M, lo, hi, split, out, f, offc, d, cf, points, ch, g.fwd, g.bwd, w, ib, ie, s, prof, zero_from, tout, t_from);
   MI_HIP(hipStreamWaitEvent(cs, ctx().ev_packed, 0));
   A.halo_transfer(comm, cs);
   if (A.d_offd.nrows_c > 0) k::spmv_offd_set(A.d_offd, A.halo.d_xext.p, A.d_offc.p, cs);
   MI_HIP(hipEventRecord(ctx().ev_halo, cs));
   MI_HIP(hipStreamWaitEvent(s, ctx().ev_halo, 0));
   if (ib > row_begin)
-    k::gs_hybrid(M, lo, hi, split, out, f, offc, d, cf, points, ch, g.fwd, g.bwd, w, row_begin, ib, s, prof, zero_from);
+    k::gs_hybrid(M, lo, hi, split, out, f, offc, d, cf, points, ch, g.fwd, g.bwd, w, row_begin, ib, s, prof, zero_from, tout,
+                 t_from);
   if (row_end > ie)
-    k::gs_hybrid(M, lo, hi, split, out, f, offc, d, cf, points, ch, g.fwd, g.bwd, w, ie, row_end, s, prof, zero_from);
+    k::gs_hybrid(M, lo, hi, split, out, f, offc, d, cf, points, ch, g.fwd, g.bwd, w, ie, row_end, s, prof, zero_from, tout,
+                 t_from);
 }
 }  // namespace
 
@@ -175,6 +177,7 @@ void BoomerAMG::relax(int level, int type, int points, const double *f, bool u_i
     if (dense_solve(Lv, comm, f, u, s)) return;
     type = p.relax_type[0];  // coarsest level too large for a dense solve
   }
+  Lv.t_valid = false;
   const GsKind g = classify(type);
   const double w = p.relax_weight * p.outer_weight;
   const bool has_cf = Lv.has_cf && !Lv.cf.empty();
@@ -231,6 +234,9 @@ void BoomerAMG::relax_pair(int level, int type, int first, const double *f, bool
   const bool use_Az = zs && Lv.has_Az && Lv.Az_chunk == ch;
   const DevCSR &A1 = use_Az ? Lv.Az : A.d_diag;
   const DevCSR &A2 = (use_Az && first == 1) ? Lv.Az : A.d_diag;
+  // the F pass of a zero-guess C-then-F pair also leaves f - A_FC u_C for the residual that follows (tile kernel)
+  Lv.t_valid = false;
+  const bool give_t = use_Az && first == 1 && Lv.has_Ar && zero_skip_mode() > 2 && k::gs_uses_tiles(A2, ch);
   if (first == 1)
     gs_pass(*this, Lv, A1, u_is_zero, u, u, 0, sn, f, d, Lv.d_cf.p, 1, ch, g, w, 0, nc, prof, z1);
   else
@@ -238,7 +244,11 @@ void BoomerAMG::relax_pair(int level, int type, int first, const double *f, bool
   // pass 2: the rows pass 1 updated are read from snap, the others from u
   const double *lo = (first == 1) ? sn : u;
   const double *hi = (first == 1) ? u : sn;
-  if (first == 1)
+  if (first == 1 && give_t) {
+    k::copy(f, Lv.tvec.p, std::min(Lv.t_from, n), ctx().stream);  // C rows and the chunk that straddles nc: f itself
+    gs_pass(*this, Lv, A2, false, lo, hi, nc, sn, f, d, Lv.d_cf.p, -1, ch, g, w, nc, n, prof, z2, Lv.tvec.p, Lv.t_from);
+    Lv.t_valid = true;
+  } else if (first == 1)
     gs_pass(*this, Lv, A2, false, lo, hi, nc, sn, f, d, Lv.d_cf.p, -1, ch, g, w, nc, n, prof, z2);
   else
     gs_pass(*this, Lv, A2, false, lo, hi, nc, sn, f, d, Lv.d_cf.p, 1, ch, g, w, 0, nc, prof, z2);
@@ -275,7 +285,11 @@ void BoomerAMG::cycle(int level, bool u_is_zero) {
   hipStream_t s = ctx().stream;
   relax_sweeps(level, 0, Lv.f.p, u_is_zero && p.num_sweeps[0] > 0);
   // r = f - A u ; f_c = P^T r ; u_c = 0
-  Lv.A->matvec(comm, -1.0, Lv.u.p, 1.0, Lv.f.p, Lv.tmp.p, s, k::prof_level(k::PROF_LVL_RESID, level));
+  if (Lv.t_valid && Lv.has_Ar)  // F rows: f - A_FC u_C is in tvec already, only their F columns are left
+    Lv.A->matvec(comm, -1.0, Lv.u.p, 1.0, Lv.tvec.p, Lv.tmp.p, s, k::prof_level(k::PROF_LVL_RESID, level), &Lv.Ar);
+  else
+    Lv.A->matvec(comm, -1.0, Lv.u.p, 1.0, Lv.f.p, Lv.tmp.p, s, k::prof_level(k::PROF_LVL_RESID, level));
+  Lv.t_valid = false;
   Lv.Rm->matvec(comm, 1.0, Lv.tmp.p, 0.0, nullptr, Ln.f.p, s, k::prof_level(k::PROF_LVL_RESTRICT, level));
   k::fill(Ln.u.p, Ln.n, 0.0, s);
   // the coarsest level is visited once per cycle; with a redundant tail the count continues into the tail

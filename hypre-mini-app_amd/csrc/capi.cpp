@@ -1138,7 +1138,7 @@ HYPRE_Int HYPRE_MI_GetCounter(const char *name, long long *value) {
 }
 HYPRE_Int HYPRE_MI_SetZeroGuessMode(HYPRE_Int mode) {
   API_BEGIN
-  if (mode < 0 || mode > 2) fail(HYPRE_ERROR_ARG, "SetZeroGuessMode: 0, 1 or 2");
+  if (mode < 0 || mode > 3) fail(HYPRE_ERROR_ARG, "SetZeroGuessMode: 0..3");
   set_zero_skip_mode(mode);
   API_END
 }
@@ -1214,6 +1214,12 @@ HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSRSize(HYPRE_Solver solver, HYPRE_Int level
     *nnz = L.has_Az ? L.Az.nnz : 0;
     return 0;
   }
+  if (which == 8) {  // operator of the residual after a zero-guess sweep (0 x 0 when the level has none)
+    *nrows = L.has_Ar ? L.Ar.nrows : 0;
+    *ncols = L.has_Ar ? L.Ar.ncols : 0;
+    *nnz = L.has_Ar ? L.Ar.nnz : 0;
+    return 0;
+  }
   if (which == 7) {  // x cache of the level operator: tiles, 0, total unique columns over the tiles
     *nrows = L.A->d_diag.nblocks;
     *ncols = 0;
@@ -1228,7 +1234,7 @@ HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSRSize(HYPRE_Solver solver, HYPRE_Int level
     case 4: M = L.Pm.get(); break;
     case 3:
     case 5: M = L.Rm.get(); break;
-    default: fail(HYPRE_ERROR_ARG, "which must be 0..7");
+    default: fail(HYPRE_ERROR_ARG, "which must be 0..8");
   }
   if (!M) {
     *nrows = *ncols = 0;

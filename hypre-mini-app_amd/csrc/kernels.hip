@@ -700,7 +700,8 @@ __global__ __launch_bounds__(SPMV_BLOCK) void gs_tile_k(int blk0, int nblk, cons
                                                         const double *__restrict__ u_lo,
                                                         const double *__restrict__ u_hi, int split,
                                                         double *__restrict__ u_new, int fwd, int bwd, double w,
-                                                        int row_begin, int row_end, int zero_from) {
+                                                        int row_begin, int row_end, int zero_from,
+                                                        double *__restrict__ tout, int t_from) {
 #define UOLD(j) (((j) < split ? u_lo : u_hi)[(j)])
   __shared__ double buf[SPMV_TILE];           // x cache, then products / in-chunk coefficients
   __shared__ unsigned short code[SPMV_TILE];  // the entries' lcol words
@@ -743,7 +744,7 @@ __global__ __launch_bounds__(SPMV_BLOCK) void gs_tile_k(int blk0, int nblk, cons
   const int LPR = nr <= 32 ? 8 : nr <= 64 ? 4 : nr <= 128 ? 2 : 1;
   const int rl = tid / LPR, sub = tid % LPR;
   const int i = r0 + rl;
-  double myu = 0.0, myrhs = 0.0, wd = 0.0;
+  double myu = 0.0, myrhs = 0.0, wd = 0.0, myf = 0.0;
   bool rowsel = false;
   int s0 = 0, s1 = 0;
   if (rl < nr) {
@@ -752,7 +753,7 @@ __global__ __launch_bounds__(SPMV_BLOCK) void gs_tile_k(int blk0, int nblk, cons
     rowsel = (mark == points) && i >= row_begin && i < row_end;
     if (rowsel) {
       const double myd = dd[i];
-      myrhs = f[i];
+      myrhs = myf = f[i];
       if (offc) myrhs -= offc[i];
       if (myd != 0.0) wd = w / myd;
       s0 = ia[i] - base_al;
@@ -817,6 +818,9 @@ __global__ __launch_bounds__(SPMV_BLOCK) void gs_tile_k(int blk0, int nblk, cons
     inmask |= (unsigned)__shfl_xor((int)inmask, m, 64);
     kin = min(kin, __shfl_xor(kin, m, 64));
   }
+  // F pass on a zero guess: S is exactly the row's product with the C values -- f - S is what the residual that
+  // follows needs from those columns (BoomerAMG::cycle)
+  if (tout && rowsel && sub == 0 && i >= t_from) tout[i] = myf - S;
   double crow[8];
 #pragma unroll
   for (int j = 0; j < 8; j++) {
@@ -1135,7 +1139,7 @@ static bool gs_tile_mode(const DevCSR &A) {
     v = e ? atoi(e) : -1;
   }
   if (v == 0) return false;
-  if (v == 1) return true;
+  if (v == 1 || A.prefer_gs_tiles) return true;
   static const double thr = getenv("MI_HYPRE_GS_TILE_AVG") ? atof(getenv("MI_HYPRE_GS_TILE_AVG")) : 5.0;
   return (double)A.nnz / (double)std::max(1, A.nrows) > thr;
 }
@@ -1234,7 +1238,8 @@ bool gs_uses_tiles(const DevCSR &A, int chunk) {
 
 void gs_hybrid(const DevCSR &A, const double *u_lo, const double *u_hi, int split, double *out, const double *f,
                const double *offc, const double *d, const signed char *cf, int points, int chunk, bool fwd, bool bwd,
-               double w, int row_begin, int row_end, hipStream_t s, int prof, int zero_from) {
+               double w, int row_begin, int row_end, hipStream_t s, int prof, int zero_from, double *tout,
+               int t_from) {
   if (A.nrows == 0 || row_end <= row_begin) return;
   MI_REQUIRE(chunk >= 1 && chunk <= GS_MAX_CHUNK, "hybrid GS chunk out of range");
   // chunks that intersect [row_begin, row_end); pre-sweep values come from u_lo
@@ -1252,7 +1257,7 @@ void gs_hybrid(const DevCSR &A, const double *u_lo, const double *u_hi, int spli
     if (b1 > b0)
       hipLaunchKernelGGL(gs_tile_k, dim3((unsigned)(b1 - b0)), dim3(SPMV_BLOCK), 0, s, b0, b1 - b0, A.tdesc.p, A.ia.p,
                          A.a.p, A.ucols.p, A.lcol.p, cf, points, d, f, offc, u_lo, u_hi, split, out,
-                         fwd ? 1 : 0, bwd ? 1 : 0, w, first_row, last_row, zero_from);
+                         fwd ? 1 : 0, bwd ? 1 : 0, w, first_row, last_row, zero_from, tout, t_from);
   } else if (chunk == 8 && !gs_force_generic()) {
     const double avg = (double)A.nnz / (double)A.nrows;
     const int p95 = A.rowlen_p95;

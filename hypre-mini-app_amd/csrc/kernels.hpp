@@ -67,7 +67,10 @@ constexpr int GS_NO_ZEROS = 0x7fffffff;
 bool gs_uses_tiles(const DevCSR &A, int chunk);
 void gs_hybrid(const DevCSR &A, const double *u_lo, const double *u_hi, int split, double *out, const double *f,
                const double *offc, const double *d, const signed char *cf, int points, int chunk, bool fwd, bool bwd,
-               double w, int row_begin, int row_end, hipStream_t s, int prof = PROF_NONE, int zero_from = GS_NO_ZEROS);
+               double w, int row_begin, int row_end, hipStream_t s, int prof = PROF_NONE, int zero_from = GS_NO_ZEROS,
+               double *tout = nullptr, int t_from = 0);
+// tout (tile kernel only -- check gs_uses_tiles): every swept row i >= t_from also stores f[i] minus its
+// out-of-chunk sum there
 
 // BLAS-1
 void dot(const double *x, const double *y, int n, double *out_dev, hipStream_t s);  // local sum, no collective

@@ -67,8 +67,10 @@ struct ParCSR {
   // host-side halo exchange of an arbitrary per-row int array (setup only)
   std::vector<int> halo_exchange_host_int(Comm &comm, const std::vector<int> &local) const;
   // y = alpha*A*x + beta*b
+  // diag_op (optional): another operator in place of the diag block (same rows and columns; BoomerAMG's residual
+  // after a zero-guess sweep leaves out entries whose product it already has); the halo block is always this one's
   void matvec(Comm &comm, double alpha, const double *x, double beta, const double *b, double *y, hipStream_t s,
-              int prof = -1);
+              int prof = -1, const DevCSR *diag_op = nullptr);
   // the same with the halo values already in halo.d_xext (no exchange)
   void matvec_ext_ready(double alpha, const double *x, double beta, const double *b, double *y, hipStream_t s);
   // offc[halo rows] = A_offd * x_ext(x)   (used by the smoothers)

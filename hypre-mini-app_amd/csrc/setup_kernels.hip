@@ -1107,7 +1107,10 @@ __global__ __launch_bounds__(BLK) void ilu_upper_jac_k(int n, const long long *_
 // ---------------------------------------------------------------- zero-guess sub-operator
 // which entries of row i a first sweep on a zero guess can touch: the row's own chunk, and for an F row
 // (i >= nc) the C columns (< nc) the preceding C pass has just written
-template <bool FILL>
+// MODE 1, the residual that follows that sweep: an F row at or beyond the first chunk boundary >= nc drops its
+// C columns -- the F pass has just formed exactly that part of the row's product (every C column lies outside the
+// row's chunk there) and hands it over as f - A_FC u_C; all other rows stay whole
+template <bool FILL, int MODE>
 __global__ __launch_bounds__(BLK) void zero_guess_rows_k(int n, int nc, int chunk, const int *__restrict__ ia,
                                                          const int *__restrict__ ja, const double *__restrict__ a,
                                                          int *__restrict__ cnt, const long long *__restrict__ zia,
@@ -1116,11 +1119,13 @@ __global__ __launch_bounds__(BLK) void zero_guess_rows_k(int n, int nc, int chun
   if (i >= n) return;
   const int c0 = (i / chunk) * chunk, c1 = c0 + chunk;
   const bool frow = i >= nc;
+  const bool drops_c = i >= (nc + chunk - 1) / chunk * chunk;  // MODE 1
   long long o = FILL ? zia[i] : 0;
   int c = 0;
   for (int k = ia[i]; k < ia[i + 1]; k++) {
     const int j = ja[k];
-    if ((j >= c0 && j < c1) || (frow && j < nc)) {
+    const bool keep = (MODE == 0) ? ((j >= c0 && j < c1) || (frow && j < nc)) : !(drops_c && j < nc);
+    if (keep) {
       if (FILL) {
         zja[o] = j;
         za[o] = a[k];
@@ -1273,7 +1278,7 @@ void to_solve_format(DCsr &src, DevCSR &dst, hipStream_t s) {
   MI_HIP(hipGetLastError());
 }
 
-void zero_guess_operator(const DevCSR &A, int nc, int chunk, DCsr &Z, hipStream_t s) {
+void zero_guess_operator(const DevCSR &A, int nc, int chunk, DCsr &Z, hipStream_t s, int mode) {
   const int n = A.nrows;
   Z.release();
   Z.nrows = n;
@@ -1281,8 +1286,10 @@ void zero_guess_operator(const DevCSR &A, int nc, int chunk, DCsr &Z, hipStream_
   Z.ia.alloc((size_t)n + 1);
   DVec<int> cnt((size_t)n);
   const unsigned grid = (unsigned)((n + BLK - 1) / BLK);
-  if (n)
-    zero_guess_rows_k<false><<<grid, BLK, 0, s>>>(n, nc, chunk, A.ia.p, A.ja.p, A.a.p, cnt.p, nullptr, nullptr, nullptr);
+  if (n && mode == 0)
+    zero_guess_rows_k<false, 0><<<grid, BLK, 0, s>>>(n, nc, chunk, A.ia.p, A.ja.p, A.a.p, cnt.p, nullptr, nullptr, nullptr);
+  else if (n)
+    zero_guess_rows_k<false, 1><<<grid, BLK, 0, s>>>(n, nc, chunk, A.ia.p, A.ja.p, A.a.p, cnt.p, nullptr, nullptr, nullptr);
   exclusive_scan(cnt.p, Z.ia.p, n, s);
   long long total = 0;
   MI_HIP(hipMemcpyAsync(&total, Z.ia.p + n, sizeof(long long), hipMemcpyDeviceToHost, s));
@@ -1290,8 +1297,10 @@ void zero_guess_operator(const DevCSR &A, int nc, int chunk, DCsr &Z, hipStream_
   Z.nnz = total;
   Z.ja.alloc((size_t)total);
   Z.a.alloc((size_t)total);
-  if (n && total)
-    zero_guess_rows_k<true><<<grid, BLK, 0, s>>>(n, nc, chunk, A.ia.p, A.ja.p, A.a.p, nullptr, Z.ia.p, Z.ja.p, Z.a.p);
+  if (n && total && mode == 0)
+    zero_guess_rows_k<true, 0><<<grid, BLK, 0, s>>>(n, nc, chunk, A.ia.p, A.ja.p, A.a.p, nullptr, Z.ia.p, Z.ja.p, Z.a.p);
+  else if (n && total)
+    zero_guess_rows_k<true, 1><<<grid, BLK, 0, s>>>(n, nc, chunk, A.ia.p, A.ja.p, A.a.p, nullptr, Z.ia.p, Z.ja.p, Z.a.p);
   MI_HIP(hipGetLastError());
   MI_HIP(hipStreamSynchronize(s));
 }

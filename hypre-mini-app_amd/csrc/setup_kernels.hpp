@@ -69,7 +69,9 @@ void to_solve_format(DCsr &src, DevCSR &dst, hipStream_t s);
 // zero guess can touch: every row keeps the entries inside its own chunk of `chunk` rows, F rows also their C
 // columns (written by the C pass that precedes the F pass).  Everything else multiplies zeros.  Columns stay
 // ascending; Z goes through to_solve_format like any operator.
-void zero_guess_operator(const DevCSR &A, int nc, int chunk, DCsr &Z, hipStream_t s);
+// mode 1: the operator of the residual that follows that sweep -- F rows from the first chunk boundary >= nc on
+// lose their C columns (the F pass hands over f - A_FC u_C for them), every other row stays whole.
+void zero_guess_operator(const DevCSR &A, int nc, int chunk, DCsr &Z, hipStream_t s, int mode = 0);
 // back to host arrays (lazy host copies for the inspection API)
 void solve_format_to_host(const DevCSR &src, HostCSR &h, hipStream_t s);
 

@@ -50,9 +50,10 @@ HYPRE_Int HYPRE_MI_StreamSynchronize(void);
 HYPRE_Int HYPRE_MI_SetGSChunk(HYPRE_Int rows_per_chunk);   /* hybrid-GS "thread" size, default 8 */
 HYPRE_Int HYPRE_MI_GetGSChunk(HYPRE_Int *rows_per_chunk);
 /* How the first relaxation sweep of a cycle's down leg (zero guess on every level) is run: 0 like any other
- * sweep, 1 without gathering the known zeros, 2 (default, env MI_HYPRE_GS_ZERO_SKIP) also on the level's
- * zero-guess sub-operator, built by BoomerAMGSetup: the rows' in-chunk entries plus the F rows' C columns --
- * everything else multiplies zeros.  Same result up to summation order. */
+ * sweep, 1 without gathering the known zeros, 2 also on the level's zero-guess sub-operator, built by
+ * BoomerAMGSetup: the rows' in-chunk entries plus the F rows' C columns -- everything else multiplies zeros; 3
+ * (default, env MI_HYPRE_GS_ZERO_SKIP) the residual that follows also reuses the F pass's product with the C values
+ * and reads the F rows without their C columns.  Same result up to summation order. */
 HYPRE_Int HYPRE_MI_SetZeroGuessMode(HYPRE_Int mode);
 /* Counters of the multi-rank choreography since the library was loaded: "matvec_overlapped" (SpMVs whose
  * neighbour exchange ran beside the diag-block product), "gs_overlapped" / "gs_in_order" (relaxation passes that
@@ -81,7 +82,8 @@ HYPRE_Int HYPRE_MI_BoomerAMGGetSetupSeconds(HYPRE_Solver solver, HYPRE_Real *sec
  * P (rows: this level, columns: next level) and R = P^T are rectangular ParCSR operators.
  * GetLevelCSRSize also takes which = 6: the level's zero-guess sub-operator (the entries of the diag block a
  * first sweep on a zero guess can meet with a non-zero; 0 x 0 when the level has none), and which = 7: the x cache
- * of the level's diag block (nrows = number of tiles, nnz = unique columns summed over the tiles). */
+ * of the level's diag block (nrows = number of tiles, nnz = unique columns summed over the tiles); which = 8: the
+ * operator of the residual after a zero-guess sweep (0 x 0 when the level has none). */
 HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSRSize(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int which, HYPRE_Int *nrows,
                                             HYPRE_Int *ncols, HYPRE_BigInt *nnz);
 HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSR(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int which, HYPRE_BigInt *ia,

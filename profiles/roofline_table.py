@@ -4,7 +4,8 @@ kernel class) for the benchmark configuration.   gpurun -- python3 profiles/roof
 Algorithmic bytes as in DESIGN.md section 5 / SURVEY 8(d): SpMV 12 nnz + 20 n; one relaxation sweep (C pass + F
 pass) 12 nnz + 48 n + n; restriction 12 nnz(R) + 20 n_c; prolongation 12 nnz(P) + 28 n.  The first sweep of the
 down leg starts from a zero guess and runs on the level's zero-guess sub-operator (only the entries that can meet
-a non-zero): its row is priced with THAT operator's entries, 12 nnz(Az) + 48 n + n."""
+a non-zero): its row is priced with THAT operator's entries, 12 nnz(Az) + 48 n + n.  The residual that follows
+reuses the F pass's product with the C values and reads the F rows without their C columns: priced with nnz(Ar)."""
 import ctypes as C
 import os
 import sys
@@ -64,7 +65,9 @@ for l in range(min(nlev, mi.PROF_LEVELS)):
         row(f"level {l:2d} zero-guess sweep (sub-op.)", mi.PROF_LVL_RELAX0 + l, 12.0 * nnzz + 49.0 * nl, per=2)
     row(f"level {l:2d} relaxation sweep (C+F)", mi.PROF_LVL_RELAX + l, 12.0 * nnzl + 49.0 * nl, per=2)
     if l + 1 < nlev:
-        row(f"level {l:2d} residual SpMV", mi.PROF_LVL_RESID + l, 12.0 * nnzl + 20.0 * nl)
+        nra, nnzra = size(l, 8)  # residual after a zero-guess sweep: F rows without their C columns
+        row(f"level {l:2d} residual SpMV" + (" (sub-op.)" if nra else ""), mi.PROF_LVL_RESID + l,
+            12.0 * (nnzra if nra else nnzl) + 20.0 * nl)
         nr, nnzr = size(l, 3)
         row(f"level {l:2d} restriction", mi.PROF_LVL_RESTRICT + l, 12.0 * nnzr + 20.0 * nr)
         npr, nnzp = size(l, 2)

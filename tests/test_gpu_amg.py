@@ -155,10 +155,11 @@ def _allclose_ref(x, xref, rtol=1e-6, atol=1e-8):
 def test_zero_guess_sub_operator(mi, n, stencil):
     """The first sweep of every down leg starts from u = 0 and runs on the level's zero-guess sub-operator (rows'
     in-chunk entries + the F rows' C columns; everything else multiplies zeros): the operator has exactly those
-    entries, and the solve agrees with the one that sweeps the full operator (mode 0) up to summation order."""
+    entries, and the solve agrees with the one that sweeps the full operator (mode 0) up to summation order.  Mode 3
+    adds the residual operator that follows the sweep."""
     runs = {}
     try:
-        for mode in (0, 1, 2):
+        for mode in (0, 1, 2, 3):
             mi.call("HYPRE_MI_SetZeroGuessMode", mode)
             A, b, x, rhs = mi.build_laplace_system(n, n, n, stencil)
             amg = mi.BoomerAMG(print_level=0)
@@ -179,11 +180,21 @@ def test_zero_guess_sub_operator(mi, n, stencil):
                 rows = np.repeat(np.arange(shape[0]), np.diff(ia))
                 keep = (ja // 8 == rows // 8) | ((rows >= ncoarse) & (ja < ncoarse))
                 assert nr.value == shape[0] and nnz.value == int(keep.sum()) and nnz.value < len(ja)
+                # mode 3: the operator of the residual after that sweep -- F rows from the first chunk boundary
+                # >= nc on without their C columns (the F pass hands their product over)
+                mi.call("HYPRE_MI_BoomerAMGGetLevelCSRSize", amg.h, l, 8, mi.C.byref(nr), mi.C.byref(nc_), mi.C.byref(nnz))
+                if mode == 3:
+                    t_from = (ncoarse + 7) // 8 * 8
+                    dropped = (rows >= t_from) & (ja < ncoarse)
+                    assert nr.value == shape[0] and nnz.value == len(ja) - int(dropped.sum())
+                    assert l > 1 or dropped.any()
+                else:
+                    assert nr.value == 0 and nnz.value == 0
                 checked += 1
             assert mode < 2 or checked >= 2
     finally:
-        mi.call("HYPRE_MI_SetZeroGuessMode", 2)
-    for mode in (1, 2):
+        mi.call("HYPRE_MI_SetZeroGuessMode", 3)
+    for mode in (1, 2, 3):
         assert runs[mode][0] == runs[0][0]
         assert np.allclose(runs[mode][1], runs[0][1], rtol=1e-9, atol=0.0)
         assert np.abs(runs[mode][2] - runs[0][2]).max() <= 1e-12
