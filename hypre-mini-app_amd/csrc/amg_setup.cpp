@@ -1352,6 +1352,10 @@ void BoomerAMG::setup_device() {
       }
     };
     if (li > 0 || !Lv.A->on_device) place(*Lv.A, Lv.oA);
+    // transfer operators are SpMV-only and short-rowed: more rows per tile (MI_HYPRE_SPMV_ROW_CAP, in rows)
+    static const int spmv_cap = getenv("MI_HYPRE_SPMV_ROW_CAP") ? atoi(getenv("MI_HYPRE_SPMV_ROW_CAP")) : k::SPMV_ONLY_ROW_CAP;
+    if (Lv.Pm) Lv.Pm->d_diag.row_cap = spmv_cap;
+    if (Lv.Rm) Lv.Rm->d_diag.row_cap = spmv_cap;
     if (Lv.Pm) place(*Lv.Pm, Lv.oP);
     if (Lv.Rm) place(*Lv.Rm, Lv.oR);
     // the down leg starts every level from u = 0: its sweep runs on the entries that can see non-zeros
@@ -1372,6 +1376,7 @@ void BoomerAMG::setup_device() {
       if (zero_skip_mode() > 2 && ch == 8 && li + 1 < L.size()) {  // a residual follows the down sweep
         sk::DCsr R;
         sk::zero_guess_operator(Lv.A->d_diag, Lv.nc, ch, R, s, 1);
+        Lv.Ar.row_cap = spmv_cap;
         sk::to_solve_format(R, Lv.Ar, s);
         Lv.t_from = (Lv.nc + ch - 1) / ch * ch;
         Lv.tvec.alloc((size_t)Lv.n);

@@ -193,7 +193,9 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream_xc(int nb, int xchunk,
       cc[it] = *reinterpret_cast<const us2_t *>(lcol + base_al + k);
     }
   }
-  // every thread sums at most one row (nr * G <= SPMV_BLOCK): its entry range travels with the other loads
+  // the entry range of the first row a thread sums travels with the other loads (operators that the tile
+  // Gauss-Seidel kernel also sweeps have <= SPMV_BLOCK rows per tile: one row per thread; SpMV-only operators
+  // with short rows -- P, R, the residual sub-operator -- get up to 4 x SPMV_BLOCK rows to fill their tiles)
   const int nr = r1 - r0;
   int G = 1;
   while (G < 64 && nr * G * 2 <= SPMV_BLOCK) G <<= 1;
@@ -242,6 +244,13 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream_xc(int nb, int xchunk,
       else
         epilogue<EPI>(r0 + rr, s, x, y, e);
     }
+  }
+  // tiles with more rows than threads (G == 1 there): the remaining rows, one lane each
+  for (int r2 = tid + SPMV_BLOCK; r2 < nr; r2 += SPMV_BLOCK) {
+    const int a0 = ia[r0 + r2] - base_al, a1 = ia[r0 + r2 + 1] - base_al;
+    double s = 0.0;
+    for (int k = a0; k < a1; k++) s += prod[k];
+    epilogue<EPI>(r0 + r2, s, x, y, e);
   }
 }
 
@@ -1100,7 +1109,8 @@ inline int vec_grid(int n) {
 // Tiles of the SpMV / tile Gauss-Seidel kernels: <= 256 rows and < SPMV_TILE entries.  Whenever no 8-row
 // chunk exceeds a tile the blocks begin and end on multiples of 8 rows (the hybrid-GS chunks), which the
 // tile Gauss-Seidel kernel needs; *chunk_aligned says whether that held for the whole matrix.
-std::vector<int> build_row_blocks(int nrows, const int64_t *ia, bool *chunk_aligned) {
+std::vector<int> build_row_blocks(int nrows, const int64_t *ia, bool *chunk_aligned, int row_cap) {
+  if (row_cap < SPMV_BLOCK) row_cap = SPMV_BLOCK;
   std::vector<int> rb;
   rb.reserve((size_t)nrows / 200 + 2);
   rb.push_back(0);
@@ -1110,7 +1120,7 @@ std::vector<int> build_row_blocks(int nrows, const int64_t *ia, bool *chunk_alig
     const int64_t start = ia[r];
     int e = r;
     if ((r & 7) == 0) {  // whole chunks while they fit
-      while (e < nrows && e - r < SPMV_BLOCK) {
+      while (e < nrows && e - r < row_cap) {
         const int e2 = std::min(nrows, e + 8);
         if (ia[e2] - start > SPMV_TILE - 1) break;
         e = e2;
@@ -1119,7 +1129,7 @@ std::vector<int> build_row_blocks(int nrows, const int64_t *ia, bool *chunk_alig
     if (e == r) {  // not even one chunk fits (or an unaligned start after such a chunk): row granularity
       aligned = false;
       // keep one slot of slack for the aligned-pair start
-      while (e < nrows && e - r < SPMV_BLOCK && ia[e + 1] - start <= SPMV_TILE - 1) e++;
+      while (e < nrows && e - r < row_cap && ia[e + 1] - start <= SPMV_TILE - 1) e++;
       if (e == r) e = r + 1;  // a single row longer than the tile
     }
     rb.push_back(e);

@@ -34,7 +34,9 @@ inline int prof_level(int base, int level) { return level < PROF_LEVELS ? base +
 
 // host: row-block schedule for spmv_stream (<= 256 rows and < SPMV_TILE entries
 // per block, or exactly one longer row)
-std::vector<int> build_row_blocks(int nrows, const int64_t *ia, bool *chunk_aligned = nullptr);
+std::vector<int> build_row_blocks(int nrows, const int64_t *ia, bool *chunk_aligned = nullptr,
+                                  int row_cap = SPMV_BLOCK);
+constexpr int SPMV_ONLY_ROW_CAP = 4 * SPMV_BLOCK;  // rows per tile of operators no Gauss-Seidel kernel sweeps
 constexpr int XC_ID_MASK = 0x7FF;   // block-local column id inside an lcol entry (SPMV_TILE <= 2048 ids)
 constexpr int XC_INCH = 0x8000;     // the column lies in the row's own 8-row chunk ...
 constexpr int XC_OFF_SHIFT = 12;    // ... at this offset (3 bits)

@@ -114,7 +114,8 @@ void DevCSR::upload(const HostCSR &h) {
     }
   }
   bool aligned = false;
-  std::vector<int> blocks = k::build_row_blocks(nrows, h.ia.data(), &aligned);
+  std::vector<int> blocks = k::build_row_blocks(nrows, h.ia.data(), &aligned, row_cap);
+  if (row_cap > k::SPMV_BLOCK) aligned = false;  // such tiles are not for the tile Gauss-Seidel kernel
   nblocks = (int)blocks.size() - 1;
   rb.upload(blocks);
   rb_host = blocks;

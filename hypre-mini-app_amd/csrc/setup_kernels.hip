@@ -1239,7 +1239,8 @@ void to_solve_format(DCsr &src, DevCSR &dst, hipStream_t s) {
   MI_HIP(hipMemcpyAsync(hia.data(), src.ia.p, ((size_t)n + 1) * sizeof(long long), hipMemcpyDeviceToHost, s));
   MI_HIP(hipStreamSynchronize(s));
   bool aligned = false;
-  std::vector<int> blocks = k::build_row_blocks(n, hia.data(), &aligned);
+  std::vector<int> blocks = k::build_row_blocks(n, hia.data(), &aligned, dst.row_cap);
+  if (dst.row_cap > k::SPMV_BLOCK) aligned = false;  // such tiles are not for the tile Gauss-Seidel kernel
   std::vector<int64_t>().swap(hia);
   dst.nblocks = (int)blocks.size() - 1;
   dst.rb.upload(blocks);
