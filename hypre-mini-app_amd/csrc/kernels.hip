@@ -1119,7 +1119,7 @@ std::vector<int> build_row_blocks(int nrows, const int64_t *ia, bool *chunk_alig
   while (r < nrows) {
     const int64_t start = ia[r];
     int e = r;
-    if ((r & 7) == 0) {  // whole chunks while they fit
+    if ((r & 7) == 0 && row_cap <= SPMV_BLOCK) {  // whole chunks while they fit (SpMV-only operators: any row)
       while (e < nrows && e - r < row_cap) {
         const int e2 = std::min(nrows, e + 8);
         if (ia[e2] - start > SPMV_TILE - 1) break;
