@@ -44,12 +44,33 @@ def parse():
     return ap.parse_args()
 
 
+def physical_cores():
+    """Physical cores this process may run on: distinct (package, core) pairs of /proc/cpuinfo among the CPUs of
+    the affinity mask (SMT siblings count once)."""
+    try:
+        allowed = os.sched_getaffinity(0)
+    except AttributeError:
+        allowed = set(range(os.cpu_count() or 1))
+    pairs, cpu, pkg = set(), None, None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("processor"):
+                cpu = int(line.split(":")[1])
+            elif line.startswith("physical id"):
+                pkg = int(line.split(":")[1])
+            elif line.startswith("core id") and cpu in allowed:
+                pairs.add((pkg, int(line.split(":")[1])))
+    except (OSError, ValueError):
+        pairs = set()
+    return max(1, min(len(pairs) or len(allowed), len(allowed)))
+
+
 def cpu_baseline(args, chunk):
     """Oracle (CPU restatement of the HYPRE algorithm; libHYPRE is not available offline)
-    timed on this host on a bounded sample of the same workload."""
+    timed on this host on a bounded sample of the same workload, OpenMP over all physical cores."""
     oc = ge.load_oracle()
     n = args.cpu_n
-    cores = min(os.cpu_count() or 1, 16)
+    cores = physical_cores()
     oc.lib().oracle_set_threads(cores)
     A, b = oc.Csr.laplace(n, n, n, args.stencil)
     t0 = time.time()
@@ -88,13 +109,31 @@ def cpu_baseline(args, chunk):
     }
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as a CHILD torch.distributed.run (nothing
+    in this process has touched the GPU yet -- no exec) and pass its output and exit code through."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: never report an N-GPU request on {world} rank(s)")
 
     import torch
 
@@ -212,15 +251,21 @@ def main():
 
     out = None
     if rank == 0:
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                key = f"{n}^3/{args.stencil}pt/{world}gpu"
-                traffic = tj.get(key, {}).get("spmv_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        # HBM traffic per launch comes from a separate rocprofv3 --pmc pass (the counters cannot be read from
+        # inside this process): the newest recorded figure for this configuration, labelled as recorded
+        traffic, traffic_source = None, None
+        for tname in ("traffic_r02.json", "traffic_r01.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if traffic is None and os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    key = f"{n}^3/{args.stencil}pt/{world}gpu"
+                    traffic = tj.get(key, {}).get("spmv_hbm_bytes_per_launch")
+                    if traffic is not None:
+                        traffic_source = (f"RECORDED in profiles/{tname} by a separate rocprofv3 --pmc pass "
+                                          "(FETCH_SIZE x2 + WRITE_SIZE per launch), not observed by this run")
+                except Exception:
+                    traffic = None
         roof = None
         if spmv_n:
             a = spmv_bytes / (spmv_ms / spmv_n * 1e-3) / 1e9
@@ -228,7 +273,7 @@ def main():
                               "runs in the preconditioner's C-first ordering of level 0, whose x gathers are less local "
                               "than the caller's lexicographic ordering -- 3.0 ms there -- but no gather/scatter per V-cycle)", "achieved": a,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": traffic,
-                    "launches": spmv_n, "avg_ms": spmv_ms / spmv_n, "min_ms": spmv_min,
+                    "traffic_source": traffic_source, "launches": spmv_n, "avg_ms": spmv_ms / spmv_n, "min_ms": spmv_min,
                     "algorithmic_bytes_per_launch": spmv_bytes}
         roof_relax = None
         if rel_n and world == 1:  # N > 1 cuts a pass into up to three launches (halo overlap): no per-launch figure

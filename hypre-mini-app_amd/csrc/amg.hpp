@@ -27,6 +27,7 @@ struct AmgParams {
   double tol = 1e-7;
   int gs_chunk = 0;  // 0 => runtime default (ctx().gs_chunk)
   int agg_num_levels = 0, agg_interp_type = 4, agg_pmax_elmts = 0, keep_transpose = 0, rap2 = 0;
+  double agg_trunc_factor = 0.0;
   int smooth_num_sweeps = 1;
   // N > 1 ranks: levels >= 1 with at most this many global rows are kept whole on every rank and cycled
   // redundantly, without halo exchanges (HYPRE_BoomerAMGSetSeqThreshold); -1 = MI_HYPRE_REDUNDANT_ROWS or 200000
@@ -103,6 +104,10 @@ struct BoomerAMG {
   int num_iterations = 0;
   double final_rel_res = 0.0;
   double setup_seconds = 0.0;
+  // the matrix HYPRE_BoomerAMGSetup was called with (and its assembly stamp): a Krylov solver may run on the
+  // hierarchy's own level-0 copy only when it is handed that very matrix (krylov.cpp amg_in_level_order)
+  const ParCSR *source_matrix = nullptr;
+  unsigned long long source_stamp = 0;
   int chunk() const;
   // the communicator this hierarchy works on: the process communicator, or a private single-rank one
   // (global hierarchy of the replicated setup, redundant coarse tail)
@@ -143,6 +148,8 @@ struct BoomerAMG {
     device_min_rows = default_device_min_rows();
     setup_host(A);
     setup_device();
+    source_matrix = &A;
+    source_stamp = A.assembly_stamp;
   }
   // hierarchy construction: host only (threads + host collectives)
   void setup_host(ParCSR &A);

@@ -365,6 +365,398 @@ void build_interp(const ParCSR &A, const Strength &S, std::vector<int> &cf, int 
     if (cf[(size_t)i] == SF_PT) cf[(size_t)i] = F_PT;
 }
 
+// ---- coarsening types beyond PMIS, and aggressive coarsening (mirrors oracle/oracle.c statement by statement)
+
+// S^T: row i lists, ascending, the points that strongly depend on i
+void strength_transpose(int n, const Strength &S, Strength &T) {
+  T.ia.assign((size_t)n + 1, 0);
+  T.ja.resize(S.ja.size());
+  for (size_t k = 0; k < S.ja.size(); k++) T.ia[(size_t)S.ja[k] + 1]++;
+  for (int i = 0; i < n; i++) T.ia[(size_t)i + 1] += T.ia[(size_t)i];
+  std::vector<int64_t> pos(T.ia.begin(), T.ia.end() - 1);
+  for (int i = 0; i < n; i++)
+    for (int64_t k = S.ia[(size_t)i]; k < S.ia[(size_t)i + 1]; k++) T.ja[(size_t)pos[(size_t)S.ja[(size_t)k]]++] = i;
+}
+
+// bucket lists of the Ruge-Stueben first pass (hypre_enter_on_lists / hypre_remove_point): one FIFO list per
+// integer measure, the next C point is the head of the highest non-empty list
+struct RsLists {
+  std::vector<int> head, tail, prev, next;
+  int top = 0;
+  RsLists(int nb, int n) : head((size_t)nb, -1), tail((size_t)nb, -1), prev((size_t)n, -1), next((size_t)n, -1) {}
+  void enter(int m, int i) {
+    prev[(size_t)i] = tail[(size_t)m];
+    next[(size_t)i] = -1;
+    if (tail[(size_t)m] >= 0)
+      next[(size_t)tail[(size_t)m]] = i;
+    else
+      head[(size_t)m] = i;
+    tail[(size_t)m] = i;
+    if (m > top) top = m;
+  }
+  void remove(int m, int i) {
+    if (prev[(size_t)i] >= 0)
+      next[(size_t)prev[(size_t)i]] = next[(size_t)i];
+    else
+      head[(size_t)m] = next[(size_t)i];
+    if (next[(size_t)i] >= 0)
+      prev[(size_t)next[(size_t)i]] = prev[(size_t)i];
+    else
+      tail[(size_t)m] = prev[(size_t)i];
+  }
+};
+
+// classical Ruge-Stueben coarsening on the (global) strength graph: hypre_BoomerAMGCoarsenRuge.  First pass by
+// measure |S^T_i| with bucket lists; second pass (types 1, 3, 6): strong F-F pairs must share a C point.
+// Sequential by definition -- HYPRE's device build offers PMIS only; these types exist so that inputs which ask
+// for them (the upstream sample: coarsen_type 6, etc/hypre_app.yaml:35) get what they ask for.
+void ruge_stueben(int n, const Strength &S, bool second_pass, std::vector<int> &cf) {
+  Strength T;
+  strength_transpose(n, S, T);
+  std::vector<int> measure((size_t)n);
+  int maxm = 0;
+  for (int i = 0; i < n; i++) {
+    measure[(size_t)i] = (int)(T.ia[(size_t)i + 1] - T.ia[(size_t)i]);
+    maxm = std::max(maxm, measure[(size_t)i]);
+  }
+  RsLists q(2 * maxm + 2, n);
+  cf.assign((size_t)n, 0);
+  int64_t num_left = 0;
+  for (int i = 0; i < n; i++) {
+    if (S.ia[(size_t)i + 1] == S.ia[(size_t)i]) {
+      cf[(size_t)i] = SF_PT;
+      measure[(size_t)i] = 0;
+    } else
+      num_left++;
+  }
+  auto bump = [&](int p2) {  // an undecided point gains one
+    q.remove(measure[(size_t)p2], p2);
+    measure[(size_t)p2]++;
+    q.enter(measure[(size_t)p2], p2);
+  };
+  for (int j = 0; j < n; j++) {
+    if (cf[(size_t)j] != 0) continue;
+    if (measure[(size_t)j] > 0) {
+      q.enter(measure[(size_t)j], j);
+    } else {
+      cf[(size_t)j] = F_PT;
+      num_left--;
+      for (int64_t k = S.ia[(size_t)j]; k < S.ia[(size_t)j + 1]; k++) {
+        const int nb = S.ja[(size_t)k];
+        if (cf[(size_t)nb] != 0) continue;
+        if (nb < j) {
+          if (measure[(size_t)nb] > 0) q.remove(measure[(size_t)nb], nb);
+          measure[(size_t)nb]++;
+          q.enter(measure[(size_t)nb], nb);
+        } else
+          measure[(size_t)nb]++;
+      }
+    }
+  }
+  while (num_left > 0) {
+    while (q.top > 0 && q.head[(size_t)q.top] < 0) q.top--;
+    const int c = q.head[(size_t)q.top];
+    if (c < 0) break;
+    cf[(size_t)c] = C_PT;
+    q.remove(measure[(size_t)c], c);
+    measure[(size_t)c] = 0;
+    num_left--;
+    for (int64_t j = T.ia[(size_t)c]; j < T.ia[(size_t)c + 1]; j++) {
+      const int nb = T.ja[(size_t)j];
+      if (cf[(size_t)nb] != 0) continue;
+      cf[(size_t)nb] = F_PT;
+      q.remove(measure[(size_t)nb], nb);
+      num_left--;
+      for (int64_t k = S.ia[(size_t)nb]; k < S.ia[(size_t)nb + 1]; k++)
+        if (cf[(size_t)S.ja[(size_t)k]] == 0) bump(S.ja[(size_t)k]);
+    }
+    for (int64_t j = S.ia[(size_t)c]; j < S.ia[(size_t)c + 1]; j++) {
+      const int nb = S.ja[(size_t)j];
+      if (cf[(size_t)nb] != 0) continue;
+      q.remove(measure[(size_t)nb], nb);
+      measure[(size_t)nb]--;
+      if (measure[(size_t)nb] > 0)
+        q.enter(measure[(size_t)nb], nb);
+      else {
+        cf[(size_t)nb] = F_PT;
+        num_left--;
+        for (int64_t k = S.ia[(size_t)nb]; k < S.ia[(size_t)nb + 1]; k++)
+          if (cf[(size_t)S.ja[(size_t)k]] == 0) bump(S.ja[(size_t)k]);
+      }
+    }
+  }
+  if (!second_pass) return;
+  std::vector<int> mark((size_t)n, -1);
+  for (int i = 0; i < n; i++) {
+    if (cf[(size_t)i] != F_PT) continue;
+    int tentative = -1;
+    for (;;) {
+      for (int64_t k = S.ia[(size_t)i]; k < S.ia[(size_t)i + 1]; k++)
+        if (cf[(size_t)S.ja[(size_t)k]] == C_PT) mark[(size_t)S.ja[(size_t)k]] = i;
+      int lonely = -1;  // first strong F neighbour that shares no C point with i
+      for (int64_t k = S.ia[(size_t)i]; k < S.ia[(size_t)i + 1] && lonely < 0; k++) {
+        const int j = S.ja[(size_t)k];
+        if (cf[(size_t)j] != F_PT) continue;
+        bool shared = false;
+        for (int64_t kk = S.ia[(size_t)j]; kk < S.ia[(size_t)j + 1]; kk++) {
+          const int c = S.ja[(size_t)kk];
+          if (mark[(size_t)c] == i && cf[(size_t)c] == C_PT) {
+            shared = true;
+            break;
+          }
+        }
+        if (!shared) lonely = j;
+      }
+      if (lonely < 0) break;
+      if (tentative < 0) {
+        tentative = lonely;
+        cf[(size_t)lonely] = C_PT;
+      } else {
+        cf[(size_t)i] = C_PT;
+        cf[(size_t)tentative] = F_PT;
+        break;
+      }
+    }
+  }
+}
+
+bool coarsen_type_restated(int type) {
+  return type == 8 || type == 10 || type == 11 || type == 6 || type == 1 || type == 3;
+}
+
+// HYPRE_BoomerAMGSetCoarsenType (src/HypreSystem.cpp:125-126): 8 PMIS; 10 HMIS / 11 = one-pass Ruge-Stueben;
+// 6 Falgout / 1 / 3 = two-pass Ruge-Stueben.  HMIS and Falgout finish with PMIS / CLJP on what the Ruge-Stueben
+// pass leaves undecided; coarsening sees the whole graph here, where nothing is left --
+// as on a single HYPRE rank.
+void coarsen_by_type(int type, int n, const Strength &S, std::vector<int> &cf) {
+  if (type == 8)
+    pmis(n, S, 0, cf);
+  else if (type == 10 || type == 11)
+    ruge_stueben(n, S, false, cf);
+  else if (type == 6 || type == 1 || type == 3)
+    ruge_stueben(n, S, true, cf);
+  else
+    fail(4, "BoomerAMG: coarsen_type " + std::to_string(type) + " is not implemented (8, 10, 11, 6, 1, 3 are)");
+}
+
+// hypre_BoomerAMGCreate2ndS, num_paths 1: graph on the C points of the first coarsening; C point i depends on
+// C point j != i iff j is in S_i or in S_k for some k in S_i.  Coarse indices, columns ascending.
+void second_strength(int n, const Strength &S, const std::vector<int> &cf, Strength &S2, int &nc_out) {
+  std::vector<int> f2c((size_t)n, -1);
+  int nc = 0;
+  for (int i = 0; i < n; i++)
+    if (cf[(size_t)i] == C_PT) f2c[(size_t)i] = nc++;
+  nc_out = nc;
+  std::vector<int> crow((size_t)nc);
+  for (int i = 0; i < n; i++)
+    if (f2c[(size_t)i] >= 0) crow[(size_t)f2c[(size_t)i]] = i;
+  const int nt = host_threads();
+  std::vector<std::vector<int>> tj((size_t)nt);
+  std::vector<int> rowlen((size_t)nc, 0);
+  std::vector<int64_t> tbeg((size_t)nt, 0);
+  std::vector<char> used((size_t)nt, 0);
+  parallel_for(nc, [&](int64_t b, int64_t e, int t) {
+    used[(size_t)t] = 1;
+    tbeg[(size_t)t] = b;
+    std::vector<int> &out = tj[(size_t)t];
+    std::vector<int> row;
+    for (int64_t ci = b; ci < e; ci++) {
+      const int i = crow[(size_t)ci];
+      row.clear();
+      auto add = [&](int j) {
+        const int cj = f2c[(size_t)j];
+        if (cj >= 0 && cj != ci) row.push_back(cj);
+      };
+      for (int64_t k = S.ia[(size_t)i]; k < S.ia[(size_t)i + 1]; k++) {
+        const int k1 = S.ja[(size_t)k];
+        add(k1);
+        for (int64_t kk = S.ia[(size_t)k1]; kk < S.ia[(size_t)k1 + 1]; kk++) add(S.ja[(size_t)kk]);
+      }
+      std::sort(row.begin(), row.end());
+      row.erase(std::unique(row.begin(), row.end()), row.end());
+      rowlen[(size_t)ci] = (int)row.size();
+      out.insert(out.end(), row.begin(), row.end());
+    }
+  });
+  S2.ia.assign((size_t)nc + 1, 0);
+  for (int q = 0; q < nc; q++) S2.ia[(size_t)q + 1] = S2.ia[(size_t)q] + rowlen[(size_t)q];
+  S2.ja.resize((size_t)S2.ia[(size_t)nc]);
+  for (int t = 0; t < nt; t++)
+    if (used[(size_t)t] && !tj[(size_t)t].empty())
+      memcpy(S2.ja.data() + S2.ia[(size_t)tbeg[(size_t)t]], tj[(size_t)t].data(), tj[(size_t)t].size() * sizeof(int));
+}
+
+// aggressive coarsening of one level (par_amg_setup.c, level < agg_num_levels; src/HypreSystem.cpp:215-219):
+// coarsen with S, coarsen the C points again with the second-generation graph, keep what survives both
+void coarsen_aggressive(int type, int n, const Strength &S, std::vector<int> &cf) {
+  coarsen_by_type(type, n, S, cf);
+  Strength S2;
+  int nc = 0;
+  second_strength(n, S, cf, S2, nc);
+  std::vector<int> cf2;
+  coarsen_by_type(type, nc, S2, cf2);
+  int q = 0;
+  for (int i = 0; i < n; i++)
+    if (cf[(size_t)i] == C_PT) {
+      if (cf2[(size_t)q] != C_PT) cf[(size_t)i] = cf2[(size_t)q];
+      q++;
+    }
+}
+
+// Multipass interpolation (hypre_BoomerAMGBuildMultipass; agg_interp_type 4, src/HypreSystem.cpp:220-224): see
+// oracle/oracle.c build_multipass for the formulas.  Pass by pass; the rows of one pass are independent (threads),
+// every row is accumulated by one thread in the oracle's order.
+void build_multipass(const ParCSR &A, const Strength &S, std::vector<int> &cf, double trunc_factor, int pmax,
+                     HostCSR &P, int &nc_out) {
+  const HostCSR &D = A.diag;
+  const int n = D.nrows;
+  std::vector<int> f2c((size_t)n, -1);
+  int nc = 0;
+  for (int i = 0; i < n; i++)
+    if (cf[(size_t)i] == C_PT) f2c[(size_t)i] = nc++;
+  nc_out = nc;
+  std::vector<int> assigned((size_t)n, -1), rlen((size_t)n, 0);
+  std::vector<int64_t> rstart((size_t)n, 0);
+  std::vector<int> pool_c;  // rows in the order they were built: coarse columns / weights in discovery order
+  std::vector<double> pool_v;
+  pool_c.reserve((size_t)n);
+  pool_v.reserve((size_t)n);
+  int64_t remaining = 0;
+  for (int i = 0; i < n; i++) {
+    if (cf[(size_t)i] == C_PT) {
+      assigned[(size_t)i] = 0;
+      rstart[(size_t)i] = (int64_t)pool_c.size();
+      rlen[(size_t)i] = 1;
+      pool_c.push_back(f2c[(size_t)i]);
+      pool_v.push_back(1.0);
+    } else if (cf[(size_t)i] != SF_PT)
+      remaining++;
+  }
+  const int nt = host_threads();
+  std::vector<std::vector<int>> cpos((size_t)nt);
+  std::vector<int> list;
+  for (int pass = 1; remaining > 0; pass++) {
+    list.clear();
+    for (int i = 0; i < n; i++) {
+      if (assigned[(size_t)i] != -1 || cf[(size_t)i] == SF_PT) continue;
+      for (int64_t k = S.ia[(size_t)i]; k < S.ia[(size_t)i + 1]; k++)
+        if (assigned[(size_t)S.ja[(size_t)k]] == pass - 1) {
+          list.push_back(i);
+          break;
+        }
+    }
+    const int64_t nl = (int64_t)list.size();
+    if (nl == 0) break;
+    std::vector<std::vector<int>> tc((size_t)nt);
+    std::vector<std::vector<double>> tv((size_t)nt);
+    std::vector<int> newlen((size_t)nl, 0);
+    std::vector<int64_t> tbeg((size_t)nt, 0);
+    std::vector<char> used((size_t)nt, 0);
+    parallel_for(nl, [&](int64_t b, int64_t e, int t) {
+      used[(size_t)t] = 1;
+      tbeg[(size_t)t] = b;
+      std::vector<int> &pos = cpos[(size_t)t];
+      if (pos.size() != (size_t)nc) pos.assign((size_t)nc, -1);
+      std::vector<int> &oc = tc[(size_t)t];
+      std::vector<double> &ov = tv[(size_t)t];
+      for (int64_t q = b; q < e; q++) {
+        const int i = list[(size_t)q];
+        const size_t base = oc.size();
+        double diagonal = 0.0, sum_N = 0.0, sum_J = 0.0;
+        int64_t ks = S.ia[(size_t)i];
+        const int64_t kse = S.ia[(size_t)i + 1];
+        for (int64_t k = D.ia[(size_t)i]; k < D.ia[(size_t)i + 1]; k++) {
+          const int j = D.ja[(size_t)k];
+          if (j == i) {
+            diagonal = D.a[(size_t)k];
+            continue;
+          }
+          sum_N += D.a[(size_t)k];
+          // S_i is a subsequence of A's row: two-pointer membership test
+          while (ks < kse && S.ja[(size_t)ks] < j) ks++;
+          const bool strong = ks < kse && S.ja[(size_t)ks] == j;
+          if (!strong || assigned[(size_t)j] != pass - 1) continue;
+          sum_J += D.a[(size_t)k];
+          const int64_t r0 = rstart[(size_t)j];
+          for (int w = 0; w < rlen[(size_t)j]; w++) {
+            const int c = pool_c[(size_t)(r0 + w)];
+            if (pos[(size_t)c] < 0) {
+              pos[(size_t)c] = (int)(oc.size() - base);
+              oc.push_back(c);
+              ov.push_back(0.0);
+            }
+            ov[base + (size_t)pos[(size_t)c]] += D.a[(size_t)k] * pool_v[(size_t)(r0 + w)];
+          }
+        }
+        for (int64_t k = A.offd.ia[(size_t)i]; k < A.offd.ia[(size_t)i + 1]; k++) sum_N += A.offd.a[(size_t)k];
+        const double alfa = (sum_J * diagonal != 0.0) ? -sum_N / (sum_J * diagonal) : 0.0;
+        const int len = (int)(oc.size() - base);
+        for (int w = 0; w < len; w++) {
+          ov[base + (size_t)w] *= alfa;
+          pos[(size_t)oc[base + (size_t)w]] = -1;
+        }
+        newlen[(size_t)q] = len;
+      }
+    });
+    // append the pass's rows to the pool (list order) -- only now do its points count as reached
+    int64_t at = (int64_t)pool_c.size();
+    for (int64_t q = 0; q < nl; q++) {
+      rstart[(size_t)list[(size_t)q]] = at;
+      rlen[(size_t)list[(size_t)q]] = newlen[(size_t)q];
+      at += newlen[(size_t)q];
+    }
+    pool_c.resize((size_t)at);
+    pool_v.resize((size_t)at);
+    for (int t = 0; t < nt; t++)
+      if (used[(size_t)t] && !tc[(size_t)t].empty()) {
+        const int64_t off = rstart[(size_t)list[(size_t)tbeg[(size_t)t]]];
+        memcpy(pool_c.data() + off, tc[(size_t)t].data(), tc[(size_t)t].size() * sizeof(int));
+        memcpy(pool_v.data() + off, tv[(size_t)t].data(), tv[(size_t)t].size() * sizeof(double));
+      }
+    for (int64_t q = 0; q < nl; q++) assigned[(size_t)list[(size_t)q]] = pass;
+    remaining -= nl;
+  }
+  // truncation and sort row by row (in place in the pool), then compaction into P
+  std::vector<int> flen((size_t)n, 0);
+  parallel_for(n, [&](int64_t b, int64_t e, int) {
+    std::vector<char> keep;
+    for (int64_t i = b; i < e; i++) {
+      int len = rlen[(size_t)i];
+      int *rc = pool_c.data() + rstart[(size_t)i];
+      double *rv = pool_v.data() + rstart[(size_t)i];
+      if (cf[(size_t)i] != C_PT && len > 0) len = truncate_row(len, rc, rv, trunc_factor, pmax, keep);
+      for (int a = 1; a < len; a++) {
+        const int c = rc[a];
+        const double v = rv[a];
+        int bb = a - 1;
+        while (bb >= 0 && rc[bb] > c) {
+          rc[bb + 1] = rc[bb];
+          rv[bb + 1] = rv[bb];
+          bb--;
+        }
+        rc[bb + 1] = c;
+        rv[bb + 1] = v;
+      }
+      flen[(size_t)i] = len;
+    }
+  });
+  P.nrows = n;
+  P.ncols = nc;
+  P.ia.assign((size_t)n + 1, 0);
+  for (int i = 0; i < n; i++) P.ia[(size_t)i + 1] = P.ia[(size_t)i] + flen[(size_t)i];
+  P.ja.resize((size_t)P.nnz());
+  P.a.resize((size_t)P.nnz());
+  parallel_for(n, [&](int64_t b, int64_t e, int) {
+    for (int64_t i = b; i < e; i++) {
+      if (!flen[(size_t)i]) continue;
+      memcpy(P.ja.data() + P.ia[(size_t)i], pool_c.data() + rstart[(size_t)i], (size_t)flen[(size_t)i] * sizeof(int));
+      memcpy(P.a.data() + P.ia[(size_t)i], pool_v.data() + rstart[(size_t)i], (size_t)flen[(size_t)i] * sizeof(double));
+    }
+  });
+  for (int i = 0; i < n; i++)
+    if (cf[(size_t)i] == SF_PT) cf[(size_t)i] = F_PT;
+}
+
 void dense_inverse(int n, std::vector<double> &M, std::vector<double> &inv) {
   inv.assign((size_t)n * n, 0.0);
   for (int i = 0; i < n; i++) inv[(size_t)i * n + i] = 1.0;
@@ -729,8 +1121,12 @@ void BoomerAMG::setup_host(ParCSR &A0) {
   is_setup = false;
   host_ready = false;
   MI_REQUIRE(!A0.row_starts.empty(), "BoomerAMGSetup: matrix is not assembled");
-  if (p.print_level > 0 && comm.rank == 0 && p.coarsen_type != 8 && p.coarsen_type != 10)
-    printf("mi_hypre BoomerAMG: coarsen_type %d is not restated; using PMIS (8)\n", p.coarsen_type);
+  if (!coarsen_type_restated(p.coarsen_type))
+    fail(4, "BoomerAMGSetup: coarsen_type " + std::to_string(p.coarsen_type) +
+                " is not implemented (8 PMIS, 10 HMIS, 11, 6 Falgout, 1, 3 are); refusing to substitute another one");
+  if (p.agg_num_levels > 0 && p.agg_interp_type != 4)
+    fail(4, "BoomerAMGSetup: agg_interp_type " + std::to_string(p.agg_interp_type) +
+                " is not implemented (4 = multipass is); refusing to substitute another one");
   if (comm.size > 1) {
     build_replicated(A0);
   } else {
@@ -771,11 +1167,22 @@ void BoomerAMG::build_natural(ParCSR &A0) {
     const int n = A.nrows;
     AmgLevel &Lv = L[(size_t)l];
     const bool on_device = device_min_rows >= 0 && n >= device_min_rows;
+    // aggressive coarsening (level < agg_num_levels) and the Ruge-Stueben family are host algorithms: on a level
+    // the device builds, the strength graph still comes from the device and the Galerkin product stays there
+    const bool aggressive = l < p.agg_num_levels;
+    const bool host_coarsen = aggressive || p.coarsen_type != 8;
     Strength S;
     std::vector<int> cf;
     sk::DCsr dS;
     DVec<int> dcf;
     double tp0 = wall_time();
+    auto strength_to_host = [&](hipStream_t s) {
+      S.ia.resize((size_t)n + 1);
+      S.ja.resize((size_t)dS.nnz);
+      MI_HIP(hipMemcpyAsync(S.ia.data(), dS.ia.p, ((size_t)n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+      if (dS.nnz) MI_HIP(hipMemcpyAsync(S.ja.data(), dS.ja.p, (size_t)dS.nnz * sizeof(int), hipMemcpyDeviceToHost, s));
+      MI_HIP(hipStreamSynchronize(s));
+    };
     if (on_device) {
       // strength graph and PMIS splitting on the device (integer/compare work, identical results)
       hipStream_t s = ctx().stream;
@@ -783,16 +1190,28 @@ void BoomerAMG::build_natural(ParCSR &A0) {
       sk::strength(Lv.sA, p.strong_threshold, p.max_row_sum, dS, s);
       t_phase[0] += wall_time() - tp0;
       tp0 = wall_time();
-      sk::pmis(dS, 2747, dcf, s);
-      cf.resize((size_t)n);
-      MI_HIP(hipMemcpyAsync(cf.data(), dcf.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
-      MI_HIP(hipStreamSynchronize(s));
+      if (host_coarsen) {
+        strength_to_host(s);
+        if (aggressive)
+          coarsen_aggressive(p.coarsen_type, n, S, cf);
+        else
+          coarsen_by_type(p.coarsen_type, n, S, cf);
+        dcf.upload(cf);
+      } else {
+        sk::pmis(dS, 2747, dcf, s);
+        cf.resize((size_t)n);
+        MI_HIP(hipMemcpyAsync(cf.data(), dcf.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+        MI_HIP(hipStreamSynchronize(s));
+      }
       t_phase[1] += wall_time() - tp0;
     } else {
       strength(A, p.strong_threshold, p.max_row_sum, S);
       t_phase[0] += wall_time() - tp0;
       tp0 = wall_time();
-      pmis(n, S, comm.rank, cf);
+      if (aggressive)
+        coarsen_aggressive(p.coarsen_type, n, S, cf);
+      else
+        coarsen_by_type(p.coarsen_type, n, S, cf);
       t_phase[1] += wall_time() - tp0;
     }
     long long nc_loc = 0;
@@ -806,7 +1225,7 @@ void BoomerAMG::build_natural(ParCSR &A0) {
     bool p_on_device = false;
     if (on_device) {
       hipStream_t s = ctx().stream;
-      if (p.interp_type == 6 || p.interp_type == 0)
+      if (!aggressive && (p.interp_type == 6 || p.interp_type == 0))
         p_on_device = sk::interp(Lv.sA, dS, dcf, p.interp_type, p.trunc_factor, p.pmax_elmts, Lv.sP, nc, s);
       if (p_on_device) {
         // stays on the device; the dimensions are all the host needs
@@ -816,22 +1235,23 @@ void BoomerAMG::build_natural(ParCSR &A0) {
         MI_HIP(hipMemcpyAsync(cf.data(), dcf.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
         MI_HIP(hipStreamSynchronize(s));
       } else {
-        // direct interpolation, or a row whose interpolatory set outgrows the kernels' tables: host routine
+        // multipass or direct interpolation, or a row whose interpolatory set outgrows the kernels' tables:
+        // host routine
         if (A.host_diag_stale) {
           Lv.sA.download(A.diag, s);
           A.host_diag_stale = false;
         }
-        S.ia.resize((size_t)n + 1);
-        S.ja.resize((size_t)dS.nnz);
-        MI_HIP(hipMemcpyAsync(S.ia.data(), dS.ia.p, ((size_t)n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-        if (dS.nnz)
-          MI_HIP(hipMemcpyAsync(S.ja.data(), dS.ja.p, (size_t)dS.nnz * sizeof(int), hipMemcpyDeviceToHost, s));
-        MI_HIP(hipStreamSynchronize(s));
+        if (!host_coarsen) strength_to_host(s);
       }
       dS.release();
       dcf.release();
     }
-    if (!p_on_device) build_interp(A, S, cf, p.interp_type, p.trunc_factor, p.pmax_elmts, Lv.P, nc);
+    if (!p_on_device) {
+      if (aggressive)
+        build_multipass(A, S, cf, p.agg_trunc_factor, p.agg_pmax_elmts, Lv.P, nc);
+      else
+        build_interp(A, S, cf, p.interp_type, p.trunc_factor, p.pmax_elmts, Lv.P, nc);
+    }
     Lv.cf = cf;
     Lv.has_cf = true;
     if (!on_device) host_transpose(Lv.P, Lv.R);

@@ -347,41 +347,53 @@ void BoomerAMG::apply_global(const double *f, double *e, bool zero_guess) {
 
 void BoomerAMG::solve(ParCSR &A, ParVector &b, ParVector &x) {
   if (!is_setup) setup(A);
-  MI_REQUIRE(x.ncomp == 1 && b.ncomp == 1, "BoomerAMGSolve: multi-component vectors are not supported");
+  MI_REQUIRE(x.ncomp == b.ncomp, "BoomerAMGSolve: b and x differ in their number of components");
   MI_REQUIRE(x.n == L[0].n && b.n == L[0].n, "BoomerAMGSolve: vector size does not match the matrix");
   Comm &comm = my_comm();
   hipStream_t s = ctx().stream;
   AmgLevel &L0 = L[0];
   const bool permuted = !L0.perm.empty();
+  const int n = L0.n, nc = b.ncomp;  // a multivector is cycled component by component
   int it = 0;
   double rel = 0.0, bn = 0.0;
-  if (p.tol > 0.0) bn = std::sqrt(par_dot_host(comm, b.data(), b.data(), b.n, s));
-  // caller order -> level-0 (C-first) order
-  if (permuted)
-    k::gather(b.data(), L0.d_perm.p, L0.f.p, L0.n, s);
-  else
-    k::copy(b.data(), L0.f.p, L0.n, s);
+  if (p.tol > 0.0) bn = std::sqrt(par_dot_host(comm, b.all(), b.all(), b.len(), s));
   // a Krylov solver that has just zeroed x says so (krylov.cpp): the first cycle
   // then needs neither x nor its halo
   const bool zero_first = zero_guess_hint();
   zero_guess_hint() = false;
   while (it < p.max_iter) {
     const bool zero = zero_first && it == 0;
-    if (zero)
-      k::fill(L0.u.p, L0.n, 0.0, s);
-    else if (permuted)
-      k::gather(x.data(), L0.d_perm.p, L0.u.p, L0.n, s);
-    else
-      k::copy(x.data(), L0.u.p, L0.n, s);
-    cycle(0, zero);
-    if (permuted)
-      k::scatter_set(x.data(), L0.d_perm.p, L0.u.p, L0.n, s);
-    else
-      k::copy(L0.u.p, x.data(), L0.n, s);
+    for (int c = 0; c < nc; c++) {
+      const double *bc = b.all() + (size_t)c * (size_t)n;
+      double *xc = x.all() + (size_t)c * (size_t)n;
+      // caller order -> level-0 (C-first) order
+      if (it == 0 || nc > 1) {
+        if (permuted)
+          k::gather(bc, L0.d_perm.p, L0.f.p, n, s);
+        else
+          k::copy(bc, L0.f.p, n, s);
+      }
+      if (zero)
+        k::fill(L0.u.p, n, 0.0, s);
+      else if (permuted)
+        k::gather(xc, L0.d_perm.p, L0.u.p, n, s);
+      else
+        k::copy(xc, L0.u.p, n, s);
+      cycle(0, zero);
+      if (permuted)
+        k::scatter_set(xc, L0.d_perm.p, L0.u.p, n, s);
+      else
+        k::copy(L0.u.p, xc, n, s);
+    }
     it++;
     if (p.tol > 0.0) {
-      A.matvec(comm, -1.0, x.data(), 1.0, b.data(), L0.tmp.p, s);
-      const double rn = std::sqrt(par_dot_host(comm, L0.tmp.p, L0.tmp.p, b.n, s));
+      double rr = 0.0;
+      for (int c = 0; c < nc; c++) {
+        const size_t o = (size_t)c * (size_t)n;
+        A.matvec(comm, -1.0, x.all() + o, 1.0, b.all() + o, L0.tmp.p, s);
+        rr += par_dot_host(comm, L0.tmp.p, L0.tmp.p, n, s);
+      }
+      const double rn = std::sqrt(rr);
       rel = (bn > 0.0) ? rn / bn : rn;
       if (p.print_level > 1 && comm.rank == 0) printf("    BoomerAMG cycle %3d   ||r||/||b|| = %e\n", it, rel);
       if (rel <= p.tol) break;

@@ -100,28 +100,39 @@ void IluSolver::apply(const double *rhs, double *out) {
 int IluSolver::solve(ParCSR &A, ParVector &b, ParVector &x) {
   if (!is_setup) setup(A);
   MI_REQUIRE(b.n == n && x.n == n, "HYPRE_ILUSolve: vector size does not match the matrix");
+  MI_REQUIRE(b.ncomp == x.ncomp, "HYPRE_ILUSolve: b and x differ in their number of components");
   Comm &comm = current_comm();
   hipStream_t s = ctx().stream;
+  const int nc = b.ncomp;  // a multivector is treated component by component
   // preconditioner use (one application, no tolerance) on a zero guess: x = M^-1 b
   if (max_iter == 1 && tol <= 0.0 && zero_guess_hint()) {
     zero_guess_hint() = false;
-    apply(b.data(), x.data());
+    for (int c = 0; c < nc; c++) apply(b.all() + (size_t)c * (size_t)n, x.all() + (size_t)c * (size_t)n);
     num_iterations = 1;
     return 0;
   }
   zero_guess_hint() = false;
-  const double bn = (tol > 0.0) ? std::sqrt(par_dot_host(comm, b.data(), b.data(), n, s)) : 0.0;
+  const double bn = (tol > 0.0) ? std::sqrt(par_dot_host(comm, b.all(), b.all(), b.len(), s)) : 0.0;
   int it = 0;
   double rel = 0.0;
   while (it < max_iter) {
-    A.matvec(comm, -1.0, x.data(), 1.0, b.data(), r.p, s);
     if (tol > 0.0) {
-      const double rn = std::sqrt(par_dot_host(comm, r.p, r.p, n, s));
+      double rr = 0.0;
+      for (int c = 0; c < nc; c++) {
+        const size_t o = (size_t)c * (size_t)n;
+        A.matvec(comm, -1.0, x.all() + o, 1.0, b.all() + o, r.p, s);
+        rr += par_dot_host(comm, r.p, r.p, n, s);
+      }
+      const double rn = std::sqrt(rr);
       rel = (bn > 0.0) ? rn / bn : rn;
       if (rel <= tol) break;
     }
-    apply(r.p, z.p);
-    k::axpy(1.0, z.p, x.data(), n, s);
+    for (int c = 0; c < nc; c++) {
+      const size_t o = (size_t)c * (size_t)n;
+      A.matvec(comm, -1.0, x.all() + o, 1.0, b.all() + o, r.p, s);
+      apply(r.p, z.p);
+      k::axpy(1.0, z.p, x.all() + o, n, s);
+    }
     it++;
   }
   num_iterations = it;

@@ -17,12 +17,24 @@ namespace mi {
 void KrylovSolver::apply_precond(ParCSR &A, ParVector &rhs, ParVector &out) {
   hipStream_t s = ctx().stream;
   if (precond_solve) {
-    k::fill(out.data(), out.n, 0.0, s);
+    k::fill(out.all(), out.len(), 0.0, s);
     zero_guess_hint() = true;
     precond_solve(precond_data, &A, &rhs, &out);
     zero_guess_hint() = false;
   } else {
-    k::copy(rhs.data(), out.data(), out.n, s);
+    k::copy(rhs.all(), out.all(), out.len(), s);
+  }
+}
+
+// y_c = alpha A x_c + beta b_c for every component c of a multivector (component-major storage, nloc rows each).
+// HYPRE's ParCSRMatrixMatvec does the same for hypre_ParVectorNumVectors > 1.
+void KrylovSolver::matvec_all(ParCSR &A, double alpha, const double *x, double beta, const double *b, double *y, int nloc,
+                              int ncomp, int prof) {
+  Comm &comm = current_comm();
+  hipStream_t s = ctx().stream;
+  for (int c = 0; c < ncomp; c++) {
+    const size_t o = (size_t)c * (size_t)nloc;
+    A.matvec(comm, alpha, x + o, beta, b ? b + o : nullptr, y + o, s, prof);
   }
 }
 
@@ -42,24 +54,31 @@ BoomerAMG *KrylovSolver::amg_in_level_order(ParCSR &A, int n) const {
   if (!amg.is_setup || amg.p.max_iter != 1 || amg.p.tol != 0.0 || amg.L.empty()) return nullptr;
   AmgLevel &L0 = amg.L[0];
   if (L0.perm.empty() || L0.A == &A || L0.n != n || !L0.A->on_device) return nullptr;
+  // the level-0 operator is a renumbered copy of the matrix BoomerAMGSetup saw: only when the Krylov solver is
+  // handed that very matrix may its matvec run on the copy (HYPRE multiplies by the A passed to Solve, which may
+  // legally differ from the operator the preconditioner was built on)
+  if (amg.source_matrix != &A || amg.source_stamp != A.assembly_stamp) return nullptr;
   return &amg;
 }
 
 BoomerAMG *KrylovSolver::enter_level_order(ParCSR &A_in, ParVector &b_in, ParVector &x_in, ParCSR *&A, ParVector *&b,
                                            ParVector *&x) {
-  const int n = b_in.n;
+  const int n = b_in.n, nc = b_in.ncomp;
   BoomerAMG *amg = amg_in_level_order(A_in, n);
   A = &A_in;
   b = &b_in;
   x = &x_in;
   if (!amg) return nullptr;
   hipStream_t s = ctx().stream;
-  if (bp.n != n) {
-    bp.init(b_in.start, b_in.end, 1);
-    xp.init(b_in.start, b_in.end, 1);
+  if (bp.n != n || bp.ncomp != nc) {
+    bp.init(b_in.start, b_in.end, nc);
+    xp.init(b_in.start, b_in.end, nc);
   }
-  k::gather(b_in.data(), amg->L[0].d_perm.p, bp.data(), n, s);
-  k::gather(x_in.data(), amg->L[0].d_perm.p, xp.data(), n, s);
+  for (int c = 0; c < nc; c++) {
+    const size_t o = (size_t)c * (size_t)n;
+    k::gather(b_in.all() + o, amg->L[0].d_perm.p, bp.all() + o, n, s);
+    k::gather(x_in.all() + o, amg->L[0].d_perm.p, xp.all() + o, n, s);
+  }
   A = amg->L[0].A;
   b = &bp;
   x = &xp;
@@ -67,39 +86,48 @@ BoomerAMG *KrylovSolver::enter_level_order(ParCSR &A_in, ParVector &b_in, ParVec
 }
 
 void KrylovSolver::leave_level_order(BoomerAMG *amg, ParVector &x_in) {
-  if (amg) k::scatter_set(x_in.data(), amg->L[0].d_perm.p, xp.data(), x_in.n, ctx().stream);
+  if (!amg) return;
+  for (int c = 0; c < x_in.ncomp; c++) {
+    const size_t o = (size_t)c * (size_t)x_in.n;
+    k::scatter_set(x_in.all() + o, amg->L[0].d_perm.p, xp.all() + o, x_in.n, ctx().stream);
+  }
 }
 
 const double *KrylovSolver::precond_in_order(BoomerAMG *amg, ParCSR &A, ParVector &rhs, ParVector &out, bool need_copy) {
   if (!amg) {
     apply_precond(A, rhs, out);
-    return out.data();
+    return out.all();
   }
   hipStream_t s = ctx().stream;
   AmgLevel &L0 = amg->L[0];
-  const int n = L0.n;
+  const int n = L0.n, nc = rhs.ncomp;
   double *own_f = L0.f.p;
-  L0.f.p = rhs.data();  // read-only inside the cycle
-  k::fill(L0.u.p, n, 0.0, s);
-  try {
-    amg->cycle(0, true);
-  } catch (...) {
+  for (int c = 0; c < nc; c++) {  // one cycle per component of a multivector
+    const size_t o = (size_t)c * (size_t)n;
+    L0.f.p = rhs.all() + o;  // read-only inside the cycle
+    k::fill(L0.u.p, n, 0.0, s);
+    try {
+      amg->cycle(0, true);
+    } catch (...) {
+      L0.f.p = own_f;
+      throw;
+    }
     L0.f.p = own_f;
-    throw;
+    if (nc == 1 && !need_copy) return L0.u.p;
+    k::copy(L0.u.p, out.all() + o, n, s);
   }
-  L0.f.p = own_f;
-  if (!need_copy) return L0.u.p;
-  k::copy(L0.u.p, out.data(), n, s);
-  return out.data();
+  return out.all();
 }
 
 void GmresSolver::setup(ParCSR &A, ParVector &b, ParVector &x) {
   ensure_init();
-  MI_REQUIRE(b.ncomp == 1 && x.ncomp == 1, "GMRES: multi-component vectors are not supported");
+  MI_REQUIRE(b.ncomp == x.ncomp, "GMRES: b and x differ in their number of components");
   // Krylov basis vectors are created on demand in solve(): GMRES(50) rarely
   // fills its basis behind an AMG preconditioner
-  r.init(b.start, b.end, 1);
-  w.init(b.start, b.end, 1);
+  r.init(b.start, b.end, b.ncomp);
+  w.init(b.start, b.end, b.ncomp);
+  p.clear();
+  z.clear();
   if (precond_setup) precond_setup(precond_data, &A, &b, &x);
 }
 
@@ -109,16 +137,18 @@ int GmresSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
   Comm &comm = current_comm();
   hipStream_t s = c.stream;
   const double t_start = wall_time();
-  const int n = b_in.n;
+  const int nloc = b_in.n, nc = b_in.ncomp;
+  const int n = nloc * nc;  // length of the (multi)vector: every BLAS-1 call below runs over all components
+  MI_REQUIRE(x_in.ncomp == nc && x_in.n == nloc, "GMRES: b and x differ in size");
   const int kd = k_dim < 1 ? 1 : k_dim;
   MI_REQUIRE(kd + 2 <= (ortho > 1 ? 120 : 250), "GMRES: k_dim too large for the device scalar slots");
   MI_REQUIRE(ortho >= 0 && ortho <= 2, "GMRES: orthogonalisation must be 0 (MGS), 1 or 2 (classical passes)");
-  if (r.n != n) setup(A_in, b_in, x_in);
+  if (r.n != nloc || r.ncomp != nc) setup(A_in, b_in, x_in);
   const double epsmac = 1.e-16;
   auto basis = [&](int i) -> ParVector & {
     while ((int)p.size() <= i) {
       std::unique_ptr<ParVector> v(new ParVector());
-      v->init(b_in.start, b_in.end, 1);
+      v->init(b_in.start, b_in.end, nc);
       p.push_back(std::move(v));
     }
     return *p[(size_t)i];
@@ -126,7 +156,7 @@ int GmresSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
   auto zvec = [&](int i) -> ParVector & {
     while ((int)z.size() <= i) {
       std::unique_ptr<ParVector> v(new ParVector());
-      v->init(b_in.start, b_in.end, 1);
+      v->init(b_in.start, b_in.end, nc);
       z.push_back(std::move(v));
     }
     return *z[(size_t)i];
@@ -146,9 +176,12 @@ int GmresSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
     return precond_in_order(amg, A, rhs, out, need_copy);
   };
 
+  auto mv = [&](double alpha, const double *xv, double beta, const double *bv, double *yv) {
+    matvec_all(A, alpha, xv, beta, bv, yv, nloc, nc, k::PROF_SPMV_L0);
+  };
   ParVector &p0 = basis(0);
-  A.matvec(comm, -1.0, x.data(), 1.0, b.data(), p0.data(), s, k::PROF_SPMV_L0);
-  const double b_norm = std::sqrt(par_dot_host(comm, b.data(), b.data(), n, s));
+  mv(-1.0, x.all(), 1.0, b.all(), p0.data());
+  const double b_norm = std::sqrt(par_dot_host(comm, b.all(), b.all(), n, s));
   double r_norm = std::sqrt(par_dot_host(comm, p0.data(), p0.data(), n, s));
   const double r_norm_0 = r_norm;
   const double den = (b_norm > 0.0) ? b_norm : r_norm;
@@ -171,7 +204,7 @@ int GmresSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
       break;
     }
     if (r_norm <= eps && iter >= min_iter) {
-      A.matvec(comm, -1.0, x.data(), 1.0, b.data(), r.data(), s, k::PROF_SPMV_L0);
+      mv(-1.0, x.all(), 1.0, b.all(), r.data());
       r_norm = std::sqrt(par_dot_host(comm, r.data(), r.data(), n, s));
       if (r_norm <= eps) {
         converged = true;
@@ -188,7 +221,7 @@ int GmresSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
       ParVector &pim1 = basis(i - 1);
       ParVector &dir = flexible ? zvec(i - 1) : r;  // M^-1 p_{i-1}
       const double *mp = precond(pim1, dir, flexible);
-      A.matvec(comm, 1.0, mp, 0.0, nullptr, pi.data(), s, k::PROF_SPMV_L0);
+      mv(1.0, mp, 0.0, nullptr, pi.data());
       if (ortho == 0) {
         // modified Gram-Schmidt with the axpy of step j-1 fused into the dot of step j
         // (and the last axpy into the norm): h_j = <p_j, w>, w -= h_j p_j, one pass each
@@ -262,17 +295,17 @@ int GmresSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
     }
     if (flexible) {
       // x += sum_j y_j z_j
-      for (int j = i - 1; j >= 0; j--) k::axpy(y[(size_t)j], zvec(j).data(), x.data(), n, s);
+      for (int j = i - 1; j >= 0; j--) k::axpy(y[(size_t)j], zvec(j).data(), x.all(), n, s);
     } else {
       // w = sum_j y_j p_j ; x += M^-1 w
       k::copy(basis(i - 1).data(), w.data(), n, s);
       k::scale(y[(size_t)i - 1], w.data(), n, s);
       for (int j = i - 2; j >= 0; j--) k::axpy(y[(size_t)j], basis(j).data(), w.data(), n, s);
       const double *mw = precond(w, r, false);
-      k::axpy(1.0, mw, x.data(), n, s);
+      k::axpy(1.0, mw, x.all(), n, s);
     }
     if (r_norm <= eps && iter >= min_iter) {
-      A.matvec(comm, -1.0, x.data(), 1.0, b.data(), r.data(), s, k::PROF_SPMV_L0);
+      mv(-1.0, x.all(), 1.0, b.all(), r.data());
       r_norm = std::sqrt(par_dot_host(comm, r.data(), r.data(), n, s));
       if (r_norm <= eps) {
         converged = true;
@@ -285,7 +318,7 @@ int GmresSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
     if (flexible) {
       // flexgmres.c restarts from the explicitly recomputed residual
       if (i) {
-        A.matvec(comm, -1.0, x.data(), 1.0, b.data(), basis(0).data(), s, k::PROF_SPMV_L0);
+        mv(-1.0, x.all(), 1.0, b.all(), basis(0).data());
         r_norm = std::sqrt(par_dot_host(comm, basis(0).data(), basis(0).data(), n, s));
       }
       continue;
@@ -316,8 +349,8 @@ int GmresSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
 
 void PcgSolver::setup(ParCSR &A, ParVector &b, ParVector &x) {
   ensure_init();
-  MI_REQUIRE(b.ncomp == 1 && x.ncomp == 1, "PCG: multi-component vectors are not supported");
-  for (ParVector *v : {&r, &pv, &sv}) v->init(b.start, b.end, 1);
+  MI_REQUIRE(b.ncomp == x.ncomp, "PCG: b and x differ in their number of components");
+  for (ParVector *v : {&r, &pv, &sv}) v->init(b.start, b.end, b.ncomp);
   if (precond_setup) precond_setup(precond_data, &A, &b, &x);
 }
 
@@ -328,27 +361,32 @@ int PcgSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
   Comm &comm = current_comm();
   hipStream_t s = ctx().stream;
   const double t_start = wall_time();
-  const int n = b_in.n;
-  if (r.n != n) setup(A_in, b_in, x_in);
+  const int nloc = b_in.n, nc = b_in.ncomp;
+  const int n = nloc * nc;
+  MI_REQUIRE(x_in.ncomp == nc && x_in.n == nloc, "PCG: b and x differ in size");
+  if (r.n != nloc || r.ncomp != nc) setup(A_in, b_in, x_in);
   ParCSR *Ap;
   ParVector *bq, *xq;
   BoomerAMG *amg = enter_level_order(A_in, b_in, x_in, Ap, bq, xq);
   ParCSR &A = *Ap;
   ParVector &b = *bq;
   ParVector &x = *xq;
+  auto mv = [&](double alpha, const double *xv, double beta, const double *bv, double *yv) {
+    matvec_all(A, alpha, xv, beta, bv, yv, nloc, nc, k::PROF_SPMV_L0);
+  };
   double bi_prod;
   if (two_norm) {
-    bi_prod = par_dot_host(comm, b.data(), b.data(), n, s);
+    bi_prod = par_dot_host(comm, b.all(), b.all(), n, s);
   } else {
     precond_in_order(amg, A, b, pv, true);
-    bi_prod = par_dot_host(comm, pv.data(), b.data(), n, s);
+    bi_prod = par_dot_host(comm, pv.data(), b.all(), n, s);
   }
   double eps = tol * tol;
   norms.clear();
   converged = false;
   num_iterations = 0;
   if (!(bi_prod > 0.0)) {  // zero right-hand side: x = 0 (pcg.c)
-    k::fill(x.data(), n, 0.0, s);
+    k::fill(x.all(), n, 0.0, s);
     leave_level_order(amg, x_in);
     MI_HIP(hipStreamSynchronize(s));
     rel_residual_norm = 0.0;
@@ -357,7 +395,7 @@ int PcgSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
     return 0;
   }
   if (atol > 0.0) eps = std::max(eps, atol * atol / bi_prod);
-  A.matvec(comm, -1.0, x.data(), 1.0, b.data(), r.data(), s, k::PROF_SPMV_L0);
+  mv(-1.0, x.all(), 1.0, b.all(), r.data());
   precond_in_order(amg, A, r, pv, true);
   double gamma = par_dot_host(comm, r.data(), pv.data(), n, s);
   double i_prod = two_norm ? par_dot_host(comm, r.data(), r.data(), n, s) : gamma;
@@ -366,12 +404,12 @@ int PcgSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
   const bool chatty = print_level > 1 && comm.rank == 0;
   while (i + 1 <= max_iter) {
     i++;
-    A.matvec(comm, 1.0, pv.data(), 0.0, nullptr, sv.data(), s, k::PROF_SPMV_L0);
+    mv(1.0, pv.data(), 0.0, nullptr, sv.data());
     const double sdotp = par_dot_host(comm, sv.data(), pv.data(), n, s);
     if (sdotp == 0.0) break;
     const double alpha = gamma / sdotp;
     const double gamma_old = gamma;
-    k::axpy(alpha, pv.data(), x.data(), n, s);
+    k::axpy(alpha, pv.data(), x.all(), n, s);
     k::axpy(-alpha, sv.data(), r.data(), n, s);
     precond_in_order(amg, A, r, sv, true);
     gamma = par_dot_host(comm, r.data(), sv.data(), n, s);
@@ -396,8 +434,8 @@ int PcgSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
 
 void BicgstabSolver::setup(ParCSR &A, ParVector &b, ParVector &x) {
   ensure_init();
-  MI_REQUIRE(b.ncomp == 1 && x.ncomp == 1, "BiCGSTAB: multi-component vectors are not supported");
-  for (ParVector *v : {&r0, &r, &pv, &v, &q, &sv, &t}) v->init(b.start, b.end, 1);
+  MI_REQUIRE(b.ncomp == x.ncomp, "BiCGSTAB: b and x differ in their number of components");
+  for (ParVector *v : {&r0, &r, &pv, &v, &q, &sv, &t}) v->init(b.start, b.end, b.ncomp);
   if (precond_setup) precond_setup(precond_data, &A, &b, &x);
 }
 
@@ -407,19 +445,24 @@ int BicgstabSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
   Comm &comm = current_comm();
   hipStream_t s = c.stream;
   const double t_start = wall_time();
-  const int n = b_in.n;
-  if (r.n != n) setup(A_in, b_in, x_in);
+  const int nloc = b_in.n, nc = b_in.ncomp;
+  const int n = nloc * nc;
+  MI_REQUIRE(x_in.ncomp == nc && x_in.n == nloc, "BiCGSTAB: b and x differ in size");
+  if (r.n != nloc || r.ncomp != nc) setup(A_in, b_in, x_in);
   ParCSR *Ap;
   ParVector *bq, *xq;
   BoomerAMG *amg = enter_level_order(A_in, b_in, x_in, Ap, bq, xq);
   ParCSR &A = *Ap;
   ParVector &b = *bq;
   ParVector &x = *xq;
+  auto mv = [&](double alpha, const double *xv, double beta, const double *bv, double *yv) {
+    matvec_all(A, alpha, xv, beta, bv, yv, nloc, nc, k::PROF_SPMV_L0);
+  };
   const double epsmac = 1.e-128;
-  A.matvec(comm, -1.0, x.data(), 1.0, b.data(), r0.data(), s, k::PROF_SPMV_L0);
+  mv(-1.0, x.all(), 1.0, b.all(), r0.data());
   k::copy(r0.data(), r.data(), n, s);
   k::copy(r0.data(), pv.data(), n, s);
-  const double b_norm = std::sqrt(par_dot_host(comm, b.data(), b.data(), n, s));
+  const double b_norm = std::sqrt(par_dot_host(comm, b.all(), b.all(), n, s));
   double rho = par_dot_host(comm, r0.data(), r0.data(), n, s);
   double r_norm = std::sqrt(rho);
   const double den = (b_norm > 0.0) ? b_norm : r_norm;
@@ -430,7 +473,7 @@ int BicgstabSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
   norms.push_back(r_norm);
   const bool chatty = print_level > 1 && comm.rank == 0;
   auto true_res_ok = [&]() {
-    A.matvec(comm, -1.0, x.data(), 1.0, b.data(), t.data(), s, k::PROF_SPMV_L0);
+    mv(-1.0, x.all(), 1.0, b.all(), t.data());
     const double tn = std::sqrt(par_dot_host(comm, t.data(), t.data(), n, s));
     if (tn <= eps) {
       r_norm = tn;
@@ -441,11 +484,11 @@ int BicgstabSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
   while (!converged && iter < max_iter) {
     iter++;
     precond_in_order(amg, A, pv, v, true);
-    A.matvec(comm, 1.0, v.data(), 0.0, nullptr, q.data(), s, k::PROF_SPMV_L0);
+    mv(1.0, v.data(), 0.0, nullptr, q.data());
     const double temp = par_dot_host(comm, r0.data(), q.data(), n, s);
     if (std::fabs(temp) < epsmac) break;
     const double alpha = rho / temp;
-    k::axpy(alpha, v.data(), x.data(), n, s);
+    k::axpy(alpha, v.data(), x.all(), n, s);
     k::axpy(-alpha, q.data(), r.data(), n, s);
     r_norm = std::sqrt(par_dot_host(comm, r.data(), r.data(), n, s));
     if (r_norm <= eps && iter >= min_iter && true_res_ok()) {
@@ -454,10 +497,10 @@ int BicgstabSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
       break;
     }
     precond_in_order(amg, A, r, v, true);
-    A.matvec(comm, 1.0, v.data(), 0.0, nullptr, sv.data(), s, k::PROF_SPMV_L0);
+    mv(1.0, v.data(), 0.0, nullptr, sv.data());
     const double ss = par_dot_host(comm, sv.data(), sv.data(), n, s);
     const double gamma = (ss != 0.0) ? par_dot_host(comm, r.data(), sv.data(), n, s) / ss : 0.0;
-    k::axpy(gamma, v.data(), x.data(), n, s);
+    k::axpy(gamma, v.data(), x.all(), n, s);
     k::axpy(-gamma, sv.data(), r.data(), n, s);
     r_norm = std::sqrt(par_dot_host(comm, r.data(), r.data(), n, s));
     norms.push_back(r_norm);

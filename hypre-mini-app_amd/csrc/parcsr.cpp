@@ -248,6 +248,8 @@ void assemble_parcsr(Comm &comm, gidx ilower, gidx iupper, gidx jlower, gidx jup
   comm.allreduce_host(&gend, 1, CommDType::I64, CommOp::MAX);
   out.row_starts = starts;
   out.row_starts.push_back(gend);
+  static unsigned long long stamp = 0;
+  out.assembly_stamp = ++stamp;
 }
 
 // ------------------------------------------------------------------ halo plan + device mirror

@@ -14,6 +14,11 @@ struct ParVector {
   DVec<double> d;  // ncomp * n, component-major
   double *data() { return d.p + (size_t)cur * n; }
   const double *data() const { return d.p + (size_t)cur * n; }
+  // multivector view (HYPRE_IJVectorSetNumComponents > 1): all components, component-major.  Solvers work on the
+  // whole multivector, as HYPRE's do: the block system diag(A, .., A) with inner products over every component
+  double *all() { return d.p; }
+  const double *all() const { return d.p; }
+  int len() const { return n * ncomp; }
   void init(gidx s, gidx e, int nc);
 };
 
@@ -40,6 +45,9 @@ struct ParCSR {
   DevOffd d_offd;
   DVec<double> d_offc;  // per-row halo contribution scratch (zero outside halo rows)
   bool on_device = false;
+  // unique per assembly (0 = never assembled): tells a re-assembled or re-allocated matrix from the one a
+  // preconditioner was set up on
+  unsigned long long assembly_stamp = 0;
   // A level built by the device setup keeps its diag block on the device only: the host arrays of `diag`
   // are filled on demand (BoomerAMG::ensure_host); nrows / ncols of `diag` are always valid.
   bool host_diag_stale = false;

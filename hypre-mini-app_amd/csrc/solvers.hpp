@@ -30,6 +30,9 @@ struct KrylovSolver : SolverBase {
   double solve_seconds = 0.0;
   explicit KrylovSolver(Kind k) : SolverBase(k) {}
   void apply_precond(ParCSR &A, ParVector &rhs, ParVector &out);
+  // matvec on every component of a multivector (krylov.cpp)
+  void matvec_all(ParCSR &A, double alpha, const double *x, double beta, const double *b, double *y, int nloc, int ncomp,
+                  int prof);
   // the BoomerAMG behind precond_solve when the Krylov loop may run in its level-0 ordering (krylov.cpp)
   BoomerAMG *amg_in_level_order(ParCSR &A, int n) const;
   // the loop's view of the system: the caller's objects, or (fast path) the level-0 operator of the AMG with

@@ -157,18 +157,39 @@ class IJMatrix:
 
 
 class IJVector:
-    def __init__(self, jlower, jupper, values=None):
+    def __init__(self, jlower, jupper, values=None, ncomp=1):
+        """ncomp > 1: a multivector as init_system builds it for non-segregated solves
+        (/root/reference/src/HypreSystem.cpp:567-571); values then has shape (ncomp, n)."""
         self.h = vp()
         self.jlower, self.jupper = jlower, jupper
         self.n = jupper - jlower + 1
+        self.ncomp = ncomp
         call("HYPRE_IJVectorCreate", 0, c_big(jlower), c_big(jupper), C.byref(self.h))
         call("HYPRE_IJVectorSetObjectType", self.h, HYPRE_PARCSR)
+        if ncomp != 1:
+            call("HYPRE_IJVectorSetNumComponents", self.h, ncomp)
         call("HYPRE_IJVectorInitialize", self.h)
         self.par = vp()
         call("HYPRE_IJVectorGetObject", self.h, C.byref(self.par))
         if values is not None:
-            self.set(values)
+            if ncomp == 1:
+                self.set(values)
+            else:
+                for c in range(ncomp):
+                    self.set_component(c)
+                    self.set(values[c])
         call("HYPRE_IJVectorAssemble", self.h)
+
+    def set_component(self, c):
+        """HYPRE_IJVectorSetComponent, /root/reference/src/HypreSystem.cpp:967"""
+        call("HYPRE_IJVectorSetComponent", self.h, c)
+
+    def get_all(self):
+        out = np.empty((self.ncomp, self.n))
+        for c in range(self.ncomp):
+            self.set_component(c)
+            out[c] = self.get()
+        return out
 
     def set(self, values):
         values = dbl(values)
@@ -604,6 +625,17 @@ def halo_plan(A):
     call("HYPRE_MI_ParCSRGetHaloPlan", A.par, C.byref(ns), sp, ss, sm, C.byref(nr), rp, rs)
     return dict(send_peers=sp[: ns.value], send_starts=ss, send_map=sm[: int(ss[-1])], recv_peers=rp[: nr.value],
                 recv_starts=rs)
+
+
+def matrix_from_scipy(M, ilower=0, iupper=None):
+    """IJ matrix of rows [ilower, iupper] of a scipy sparse matrix (global column ids)."""
+    M = M.tocsr()
+    iupper = M.shape[0] - 1 if iupper is None else iupper
+    coo = M[ilower:iupper + 1].tocoo()
+    A = IJMatrix(ilower, iupper)
+    A.set_values_coo(coo.row.astype(np.int64) + ilower, coo.col.astype(np.int64), coo.data)
+    A.assemble()
+    return A
 
 
 def csr_device_op(op, A, B=None, perm=None, colpos=None):

@@ -267,6 +267,10 @@ void oamg_default_params(oamg_params *p) {
   p->max_iter = 1;
   p->tol = 0.0;
   p->redundant_rows = 0;
+  p->agg_num_levels = 0;
+  p->agg_interp_type = 4;
+  p->agg_pmax_elmts = 0;
+  p->agg_trunc_factor = 0.0;
 }
 
 static int *part_of_rows(int n, int nparts, const obig *ps) {
@@ -383,6 +387,281 @@ static void pmis(int n, const obig *Sia, const int *Sja, const int *part_of, int
   free(measure);
   free(graph);
   free(tmp);
+}
+
+
+/* Transposed strength pattern: row i of S^T lists, ascending, the points that strongly depend on i. */
+static void strength_transpose(int n, const obig *Sia, const int *Sja, obig **Tia_out, int **Tja_out) {
+  obig *Tia = (obig *)xcalloc((size_t)n + 1, sizeof(obig));
+  int *Tja = (int *)xmalloc(sizeof(int) * (size_t)Sia[n]);
+  for (obig k = 0; k < Sia[n]; k++) Tia[Sja[k] + 1]++;
+  for (int i = 0; i < n; i++) Tia[i + 1] += Tia[i];
+  obig *pos = (obig *)xmalloc(sizeof(obig) * ((size_t)n + 1));
+  memcpy(pos, Tia, sizeof(obig) * ((size_t)n + 1));
+  for (int i = 0; i < n; i++)
+    for (obig k = Sia[i]; k < Sia[i + 1]; k++) Tja[pos[Sja[k]]++] = i;
+  free(pos);
+  *Tia_out = Tia;
+  *Tja_out = Tja;
+}
+
+/* Bucket lists of the Ruge-Stueben first pass (hypre_enter_on_lists / hypre_remove_point, amg_linklist.c):
+ * one FIFO list per integer measure; the next C point is the HEAD of the list with the largest measure. */
+typedef struct rs_lists {
+  int *head, *tail, *prev, *next, top, nb;
+} rs_lists;
+static void rs_enter(rs_lists *q, int m, int i) {
+  q->prev[i] = q->tail[m];
+  q->next[i] = -1;
+  if (q->tail[m] >= 0)
+    q->next[q->tail[m]] = i;
+  else
+    q->head[m] = i;
+  q->tail[m] = i;
+  if (m > q->top) q->top = m;
+}
+static void rs_remove(rs_lists *q, int m, int i) {
+  if (q->prev[i] >= 0)
+    q->next[q->prev[i]] = q->next[i];
+  else
+    q->head[m] = q->next[i];
+  if (q->next[i] >= 0)
+    q->prev[q->next[i]] = q->prev[i];
+  else
+    q->tail[m] = q->prev[i];
+}
+
+/* Classical Ruge-Stueben coarsening (par_coarsen.c hypre_BoomerAMGCoarsenRuge) on the GLOBAL strength graph.
+ * First pass: measure_i = |S^T_i|; repeatedly the head of the highest list becomes C, every undecided point
+ * that depends on it becomes F and the points THOSE depend on gain one, the points the new C point depends on
+ * lose one (falling to zero makes them F).  Points that influence nobody are F from the start; rows without
+ * strong connections are special F points.
+ * Second pass (second_pass != 0; coarsen types 1, 3, 6): every strong F-F pair must share a C point -- for an
+ * F point i the first strong F neighbour j without a common C point tentatively becomes C, a second one makes
+ * i itself C and j F again.
+ * coarsen_type 10 (HMIS) = first pass, then PMIS on what is left undecided, 6 (Falgout) = both passes, then
+ * CLJP on what is left: coarsening here sees the whole graph (the hierarchy does not depend
+ * on the row partition), where the first pass decides every point and nothing is left -- as on one HYPRE rank. */
+static void ruge_stueben(int n, const obig *Sia, const int *Sja, int second_pass, int *cf) {
+  obig *Tia;
+  int *Tja;
+  strength_transpose(n, Sia, Sja, &Tia, &Tja);
+  int *measure = (int *)xmalloc(sizeof(int) * (size_t)n);
+  int maxm = 0;
+  for (int i = 0; i < n; i++) {
+    measure[i] = (int)(Tia[i + 1] - Tia[i]);
+    if (measure[i] > maxm) maxm = measure[i];
+  }
+  rs_lists q;
+  q.nb = 2 * maxm + 2; /* a measure grows by at most one per point that depends on its owner */
+  q.head = (int *)xmalloc(sizeof(int) * (size_t)q.nb);
+  q.tail = (int *)xmalloc(sizeof(int) * (size_t)q.nb);
+  q.prev = (int *)xmalloc(sizeof(int) * (size_t)n);
+  q.next = (int *)xmalloc(sizeof(int) * (size_t)n);
+  for (int m = 0; m < q.nb; m++) q.head[m] = q.tail[m] = -1;
+  q.top = 0;
+  int num_left = 0;
+  for (int i = 0; i < n; i++) {
+    if (Sia[i + 1] == Sia[i]) {
+      cf[i] = SF_PT;
+      measure[i] = 0;
+    } else {
+      cf[i] = 0;
+      num_left++;
+    }
+  }
+  for (int j = 0; j < n; j++) {
+    if (cf[j] != 0) continue;
+    if (measure[j] > 0) {
+      rs_enter(&q, measure[j], j);
+    } else {
+      cf[j] = F_PT;
+      num_left--;
+      for (obig k = Sia[j]; k < Sia[j + 1]; k++) {
+        const int nb = Sja[k];
+        if (cf[nb] != 0) continue; /* decided (or special) */
+        if (nb < j) {
+          if (measure[nb] > 0) rs_remove(&q, measure[nb], nb);
+          measure[nb]++;
+          rs_enter(&q, measure[nb], nb);
+        } else
+          measure[nb]++;
+      }
+    }
+  }
+  while (num_left > 0) {
+    while (q.top > 0 && q.head[q.top] < 0) q.top--;
+    const int c = q.head[q.top];
+    if (c < 0) break; /* cannot happen: every undecided point sits on a list */
+    cf[c] = C_PT;
+    rs_remove(&q, measure[c], c);
+    measure[c] = 0;
+    num_left--;
+    for (obig j = Tia[c]; j < Tia[c + 1]; j++) {
+      const int nb = Tja[j];
+      if (cf[nb] != 0) continue;
+      cf[nb] = F_PT;
+      rs_remove(&q, measure[nb], nb);
+      num_left--;
+      for (obig k = Sia[nb]; k < Sia[nb + 1]; k++) {
+        const int n2 = Sja[k];
+        if (cf[n2] != 0) continue;
+        rs_remove(&q, measure[n2], n2);
+        measure[n2]++;
+        rs_enter(&q, measure[n2], n2);
+      }
+    }
+    for (obig j = Sia[c]; j < Sia[c + 1]; j++) {
+      const int nb = Sja[j];
+      if (cf[nb] != 0) continue;
+      rs_remove(&q, measure[nb], nb);
+      measure[nb]--;
+      if (measure[nb] > 0)
+        rs_enter(&q, measure[nb], nb);
+      else {
+        cf[nb] = F_PT;
+        num_left--;
+        for (obig k = Sia[nb]; k < Sia[nb + 1]; k++) {
+          const int n2 = Sja[k];
+          if (cf[n2] != 0) continue;
+          rs_remove(&q, measure[n2], n2);
+          measure[n2]++;
+          rs_enter(&q, measure[n2], n2);
+        }
+      }
+    }
+  }
+  if (second_pass) {
+    int *mark = (int *)xmalloc(sizeof(int) * (size_t)n);
+    for (int i = 0; i < n; i++) mark[i] = -1;
+    for (int i = 0; i < n; i++) {
+      if (cf[i] != F_PT) continue;
+      int tentative = -1;
+      for (;;) {
+        for (obig k = Sia[i]; k < Sia[i + 1]; k++)
+          if (cf[Sja[k]] == C_PT) mark[Sja[k]] = i;
+        int lonely = -1; /* first strong F neighbour that shares no C point with i */
+        for (obig k = Sia[i]; k < Sia[i + 1] && lonely < 0; k++) {
+          const int j = Sja[k];
+          if (cf[j] != F_PT) continue;
+          int shared = 0;
+          for (obig kk = Sia[j]; kk < Sia[j + 1]; kk++)
+            if (mark[Sja[kk]] == i && cf[Sja[kk]] == C_PT) {
+              shared = 1;
+              break;
+            }
+          if (!shared) lonely = j;
+        }
+        if (lonely < 0) break;
+        if (tentative < 0) {
+          tentative = lonely;
+          cf[lonely] = C_PT;
+        } else {
+          cf[i] = C_PT;
+          cf[tentative] = F_PT;
+          break;
+        }
+      }
+    }
+    free(mark);
+  }
+  free(Tia);
+  free(Tja);
+  free(measure);
+  free(q.head);
+  free(q.tail);
+  free(q.prev);
+  free(q.next);
+}
+
+/* Coarsening by type (HYPRE_BoomerAMGSetCoarsenType, src/HypreSystem.cpp:125-126; the sample input asks for 6,
+ * etc/hypre_app.yaml:35).  Returns 0, or -1 for a type that is not restated (0 CLJP, 7, 9, 21, 22). */
+static void pmis(int n, const obig *Sia, const int *Sja, const int *part_of, int nparts, const obig *ps, int *cf);
+static int coarsen_by_type(int type, int n, const obig *Sia, const int *Sja, int *cf) {
+  if (type == 8) {
+    int *one_part = (int *)xcalloc((size_t)n, sizeof(int));
+    pmis(n, Sia, Sja, one_part, 1, NULL, cf);
+    free(one_part);
+    return 0;
+  }
+  if (type == 10 || type == 11) {
+    ruge_stueben(n, Sia, Sja, 0, cf);
+    return 0;
+  }
+  if (type == 6 || type == 1 || type == 3) {
+    ruge_stueben(n, Sia, Sja, 1, cf);
+    return 0;
+  }
+  return -1;
+}
+
+/* Second-generation strength graph of aggressive coarsening (par_strength.c hypre_BoomerAMGCreate2ndS,
+ * num_paths 1 = "A2"): a graph on the C points of the first coarsening -- C point i depends on C point j != i
+ * iff j is in S_i or in S_k for some k in S_i (a strong path of length at most two).  Rows and columns are
+ * coarse indices (running count of C points), columns ascending. */
+static void second_strength(int n, const obig *Sia, const int *Sja, const int *cf, obig **S2ia_out, int **S2ja_out,
+                            int *nc_out) {
+  int *f2c = (int *)xmalloc(sizeof(int) * (size_t)n);
+  int nc = 0;
+  for (int i = 0; i < n; i++) f2c[i] = (cf[i] == C_PT) ? nc++ : -1;
+  int *mark = (int *)xmalloc(sizeof(int) * (size_t)(nc ? nc : 1));
+  for (int q = 0; q < nc; q++) mark[q] = -1;
+  obig *ia = (obig *)xcalloc((size_t)nc + 1, sizeof(obig));
+  obig cap = (obig)nc * 16 + 16, w = 0;
+  int *ja = (int *)xmalloc(sizeof(int) * (size_t)cap);
+  for (int i = 0; i < n; i++) {
+    if (cf[i] != C_PT) continue;
+    const int ci = f2c[i];
+    const obig row0 = w;
+#define S2_ADD(j)                                                \
+  do {                                                           \
+    const int cj_ = f2c[j];                                      \
+    if (cj_ >= 0 && cj_ != ci && mark[cj_] != ci) {              \
+      mark[cj_] = ci;                                            \
+      if (w >= cap) {                                            \
+        cap *= 2;                                                \
+        ja = (int *)realloc(ja, sizeof(int) * (size_t)cap);      \
+      }                                                          \
+      ja[w++] = cj_;                                             \
+    }                                                            \
+  } while (0)
+    for (obig k = Sia[i]; k < Sia[i + 1]; k++) {
+      const int k1 = Sja[k];
+      S2_ADD(k1);
+      for (obig kk = Sia[k1]; kk < Sia[k1 + 1]; kk++) S2_ADD(Sja[kk]);
+    }
+#undef S2_ADD
+    qsort(ja + row0, (size_t)(w - row0), sizeof(int), cmp_int);
+    ia[ci + 1] = w;
+  }
+  free(mark);
+  free(f2c);
+  *S2ia_out = ia;
+  *S2ja_out = ja;
+  *nc_out = nc;
+}
+
+/* Aggressive coarsening of one level (par_amg_setup.c, level < agg_num_levels; src/HypreSystem.cpp:215-219):
+ * coarsen with S, coarsen the resulting C points again with the second-generation graph, and keep as C only
+ * what survives both (hypre_BoomerAMGCorrectCFMarker); a first-stage C point the second stage rejects takes the
+ * second stage's verdict (F, or special F when it has no second-generation connection). */
+static int coarsen_aggressive(int type, int n, const obig *Sia, const int *Sja, int *cf) {
+  if (coarsen_by_type(type, n, Sia, Sja, cf)) return -1;
+  obig *S2ia;
+  int *S2ja, nc;
+  second_strength(n, Sia, Sja, cf, &S2ia, &S2ja, &nc);
+  int *cf2 = (int *)xmalloc(sizeof(int) * (size_t)(nc ? nc : 1));
+  coarsen_by_type(type, nc, S2ia, S2ja, cf2);
+  int q = 0;
+  for (int i = 0; i < n; i++)
+    if (cf[i] == C_PT) {
+      if (cf2[q] != C_PT) cf[i] = cf2[q];
+      q++;
+    }
+  free(cf2);
+  free(S2ia);
+  free(S2ja);
+  return 0;
 }
 
 /* Truncation (par_interp.c hypre_BoomerAMGInterpTruncation): drop entries below
@@ -615,6 +894,163 @@ static ocsr *build_interp(const ocsr *A, const obig *Sia, const int *Sja, int *c
   return P;
 }
 
+
+/* Multipass interpolation (par_multi_interp.c hypre_BoomerAMGBuildMultipass; Stueben 1999, Yang 2010) -- the
+ * interpolation of aggressive-coarsening levels, agg_interp_type 4 (library default; src/HypreSystem.cpp:220-224).
+ * Pass 1: F points with a strong C neighbour interpolate directly from their strong C neighbours,
+ *   w_ij = -(sum_N / sum_C) a_ij / a_ii,  sum_N = all off-diagonal entries of row i, sum_C = those to C_i^s.
+ * Pass k > 1: F points not reached yet with a strong neighbour reached in pass k-1 interpolate THROUGH those
+ * neighbours j (their rows w_j. are final):  w_i. = -(sum_N / sum_J) / a_ii * sum_j a_ij w_j. ,  sum_J = sum of
+ * the a_ij used.  Points never reached (and special F points) keep an empty row.  Rows are accumulated in
+ * discovery order (A's row, then the neighbour's P row), truncated (agg_trunc_factor, agg_P_max_elmts) after
+ * the last pass, then sorted by coarse column. */
+static ocsr *build_multipass(const ocsr *A, const obig *Sia, const int *Sja, int *cf, double trunc_factor, int pmax,
+                             int *ncoarse_out) {
+  const int n = A->nrows;
+  int *f2c = (int *)xmalloc(sizeof(int) * (size_t)n);
+  int nc = 0;
+  for (int i = 0; i < n; i++) f2c[i] = (cf[i] == C_PT) ? nc++ : -1;
+  *ncoarse_out = nc;
+  int *assigned = (int *)xmalloc(sizeof(int) * (size_t)n); /* pass number; 0 = C, -1 = not reached */
+  int *rlen = (int *)xcalloc((size_t)n, sizeof(int));
+  int **rcol = (int **)xcalloc((size_t)n, sizeof(int *)); /* per row: coarse columns / weights, discovery order */
+  double **rval = (double **)xcalloc((size_t)n, sizeof(double *));
+  int remaining = 0;
+  for (int i = 0; i < n; i++) {
+    if (cf[i] == C_PT) {
+      assigned[i] = 0;
+      rcol[i] = (int *)xmalloc(sizeof(int));
+      rval[i] = (double *)xmalloc(sizeof(double));
+      rcol[i][0] = f2c[i];
+      rval[i][0] = 1.0;
+      rlen[i] = 1;
+    } else {
+      assigned[i] = -1;
+      if (cf[i] != SF_PT) remaining++;
+    }
+  }
+  int *smark = (int *)xmalloc(sizeof(int) * (size_t)n);   /* strong neighbour of the previous pass, of row i */
+  int *cpos = (int *)xmalloc(sizeof(int) * (size_t)(nc ? nc : 1)); /* coarse column -> position in the row */
+  for (int i = 0; i < n; i++) smark[i] = -1;
+  for (int q = 0; q < nc; q++) cpos[q] = -1;
+  int cap = 64;
+  int *tc = (int *)xmalloc(sizeof(int) * (size_t)cap);
+  double *tv = (double *)xmalloc(sizeof(double) * (size_t)cap);
+  int *list = (int *)xmalloc(sizeof(int) * (size_t)n);
+  for (int pass = 1; remaining > 0; pass++) {
+    int nl = 0;
+    for (int i = 0; i < n; i++) {
+      if (assigned[i] != -1 || cf[i] == SF_PT) continue;
+      for (obig k = Sia[i]; k < Sia[i + 1]; k++)
+        if (assigned[Sja[k]] == pass - 1) {
+          list[nl++] = i;
+          break;
+        }
+    }
+    if (nl == 0) break; /* the rest cannot be reached along strong connections */
+    for (int t = 0; t < nl; t++) {
+      const int i = list[t];
+      for (obig k = Sia[i]; k < Sia[i + 1]; k++)
+        if (assigned[Sja[k]] == pass - 1) smark[Sja[k]] = i;
+      double diagonal = 0.0, sum_N = 0.0, sum_J = 0.0;
+      int len = 0;
+      for (obig k = A->ia[i]; k < A->ia[i + 1]; k++) {
+        const int j = A->ja[k];
+        if (j == i) {
+          diagonal = A->a[k];
+          continue;
+        }
+        sum_N += A->a[k];
+        if (smark[j] != i) continue;
+        sum_J += A->a[k];
+        for (int q = 0; q < rlen[j]; q++) {
+          const int c = rcol[j][q];
+          if (cpos[c] < 0) {
+            if (len >= cap) {
+              cap *= 2;
+              tc = (int *)realloc(tc, sizeof(int) * (size_t)cap);
+              tv = (double *)realloc(tv, sizeof(double) * (size_t)cap);
+            }
+            cpos[c] = len;
+            tc[len] = c;
+            tv[len] = 0.0;
+            len++;
+          }
+          tv[cpos[c]] += A->a[k] * rval[j][q];
+        }
+      }
+      const double alfa = (sum_J * diagonal != 0.0) ? -sum_N / (sum_J * diagonal) : 0.0;
+      rcol[i] = (int *)xmalloc(sizeof(int) * (size_t)(len ? len : 1));
+      rval[i] = (double *)xmalloc(sizeof(double) * (size_t)(len ? len : 1));
+      for (int q = 0; q < len; q++) {
+        rcol[i][q] = tc[q];
+        rval[i][q] = tv[q] * alfa;
+        cpos[tc[q]] = -1;
+      }
+      rlen[i] = len;
+    }
+    /* the pass is complete before its points count as reached */
+    for (int t = 0; t < nl; t++) assigned[list[t]] = pass;
+    remaining -= nl;
+  }
+  /* truncation + sort, row by row */
+  obig *pia = (obig *)xcalloc((size_t)n + 1, sizeof(obig));
+  obig tot = 0;
+  int maxlen = 1;
+  for (int i = 0; i < n; i++) {
+    tot += rlen[i];
+    if (rlen[i] > maxlen) maxlen = rlen[i];
+  }
+  int *pj = (int *)xmalloc(sizeof(int) * (size_t)(tot ? tot : 1));
+  double *pa = (double *)xmalloc(sizeof(double) * (size_t)(tot ? tot : 1));
+  int *keep = (int *)xmalloc(sizeof(int) * (size_t)maxlen);
+  obig w = 0;
+  for (int i = 0; i < n; i++) {
+    int len = rlen[i];
+    if (cf[i] != C_PT && len > 0) len = truncate_row(len, rcol[i], rval[i], trunc_factor, pmax, keep);
+    for (int a = 1; a < len; a++) { /* insertion sort by coarse column */
+      const int c = rcol[i][a];
+      const double v = rval[i][a];
+      int b = a - 1;
+      while (b >= 0 && rcol[i][b] > c) {
+        rcol[i][b + 1] = rcol[i][b];
+        rval[i][b + 1] = rval[i][b];
+        b--;
+      }
+      rcol[i][b + 1] = c;
+      rval[i][b + 1] = v;
+    }
+    for (int q = 0; q < len; q++) {
+      pj[w] = rcol[i][q];
+      pa[w] = rval[i][q];
+      w++;
+    }
+    pia[i + 1] = w;
+    free(rcol[i]);
+    free(rval[i]);
+  }
+  ocsr *P = (ocsr *)xmalloc(sizeof(ocsr));
+  P->nrows = n;
+  P->ncols = nc;
+  P->ia = pia;
+  P->ja = pj;
+  P->a = pa;
+  for (int i = 0; i < n; i++)
+    if (cf[i] == SF_PT) cf[i] = F_PT;
+  free(f2c);
+  free(assigned);
+  free(rlen);
+  free(rcol);
+  free(rval);
+  free(smark);
+  free(cpos);
+  free(tc);
+  free(tv);
+  free(list);
+  free(keep);
+  return P;
+}
+
 /* l1 norms.  l1gs: hypre_ParCSRComputeL1NormsThreads option 4 (par_relax_more.c),
  * "threads" = hybrid-GS chunks: |a_ii| + 0.5*sum |a_ij| over entries outside the
  * row's chunk (incl. other partitions) whose C/F type equals the row's (all of
@@ -832,7 +1268,14 @@ oamg *oamg_setup(const ocsr *A0, const oamg_params *p) {
     int *cf = (int *)xmalloc(sizeof(int) * (size_t)n);
     /* coarsening and interpolation are GLOBAL algorithms (independent of the row partition) */
     int *one_part = (int *)xcalloc((size_t)n, sizeof(int));
-    pmis(n, Sia, Sja, one_part, nparts, L->part_starts, cf);
+    const int aggressive = l < p->agg_num_levels;
+    const int bad = aggressive ? coarsen_aggressive(p->coarsen_type, n, Sia, Sja, cf)
+                               : coarsen_by_type(p->coarsen_type, n, Sia, Sja, cf);
+    if (bad || (aggressive && p->agg_interp_type != 4)) {
+      fprintf(stderr, "oracle: coarsen_type %d / agg_interp_type %d is not restated\n", p->coarsen_type,
+              p->agg_interp_type);
+      abort();
+    }
     int nc = 0;
     for (int i = 0; i < n; i++) nc += (cf[i] == C_PT);
     if (nc == 0 || nc == n || nc < p->min_coarse_size) {
@@ -844,7 +1287,8 @@ oamg *oamg_setup(const ocsr *A0, const oamg_params *p) {
       break;
     }
     int nc2;
-    ocsr *P = build_interp(A, Sia, Sja, cf, one_part, p->interp_type, p->trunc_factor, p->pmax_elmts, &nc2);
+    ocsr *P = aggressive ? build_multipass(A, Sia, Sja, cf, p->agg_trunc_factor, p->agg_pmax_elmts, &nc2)
+                         : build_interp(A, Sia, Sja, cf, one_part, p->interp_type, p->trunc_factor, p->pmax_elmts, &nc2);
     free(one_part);
     L->cf = cf;
     L->P = P;
@@ -1113,6 +1557,15 @@ int oamg_solve(const oamg *h, const double *b, double *x, int *iters, double *re
 void oamg_precond(void *ctx, const double *r, double *z) {
   const oamg *h = (const oamg *)ctx;
   oamg_solve(h, r, z, NULL, NULL);
+}
+
+/* Multivectors (HYPRE_IJVectorSetNumComponents > 1; non-segregated solves of
+ * src/HypreSystem.cpp:1035-1036, one Solve call at :723 on all components): the Krylov solver sees the block
+ * system diag(A, .., A) -- build it with scipy.sparse.kron(I, A) -- and the preconditioner is applied
+ * component by component (component-major storage). */
+void omulti_precond(void *ctx, const double *r, double *z) {
+  const omulti *m = (const omulti *)ctx;
+  for (int c = 0; c < m->ncomp; c++) m->M(m->Mctx, r + (size_t)c * m->n, z + (size_t)c * m->n);
 }
 
 /* ---------------------------------------------------------------- GMRES -- */

@@ -53,7 +53,7 @@ void oracle_rand_seed(int seed);
 double oracle_rand(void);
 
 typedef struct oamg_params {
-  int coarsen_type;        /* 8 PMIS (HypreSystem.cpp:126) */
+  int coarsen_type;        /* 8 PMIS (HypreSystem.cpp:126); 10 HMIS, 11 one-pass RS; 6 Falgout, 1 RS, 3 RS3 (two-pass RS) */
   int interp_type;         /* 6 ext+i (library default), 3 direct, 0 classical modified */
   double strong_threshold; /* 0.57 (HypreSystem.cpp:159) */
   double max_row_sum;      /* 0.9 library default */
@@ -75,6 +75,12 @@ typedef struct oamg_params {
   double tol;              /* 0 as preconditioner (HypreSystem.cpp:154) */
   obig redundant_rows;     /* nparts > 1: levels >= 1 with at most this many rows are solved redundantly by every
                             * rank (one part: HYPRE's seq_threshold idea); 0 = every level distributed */
+  /* aggressive coarsening on levels < agg_num_levels (src/HypreSystem.cpp:215-229): coarsen twice (second time on
+   * the second-generation strength graph), multipass interpolation (agg_interp_type 4, the only one restated) */
+  int agg_num_levels;      /* 0 */
+  int agg_interp_type;     /* 4 multipass */
+  int agg_pmax_elmts;      /* 0 = no limit (the YAML key `pmax_elmts` lands here, HypreSystem.cpp:210-213) */
+  double agg_trunc_factor; /* 0 */
 } oamg_params;
 
 void oamg_default_params(oamg_params *p);
@@ -104,6 +110,14 @@ int oamg_solve(const oamg *h, const double *b, double *x, int *iters, double *re
 
 typedef void (*oprecond_fn)(void *ctx, const double *r, double *z); /* z = M^-1 r, z arrives zeroed */
 void oamg_precond(void *ctx, const double *r, double *z);
+
+/* a preconditioner applied to every component of a multivector (component-major, n rows each) */
+typedef struct omulti {
+  oprecond_fn M;
+  void *Mctx;
+  int n, ncomp;
+} omulti;
+void omulti_precond(void *ctx, const double *r, double *z);
 
 /* Block-Jacobi ILU(0) (HYPRE_ILU, ilu_type 0, level of fill 0; src/HypreSystem.cpp:328-370, :457-497):
  * every part factorises its own diagonal block in place (IKJ order, entries outside the block dropped).

@@ -44,6 +44,10 @@ class AmgParams(C.Structure):
         ("max_iter", C.c_int),
         ("tol", C.c_double),
         ("redundant_rows", C.c_longlong),
+        ("agg_num_levels", C.c_int),
+        ("agg_interp_type", C.c_int),
+        ("agg_pmax_elmts", C.c_int),
+        ("agg_trunc_factor", C.c_double),
     ]
 
 
@@ -123,6 +127,7 @@ def lib():
         L.oilu_solve.restype = C.c_int
         L.oilu_solve.argtypes = [C.c_void_p, P(_Csr), C.c_void_p, C.c_void_p, C.c_int, C.c_double, P(C.c_double)]
         L.oracle_set_threads.argtypes = [C.c_int]
+        L.omulti_precond.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -318,7 +323,13 @@ class Ilu:
             self.h = None
 
 
-def _krylov(fn, A, b, x0, args, amg, maxit):
+class _Multi(C.Structure):
+    _fields_ = [("M", C.c_void_p), ("Mctx", C.c_void_p), ("n", C.c_int), ("ncomp", C.c_int)]
+
+
+def _krylov(fn, A, b, x0, args, amg, maxit, ncomp=1):
+    """ncomp > 1: A is the block system kron(I_ncomp, A_1), b / x are component-major multivectors and the
+    preconditioner (built on A_1) is applied to every component."""
     b = np.ascontiguousarray(b, dtype=np.float64)
     x = np.zeros_like(b) if x0 is None else np.array(x0, dtype=np.float64)
     res = KrylovResult()
@@ -328,26 +339,30 @@ def _krylov(fn, A, b, x0, args, amg, maxit):
     else:
         M = C.cast(lib().oamg_precond, C.c_void_p) if amg is not None else None
     ctx = amg.h if amg is not None else None
+    if ncomp > 1 and amg is not None:
+        multi = _Multi(M, ctx, len(b) // ncomp, ncomp)
+        M = C.cast(lib().omulti_precond, C.c_void_p)
+        ctx = C.cast(C.pointer(multi), C.c_void_p)
     fn(A.h, _ptr(b), _ptr(x), *args, M, ctx, C.byref(res), _ptr(norms))
     return x, dict(iters=res.iters, converged=bool(res.converged), rel_res=res.rel_res,
                    true_rel_res=res.true_rel_res, norms=norms[: res.iters + 1].copy())
 
 
-def gmres(A, b, x0=None, kdim=50, tol=1e-6, atol=0.0, maxit=100, amg=None):
-    return _krylov(lib().ogmres_solve, A, b, x0, (kdim, tol, atol, maxit), amg, maxit)
+def gmres(A, b, x0=None, kdim=50, tol=1e-6, atol=0.0, maxit=100, amg=None, ncomp=1):
+    return _krylov(lib().ogmres_solve, A, b, x0, (kdim, tol, atol, maxit), amg, maxit, ncomp)
 
 
-def bicgstab(A, b, x0=None, tol=1e-6, atol=0.0, maxit=100, amg=None):
-    return _krylov(lib().obicgstab_solve, A, b, x0, (tol, atol, maxit), amg, maxit)
+def bicgstab(A, b, x0=None, tol=1e-6, atol=0.0, maxit=100, amg=None, ncomp=1):
+    return _krylov(lib().obicgstab_solve, A, b, x0, (tol, atol, maxit), amg, maxit, ncomp)
 
 
-def fgmres(A, b, x0=None, kdim=50, tol=1e-6, atol=0.0, maxit=100, amg=None):
-    return _krylov(lib().ofgmres_solve, A, b, x0, (kdim, tol, atol, maxit), amg, maxit)
+def fgmres(A, b, x0=None, kdim=50, tol=1e-6, atol=0.0, maxit=100, amg=None, ncomp=1):
+    return _krylov(lib().ofgmres_solve, A, b, x0, (kdim, tol, atol, maxit), amg, maxit, ncomp)
 
 
 def cogmres(A, b, x0=None, kdim=50, cgs=0, tol=1e-6, atol=0.0, maxit=100, amg=None):
     return _krylov(lib().ocogmres_solve, A, b, x0, (kdim, cgs, tol, atol, maxit), amg, maxit)
 
 
-def pcg(A, b, x0=None, tol=1e-6, atol=0.0, maxit=100, amg=None):
-    return _krylov(lib().opcg_solve, A, b, x0, (tol, atol, maxit), amg, maxit)
+def pcg(A, b, x0=None, tol=1e-6, atol=0.0, maxit=100, amg=None, ncomp=1):
+    return _krylov(lib().opcg_solve, A, b, x0, (tol, atol, maxit), amg, maxit, ncomp)

@@ -84,6 +84,31 @@ def main():
     np.savez_compressed(os.path.join(HERE, "random_mmatrix_400.npz"), indptr=M.indptr, indices=M.indices, data=M.data,
                         rhs=b, x_direct=xd)
     print("wrote random_mmatrix_400")
+    multicomponent_fixture()
+
+
+def multicomponent_fixture():
+    """BASELINE.json config 5 stand-in: 3-component seeded convection-diffusion system, BiCGSTAB + BoomerAMG,
+    as ONE multivector solve (segregated_solve 0) and as three segregated solves; scipy direct solutions."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from systems import convection_diffusion_3d, three_component_rhs
+
+    n = 12
+    M = convection_diffusion_3d(n)
+    B, X = three_component_rhs(M)
+    A = oc.Csr.from_scipy(M)
+    amg = oc.Amg(A, oc.default_params(gs_chunk=8))
+    blk = oc.Csr.from_scipy(sp.kron(sp.eye(3), M).tocsr())
+    xm, im = oc.bicgstab(blk, B.ravel(), tol=1e-9, maxit=60, amg=amg, ncomp=3)
+    seg = [oc.bicgstab(A, B[c], tol=1e-9, maxit=60, amg=amg) for c in range(3)]
+    lu = spl.splu(M.tocsc())
+    np.savez_compressed(os.path.join(HERE, "convdiff3_12.npz"), n=n, indptr=M.indptr, indices=M.indices, data=M.data,
+                        rhs=B, x_direct=np.stack([lu.solve(B[c]) for c in range(3)]),
+                        x_multi=xm.reshape(3, -1), iters_multi=im["iters"], rel_res_multi=im["rel_res"],
+                        norms_multi=im["norms"], x_seg=np.stack([s[0] for s in seg]),
+                        iters_seg=np.array([s[1]["iters"] for s in seg]),
+                        rel_res_seg=np.array([s[1]["rel_res"] for s in seg]))
+    print("wrote convdiff3_12: multivector", im["iters"], "iterations; segregated", [s[1]["iters"] for s in seg])
 
 
 if __name__ == "__main__":

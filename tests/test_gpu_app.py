@@ -283,3 +283,59 @@ solver_settings:
   print_level: 0
 """ + DEFAULT_AMG)
     assert "allClose=1" in out
+
+
+@pytest.mark.parametrize("segregated", [1, 0])
+@pytest.mark.parametrize("fmt", ["hypre_ij", "matrix_market"])
+def test_three_component_system(tmp_path, segregated, fmt):
+    """BASELINE.json config 5: `num_components: 3` (rhs_file0..2 / sln_file0..2), BiCGSTAB + BoomerAMG on a seeded
+    non-symmetric convection-diffusion operator; segregated_solve 1 = three solves on one hierarchy,
+    0 = ONE solve on a 3-component multivector (/root/reference/src/HypreSystem.cpp:1033-1036, :681-729, :967).
+    Every component is checked by the reference's closeness rule (:815-818) against scipy's direct solve."""
+    from tests.systems import convection_diffusion_3d, three_component_rhs
+
+    A = convection_diffusion_3d(10)
+    B, _ = three_component_rhs(A)
+    lu = spl.splu(A.tocsc())
+    X = [lu.solve(B[c]) for c in range(3)]
+    if fmt == "hypre_ij":
+        vecs = {}
+        for c in range(3):
+            vecs[f"rhs{c}.ij"] = B[c]
+            vecs[f"sln{c}.ij"] = X[c]
+        _write_ij(str(tmp_path), A, vecs, 2)
+        files = "  matrix_file: mat.ij\n  num_partitions: 2\n" + "".join(
+            f"  rhs_file{c}: rhs{c}.ij\n  sln_file{c}: sln{c}.ij\n" for c in range(3))
+    else:
+        _write_mm_matrix(tmp_path / "mat.mm", A)
+        for c in range(3):
+            _write_mm_vector(tmp_path / f"rhs{c}.mm", B[c])
+            _write_mm_vector(tmp_path / f"sln{c}.mm", X[c])
+        files = "  matrix_file: mat.mm\n" + "".join(
+            f"  rhs_file{c}: rhs{c}.mm\n  sln_file{c}: sln{c}.mm\n" for c in range(3))
+    out = _run(tmp_path, f"""
+linear_system:
+  type: {fmt}
+{files}  num_components: 3
+  segregated_solve: {segregated}
+  rtol: 1.0e-6
+  atol: 1.0e-8
+  write_solution: true
+
+solver_settings:
+  method: bicg
+  preconditioner: boomeramg
+  tolerance: 1.0e-11
+  max_iterations: 100
+  print_level: 0
+""" + DEFAULT_AMG)
+    assert out.count("allClose=1") == 3, out[-3000:]
+    assert "allClose=0" not in out
+    # one hierarchy for all components (the reference rebuilds it per component, :692 inside the :681 loop)
+    assert out.count("mi_hypre BoomerAMG setup:") == 1
+    solves = re.findall(r"Solve (\d+) : (\d+) iterations, final relative residual ([0-9.eE+-]+)", out)
+    assert len(solves) == (3 if segregated else 1)
+    assert all(0 < int(it) < 40 and float(rr) <= 1e-11 for _, it, rr in solves)
+    for c in range(3):  # write_solution: IJV<c>.sln holds component c in either mode (:755-763)
+        got = np.loadtxt(tmp_path / f"IJV{c}.sln.00000", skiprows=1)
+        assert np.allclose(got[:, 1], X[c], rtol=1e-5, atol=1e-7)
