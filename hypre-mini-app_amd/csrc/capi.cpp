@@ -692,6 +692,15 @@ HYPRE_Int HYPRE_BoomerAMGSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_
   AMG(solver)->amg.solve(*PM(A), *PV(b), *PV(x));
   API_END
 }
+// a setting this implementation accepts but does not act on: said once per key, on stderr, whatever print_level
+static void warn_ignored(const char *key, double v) {
+  static std::vector<std::string> seen;
+  for (const auto &k : seen)
+    if (k == key) return;
+  seen.push_back(key);
+  if (current_comm().rank == 0)
+    fprintf(stderr, "mi_hypre BoomerAMG: %s = %g is accepted but NOT implemented; the setting has no effect\n", key, v);
+}
 #define AMG_SET(NAME, TYPE, STMT)                               \
   HYPRE_Int HYPRE_BoomerAMGSet##NAME(HYPRE_Solver solver, TYPE v) { \
     API_BEGIN                                                   \
@@ -724,12 +733,13 @@ AMG_SET(OuterWt, HYPRE_Real, p.outer_weight = v)
 AMG_SET(AggNumLevels, HYPRE_Int, p.agg_num_levels = v)
 AMG_SET(AggInterpType, HYPRE_Int, p.agg_interp_type = v)
 AMG_SET(AggPMaxElmts, HYPRE_Int, p.agg_pmax_elmts = v)
+AMG_SET(AggTruncFactor, HYPRE_Real, p.agg_trunc_factor = v)
 AMG_SET(KeepTranspose, HYPRE_Int, p.keep_transpose = v)
 AMG_SET(RAP2, HYPRE_Int, p.rap2 = v)
-AMG_SET(Variant, HYPRE_Int, (void)v)
-AMG_SET(NonGalerkinTol, HYPRE_Real, (void)v)
-AMG_SET(SmoothType, HYPRE_Int, (void)v)
-AMG_SET(SmoothNumLevels, HYPRE_Int, (void)v)
+AMG_SET(Variant, HYPRE_Int, if (v != 0) warn_ignored("variant", v))
+AMG_SET(NonGalerkinTol, HYPRE_Real, if (v != 0.0) warn_ignored("non_galerkin_tol", v))
+AMG_SET(SmoothType, HYPRE_Int, (void)v)  /* only acts through smooth_num_levels > 0 */
+AMG_SET(SmoothNumLevels, HYPRE_Int, if (v > 0) warn_ignored("smooth_num_levels (complex smoothers)", v))
 AMG_SET(ILUType, HYPRE_Int, (void)v)
 AMG_SET(ILULevel, HYPRE_Int, (void)v)
 AMG_SET(ILULocalReordering, HYPRE_Int, (void)v)
@@ -744,9 +754,10 @@ AMG_SET(ILUTriSolve, HYPRE_Int, (void)v)
 AMG_SET(ILULowerJacobiIters, HYPRE_Int, (void)v)
 AMG_SET(ILUUpperJacobiIters, HYPRE_Int, (void)v)
 #undef AMG_SET
-HYPRE_Int HYPRE_BoomerAMGSetLevelNonGalerkinTol(HYPRE_Solver solver, HYPRE_Real, HYPRE_Int) {
+HYPRE_Int HYPRE_BoomerAMGSetLevelNonGalerkinTol(HYPRE_Solver solver, HYPRE_Real tol, HYPRE_Int) {
   API_BEGIN
   (void)AMG(solver);
+  if (tol != 0.0) warn_ignored("non_galerkin_level_tols", tol);
   API_END
 }
 HYPRE_Int HYPRE_BoomerAMGSetCycleRelaxType(HYPRE_Solver solver, HYPRE_Int relax_type, HYPRE_Int k) {

@@ -260,6 +260,10 @@ class BoomerAMG:
                               ("max_coarse_size", "HYPRE_BoomerAMGSetMaxCoarseSize", int),
                               ("seq_threshold", "HYPRE_BoomerAMGSetSeqThreshold", int),
                               ("agg_num_levels", "HYPRE_BoomerAMGSetAggNumLevels", int),
+                              ("agg_interp_type", "HYPRE_BoomerAMGSetAggInterpType", int),
+                              ("agg_pmax_elmts", "HYPRE_BoomerAMGSetAggPMaxElmts", int),
+                              ("pmax_elmts", "HYPRE_BoomerAMGSetAggPMaxElmts", int),  # sic, HypreSystem.cpp:210-213
+                              ("agg_trunc_factor", "HYPRE_BoomerAMGSetAggTruncFactor", float),
                               ("trunc_factor", "HYPRE_BoomerAMGSetTruncFactor", float),
                               ("keep_transpose", "HYPRE_BoomerAMGSetKeepTranspose", int),
                               ("rap2", "HYPRE_BoomerAMGSetRAP2", int),

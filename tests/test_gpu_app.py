@@ -339,3 +339,31 @@ solver_settings:
     for c in range(3):  # write_solution: IJV<c>.sln holds component c in either mode (:755-763)
         got = np.loadtxt(tmp_path / f"IJV{c}.sln.00000", skiprows=1)
         assert np.allclose(got[:, 1], X[c], rtol=1e-5, atol=1e-7)
+
+
+def test_shipped_sample_input_runs_unchanged(tmp_path):
+    """hypre-mini-app_amd/etc/hypre_app.yaml AS SHIPPED: the upstream sample's keys and values
+    (/root/reference/etc/hypre_app.yaml: Falgout coarsening 6, hybrid symmetric GS 6, two sweeps, classical
+    interpolation 0, GMRES(10), tol 1e-6), files mat.mm / rhs.mm / sln.mm in the working directory."""
+    import yaml
+
+    shipped = os.path.join(ROOT, "hypre-mini-app_amd", "etc", "hypre_app.yaml")
+    cfg = yaml.safe_load(open(shipped))
+    amg = cfg["boomeramg_settings"]
+    assert (amg["coarsen_type"], amg["relax_type"], amg["num_sweeps"], amg["interp_type"]) == (6, 6, 2, 0)
+    assert amg["strong_threshold"] == 0.57 and cfg["solver_settings"]["kspace"] == 10
+    A, b, x = _system(48, 5)
+    _write_mm_matrix(tmp_path / "mat.mm", A)
+    _write_mm_vector(tmp_path / "rhs.mm", b)
+    _write_mm_vector(tmp_path / "sln.mm", x)
+    p = subprocess.run([APP, shipped], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:]
+    out = p.stdout
+    m = re.search(r"Solve 0 : (\d+) iterations, final relative residual ([0-9.eE+-]+)", out)
+    assert m and int(m.group(1)) < 30 and float(m.group(2)) <= 1e-6, out[-2000:]
+    # tol 1e-6 on the residual: the solution is close to the direct solve, at the rule's default rtol 1e-6 it
+    # need not be "allClose"; the driver must have run the check and reported a small error
+    m = re.search(r"max rel err=([0-9.eE+-]+)", out)
+    assert m and float(m.group(1)) < 1e-3, out[-2000:]
+    assert "not implemented" not in out and "not restated" not in out

@@ -16,13 +16,27 @@ def _host_amg(mi, n, stencil, **kw):
 
 @pytest.mark.parametrize("n,stencil,kw", [(14, 7, {}), (9, 27, {}), (12, 7, dict(interp_type=3)),
                                           (12, 7, dict(interp_type=0)), (12, 7, dict(strong_threshold=0.25)),
-                                          (12, 7, dict(max_coarse_size=100)), (12, 7, dict(max_levels=3))])
+                                          (12, 7, dict(max_coarse_size=100)), (12, 7, dict(max_levels=3)),
+                                          # coarsening types: HMIS, one-pass RS, Falgout / RS (two passes)
+                                          (12, 7, dict(coarsen_type=10)), (9, 27, dict(coarsen_type=10)),
+                                          (12, 7, dict(coarsen_type=11)), (13, 7, dict(coarsen_type=6)),
+                                          (9, 27, dict(coarsen_type=6)), (12, 7, dict(coarsen_type=1, interp_type=0)),
+                                          (12, 7, dict(coarsen_type=3, interp_type=3)),
+                                          # the upstream sample's AMG block (etc/hypre_app.yaml:33-42)
+                                          (14, 7, dict(coarsen_type=6, interp_type=0, relax_type=6, num_sweeps=2)),
+                                          # aggressive coarsening + multipass interpolation
+                                          (14, 7, dict(agg_num_levels=1)), (16, 7, dict(agg_num_levels=2)),
+                                          (10, 27, dict(agg_num_levels=1)),
+                                          (14, 7, dict(agg_num_levels=1, agg_pmax_elmts=4)),
+                                          (14, 7, dict(agg_num_levels=1, agg_trunc_factor=0.3)),
+                                          (14, 7, dict(agg_num_levels=1, coarsen_type=10)),
+                                          (13, 7, dict(agg_num_levels=1, coarsen_type=6, interp_type=0))])
 def test_host_setup_equals_oracle(mi_lib, oc, n, stencil, kw):
     mi = mi_lib
     A, amg = _host_amg(mi, n, stencil, **kw)
     Ao, bo = oc.Csr.laplace(n, n, n, stencil)
     oamg = oc.Amg(Ao, oc.default_params(**kw))
-    assert amg.num_levels == oamg.num_levels
+    assert amg.num_levels == oamg.num_levels and amg.num_levels > 1
     for l in range(amg.num_levels):
         ia, ja, a, shape = amg.level_csr(l, 0)
         oia, oja, oa = oamg.level_A(l).arrays()
@@ -102,3 +116,50 @@ def test_empty_and_tiny_systems_host(mi_lib, oc):
     amg = mi.BoomerAMG(print_level=0)
     mi.call("HYPRE_MI_BoomerAMGSetupHostOnly", amg.h, D.par)
     assert amg.num_levels == 1
+
+
+def test_unrestated_settings_are_refused_not_substituted(mi_lib):
+    """CLJP (0) and the two-stage aggressive interpolations are not implemented: Setup says so instead of
+    silently building a PMIS / multipass hierarchy."""
+    mi = mi_lib
+    A, rhs = mi.build_laplace_system_host(6, 6, 6, 7, 0, 1)
+    for kw in (dict(coarsen_type=0), dict(coarsen_type=21), dict(agg_num_levels=1, agg_interp_type=1)):
+        amg = mi.BoomerAMG(print_level=0, **kw)
+        with pytest.raises(mi.HypreError, match="not implemented"):
+            mi.call("HYPRE_MI_BoomerAMGSetupHostOnly", amg.h, A.par)
+        mi.call("HYPRE_ClearAllErrors")
+
+
+def test_random_mmatrix_coarsening_types_host(mi_lib, oc):
+    """Irregular graph (random M-matrix): every coarsening type and aggressive coarsening against the oracle."""
+    mi = mi_lib
+    rng = np.random.default_rng(5)
+    n = 600
+    M = sp.random(n, n, density=0.01, random_state=rng, format="csr")
+    M = (M + M.T).tocsr()
+    M = (M - sp.diags(M.diagonal())).tocsr()
+    M = (-abs(M) + sp.diags(abs(M).sum(axis=1).A1 + 0.1)).tocsr()
+    M.sort_indices()
+    coo = M.tocoo()
+    for kw in (dict(coarsen_type=10), dict(coarsen_type=6), dict(agg_num_levels=1), dict(agg_num_levels=1, coarsen_type=6),
+               dict(strong_threshold=0.25, coarsen_type=6, interp_type=0)):
+        A = mi.IJMatrix.__new__(mi.IJMatrix)
+        A.h = mi.vp()
+        mi.call("HYPRE_IJMatrixCreate", 0, mi.c_big(0), mi.c_big(n - 1), mi.c_big(0), mi.c_big(n - 1), mi.C.byref(A.h))
+        A.par = mi.vp()
+        mi.call("HYPRE_IJMatrixGetObject", A.h, mi.C.byref(A.par))
+        A.set_values_coo(coo.row.astype(np.int64), coo.col.astype(np.int64), coo.data)
+        mi.call("HYPRE_MI_IJMatrixAssembleHostOnly", A.h)
+        amg = mi.BoomerAMG(print_level=0, **kw)
+        mi.call("HYPRE_MI_BoomerAMGSetupHostOnly", amg.h, A.par)
+        oamg = oc.Amg(oc.Csr.from_scipy(M), oc.default_params(**kw))
+        assert amg.num_levels == oamg.num_levels and amg.num_levels > 1
+        for l in range(amg.num_levels):
+            ia, ja, a, shape = amg.level_csr(l, 0)
+            oia, oja, oa = oamg.level_A(l).arrays()
+            assert np.array_equal(ia, oia) and np.array_equal(ja, oja) and np.array_equal(a, oa)
+            if l < amg.num_levels - 1:
+                assert np.array_equal(amg.level_cf(l), oamg.level_cf(l))
+                pia, pja, pa, _ = amg.level_csr(l, 2)
+                qia, qja, qa = oamg.level_P(l).arrays()
+                assert np.array_equal(pia, qia) and np.array_equal(pja, qja) and np.array_equal(pa, qa)
