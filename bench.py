@@ -38,9 +38,13 @@ def parse():
     ap.add_argument("--tol", type=float, default=1e-8)
     ap.add_argument("--kdim", type=int, default=50)
     ap.add_argument("--max-iter", type=int, default=200)
-    ap.add_argument("--cpu-n", type=int, default=int(os.environ.get("MI_BENCH_CPU_N", "128")),
-                    help="grid side of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-n", type=int, default=int(os.environ.get("MI_BENCH_CPU_N", "-1")),
+                    help="grid side of the bounded CPU-baseline sample (0 = skip; default: 256 = BASELINE.json "
+                         "config 2 when the host has the memory, else 128)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--amg", action="append", default=[], metavar="KEY=VALUE",
+                    help="boomeramg_settings override for a side-line (e.g. --amg agg_num_levels=1); the headline "
+                         "configuration is the one without overrides")
     return ap.parse_args()
 
 
@@ -70,6 +74,15 @@ def cpu_baseline(args, chunk):
     timed on this host on a bounded sample of the same workload, OpenMP over all physical cores."""
     oc = ge.load_oracle()
     n = args.cpu_n
+    if n < 0:
+        avail_gb = 0.0
+        try:
+            for line in open("/proc/meminfo"):
+                if line.startswith("MemAvailable"):
+                    avail_gb = int(line.split()[1]) / 1e6
+        except OSError:
+            pass
+        n = 256 if avail_gb >= 48.0 else 128
     cores = physical_cores()
     oc.lib().oracle_set_threads(cores)
     A, b = oc.Csr.laplace(n, n, n, args.stencil)
@@ -88,22 +101,25 @@ def cpu_baseline(args, chunk):
                 break
     except OSError:
         pass
-    # the same solve on ONE thread, for the per-core figure
-    oc.lib().oracle_set_threads(1)
-    t0 = time.time()
-    _, info1 = oc.gmres(A, b, kdim=args.kdim, tol=args.tol, maxit=args.max_iter, amg=amg)
-    t_solve1 = time.time() - t0
-    oc.lib().oracle_set_threads(cores)
+    # the same solve on ONE thread, for the per-core figure (only on the small sample: it would not fit the
+    # few-minutes budget at 256^3)
+    one_thread = ""
+    if n <= 128:
+        oc.lib().oracle_set_threads(1)
+        t0 = time.time()
+        _, info1 = oc.gmres(A, b, kdim=args.kdim, tol=args.tol, maxit=args.max_iter, amg=amg)
+        t_solve1 = time.time() - t0
+        oc.lib().oracle_set_threads(cores)
+        one_thread = f"; on 1 thread: {t_solve1:.2f} s = {ndof * info1['iters'] / t_solve1 / 1e9:.4f} GDOF/s"
     return {
         "value": ndof * info["iters"] / t_solve / 1e9,
         "unit": "GDOF/s",
         "cores": cores,
         "kind": "port",
         "sample": f"laplace_3d {n}^3 {args.stencil}-pt, GMRES({args.kdim})+AMG tol {args.tol:g}: "
-                  f"{info['iters']} iterations in {t_solve:.2f} s solve (+{t_setup:.2f} s setup, 1 thread), "
+                  f"{info['iters']} iterations in {t_solve:.2f} s solve (+{t_setup:.2f} s setup on min({cores}, 32) threads), "
                   f"rel res {info['rel_res']:.2e}; HYPRE-algorithm CPU restatement (oracle/), OpenMP {cores} threads of "
-                  f"{os.cpu_count()} visible on {cpu_model}; on 1 thread: {t_solve1:.2f} s = "
-                  f"{ndof * info1['iters'] / t_solve1 / 1e9:.4f} GDOF/s",
+                  f"{os.cpu_count()} visible on {cpu_model}{one_thread}",
         "iterations": info["iters"],
         "iterations_per_s": info["iters"] / t_solve,
     }
@@ -194,7 +210,11 @@ def main():
     t0 = time.time()
     A, b, x, _ = mi.build_laplace_system(n, n, n, args.stencil, rank, world)
     t_build = time.time() - t0
-    amg = mi.BoomerAMG(print_level=1 if (rank == 0 and os.environ.get("MI_BENCH_VERBOSE")) else 0)
+    amg_kw = {}
+    for kv in args.amg:
+        k_, v_ = kv.split("=", 1)
+        amg_kw[k_] = float(v_) if any(c in v_ for c in ".eE") else int(v_)
+    amg = mi.BoomerAMG(print_level=1 if (rank == 0 and os.environ.get("MI_BENCH_VERBOSE")) else 0, **amg_kw)
     gm = mi.GMRES(tolerance=args.tol, max_iterations=args.max_iter, kspace=args.kdim, print_level=0)
     gm.set_precond(amg)
     t0 = time.time()
@@ -301,7 +321,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"laplace_3d {n}^3 {args.stencil}-pt (N={ndof}), GMRES({args.kdim})+BoomerAMG "
-                            f"(PMIS, ext+i, C/F l1-hybrid-SGS chunk {chunk.value}, V(1,1)), tol {args.tol:g}, x0=0",
+                            f"(PMIS, ext+i, C/F l1-hybrid-SGS chunk {chunk.value}, V(1,1)), tol {args.tol:g}, x0=0"
+                            + (f"; SIDE-LINE with boomeramg_settings overrides {amg_kw}" if amg_kw else ""),
                 "row_partition": f"{world} contiguous block-row slab(s)",
                 "transport": transport,
             },
@@ -318,7 +339,7 @@ def main():
         }
         if rehearsal:
             out["rehearsal"] = True
-        if not args.no_cpu and args.cpu_n > 0 and world == 1:  # rank 0 at N=1 only
+        if not args.no_cpu and args.cpu_n != 0 and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, chunk.value)
         else:
             out["cpu_baseline"] = None

@@ -1115,6 +1115,7 @@ void BoomerAMG::apply_cf_ordering() {
 }
 
 void BoomerAMG::setup_host(ParCSR &A0) {
+  TraceRange trace_setup("mi_hypre BoomerAMGSetup (hierarchy)");
   Comm &comm = my_comm();
   t_setup_start = wall_time();
   for (double &t : t_phase) t = 0.0;
@@ -1756,6 +1757,7 @@ void BoomerAMG::build_replicated(ParCSR &A0) {
 }
 
 void BoomerAMG::setup_device() {
+  TraceRange trace_setup("mi_hypre BoomerAMGSetup (solve-phase format)");
   MI_REQUIRE(host_ready, "BoomerAMG: setup_device before setup_host");
   ensure_init();
   Comm &comm = my_comm();

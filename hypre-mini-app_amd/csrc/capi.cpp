@@ -1134,6 +1134,14 @@ HYPRE_Int HYPRE_MI_SetGSChunk(HYPRE_Int rows) {
   ctx().gs_chunk = rows;
   API_END
 }
+// the size check HYPRE_IJMatrixAssemble and the solve format apply to one rank's block, on a caller-supplied
+// row-pointer array (tests exercise the 32-bit boundary without building a 2^31-entry matrix)
+HYPRE_Int HYPRE_MI_CheckBlockRowPointers(HYPRE_BigInt nrows, const HYPRE_BigInt *row_ptr) {
+  API_BEGIN
+  if (nrows < 0 || (nrows > 0 && !row_ptr)) fail(HYPRE_ERROR_ARG, "CheckBlockRowPointers: bad argument");
+  require_int32_block(nrows, nrows > 0 ? row_ptr[nrows] : 0, "IJMatrixAssemble");
+  API_END
+}
 HYPRE_Int HYPRE_MI_GetCounter(const char *name, long long *value) {
   API_BEGIN
   const std::string n(name ? name : "");

@@ -132,6 +132,7 @@ void GmresSolver::setup(ParCSR &A, ParVector &b, ParVector &x) {
 }
 
 int GmresSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
+  TraceRange trace_solve(flexible ? "mi_hypre FlexGMRESSolve" : (ortho ? "mi_hypre COGMRESSolve" : "mi_hypre GMRESSolve"));
   ensure_init();
   Ctx &c = ctx();
   Comm &comm = current_comm();
@@ -220,8 +221,13 @@ int GmresSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
       ParVector &pi = basis(i);
       ParVector &pim1 = basis(i - 1);
       ParVector &dir = flexible ? zvec(i - 1) : r;  // M^-1 p_{i-1}
-      const double *mp = precond(pim1, dir, flexible);
+      const double *mp;
+      {
+        TraceRange tr("precond (BoomerAMG cycle)");
+        mp = precond(pim1, dir, flexible);
+      }
       mv(1.0, mp, 0.0, nullptr, pi.data());
+      TraceRange trace_ortho("Gram-Schmidt + Givens");
       if (ortho == 0) {
         // modified Gram-Schmidt with the axpy of step j-1 fused into the dot of step j
         // (and the last axpy into the norm): h_j = <p_j, w>, w -= h_j p_j, one pass each
@@ -357,6 +363,7 @@ void PcgSolver::setup(ParCSR &A, ParVector &b, ParVector &x) {
 // hypre_PCGSolve (krylov/pcg.c), default options: two_norm 0 (the convergence
 // measure is <C r, r> / <C b, b> against tol^2), no residual recomputation
 int PcgSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
+  TraceRange trace_solve("mi_hypre PCGSolve");
   ensure_init();
   Comm &comm = current_comm();
   hipStream_t s = ctx().stream;
@@ -440,6 +447,7 @@ void BicgstabSolver::setup(ParCSR &A, ParVector &b, ParVector &x) {
 }
 
 int BicgstabSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
+  TraceRange trace_solve("mi_hypre BiCGSTABSolve");
   ensure_init();
   Ctx &c = ctx();
   Comm &comm = current_comm();

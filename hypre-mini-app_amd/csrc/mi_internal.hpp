@@ -217,6 +217,18 @@ void ensure_init();
 void zero_on_stream(void *p, size_t bytes);
 Comm &current_comm();  // never needs a device (self comm by default)
 
+// ---------------------------------------------------------------- tracing
+// roctx ranges around the phases of the path (rocprofv3 --marker-trace shows them beside the kernels): setup and
+// its steps, the Krylov solve, every preconditioner application.  librocprofiler-sdk-roctx is dlopen'ed on first
+// use; without it (or with MI_HYPRE_ROCTX=0) a range costs one branch.
+struct TraceRange {
+  explicit TraceRange(const char *name);
+  ~TraceRange();
+  TraceRange(const TraceRange &) = delete;
+  TraceRange &operator=(const TraceRange &) = delete;
+  bool on = false;
+};
+
 // ---------------------------------------------------------------- small helpers
 void parallel_for(int64_t n, const std::function<void(int64_t, int64_t, int)> &fn, int max_threads = 0);
 int host_threads();

@@ -31,12 +31,22 @@ void ParVector::init(gidx s, gidx e, int nc) {
   if (n) zero_on_stream(d.p, (size_t)n * ncomp * sizeof(double));
 }
 
+void require_int32_block(int64_t nrows, int64_t nnz, const char *what) {
+  if (nrows >= MAX_BLOCK_ENTRIES)
+    fail(4, std::string(what) + ": " + std::to_string(nrows) +
+                " local rows exceed the 32-bit local row ids of the solve format; split the rows over more ranks");
+  if (nnz >= MAX_BLOCK_ENTRIES)
+    fail(4, std::string(what) + ": " + std::to_string(nnz) + " entries in one rank's block exceed the 32-bit entry offsets "
+                "of the solve format (limit " + std::to_string(MAX_BLOCK_ENTRIES) + "); split the rows over more ranks");
+}
+
 // ------------------------------------------------------------------ IJ assembly
 // HYPRE_IJMatrixAssemble semantics: entries with a column in
 // [jlower, jupper] go to diag, the rest to offd; for one (row, col) the batches
 // are applied in submission order, Set overwrites and AddTo accumulates.
 void assemble_parcsr(Comm &comm, gidx ilower, gidx iupper, gidx jlower, gidx jupper,
                      std::vector<IJEntryBatch> &batches, ParCSR &out) {
+  require_int32_block(iupper - ilower + 1, 0, "IJMatrixAssemble");
   const int nrows = (int)(iupper - ilower + 1);
   const int ncols_loc = (int)(jupper - jlower + 1);
   std::vector<int64_t> ia((size_t)nrows + 1, 0);
@@ -204,6 +214,8 @@ void assemble_parcsr(Comm &comm, gidx ilower, gidx iupper, gidx jlower, gidx jup
     D.ia[(size_t)i + 1] = D.ia[(size_t)i] + ndiag[(size_t)i];
     O.ia[(size_t)i + 1] = O.ia[(size_t)i] + noffd[(size_t)i];
   }
+  require_int32_block(nrows, D.nnz(), "IJMatrixAssemble (diagonal block)");
+  require_int32_block(nrows, O.nnz(), "IJMatrixAssemble (off-diagonal block)");
   D.ja.resize((size_t)D.nnz());
   D.a.resize((size_t)D.nnz());
   O.ja.resize((size_t)O.nnz());

@@ -1,5 +1,7 @@
 // Runtime context: device/stream ownership, scratch, device CSR upload,
 // event timers, the host thread helper.
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cstring>
@@ -7,6 +9,7 @@
 
 #include "kernels.hpp"
 #include "mi_internal.hpp"
+#include "parcsr.hpp"
 #include "profile.hpp"
 
 namespace mi {
@@ -94,11 +97,44 @@ void ensure_init() {
   c.inited = true;
 }
 
+namespace {
+struct Roctx {
+  int (*push)(const char *) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    const char *e = getenv("MI_HYPRE_ROCTX");
+    if (e && atoi(e) == 0) return;
+    void *h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return;
+    push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+    pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+    if (!push || !pop) push = nullptr, pop = nullptr;
+  }
+};
+Roctx &roctx() {
+  static Roctx r;
+  return r;
+}
+}  // namespace
+
+TraceRange::TraceRange(const char *name) {
+  Roctx &r = roctx();
+  if (r.push) {
+    r.push(name);
+    on = true;
+  }
+}
+TraceRange::~TraceRange() {
+  if (on) roctx().pop();
+}
+
 void DevCSR::upload(const HostCSR &h) {
   nrows = h.nrows;
   ncols = h.ncols;
   nnz = h.nnz();
-  MI_REQUIRE(nnz < (int64_t)2147483000, "per-rank matrix block exceeds int32 row pointers");
+  require_int32_block(nrows, nnz, "solve format");
   std::vector<int> ia32((size_t)nrows + 1);
   for (int i = 0; i <= nrows; i++) ia32[(size_t)i] = (int)h.ia[(size_t)i];
   ia.upload(ia32);

@@ -17,6 +17,7 @@
 #include <algorithm>
 
 #include "kernels.hpp"
+#include "parcsr.hpp"
 
 namespace mi {
 namespace sk {
@@ -1208,7 +1209,7 @@ void launch_bins(const Bins &bins, const int *rows, const int *T, int S_hint, co
 
 void to_solve_format(DCsr &src, DevCSR &dst, hipStream_t s) {
   const int n = src.nrows;
-  MI_REQUIRE(src.nnz < (int64_t)2147483000, "per-rank matrix block exceeds int32 row pointers");
+  require_int32_block(src.nrows, src.nnz, "solve format");
   dst.nrows = n;
   dst.ncols = src.ncols;
   dst.nnz = src.nnz;

@@ -5,7 +5,7 @@
 namespace mi {
 
 struct SolverBase {
-  enum Kind { K_GMRES, K_BICGSTAB, K_PCG, K_AMG, K_ILU, K_STUB } kind;
+  enum Kind { K_GMRES, K_BICGSTAB, K_PCG, K_AMG, K_ILU } kind;
   explicit SolverBase(Kind k) : kind(k) {}
   virtual ~SolverBase() {}
 };
@@ -96,12 +96,6 @@ struct IluSolver : SolverBase {
   void setup(ParCSR &A);
   void apply(const double *rhs, double *out);           // out = U^-1 L^-1 rhs
   int solve(ParCSR &A, ParVector &b, ParVector &x);     // x += M^-1 (b - A x), max_iter times or to tol
-};
-
-// placeholder for entry points that stay unimplemented: every call reports HYPRE_ERROR_GENERIC
-struct StubSolver : SolverBase {
-  std::string family;
-  explicit StubSolver(const char *f) : SolverBase(K_STUB), family(f) {}
 };
 
 }  // namespace mi

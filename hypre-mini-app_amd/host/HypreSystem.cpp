@@ -6,7 +6,9 @@
 #include "HypreSystem.h"
 
 #include <fcntl.h>
+#ifndef MI_HOST_WITH_LIBHYPRE
 #include <hip/hip_runtime.h>
+#endif
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -602,6 +604,9 @@ void HypreSystem::assemble_system() {
 
 // /root/reference/src/HypreSystem.cpp:638-671
 void HypreSystem::checkMemory() {
+#ifdef MI_HOST_WITH_LIBHYPRE
+  return;  // CPU libHYPRE: no device
+#else
   int count = 0, device = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return;
   (void)hipGetDevice(&device);
@@ -612,6 +617,7 @@ void HypreSystem::checkMemory() {
   printf("rank=%d : %s : %s arch=%s : device=%d of %d : free memory=%1.8g GB, total memory=%1.8g GB\n", iproc_,
          __FUNCTION__, prop.name, prop.gcnArchName, device, count, free_b / 1.e9, total_b / 1.e9);
   fflush(stdout);
+#endif
 }
 
 // /root/reference/src/HypreSystem.cpp:673-737 -- the call site of the hot path.

@@ -15,7 +15,11 @@
 #include "HYPRE_parcsr_ls.h"
 #include "_hypre_parcsr_ls.h"
 #include "krylov.h"
+#ifdef MI_HOST_WITH_LIBHYPRE
+#include "libhypre_backend.h"  // opt-in: real MPI + real libHYPRE (make app-libhypre HYPRE_DIR=...)
+#else
 #include "mpi_shim.h"
+#endif
 #include "yaml_lite.hpp"
 
 namespace nalu {

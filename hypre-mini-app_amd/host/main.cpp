@@ -4,7 +4,9 @@
 // Launch: one process per GPU with RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR /
 // MASTER_PORT in the environment (python -m torch.distributed.run --no-python
 // ./hypre_app input.yaml does that), or a single process with nothing set.
+#ifndef MI_HOST_WITH_LIBHYPRE
 #include <hip/hip_runtime.h>
+#endif
 
 #include <chrono>
 #include <cstdio>
@@ -23,6 +25,14 @@ static int pick_device(int count) {
 
 int main(int argc, char *argv[]) {
   MPI_Init(&argc, &argv);
+#ifdef MI_HOST_WITH_LIBHYPRE
+  // opt-in adapter build against a real (CPU) libHYPRE: host memory, host execution, no device
+  int iproc = 0, nproc = 1;
+  MPI_Comm_rank(MPI_COMM_WORLD, &iproc);
+  MPI_Comm_size(MPI_COMM_WORLD, &nproc);
+  if (HYPRE_Init()) return 2;
+  (void)pick_device;
+#else
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
     std::cerr << "ERROR!! hypre_app needs a HIP device (MI355X); none is visible and there is no CPU path."
@@ -45,6 +55,7 @@ int main(int argc, char *argv[]) {
     printf("rank=%d : %s : %s arch=%s : device=%d of %d : free memory=%1.8g GB, total memory=%1.8g GB\n", iproc,
            __FUNCTION__, prop.name, prop.gcnArchName, device, count, free_b / 1.e9, total_b / 1.e9);
   }
+#endif
   fflush(stdout);
   MPI_Barrier(MPI_COMM_WORLD);
   auto start = std::chrono::steady_clock::now();
@@ -62,6 +73,10 @@ int main(int argc, char *argv[]) {
 
     // memory / execution policy and the vendor-kernel knobs (src/main.cpp:97-156):
     // the library is device-only and has no vendor paths, the knobs are accepted
+#ifdef MI_HOST_WITH_LIBHYPRE
+    HYPRE_SetMemoryLocation(HYPRE_MEMORY_HOST);
+    HYPRE_SetExecutionPolicy(HYPRE_EXEC_HOST);
+#else
     HYPRE_SetGPUMemoryPoolSize(8, 3, 9, 2000LL * 1024 * 1024);
     HYPRE_SetUmpireDevicePoolName("HYPRE_DEVICE_POOL");
     HYPRE_SetUmpireDevicePoolSize((size_t)nalu::get_optional(node, "umpire_device_pool_mbs", 4096) * 1024 * 1024);
@@ -70,13 +85,16 @@ int main(int argc, char *argv[]) {
     HYPRE_SetSpGemmUseVendor(nalu::get_optional(node, "spgemm_use_vendor", 0) == 1);
     HYPRE_SetSpMVUseVendor(nalu::get_optional(node, "spmv_use_vendor", 0) == 1);
     HYPRE_SetSpTransUseVendor(nalu::get_optional(node, "sptrans_use_vendor", 0) == 1);
+#endif
 
     const std::string csv_profile_file = nalu::get_optional<std::string>(node, "csv_profile_file", "");
     std::vector<std::string> names;
     std::vector<std::vector<double>> data;
     const int num_tests = nalu::get_optional(node, "num_tests", 1);
     for (int i = 0; i < num_tests; ++i) {
+#ifndef MI_HOST_WITH_LIBHYPRE
       hypre_ResetDeviceRandGenerator(1234ULL, 0ULL);
+#endif
       nalu::HypreSystem linsys(MPI_COMM_WORLD, inpfile);
       linsys.setup_precon_and_solver();
       linsys.checkMemory();
@@ -107,7 +125,13 @@ int main(int argc, char *argv[]) {
     std::cerr << "rank " << iproc << " : ERROR : " << e.what() << std::endl;
     rc = 1;
   }
-  MPI_Finalize();
+#ifdef MI_HOST_WITH_LIBHYPRE
   HYPRE_Finalize();
+  MPI_Finalize();
+#else
+  MPI_Finalize();  // = HYPRE_MI_CommFinalize: the communicator lives in the library
+  HYPRE_Finalize();
+#endif
+  (void)nproc;
   return rc;
 }

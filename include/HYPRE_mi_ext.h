@@ -59,6 +59,11 @@ HYPRE_Int HYPRE_MI_SetZeroGuessMode(HYPRE_Int mode);
  * neighbour exchange ran beside the diag-block product), "gs_overlapped" / "gs_in_order" (relaxation passes that
  * swept their halo-free rows while the halo travelled / that waited for it first). */
 HYPRE_Int HYPRE_MI_GetCounter(const char *name, long long *value);
+/* One rank's block keeps 32-bit local row ids and entry offsets in the solve format: HYPRE_IJMatrixAssemble
+ * refuses (HYPRE_ERROR_ARG + message) a block with >= 2147483000 rows or entries -- e.g. the reference's 27-point
+ * operator at 512^3 (3.6e9 entries, /root/reference/src/laplace_3d_weak_scaling.hpp:558,600) on ONE rank -- instead
+ * of wrapping around.  This applies the same check to a row-pointer array (row_ptr[nrows] = entries). */
+HYPRE_Int HYPRE_MI_CheckBlockRowPointers(HYPRE_BigInt nrows, const HYPRE_BigInt *row_ptr);
 
 /* ---- results the driver never asks HYPRE for */
 HYPRE_Int HYPRE_MI_KrylovGetResidualHistory(HYPRE_Solver solver, HYPRE_Real *norms, HYPRE_Int max_n, HYPRE_Int *n);

@@ -112,7 +112,7 @@ HYPRE_Int HYPRE_ParCSRBiCGSTABGetFinalRelativeResidualNorm(HYPRE_Solver solver, 
 
 /* ---------------------------------------------------------------- further Krylov families;
  * all implemented; HYPRE_ILU further down covers ILU(0) */
-#define MI_HYPRE_DECLARE_KRYLOV_STUB(NAME)                                                                           \
+#define MI_HYPRE_DECLARE_KRYLOV_FAMILY(NAME)                                                                           \
   HYPRE_Int HYPRE_ParCSR##NAME##Create(MPI_Comm comm, HYPRE_Solver *solver);                                         \
   HYPRE_Int HYPRE_ParCSR##NAME##Destroy(HYPRE_Solver solver);                                                        \
   HYPRE_Int HYPRE_ParCSR##NAME##Setup(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x); \
@@ -127,9 +127,9 @@ HYPRE_Int HYPRE_ParCSRBiCGSTABGetFinalRelativeResidualNorm(HYPRE_Solver solver, 
  * PCG = preconditioned conjugate gradients (krylov/pcg.c), COGMRES = the GMRES skeleton with classical
  * Gram-Schmidt in block form: one block of inner products (one all-reduce) + one block update per pass
  * (krylov/cogmres.c); SetCGS(cgs): cgs <= 1 one pass, cgs >= 2 two passes */
-MI_HYPRE_DECLARE_KRYLOV_STUB(COGMRES)  /* src/HypreSystem.cpp:372-388 */
-MI_HYPRE_DECLARE_KRYLOV_STUB(FlexGMRES) /* :406-421 */
-MI_HYPRE_DECLARE_KRYLOV_STUB(PCG)      /* :440-455 */
+MI_HYPRE_DECLARE_KRYLOV_FAMILY(COGMRES)  /* src/HypreSystem.cpp:372-388 */
+MI_HYPRE_DECLARE_KRYLOV_FAMILY(FlexGMRES) /* :406-421 */
+MI_HYPRE_DECLARE_KRYLOV_FAMILY(PCG)      /* :440-455 */
 HYPRE_Int HYPRE_ParCSRFlexGMRESSetAbsoluteTol(HYPRE_Solver solver, HYPRE_Real a_tol);
 HYPRE_Int HYPRE_ParCSRFlexGMRESSetMinIter(HYPRE_Solver solver, HYPRE_Int min_iter);
 HYPRE_Int HYPRE_ParCSRFlexGMRESSetLogging(HYPRE_Solver solver, HYPRE_Int logging);

@@ -16,6 +16,12 @@
 #include <omp.h>
 #endif
 
+#include <time.h>
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 static int g_threads = 1;
 void oracle_set_threads(int n) {
   g_threads = n < 1 ? 1 : n;
@@ -23,6 +29,16 @@ void oracle_set_threads(int n) {
   omp_set_num_threads(g_threads);
 #endif
 }
+
+/* threads of the setup phase: rows are independent in strength / interpolation / the Galerkin products, every row
+ * is computed by one thread in the sequential order, so the hierarchy does not depend on the thread count; the
+ * per-thread marker arrays cap the count */
+static int setup_threads(void) { return g_threads > 32 ? 32 : g_threads; }
+#ifdef _OPENMP
+#define OTHREAD() omp_get_thread_num()
+#else
+#define OTHREAD() 0
+#endif
 
 #define C_PT 1
 #define F_PT (-1)
@@ -115,48 +131,60 @@ static int cmp_int(const void *a, const void *b) {
  * (Galerkin product of par_rap.c is R*(A*P) evaluated with this routine.) */
 ocsr *ocsr_matmul(const ocsr *A, const ocsr *B) {
   const int n = A->nrows, m = B->ncols;
-  int *mark = (int *)xmalloc(sizeof(int) * (size_t)m);
-  for (int j = 0; j < m; j++) mark[j] = -1;
+  const int nthr = setup_threads();
   obig *cia = (obig *)xcalloc((size_t)n + 1, sizeof(obig));
-  for (int i = 0; i < n; i++) {
-    obig cnt = 0;
-    for (obig ka = A->ia[i]; ka < A->ia[i + 1]; ka++) {
-      int k = A->ja[ka];
-      for (obig kb = B->ia[k]; kb < B->ia[k + 1]; kb++) {
-        int j = B->ja[kb];
-        if (mark[j] != i) {
-          mark[j] = i;
-          cnt++;
+#pragma omp parallel num_threads(nthr) if (nthr > 1)
+  {
+    int *mark = (int *)xmalloc(sizeof(int) * (size_t)m);
+    for (int j = 0; j < m; j++) mark[j] = -1;
+#pragma omp for schedule(static)
+    for (int i = 0; i < n; i++) {
+      obig cnt = 0;
+      for (obig ka = A->ia[i]; ka < A->ia[i + 1]; ka++) {
+        int k = A->ja[ka];
+        for (obig kb = B->ia[k]; kb < B->ia[k + 1]; kb++) {
+          int j = B->ja[kb];
+          if (mark[j] != i) {
+            mark[j] = i;
+            cnt++;
+          }
         }
       }
+      cia[i + 1] = cnt;
     }
-    cia[i + 1] = cia[i] + cnt;
+    free(mark);
   }
+  for (int i = 0; i < n; i++) cia[i + 1] += cia[i];
   ocsr *C = ocsr_new(n, m, cia[n]);
   memcpy(C->ia, cia, sizeof(obig) * ((size_t)n + 1));
   free(cia);
-  double *acc = (double *)xcalloc((size_t)m, sizeof(double));
-  for (int j = 0; j < m; j++) mark[j] = -1;
-  for (int i = 0; i < n; i++) {
-    obig q = C->ia[i];
-    for (obig ka = A->ia[i]; ka < A->ia[i + 1]; ka++) {
-      int k = A->ja[ka];
-      double av = A->a[ka];
-      for (obig kb = B->ia[k]; kb < B->ia[k + 1]; kb++) {
-        int j = B->ja[kb];
-        if (mark[j] != i) {
-          mark[j] = i;
-          C->ja[q++] = j;
-          acc[j] = av * B->a[kb];
-        } else
-          acc[j] += av * B->a[kb];
+#pragma omp parallel num_threads(nthr) if (nthr > 1)
+  {
+    int *mark = (int *)xmalloc(sizeof(int) * (size_t)m);
+    double *acc = (double *)xcalloc((size_t)m, sizeof(double));
+    for (int j = 0; j < m; j++) mark[j] = -1;
+#pragma omp for schedule(static)
+    for (int i = 0; i < n; i++) {
+      obig q = C->ia[i];
+      for (obig ka = A->ia[i]; ka < A->ia[i + 1]; ka++) {
+        int k = A->ja[ka];
+        double av = A->a[ka];
+        for (obig kb = B->ia[k]; kb < B->ia[k + 1]; kb++) {
+          int j = B->ja[kb];
+          if (mark[j] != i) {
+            mark[j] = i;
+            C->ja[q++] = j;
+            acc[j] = av * B->a[kb];
+          } else
+            acc[j] += av * B->a[kb];
+        }
       }
+      qsort(C->ja + C->ia[i], (size_t)(C->ia[i + 1] - C->ia[i]), sizeof(int), cmp_int);
+      for (obig k = C->ia[i]; k < C->ia[i + 1]; k++) C->a[k] = acc[C->ja[k]];
     }
-    qsort(C->ja + C->ia[i], (size_t)(C->ia[i + 1] - C->ia[i]), sizeof(int), cmp_int);
-    for (obig k = C->ia[i]; k < C->ia[i + 1]; k++) C->a[k] = acc[C->ja[k]];
+    free(acc);
+    free(mark);
   }
-  free(acc);
-  free(mark);
   return C;
 }
 
@@ -286,30 +314,41 @@ static int *part_of_rows(int n, int nparts, const obig *ps) {
 static void strength(const ocsr *A, double theta, double max_row_sum, obig **Sia_out, int **Sja_out) {
   const int n = A->nrows;
   obig *Sia = (obig *)xcalloc((size_t)n + 1, sizeof(obig));
-  int *Sja = (int *)xmalloc(sizeof(int) * (size_t)ocsr_nnz(A));
-  obig q = 0;
-  for (int i = 0; i < n; i++) {
-    double diag = 0.0, row_sum = 0.0, scale = 0.0;
-    for (obig k = A->ia[i]; k < A->ia[i + 1]; k++) {
-      row_sum += A->a[k];
-      if (A->ja[k] == i) diag = A->a[k];
+  /* pass 0 counts the strong entries of every row, pass 1 writes them (rows are independent) */
+  int *Sja = NULL;
+  for (int pass = 0; pass < 2; pass++) {
+    if (pass == 1) {
+      for (int i = 0; i < n; i++) Sia[i + 1] += Sia[i];
+      Sja = (int *)xmalloc(sizeof(int) * (size_t)(Sia[n] ? Sia[n] : 1));
     }
-    for (obig k = A->ia[i]; k < A->ia[i + 1]; k++) {
-      if (A->ja[k] == i) continue;
-      if (diag < 0) {
-        if (A->a[k] > scale) scale = A->a[k];
-      } else {
-        if (A->a[k] < scale) scale = A->a[k];
+#pragma omp parallel for schedule(static) num_threads(setup_threads()) if (setup_threads() > 1)
+    for (int i = 0; i < n; i++) {
+      double diag = 0.0, row_sum = 0.0, scale = 0.0;
+      for (obig k = A->ia[i]; k < A->ia[i + 1]; k++) {
+        row_sum += A->a[k];
+        if (A->ja[k] == i) diag = A->a[k];
       }
-    }
-    int all_weak = (fabs(row_sum) > fabs(diag) * max_row_sum) && (max_row_sum < 1.0);
-    if (!all_weak)
       for (obig k = A->ia[i]; k < A->ia[i + 1]; k++) {
         if (A->ja[k] == i) continue;
-        int strong = (diag < 0) ? (A->a[k] > theta * scale) : (A->a[k] < theta * scale);
-        if (strong) Sja[q++] = A->ja[k];
+        if (diag < 0) {
+          if (A->a[k] > scale) scale = A->a[k];
+        } else {
+          if (A->a[k] < scale) scale = A->a[k];
+        }
       }
-    Sia[i + 1] = q;
+      int all_weak = (fabs(row_sum) > fabs(diag) * max_row_sum) && (max_row_sum < 1.0);
+      obig q = pass ? Sia[i] : 0;
+      if (!all_weak)
+        for (obig k = A->ia[i]; k < A->ia[i + 1]; k++) {
+          if (A->ja[k] == i) continue;
+          int strong = (diag < 0) ? (A->a[k] > theta * scale) : (A->a[k] < theta * scale);
+          if (strong) {
+            if (pass) Sja[q] = A->ja[k];
+            q++;
+          }
+        }
+      if (!pass) Sia[i + 1] = q;
+    }
   }
   *Sia_out = Sia;
   *Sja_out = Sja;
@@ -713,13 +752,24 @@ static ocsr *build_interp(const ocsr *A, const obig *Sia, const int *Sja, int *c
   int nc = 0;
   for (int i = 0; i < n; i++) f2c[i] = (cf[i] == C_PT) ? nc++ : -1;
   *ncoarse_out = nc;
+  obig *pia = (obig *)xcalloc((size_t)n + 1, sizeof(obig));
+  /* rows are independent: each thread owns a contiguous range of rows (static schedule), its own marker array and
+   * its own output buffer; the buffers are concatenated in thread order afterwards */
+  const int nthr = setup_threads();
+  int **tpj = (int **)xcalloc((size_t)nthr, sizeof(int *));
+  double **tpa = (double **)xcalloc((size_t)nthr, sizeof(double *));
+  obig *tq = (obig *)xcalloc((size_t)nthr, sizeof(obig));
+  int *tfirst = (int *)xmalloc(sizeof(int) * (size_t)nthr);
+  for (int t = 0; t < nthr; t++) tfirst[t] = -1;
+#pragma omp parallel num_threads(nthr) if (nthr > 1)
+  {
+  const int tid = OTHREAD();
   int *Pmark = (int *)xmalloc(sizeof(int) * (size_t)n); /* position of fine col in current row, or marker */
   for (int i = 0; i < n; i++) Pmark[i] = -1;
   /* growing buffers */
-  obig cap = (obig)n * 4 + 16, q = 0;
+  obig cap = (obig)n * 4 / nthr + 64, q = 0;
   int *pj = (int *)xmalloc(sizeof(int) * (size_t)cap);
   double *pa = (double *)xmalloc(sizeof(double) * (size_t)cap);
-  obig *pia = (obig *)xcalloc((size_t)n + 1, sizeof(obig));
   int rowcap = 64;
   int *rc = (int *)xmalloc(sizeof(int) * (size_t)rowcap);
   double *rv = (double *)xmalloc(sizeof(double) * (size_t)rowcap);
@@ -734,8 +784,10 @@ static ocsr *build_interp(const ocsr *A, const obig *Sia, const int *Sja, int *c
       keep = (int *)realloc(keep, sizeof(int) * (size_t)rowcap);   \
     }                                                         \
   } while (0)
+#pragma omp for schedule(static)
   for (int i = 0; i < n; i++) {
     int len = 0;
+    if (tfirst[tid] < 0) tfirst[tid] = i;
     if (cf[i] == C_PT) {
       rc[0] = i;
       rv[0] = 1.0;
@@ -874,23 +926,40 @@ static ocsr *build_interp(const ocsr *A, const obig *Sia, const int *Sja, int *c
       pa[q] = rv[k];
       q++;
     }
-    pia[i + 1] = q;
+    pia[i + 1] = len;
   }
 #undef GROW_ROW
-  ocsr *P = (ocsr *)xmalloc(sizeof(ocsr));
-  P->nrows = n;
-  P->ncols = nc;
-  P->ia = pia;
-  P->ja = pj;
-  P->a = pa;
-  /* special F points act as plain F points from here on (par_amg_setup.c) */
-  for (int i = 0; i < n; i++)
-    if (cf[i] == SF_PT) cf[i] = F_PT;
-  free(f2c);
+  tpj[tid] = pj;
+  tpa[tid] = pa;
+  tq[tid] = q;
   free(Pmark);
   free(rc);
   free(rv);
   free(keep);
+  } /* parallel */
+  for (int i = 0; i < n; i++) pia[i + 1] += pia[i];
+  ocsr *P = (ocsr *)xmalloc(sizeof(ocsr));
+  P->nrows = n;
+  P->ncols = nc;
+  P->ia = pia;
+  P->ja = (int *)xmalloc(sizeof(int) * (size_t)(pia[n] ? pia[n] : 1));
+  P->a = (double *)xmalloc(sizeof(double) * (size_t)(pia[n] ? pia[n] : 1));
+  for (int t = 0; t < nthr; t++) {
+    if (tfirst[t] >= 0 && tq[t] > 0) {
+      memcpy(P->ja + pia[tfirst[t]], tpj[t], sizeof(int) * (size_t)tq[t]);
+      memcpy(P->a + pia[tfirst[t]], tpa[t], sizeof(double) * (size_t)tq[t]);
+    }
+    free(tpj[t]);
+    free(tpa[t]);
+  }
+  free(tpj);
+  free(tpa);
+  free(tq);
+  free(tfirst);
+  /* special F points act as plain F points from here on (par_amg_setup.c) */
+  for (int i = 0; i < n; i++)
+    if (cf[i] == SF_PT) cf[i] = F_PT;
+  free(f2c);
   return P;
 }
 
@@ -1169,6 +1238,7 @@ static ocsr *permute_csr(const ocsr *A, const int *rowpos, const int *rowperm, c
     const int i = rowperm ? rowperm[q] : q;
     B->ia[q + 1] = B->ia[q] + (A->ia[i + 1] - A->ia[i]);
   }
+#pragma omp parallel for schedule(static) num_threads(setup_threads()) if (setup_threads() > 1)
   for (int q = 0; q < n; q++) {
     const int i = rowperm ? rowperm[q] : q;
     const obig len = A->ia[i + 1] - A->ia[i];
@@ -1256,6 +1326,7 @@ oamg *oamg_setup(const ocsr *A0, const oamg_params *p) {
     h->L[0].part_starts[1] = A0->nrows;
   }
   h->p.part_starts = NULL;
+  double tph[6] = {0, 0, 0, 0, 0, 0};
   int l = 0;
   while (l < p->max_levels - 1 && h->L[l].A->nrows > p->max_coarse_size) {
     olevel *L = &h->L[l];
@@ -1263,7 +1334,10 @@ oamg *oamg_setup(const ocsr *A0, const oamg_params *p) {
     const int n = A->nrows;
     obig *Sia;
     int *Sja;
+    double tt = now_s();
     strength(A, p->strong_threshold, p->max_row_sum, &Sia, &Sja);
+    tph[0] += now_s() - tt;
+    tt = now_s();
     int *part_of = part_of_rows(n, nparts, L->part_starts);
     int *cf = (int *)xmalloc(sizeof(int) * (size_t)n);
     /* coarsening and interpolation are GLOBAL algorithms (independent of the row partition) */
@@ -1276,6 +1350,8 @@ oamg *oamg_setup(const ocsr *A0, const oamg_params *p) {
               p->agg_interp_type);
       abort();
     }
+    tph[1] += now_s() - tt;
+    tt = now_s();
     int nc = 0;
     for (int i = 0; i < n; i++) nc += (cf[i] == C_PT);
     if (nc == 0 || nc == n || nc < p->min_coarse_size) {
@@ -1293,9 +1369,12 @@ oamg *oamg_setup(const ocsr *A0, const oamg_params *p) {
     L->cf = cf;
     L->P = P;
     L->own_P = 1;
+    tph[2] += now_s() - tt;
+    tt = now_s();
     ocsr *R = ocsr_transpose(P);
     ocsr *AP = ocsr_matmul(A, P);
     ocsr *Ac = ocsr_matmul(R, AP);
+    tph[3] += now_s() - tt;
     ocsr_free(AP);
     ocsr_free(R);
     olevel *Ln = &h->L[l + 1];
@@ -1316,8 +1395,15 @@ oamg *oamg_setup(const ocsr *A0, const oamg_params *p) {
     l++;
   }
   h->nlev = l + 1;
+  double tt = now_s();
   apply_cf_ordering(h);
+  tph[4] += now_s() - tt;
+  tt = now_s();
   finish_levels(h);
+  tph[5] += now_s() - tt;
+  if (getenv("ORACLE_TIMING"))
+    fprintf(stderr, "oracle setup: strength %.2f  coarsen %.2f  interp %.2f  galerkin %.2f  ordering %.2f  finish %.2f s\n",
+            tph[0], tph[1], tph[2], tph[3], tph[4], tph[5]);
   return h;
 }
 

@@ -150,3 +150,38 @@ def test_benchmark_size_512(mi):
     mi.call("HYPRE_ParVectorInnerProd", r.par, r.par, mi.C.byref(dot))
     rn = np.sqrt(dot.value) / np.linalg.norm(rhs)
     assert rn <= 1e-8 and abs(rn - gm.final_rel_res) <= 1e-10
+
+
+def test_config2_size_256(mi):
+    """BASELINE.json config 2 at its own size: laplace_3d 256^3 (16.8 M rows), GMRES(50)+BoomerAMG V-cycle on one
+    MI355X -- known answer x* = 1, true residual, Givens estimate == true residual, identical repeat solve; and the
+    side-line hierarchies (HMIS, aggressive coarsening) converge to the same answer at this size."""
+    n = 256
+    ndof = n ** 3
+    A, b, x, rhs = mi.build_laplace_system(n, n, n, 7)
+    bn = np.linalg.norm(rhs)
+    iters = {}
+    for name, kw in (("default", {}), ("hmis", dict(coarsen_type=10)), ("agg1", dict(agg_num_levels=1))):
+        amg = mi.BoomerAMG(print_level=0, **kw)
+        gm = mi.GMRES(tolerance=1e-8, max_iterations=100, kspace=50, print_level=0)
+        gm.set_precond(amg)
+        gm.setup(A, b, x)
+        hists = []
+        for _ in range(2 if name == "default" else 1):
+            x.fill(0.0)
+            assert gm.solve(A, b, x) == 0
+            hists.append(np.array(gm.residual_history()))
+        if name == "default":
+            assert np.array_equal(hists[0], hists[1])
+            assert 8 <= amg.num_levels <= 20 and 2.0 < amg.operator_complexity < 5.0
+        elif name == "agg1":
+            assert amg.operator_complexity < 2.0
+        iters[name] = gm.num_iterations
+        xs = x.get()
+        assert np.all(np.abs(xs - 1.0) < 1e-5)
+        r = mi.IJVector(0, ndof - 1, rhs)
+        mi.call("HYPRE_ParCSRMatrixMatvec", -1.0, A.par, x.par, 1.0, r.par)
+        rn = np.linalg.norm(r.get()) / bn
+        assert rn <= 1e-8 and abs(rn - gm.final_rel_res) <= 1e-10
+        amg.destroy()
+    assert 10 <= iters["default"] <= 25 and iters["hmis"] <= 25 and iters["agg1"] <= 45
