@@ -66,7 +66,25 @@ def physical_cores():
                 pairs.add((pkg, int(line.split(":")[1])))
     except (OSError, ValueError):
         pairs = set()
-    return max(1, min(len(pairs) or len(allowed), len(allowed)))
+    cores = max(1, min(len(pairs) or len(allowed), len(allowed)))
+    # a container's CPU quota (cgroup cpu.max) is what the threads can actually use: more threads than that are
+    # throttled, not faster (the one-GPU boxes of this pool grant 16 CPUs of a 2 x 64-core host)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = int(q) / int(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota:
+        cores = max(1, min(cores, int(quota + 0.5)))
+    return cores
 
 
 def cpu_baseline(args, chunk):
@@ -117,9 +135,10 @@ def cpu_baseline(args, chunk):
         "cores": cores,
         "kind": "port",
         "sample": f"laplace_3d {n}^3 {args.stencil}-pt, GMRES({args.kdim})+AMG tol {args.tol:g}: "
-                  f"{info['iters']} iterations in {t_solve:.2f} s solve (+{t_setup:.2f} s setup on min({cores}, 32) threads), "
-                  f"rel res {info['rel_res']:.2e}; HYPRE-algorithm CPU restatement (oracle/), OpenMP {cores} threads of "
-                  f"{os.cpu_count()} visible on {cpu_model}{one_thread}",
+                  f"{info['iters']} iterations in {t_solve:.2f} s solve (+{t_setup:.2f} s setup on {min(cores, 32)} threads), "
+                  f"rel res {info['rel_res']:.2e}; HYPRE-algorithm CPU restatement (oracle/), OpenMP {cores} threads = all "
+                  f"physical cores this container may use (CPU quota / affinity; {os.cpu_count()} logical CPUs visible) on "
+                  f"{cpu_model}{one_thread}",
         "iterations": info["iters"],
         "iterations_per_s": info["iters"] / t_solve,
     }

@@ -155,6 +155,10 @@ struct BoomerAMG {
   void setup_host(ParCSR &A);
   void build_natural(ParCSR &A);      // strength / PMIS / interpolation / Galerkin loop, natural ordering
   void build_replicated(ParCSR &A);   // N > 1: global hierarchy on every rank, then this rank's row slices
+  // N > 1: the same hierarchy built with O(N_global / P) per rank (amg_setup_dist.cpp); PMIS without aggressive
+  // levels (the Ruge-Stueben family is sequential on the global graph: replicated path)
+  void build_distributed(ParCSR &A);
+  bool can_build_distributed() const;
   void make_local_transfer_operators();
   void finish_host();                 // l1 norms, coarsest-level dense inverse
   // device mirror of the hierarchy (needs a GPU)
@@ -185,6 +189,11 @@ void set_zero_skip_mode(int mode);  // applies to hierarchies set up afterwards 
 // set by a Krylov solver right before it calls the preconditioner with x == 0,
 // consumed (and cleared) by BoomerAMG::solve
 bool &zero_guess_hint();
+
+// counters of the distributed setup (HYPRE_MI_GetCounter): largest per-rank extended sub-problem (rows), global rows
+// gathered on every rank (the redundant tail only), number of distributed setups; -1 = unknown name
+long long dist_setup_counter(const char *name);
+void dist_setup_counters_reset();
 
 // host algorithms (amg_setup.cpp), exposed for tests
 void host_transpose(const HostCSR &A, HostCSR &T);

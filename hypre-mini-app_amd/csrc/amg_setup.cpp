@@ -13,13 +13,13 @@
 #include <cstring>
 
 #include "amg.hpp"
+#include "amg_setup_internal.hpp"
 #include "kernels.hpp"
 
 namespace mi {
 
-namespace {
+namespace hs {  // host setup algorithms, shared with amg_setup_dist.cpp (amg_setup_internal.hpp)
 
-constexpr int C_PT = 1, F_PT = -1, SF_PT = -3;
 constexpr int MAX_DENSE = 4096;
 
 // hypre_SeedRand / hypre_Rand (Park-Miller minimal standard)
@@ -33,11 +33,6 @@ struct ParkMiller {
     seed = (t > 0) ? t : t + m;
     return (double)seed / m;
   }
-};
-
-struct Strength {
-  std::vector<int64_t> ia;
-  std::vector<int> ja;
 };
 
 // strong iff a_ij < theta*min_k a_ik (a_ii > 0; mirrored for a_ii < 0); the row
@@ -208,7 +203,7 @@ int truncate_row(int len, int *cols, double *vals, double trunc_factor, int pmax
 // interpolation of the rank-local block; halo entries are lumped into the
 // diagonal like weak connections
 void build_interp(const ParCSR &A, const Strength &S, std::vector<int> &cf, int interp_type, double trunc_factor,
-                  int pmax, HostCSR &P, int &nc_out) {
+                  int pmax, HostCSR &P, int &nc_out, const std::vector<char> *want_rows) {
   const HostCSR &D = A.diag, &O = A.offd;
   const int n = D.nrows;
   std::vector<int> f2c((size_t)n, -1);
@@ -239,7 +234,9 @@ void build_interp(const ParCSR &A, const Strength &S, std::vector<int> &cf, int 
       rc.clear();
       rv.clear();
       sf.clear();
-      if (cf[(size_t)i] == C_PT) {
+      if (want_rows && !(*want_rows)[(size_t)i]) {
+        // a row of the extended sub-problem that belongs to another rank: left empty
+      } else if (cf[(size_t)i] == C_PT) {
         rc.push_back((int)i);
         rv.push_back(1.0);
       } else if (cf[(size_t)i] != SF_PT) {
@@ -361,8 +358,9 @@ void build_interp(const ParCSR &A, const Strength &S, std::vector<int> &cf, int 
     memcpy(P.ja.data() + off, tj[(size_t)t].data(), tj[(size_t)t].size() * sizeof(int));
     memcpy(P.a.data() + off, ta[(size_t)t].data(), ta[(size_t)t].size() * sizeof(double));
   }
-  for (int i = 0; i < n; i++)
-    if (cf[(size_t)i] == SF_PT) cf[(size_t)i] = F_PT;
+  if (!want_rows)
+    for (int i = 0; i < n; i++)
+      if (cf[(size_t)i] == SF_PT) cf[(size_t)i] = F_PT;
 }
 
 // ---- coarsening types beyond PMIS, and aggressive coarsening (mirrors oracle/oracle.c statement by statement)
@@ -829,7 +827,8 @@ void level_norms(const ParCSR &A, const std::vector<int> &cf, const std::vector<
   });
 }
 
-}  // namespace
+}  // namespace hs
+using namespace hs;
 
 void host_transpose(const HostCSR &A, HostCSR &T) {
   T.nrows = A.ncols;
@@ -1128,7 +1127,9 @@ void BoomerAMG::setup_host(ParCSR &A0) {
   if (p.agg_num_levels > 0 && p.agg_interp_type != 4)
     fail(4, "BoomerAMGSetup: agg_interp_type " + std::to_string(p.agg_interp_type) +
                 " is not implemented (4 = multipass is); refusing to substitute another one");
-  if (comm.size > 1) {
+  if (comm.size > 1 && can_build_distributed()) {
+    build_distributed(A0);
+  } else if (comm.size > 1) {
     build_replicated(A0);
   } else {
     tail.reset();

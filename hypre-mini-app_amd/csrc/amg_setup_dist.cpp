@@ -1,0 +1,1077 @@
+// Distributed BoomerAMG setup on N > 1 ranks (SURVEY.md 8e "coarse levels inherit the partition", 8 f2;
+// partition rule: init_row_decomposition, /root/reference/src/HypreSystem.cpp:525-544).
+//
+// Coarsening, interpolation and the Galerkin product are GLOBAL algorithms here: the
+// hierarchy -- and with it the iteration count -- does not depend on the number of ranks.  The first
+// implementation got that by replication (every rank built the global hierarchy: O(N_global) memory and time per
+// rank, BoomerAMG::build_replicated).  This file builds the SAME hierarchy with O(N_global / P + halo) per rank:
+//
+//   strength        row-local (row scale and row sum see diag and halo entries alike)
+//   PMIS            measures |S^T_i| + rand_i with the halo part of S^T summed back to the owners, rand_i = element i
+//                   of the one global Park-Miller stream (jump-ahead by modular exponentiation); every round
+//                   exchanges the C/F state of the halo points and sends the "you lose" flags back
+//   interpolation   on a per-rank EXTENDED sub-problem: own rows + the rows of the halo points (fetched with
+//                   their strength flags) + the second-ring columns those rows touch, numbered in ascending
+//                   global order -- so stored order, discovery order and with them every floating-point sum are
+//                   the ones of the single-rank algorithm, and the existing routine (hs::build_interp) runs
+//                   unchanged on the extended CSR
+//   Galerkin        A*P with the P rows of the halo columns fetched from their owners; P^T by an exchange of the
+//                   entries whose coarse column lives elsewhere, sent together with the (A*P) row they multiply:
+//                   the owner of a coarse row evaluates R*(A*P) itself, in the single-rank order (bit-identical)
+//   ordering        C-first renumbering per rank; halo / transfer-operator columns are translated by asking
+//                   the owners for the new positions
+//
+// Below the redundancy threshold (HYPRE_BoomerAMGSetSeqThreshold) the level is gathered and every rank builds
+// the small remaining hierarchy for itself, as before.  Ruge-Stueben coarsening and aggressive coarsening are
+// sequential / two-generation algorithms on the global graph: on N > 1 they keep the replicated path.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "amg.hpp"
+#include "amg_setup_internal.hpp"
+
+namespace mi {
+using namespace hs;
+
+namespace {
+
+long long g_ext_rows_max = 0, g_global_rows_gathered = 0, g_dist_setups = 0;
+
+// this rank's rows of a distributed operator: GLOBAL column ids, ascending inside a row
+struct GlobCSR {
+  int nrows = 0;
+  std::vector<int64_t> ia;
+  std::vector<gidx> gj;
+  std::vector<double> a;
+  int64_t nnz() const { return ia.empty() ? 0 : ia.back(); }
+};
+
+int rank_of_id(const std::vector<gidx> &starts, gidx g) {
+  return (int)(std::upper_bound(starts.begin(), starts.end(), g) - starts.begin()) - 1;
+}
+
+template <class T>
+void put(std::vector<char> &buf, const T *p, size_t n) {
+  const size_t off = buf.size();
+  buf.resize(off + n * sizeof(T));
+  if (n) memcpy(buf.data() + off, p, n * sizeof(T));
+}
+template <class T>
+void put1(std::vector<char> &buf, T v) {
+  put(buf, &v, 1);
+}
+struct Reader {
+  const char *p, *e;
+  explicit Reader(const std::vector<char> &b) : p(b.data()), e(b.data() + b.size()) {}
+  template <class T>
+  T get() {
+    T v;
+    MI_REQUIRE(p + sizeof(T) <= e, "distributed setup: short message");
+    memcpy(&v, p, sizeof(T));
+    p += sizeof(T);
+    return v;
+  }
+  template <class T>
+  void get(T *out, size_t n) {
+    MI_REQUIRE(p + n * sizeof(T) <= e, "distributed setup: short message");
+    if (n) memcpy(out, p, n * sizeof(T));
+    p += n * sizeof(T);
+  }
+  bool done() const { return p >= e; }
+};
+
+// Neighbour plan for a sorted set of remote ids of a vector partitioned by `starts`: who owns them (receive side)
+// and which of my entries the others asked for (send side).  hypre_ParCSRCommPkg for an arbitrary id set.
+struct Ring {
+  std::vector<gidx> ids;  // the remote ids, ascending (so the ids of one owner are contiguous)
+  std::vector<int> recv_peers, recv_starts, send_peers, send_starts, send_map;
+  gidx my0 = 0;
+
+  void build(Comm &comm, const std::vector<gidx> &starts, std::vector<gidx> need) {
+    ids.swap(need);
+    my0 = starts[(size_t)comm.rank];
+    const gidx my1 = starts[(size_t)comm.rank + 1];
+    recv_peers.clear(), recv_starts.assign(1, 0), send_peers.clear(), send_starts.assign(1, 0), send_map.clear();
+    for (size_t k = 0; k < ids.size(); k++) {
+      const int o = rank_of_id(starts, ids[k]);
+      MI_REQUIRE(o >= 0 && o < comm.size && o != comm.rank, "distributed setup: remote id without an owner");
+      if (recv_peers.empty() || recv_peers.back() != o) {
+        if (!recv_peers.empty()) recv_starts.push_back((int)k);
+        recv_peers.push_back(o);
+      }
+    }
+    if (!recv_peers.empty()) recv_starts.push_back((int)ids.size());
+    if (recv_peers.empty()) recv_starts.assign(1, 0);
+    std::vector<std::vector<char>> req(recv_peers.size());
+    for (size_t i = 0; i < recv_peers.size(); i++)
+      put(req[i], ids.data() + recv_starts[i], (size_t)(recv_starts[i + 1] - recv_starts[i]));
+    std::vector<int> from;
+    std::vector<std::vector<char>> got;
+    comm.exchange_host(recv_peers, req, from, got);
+    for (size_t i = 0; i < from.size(); i++) {
+      const size_t cnt = got[i].size() / sizeof(gidx);
+      const gidx *g = reinterpret_cast<const gidx *>(got[i].data());
+      for (size_t k = 0; k < cnt; k++) {
+        MI_REQUIRE(g[k] >= my0 && g[k] < my1, "distributed setup: a peer asked for an entry this rank does not own");
+        send_map.push_back((int)(g[k] - my0));
+      }
+      send_peers.push_back(from[i]);
+      send_starts.push_back((int)send_map.size());
+    }
+  }
+  int slot_of(gidx g) const {  // position of a remote id in `ids`
+    return (int)(std::lower_bound(ids.begin(), ids.end(), g) - ids.begin());
+  }
+  // values of my entries -> their halo copies
+  template <class T>
+  std::vector<T> forward(Comm &comm, const std::vector<T> &local) const {
+    std::vector<T> ext(ids.size());
+    std::vector<std::vector<char>> send(send_peers.size());
+    for (size_t i = 0; i < send_peers.size(); i++) {
+      send[i].resize((size_t)(send_starts[i + 1] - send_starts[i]) * sizeof(T));
+      T *o = reinterpret_cast<T *>(send[i].data());
+      for (int k = send_starts[i]; k < send_starts[i + 1]; k++) o[k - send_starts[i]] = local[(size_t)send_map[(size_t)k]];
+    }
+    std::vector<int> from;
+    std::vector<std::vector<char>> got;
+    comm.exchange_host(send_peers, send, from, got);
+    for (size_t i = 0; i < from.size(); i++) {
+      const size_t pi = (size_t)(std::find(recv_peers.begin(), recv_peers.end(), from[i]) - recv_peers.begin());
+      MI_REQUIRE(pi < recv_peers.size(), "distributed setup: unexpected sender");
+      const size_t cnt = (size_t)(recv_starts[pi + 1] - recv_starts[pi]);
+      MI_REQUIRE(got[i].size() == cnt * sizeof(T), "distributed setup: halo message of the wrong size");
+      memcpy(ext.data() + recv_starts[pi], got[i].data(), got[i].size());
+    }
+    return ext;
+  }
+  // one value per halo id -> the owners, folded into their entries
+  template <class T, class F>
+  void reverse(Comm &comm, const std::vector<T> &ext, std::vector<T> &local, F fold) const {
+    std::vector<std::vector<char>> send(recv_peers.size());
+    for (size_t i = 0; i < recv_peers.size(); i++)
+      put(send[i], ext.data() + recv_starts[i], (size_t)(recv_starts[i + 1] - recv_starts[i]));
+    std::vector<int> from;
+    std::vector<std::vector<char>> got;
+    comm.exchange_host(recv_peers, send, from, got);
+    for (size_t i = 0; i < from.size(); i++) {
+      const size_t pi = (size_t)(std::find(send_peers.begin(), send_peers.end(), from[i]) - send_peers.begin());
+      MI_REQUIRE(pi < send_peers.size(), "distributed setup: unexpected sender");
+      const size_t cnt = (size_t)(send_starts[pi + 1] - send_starts[pi]);
+      MI_REQUIRE(got[i].size() == cnt * sizeof(T), "distributed setup: reverse halo message of the wrong size");
+      const T *v = reinterpret_cast<const T *>(got[i].data());
+      for (size_t k = 0; k < cnt; k++) fold(local[(size_t)send_map[(size_t)send_starts[pi] + k]], v[k]);
+    }
+  }
+  // a variable-size record of every row the peers asked for -> per receive peer one byte string holding the
+  // records of its ids in ascending id order
+  template <class Pack>
+  std::vector<std::vector<char>> forward_records(Comm &comm, Pack pack) const {
+    std::vector<std::vector<char>> send(send_peers.size());
+    for (size_t i = 0; i < send_peers.size(); i++)
+      for (int k = send_starts[i]; k < send_starts[i + 1]; k++) pack(send_map[(size_t)k], send[i]);
+    std::vector<int> from;
+    std::vector<std::vector<char>> got;
+    comm.exchange_host(send_peers, send, from, got);
+    std::vector<std::vector<char>> out(recv_peers.size());
+    for (size_t i = 0; i < from.size(); i++) {
+      const size_t pi = (size_t)(std::find(recv_peers.begin(), recv_peers.end(), from[i]) - recv_peers.begin());
+      MI_REQUIRE(pi < recv_peers.size(), "distributed setup: unexpected sender");
+      out[pi].swap(got[i]);
+    }
+    return out;
+  }
+};
+
+// element `index` (0-based) of the Park-Miller stream seeded with `seed`: seed * 16807^(index+1) mod (2^31 - 1)
+int park_miller_at(int seed, long long index) {
+  const unsigned long long m = 2147483647ULL;
+  unsigned long long base = 16807ULL, acc = (unsigned long long)(seed ? seed : 13579) % m;
+  unsigned long long e = (unsigned long long)index + 1ULL;
+  while (e) {
+    if (e & 1ULL) acc = (acc * base) % m;
+    base = (base * base) % m;
+    e >>= 1;
+  }
+  return (int)acc;
+}
+
+// one level of the hierarchy while it is being built (natural ordering, global ids)
+struct DLevel {
+  std::vector<gidx> starts;  // row partition
+  GlobCSR A;
+  std::vector<char> strong;  // per entry of A
+  Ring ring;                 // halo of A: its remote columns
+  std::vector<int> cf;       // local rows (special F already turned into F)
+  std::vector<gidx> cgid;    // local rows: global coarse id of a C point, -1 otherwise
+  GlobCSR P;                 // my fine rows x global coarse ids
+  GlobCSR R;                 // my coarse rows x global fine ids
+  bool has_cf = false;
+  gidx n0() const { return starts.empty() ? 0 : starts.front(); }
+};
+
+// index set {local range} u {sorted remote ids}, numbered in ascending global order
+struct ExtIndex {
+  gidx s = 0, e = 0;
+  std::vector<gidx> remote;  // sorted unique, none in [s, e)
+  int nbelow = 0;
+  void finish() { nbelow = (int)(std::lower_bound(remote.begin(), remote.end(), s) - remote.begin()); }
+  int size() const { return (int)(e - s) + (int)remote.size(); }
+  int of(gidx g) const {
+    if (g >= s && g < e) return nbelow + (int)(g - s);
+    const int q = (int)(std::lower_bound(remote.begin(), remote.end(), g) - remote.begin());
+    return g < s ? q : q + (int)(e - s);
+  }
+  gidx global(int idx) const {
+    if (idx < nbelow) return remote[(size_t)idx];
+    if (idx < nbelow + (int)(e - s)) return s + (idx - nbelow);
+    return remote[(size_t)(idx - (int)(e - s))];
+  }
+};
+
+void sort_unique(std::vector<gidx> &v) {
+  std::sort(v.begin(), v.end());
+  v.erase(std::unique(v.begin(), v.end()), v.end());
+}
+
+// rows in `order` (local row ids; empty = natural), columns translated through `newcol` (one new GLOBAL id per
+// entry of M) and sorted, split at this rank's column range into the diag / halo blocks of a ParCSR
+std::unique_ptr<ParCSR> assemble_rows(const GlobCSR &M, const std::vector<int> &order, const std::vector<gidx> &newcol,
+                                      const std::vector<gidx> &row_starts, const std::vector<gidx> &col_starts, int rank) {
+  std::unique_ptr<ParCSR> Q(new ParCSR());
+  const int n = M.nrows;
+  const gidx c0 = col_starts[(size_t)rank], c1 = col_starts[(size_t)rank + 1];
+  Q->nrows = n;
+  Q->row_starts = row_starts;
+  Q->col_starts = col_starts;
+  Q->row_start = row_starts[(size_t)rank];
+  Q->row_end = row_starts[(size_t)rank + 1];
+  HostCSR &D = Q->diag, &O = Q->offd;
+  D.nrows = O.nrows = n;
+  D.ncols = (int)(c1 - c0);
+  D.ia.assign((size_t)n + 1, 0);
+  O.ia.assign((size_t)n + 1, 0);
+  for (int q = 0; q < n; q++) {
+    const int i = order.empty() ? q : order[(size_t)q];
+    int nd = 0;
+    for (int64_t k = M.ia[(size_t)i]; k < M.ia[(size_t)i + 1]; k++) nd += (newcol[(size_t)k] >= c0 && newcol[(size_t)k] < c1);
+    D.ia[(size_t)q + 1] = D.ia[(size_t)q] + nd;
+    O.ia[(size_t)q + 1] = O.ia[(size_t)q] + (M.ia[(size_t)i + 1] - M.ia[(size_t)i] - nd);
+  }
+  D.ja.resize((size_t)D.nnz());
+  D.a.resize((size_t)D.nnz());
+  O.ja.resize((size_t)O.nnz());
+  O.a.resize((size_t)O.nnz());
+  std::vector<gidx> ogid((size_t)O.nnz());
+  parallel_for(n, [&](int64_t b, int64_t e, int) {
+    std::vector<std::pair<gidx, double>> row;
+    for (int64_t q = b; q < e; q++) {
+      const int i = order.empty() ? (int)q : order[(size_t)q];
+      row.clear();
+      for (int64_t k = M.ia[(size_t)i]; k < M.ia[(size_t)i + 1]; k++) row.push_back({newcol[(size_t)k], M.a[(size_t)k]});
+      std::sort(row.begin(), row.end(),
+                [](const std::pair<gidx, double> &x, const std::pair<gidx, double> &y) { return x.first < y.first; });
+      int64_t pd = D.ia[(size_t)q], po = O.ia[(size_t)q];
+      for (auto &en : row) {
+        if (en.first >= c0 && en.first < c1) {
+          D.ja[(size_t)pd] = (int)(en.first - c0);
+          D.a[(size_t)pd++] = en.second;
+        } else {
+          ogid[(size_t)po] = en.first;
+          O.a[(size_t)po++] = en.second;
+        }
+      }
+    }
+  });
+  Q->col_map_offd = ogid;
+  sort_unique(Q->col_map_offd);
+  for (size_t k = 0; k < ogid.size(); k++)
+    O.ja[k] = (int)(std::lower_bound(Q->col_map_offd.begin(), Q->col_map_offd.end(), ogid[k]) - Q->col_map_offd.begin());
+  O.ncols = (int)Q->col_map_offd.size();
+  return Q;
+}
+
+// wrap an extended-index CSR as the single-rank operator the host routines expect
+void as_single_rank(HostCSR &&M, ParCSR &Q) {
+  Q.nrows = M.nrows;
+  Q.row_start = 0;
+  Q.row_end = M.nrows;
+  Q.row_starts = {0, (gidx)M.nrows};
+  Q.offd.nrows = M.nrows;
+  Q.offd.ncols = 0;
+  Q.offd.ia.assign((size_t)M.nrows + 1, 0);
+  Q.diag = std::move(M);
+}
+
+}  // namespace
+
+long long dist_setup_counter(const char *name) {
+  const std::string n(name);
+  if (n == "setup_ext_rows_max") return g_ext_rows_max;
+  if (n == "setup_global_rows_gathered") return g_global_rows_gathered;
+  if (n == "setup_distributed") return g_dist_setups;
+  return -1;
+}
+void dist_setup_counters_reset() { g_ext_rows_max = g_global_rows_gathered = g_dist_setups = 0; }
+
+bool BoomerAMG::can_build_distributed() const {
+  static const bool forced_off = getenv("MI_HYPRE_REPLICATED_SETUP") && atoi(getenv("MI_HYPRE_REPLICATED_SETUP")) != 0;
+  return !forced_off && p.coarsen_type == 8 && p.agg_num_levels <= 0;
+}
+
+void BoomerAMG::build_distributed(ParCSR &A0) {
+  Comm &comm = my_comm();
+  const int rank = comm.rank, size = comm.size;
+  g_dist_setups++;
+  std::vector<DLevel> D;
+  D.reserve((size_t)std::max(2, p.max_levels + 1));
+  D.emplace_back();
+  D[0].starts = A0.row_starts;
+  {  // level 0: diag + halo blocks merged into one row of ascending global columns
+    GlobCSR &G = D[0].A;
+    const int n = A0.nrows;
+    G.nrows = n;
+    G.ia.assign((size_t)n + 1, 0);
+    for (int i = 0; i < n; i++)
+      G.ia[(size_t)i + 1] = G.ia[(size_t)i] + (A0.diag.ia[(size_t)i + 1] - A0.diag.ia[(size_t)i]) +
+                            (A0.offd.ia[(size_t)i + 1] - A0.offd.ia[(size_t)i]);
+    G.gj.resize((size_t)G.nnz());
+    G.a.resize((size_t)G.nnz());
+    parallel_for(n, [&](int64_t b, int64_t e, int) {
+      for (int64_t i = b; i < e; i++) {
+        int64_t w = G.ia[(size_t)i];
+        int64_t kd = A0.diag.ia[(size_t)i], ko = A0.offd.ia[(size_t)i];
+        const int64_t ed = A0.diag.ia[(size_t)i + 1], eo = A0.offd.ia[(size_t)i + 1];
+        while (kd < ed || ko < eo) {
+          const gidx gd = kd < ed ? A0.row_start + A0.diag.ja[(size_t)kd] : (gidx)-1;
+          const gidx go = ko < eo ? A0.col_map_offd[(size_t)A0.offd.ja[(size_t)ko]] : (gidx)-1;
+          if (ko >= eo || (kd < ed && gd < go)) {
+            G.gj[(size_t)w] = gd;
+            G.a[(size_t)w++] = A0.diag.a[(size_t)kd++];
+          } else {
+            G.gj[(size_t)w] = go;
+            G.a[(size_t)w++] = A0.offd.a[(size_t)ko++];
+          }
+        }
+      }
+    });
+  }
+  const long long red_rows = effective_redundant_rows();
+  bool has_tail = false;
+  int l = 0;
+  double tp0;
+  while (l < p.max_levels - 1 && D[(size_t)l].starts.back() > p.max_coarse_size) {
+    if (red_rows > 0 && l >= 1 && D[(size_t)l].starts.back() <= red_rows) {
+      has_tail = true;
+      break;
+    }
+    DLevel &Lv = D[(size_t)l];
+    const GlobCSR &A = Lv.A;
+    const int n = A.nrows;
+    const gidx s = Lv.starts[(size_t)rank], e = Lv.starts[(size_t)rank + 1];
+    const gidx N = Lv.starts.back();
+    MI_REQUIRE((gidx)n == e - s, "distributed setup: partition and rows disagree");
+
+    // ---- strength (par_strength.c), row-local
+    tp0 = wall_time();
+    Lv.strong.assign((size_t)A.nnz(), 0);
+    parallel_for(n, [&](int64_t b, int64_t en, int) {
+      for (int64_t i = b; i < en; i++) {
+        const gidx gi = s + i;
+        double diag = 0.0, row_sum = 0.0, scale = 0.0;
+        for (int64_t k = A.ia[(size_t)i]; k < A.ia[(size_t)i + 1]; k++) {
+          row_sum += A.a[(size_t)k];
+          if (A.gj[(size_t)k] == gi) diag = A.a[(size_t)k];
+        }
+        for (int64_t k = A.ia[(size_t)i]; k < A.ia[(size_t)i + 1]; k++) {
+          if (A.gj[(size_t)k] == gi) continue;
+          const double v = A.a[(size_t)k];
+          if (diag < 0) {
+            if (v > scale) scale = v;
+          } else {
+            if (v < scale) scale = v;
+          }
+        }
+        const bool all_weak = (std::fabs(row_sum) > std::fabs(diag) * p.max_row_sum) && (p.max_row_sum < 1.0);
+        if (all_weak) continue;
+        const double thr = p.strong_threshold * scale;
+        for (int64_t k = A.ia[(size_t)i]; k < A.ia[(size_t)i + 1]; k++) {
+          if (A.gj[(size_t)k] == gi) continue;
+          const double v = A.a[(size_t)k];
+          if ((diag < 0) ? (v > thr) : (v < thr)) Lv.strong[(size_t)k] = 1;
+        }
+      }
+    });
+    // halo of A
+    {
+      std::vector<gidx> need;
+      for (int64_t k = 0; k < A.nnz(); k++)
+        if (A.gj[(size_t)k] < s || A.gj[(size_t)k] >= e) need.push_back(A.gj[(size_t)k]);
+      sort_unique(need);
+      Lv.ring.build(comm, Lv.starts, std::move(need));
+    }
+    const Ring &ring = Lv.ring;
+    const int nh = (int)ring.ids.size();
+    // halo slot of every remote entry of A (reused by every pass below)
+    std::vector<int> hslot((size_t)A.nnz(), -1);
+    parallel_for(n, [&](int64_t b, int64_t en, int) {
+      for (int64_t i = b; i < en; i++)
+        for (int64_t k = A.ia[(size_t)i]; k < A.ia[(size_t)i + 1]; k++)
+          if (A.gj[(size_t)k] < s || A.gj[(size_t)k] >= e) hslot[(size_t)k] = ring.slot_of(A.gj[(size_t)k]);
+    });
+    t_phase[0] += wall_time() - tp0;
+
+    // ---- PMIS on the global graph (par_coarsen.c), one global random stream
+    tp0 = wall_time();
+    std::vector<int> cf((size_t)n, 0), cf_h;
+    {
+      std::vector<int> cnt((size_t)n, 0), cnt_h((size_t)nh, 0);
+      for (int i = 0; i < n; i++)
+        for (int64_t k = A.ia[(size_t)i]; k < A.ia[(size_t)i + 1]; k++) {
+          if (!Lv.strong[(size_t)k]) continue;
+          if (hslot[(size_t)k] < 0)
+            cnt[(size_t)(A.gj[(size_t)k] - s)]++;
+          else
+            cnt_h[(size_t)hslot[(size_t)k]]++;
+        }
+      ring.reverse(comm, cnt_h, cnt, [](int &mine, int v) { mine += v; });
+      std::vector<double> measure((size_t)n, 0.0);
+      if (n) {
+        int seed = park_miller_at(2747, s);  // element s of the stream; the following ones by the recurrence
+        for (int i = 0; i < n; i++) {
+          if (i) {
+            const int a = 16807, m = 2147483647, q = 127773, r = 2836;
+            const int lo = seed % q, hi = seed / q;
+            const int t = a * lo - r * hi;
+            seed = (t > 0) ? t : t + m;
+          }
+          measure[(size_t)i] = (double)cnt[(size_t)i] + (double)seed / 2147483647;
+        }
+      }
+      std::vector<int> graph;
+      for (int i = 0; i < n; i++) {
+        bool any = false;
+        for (int64_t k = A.ia[(size_t)i]; k < A.ia[(size_t)i + 1] && !any; k++) any = Lv.strong[(size_t)k] != 0;
+        if (!any) {
+          cf[(size_t)i] = SF_PT;
+          measure[(size_t)i] = 0.0;
+        } else if (measure[(size_t)i] < 1.0) {
+          cf[(size_t)i] = F_PT;
+          measure[(size_t)i] = 0.0;
+        } else
+          graph.push_back(i);
+      }
+      const std::vector<double> m_h = ring.forward(comm, measure);
+      cf_h = ring.forward(comm, cf);
+      std::vector<signed char> tmp((size_t)n, 0);
+      for (;;) {
+        long long left = (long long)graph.size();
+        comm.allreduce_host(&left, 1, CommDType::I64, CommOp::SUM);
+        if (left == 0) break;
+        std::vector<int> lose_h((size_t)nh, 1);  // 0: the halo point lost a comparison against one of my rows
+        for (int g : graph) tmp[(size_t)g] = 1;
+        for (int g : graph) {
+          const double mi_ = measure[(size_t)g];
+          for (int64_t k = A.ia[(size_t)g]; k < A.ia[(size_t)g + 1]; k++) {
+            if (!Lv.strong[(size_t)k]) continue;
+            const int h = hslot[(size_t)k];
+            if (h < 0) {
+              const int j = (int)(A.gj[(size_t)k] - s);
+              if (cf[(size_t)j] != 0) continue;
+              if (mi_ > measure[(size_t)j])
+                tmp[(size_t)j] = 0;
+              else if (measure[(size_t)j] > mi_)
+                tmp[(size_t)g] = 0;
+            } else {
+              if (cf_h[(size_t)h] != 0) continue;
+              if (mi_ > m_h[(size_t)h])
+                lose_h[(size_t)h] = 0;
+              else if (m_h[(size_t)h] > mi_)
+                tmp[(size_t)g] = 0;
+            }
+          }
+        }
+        {
+          std::vector<int> keep((size_t)n, 1);
+          ring.reverse(comm, lose_h, keep, [](int &mine, int v) { mine = std::min(mine, v); });
+          for (int g : graph)
+            if (!keep[(size_t)g]) tmp[(size_t)g] = 0;
+        }
+        for (int g : graph)
+          if (tmp[(size_t)g] == 1) cf[(size_t)g] = C_PT;
+        cf_h = ring.forward(comm, cf);
+        std::vector<int> next;
+        for (int g : graph) {
+          if (cf[(size_t)g] != 0) continue;
+          bool dep_c = false;
+          for (int64_t k = A.ia[(size_t)g]; k < A.ia[(size_t)g + 1] && !dep_c; k++) {
+            if (!Lv.strong[(size_t)k]) continue;
+            const int h = hslot[(size_t)k];
+            dep_c = h < 0 ? cf[(size_t)(A.gj[(size_t)k] - s)] == C_PT : cf_h[(size_t)h] == C_PT;
+          }
+          if (dep_c)
+            tmp[(size_t)g] = 2;  // becomes F once the scan is over (the scan sees this round's C points only)
+          else
+            next.push_back(g);
+        }
+        for (int g : graph)
+          if (tmp[(size_t)g] == 2) cf[(size_t)g] = F_PT;
+        graph.swap(next);
+        cf_h = ring.forward(comm, cf);
+      }
+    }
+    long long nc_loc = 0;
+    for (int i = 0; i < n; i++) nc_loc += (cf[(size_t)i] == C_PT);
+    long long nc_glob = nc_loc;
+    comm.allreduce_host(&nc_glob, 1, CommDType::I64, CommOp::SUM);
+    t_phase[1] += wall_time() - tp0;
+    if (nc_glob == 0 || nc_glob == N || nc_glob < p.min_coarse_size) break;
+
+    // ---- coarse partition: the owner of a C point owns its coarse unknown
+    tp0 = wall_time();
+    D.emplace_back();  // D was reserved: Lv / A / ring stay valid
+    DLevel &Ln = D[(size_t)l + 1];
+    {
+      std::vector<long long> all((size_t)size, 0);
+      comm.allgather_host(&nc_loc, all.data(), sizeof(long long));
+      Ln.starts.assign((size_t)size + 1, 0);
+      for (int r = 0; r < size; r++) Ln.starts[(size_t)r + 1] = Ln.starts[(size_t)r] + all[(size_t)r];
+    }
+    const gidx cs = Ln.starts[(size_t)rank];
+    Lv.cgid.assign((size_t)n, -1);
+    {
+      gidx q = cs;
+      for (int i = 0; i < n; i++)
+        if (cf[(size_t)i] == C_PT) Lv.cgid[(size_t)i] = q++;
+    }
+    const std::vector<gidx> cgid_h = ring.forward(comm, Lv.cgid);
+
+    // ---- interpolation on the extended sub-problem
+    // rows of the halo points with, per entry, strength flag, C/F state and coarse id of the column
+    std::vector<std::vector<char>> hrows = ring.forward_records(comm, [&](int row, std::vector<char> &buf) {
+      const int64_t b = A.ia[(size_t)row], len = A.ia[(size_t)row + 1] - b;
+      put1<int>(buf, (int)len);
+      put(buf, A.gj.data() + b, (size_t)len);
+      put(buf, A.a.data() + b, (size_t)len);
+      put(buf, Lv.strong.data() + b, (size_t)len);
+      for (int64_t k = b; k < b + len; k++) {
+        const int h = hslot[(size_t)k];
+        put1<int>(buf, h < 0 ? cf[(size_t)(A.gj[(size_t)k] - s)] : cf_h[(size_t)h]);
+        put1<gidx>(buf, h < 0 ? Lv.cgid[(size_t)(A.gj[(size_t)k] - s)] : cgid_h[(size_t)h]);
+      }
+    });
+    struct HRow {
+      std::vector<gidx> col, cg;
+      std::vector<double> val;
+      std::vector<char> strong;
+      std::vector<int> cfc;
+    };
+    std::vector<HRow> H((size_t)nh);
+    {
+      ExtIndex X;
+      X.s = s, X.e = e;
+      X.remote = ring.ids;
+      for (size_t pi = 0; pi < hrows.size(); pi++) {
+        Reader rd(hrows[pi]);
+        for (int q = ring.recv_starts[pi]; q < ring.recv_starts[pi + 1]; q++) {
+          HRow &hr = H[(size_t)q];
+          const int len = rd.get<int>();
+          hr.col.resize((size_t)len), hr.val.resize((size_t)len), hr.strong.resize((size_t)len);
+          hr.cfc.resize((size_t)len), hr.cg.resize((size_t)len);
+          rd.get(hr.col.data(), (size_t)len);
+          rd.get(hr.val.data(), (size_t)len);
+          rd.get(hr.strong.data(), (size_t)len);
+          for (int k = 0; k < len; k++) {
+            hr.cfc[(size_t)k] = rd.get<int>();
+            hr.cg[(size_t)k] = rd.get<gidx>();
+            if (hr.col[(size_t)k] < s || hr.col[(size_t)k] >= e) X.remote.push_back(hr.col[(size_t)k]);
+          }
+        }
+      }
+      std::vector<std::vector<char>>().swap(hrows);
+      sort_unique(X.remote);
+      X.finish();
+      const int ne = X.size();
+      g_ext_rows_max = std::max<long long>(g_ext_rows_max, ne);
+      // extended operator, strength pattern, C/F state and coarse ids
+      HostCSR Ae;
+      Strength Se;
+      Ae.nrows = Ae.ncols = ne;
+      Ae.ia.assign((size_t)ne + 1, 0);
+      Se.ia.assign((size_t)ne + 1, 0);
+      std::vector<int> cfe((size_t)ne, F_PT);
+      std::vector<gidx> cge((size_t)ne, -1);
+      std::vector<char> want((size_t)ne, 0);
+      std::vector<int> hext((size_t)nh);
+      for (int q = 0; q < nh; q++) hext[(size_t)q] = X.of(ring.ids[(size_t)q]);
+      for (int i = 0; i < n; i++) {
+        const int x = X.nbelow + i;
+        Ae.ia[(size_t)x + 1] = A.ia[(size_t)i + 1] - A.ia[(size_t)i];
+        int ns = 0;
+        for (int64_t k = A.ia[(size_t)i]; k < A.ia[(size_t)i + 1]; k++) ns += Lv.strong[(size_t)k];
+        Se.ia[(size_t)x + 1] = ns;
+        cfe[(size_t)x] = cf[(size_t)i];
+        cge[(size_t)x] = Lv.cgid[(size_t)i];
+        want[(size_t)x] = 1;
+      }
+      std::vector<char> known(want);  // own rows and first-ring halo points: state known from the exchanges above
+      for (int q = 0; q < nh; q++) {
+        const int x = hext[(size_t)q];
+        known[(size_t)x] = 1;
+        Ae.ia[(size_t)x + 1] = (int64_t)H[(size_t)q].col.size();
+        int ns = 0;
+        for (char f : H[(size_t)q].strong) ns += f;
+        Se.ia[(size_t)x + 1] = ns;
+        cfe[(size_t)x] = cf_h[(size_t)q];
+        cge[(size_t)x] = cgid_h[(size_t)q];
+      }
+      for (int x = 0; x < ne; x++) {
+        Ae.ia[(size_t)x + 1] += Ae.ia[(size_t)x];
+        Se.ia[(size_t)x + 1] += Se.ia[(size_t)x];
+      }
+      Ae.ja.resize((size_t)Ae.nnz());
+      Ae.a.resize((size_t)Ae.nnz());
+      Se.ja.resize((size_t)Se.ia[(size_t)ne]);
+      parallel_for(n, [&](int64_t b, int64_t en, int) {
+        for (int64_t i = b; i < en; i++) {
+          const int x = X.nbelow + (int)i;
+          int64_t w = Ae.ia[(size_t)x], ws = Se.ia[(size_t)x];
+          for (int64_t k = A.ia[(size_t)i]; k < A.ia[(size_t)i + 1]; k++, w++) {
+            const int h = hslot[(size_t)k];
+            const int c = h < 0 ? X.nbelow + (int)(A.gj[(size_t)k] - s) : hext[(size_t)h];
+            Ae.ja[(size_t)w] = c;
+            Ae.a[(size_t)w] = A.a[(size_t)k];
+            if (Lv.strong[(size_t)k]) Se.ja[(size_t)ws++] = c;
+          }
+        }
+      });
+      for (int q = 0; q < nh; q++) {
+        const HRow &hr = H[(size_t)q];
+        const int x = hext[(size_t)q];
+        int64_t w = Ae.ia[(size_t)x], ws = Se.ia[(size_t)x];
+        for (size_t k = 0; k < hr.col.size(); k++, w++) {
+          const int c = X.of(hr.col[k]);
+          Ae.ja[(size_t)w] = c;
+          Ae.a[(size_t)w] = hr.val[k];
+          if (hr.strong[k]) Se.ja[(size_t)ws++] = c;
+          if (!known[(size_t)c]) {  // a second-ring column: its state came with the row
+            cfe[(size_t)c] = hr.cfc[k];
+            cge[(size_t)c] = hr.cg[k];
+          }
+        }
+      }
+      std::vector<HRow>().swap(H);
+      ParCSR Aw;
+      as_single_rank(std::move(Ae), Aw);
+      HostCSR Pe;
+      int nce = 0;
+      build_interp(Aw, Se, cfe, p.interp_type, p.trunc_factor, p.pmax_elmts, Pe, nce, &want);
+      // extended coarse index -> global coarse id (both ascend with the fine id)
+      std::vector<gidx> cmap((size_t)nce);
+      {
+        int q = 0;
+        for (int x = 0; x < ne; x++)
+          if (cfe[(size_t)x] == C_PT) cmap[(size_t)q++] = cge[(size_t)x];
+        MI_REQUIRE(q == nce, "distributed setup: coarse point count of the extended sub-problem");
+      }
+      GlobCSR &P = Lv.P;
+      P.nrows = n;
+      P.ia.assign((size_t)n + 1, 0);
+      for (int i = 0; i < n; i++)
+        P.ia[(size_t)i + 1] = P.ia[(size_t)i] + (Pe.ia[(size_t)(X.nbelow + i) + 1] - Pe.ia[(size_t)(X.nbelow + i)]);
+      P.gj.resize((size_t)P.nnz());
+      P.a.resize((size_t)P.nnz());
+      for (int i = 0; i < n; i++) {
+        int64_t w = P.ia[(size_t)i];
+        for (int64_t k = Pe.ia[(size_t)(X.nbelow + i)]; k < Pe.ia[(size_t)(X.nbelow + i) + 1]; k++, w++) {
+          P.gj[(size_t)w] = cmap[(size_t)Pe.ja[(size_t)k]];
+          MI_REQUIRE(P.gj[(size_t)w] >= 0, "distributed setup: interpolation from a point without a coarse id");
+          P.a[(size_t)w] = Pe.a[(size_t)k];
+        }
+      }
+    }
+    for (int i = 0; i < n; i++)
+      if (cf[(size_t)i] == SF_PT) cf[(size_t)i] = F_PT;
+    Lv.cf = cf;
+    Lv.has_cf = true;
+    t_phase[2] += wall_time() - tp0;
+
+    // ---- Galerkin product A_c = R (A P), every row in the single-rank order
+    tp0 = wall_time();
+    const GlobCSR &P = Lv.P;
+    GlobCSR AP;  // my fine rows x global coarse ids
+    {
+      std::vector<std::vector<char>> prow = ring.forward_records(comm, [&](int row, std::vector<char> &buf) {
+        const int64_t b = P.ia[(size_t)row], len = P.ia[(size_t)row + 1] - b;
+        put1<int>(buf, (int)len);
+        put(buf, P.gj.data() + b, (size_t)len);
+        put(buf, P.a.data() + b, (size_t)len);
+      });
+      // P restricted to rows {own} u {halo of A}, in ascending global row order
+      ExtIndex E1;
+      E1.s = s, E1.e = e, E1.remote = ring.ids;
+      E1.finish();
+      const int n1 = E1.size();
+      HostCSR Pe;
+      Pe.nrows = n1;
+      Pe.ia.assign((size_t)n1 + 1, 0);
+      std::vector<std::vector<gidx>> hc((size_t)nh);
+      std::vector<std::vector<double>> hv((size_t)nh);
+      for (size_t pi = 0; pi < prow.size(); pi++) {
+        Reader rd(prow[pi]);
+        for (int q = ring.recv_starts[pi]; q < ring.recv_starts[pi + 1]; q++) {
+          const int len = rd.get<int>();
+          hc[(size_t)q].resize((size_t)len), hv[(size_t)q].resize((size_t)len);
+          rd.get(hc[(size_t)q].data(), (size_t)len);
+          rd.get(hv[(size_t)q].data(), (size_t)len);
+        }
+      }
+      std::vector<gidx> CE(P.gj);
+      for (auto &v : hc) CE.insert(CE.end(), v.begin(), v.end());
+      sort_unique(CE);
+      auto cidx = [&](gidx g) { return (int)(std::lower_bound(CE.begin(), CE.end(), g) - CE.begin()); };
+      for (int x = 0; x < n1; x++) {
+        const gidx g = E1.global(x);
+        const int64_t len = (g >= s && g < e) ? P.ia[(size_t)(g - s) + 1] - P.ia[(size_t)(g - s)]
+                                               : (int64_t)hc[(size_t)ring.slot_of(g)].size();
+        Pe.ia[(size_t)x + 1] = Pe.ia[(size_t)x] + len;
+      }
+      Pe.ncols = (int)CE.size();
+      Pe.ja.resize((size_t)Pe.nnz());
+      Pe.a.resize((size_t)Pe.nnz());
+      parallel_for(n1, [&](int64_t b, int64_t en, int) {
+        for (int64_t x = b; x < en; x++) {
+          const gidx g = E1.global((int)x);
+          int64_t w = Pe.ia[(size_t)x];
+          if (g >= s && g < e) {
+            for (int64_t k = P.ia[(size_t)(g - s)]; k < P.ia[(size_t)(g - s) + 1]; k++, w++) {
+              Pe.ja[(size_t)w] = cidx(P.gj[(size_t)k]);
+              Pe.a[(size_t)w] = P.a[(size_t)k];
+            }
+          } else {
+            const int q = ring.slot_of(g);
+            for (size_t k = 0; k < hc[(size_t)q].size(); k++, w++) {
+              Pe.ja[(size_t)w] = cidx(hc[(size_t)q][k]);
+              Pe.a[(size_t)w] = hv[(size_t)q][k];
+            }
+          }
+        }
+      });
+      HostCSR Ae;
+      Ae.nrows = n;
+      Ae.ncols = n1;
+      Ae.ia.assign(A.ia.begin(), A.ia.end());
+      Ae.a = A.a;
+      Ae.ja.resize((size_t)A.nnz());
+      std::vector<int> hext((size_t)nh);
+      for (int q = 0; q < nh; q++) hext[(size_t)q] = E1.of(ring.ids[(size_t)q]);
+      parallel_for(n, [&](int64_t b, int64_t en, int) {
+        for (int64_t i = b; i < en; i++)
+          for (int64_t k = A.ia[(size_t)i]; k < A.ia[(size_t)i + 1]; k++)
+            Ae.ja[(size_t)k] = hslot[(size_t)k] < 0 ? E1.nbelow + (int)(A.gj[(size_t)k] - s) : hext[(size_t)hslot[(size_t)k]];
+      });
+      HostCSR APe;
+      host_spgemm(Ae, Pe, APe);
+      AP.nrows = n;
+      AP.ia = APe.ia;
+      AP.a.swap(APe.a);
+      AP.gj.resize(APe.ja.size());
+      for (size_t k = 0; k < APe.ja.size(); k++) AP.gj[k] = CE[(size_t)APe.ja[k]];
+    }
+    // transpose exchange: P entries whose coarse column lives elsewhere travel to its owner together with the
+    // (A P) row of their fine row
+    struct Incoming {
+      gidx fine;
+      std::vector<gidx> pc;  // coarse ids (mine)
+      std::vector<double> pv;
+      std::vector<gidx> ac;  // the fine row's (A P) row
+      std::vector<double> av;
+    };
+    std::vector<Incoming> inc;
+    {
+      std::vector<std::vector<char>> out((size_t)size);
+      std::vector<gidx> pc;
+      std::vector<double> pv;
+      for (int i = 0; i < n; i++) {
+        int64_t k = P.ia[(size_t)i];
+        const int64_t ke = P.ia[(size_t)i + 1];
+        while (k < ke) {
+          const int o = rank_of_id(Ln.starts, P.gj[(size_t)k]);
+          pc.clear(), pv.clear();
+          while (k < ke && P.gj[(size_t)k] < Ln.starts[(size_t)o + 1]) {  // columns ascend: one owner's run
+            pc.push_back(P.gj[(size_t)k]);
+            pv.push_back(P.a[(size_t)k]);
+            k++;
+          }
+          if (o == rank) continue;
+          std::vector<char> &buf = out[(size_t)o];
+          put1<gidx>(buf, s + i);
+          put1<int>(buf, (int)pc.size());
+          put(buf, pc.data(), pc.size());
+          put(buf, pv.data(), pv.size());
+          const int64_t ab = AP.ia[(size_t)i], alen = AP.ia[(size_t)i + 1] - ab;
+          put1<int>(buf, (int)alen);
+          put(buf, AP.gj.data() + ab, (size_t)alen);
+          put(buf, AP.a.data() + ab, (size_t)alen);
+        }
+      }
+      std::vector<int> peers;
+      std::vector<std::vector<char>> send;
+      for (int r = 0; r < size; r++)
+        if (!out[(size_t)r].empty()) {
+          peers.push_back(r);
+          send.emplace_back(std::move(out[(size_t)r]));
+        }
+      std::vector<int> from;
+      std::vector<std::vector<char>> got;
+      comm.exchange_host(peers, send, from, got);
+      for (auto &buf : got) {
+        Reader rd(buf);
+        while (!rd.done()) {
+          inc.emplace_back();
+          Incoming &in = inc.back();
+          in.fine = rd.get<gidx>();
+          const int np = rd.get<int>();
+          in.pc.resize((size_t)np), in.pv.resize((size_t)np);
+          rd.get(in.pc.data(), (size_t)np);
+          rd.get(in.pv.data(), (size_t)np);
+          const int na = rd.get<int>();
+          in.ac.resize((size_t)na), in.av.resize((size_t)na);
+          rd.get(in.ac.data(), (size_t)na);
+          rd.get(in.av.data(), (size_t)na);
+        }
+      }
+      std::sort(inc.begin(), inc.end(), [](const Incoming &x, const Incoming &y) { return x.fine < y.fine; });
+    }
+    {
+      const int ncl = (int)nc_loc;
+      ExtIndex E2;  // fine rows that reach my coarse rows: own rows + the senders' rows
+      E2.s = s, E2.e = e;
+      for (auto &in : inc) E2.remote.push_back(in.fine);
+      E2.finish();
+      const int n2 = E2.size();
+      g_ext_rows_max = std::max<long long>(g_ext_rows_max, n2);
+      std::vector<gidx> CE2(AP.gj);
+      for (auto &in : inc) CE2.insert(CE2.end(), in.ac.begin(), in.ac.end());
+      sort_unique(CE2);
+      auto cidx = [&](gidx g) { return (int)(std::lower_bound(CE2.begin(), CE2.end(), g) - CE2.begin()); };
+      // (A P) on the extended fine rows
+      HostCSR APe;
+      APe.nrows = n2;
+      APe.ncols = (int)CE2.size();
+      APe.ia.assign((size_t)n2 + 1, 0);
+      auto inc_of = [&](int x) -> const Incoming & { return inc[(size_t)(x < E2.nbelow ? x : x - n)]; };
+      for (int x = 0; x < n2; x++) {
+        const bool own = x >= E2.nbelow && x < E2.nbelow + n;
+        const int64_t len = own ? AP.ia[(size_t)(x - E2.nbelow) + 1] - AP.ia[(size_t)(x - E2.nbelow)] : (int64_t)inc_of(x).ac.size();
+        APe.ia[(size_t)x + 1] = APe.ia[(size_t)x] + len;
+      }
+      APe.ja.resize((size_t)APe.nnz());
+      APe.a.resize((size_t)APe.nnz());
+      parallel_for(n2, [&](int64_t b, int64_t en, int) {
+        for (int64_t x = b; x < en; x++) {
+          int64_t w = APe.ia[(size_t)x];
+          if (x >= E2.nbelow && x < E2.nbelow + n) {
+            const int64_t i = x - E2.nbelow;
+            for (int64_t k = AP.ia[(size_t)i]; k < AP.ia[(size_t)i + 1]; k++, w++) {
+              APe.ja[(size_t)w] = cidx(AP.gj[(size_t)k]);
+              APe.a[(size_t)w] = AP.a[(size_t)k];
+            }
+          } else {
+            const Incoming &in = inc_of((int)x);
+            for (size_t k = 0; k < in.ac.size(); k++, w++) {
+              APe.ja[(size_t)w] = cidx(in.ac[k]);
+              APe.a[(size_t)w] = in.av[k];
+            }
+          }
+        }
+      });
+      // R = P^T restricted to my coarse rows, columns = extended fine rows (ascending)
+      HostCSR Re;
+      Re.nrows = ncl;
+      Re.ncols = n2;
+      Re.ia.assign((size_t)ncl + 1, 0);
+      auto each_entry = [&](auto &&f) {  // (coarse local row, extended fine index, value), fine index ascending
+        for (int x = 0; x < n2; x++) {
+          if (x >= E2.nbelow && x < E2.nbelow + n) {
+            const int i = x - E2.nbelow;
+            for (int64_t k = P.ia[(size_t)i]; k < P.ia[(size_t)i + 1]; k++)
+              if (P.gj[(size_t)k] >= cs && P.gj[(size_t)k] < cs + ncl) f((int)(P.gj[(size_t)k] - cs), x, P.a[(size_t)k]);
+          } else {
+            const Incoming &in = inc_of(x);
+            for (size_t k = 0; k < in.pc.size(); k++) f((int)(in.pc[k] - cs), x, in.pv[k]);
+          }
+        }
+      };
+      each_entry([&](int r, int, double) { Re.ia[(size_t)r + 1]++; });
+      for (int r = 0; r < ncl; r++) Re.ia[(size_t)r + 1] += Re.ia[(size_t)r];
+      Re.ja.resize((size_t)Re.nnz());
+      Re.a.resize((size_t)Re.nnz());
+      {
+        std::vector<int64_t> pos(Re.ia.begin(), Re.ia.end() - 1);
+        each_entry([&](int r, int x, double v) {
+          Re.ja[(size_t)pos[(size_t)r]] = x;
+          Re.a[(size_t)pos[(size_t)r]++] = v;
+        });
+      }
+      HostCSR Ace;
+      host_spgemm(Re, APe, Ace);
+      GlobCSR &Ac = Ln.A;
+      Ac.nrows = ncl;
+      Ac.ia = Ace.ia;
+      Ac.a.swap(Ace.a);
+      Ac.gj.resize(Ace.ja.size());
+      for (size_t k = 0; k < Ace.ja.size(); k++) Ac.gj[k] = CE2[(size_t)Ace.ja[k]];
+      GlobCSR &R = Lv.R;
+      R.nrows = ncl;
+      R.ia = Re.ia;
+      R.a.swap(Re.a);
+      R.gj.resize(Re.ja.size());
+      for (size_t k = 0; k < Re.ja.size(); k++) R.gj[k] = E2.global(Re.ja[k]);
+    }
+    t_phase[3] += wall_time() - tp0;
+    l++;
+  }
+  const size_t nlev = D.size();
+
+  // ---- C-first ordering of every level with a splitting, and the final ParCSR blocks
+  tp0 = wall_time();
+  std::vector<std::vector<int>> pos(nlev), perm(nlev);
+  for (size_t li = 0; li < nlev; li++) {
+    const DLevel &Lv = D[li];
+    if (!Lv.has_cf) continue;
+    const int n = Lv.A.nrows;
+    pos[li].resize((size_t)n), perm[li].resize((size_t)n);
+    int q = 0;
+    for (int i = 0; i < n; i++)
+      if (Lv.cf[(size_t)i] == C_PT) pos[li][(size_t)i] = q++;
+    for (int i = 0; i < n; i++)
+      if (Lv.cf[(size_t)i] != C_PT) pos[li][(size_t)i] = q++;
+    for (int i = 0; i < n; i++) perm[li][(size_t)pos[li][(size_t)i]] = i;
+  }
+  // new global ids of the columns of M (ids of level `lev`)
+  auto translate = [&](const GlobCSR &M, size_t lev, const Ring *known_ring) {
+    std::vector<gidx> out(M.gj);
+    if (pos[lev].empty()) return out;
+    const std::vector<gidx> &st = D[lev].starts;
+    const gidx s = st[(size_t)rank], e = st[(size_t)rank + 1];
+    Ring own;
+    const Ring *rg = known_ring;
+    if (!rg) {
+      std::vector<gidx> need;
+      for (gidx g : M.gj)
+        if (g < s || g >= e) need.push_back(g);
+      sort_unique(need);
+      own.build(comm, st, std::move(need));
+      rg = &own;
+    }
+    const std::vector<int> pos_h = rg->forward(comm, pos[lev]);
+    parallel_for((int64_t)out.size(), [&](int64_t b, int64_t en, int) {
+      for (int64_t k = b; k < en; k++) {
+        const gidx g = M.gj[(size_t)k];
+        if (g >= s && g < e)
+          out[(size_t)k] = s + pos[lev][(size_t)(g - s)];
+        else
+          out[(size_t)k] = st[(size_t)rank_of_id(st, g)] + pos_h[(size_t)rg->slot_of(g)];
+      }
+    });
+    return out;
+  };
+  L.clear();
+  L.resize(nlev);
+  tail.reset();
+  tail_A.reset();
+  for (size_t li = 0; li < nlev; li++) {
+    DLevel &Lv = D[li];
+    AmgLevel &Out = L[li];
+    const int n = Lv.A.nrows;
+    const bool ring_ok = Lv.has_cf;  // the halo ring of A was built in the coarsening loop
+    Out.A_own = assemble_rows(Lv.A, perm[li], translate(Lv.A, li, ring_ok ? &Lv.ring : nullptr), Lv.starts, Lv.starts, rank);
+    Out.A = Out.A_own.get();
+    Out.A->build_halo_plan(comm);
+    Out.has_cf = Lv.has_cf;
+    if (Lv.has_cf) {
+      Out.perm = perm[li];
+      Out.cf.resize((size_t)n);
+      Out.nc = 0;
+      for (int q = 0; q < n; q++) {
+        Out.cf[(size_t)q] = Lv.cf[(size_t)perm[li][(size_t)q]];
+        Out.nc += (Out.cf[(size_t)q] == C_PT);
+      }
+      Out.Pm = assemble_rows(Lv.P, perm[li], translate(Lv.P, li + 1, nullptr), Lv.starts, D[li + 1].starts, rank);
+      // with a redundant tail the coarse correction is whole on every rank: no exchange for the last P
+      if (!(has_tail && li + 2 == nlev)) Out.Pm->build_halo_plan(comm);
+      Out.Rm = assemble_rows(Lv.R, perm[li + 1], translate(Lv.R, li, nullptr), D[li + 1].starts, Lv.starts, rank);
+      Out.Rm->build_halo_plan(comm);
+    }
+  }
+  if (has_tail) {
+    // the first redundant level: gathered once, then one single-rank hierarchy per rank (as before)
+    const DLevel &Ls = D[nlev - 1];
+    const gidx Ng = Ls.starts.back();
+    MI_REQUIRE(Ng < (gidx)2147483000, "redundant level exceeds int32");
+    g_global_rows_gathered += Ng;
+    std::vector<char> mine;
+    {
+      const GlobCSR &G = Ls.A;
+      std::vector<int> len((size_t)G.nrows);
+      for (int i = 0; i < G.nrows; i++) len[(size_t)i] = (int)(G.ia[(size_t)i + 1] - G.ia[(size_t)i]);
+      put(mine, len.data(), len.size());
+      put(mine, G.gj.data(), G.gj.size());
+      put(mine, G.a.data(), G.a.size());
+    }
+    std::vector<size_t> offs;
+    std::vector<char> everyone;
+    comm.allgatherv_host(mine.data(), mine.size(), offs, everyone);
+    tail_A.reset(new ParCSR());
+    HostCSR &G = tail_A->diag;
+    G.nrows = G.ncols = (int)Ng;
+    G.ia.assign((size_t)Ng + 1, 0);
+    for (int r = 0; r < size; r++) {
+      const gidx rs = Ls.starts[(size_t)r], re = Ls.starts[(size_t)r + 1];
+      const int *len = reinterpret_cast<const int *>(everyone.data() + offs[(size_t)r]);
+      for (gidx g = rs; g < re; g++) G.ia[(size_t)g + 1] = G.ia[(size_t)g] + len[(size_t)(g - rs)];
+    }
+    G.ja.resize((size_t)G.nnz());
+    G.a.resize((size_t)G.nnz());
+    for (int r = 0; r < size; r++) {
+      const gidx rs = Ls.starts[(size_t)r], re = Ls.starts[(size_t)r + 1];
+      if (re == rs) continue;
+      const size_t nr = (size_t)(re - rs), tot = (size_t)(G.ia[(size_t)re] - G.ia[(size_t)rs]);
+      const char *base = everyone.data() + offs[(size_t)r] + sizeof(int) * nr;
+      std::vector<gidx> cols(tot);
+      memcpy(cols.data(), base, tot * sizeof(gidx));
+      for (size_t k = 0; k < tot; k++) G.ja[(size_t)G.ia[(size_t)rs] + k] = (int)cols[k];
+      memcpy(G.a.data() + G.ia[(size_t)rs], base + tot * sizeof(gidx), tot * sizeof(double));
+    }
+    tail_A->nrows = (int)Ng;
+    tail_A->row_start = 0;
+    tail_A->row_end = Ng;
+    tail_A->row_starts = {0, Ng};
+    tail_A->offd.nrows = (int)Ng;
+    tail_A->offd.ncols = 0;
+    tail_A->offd.ia.assign((size_t)Ng + 1, 0);
+    tail.reset(new BoomerAMG());
+    tail->p = p;
+    tail->p.print_level = 0;
+    tail->p.max_levels = std::max(1, p.max_levels - (int)(nlev - 1));
+    tail->device_min_rows = device_min_rows;
+    tail->use_private_self_comm();
+    tail->setup_host(*tail_A);
+    tail_start = Ls.starts[(size_t)rank];
+    int slot = 0;
+    for (int r = 0; r < size; r++) slot = std::max(slot, (int)(Ls.starts[(size_t)r + 1] - Ls.starts[(size_t)r]));
+    tail_slot = slot;
+    std::vector<int> map((size_t)Ng);
+    for (int r = 0; r < size; r++)
+      for (gidx i = Ls.starts[(size_t)r]; i < Ls.starts[(size_t)r + 1]; i++) map[(size_t)i] = r * slot + (int)(i - Ls.starts[(size_t)r]);
+    tail_map_host.swap(map);
+  }
+  t_phase[4] += wall_time() - tp0;
+  if (p.print_level > 0 && rank == 0)
+    printf("mi_hypre BoomerAMG: distributed setup on %d ranks (%zu distributed levels%s; largest per-rank sub-problem %lld "
+           "rows of %lld global)\n",
+           size, nlev, has_tail ? " + redundant tail" : "", g_ext_rows_max, (long long)A0.global_rows());
+}
+
+}  // namespace mi

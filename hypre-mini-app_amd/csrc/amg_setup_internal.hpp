@@ -1,0 +1,24 @@
+// Host setup algorithms of amg_setup.cpp that the distributed setup (amg_setup_dist.cpp) runs on its
+// per-rank extended sub-problems.  Not part of any ABI.
+#pragma once
+#include "amg.hpp"
+
+namespace mi {
+namespace hs {
+
+constexpr int C_PT = 1, F_PT = -1, SF_PT = -3;
+
+// strength pattern of the diag block (columns ascending, a subsequence of the matrix row)
+struct Strength {
+  std::vector<int64_t> ia;
+  std::vector<int> ja;
+};
+
+void strength(const ParCSR &A, double theta, double max_row_sum, Strength &S);
+// interpolation rows of the single-rank operator A (diag block).  want_rows (optional): rows with a zero flag
+// are left empty and the special-F markers of cf are kept (the caller owns them)
+void build_interp(const ParCSR &A, const Strength &S, std::vector<int> &cf, int interp_type, double trunc_factor,
+                  int pmax, HostCSR &P, int &nc_out, const std::vector<char> *want_rows = nullptr);
+
+}  // namespace hs
+}  // namespace mi

@@ -1151,6 +1151,8 @@ HYPRE_Int HYPRE_MI_GetCounter(const char *name, long long *value) {
     *value = ctx().n_gs_overlapped;
   else if (n == "gs_in_order")
     *value = ctx().n_gs_in_order;
+  else if (dist_setup_counter(n.c_str()) >= 0)
+    *value = dist_setup_counter(n.c_str());
   else
     fail(HYPRE_ERROR_ARG, "GetCounter: unknown counter " + n);
   API_END

@@ -104,6 +104,29 @@ def main():
     else:
         amg.setup(A)
     assert amg.num_levels == oamg.num_levels, (amg.num_levels, oamg.num_levels)
+
+    # ---- which setup ran, and what it held per rank (SURVEY 8e "coarse levels inherit the partition")
+    def counter(name):
+        v = mi.C.c_longlong()
+        mi.call("HYPRE_MI_GetCounter", name.encode(), mi.C.byref(v))
+        return v.value
+
+    replicated = os.environ.get("MI_HYPRE_REPLICATED_SETUP", "0") not in ("", "0")
+    if size > 1 and not replicated:
+        assert counter("setup_distributed") >= 1, "the distributed setup did not run"
+        # per-rank memory: the largest extended sub-problem is this rank's rows plus two halo rings (for z-slabs of
+        # an n^3 grid: at most 2 x 2 planes on each side for the 7/27-point operators and their coarse grids,
+        # whose stencils reach a few planes), never the global operator; only levels below the redundancy
+        # threshold are gathered
+        nloc0 = starts[rank + 1] - starts[rank]
+        assert counter("setup_ext_rows_max") <= nloc0 + 8 * n * n, (counter("setup_ext_rows_max"), nloc0, N)
+        if N >= 8 * (nloc0 + 8 * n * n) // 4:
+            assert counter("setup_ext_rows_max") < N
+        gathered = counter("setup_global_rows_gathered")
+        assert gathered <= max(seq, 0), (gathered, seq)
+    elif size > 1:
+        assert counter("setup_distributed") == 0
+
     def coarse_partition(l):
         """Row partition of level l+1 as the product builds it: owner of the C point."""
         ps = oamg.level_part_starts(l)

@@ -17,8 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
 
 
-def _run(nproc, mode, n, stencil, port, staging="host", seq=-1, devmin=None, golden=""):
+def _run(nproc, mode, n, stencil, port, staging="host", seq=-1, devmin=None, golden="", replicated=False):
     env = dict(os.environ)
+    env["MI_HYPRE_REPLICATED_SETUP"] = "1" if replicated else "0"
     if devmin is not None:  # levels with at least this many rows are built (and sliced) on the device
         env["MI_HYPRE_DEVICE_SETUP_MIN_ROWS"] = str(devmin)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -38,7 +39,18 @@ def _run(nproc, mode, n, stencil, port, staging="host", seq=-1, devmin=None, gol
                                                   (4, 6, 7, 0),    # coarse levels leave ranks without rows
                                                   (8, 8, 7, 0), (8, 10, 7, -1)])  # the node size of the benchmark
 def test_host_setup_world_size_n_gloo(nproc, n, stencil, seq):
+    """The DISTRIBUTED setup (amg_setup_dist.cpp: distributed PMIS rounds, interpolation on the two-ring extended
+    sub-problem, R*(A*P) evaluated by the owners of the coarse rows): the same partition-independent hierarchy as
+    the oracle's, level by level, with per-rank sub-problems of local size (asserted by the worker)."""
     out = _run(nproc, "host", n, stencil, 29611 + nproc + (7 if seq > 0 else 0) + n, seq=seq)
+    assert "dist host setup ok" in out
+
+
+@pytest.mark.parametrize("nproc,n,stencil,seq", [(2, 12, 7, -1), (3, 10, 27, 0), (4, 6, 7, 0)])
+def test_host_setup_replicated_path_gloo(nproc, n, stencil, seq):
+    """The replicated setup (every rank builds the global hierarchy and keeps its slices) stays the path of the
+    Ruge-Stueben family and of aggressive coarsening on N > 1; MI_HYPRE_REPLICATED_SETUP=1 forces it."""
+    out = _run(nproc, "host", n, stencil, 29911 + nproc + n, seq=seq, replicated=True)
     assert "dist host setup ok" in out
 
 
@@ -55,7 +67,7 @@ def test_device_solve_shared_gpu(nproc, n, stencil, seq):
 def test_device_setup_and_slicing_shared_gpu(nproc, n, stencil, seq):
     """Every level of the global hierarchy built on the device and sliced there (the production path for
     large problems; the small grids of the other tests stay below the device threshold)."""
-    out = _run(nproc, "solve", n, stencil, 29731 + nproc + n, seq=seq, devmin=0)
+    out = _run(nproc, "solve", n, stencil, 29731 + nproc + n, seq=seq, devmin=0, replicated=True)
     assert "dist solve ok" in out
 
 
