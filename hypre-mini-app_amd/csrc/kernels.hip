@@ -753,7 +753,7 @@ __global__ __launch_bounds__(SPMV_BLOCK) void gs_tile_k(int blk0, int nblk, cons
   const int LPR = nr <= 32 ? 8 : nr <= 64 ? 4 : nr <= 128 ? 2 : 1;
   const int rl = tid / LPR, sub = tid % LPR;
   const int i = r0 + rl;
-  double myu = 0.0, myrhs = 0.0, wd = 0.0, myf = 0.0;
+  double myu = 0.0, myrhs = 0.0, wd = 0.0;
   bool rowsel = false;
   int s0 = 0, s1 = 0;
   if (rl < nr) {
@@ -762,7 +762,7 @@ __global__ __launch_bounds__(SPMV_BLOCK) void gs_tile_k(int blk0, int nblk, cons
     rowsel = (mark == points) && i >= row_begin && i < row_end;
     if (rowsel) {
       const double myd = dd[i];
-      myrhs = myf = f[i];
+      myrhs = f[i];
       if (offc) myrhs -= offc[i];
       if (myd != 0.0) wd = w / myd;
       s0 = ia[i] - base_al;
@@ -829,7 +829,8 @@ __global__ __launch_bounds__(SPMV_BLOCK) void gs_tile_k(int blk0, int nblk, cons
   }
   // F pass on a zero guess: S is exactly the row's product with the C values -- f - S is what the residual that
   // follows needs from those columns (BoomerAMG::cycle)
-  if (tout && rowsel && sub == 0 && i >= t_from) tout[i] = myf - S;
+  // (f is read again here rather than kept in two registers through the kernel: 66 -> 64 VGPRs = 8 waves per SIMD)
+  if (tout && rowsel && sub == 0 && i >= t_from) tout[i] = f[i] - S;
   double crow[8];
 #pragma unroll
   for (int j = 0; j < 8; j++) {

@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi_hypre.so")
+# MI_HYPRE_LIB: another build of the same library (A/B timing of kernel variants on one box); never a fallback
+LIB_PATH = os.environ.get("MI_HYPRE_LIB") or os.path.join(_HERE, "libmi_hypre.so")
 
 HYPRE_PARCSR = 5555
 HYPRE_MEMORY_DEVICE = 1
