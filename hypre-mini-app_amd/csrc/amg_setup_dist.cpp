@@ -303,6 +303,25 @@ void as_single_rank(HostCSR &&M, ParCSR &Q) {
   Q.diag = std::move(M);
 }
 
+// C = A * B for the extended sub-problems: the device SpGEMM (same accumulation order, bit-identical:
+// tests/test_gpu_setup_kernels.py) when a GPU is in use and the product is large, the threaded host routine otherwise
+void spgemm_auto(const HostCSR &A, const HostCSR &B, HostCSR &C, long long device_min_rows) {
+  if (device_min_rows >= 0 && A.nrows >= device_min_rows && ctx().inited) {
+    hipStream_t s = ctx().stream;
+    sk::DCsr dA, dB, dC;
+    dA.upload(A, s);
+    dB.upload(B, s);
+    sk::spgemm(dA, dB, dC, s);
+    dA.release();
+    dB.release();
+    dC.download(C, s);
+    C.nrows = A.nrows;
+    C.ncols = B.ncols;
+    return;
+  }
+  host_spgemm(A, B, C);
+}
+
 }  // namespace
 
 long long dist_setup_counter(const char *name) {
@@ -771,7 +790,7 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
             Ae.ja[(size_t)k] = hslot[(size_t)k] < 0 ? E1.nbelow + (int)(A.gj[(size_t)k] - s) : hext[(size_t)hslot[(size_t)k]];
       });
       HostCSR APe;
-      host_spgemm(Ae, Pe, APe);
+      spgemm_auto(Ae, Pe, APe, device_min_rows);
       AP.nrows = n;
       AP.ia = APe.ia;
       AP.a.swap(APe.a);
@@ -915,7 +934,7 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
         });
       }
       HostCSR Ace;
-      host_spgemm(Re, APe, Ace);
+      spgemm_auto(Re, APe, Ace, device_min_rows);
       GlobCSR &Ac = Ln.A;
       Ac.nrows = ncl;
       Ac.ia = Ace.ia;

@@ -62,6 +62,7 @@ bool dense_solve(AmgLevel &Lv, Comm &comm, const double *f, double *u, hipStream
   } else {
     k::copy(f, Lv.fslot.p, Lv.n, s);
     comm.allgather_dev(Lv.fslot.p, Lv.fgather.p, (size_t)Lv.slot * sizeof(double), s);
+    ctx().n_allgather++;
     k::dense_matvec(Lv.Cinv.p, Lv.fgather.p, u, Lv.n, comm.size * Lv.slot, s);
   }
   return true;
@@ -317,6 +318,7 @@ void BoomerAMG::tail_cycle(bool zero_guess) {
   const int ng = tail_A->nrows;
   if (Lv.n) k::copy(Lv.f.p, tail_fslot.p, Lv.n, s);
   comm.allgather_dev(tail_fslot.p, tail_fgather.p, (size_t)tail_slot * sizeof(double), s);
+  ctx().n_allgather++;
   k::gather(tail_fgather.p, tail_map.p, tail_f.p, ng, s);
   tail->apply_global(tail_f.p, tail_e.p, zero_guess);
   if (Lv.n) k::copy(tail_e.p + tail_start, Lv.u.p, Lv.n, s);

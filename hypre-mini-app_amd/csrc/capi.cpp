@@ -1151,6 +1151,12 @@ HYPRE_Int HYPRE_MI_GetCounter(const char *name, long long *value) {
     *value = ctx().n_gs_overlapped;
   else if (n == "gs_in_order")
     *value = ctx().n_gs_in_order;
+  else if (n == "allreduce")
+    *value = ctx().n_allreduce;
+  else if (n == "halo_exchange")
+    *value = ctx().n_halo_exchange;
+  else if (n == "allgather")
+    *value = ctx().n_allgather;
   else if (dist_setup_counter(n.c_str()) >= 0)
     *value = dist_setup_counter(n.c_str());
   else

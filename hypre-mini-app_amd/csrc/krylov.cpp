@@ -235,7 +235,7 @@ int GmresSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
         for (int j = 1; j <= i; j++) {
           k::axpy_dot(slots + j - 1, -1.0, basis(j - 1).data(), pi.data(), j < i ? basis(j).data() : nullptr, n,
                       slots + j, s);
-          if (comm.size > 1) comm.allreduce_dev(slots + j, 1, CommDType::F64, CommOp::SUM, s);
+          if (comm.size > 1) comm.allreduce_dev(slots + j, 1, CommDType::F64, CommOp::SUM, s), c.n_allreduce++;
         }
         k::scale_inv_sqrt_dev(slots + i, pi.data(), n, s);
         MI_HIP(hipMemcpyAsync(c.h_pinned, slots, (size_t)(i + 1) * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -249,7 +249,7 @@ int GmresSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
         for (int q = 0; q < ortho; q++) {
           double *cs_dev = slots + 128 * q;
           k::mass_dot(vecs.data(), i, pi.data(), n, cs_dev, s);
-          if (comm.size > 1) comm.allreduce_dev(cs_dev, (size_t)i, CommDType::F64, CommOp::SUM, s);
+          if (comm.size > 1) comm.allreduce_dev(cs_dev, (size_t)i, CommDType::F64, CommOp::SUM, s), c.n_allreduce++;
           k::mass_axpy(vecs.data(), i, cs_dev, -1.0, pi.data(), n, s);
         }
         double *nrm = (ortho == 1) ? slots + i : slots + 128 + i;  // adjacent to the last pass: one copy below

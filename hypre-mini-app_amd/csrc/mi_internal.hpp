@@ -209,6 +209,9 @@ struct Ctx {
   // event counters of the multi-rank choreography (HYPRE_MI_GetCounter; the distributed tests check that the
   // overlapped paths are the ones that ran)
   long long n_matvec_overlapped = 0, n_gs_overlapped = 0, n_gs_in_order = 0;
+  // collectives the solve phase issued on N > 1 ranks: scalar / block all-reduces (inner products), neighbour
+  // exchange groups (one per halo update), all-gathers (coarsest / redundant levels)
+  long long n_allreduce = 0, n_halo_exchange = 0, n_allgather = 0;
 };
 Ctx &ctx();
 void ensure_init();

@@ -355,6 +355,7 @@ void ParCSR::halo_transfer(Comm &comm, hipStream_t s) {
     rb.push_back({halo.recv_peers[i], halo.d_xext.p + halo.recv_starts[i],
                   (size_t)(halo.recv_starts[i + 1] - halo.recv_starts[i]) * sizeof(double)});
   comm.exchange_dev(sb, rb, s);
+  ctx().n_halo_exchange++;
 }
 
 void ParCSR::halo_exchange(Comm &comm, const double *x, hipStream_t s, const double *x_hi, int split) {
@@ -430,7 +431,7 @@ const double *ParCSR::offd_contrib(Comm &comm, const double *x, hipStream_t s, c
 
 void par_dot(Comm &comm, const double *x, const double *y, int n, double *out_dev, hipStream_t s) {
   k::dot(x, y, n, out_dev, s);
-  if (comm.size > 1) comm.allreduce_dev(out_dev, 1, CommDType::F64, CommOp::SUM, s);
+  if (comm.size > 1) comm.allreduce_dev(out_dev, 1, CommDType::F64, CommOp::SUM, s), ctx().n_allreduce++;
 }
 
 double par_dot_host(Comm &comm, const double *x, const double *y, int n, hipStream_t s) {

@@ -57,7 +57,12 @@ HYPRE_Int HYPRE_MI_GetGSChunk(HYPRE_Int *rows_per_chunk);
 HYPRE_Int HYPRE_MI_SetZeroGuessMode(HYPRE_Int mode);
 /* Counters of the multi-rank choreography since the library was loaded: "matvec_overlapped" (SpMVs whose
  * neighbour exchange ran beside the diag-block product), "gs_overlapped" / "gs_in_order" (relaxation passes that
- * swept their halo-free rows while the halo travelled / that waited for it first). */
+ * swept their halo-free rows while the halo travelled / that waited for it first); collectives of the solve phase
+ * on N > 1 ranks: "allreduce" (one per inner product; modified Gram-Schmidt needs i + 1 of them at Arnoldi step i --
+ * each coefficient depends on the previous update -- the block classical Gram-Schmidt of COGMRES 2 per step),
+ * "halo_exchange" (neighbour send/recv groups), "allgather" (coarsest / redundant levels); the distributed setup:
+ * "setup_distributed" (count), "setup_ext_rows_max" (largest per-rank extended sub-problem, rows),
+ * "setup_global_rows_gathered" (rows gathered on every rank: the redundant tail only). */
 HYPRE_Int HYPRE_MI_GetCounter(const char *name, long long *value);
 /* One rank's block keeps 32-bit local row ids and entry offsets in the solve format: HYPRE_IJMatrixAssemble
  * refuses (HYPRE_ERROR_ARG + message) a block with >= 2147483000 rows or entries -- e.g. the reference's 27-point

@@ -179,11 +179,51 @@ def main():
         assert n_redundant == 0
 
     if args.mode == "solve":
+        def counters():
+            out = {}
+            for name in ("allreduce", "halo_exchange", "allgather"):
+                v = mi.C.c_longlong()
+                mi.call("HYPRE_MI_GetCounter", name.encode(), mi.C.byref(v))
+                out[name] = v.value
+            return out
+
         gm = mi.GMRES(tolerance=1e-8, max_iterations=60, kspace=20, print_level=0)
         gm.set_precond(amg)
         gm.setup(A, b, x)
+        c0 = counters()
         rc = gm.solve(A, b, x)
+        c1 = counters()
         assert rc == 0
+        m = gm.num_iterations
+        if size > 1 and m <= 20:
+            # collectives of one solve (no restart): ||b||, ||r0||, the final true-residual norm, and per Arnoldi
+            # step i the i coefficients of modified Gram-Schmidt + the norm -- each coefficient needs the vector
+            # the previous one updated, so MGS cannot batch them (HYPRE's GMRES does the same i + 1 reductions)
+            assert c1["allreduce"] - c0["allreduce"] == 3 + m + m * (m + 1) // 2, (c0, c1, m)
+            n_dist = amg.num_levels - n_redundant
+            cycles = m + 1
+            # halo updates per cycle and distributed level: <= 2 sweeps x 2 passes + residual + restriction +
+            # prolongation (the first pass of the down leg starts from zero and exchanges nothing); + 1 GMRES matvec
+            per_cycle = (c1["halo_exchange"] - c0["halo_exchange"]) / cycles
+            assert per_cycle <= 7 * n_dist + 2, (per_cycle, n_dist)
+            assert (c1["allgather"] - c0["allgather"]) <= cycles  # coarsest gather or redundant tail: one per cycle
+            # COGMRES (method: cogmres, src/HypreSystem.cpp:372-388): one block all-reduce + the norm per step
+            x.fill(0.0)
+            cg = mi.COGMRES(tolerance=1e-8, max_iterations=60, kspace=20, print_level=0)
+            cg.set_precond(amg)
+            cg.setup(A, b, x)
+            c2 = counters()
+            assert cg.solve(A, b, x) == 0
+            c3 = counters()
+            mc = cg.num_iterations
+            if mc <= 20:
+                assert c3["allreduce"] - c2["allreduce"] == 3 + 2 * mc, (c2, c3, mc)
+            if rank == 0:
+                print(f"collectives per solve: GMRES {c1['allreduce'] - c0['allreduce']} all-reduces ({m} iterations), "
+                      f"COGMRES {c3['allreduce'] - c2['allreduce']} ({mc} iterations), {per_cycle:.1f} halo exchanges per cycle "
+                      f"on {n_dist} distributed levels")
+            x.fill(0.0)
+            assert gm.solve(A, b, x) == 0  # back to the GMRES solution for the checks below
         xo, info = oc.gmres(Ao, bo, kdim=20, tol=1e-8, maxit=60, amg=oamg)
         assert gm.num_iterations == info["iters"], (gm.num_iterations, info["iters"])
         hist = gm.residual_history()

@@ -72,6 +72,14 @@ def test_device_setup_and_slicing_shared_gpu(nproc, n, stencil, seq):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nproc,n,stencil,seq", [(2, 16, 7, -1), (3, 14, 7, 300), (4, 12, 27, 0)])
+def test_distributed_setup_device_spgemm_shared_gpu(nproc, n, stencil, seq):
+    """The distributed setup with its sub-problem products A*P and R*(A*P) on the device (what large levels do)."""
+    out = _run(nproc, "solve", n, stencil, 29831 + nproc + n, seq=seq, devmin=0)
+    assert "dist solve ok" in out
+
+
+@pytest.mark.gpu
 def test_device_solve_cuda_staged_transport():
     """bench.py's fallback transport (torch.distributed collectives on device tensors behind the callback
     interface), exercised here over gloo because two nccl ranks cannot share the one GPU of the test box."""
