@@ -311,45 +311,81 @@ int pow2_at_most(double v, int cap) {
 
 
 // ---------------------------------------------------------------- strength of connection
+// G lanes share one row (G = 1 for short rows: thread per row).  With one thread per row a wave touches 64 rows
+// whose entries are row-length x 12 B apart: on the 30-150-entry rows of the coarse levels every load fetched a
+// line of its own (832 GB read for a 1.8 GB matrix on level 1 of 512^3, profiles/r01_pmc512_fetch_write.txt).  The
+// lanes of a group read consecutive entries instead; sums that the host forms in stored order (row sum) are
+// accumulated in stored order here too: every lane adds the G loaded values one after the other (shuffles), so the
+// result is bit-identical; the kept columns are written in stored order through a ballot prefix.
 // FILL = false: count per row; FILL = true: write the kept columns (stored order)
-template <bool FILL>
+template <bool FILL, int G>
 __global__ __launch_bounds__(BLK) void strength_k(int n, const long long *__restrict__ ia, const int *__restrict__ ja,
                                                   const double *__restrict__ a, double theta, double max_row_sum,
                                                   int *__restrict__ cnt, const long long *__restrict__ sia,
                                                   int *__restrict__ sja) {
-  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
-  if (i >= n) return;
-  const long long k0 = ia[i], k1 = ia[i + 1];
-  double diag = 0.0, row_sum = 0.0;
-  for (long long k = k0; k < k1; k++) {
-    row_sum += a[k];
-    if (ja[k] == i) diag = a[k];
-  }
-  double scale = 0.0;
-  for (long long k = k0; k < k1; k++) {
-    if (ja[k] == i) continue;
-    const double v = a[k];
-    if (diag < 0) {
-      if (v > scale) scale = v;
-    } else {
-      if (v < scale) scale = v;
+  const long long i = ((long long)blockIdx.x * BLK + threadIdx.x) / G;
+  const int sub = threadIdx.x % G, lane = threadIdx.x & 63, gbase = lane - sub;
+  const bool live = i < n;
+  const long long k0 = live ? ia[i] : 0, k1 = live ? ia[i + 1] : 0;
+  double diag = 0.0, row_sum = 0.0, scale_pos = 0.0, scale_neg = 0.0;  // max / min over the off-diagonal entries
+  // the longest row of the wave decides the trip count (shuffles need every lane)
+  long long len = k1 - k0;
+  for (int m = G; m < 64; m <<= 1) len = max(len, (long long)__shfl_xor((int)len, m, 64));
+  for (long long t = 0; t < len; t += G) {
+    const long long k = k0 + t + sub;
+    const bool ok = k < k1;
+    const double v = ok ? a[k] : 0.0;
+    const int j = ok ? ja[k] : -1;
+    const bool isd = ok && j == i;
+    if (ok && !isd) {
+      scale_pos = fmax(scale_pos, v);
+      scale_neg = fmin(scale_neg, v);
     }
-  }
-  const bool all_weak = (fabs(row_sum) > fabs(diag) * max_row_sum) && (max_row_sum < 1.0);
-  int c = 0;
-  if (!all_weak) {
-    const double thr = theta * scale;
-    long long q = FILL ? sia[i] : 0;
-    for (long long k = k0; k < k1; k++) {
-      if (ja[k] == i) continue;
-      const double v = a[k];
-      if ((diag < 0) ? (v > thr) : (v < thr)) {
-        if (FILL) sja[q++] = ja[k];
-        c++;
+#pragma unroll
+    for (int q = 0; q < G; q++) {
+      const double vq = (G > 1) ? __shfl(v, gbase + q, 64) : v;
+      const int dq = (G > 1) ? __shfl((int)isd, gbase + q, 64) : (int)isd;
+      if (k0 + t + q < k1) {
+        row_sum += vq;
+        if (dq) diag = vq;
       }
     }
   }
-  if (!FILL) cnt[i] = c;
+  for (int m = 1; m < G; m <<= 1) {
+    scale_pos = fmax(scale_pos, __shfl_xor(scale_pos, m, 64));
+    scale_neg = fmin(scale_neg, __shfl_xor(scale_neg, m, 64));
+  }
+  const double scale = (diag < 0) ? scale_pos : scale_neg;
+  const bool all_weak = (fabs(row_sum) > fabs(diag) * max_row_sum) && (max_row_sum < 1.0);
+  const double thr = theta * scale;
+  int c = 0;
+  long long q0 = (FILL && live) ? sia[i] : 0;
+  for (long long t = 0; t < len; t += G) {
+    const long long k = k0 + t + sub;
+    const bool ok = k < k1 && !all_weak;
+    bool strong = false;
+    int j = -1;
+    if (ok) {
+      j = ja[k];
+      const double v = a[k];
+      strong = (j != i) && ((diag < 0) ? (v > thr) : (v < thr));
+    }
+    if (G == 1) {
+      if (strong) {
+        if (FILL) sja[q0] = j;
+        q0++;
+        c++;
+      }
+    } else {
+      const unsigned long long bal = __ballot(strong);
+      const unsigned long long mine = (G == 64) ? bal : ((bal >> gbase) & ((1ull << G) - 1ull));
+      if (FILL && strong) sja[q0 + __popcll(mine & ((1ull << sub) - 1ull))] = j;
+      const int add = __popcll(mine);
+      q0 += add;
+      c += add;
+    }
+  }
+  if (!FILL && live && sub == 0) cnt[i] = c;
 }
 
 // ---------------------------------------------------------------- PMIS
@@ -987,26 +1023,49 @@ __global__ __launch_bounds__(BLK) void xcache_compact_k(int nb, const int *__res
 }
 
 // ---------------------------------------------------------------- l1 norms
+// G lanes per row, sums in stored order (see strength_k)
+template <int G>
 __global__ __launch_bounds__(BLK) void level_norms_k(int n, const long long *__restrict__ ia, const int *__restrict__ ja,
                                                      const double *__restrict__ a, const int *__restrict__ cf, int chunk,
                                                      double *__restrict__ diag, double *__restrict__ l1gs,
                                                      double *__restrict__ l1jac) {
-  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
-  if (i >= n) return;
-  const long long cs = (i / chunk) * chunk, ce = cs + chunk;
-  const int mycf = cf ? cf[i] : 0;
+  const long long i = ((long long)blockIdx.x * BLK + threadIdx.x) / G;
+  const int sub = threadIdx.x % G, lane = threadIdx.x & 63, gbase = lane - sub;
+  const bool live = i < n;
+  const long long k0 = live ? ia[i] : 0, k1 = live ? ia[i + 1] : 0;
+  const long long cs = live ? (i / chunk) * chunk : 0, ce = cs + chunk;
+  const int mycf = (cf && live) ? cf[i] : 0;
   double d = 0.0, l1 = 0.0, full = 0.0;
-  for (long long k = ia[i]; k < ia[i + 1]; k++) {
-    const int j = ja[k];
-    const double av = fabs(a[k]);
-    full += av;
-    if (j == i) {
-      d = a[k];
-      l1 += av;
-    } else if (j < cs || j >= ce) {
-      if (!cf || cf[j] == mycf) l1 += 0.5 * av;
+  long long len = k1 - k0;
+  for (int m = G; m < 64; m <<= 1) len = max(len, (long long)__shfl_xor((int)len, m, 64));
+  for (long long t = 0; t < len; t += G) {
+    const long long k = k0 + t + sub;
+    const bool ok = k < k1;
+    const double v = ok ? a[k] : 0.0;
+    const int j = ok ? ja[k] : -1;
+    // contribution of this entry to l1: |a| for the diagonal, |a|/2 for an out-of-chunk entry of the row's own
+    // C/F type, nothing otherwise
+    double h = 0.0;
+    if (ok) {
+      if (j == i)
+        h = fabs(v);
+      else if ((j < cs || j >= ce) && (!cf || cf[j] == mycf))
+        h = 0.5 * fabs(v);
+    }
+    const bool isd = ok && j == i;
+#pragma unroll
+    for (int q = 0; q < G; q++) {
+      const double vq = (G > 1) ? __shfl(v, gbase + q, 64) : v;
+      const double hq = (G > 1) ? __shfl(h, gbase + q, 64) : h;
+      const int dq = (G > 1) ? __shfl((int)isd, gbase + q, 64) : (int)isd;
+      if (k0 + t + q < k1) {
+        full += fabs(vq);
+        if (dq) d = vq;
+        if (hq != 0.0) l1 += hq;  // the host adds only the contributing entries, in stored order
+      }
     }
   }
+  if (!live || sub != 0) return;
   if (l1 <= 4.0 / 3.0 * fabs(d)) l1 = fabs(d);
   if (d < 0) {
     l1 = -l1;
@@ -1111,33 +1170,75 @@ __global__ __launch_bounds__(BLK) void ilu_upper_jac_k(int n, const long long *_
 // MODE 1, the residual that follows that sweep: an F row at or beyond the first chunk boundary >= nc drops its
 // C columns -- the F pass has just formed exactly that part of the row's product (every C column lies outside the
 // row's chunk there) and hands it over as f - A_FC u_C; all other rows stay whole
-template <bool FILL, int MODE>
+template <bool FILL, int MODE, int G>
 __global__ __launch_bounds__(BLK) void zero_guess_rows_k(int n, int nc, int chunk, const int *__restrict__ ia,
                                                          const int *__restrict__ ja, const double *__restrict__ a,
                                                          int *__restrict__ cnt, const long long *__restrict__ zia,
                                                          int *__restrict__ zja, double *__restrict__ za) {
-  const int i = blockIdx.x * BLK + threadIdx.x;
-  if (i >= n) return;
-  const int c0 = (i / chunk) * chunk, c1 = c0 + chunk;
+  // G lanes per row: coalesced reads, kept entries written in stored order through a ballot prefix (see strength_k)
+  const int i = (int)(((long long)blockIdx.x * BLK + threadIdx.x) / G);
+  const int sub = threadIdx.x % G, lane = threadIdx.x & 63, gbase = lane - sub;
+  const bool live = i < n;
+  const int k0 = live ? ia[i] : 0, k1 = live ? ia[i + 1] : 0;
+  const int c0 = live ? (i / chunk) * chunk : 0, c1 = c0 + chunk;
   const bool frow = i >= nc;
   const bool drops_c = i >= (nc + chunk - 1) / chunk * chunk;  // MODE 1
-  long long o = FILL ? zia[i] : 0;
+  long long o = (FILL && live) ? zia[i] : 0;
   int c = 0;
-  for (int k = ia[i]; k < ia[i + 1]; k++) {
-    const int j = ja[k];
-    const bool keep = (MODE == 0) ? ((j >= c0 && j < c1) || (frow && j < nc)) : !(drops_c && j < nc);
-    if (keep) {
-      if (FILL) {
-        zja[o] = j;
-        za[o] = a[k];
+  int len = k1 - k0;
+  for (int m = G; m < 64; m <<= 1) len = max(len, __shfl_xor(len, m, 64));
+  for (int t = 0; t < len; t += G) {
+    const int k = k0 + t + sub;
+    bool keep = false;
+    int j = -1;
+    double v = 0.0;
+    if (k < k1) {
+      j = ja[k];
+      keep = (MODE == 0) ? ((j >= c0 && j < c1) || (frow && j < nc)) : !(drops_c && j < nc);
+      if (FILL && keep) v = a[k];
+    }
+    if (G == 1) {
+      if (keep) {
+        if (FILL) {
+          zja[o] = j;
+          za[o] = v;
+        }
         o++;
-      } else {
         c++;
       }
+    } else {
+      const unsigned long long bal = __ballot(keep);
+      const unsigned long long mine = (G == 64) ? bal : ((bal >> gbase) & ((1ull << G) - 1ull));
+      if (FILL && keep) {
+        const long long w = o + __popcll(mine & ((1ull << sub) - 1ull));
+        zja[w] = j;
+        za[w] = v;
+      }
+      const int add = __popcll(mine);
+      o += add;
+      c += add;
     }
   }
-  if (!FILL) cnt[i] = c;
+  if (!FILL && live && sub == 0) cnt[i] = c;
 }
+
+// lanes per row for the row-cooperative setup kernels: the power of two next to half the mean row length
+inline int row_group(long long nnz, long long n) {
+  const double avg = n > 0 ? (double)nnz / (double)n : 0.0;
+  int g = 1;
+  while (g < 64 && (double)g * 1.5 < avg) g <<= 1;
+  return g;
+}
+#define MI_ROW_GROUP_DISPATCH(G_, CALL)  \
+  switch (G_) {                          \
+    case 1: { constexpr int G = 1; CALL; } break;   \
+    case 2: { constexpr int G = 2; CALL; } break;   \
+    case 4: { constexpr int G = 4; CALL; } break;   \
+    case 8: { constexpr int G = 8; CALL; } break;   \
+    case 16: { constexpr int G = 16; CALL; } break; \
+    case 32: { constexpr int G = 32; CALL; } break; \
+    default: { constexpr int G = 64; CALL; } break; \
+  }
 
 }  // namespace
 
@@ -1287,11 +1388,13 @@ void zero_guess_operator(const DevCSR &A, int nc, int chunk, DCsr &Z, hipStream_
   Z.ncols = A.ncols;
   Z.ia.alloc((size_t)n + 1);
   DVec<int> cnt((size_t)n);
-  const unsigned grid = (unsigned)((n + BLK - 1) / BLK);
-  if (n && mode == 0)
-    zero_guess_rows_k<false, 0><<<grid, BLK, 0, s>>>(n, nc, chunk, A.ia.p, A.ja.p, A.a.p, cnt.p, nullptr, nullptr, nullptr);
-  else if (n)
-    zero_guess_rows_k<false, 1><<<grid, BLK, 0, s>>>(n, nc, chunk, A.ia.p, A.ja.p, A.a.p, cnt.p, nullptr, nullptr, nullptr);
+  const int rg = row_group(A.nnz, n);
+  const unsigned grid = (unsigned)(((long long)n * rg + BLK - 1) / BLK);
+  if (n && mode == 0) {
+    MI_ROW_GROUP_DISPATCH(rg, (zero_guess_rows_k<false, 0, G><<<grid, BLK, 0, s>>>(n, nc, chunk, A.ia.p, A.ja.p, A.a.p, cnt.p, nullptr, nullptr, nullptr)))
+  } else if (n) {
+    MI_ROW_GROUP_DISPATCH(rg, (zero_guess_rows_k<false, 1, G><<<grid, BLK, 0, s>>>(n, nc, chunk, A.ia.p, A.ja.p, A.a.p, cnt.p, nullptr, nullptr, nullptr)))
+  }
   exclusive_scan(cnt.p, Z.ia.p, n, s);
   long long total = 0;
   MI_HIP(hipMemcpyAsync(&total, Z.ia.p + n, sizeof(long long), hipMemcpyDeviceToHost, s));
@@ -1299,10 +1402,11 @@ void zero_guess_operator(const DevCSR &A, int nc, int chunk, DCsr &Z, hipStream_
   Z.nnz = total;
   Z.ja.alloc((size_t)total);
   Z.a.alloc((size_t)total);
-  if (n && total && mode == 0)
-    zero_guess_rows_k<true, 0><<<grid, BLK, 0, s>>>(n, nc, chunk, A.ia.p, A.ja.p, A.a.p, nullptr, Z.ia.p, Z.ja.p, Z.a.p);
-  else if (n && total)
-    zero_guess_rows_k<true, 1><<<grid, BLK, 0, s>>>(n, nc, chunk, A.ia.p, A.ja.p, A.a.p, nullptr, Z.ia.p, Z.ja.p, Z.a.p);
+  if (n && total && mode == 0) {
+    MI_ROW_GROUP_DISPATCH(rg, (zero_guess_rows_k<true, 0, G><<<grid, BLK, 0, s>>>(n, nc, chunk, A.ia.p, A.ja.p, A.a.p, nullptr, Z.ia.p, Z.ja.p, Z.a.p)))
+  } else if (n && total) {
+    MI_ROW_GROUP_DISPATCH(rg, (zero_guess_rows_k<true, 1, G><<<grid, BLK, 0, s>>>(n, nc, chunk, A.ia.p, A.ja.p, A.a.p, nullptr, Z.ia.p, Z.ja.p, Z.a.p)))
+  }
   MI_HIP(hipGetLastError());
   MI_HIP(hipStreamSynchronize(s));
 }
@@ -1329,7 +1433,9 @@ void solve_format_to_host(const DevCSR &src, HostCSR &h, hipStream_t s) {
 void level_norms(const DCsr &A, const int *cf, int chunk, double *diag, double *l1gs, double *l1jac, hipStream_t s) {
   const int n = A.nrows;
   if (n == 0) return;
-  level_norms_k<<<(unsigned)((n + BLK - 1) / BLK), BLK, 0, s>>>(n, A.ia.p, A.ja.p, A.a.p, cf, chunk, diag, l1gs, l1jac);
+  const int rg = row_group(A.nnz, n);
+  const unsigned grid = (unsigned)(((long long)n * rg + BLK - 1) / BLK);
+  MI_ROW_GROUP_DISPATCH(rg, (level_norms_k<G><<<grid, BLK, 0, s>>>(n, A.ia.p, A.ja.p, A.a.p, cf, chunk, diag, l1gs, l1jac)))
   MI_HIP(hipGetLastError());
 }
 
@@ -1340,16 +1446,20 @@ void strength(const DCsr &A, double theta, double max_row_sum, DCsr &S, hipStrea
   S.ncols = A.ncols;
   S.ia.alloc((size_t)n + 1);
   DVec<int> cnt((size_t)n);
-  const unsigned grid = (unsigned)((n + BLK - 1) / BLK);
-  if (n) strength_k<false><<<grid, BLK, 0, s>>>(n, A.ia.p, A.ja.p, A.a.p, theta, max_row_sum, cnt.p, nullptr, nullptr);
+  const int rg = row_group(A.nnz, n);
+  const unsigned grid = (unsigned)(((long long)n * rg + BLK - 1) / BLK);
+  if (n) {
+    MI_ROW_GROUP_DISPATCH(rg, (strength_k<false, G><<<grid, BLK, 0, s>>>(n, A.ia.p, A.ja.p, A.a.p, theta, max_row_sum, cnt.p, nullptr, nullptr)))
+  }
   exclusive_scan(cnt.p, S.ia.p, n, s);
   long long total = 0;
   MI_HIP(hipMemcpyAsync(&total, S.ia.p + n, sizeof(long long), hipMemcpyDeviceToHost, s));
   MI_HIP(hipStreamSynchronize(s));
   S.nnz = total;
   S.ja.alloc((size_t)total);
-  if (n && total)
-    strength_k<true><<<grid, BLK, 0, s>>>(n, A.ia.p, A.ja.p, A.a.p, theta, max_row_sum, nullptr, S.ia.p, S.ja.p);
+  if (n && total) {
+    MI_ROW_GROUP_DISPATCH(rg, (strength_k<true, G><<<grid, BLK, 0, s>>>(n, A.ia.p, A.ja.p, A.a.p, theta, max_row_sum, nullptr, S.ia.p, S.ja.p)))
+  }
   MI_HIP(hipGetLastError());
   MI_HIP(hipStreamSynchronize(s));
 }
