@@ -42,10 +42,148 @@ def parse():
                     help="grid side of the bounded CPU-baseline sample (0 = skip; default: 256 = BASELINE.json "
                          "config 2 when the host has the memory, else 128)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--workload", choices=("laplace", "convdiff3"), default="laplace",
+                    help="laplace = the headline (BASELINE.json configs 2/3: strong scaling of one n^3 grid); convdiff3 = "
+                         "side-line for config 5: 3-component non-symmetric convection-diffusion system, BiCGSTAB + "
+                         "BoomerAMG, WEAK scaling (n^3 rows per rank, z-slabs stacked)")
+    ap.add_argument("--segregated", type=int, default=0,
+                    help="convdiff3: 1 = one solve per component (segregated_solve 1), 0 = one multivector solve")
     ap.add_argument("--amg", action="append", default=[], metavar="KEY=VALUE",
                     help="boomeramg_settings override for a side-line (e.g. --amg agg_num_levels=1); the headline "
                          "configuration is the one without overrides")
     return ap.parse_args()
+
+
+def build_convdiff3(mi, n, rank, world):
+    """BASELINE.json config 5 stand-in (no nalu-wind dump exists offline): rows of this rank's z-slab of the
+    n x n x (n*world) grid (weak scaling; lexicographic numbering = contiguous block rows, HypreSystem.cpp:525-544) of
+    a 7-point convection-diffusion operator -- diffusion 6 / -1, first-order upwind convection with a smooth,
+    partition-independent velocity field of cell Peclet number <= 0.6 -- and three right-hand sides b_c = A x_c for
+    closed-form x_c.  Diagonally dominant, non-symmetric M-matrix."""
+    nzg = n * world
+    z0 = n * rank
+    zz, yy, xx = np.meshgrid(np.arange(z0, z0 + n), np.arange(n), np.arange(n), indexing="ij")
+    gid = (xx + n * (yy + n * zz)).astype(np.int64)
+
+    def vel(ax, x_, y_, z_):
+        fx, fy, fz = 2 * np.pi * x_ / n, 2 * np.pi * y_ / n, 2 * np.pi * z_ / nzg
+        return 0.6 * (np.sin(fy) * np.cos(fz) if ax == 0 else np.sin(fz) * np.cos(fx) if ax == 1 else np.sin(fx) * np.cos(fy))
+
+    def exact(c, x_, y_, z_):
+        if c == 0:
+            return np.ones_like(x_, dtype=np.float64)
+        if c == 1:
+            return np.sin(3.0 * x_ / n) * np.cos(2.0 * y_ / n) + z_ / nzg
+        return np.cos(5.0 * (x_ + y_) / n) * np.sin(4.0 * z_ / nzg + 0.3)
+
+    rows, cols, vals = [], [], []
+    diag = np.full(gid.shape, 6.0)
+    rhs = [np.zeros(gid.shape) for _ in range(3)]
+    dims = (n, n, nzg)
+    for ax, (dx, dy, dz) in enumerate(((1, 0, 0), (0, 1, 0), (0, 0, 1))):
+        v = vel(ax, xx, yy, zz)
+        diag += np.abs(v)
+        for sgn in (-1, 1):
+            X, Y, Z = xx + sgn * dx, yy + sgn * dy, zz + sgn * dz
+            inside = (X >= 0) & (X < dims[0]) & (Y >= 0) & (Y < dims[1]) & (Z >= 0) & (Z < dims[2])
+            coef = -1.0 - (np.maximum(v, 0.0) if sgn < 0 else np.maximum(-v, 0.0))
+            rows.append(gid[inside])
+            cols.append((X + n * (Y + n * Z))[inside].astype(np.int64))
+            vals.append(coef[inside])
+            for c in range(3):
+                rhs[c] += np.where(inside, coef * exact(c, X, Y, Z), 0.0)
+    rows.append(gid.ravel())
+    cols.append(gid.ravel())
+    vals.append(diag.ravel())
+    xs = [exact(c, xx, yy, zz) for c in range(3)]
+    for c in range(3):
+        rhs[c] += diag * xs[c]
+    ilower, iupper = int(gid.min()), int(gid.max())
+    A = mi.IJMatrix(ilower, iupper)
+    A.set_values_coo(np.concatenate(rows), np.concatenate(cols), np.concatenate(vals))
+    A.assemble()
+    B = np.stack([r.ravel() for r in rhs])
+    X = np.stack([x_.ravel() for x_ in xs])
+    return A, B, X, ilower, iupper
+
+
+def run_convdiff3(args, mi, dist, rank, world, transport, rehearsal, torch):
+    """Side-line for BASELINE.json config 5: one step = the solve of all three components (one multivector solve, or
+    three segregated solves on one hierarchy); value = 3 * N_global * iterations / t in GDOF/s."""
+    n = args.n
+    t0 = time.time()
+    A, B, X, ilower, iupper = build_convdiff3(mi, n, rank, world)
+    t_build = time.time() - t0
+    nloc = iupper - ilower + 1
+    ndof = n ** 3 * world
+    amg = mi.BoomerAMG(print_level=1 if (rank == 0 and os.environ.get("MI_BENCH_VERBOSE")) else 0)
+    bi = mi.BiCGSTAB(tolerance=args.tol, max_iterations=args.max_iter, print_level=0)
+    bi.set_precond(amg)
+    if args.segregated:
+        bs = [mi.IJVector(ilower, iupper, B[c]) for c in range(3)]
+        xv = [mi.IJVector(ilower, iupper, np.zeros(nloc)) for c in range(3)]
+    else:
+        bs = [mi.IJVector(ilower, iupper, B, ncomp=3)]
+        xv = [mi.IJVector(ilower, iupper, np.zeros((3, nloc)), ncomp=3)]
+    t0 = time.time()
+    bi.setup(A, bs[0], xv[0])
+    t_setup = time.time() - t0
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        mi.call("HYPRE_MI_StreamSynchronize")
+
+    def one_step():
+        its = 0
+        for bvec, xvec in zip(bs, xv):
+            xvec.fill(0.0)
+            bi.solve(A, bvec, xvec)
+            its += bi.num_iterations * (1 if args.segregated else 3)
+        return its  # component-iterations
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    comp_iters = 0
+    for _ in range(args.steps):
+        comp_iters += one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    got = xv[0].get_all() if not args.segregated else np.stack([v.get() for v in xv])
+    err = float(np.abs(got - X).max())
+    if dist is not None:
+        e = torch.tensor([err], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        dist.all_reduce(e, op=dist.ReduceOp.MAX)
+        err = float(e.item())
+    if rank == 0:
+        out = {
+            "metric": "BiCGSTAB+AMG solve GDOF/s on a 3-component convection-diffusion system (components * N_global * "
+                      "iterations / t_solve), config-5 side-line",
+            "value": ndof * comp_iters / elapsed / 1e9, "unit": "GDOF/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"convdiff3: 7-pt upwind convection-diffusion, {n}^3 rows per rank x {world} rank(s) "
+                                   f"(N={ndof}), 3 components, BiCGSTAB+BoomerAMG tol {args.tol:g}, "
+                                   f"{'segregated solves' if args.segregated else 'one multivector solve'}, x0=0",
+                       "row_partition": f"{world} contiguous block-row slab(s)", "transport": transport},
+            "iterations_per_solve": bi.num_iterations, "final_rel_residual": bi.final_rel_res,
+            "max_abs_error_vs_exact": err, "amg_levels": amg.num_levels, "operator_complexity": amg.operator_complexity,
+            "setup_s": t_setup, "build_s": t_build, "roofline": None, "cpu_baseline": None,
+        }
+        if rehearsal:
+            out["rehearsal"] = True
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        mi.call("HYPRE_MI_CommFinalize")
+        dist.destroy_process_group()
 
 
 def physical_cores():
@@ -223,6 +361,9 @@ def main():
                 print("[bench] WARNING: falling back to the torch.distributed transport", file=sys.stderr, flush=True)
             mi.call("HYPRE_MI_CommFinalize")
             mi.init_comm_torch(dist, device="cuda")
+
+    if args.workload == "convdiff3":
+        return run_convdiff3(args, mi, dist, rank, world, transport, rehearsal, torch)
 
     n = args.n
     ndof = n ** 3
