@@ -965,6 +965,8 @@ double BoomerAMG::operator_complexity() const {
 void BoomerAMG::apply_cf_ordering() {
   Comm &comm = my_comm();
   const size_t nlev = L.size();
+  const bool timing = getenv("MI_HYPRE_SETUP_TIMING") != nullptr && comm.rank == 0;
+  double tcf0 = wall_time();
   std::vector<std::vector<int>> pos(nlev);  // old -> new local row
   for (size_t l = 0; l < nlev; l++) {
     AmgLevel &Lv = L[l];
@@ -972,14 +974,37 @@ void BoomerAMG::apply_cf_ordering() {
     const int n = Lv.A->nrows;
     pos[l].resize((size_t)n);
     Lv.perm.resize((size_t)n);
-    int q = 0;
-    for (int i = 0; i < n; i++)
-      if (Lv.cf[(size_t)i] == C_PT) pos[l][(size_t)i] = q++;
-    Lv.nc = q;
-    for (int i = 0; i < n; i++)
-      if (Lv.cf[(size_t)i] != C_PT) pos[l][(size_t)i] = q++;
-    for (int i = 0; i < n; i++) Lv.perm[(size_t)pos[l][(size_t)i]] = i;
+    // C points first, F points after, original order kept in both: the static partition of parallel_for is the
+    // same in both passes (same n), so per-thread C counts give every thread its offsets
+    const int nt = host_threads();
+    std::vector<int64_t> cb((size_t)nt + 1, 0), ce((size_t)nt + 1, 0), ncnt((size_t)nt + 1, 0);
+    parallel_for(n, [&](int64_t b, int64_t e, int t) {
+      int64_t c = 0;
+      for (int64_t i = b; i < e; i++) c += (Lv.cf[(size_t)i] == C_PT);
+      cb[(size_t)t] = b, ce[(size_t)t] = e, ncnt[(size_t)t] = c;
+    });
+    int64_t nc_tot = 0;
+    for (int t = 0; t < nt; t++) nc_tot += ncnt[(size_t)t];
+    Lv.nc = (int)nc_tot;
+    std::vector<int64_t> coff((size_t)nt + 1, 0), foff((size_t)nt + 1, 0);
+    {
+      int64_t c = 0, f = nc_tot;
+      for (int t = 0; t < nt; t++) {
+        coff[(size_t)t] = c, foff[(size_t)t] = f;
+        c += ncnt[(size_t)t];
+        f += (ce[(size_t)t] - cb[(size_t)t]) - ncnt[(size_t)t];
+      }
+    }
+    parallel_for(n, [&](int64_t b, int64_t e, int t) {
+      int64_t c = coff[(size_t)t], f = foff[(size_t)t];
+      for (int64_t i = b; i < e; i++) {
+        const int q = (int)((Lv.cf[(size_t)i] == C_PT) ? c++ : f++);
+        pos[l][(size_t)i] = q;
+        Lv.perm[(size_t)q] = (int)i;
+      }
+    });
   }
+  if (timing) printf("   C-first ordering: positions %.2f s\n", wall_time() - tcf0);
   auto sort_rows = [](HostCSR &M) {
     parallel_for(M.nrows, [&](int64_t b, int64_t e, int) {
       std::vector<std::pair<int, double>> row;
@@ -1030,6 +1055,15 @@ void BoomerAMG::apply_cf_ordering() {
   };
   for (size_t l = 0; l < nlev; l++) {
     AmgLevel &Lv = L[l];
+    const double tl0 = wall_time();
+    struct LevelTimer {
+      bool on;
+      size_t l;
+      double t0;
+      ~LevelTimer() {
+        if (on) printf("   C-first ordering: level %zu %.2f s\n", l, wall_time() - t0);
+      }
+    } level_timer{timing && l < 4, l, tl0};
     if (pos[l].empty() && Lv.A->host_diag_stale && Lv.sA.nrows == Lv.A->nrows) {
       // a level without C/F splitting (the coarsest) keeps its ordering: fetch it before sA goes away
       const int nr = Lv.A->diag.nrows, ncl = Lv.A->diag.ncols;
@@ -1763,9 +1797,22 @@ void BoomerAMG::setup_device() {
   ensure_init();
   Comm &comm = my_comm();
   const int ch = chunk();
+  const bool timing = getenv("MI_HYPRE_SETUP_TIMING") != nullptr && comm.rank == 0;
   for (size_t li = 0; li < L.size(); li++) {
     AmgLevel &Lv = L[li];
     hipStream_t s = ctx().stream;
+    const double tdev0 = wall_time();
+    struct LevelTimer {
+      bool on;
+      size_t l;
+      double t0;
+      ~LevelTimer() {
+        if (on) {
+          (void)hipDeviceSynchronize();
+          printf("   solve-phase format: level %zu %.2f s\n", l, wall_time() - t0);
+        }
+      }
+    } level_timer{timing && li < 4, li, tdev0};
     auto place = [&](ParCSR &M, sk::DCsr &dev) {
       if (dev.nrows == M.nrows && M.host_diag_stale) {  // built on the device: no host round trip
         sk::to_solve_format(dev, M.d_diag, s);
