@@ -104,6 +104,13 @@ struct BoomerAMG {
   int num_iterations = 0;
   double final_rel_res = 0.0;
   double setup_seconds = 0.0;
+  // Internal locality numbering (single rank; amg_setup.cpp locality_order): the hierarchy is built on Q A Q^T,
+  // where Q groups rows into graph-compact clusters so that a tile of consecutive rows touches few distinct columns.
+  // input_order[new] = caller's row; empty = identity.  Level 0's perm is composed with it, so every solve path
+  // gathers / scatters caller vectors as before.
+  std::vector<int> input_order;
+  std::unique_ptr<ParCSR> Aq_own;
+  bool use_locality_order(const ParCSR &A) const;
   // the matrix HYPRE_BoomerAMGSetup was called with (and its assembly stamp): a Krylov solver may run on the
   // hierarchy's own level-0 copy only when it is handed that very matrix (krylov.cpp amg_in_level_order)
   const ParCSR *source_matrix = nullptr;

@@ -9,6 +9,8 @@
 // to halo columns are treated as weak), so P has no off-rank columns and the
 // Galerkin product needs exactly one exchange: the P rows of the halo columns.
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cmath>
 #include <cstring>
 
@@ -1147,6 +1149,111 @@ void BoomerAMG::apply_cf_ordering() {
   }
 }
 
+// ---- internal locality numbering ------------------------------------------------------------------------------
+// The x-cache kernels gather, per tile of <= 256 consecutive rows, the tile's unique columns; with a lexicographic
+// numbering of a 3-D problem a tile is a piece of ONE grid line and gathers ~5 distinct columns per row, a
+// brick-shaped tile ~2.3 (profiles/run_numbering_experiment.py: numbering the same Laplacian by 8x8x8 bricks makes
+// the solve 10 % faster per iteration at 256^3).  The geometry is not known here, so bricks are grown on the
+// matrix graph: rows are cut into fixed segments of 2^20 consecutive rows (threads; the result does not depend on
+// the thread count), and inside a segment every still unassigned row, in ascending order, seeds a breadth-first
+// ball of up to 512 unassigned rows.  New order = clusters in seed order, natural order inside a cluster (a stable
+// sort by cluster label); the coarse levels inherit it, C points keeping their relative order.
+namespace {
+constexpr int LOCALITY_SEGMENT = 1 << 20;
+const int LOCALITY_CLUSTER = getenv("MI_HYPRE_LOCALITY_CLUSTER") ? std::max(8, atoi(getenv("MI_HYPRE_LOCALITY_CLUSTER"))) : 512;
+
+void locality_order(const HostCSR &D, std::vector<int> &order) {
+  const int n = D.nrows;
+  std::vector<int> label((size_t)n, -1);
+  const int nseg = (n + LOCALITY_SEGMENT - 1) / LOCALITY_SEGMENT;
+  std::vector<int> seg_clusters((size_t)nseg, 0);
+  // segments are independent: threads take them from a shared counter (parallel_for does not split short ranges)
+  std::atomic<int> next_seg(0);
+  auto worker = [&]() {
+    std::vector<int> queue;
+    queue.reserve(LOCALITY_CLUSTER + 64);
+    for (int sg = next_seg++; sg < nseg; sg = next_seg++) {
+      const int r0 = (int)((int64_t)sg * LOCALITY_SEGMENT), r1 = (int)std::min<int64_t>(n, ((int64_t)sg + 1) * LOCALITY_SEGMENT);
+      int ncl = 0;
+      for (int seed = r0; seed < r1; seed++) {
+        if (label[(size_t)seed] >= 0) continue;
+        queue.clear();
+        queue.push_back(seed);
+        label[(size_t)seed] = ncl;
+        for (size_t head = 0; head < queue.size() && (int)queue.size() < LOCALITY_CLUSTER; head++) {
+          const int v = queue[head];
+          for (int64_t k = D.ia[(size_t)v]; k < D.ia[(size_t)v + 1]; k++) {
+            const int j = D.ja[(size_t)k];
+            if (j < r0 || j >= r1 || label[(size_t)j] >= 0) continue;
+            label[(size_t)j] = ncl;
+            queue.push_back(j);
+            if ((int)queue.size() >= LOCALITY_CLUSTER) break;
+          }
+        }
+        ncl++;
+      }
+      seg_clusters[(size_t)sg] = ncl;
+    }
+  };
+  {
+    const int nt = std::max(1, std::min(nseg, host_threads()));
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(worker);
+    worker();
+    for (auto &x : th) x.join();
+  }
+  // stable counting sort by (segment, cluster label)
+  std::vector<int64_t> seg_base((size_t)nseg + 1, 0);
+  for (int sg = 0; sg < nseg; sg++) seg_base[(size_t)sg + 1] = seg_base[(size_t)sg] + seg_clusters[(size_t)sg];
+  std::vector<int64_t> start((size_t)seg_base[(size_t)nseg] + 1, 0);
+  for (int i = 0; i < n; i++) start[(size_t)(seg_base[(size_t)(i / LOCALITY_SEGMENT)] + label[(size_t)i]) + 1]++;
+  for (size_t c = 0; c + 1 < start.size(); c++) start[c + 1] += start[c];
+  order.resize((size_t)n);
+  for (int i = 0; i < n; i++) order[(size_t)start[(size_t)(seg_base[(size_t)(i / LOCALITY_SEGMENT)] + label[(size_t)i])]++] = i;
+}
+
+// B = Q A Q^T: rows of A in `order` (new -> old), columns renumbered, rows re-sorted
+void permute_symmetric(const HostCSR &A, const std::vector<int> &order, HostCSR &B) {
+  const int n = A.nrows;
+  std::vector<int> newid((size_t)n);
+  parallel_for(n, [&](int64_t b, int64_t e, int) {
+    for (int64_t q = b; q < e; q++) newid[(size_t)order[(size_t)q]] = (int)q;
+  });
+  B.nrows = n;
+  B.ncols = A.ncols;
+  B.ia.assign((size_t)n + 1, 0);
+  for (int q = 0; q < n; q++) {
+    const int i = order[(size_t)q];
+    B.ia[(size_t)q + 1] = B.ia[(size_t)q] + (A.ia[(size_t)i + 1] - A.ia[(size_t)i]);
+  }
+  B.ja.resize((size_t)B.nnz());
+  B.a.resize((size_t)B.nnz());
+  parallel_for(n, [&](int64_t b, int64_t e, int) {
+    std::vector<std::pair<int, double>> row;
+    for (int64_t q = b; q < e; q++) {
+      const int i = order[(size_t)q];
+      row.clear();
+      for (int64_t k = A.ia[(size_t)i]; k < A.ia[(size_t)i + 1]; k++) row.push_back({newid[(size_t)A.ja[(size_t)k]], A.a[(size_t)k]});
+      std::sort(row.begin(), row.end(), [](const std::pair<int, double> &x, const std::pair<int, double> &y) { return x.first < y.first; });
+      int64_t w = B.ia[(size_t)q];
+      for (auto &en : row) {
+        B.ja[(size_t)w] = en.first;
+        B.a[(size_t)w++] = en.second;
+      }
+    }
+  });
+}
+}  // namespace
+
+bool BoomerAMG::use_locality_order(const ParCSR &A) const {
+  if (forced_comm || my_comm().size != 1 || !A.col_map_offd.empty() || A.host_diag_stale) return false;
+  const char *e = getenv("MI_HYPRE_LOCALITY_ORDER");
+  if (e && atoi(e) == 0) return false;
+  if (e && atoi(e) > 0) return A.nrows > 1;
+  static const long long min_rows = getenv("MI_HYPRE_LOCALITY_MIN_ROWS") ? atoll(getenv("MI_HYPRE_LOCALITY_MIN_ROWS")) : 1000000;
+  return A.nrows >= min_rows;
+}
+
 void BoomerAMG::setup_host(ParCSR &A0) {
   TraceRange trace_setup("mi_hypre BoomerAMGSetup (hierarchy)");
   Comm &comm = my_comm();
@@ -1168,10 +1275,39 @@ void BoomerAMG::setup_host(ParCSR &A0) {
   } else {
     tail.reset();
     tail_A.reset();
-    build_natural(A0);
+    input_order.clear();
+    Aq_own.reset();
+    ParCSR *Ain = &A0;
+    if (use_locality_order(A0)) {
+      const double tq0 = wall_time();
+      locality_order(A0.diag, input_order);
+      Aq_own.reset(new ParCSR());
+      ParCSR &Q = *Aq_own;
+      permute_symmetric(A0.diag, input_order, Q.diag);
+      Q.nrows = A0.nrows;
+      Q.row_start = A0.row_start;
+      Q.row_end = A0.row_end;
+      Q.row_starts = A0.row_starts;
+      Q.offd.nrows = A0.nrows;
+      Q.offd.ncols = 0;
+      Q.offd.ia.assign((size_t)A0.nrows + 1, 0);
+      Q.build_halo_plan(comm);
+      Ain = Aq_own.get();
+      if (getenv("MI_HYPRE_SETUP_TIMING")) printf("   locality numbering of the input: %.2f s\n", wall_time() - tq0);
+    }
+    build_natural(*Ain);
     const double tp0 = wall_time();
     apply_cf_ordering();
     make_local_transfer_operators();
+    if (!input_order.empty()) {
+      // level 0 rows -> caller rows
+      AmgLevel &L0 = L[0];
+      if (L0.perm.empty())
+        L0.perm = input_order;
+      else
+        for (int &q : L0.perm) q = input_order[(size_t)q];
+      if (L0.A != Aq_own.get()) Aq_own.reset();  // level 0 is its C-first copy: the intermediate matrix can go
+    }
     t_phase[4] += wall_time() - tp0;
   }
   finish_host();
@@ -1864,8 +2000,8 @@ void BoomerAMG::setup_device() {
       std::vector<signed char> c8(Lv.cf.size());
       for (size_t i = 0; i < c8.size(); i++) c8[i] = (signed char)Lv.cf[i];
       Lv.d_cf.upload(c8);
-      Lv.d_perm.upload(Lv.perm);
     }
+    if (!Lv.perm.empty()) Lv.d_perm.upload(Lv.perm);
     Lv.u.alloc((size_t)Lv.n);
     Lv.f.alloc((size_t)Lv.n);
     Lv.tmp.alloc((size_t)Lv.n);

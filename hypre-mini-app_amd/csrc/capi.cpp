@@ -1304,6 +1304,18 @@ HYPRE_Int HYPRE_MI_BoomerAMGGetLevelPerm(HYPRE_Solver solver, HYPRE_Int level, H
   for (int i = 0; i < Lv.A->nrows; i++) perm[i] = Lv.perm.empty() ? i : Lv.perm[(size_t)i];
   API_END
 }
+// the internal locality numbering of the input (order[new] = caller's local row); *applied = 0 and the identity
+// when the hierarchy was built on the caller's numbering
+HYPRE_Int HYPRE_MI_BoomerAMGGetInputOrdering(HYPRE_Solver solver, HYPRE_Int *applied, HYPRE_Int *order) {
+  API_BEGIN
+  AmgSolver *a = AMG(solver);
+  if (applied) *applied = a->amg.input_order.empty() ? 0 : 1;
+  if (order) {
+    const int n = a->amg.L.empty() ? 0 : a->amg.L[0].n;
+    for (int i = 0; i < n; i++) order[i] = a->amg.input_order.empty() ? i : a->amg.input_order[(size_t)i];
+  }
+  API_END
+}
 HYPRE_Int HYPRE_MI_BoomerAMGGetLevelColMap(HYPRE_Solver solver, HYPRE_Int level, HYPRE_BigInt *col_map_offd,
                                            HYPRE_BigInt *row_start) {
   API_BEGIN

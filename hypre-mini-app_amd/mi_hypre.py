@@ -321,6 +321,15 @@ class BoomerAMG:
         call("HYPRE_MI_BoomerAMGGetLevelPerm", self.h, level, perm)
         return perm
 
+    def input_ordering(self):
+        """(applied, order): the internal locality numbering of the input, order[new] = caller's local row."""
+        nr, nc, nnz = c_int(), c_int(), c_big()
+        call("HYPRE_MI_BoomerAMGGetLevelCSRSize", self.h, 0, 0, C.byref(nr), C.byref(nc), C.byref(nnz))
+        applied = c_int()
+        order = np.zeros(nr.value, dtype=np.int32)
+        call("HYPRE_MI_BoomerAMGGetInputOrdering", self.h, C.byref(applied), order)
+        return bool(applied.value), order
+
     def level_colmap(self, level):
         nr, nc, nnz = c_int(), c_int(), c_big()
         call("HYPRE_MI_BoomerAMGGetLevelCSRSize", self.h, level, 1, C.byref(nr), C.byref(nc), C.byref(nnz))

@@ -102,6 +102,12 @@ HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCF(HYPRE_Solver solver, HYPRE_Int level, HYP
 /* the level's C-first ordering: perm[new local row] = old local row (level matrices, P, R and the
  * C/F marker are reported in the NEW ordering; level 0 is a renumbered copy of the caller's matrix) */
 HYPRE_Int HYPRE_MI_BoomerAMGGetLevelPerm(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int *perm);
+/* Internal locality numbering of the input (one rank, large systems; MI_HYPRE_LOCALITY_ORDER = 0 off / 1 on, unset:
+ * at least MI_HYPRE_LOCALITY_MIN_ROWS = 1e6 rows): the hierarchy is built on Q A Q^T where Q groups rows into
+ * graph-compact clusters (breadth-first balls of 512 rows) so that tiles of consecutive rows gather few distinct
+ * columns.  order[new] = caller's local row (identity and *applied = 0 when not in use); GetLevelPerm(0) already
+ * includes it (level-0 row -> caller row). */
+HYPRE_Int HYPRE_MI_BoomerAMGGetInputOrdering(HYPRE_Solver solver, HYPRE_Int *applied, HYPRE_Int *order);
 HYPRE_Int HYPRE_MI_BoomerAMGGetLevelColMap(HYPRE_Solver solver, HYPRE_Int level, HYPRE_BigInt *col_map_offd,
                                            HYPRE_BigInt *row_start);
 /* sorted global column ids of an offd block (which: 1 A, 4 P, 5 R; length = that block's ncols) */
