@@ -1158,13 +1158,19 @@ void BoomerAMG::apply_cf_ordering() {
 // the thread count), and inside a segment every still unassigned row, in ascending order, seeds a breadth-first
 // ball of up to 512 unassigned rows.  New order = clusters in seed order, natural order inside a cluster (a stable
 // sort by cluster label); the coarse levels inherit it, C points keeping their relative order.
-namespace {
+namespace hs {
 constexpr int LOCALITY_SEGMENT = 1 << 20;
 const int LOCALITY_CLUSTER = getenv("MI_HYPRE_LOCALITY_CLUSTER") ? std::max(8, atoi(getenv("MI_HYPRE_LOCALITY_CLUSTER"))) : 512;
 
-void locality_order(const HostCSR &D, std::vector<int> &order) {
+// exclude (optional): rows that stay out of the clustering and come LAST, in natural order (rows with halo
+// entries on N > 1 ranks: the halo-free rows then form one stretch that is swept while the halo travels)
+void locality_order(const HostCSR &D, std::vector<int> &order, const std::vector<char> *exclude) {
   const int n = D.nrows;
   std::vector<int> label((size_t)n, -1);
+  constexpr int EXCLUDED = 1 << 30;
+  if (exclude)
+    for (int i = 0; i < n; i++)
+      if ((*exclude)[(size_t)i]) label[(size_t)i] = EXCLUDED;
   const int nseg = (n + LOCALITY_SEGMENT - 1) / LOCALITY_SEGMENT;
   std::vector<int> seg_clusters((size_t)nseg, 0);
   // segments are independent: threads take them from a shared counter (parallel_for does not split short ranges)
@@ -1205,11 +1211,15 @@ void locality_order(const HostCSR &D, std::vector<int> &order) {
   // stable counting sort by (segment, cluster label)
   std::vector<int64_t> seg_base((size_t)nseg + 1, 0);
   for (int sg = 0; sg < nseg; sg++) seg_base[(size_t)sg + 1] = seg_base[(size_t)sg] + seg_clusters[(size_t)sg];
-  std::vector<int64_t> start((size_t)seg_base[(size_t)nseg] + 1, 0);
-  for (int i = 0; i < n; i++) start[(size_t)(seg_base[(size_t)(i / LOCALITY_SEGMENT)] + label[(size_t)i]) + 1]++;
+  std::vector<int64_t> start((size_t)seg_base[(size_t)nseg] + 2, 0);  // last bucket: the excluded rows
+  auto bucket = [&](int i) -> size_t {
+    return label[(size_t)i] == EXCLUDED ? (size_t)seg_base[(size_t)nseg]
+                                        : (size_t)(seg_base[(size_t)(i / LOCALITY_SEGMENT)] + label[(size_t)i]);
+  };
+  for (int i = 0; i < n; i++) start[bucket(i) + 1]++;
   for (size_t c = 0; c + 1 < start.size(); c++) start[c + 1] += start[c];
   order.resize((size_t)n);
-  for (int i = 0; i < n; i++) order[(size_t)start[(size_t)(seg_base[(size_t)(i / LOCALITY_SEGMENT)] + label[(size_t)i])]++] = i;
+  for (int i = 0; i < n; i++) order[(size_t)start[bucket(i)]++] = i;
 }
 
 // B = Q A Q^T: rows of A in `order` (new -> old), columns renumbered, rows re-sorted
@@ -1243,15 +1253,20 @@ void permute_symmetric(const HostCSR &A, const std::vector<int> &order, HostCSR 
     }
   });
 }
-}  // namespace
+}  // namespace hs
 
+// one rank: large systems (or MI_HYPRE_LOCALITY_ORDER=1); N > 1 ranks (distributed setup): the same rule on the mean
+// rows per rank, so that every rank decides alike
 bool BoomerAMG::use_locality_order(const ParCSR &A) const {
-  if (forced_comm || my_comm().size != 1 || !A.col_map_offd.empty() || A.host_diag_stale) return false;
+  if (forced_comm || A.host_diag_stale) return false;
+  const int size = my_comm().size;
+  if (size == 1 && !A.col_map_offd.empty()) return false;
   const char *e = getenv("MI_HYPRE_LOCALITY_ORDER");
   if (e && atoi(e) == 0) return false;
-  if (e && atoi(e) > 0) return A.nrows > 1;
+  const long long rows = (long long)(A.global_rows() / std::max(1, size));
+  if (e && atoi(e) > 0) return rows > 1;
   static const long long min_rows = getenv("MI_HYPRE_LOCALITY_MIN_ROWS") ? atoll(getenv("MI_HYPRE_LOCALITY_MIN_ROWS")) : 1000000;
-  return A.nrows >= min_rows;
+  return rows >= min_rows;
 }
 
 void BoomerAMG::setup_host(ParCSR &A0) {
@@ -1268,6 +1283,7 @@ void BoomerAMG::setup_host(ParCSR &A0) {
   if (p.agg_num_levels > 0 && p.agg_interp_type != 4)
     fail(4, "BoomerAMGSetup: agg_interp_type " + std::to_string(p.agg_interp_type) +
                 " is not implemented (4 = multipass is); refusing to substitute another one");
+  if (comm.size > 1) input_order.clear();
   if (comm.size > 1 && can_build_distributed()) {
     build_distributed(A0);
   } else if (comm.size > 1) {
@@ -1280,7 +1296,7 @@ void BoomerAMG::setup_host(ParCSR &A0) {
     ParCSR *Ain = &A0;
     if (use_locality_order(A0)) {
       const double tq0 = wall_time();
-      locality_order(A0.diag, input_order);
+      locality_order(A0.diag, input_order, nullptr);
       Aq_own.reset(new ParCSR());
       ParCSR &Q = *Aq_own;
       permute_symmetric(A0.diag, input_order, Q.diag);

@@ -346,31 +346,54 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
   D.reserve((size_t)std::max(2, p.max_levels + 1));
   D.emplace_back();
   D[0].starts = A0.row_starts;
+  // internal locality numbering of this rank's rows (BoomerAMG::use_locality_order): clusters of the diag-block
+  // graph, rows with halo entries last; the halo columns follow their owners' renumbering (one exchange)
+  input_order.clear();
+  std::vector<int> newloc;       // old local row -> new local row
+  std::vector<gidx> newcol_h;    // new GLOBAL id of every halo column of A0
+  if (use_locality_order(A0)) {
+    const int n = A0.nrows;
+    std::vector<char> has_halo((size_t)n, 0);
+    for (int i = 0; i < n; i++) has_halo[(size_t)i] = A0.offd.ia[(size_t)i + 1] > A0.offd.ia[(size_t)i];
+    locality_order(A0.diag, input_order, &has_halo);
+    newloc.resize((size_t)n);
+    for (int q = 0; q < n; q++) newloc[(size_t)input_order[(size_t)q]] = q;
+    Ring r0;
+    r0.build(comm, A0.row_starts, A0.col_map_offd);
+    const std::vector<int> ext = r0.forward(comm, newloc);
+    newcol_h.resize(A0.col_map_offd.size());
+    for (size_t k = 0; k < newcol_h.size(); k++)
+      newcol_h[k] = A0.row_starts[(size_t)rank_of_id(A0.row_starts, A0.col_map_offd[k])] + ext[k];
+  }
   {  // level 0: diag + halo blocks merged into one row of ascending global columns
     GlobCSR &G = D[0].A;
     const int n = A0.nrows;
     G.nrows = n;
     G.ia.assign((size_t)n + 1, 0);
-    for (int i = 0; i < n; i++)
-      G.ia[(size_t)i + 1] = G.ia[(size_t)i] + (A0.diag.ia[(size_t)i + 1] - A0.diag.ia[(size_t)i]) +
+    const bool renum = !input_order.empty();
+    for (int q = 0; q < n; q++) {
+      const int i = renum ? input_order[(size_t)q] : q;
+      G.ia[(size_t)q + 1] = G.ia[(size_t)q] + (A0.diag.ia[(size_t)i + 1] - A0.diag.ia[(size_t)i]) +
                             (A0.offd.ia[(size_t)i + 1] - A0.offd.ia[(size_t)i]);
+    }
     G.gj.resize((size_t)G.nnz());
     G.a.resize((size_t)G.nnz());
     parallel_for(n, [&](int64_t b, int64_t e, int) {
-      for (int64_t i = b; i < e; i++) {
-        int64_t w = G.ia[(size_t)i];
-        int64_t kd = A0.diag.ia[(size_t)i], ko = A0.offd.ia[(size_t)i];
-        const int64_t ed = A0.diag.ia[(size_t)i + 1], eo = A0.offd.ia[(size_t)i + 1];
-        while (kd < ed || ko < eo) {
-          const gidx gd = kd < ed ? A0.row_start + A0.diag.ja[(size_t)kd] : (gidx)-1;
-          const gidx go = ko < eo ? A0.col_map_offd[(size_t)A0.offd.ja[(size_t)ko]] : (gidx)-1;
-          if (ko >= eo || (kd < ed && gd < go)) {
-            G.gj[(size_t)w] = gd;
-            G.a[(size_t)w++] = A0.diag.a[(size_t)kd++];
-          } else {
-            G.gj[(size_t)w] = go;
-            G.a[(size_t)w++] = A0.offd.a[(size_t)ko++];
-          }
+      std::vector<std::pair<gidx, double>> row;
+      for (int64_t q = b; q < e; q++) {
+        const int i = renum ? input_order[(size_t)q] : (int)q;
+        row.clear();
+        for (int64_t k = A0.diag.ia[(size_t)i]; k < A0.diag.ia[(size_t)i + 1]; k++)
+          row.push_back({A0.row_start + (renum ? newloc[(size_t)A0.diag.ja[(size_t)k]] : A0.diag.ja[(size_t)k]), A0.diag.a[(size_t)k]});
+        for (int64_t k = A0.offd.ia[(size_t)i]; k < A0.offd.ia[(size_t)i + 1]; k++)
+          row.push_back({renum ? newcol_h[(size_t)A0.offd.ja[(size_t)k]] : A0.col_map_offd[(size_t)A0.offd.ja[(size_t)k]],
+                         A0.offd.a[(size_t)k]});
+        std::sort(row.begin(), row.end(),
+                  [](const std::pair<gidx, double> &x, const std::pair<gidx, double> &y) { return x.first < y.first; });
+        int64_t w = G.ia[(size_t)q];
+        for (auto &en : row) {
+          G.gj[(size_t)w] = en.first;
+          G.a[(size_t)w++] = en.second;
         }
       }
     });
@@ -1023,6 +1046,13 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
       Out.Rm = assemble_rows(Lv.R, perm[li + 1], translate(Lv.R, li, nullptr), D[li + 1].starts, Lv.starts, rank);
       Out.Rm->build_halo_plan(comm);
     }
+  }
+  if (!input_order.empty()) {  // level-0 rows -> caller rows
+    AmgLevel &L0 = L[0];
+    if (L0.perm.empty())
+      L0.perm = input_order;
+    else
+      for (int &q : L0.perm) q = input_order[(size_t)q];
   }
   if (has_tail) {
     // the first redundant level: gathered once, then one single-rank hierarchy per rank (as before)

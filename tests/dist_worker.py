@@ -52,10 +52,14 @@ def main():
     ap.add_argument("--staging", default="host", help="host | cuda (device-tensor staging of the callback transport)")
     ap.add_argument("--seq", type=int, default=-1, help="redundant-level threshold (HYPRE seq_threshold); -1 = library default")
     ap.add_argument("--golden", default="", help="name of a multi-part fixture of tests/golden to replay after the oracle checks")
+    ap.add_argument("--locality", type=int, default=0,
+                    help="1: force the per-rank internal locality numbering (MI_HYPRE_LOCALITY_ORDER=1); the oracle then "
+                         "works on the globally permuted system")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
 
+    os.environ["MI_HYPRE_LOCALITY_ORDER"] = "1" if args.locality else "0"
     dist.init_process_group(backend="gloo")
     rank, size = dist.get_rank(), dist.get_world_size()
     mi = ge.load_binding()
@@ -103,6 +107,25 @@ def main():
         mi.call("HYPRE_MI_BoomerAMGSetupHostOnly", amg.h, A.par)
     else:
         amg.setup(A)
+    order = np.arange(starts[rank + 1] - starts[rank])
+    Ao_used, bo_used = Ao, bo
+    if args.locality:
+        # every rank renumbered its rows (clusters of its diag-block graph, rows with halo entries last): the oracle
+        # gets the globally permuted system with the same row partition
+        applied, order = amg.input_ordering()
+        assert applied and np.array_equal(np.sort(order), np.arange(len(order)))
+        parts = [None] * size
+        dist.all_gather_object(parts, (order + starts[rank]).astype(np.int64))
+        order_g = np.concatenate(parts)
+        Mq = Ao.to_scipy().tocsr()[order_g][:, order_g].tocsr()
+        Mq.sort_indices()
+        Ao_used, bo_used = oc.Csr.from_scipy(Mq), bo[order_g]
+        oamg = oc.Amg(Ao_used, oc.default_params(gs_chunk=chunk.value, part_starts=starts, redundant_rows=seq))
+        if size > 1:  # rows with halo entries come last on every rank
+            S0 = Ao.to_scipy().tocsr()[starts[rank]:starts[rank + 1]]
+            touches = np.asarray((S0[:, :starts[rank]].getnnz(axis=1) + S0[:, starts[rank + 1]:].getnnz(axis=1)) > 0)
+            nh = int(touches.sum())
+            assert nh == 0 or (np.all(touches[order[-nh:]]) and not np.any(touches[order[:-nh]]))
     assert amg.num_levels == oamg.num_levels, (amg.num_levels, oamg.num_levels)
 
     # ---- which setup ran, and what it held per rank (SURVEY 8e "coarse levels inherit the partition")
@@ -158,7 +181,9 @@ def main():
             cf = amg.level_cf(l)
             assert np.array_equal(cf, oamg.level_cf(l)[ps[rank]:ps[rank + 1]]), (l, rank)
             perm = amg.level_perm(l)
-            assert np.array_equal(perm + ps[rank], oamg.level_perm(l)[ps[rank]:ps[rank + 1]]), (l, rank)
+            operm = oamg.level_perm(l)[ps[rank]:ps[rank + 1]] - ps[rank]
+            # level 0: the product's perm leads to the CALLER's rows, through the internal numbering
+            assert np.array_equal(perm, order[operm] if l == 0 else operm), (l, rank)
             # interpolation reaches C points of other ranks: P and R = P^T carry halo blocks
             OP = oamg.level_P(l).to_scipy()
             psn = oamg.level_part_starts(l + 1)
@@ -224,12 +249,12 @@ def main():
                       f"on {n_dist} distributed levels")
             x.fill(0.0)
             assert gm.solve(A, b, x) == 0  # back to the GMRES solution for the checks below
-        xo, info = oc.gmres(Ao, bo, kdim=20, tol=1e-8, maxit=60, amg=oamg)
+        xo, info = oc.gmres(Ao_used, bo_used, kdim=20, tol=1e-8, maxit=60, amg=oamg)
         assert gm.num_iterations == info["iters"], (gm.num_iterations, info["iters"])
         hist = gm.residual_history()
         assert np.allclose(hist, info["norms"], rtol=1e-7), (hist, info["norms"])
         assert abs(gm.final_rel_res - info["rel_res"]) <= 1e-10
-        xs = x.get()
+        xs = x.get()[order]
         ref = xo[starts[rank]:starts[rank + 1]]
         assert np.all(np.abs(xs - ref) < np.maximum(1e-6 * np.maximum(np.abs(xs), np.abs(ref)), 1e-8))
         # distributed matvec / dot against the serial oracle

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
 
 
-def _run(nproc, mode, n, stencil, port, staging="host", seq=-1, devmin=None, golden="", replicated=False):
+def _run(nproc, mode, n, stencil, port, staging="host", seq=-1, devmin=None, golden="", replicated=False, locality=0):
     env = dict(os.environ)
     env["MI_HYPRE_REPLICATED_SETUP"] = "1" if replicated else "0"
     if devmin is not None:  # levels with at least this many rows are built (and sliced) on the device
@@ -30,6 +30,8 @@ def _run(nproc, mode, n, stencil, port, staging="host", seq=-1, devmin=None, gol
            "--stencil", str(stencil), "--staging", staging, "--seq", str(seq)]
     if golden:
         cmd += ["--golden", golden]
+    if locality:
+        cmd += ["--locality", "1"]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-4000:]
     return p.stdout
@@ -43,6 +45,14 @@ def test_host_setup_world_size_n_gloo(nproc, n, stencil, seq):
     sub-problem, R*(A*P) evaluated by the owners of the coarse rows): the same partition-independent hierarchy as
     the oracle's, level by level, with per-rank sub-problems of local size (asserted by the worker)."""
     out = _run(nproc, "host", n, stencil, 29611 + nproc + (7 if seq > 0 else 0) + n, seq=seq)
+    assert "dist host setup ok" in out
+
+
+@pytest.mark.parametrize("nproc,n,stencil,seq", [(2, 12, 7, -1), (3, 10, 27, 0), (2, 14, 7, 300), (4, 8, 7, 0)])
+def test_host_setup_with_locality_numbering_gloo(nproc, n, stencil, seq):
+    """The per-rank internal locality numbering (clusters of the diag-block graph, rows with halo entries last) in
+    the distributed setup: hierarchy equal to the oracle's on the globally permuted system, level-0 perm composed."""
+    out = _run(nproc, "host", n, stencil, 29951 + nproc + n, seq=seq, locality=1)
     assert "dist host setup ok" in out
 
 
@@ -76,6 +86,13 @@ def test_device_setup_and_slicing_shared_gpu(nproc, n, stencil, seq):
 def test_distributed_setup_device_spgemm_shared_gpu(nproc, n, stencil, seq):
     """The distributed setup with its sub-problem products A*P and R*(A*P) on the device (what large levels do)."""
     out = _run(nproc, "solve", n, stencil, 29831 + nproc + n, seq=seq, devmin=0)
+    assert "dist solve ok" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,n,stencil,seq", [(2, 16, 7, -1), (3, 12, 27, 0), (4, 16, 7, 1000)])
+def test_device_solve_with_locality_numbering_shared_gpu(nproc, n, stencil, seq):
+    out = _run(nproc, "solve", n, stencil, 29871 + nproc + n, seq=seq, locality=1)
     assert "dist solve ok" in out
 
 
