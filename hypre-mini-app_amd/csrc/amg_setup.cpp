@@ -1175,14 +1175,56 @@ void locality_order(const HostCSR &D, std::vector<int> &order, const std::vector
   std::vector<int> seg_clusters((size_t)nseg, 0);
   // segments are independent: threads take them from a shared counter (parallel_for does not split short ranges)
   std::atomic<int> next_seg(0);
+  // MI_HYPRE_LOCALITY_GROW=1 (experiment): instead of breadth-first order, always add the frontier row with the most
+  // neighbours already inside the cluster (ties: first come) -- grows bricks rather than diamonds on grid graphs
+  static const bool greedy_grow = getenv("MI_HYPRE_LOCALITY_GROW") && atoi(getenv("MI_HYPRE_LOCALITY_GROW")) != 0;
   auto worker = [&]() {
     std::vector<int> queue;
     queue.reserve(LOCALITY_CLUSTER + 64);
+    constexpr int MAXC = 16;
+    std::vector<std::vector<int>> bucket(MAXC + 1);
+    std::vector<size_t> bhead(MAXC + 1, 0);
+    std::vector<unsigned char> cnt;
     for (int sg = next_seg++; sg < nseg; sg = next_seg++) {
       const int r0 = (int)((int64_t)sg * LOCALITY_SEGMENT), r1 = (int)std::min<int64_t>(n, ((int64_t)sg + 1) * LOCALITY_SEGMENT);
       int ncl = 0;
+      if (greedy_grow) cnt.assign((size_t)(r1 - r0), 0);
       for (int seed = r0; seed < r1; seed++) {
         if (label[(size_t)seed] >= 0) continue;
+        if (greedy_grow) {
+          for (int c = 0; c <= MAXC; c++) bucket[(size_t)c].clear(), bhead[(size_t)c] = 0;
+          int size = 0, v = seed;
+          std::vector<int> touched;
+          for (;;) {
+            label[(size_t)v] = ncl;
+            size++;
+            if (size >= LOCALITY_CLUSTER) break;
+            for (int64_t k = D.ia[(size_t)v]; k < D.ia[(size_t)v + 1]; k++) {
+              const int j = D.ja[(size_t)k];
+              if (j < r0 || j >= r1 || label[(size_t)j] >= 0) continue;
+              unsigned char &c = cnt[(size_t)(j - r0)];
+              if (c == 0) touched.push_back(j);
+              if (c < MAXC) c++;
+              bucket[(size_t)c].push_back(j);
+            }
+            v = -1;
+            for (int c = MAXC; c >= 1 && v < 0; c--) {
+              std::vector<int> &b = bucket[(size_t)c];
+              size_t &h = bhead[(size_t)c];
+              while (h < b.size()) {
+                const int u = b[h++];
+                if (label[(size_t)u] < 0 && cnt[(size_t)(u - r0)] == c) {  // not stale
+                  v = u;
+                  break;
+                }
+              }
+            }
+            if (v < 0) break;
+          }
+          for (int u : touched) cnt[(size_t)(u - r0)] = 0;
+          ncl++;
+          continue;
+        }
         queue.clear();
         queue.push_back(seed);
         label[(size_t)seed] = ncl;

@@ -110,3 +110,28 @@ def test_multi_part_golden_fixtures(name, nproc, n, seq):
     """The committed multi-part fixtures (tests/golden), replayed with one rank per part."""
     out = _run(nproc, "solve", n, 7, 29771 + nproc + n, seq=seq, golden=name)
     assert f"golden {name} ok" in out
+
+
+@pytest.mark.gpu
+def test_rccl_overlap_equals_in_order_on_two_gpus():
+    """with at least two GPUs, the RCCL transport's side-stream choreography (MI_HYPRE_OVERLAP_HALO=1) must
+    give bitwise the same solve as the in-order one (=0).  The one-GPU test boxes skip this; bench.py exercises the
+    same path whenever the driver runs it on a multi-GPU node."""
+    import json
+
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL refuses two ranks on one device)")
+    outs = []
+    for overlap in ("1", "0"):
+        env = dict(os.environ, MI_HYPRE_OVERLAP_HALO=overlap, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--n", "96", "--steps", "1",
+                            "--warmup", "0", "--no-cpu"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           text=True, timeout=900)
+        assert p.returncode == 0, p.stdout[-3000:]
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+        outs.append(json.loads(line))
+    assert outs[0]["iterations_per_solve"] == outs[1]["iterations_per_solve"]
+    assert outs[0]["final_rel_residual"] == outs[1]["final_rel_residual"]  # bitwise
+    assert "rccl" in outs[0]["config"]["transport"]

@@ -367,3 +367,35 @@ def test_shipped_sample_input_runs_unchanged(tmp_path):
     m = re.search(r"max abs err=([0-9.eE+-]+)", out)
     assert m and float(m.group(1)) < 1e-3 * np.abs(x).max(), out[-2000:]
     assert "not implemented" not in out and "not restated" not in out
+
+
+def test_driver_with_internal_locality_numbering(tmp_path, monkeypatch):
+    """The driver on a MatrixMarket system with the internal locality numbering forced on (it is automatic above
+    10^6 rows): the solution is checked in the caller's numbering against scipy's direct solve, and the written
+    solution file is in the caller's numbering too."""
+    monkeypatch.setenv("MI_HYPRE_LOCALITY_ORDER", "1")
+    A, b, x = _system(48, 9, nonsym=True)
+    _write_mm_matrix(tmp_path / "mat.mm", A)
+    _write_mm_vector(tmp_path / "rhs.mm", b)
+    _write_mm_vector(tmp_path / "sln.mm", x)
+    out = _run(tmp_path, """
+linear_system:
+  type: matrix_market
+  matrix_file: mat.mm
+  rhs_file: rhs.mm
+  sln_file: sln.mm
+  rtol: 1.0e-6
+  atol: 1.0e-8
+  write_solution: true
+
+solver_settings:
+  method: gmres
+  preconditioner: boomeramg
+  tolerance: 1.0e-12
+  max_iterations: 100
+  kspace: 30
+  print_level: 0
+""" + DEFAULT_AMG)
+    assert "allClose=1" in out
+    got = np.loadtxt(tmp_path / "IJV0.sln.00000", skiprows=1)
+    assert np.allclose(got[:, 1], x, rtol=1e-6, atol=1e-8)

@@ -135,3 +135,49 @@ def test_device_solve_with_locality_order(mi, oc, n, stencil, monkeypatch):
     assert abs(gm.final_rel_res - info["rel_res"]) <= 1e-10
     xs = x.get()
     assert np.abs(xs[order] - xo).max() < 1e-9 and np.abs(xs - 1.0).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_irregular_graph_with_locality_order(mi, oc, monkeypatch):
+    """A random sparse M-matrix (no grid structure, isolated rows, rows of very different length): the numbering is a
+    permutation, the solve matches the oracle on the permuted system and scipy's direct solve in the caller's order."""
+    import scipy.sparse.linalg as spl
+
+    monkeypatch.setenv("MI_HYPRE_LOCALITY_ORDER", "1")
+    rng = np.random.default_rng(77)
+    n = 4000
+    M = sp.random(n, n, density=0.0015, random_state=rng, format="csr")
+    M = (M + M.T).tocsr()
+    M = (M - sp.diags(M.diagonal())).tolil()
+    M[17, :] = 0.0  # isolated rows
+    M[:, 17] = 0.0
+    M[2048, :] = 0.0
+    M[:, 2048] = 0.0
+    M = M.tocsr()
+    M = (-abs(M) + sp.diags(abs(M).sum(axis=1).A1 + 0.3)).tocsr()
+    M.eliminate_zeros()
+    M.sort_indices()
+    xs = rng.standard_normal(n)
+    rhs = M @ xs
+    A = mi.matrix_from_scipy(M)
+    b = mi.IJVector(0, n - 1, rhs)
+    x = mi.IJVector(0, n - 1, np.zeros(n))
+    amg = mi.BoomerAMG(print_level=0, strong_threshold=0.25)
+    gm = mi.GMRES(tolerance=1e-11, max_iterations=100, kspace=50, print_level=0)
+    gm.set_precond(amg)
+    gm.setup(A, b, x)
+    assert gm.solve(A, b, x) == 0
+    applied, order = amg.input_ordering()
+    assert applied and np.array_equal(np.sort(order), np.arange(n))
+    chunk = mi.c_int()
+    mi.call("HYPRE_MI_GetGSChunk", mi.C.byref(chunk))
+    Mq = M[order][:, order].tocsr()
+    Mq.sort_indices()
+    Aq = oc.Csr.from_scipy(Mq)
+    oamg = oc.Amg(Aq, oc.default_params(gs_chunk=chunk.value, strong_threshold=0.25))
+    xo, info = oc.gmres(Aq, rhs[order], kdim=50, tol=1e-11, maxit=100, amg=oamg)
+    assert gm.num_iterations == info["iters"] and abs(gm.final_rel_res - info["rel_res"]) <= 1e-10
+    got = x.get()
+    assert np.abs(got[order] - xo).max() <= 1e-9 * np.abs(xo).max()
+    xd = spl.spsolve(M.tocsc(), rhs)
+    assert np.abs(got - xd).max() <= 1e-8 * np.abs(xd).max()
