@@ -292,7 +292,9 @@ def spawn_ranks(args):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
+    # torch.distributed.run's parser trips over an abbreviated "--n" even behind the script name: spell it out
+    cmd += ["--grid" if a == "--n" else ("--grid=" + a[4:] if a.startswith("--n=") else a) for a in sys.argv[1:]]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.run(cmd, env=env).returncode

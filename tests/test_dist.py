@@ -126,7 +126,7 @@ def test_rccl_overlap_equals_in_order_on_two_gpus():
     outs = []
     for overlap in ("1", "0"):
         env = dict(os.environ, MI_HYPRE_OVERLAP_HALO=overlap, HSA_ENABLE_IPC_MODE_LEGACY="0")
-        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--n", "96", "--steps", "1",
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "96", "--steps", "1",
                             "--warmup", "0", "--no-cpu"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                            text=True, timeout=900)
         assert p.returncode == 0, p.stdout[-3000:]
