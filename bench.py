@@ -153,13 +153,13 @@ def run_convdiff3(args, mi, dist, rank, world, transport, rehearsal, torch):
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     got = xv[0].get_all() if not args.segregated else np.stack([v.get() for v in xv])
     err = float(np.abs(got - X).max())
     if dist is not None:
-        e = torch.tensor([err], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        e = torch.tensor([err], dtype=torch.float64, device="cpu")
         dist.all_reduce(e, op=dist.ReduceOp.MAX)
         err = float(e.item())
     if rank == 0:
@@ -325,10 +325,10 @@ def main():
         import torch.distributed as dist_
 
         dist = dist_
-        if rehearsal:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # control plane only (unique-id hand-off, barriers, the max over ranks of the elapsed time): gloo.  The data
+        # path -- halo exchanges, all-reduces, all-gathers -- runs on the LIBRARY's own RCCL communicator, the only
+        # RCCL communicator of the process (a second, torch-owned one would share the GPUs' channels for nothing)
+        dist.init_process_group(backend="gloo")
 
     mi = ge.load_binding()
     mi.init()
@@ -338,7 +338,7 @@ def main():
         mi.init_comm_torch(dist, device=None)
     elif world > 1:
         # ncclUniqueId from rank 0 to everyone, then the library opens its own RCCL communicator
-        transport = "rccl (library communicator: ncclSend/ncclRecv halo groups, ncclAllReduce dots)"
+        transport = "rccl (library communicator: ncclSend/ncclRecv halo groups, ncclAllReduce dots); control plane gloo"
         ok = 1
         try:
             idbuf = torch.zeros(128, dtype=torch.uint8)
@@ -346,23 +346,22 @@ def main():
                 raw = (C.c_ubyte * 128)()
                 mi.call("HYPRE_MI_CommGetUniqueId", raw)
                 idbuf = torch.tensor(list(raw), dtype=torch.uint8)
-            idbuf = idbuf.cuda()
             dist.broadcast(idbuf, src=0)
-            raw = (C.c_ubyte * 128)(*idbuf.cpu().tolist())
+            raw = (C.c_ubyte * 128)(*idbuf.tolist())
             mi.call("HYPRE_MI_CommInitRCCL", raw, rank, world)
         except Exception as e:  # noqa: BLE001
             ok = 0
             print(f"[bench rank {rank}] library RCCL communicator failed: {e}", file=sys.stderr, flush=True)
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        flag = torch.tensor([ok], dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
-            # LOUD fallback, still RCCL: the same collectives through torch.distributed's
-            # communicator, staged through host callbacks (slower; reported in the JSON)
-            transport = "torch.distributed(nccl) callbacks -- library RCCL communicator FAILED, see stderr"
+            # LOUD fallback: the same collectives through torch.distributed (gloo), staged through host callbacks
+            # (much slower; reported in the JSON so that the line cannot pass for an RCCL measurement)
+            transport = "FALLBACK torch.distributed(gloo) host callbacks -- library RCCL communicator FAILED, see stderr"
             if rank == 0:
                 print("[bench] WARNING: falling back to the torch.distributed transport", file=sys.stderr, flush=True)
             mi.call("HYPRE_MI_CommFinalize")
-            mi.init_comm_torch(dist, device="cuda")
+            mi.init_comm_torch(dist, device=None)
 
     if args.workload == "convdiff3":
         return run_convdiff3(args, mi, dist, rank, world, transport, rehearsal, torch)
@@ -407,7 +406,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
