@@ -1250,18 +1250,48 @@ void locality_order(const HostCSR &D, std::vector<int> &order, const std::vector
     worker();
     for (auto &x : th) x.join();
   }
-  // stable counting sort by (segment, cluster label)
-  std::vector<int64_t> seg_base((size_t)nseg + 1, 0);
-  for (int sg = 0; sg < nseg; sg++) seg_base[(size_t)sg + 1] = seg_base[(size_t)sg] + seg_clusters[(size_t)sg];
-  std::vector<int64_t> start((size_t)seg_base[(size_t)nseg] + 2, 0);  // last bucket: the excluded rows
-  auto bucket = [&](int i) -> size_t {
-    return label[(size_t)i] == EXCLUDED ? (size_t)seg_base[(size_t)nseg]
-                                        : (size_t)(seg_base[(size_t)(i / LOCALITY_SEGMENT)] + label[(size_t)i]);
+  // stable counting sort by (segment, cluster label): a segment's clustered rows stay inside one contiguous range
+  // of the new order (segments in order, the excluded rows after all of them), so every segment sorts its own
+  std::vector<int64_t> seg_rows((size_t)nseg + 1, 0);  // clustered (non-excluded) rows per segment, then prefix
+  std::vector<std::thread> th;
+  std::atomic<int> next2(0);
+  auto count_worker = [&]() {
+    for (int sg = next2++; sg < nseg; sg = next2++) {
+      const int r0 = (int)((int64_t)sg * LOCALITY_SEGMENT), r1 = (int)std::min<int64_t>(n, ((int64_t)sg + 1) * LOCALITY_SEGMENT);
+      int64_t c = 0;
+      for (int i = r0; i < r1; i++) c += (label[(size_t)i] != EXCLUDED);
+      seg_rows[(size_t)sg + 1] = c;
+    }
   };
-  for (int i = 0; i < n; i++) start[bucket(i) + 1]++;
-  for (size_t c = 0; c + 1 < start.size(); c++) start[c + 1] += start[c];
+  const int nt2 = std::max(1, std::min(nseg, host_threads()));
+  for (int t = 1; t < nt2; t++) th.emplace_back(count_worker);
+  count_worker();
+  for (auto &x : th) x.join();
+  th.clear();
+  for (int sg = 0; sg < nseg; sg++) seg_rows[(size_t)sg + 1] += seg_rows[(size_t)sg];
   order.resize((size_t)n);
-  for (int i = 0; i < n; i++) order[(size_t)start[bucket(i)]++] = i;
+  std::atomic<int> next3(0);
+  auto sort_worker = [&]() {
+    std::vector<int64_t> start;
+    for (int sg = next3++; sg < nseg; sg = next3++) {
+      const int r0 = (int)((int64_t)sg * LOCALITY_SEGMENT), r1 = (int)std::min<int64_t>(n, ((int64_t)sg + 1) * LOCALITY_SEGMENT);
+      start.assign((size_t)seg_clusters[(size_t)sg] + 1, 0);
+      for (int i = r0; i < r1; i++)
+        if (label[(size_t)i] != EXCLUDED) start[(size_t)label[(size_t)i] + 1]++;
+      start[0] = seg_rows[(size_t)sg];
+      for (size_t c = 0; c + 1 < start.size(); c++) start[c + 1] += start[c];
+      for (int i = r0; i < r1; i++)
+        if (label[(size_t)i] != EXCLUDED) order[(size_t)start[(size_t)label[(size_t)i]]++] = i;
+    }
+  };
+  for (int t = 1; t < nt2; t++) th.emplace_back(sort_worker);
+  sort_worker();
+  for (auto &x : th) x.join();
+  if (exclude) {  // the excluded rows last, natural order
+    int64_t w = seg_rows[(size_t)nseg];
+    for (int i = 0; i < n; i++)
+      if (label[(size_t)i] == EXCLUDED) order[(size_t)w++] = i;
+  }
 }
 
 // B = Q A Q^T: rows of A in `order` (new -> old), columns renumbered, rows re-sorted

@@ -126,8 +126,10 @@ void GmresSolver::setup(ParCSR &A, ParVector &b, ParVector &x) {
   // fills its basis behind an AMG preconditioner
   r.init(b.start, b.end, b.ncomp);
   w.init(b.start, b.end, b.ncomp);
-  p.clear();
-  z.clear();
+  // the basis survives a repeated Setup on vectors of the same shape (the reference calls Setup before every
+  // Solve, src/HypreSystem.cpp:692 inside the loop at :681); another shape starts afresh
+  if (!p.empty() && (p[0]->n != b.n || p[0]->ncomp != b.ncomp || p[0]->start != b.start)) p.clear();
+  if (!z.empty() && (z[0]->n != b.n || z[0]->ncomp != b.ncomp || z[0]->start != b.start)) z.clear();
   if (precond_setup) precond_setup(precond_data, &A, &b, &x);
 }
 
