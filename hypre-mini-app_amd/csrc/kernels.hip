@@ -8,6 +8,8 @@
 #include <algorithm>
 
 #include "kernels.hpp"
+
+#include <cstring>
 #include "profile.hpp"
 
 namespace mi {
@@ -32,6 +34,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 typedef double d2_t __attribute__((ext_vector_type(2)));
 typedef int i2_t __attribute__((ext_vector_type(2)));
 typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+typedef unsigned char uc2_t __attribute__((ext_vector_type(2)));
 template <class T>
 __device__ __forceinline__ T nt_load(const T *p) {
   return __builtin_nontemporal_load(p);
@@ -148,19 +151,24 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream(int nb, int xchunk, co
 // pointers of the row sums; the x gathers start as soon as the column ids are back, while the stream is still
 // in flight.  (Worth ~0.5 % of the 512^3 solve over the rb -> ia -> stream / uptr -> ucols -> x order: the
 // kernel is not bound by this chain alone -- VALU, LDS and the L1 gather path are each 25-30 % busy.)
-template <int EPI, int TAG>
+// VAL8: the operator has a value dictionary (DevCSR::vidx / vlut): the stream is one byte per value, looked up in
+// a 2 KB LDS copy of the table
+template <int EPI, int TAG, bool VAL8>
 __global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream_xc(int nb, int xchunk, const int *__restrict__ tdesc,
                                                              const int *__restrict__ ia, const int *__restrict__ ja,
                                                              const double *__restrict__ av,
                                                              const int *__restrict__ ucols,
                                                              const unsigned short *__restrict__ lcol,
                                                              const double *__restrict__ x, double *__restrict__ y,
-                                                             EpiArgs e) {
+                                                             EpiArgs e, const unsigned char *__restrict__ vidx,
+                                                             const double *__restrict__ vlut) {
   __shared__ double prod[SPMV_TILE];
+  __shared__ double slut[VAL8 ? 256 : 1];
   double *xs = prod;
   const int blk = xcd_remap(blockIdx.x, xchunk);
   if (blk >= nb) return;
   const int tid = threadIdx.x;
+  if (VAL8) slut[tid] = vlut[tid];  // visible after the first barrier below
   const int4 d0 = reinterpret_cast<const int4 *>(tdesc)[2 * blk];
   const int4 d1 = reinterpret_cast<const int4 *>(tdesc)[2 * blk + 1];
   const int r0 = d0.x, r1 = d0.y, base = d0.z, end = d0.w, u0 = d1.x, nu = d1.y;
@@ -185,11 +193,15 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream_xc(int nb, int xchunk,
   constexpr int NIT = SPMV_TILE / (2 * SPMV_BLOCK);
   d2_t vv[NIT];
   us2_t cc[NIT];
+  uc2_t vi[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; it++) {
     const int k = 2 * tid + it * 2 * SPMV_BLOCK;
     if (k < cnt) {
-      vv[it] = *reinterpret_cast<const d2_t *>(av + base_al + k);
+      if (VAL8)
+        vi[it] = *reinterpret_cast<const uc2_t *>(vidx + base_al + k);
+      else
+        vv[it] = *reinterpret_cast<const d2_t *>(av + base_al + k);
       cc[it] = *reinterpret_cast<const us2_t *>(lcol + base_al + k);
     }
   }
@@ -220,6 +232,10 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream_xc(int nb, int xchunk,
     if (k < cnt) {
       const bool ok0 = (base_al + k >= base);
       const bool ok1 = (base_al + k + 1 < end);
+      if (VAL8) {
+        vv[it].x = slut[vi[it].x];
+        vv[it].y = slut[vi[it].y];
+      }
       vv[it].x = ok0 ? vv[it].x * xs[cc[it].x & XC_ID_MASK] : 0.0;
       vv[it].y = ok1 ? vv[it].y * xs[cc[it].y & XC_ID_MASK] : 0.0;
     }
@@ -699,6 +715,7 @@ __global__ __launch_bounds__(256) void gs_dense_k(int n, int chunk0, int nchunks
 // products out of LDS, picks its in-chunk coefficients by the code bits of the
 // 16-bit column entries, and runs the dense 8x8 sweep of gs_dense_k.
 // ---------------------------------------------------------------------------
+template <bool VAL8>
 __global__ __launch_bounds__(SPMV_BLOCK) void gs_tile_k(int blk0, int nblk, const int *__restrict__ tdesc,
                                                         const int *__restrict__ ia, const double *__restrict__ av,
                                                         const int *__restrict__ ucols,
@@ -710,13 +727,19 @@ __global__ __launch_bounds__(SPMV_BLOCK) void gs_tile_k(int blk0, int nblk, cons
                                                         const double *__restrict__ u_hi, int split,
                                                         double *__restrict__ u_new, int fwd, int bwd, double w,
                                                         int row_begin, int row_end, int zero_from,
-                                                        double *__restrict__ tout, int t_from) {
+                                                        double *__restrict__ tout, int t_from,
+                                                        const unsigned char *__restrict__ vidx,
+                                                        const double *__restrict__ vlut) {
 #define UOLD(j) (((j) < split ? u_lo : u_hi)[(j)])
   __shared__ double buf[SPMV_TILE];           // x cache, then products / in-chunk coefficients
   __shared__ unsigned short code[SPMV_TILE];  // the entries' lcol words
+  // value dictionary (see spmv_stream_xc): lives in the first 2 KB of `code`, which is only written after the last
+  // lookup (second barrier) -- no LDS beyond the 20 KB that allow 8 workgroups per CU
+  double *slut = reinterpret_cast<double *>(code);
   if ((int)blockIdx.x >= nblk) return;
   const int blk = blk0 + blockIdx.x;
   const int tid = threadIdx.x;
+  if (VAL8) slut[tid] = vlut[tid];
   // one descriptor load, then the loads in the order of their dependent chains (see spmv_stream_xc): column
   // list, matrix stream, per-row data; the gathers start when the column ids are back
   const int4 d0 = reinterpret_cast<const int4 *>(tdesc)[2 * blk];
@@ -739,11 +762,15 @@ __global__ __launch_bounds__(SPMV_BLOCK) void gs_tile_k(int blk0, int nblk, cons
   constexpr int NIT = SPMV_TILE / (2 * SPMV_BLOCK);
   d2_t vv[NIT];
   us2_t cc[NIT];
+  uc2_t vi[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; it++) {
     const int k = 2 * tid + it * 2 * SPMV_BLOCK;
     if (k < cnt) {
-      vv[it] = *reinterpret_cast<const d2_t *>(av + base_al + k);
+      if (VAL8)
+        vi[it] = *reinterpret_cast<const uc2_t *>(vidx + base_al + k);
+      else
+        vv[it] = *reinterpret_cast<const d2_t *>(av + base_al + k);
       cc[it] = *reinterpret_cast<const us2_t *>(lcol + base_al + k);
     }
   }
@@ -787,6 +814,10 @@ __global__ __launch_bounds__(SPMV_BLOCK) void gs_tile_k(int blk0, int nblk, cons
       const bool ok0 = (base_al + k >= base);
       const bool ok1 = (base_al + k + 1 < end);
       const unsigned c0 = cc[it].x, c1 = cc[it].y;
+      if (VAL8) {
+        vv[it].x = slut[vi[it].x];
+        vv[it].y = slut[vi[it].y];
+      }
       // out-of-chunk: product with the snapshot value; in-chunk: the coefficient itself
       const double x0 = all_zero ? 0.0 : buf[c0 & XC_ID_MASK], x1 = all_zero ? 0.0 : buf[c1 & XC_ID_MASK];
       vv[it].x = ok0 ? ((c0 & XC_INCH) ? vv[it].x : vv[it].x * x0) : 0.0;
@@ -1178,15 +1209,25 @@ static void launch_stream(int epi, const DevCSR &A, const double *x, double *y, 
   const int xchunk = (nb + 7) / 8;
   const dim3 grid(xchunk * 8), block(SPMV_BLOCK);
   if (A.xcache) {
-    if (epi == 0 && level0)
-      hipLaunchKernelGGL((spmv_stream_xc<0, 1>), grid, block, 0, s, nb, xchunk, A.tdesc.p, A.ia.p, A.ja.p, A.a.p,
-                         A.ucols.p, A.lcol.p, x, y, e);
-    else if (epi == 0)
-      hipLaunchKernelGGL((spmv_stream_xc<0, 0>), grid, block, 0, s, nb, xchunk, A.tdesc.p, A.ia.p, A.ja.p, A.a.p,
-                         A.ucols.p, A.lcol.p, x, y, e);
-    else
-      hipLaunchKernelGGL((spmv_stream_xc<1, 0>), grid, block, 0, s, nb, xchunk, A.tdesc.p, A.ia.p, A.ja.p, A.a.p,
-                         A.ucols.p, A.lcol.p, x, y, e);
+#define XC_LAUNCH(EPI_, TAG_, V8_)                                                                                  \
+  hipLaunchKernelGGL((spmv_stream_xc<EPI_, TAG_, V8_>), grid, block, 0, s, nb, xchunk, A.tdesc.p, A.ia.p, A.ja.p, \
+                     A.a.p, A.ucols.p, A.lcol.p, x, y, e, A.vidx.p, A.vlut.p)
+    if (A.val8) {
+      if (epi == 0 && level0)
+        XC_LAUNCH(0, 1, true);
+      else if (epi == 0)
+        XC_LAUNCH(0, 0, true);
+      else
+        XC_LAUNCH(1, 0, true);
+    } else {
+      if (epi == 0 && level0)
+        XC_LAUNCH(0, 1, false);
+      else if (epi == 0)
+        XC_LAUNCH(0, 0, false);
+      else
+        XC_LAUNCH(1, 0, false);
+    }
+#undef XC_LAUNCH
   } else if (epi == 0 && level0)
     hipLaunchKernelGGL((spmv_stream<0, 1>), grid, block, 0, s, nb, xchunk, A.rb.p, A.ia.p, A.ja.p, A.a.p, x, y, e);
   else if (epi == 0)
@@ -1196,6 +1237,70 @@ static void launch_stream(int epi, const DevCSR &A, const double *x, double *y, 
   MI_HIP(hipGetLastError());
 }
 
+namespace {
+// vidx[k] = position of a[k] in the sorted table of bit patterns; *fail counts values that are not in it
+__global__ __launch_bounds__(256) void value_index_k(long long n, const double *__restrict__ a,
+                                                     const long long *__restrict__ table, int nt,
+                                                     unsigned char *__restrict__ vidx, int *__restrict__ fail) {
+  const long long stride = (long long)gridDim.x * 256;
+  int bad = 0;
+  for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < n; k += stride) {
+    const long long bits = __double_as_longlong(a[k]);
+    int lo = 0, hi = nt;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (table[mid] < bits)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    if (lo < nt && table[lo] == bits)
+      vidx[k] = (unsigned char)lo;
+    else
+      bad = 1;
+  }
+  if (bad) atomicAdd(fail, 1);
+}
+}  // namespace
+
+// Value dictionary of an operator in the solve format: distinct values (bit patterns) of a sample, at most 256;
+// one pass then encodes every entry or finds one that is not in the table (the operator keeps the plain stream).
+// MI_HYPRE_VALUE_DICT=0 switches it off.
+void build_value_dictionary(DevCSR &A, hipStream_t s) {
+  A.val8 = false;
+  A.vidx.release();
+  A.vlut.release();
+  static const bool enabled = !(getenv("MI_HYPRE_VALUE_DICT") && atoi(getenv("MI_HYPRE_VALUE_DICT")) == 0);
+  if (!enabled || !A.xcache || A.nnz < (1 << 16) || !A.a.p) return;
+  const size_t sample = (size_t)std::min<int64_t>(A.nnz, 1 << 16);  // enough to see > 256 distinct values at once
+  std::vector<double> hs(sample);
+  MI_HIP(hipMemcpyAsync(hs.data(), A.a.p, sample * sizeof(double), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+  std::vector<long long> bits(sample);
+  std::memcpy(bits.data(), hs.data(), sample * sizeof(double));
+  std::sort(bits.begin(), bits.end());
+  bits.erase(std::unique(bits.begin(), bits.end()), bits.end());
+  if (bits.size() > 256) return;
+  const int nt = (int)bits.size();
+  DVec<long long> dtab;
+  dtab.upload(bits);
+  DVec<int> fail(1);
+  MI_HIP(hipMemsetAsync(fail.p, 0, sizeof(int), s));
+  A.vidx.alloc((size_t)A.nnz);
+  hipLaunchKernelGGL(value_index_k, dim3(4096), dim3(256), 0, s, (long long)A.nnz, A.a.p, dtab.p, nt, A.vidx.p, fail.p);
+  int nfail = 0;
+  MI_HIP(hipMemcpyAsync(&nfail, fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+  if (nfail) {  // a value beyond the sample's 256: plain stream
+    A.vidx.release();
+    return;
+  }
+  std::vector<double> lut(256, 0.0);
+  std::memcpy(lut.data(), bits.data(), (size_t)nt * sizeof(double));
+  A.vlut.upload(lut);
+  A.val8 = true;
+}
+
 void build_tile_desc(DevCSR &A, hipStream_t s) {
   A.tdesc.release();
   if (A.nblocks <= 0 || !A.rb.p) return;
@@ -1203,6 +1308,7 @@ void build_tile_desc(DevCSR &A, hipStream_t s) {
   hipLaunchKernelGGL(tile_desc_k, dim3((unsigned)((A.nblocks + 255) / 256)), dim3(256), 0, s, A.nblocks, A.rb.p, A.ia.p,
                      A.xcache ? A.uptr.p : nullptr, A.tdesc.p);
   MI_HIP(hipGetLastError());
+  build_value_dictionary(A, s);
 }
 
 void spmv(const DevCSR &A, const double *x, double alpha, double beta, const double *b, double *y, hipStream_t s,
@@ -1265,10 +1371,14 @@ void gs_hybrid(const DevCSR &A, const double *u_lo, const double *u_hi, int spli
     const int first_row = (int)(c0 * 8), last_row = (int)std::min<long long>(c1 * 8, A.nrows);
     const int b0 = (int)(std::upper_bound(rbh.begin(), rbh.end(), first_row) - rbh.begin()) - 1;
     const int b1 = (int)(std::lower_bound(rbh.begin(), rbh.end(), last_row) - rbh.begin());
-    if (b1 > b0)
-      hipLaunchKernelGGL(gs_tile_k, dim3((unsigned)(b1 - b0)), dim3(SPMV_BLOCK), 0, s, b0, b1 - b0, A.tdesc.p, A.ia.p,
-                         A.a.p, A.ucols.p, A.lcol.p, cf, points, d, f, offc, u_lo, u_hi, split, out,
-                         fwd ? 1 : 0, bwd ? 1 : 0, w, first_row, last_row, zero_from, tout, t_from);
+    if (b1 > b0 && A.val8)
+      hipLaunchKernelGGL(gs_tile_k<true>, dim3((unsigned)(b1 - b0)), dim3(SPMV_BLOCK), 0, s, b0, b1 - b0, A.tdesc.p,
+                         A.ia.p, A.a.p, A.ucols.p, A.lcol.p, cf, points, d, f, offc, u_lo, u_hi, split, out,
+                         fwd ? 1 : 0, bwd ? 1 : 0, w, first_row, last_row, zero_from, tout, t_from, A.vidx.p, A.vlut.p);
+    else if (b1 > b0)
+      hipLaunchKernelGGL(gs_tile_k<false>, dim3((unsigned)(b1 - b0)), dim3(SPMV_BLOCK), 0, s, b0, b1 - b0, A.tdesc.p,
+                         A.ia.p, A.a.p, A.ucols.p, A.lcol.p, cf, points, d, f, offc, u_lo, u_hi, split, out,
+                         fwd ? 1 : 0, bwd ? 1 : 0, w, first_row, last_row, zero_from, tout, t_from, nullptr, nullptr);
   } else if (chunk == 8 && !gs_force_generic()) {
     const double avg = (double)A.nnz / (double)A.nrows;
     const int p95 = A.rowlen_p95;

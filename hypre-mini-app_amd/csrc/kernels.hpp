@@ -44,6 +44,8 @@ constexpr int XC_OFF_SHIFT = 12;    // ... at this offset (3 bits)
 // per-tile descriptors of the SpMV / tile-GS kernels (row range, entry range, column-list range: 8 ints per
 // tile); call after rb, ia and (x cache) uptr are in place
 void build_tile_desc(DevCSR &A, hipStream_t s);
+// value dictionary of an operator with at most 256 distinct values (called by build_tile_desc)
+void build_value_dictionary(DevCSR &A, hipStream_t s);
 // y = alpha*A*x + beta*b   (b may alias y)
 void spmv(const DevCSR &A, const double *x, double alpha, double beta, const double *b, double *y, hipStream_t s,
           int prof = PROF_NONE);

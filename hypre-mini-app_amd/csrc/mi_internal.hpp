@@ -117,6 +117,13 @@ struct DevCSR {
   int max_tile_rows = 256;   // rows of the largest tile
   DVec<int> uptr, ucols;
   DVec<unsigned short> lcol;
+  // value dictionary (k::build_value_dictionary): operators with at most 256 distinct values (constant-coefficient
+  // stencils such as the reference's own generator: 26 / -1, or 6 / -1) carry one byte per entry besides `a`; the
+  // x-cache SpMV and the tile Gauss-Seidel kernel then stream 3 instead of 10 bytes per entry and look the value up
+  // in a 2 KB LDS table -- the same doubles, so results do not change by a bit
+  DVec<unsigned char> vidx;
+  DVec<double> vlut;  // 256 entries (unused ones zero)
+  bool val8 = false;
   DVec<int> tdesc;  // 8 ints per tile: r0, r1, ia[r0], ia[r1], uptr[b], #unique columns, 0, 0 (k::build_tile_desc)
   bool empty() const { return nrows == 0 || nnz == 0; }
   void upload(const HostCSR &h);
