@@ -2129,6 +2129,15 @@ void BoomerAMG::setup_device() {
   MI_HIP(hipDeviceSynchronize());
   is_setup = true;
   setup_seconds = wall_time() - t_setup_start;
+  if (timing) {
+    printf("   value dictionaries (1-byte value stream):");
+    for (size_t li = 0; li < L.size(); li++) {
+      const AmgLevel &Lv = L[li];
+      printf(" L%zu[%s%s%s%s%s]", li, Lv.A->d_diag.val8 ? "A" : "", Lv.has_Az && Lv.Az.val8 ? " Az" : "",
+             Lv.has_Ar && Lv.Ar.val8 ? " Ar" : "", Lv.Pm && Lv.Pm->d_diag.val8 ? " P" : "", Lv.Rm && Lv.Rm->d_diag.val8 ? " R" : "");
+    }
+    printf("\n");
+  }
   if (p.print_level > 0 && comm.rank == 0) {
     printf("mi_hypre BoomerAMG setup: %d levels, operator complexity %.3f, chunk %d, %.3f s\n", total_levels(),
            operator_complexity(), ch, setup_seconds);

@@ -1272,9 +1272,13 @@ void build_value_dictionary(DevCSR &A, hipStream_t s) {
   A.vlut.release();
   static const bool enabled = !(getenv("MI_HYPRE_VALUE_DICT") && atoi(getenv("MI_HYPRE_VALUE_DICT")) == 0);
   if (!enabled || !A.xcache || A.nnz < (1 << 16) || !A.a.p) return;
-  const size_t sample = (size_t)std::min<int64_t>(A.nnz, 1 << 16);  // enough to see > 256 distinct values at once
+  // a strided sample over the whole array (the leading rows alone are not representative: the C rows of a
+  // zero-guess sub-operator hold nothing but their diagonal); enough to see > 256 distinct values at once
+  const size_t sample = (size_t)std::min<int64_t>(A.nnz, 1 << 16);
+  const size_t stride = (size_t)A.nnz / sample;
   std::vector<double> hs(sample);
-  MI_HIP(hipMemcpyAsync(hs.data(), A.a.p, sample * sizeof(double), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipMemcpy2DAsync(hs.data(), sizeof(double), A.a.p, stride * sizeof(double), sizeof(double), sample,
+                          hipMemcpyDeviceToHost, s));
   MI_HIP(hipStreamSynchronize(s));
   std::vector<long long> bits(sample);
   std::memcpy(bits.data(), hs.data(), sample * sizeof(double));
