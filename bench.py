@@ -456,6 +456,10 @@ def main():
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": traffic,
                     "traffic_source": traffic_source, "launches": spmv_n, "avg_ms": spmv_ms / spmv_n, "min_ms": spmv_min,
                     "algorithmic_bytes_per_launch": spmv_bytes}
+            if traffic is not None and traffic < spmv_bytes:
+                roof["note"] = ("recorded traffic below the algorithmic byte count: the level-0 operator of this stencil has "
+                                "<= 256 distinct values and streams one-byte dictionary indices (DESIGN.md section 5), while "
+                                "12 nnz + 20 N prices 8-byte values; MI_HYPRE_VALUE_DICT=0 gives the plain stream")
         roof_relax = None
         if rel_n and world == 1:  # N > 1 cuts a pass into up to three launches (halo overlap): no per-launch figure
             a = relax_bytes / (rel_ms / rel_n * 1e-3) / 1e9
