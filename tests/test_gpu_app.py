@@ -399,3 +399,56 @@ solver_settings:
     assert "allClose=1" in out
     got = np.loadtxt(tmp_path / "IJV0.sln.00000", skiprows=1)
     assert np.allclose(got[:, 1], x, rtol=1e-6, atol=1e-8)
+
+
+def test_dumps_write_outputs_and_amg_levels(tmp_path):
+    """`write_outputs` (IJM.mat, IJV0.rhs, IJV0.sln: /root/reference/src/HypreSystem.cpp:739-769) and
+    `write_amg_matrices` (<matrix>_level_<l>.IJ for every level: :701-714) in the HYPRE IJ text dialect
+    (`ilower iupper jlower jupper` / `ilower iupper` header, then `row col value` / `row value` lines)."""
+    A, b, x = _system(24, 3)
+    n = A.shape[0]
+    _write_mm_matrix(tmp_path / "mat.mm", A)
+    _write_mm_vector(tmp_path / "rhs.mm", b)
+    out = _run(tmp_path, """
+linear_system:
+  type: matrix_market
+  matrix_file: mat.mm
+  rhs_file: rhs.mm
+  write_outputs: true
+  write_amg_matrices: true
+
+solver_settings:
+  method: gmres
+  preconditioner: boomeramg
+  tolerance: 1.0e-12
+  max_iterations: 100
+  kspace: 30
+  print_level: 0
+""" + DEFAULT_AMG)
+    m = re.search(r"mi_hypre BoomerAMG setup: (\d+) levels", out)
+    assert m, out[-2000:]
+    nlev = int(m.group(1))
+
+    def read_ij_matrix(path):
+        with open(path) as f:
+            ilo, ihi, jlo, jhi = (int(v) for v in f.readline().split())
+            t = np.loadtxt(f, ndmin=2)
+        M = sp.csr_matrix((t[:, 2], (t[:, 0].astype(int) - ilo, t[:, 1].astype(int) - jlo)), shape=(ihi - ilo + 1, jhi - jlo + 1))
+        return M
+
+    M = read_ij_matrix(tmp_path / "IJM.mat.00000")
+    assert M.shape == A.shape and abs(M - A).max() == 0.0
+    rhs = np.loadtxt(tmp_path / "IJV0.rhs.00000", skiprows=1)
+    sln = np.loadtxt(tmp_path / "IJV0.sln.00000", skiprows=1)
+    assert np.array_equal(rhs[:, 0], np.arange(n)) and np.allclose(rhs[:, 1], b, rtol=1e-14, atol=0.0)
+    assert np.allclose(sln[:, 1], x, rtol=1e-8, atol=1e-10)
+    sizes = []
+    for l in range(nlev):
+        Ml = read_ij_matrix(tmp_path / f"mat_level_{l}.IJ.00000")
+        assert Ml.shape[0] == Ml.shape[1]
+        sizes.append(Ml.shape[0])
+        if l == 0:  # the level-0 operator is the caller's matrix in the hierarchy's own (C-first) ordering
+            assert Ml.nnz == A.nnz and np.allclose(np.sort(Ml.data), np.sort(A.data))
+            assert np.allclose(np.sort(Ml.diagonal()), np.sort(A.diagonal()))
+    assert sizes[0] == n and all(a > b_ for a, b_ in zip(sizes, sizes[1:]))
+    assert not (tmp_path / f"mat_level_{nlev}.IJ.00000").exists()
