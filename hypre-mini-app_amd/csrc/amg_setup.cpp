@@ -2051,7 +2051,29 @@ void BoomerAMG::setup_device() {
     if (Lv.Pm) Lv.Pm->d_diag.row_cap = spmv_cap;
     if (Lv.Rm) Lv.Rm->d_diag.row_cap = spmv_cap;
     if (Lv.Pm) place(*Lv.Pm, Lv.oP);
-    if (Lv.Rm) place(*Lv.Rm, Lv.oR);
+    // Restriction: the coarse vectors live in the coarse level's C-first order, in which neighbouring rows of R are
+    // NOT neighbouring coarse points of the fine level (first the coarse level's C points, then its F points): a
+    // tile of R then gathers a thinned-out stretch of the fine vector, and every line of it is fetched by several
+    // tiles (4x the vector's bytes at 512^3).  R is therefore stored with its rows in the order the coarse points
+    // have on the FINE level (= the coarse level's ordering before its own C-first step) and writes through a row map.
+    static const bool natural_r = !(getenv("MI_HYPRE_NATURAL_R") && atoi(getenv("MI_HYPRE_NATURAL_R")) == 0);
+    if (Lv.Rm && natural_r && li + 1 < L.size() && Lv.oR.nrows == Lv.Rm->nrows && Lv.Rm->host_diag_stale &&
+        L[li + 1].perm.size() == (size_t)Lv.Rm->nrows && Lv.Rm->nrows > 0) {
+      const std::vector<int> &cperm = L[li + 1].perm;  // stored position -> position before the C-first step
+      std::vector<int> cpos(cperm.size());
+      for (size_t q = 0; q < cperm.size(); q++) cpos[(size_t)cperm[q]] = (int)q;
+      DVec<int> dpos;
+      dpos.upload(cpos);
+      sk::DCsr nat;
+      sk::permute(Lv.oR, dpos.p, nullptr, nat, s);
+      Lv.oR.release();
+      sk::to_solve_format(nat, Lv.Rm->d_diag, s);
+      Lv.Rm->d_diag.rowmap = std::move(dpos);
+      Lv.Rm->to_device_halo();
+    } else if (Lv.Rm) {
+      Lv.Rm->d_diag.rowmap.release();
+      place(*Lv.Rm, Lv.oR);
+    }
     // the down leg starts every level from u = 0: its sweep runs on the entries that can see non-zeros
     Lv.has_Az = false;
     Lv.Az = DevCSR();

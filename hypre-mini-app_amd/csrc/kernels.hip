@@ -60,6 +60,7 @@ struct EpiArgs {
   const double *d;         // EPI 1
   const signed char *cf;   // EPI 1 (nullable)
   int points;              // EPI 1
+  const int *rowmap;       // EPI 0 (nullable): stored row r is row rowmap[r] of y and b (DevCSR::rowmap)
 };
 
 template <int EPI>
@@ -67,7 +68,8 @@ __device__ __forceinline__ void epilogue(int r, double s, const double *__restri
                                          const EpiArgs &e) {
   if (EPI == 0) {
     // y is written once and next read by another kernel: keep it out of L2's way
-    __builtin_nontemporal_store((e.beta == 0.0) ? e.alpha * s : e.alpha * s + e.beta * e.b[r], y + r);
+    const int ro = e.rowmap ? e.rowmap[r] : r;
+    __builtin_nontemporal_store((e.beta == 0.0) ? e.alpha * s : e.alpha * s + e.beta * e.b[ro], y + ro);
   } else {
     const double xi = x[r];
     double out = xi;
@@ -215,10 +217,12 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream_xc(int nb, int xchunk,
   const int rr = tid / G;
   int s0 = 0, s1 = 0;
   double bpre = 0.0;  // EPI 0 with beta != 0: the b entry of this thread's row, requested with the other loads
+  int ro = r0 + rr;   // EPI 0: where this thread's row lands in y (operators stored in another row order)
   if (rr < nr) {
     s0 = ia[r0 + rr] - base_al;
     s1 = ia[r0 + rr + 1] - base_al;
-    if (EPI == 0 && e.beta != 0.0 && lane == 0) bpre = e.b[r0 + rr];
+    if (EPI == 0 && e.rowmap && lane == 0) ro = e.rowmap[r0 + rr];
+    if (EPI == 0 && e.beta != 0.0 && lane == 0) bpre = e.b[ro];
   }
 #pragma unroll
   for (int q = 0; q < NU; q++) {
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream_xc(int nb, int xchunk,
     for (int off = G >> 1; off > 0; off >>= 1) s += __shfl_down(s, off, G);
     if (lane == 0) {
       if (EPI == 0)
-        __builtin_nontemporal_store((e.beta == 0.0) ? e.alpha * s : e.alpha * s + e.beta * bpre, y + r0 + rr);
+        __builtin_nontemporal_store((e.beta == 0.0) ? e.alpha * s : e.alpha * s + e.beta * bpre, y + ro);
       else
         epilogue<EPI>(r0 + rr, s, x, y, e);
     }
@@ -1321,6 +1325,7 @@ void spmv(const DevCSR &A, const double *x, double alpha, double beta, const dou
   e.alpha = alpha;
   e.beta = beta;
   e.b = b;
+  e.rowmap = A.rowmap.p;
   prof_begin(prof, s);
   launch_stream(0, A, x, y, e, s, prof == PROF_SPMV_L0);
   prof_end(prof, s);

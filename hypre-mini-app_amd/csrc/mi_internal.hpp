@@ -124,6 +124,11 @@ struct DevCSR {
   DVec<unsigned char> vidx;
   DVec<double> vlut;  // 256 entries (unused ones zero)
   bool val8 = false;
+  // Rows stored in another order than the vectors they produce (SpMV only): stored row r is entry rowmap[r] of y
+  // (and of b).  The restriction operators use it: their rows are kept in the order of the FINE level's C points --
+  // consecutive rows then gather neighbouring fine entries -- while the coarse level's vectors are in its own
+  // C-first order (amg_setup.cpp: setup_device).  Empty = identity.
+  DVec<int> rowmap;
   DVec<int> tdesc;  // 8 ints per tile: r0, r1, ia[r0], ia[r1], uptr[b], #unique columns, 0, 0 (k::build_tile_desc)
   bool empty() const { return nrows == 0 || nnz == 0; }
   void upload(const HostCSR &h);

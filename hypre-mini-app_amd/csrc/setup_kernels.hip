@@ -1428,6 +1428,24 @@ void solve_format_to_host(const DevCSR &src, HostCSR &h, hipStream_t s) {
     }
     MI_HIP(hipStreamSynchronize(s));
   }
+  if (src.rowmap.p && n) {  // stored row r is row rowmap[r] of the operator: hand the rows back in operator order
+    std::vector<int> map((size_t)n);
+    MI_HIP(hipMemcpy(map.data(), src.rowmap.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    HostCSR o;
+    o.nrows = n;
+    o.ncols = h.ncols;
+    o.ia.assign((size_t)n + 1, 0);
+    for (int r = 0; r < n; r++) o.ia[(size_t)map[(size_t)r] + 1] = h.ia[(size_t)r + 1] - h.ia[(size_t)r];
+    for (int r = 0; r < n; r++) o.ia[(size_t)r + 1] += o.ia[(size_t)r];
+    o.ja.resize(h.ja.size());
+    o.a.resize(h.a.size());
+    for (int r = 0; r < n; r++) {
+      const int64_t len = h.ia[(size_t)r + 1] - h.ia[(size_t)r], from = h.ia[(size_t)r], to = o.ia[(size_t)map[(size_t)r]];
+      std::copy(h.ja.begin() + from, h.ja.begin() + from + len, o.ja.begin() + to);
+      std::copy(h.a.begin() + from, h.a.begin() + from + len, o.a.begin() + to);
+    }
+    h = std::move(o);
+  }
 }
 
 void level_norms(const DCsr &A, const int *cf, int chunk, double *diag, double *l1gs, double *l1jac, hipStream_t s) {
