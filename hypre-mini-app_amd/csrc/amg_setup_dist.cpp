@@ -25,8 +25,12 @@
 // the small remaining hierarchy for itself, as before.  Ruge-Stueben coarsening and aggressive coarsening are
 // sequential / two-generation algorithms on the global graph: on N > 1 they keep the replicated path.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
 
 #include "amg.hpp"
 #include "amg_setup_internal.hpp"
@@ -234,6 +238,21 @@ void sort_unique(std::vector<gidx> &v) {
   v.erase(std::unique(v.begin(), v.end()), v.end());
 }
 
+// the ids of v outside [lo, hi), appended to out (any order, duplicates kept): almost every id of a block-row
+// partition is inside, so the column sets below are "the whole own range + these few"
+void append_outside(const std::vector<gidx> &v, gidx lo, gidx hi, std::vector<gidx> &out) {
+  std::mutex mu;
+  parallel_for((int64_t)v.size(), [&](int64_t b, int64_t en, int) {
+    std::vector<gidx> mine;
+    for (int64_t k = b; k < en; k++)
+      if (v[(size_t)k] < lo || v[(size_t)k] >= hi) mine.push_back(v[(size_t)k]);
+    if (!mine.empty()) {
+      std::lock_guard<std::mutex> g(mu);
+      out.insert(out.end(), mine.begin(), mine.end());
+    }
+  });
+}
+
 // rows in `order` (local row ids; empty = natural), columns translated through `newcol` (one new GLOBAL id per
 // entry of M) and sorted, split at this rank's column range into the diag / halo blocks of a ParCSR
 std::unique_ptr<ParCSR> assemble_rows(const GlobCSR &M, const std::vector<int> &order, const std::vector<gidx> &newcol,
@@ -251,12 +270,18 @@ std::unique_ptr<ParCSR> assemble_rows(const GlobCSR &M, const std::vector<int> &
   D.ncols = (int)(c1 - c0);
   D.ia.assign((size_t)n + 1, 0);
   O.ia.assign((size_t)n + 1, 0);
+  parallel_for(n, [&](int64_t b, int64_t e, int) {
+    for (int64_t q = b; q < e; q++) {
+      const int i = order.empty() ? (int)q : order[(size_t)q];
+      int nd = 0;
+      for (int64_t k = M.ia[(size_t)i]; k < M.ia[(size_t)i + 1]; k++) nd += (newcol[(size_t)k] >= c0 && newcol[(size_t)k] < c1);
+      D.ia[(size_t)q + 1] = nd;
+      O.ia[(size_t)q + 1] = M.ia[(size_t)i + 1] - M.ia[(size_t)i] - nd;
+    }
+  });
   for (int q = 0; q < n; q++) {
-    const int i = order.empty() ? q : order[(size_t)q];
-    int nd = 0;
-    for (int64_t k = M.ia[(size_t)i]; k < M.ia[(size_t)i + 1]; k++) nd += (newcol[(size_t)k] >= c0 && newcol[(size_t)k] < c1);
-    D.ia[(size_t)q + 1] = D.ia[(size_t)q] + nd;
-    O.ia[(size_t)q + 1] = O.ia[(size_t)q] + (M.ia[(size_t)i + 1] - M.ia[(size_t)i] - nd);
+    D.ia[(size_t)q + 1] += D.ia[(size_t)q];
+    O.ia[(size_t)q + 1] += O.ia[(size_t)q];
   }
   D.ja.resize((size_t)D.nnz());
   D.a.resize((size_t)D.nnz());
@@ -402,6 +427,15 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
   bool has_tail = false;
   int l = 0;
   double tp0;
+  const bool sub_timing = getenv("MI_HYPRE_SETUP_TIMING") != nullptr && rank == 0;
+  std::map<std::string, double> sub_times;
+  double tsub = 0.0;
+  auto lap = [&](const char *what) {
+    if (!sub_timing) return;
+    const double now = wall_time();
+    sub_times[what] += now - tsub;
+    tsub = now;
+  };
   while (l < p.max_levels - 1 && D[(size_t)l].starts.back() > p.max_coarse_size) {
     if (red_rows > 0 && l >= 1 && D[(size_t)l].starts.back() <= red_rows) {
       has_tail = true;
@@ -447,8 +481,7 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
     // halo of A
     {
       std::vector<gidx> need;
-      for (int64_t k = 0; k < A.nnz(); k++)
-        if (A.gj[(size_t)k] < s || A.gj[(size_t)k] >= e) need.push_back(A.gj[(size_t)k]);
+      append_outside(A.gj, s, e, need);
       sort_unique(need);
       Lv.ring.build(comm, Lv.starts, std::move(need));
     }
@@ -465,23 +498,27 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
 
     // ---- PMIS on the global graph (par_coarsen.c), one global random stream
     tp0 = wall_time();
+    tsub = tp0;
     std::vector<int> cf((size_t)n, 0), cf_h;
     {
+      // (integer counts and flags below are updated from several host threads with relaxed atomics: sums and
+      // "set to 0" stores commute, so the outcome does not depend on the schedule)
       std::vector<int> cnt((size_t)n, 0), cnt_h((size_t)nh, 0);
-      for (int i = 0; i < n; i++)
-        for (int64_t k = A.ia[(size_t)i]; k < A.ia[(size_t)i + 1]; k++) {
-          if (!Lv.strong[(size_t)k]) continue;
-          if (hslot[(size_t)k] < 0)
-            cnt[(size_t)(A.gj[(size_t)k] - s)]++;
-          else
-            cnt_h[(size_t)hslot[(size_t)k]]++;
-        }
+      parallel_for(n, [&](int64_t b, int64_t en, int) {
+        for (int64_t i = b; i < en; i++)
+          for (int64_t k = A.ia[(size_t)i]; k < A.ia[(size_t)i + 1]; k++) {
+            if (!Lv.strong[(size_t)k]) continue;
+            int *slot = hslot[(size_t)k] < 0 ? &cnt[(size_t)(A.gj[(size_t)k] - s)] : &cnt_h[(size_t)hslot[(size_t)k]];
+            __atomic_fetch_add(slot, 1, __ATOMIC_RELAXED);
+          }
+      });
       ring.reverse(comm, cnt_h, cnt, [](int &mine, int v) { mine += v; });
       std::vector<double> measure((size_t)n, 0.0);
-      if (n) {
-        int seed = park_miller_at(2747, s);  // element s of the stream; the following ones by the recurrence
-        for (int i = 0; i < n; i++) {
-          if (i) {
+      parallel_for(n, [&](int64_t b, int64_t en, int) {
+        if (b >= en) return;
+        int seed = park_miller_at(2747, s + b);  // element s + b of the stream; the following ones by the recurrence
+        for (int64_t i = b; i < en; i++) {
+          if (i > b) {
             const int a = 16807, m = 2147483647, q = 127773, r = 2836;
             const int lo = seed % q, hi = seed / q;
             const int t = a * lo - r * hi;
@@ -489,79 +526,101 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
           }
           measure[(size_t)i] = (double)cnt[(size_t)i] + (double)seed / 2147483647;
         }
-      }
+      });
+      lap("pmis: measures");
       std::vector<int> graph;
-      for (int i = 0; i < n; i++) {
-        bool any = false;
-        for (int64_t k = A.ia[(size_t)i]; k < A.ia[(size_t)i + 1] && !any; k++) any = Lv.strong[(size_t)k] != 0;
-        if (!any) {
-          cf[(size_t)i] = SF_PT;
-          measure[(size_t)i] = 0.0;
-        } else if (measure[(size_t)i] < 1.0) {
-          cf[(size_t)i] = F_PT;
-          measure[(size_t)i] = 0.0;
-        } else
-          graph.push_back(i);
-      }
+      parallel_for(n, [&](int64_t b, int64_t en, int) {
+        for (int64_t i = b; i < en; i++) {
+          bool any = false;
+          for (int64_t k = A.ia[(size_t)i]; k < A.ia[(size_t)i + 1] && !any; k++) any = Lv.strong[(size_t)k] != 0;
+          if (!any) {
+            cf[(size_t)i] = SF_PT;
+            measure[(size_t)i] = 0.0;
+          } else if (measure[(size_t)i] < 1.0) {
+            cf[(size_t)i] = F_PT;
+            measure[(size_t)i] = 0.0;
+          }
+        }
+      });
+      for (int i = 0; i < n; i++)
+        if (cf[(size_t)i] == 0) graph.push_back(i);
       const std::vector<double> m_h = ring.forward(comm, measure);
       cf_h = ring.forward(comm, cf);
       std::vector<signed char> tmp((size_t)n, 0);
+      lap("pmis: initial graph");
       for (;;) {
         long long left = (long long)graph.size();
         comm.allreduce_host(&left, 1, CommDType::I64, CommOp::SUM);
         if (left == 0) break;
         std::vector<int> lose_h((size_t)nh, 1);  // 0: the halo point lost a comparison against one of my rows
-        for (int g : graph) tmp[(size_t)g] = 1;
-        for (int g : graph) {
-          const double mi_ = measure[(size_t)g];
-          for (int64_t k = A.ia[(size_t)g]; k < A.ia[(size_t)g + 1]; k++) {
-            if (!Lv.strong[(size_t)k]) continue;
-            const int h = hslot[(size_t)k];
-            if (h < 0) {
-              const int j = (int)(A.gj[(size_t)k] - s);
-              if (cf[(size_t)j] != 0) continue;
-              if (mi_ > measure[(size_t)j])
-                tmp[(size_t)j] = 0;
-              else if (measure[(size_t)j] > mi_)
-                tmp[(size_t)g] = 0;
-            } else {
-              if (cf_h[(size_t)h] != 0) continue;
-              if (mi_ > m_h[(size_t)h])
-                lose_h[(size_t)h] = 0;
-              else if (m_h[(size_t)h] > mi_)
-                tmp[(size_t)g] = 0;
+        const int64_t ng = (int64_t)graph.size();
+        parallel_for(ng, [&](int64_t b, int64_t en, int) {
+          for (int64_t q = b; q < en; q++) tmp[(size_t)graph[(size_t)q]] = 1;
+        });
+        parallel_for(ng, [&](int64_t b, int64_t en, int) {
+          for (int64_t q = b; q < en; q++) {
+            const int g = graph[(size_t)q];
+            const double mi_ = measure[(size_t)g];
+            bool lost = false;
+            for (int64_t k = A.ia[(size_t)g]; k < A.ia[(size_t)g + 1]; k++) {
+              if (!Lv.strong[(size_t)k]) continue;
+              const int h = hslot[(size_t)k];
+              if (h < 0) {
+                const int j = (int)(A.gj[(size_t)k] - s);
+                if (cf[(size_t)j] != 0) continue;
+                if (mi_ > measure[(size_t)j])
+                  __atomic_store_n(&tmp[(size_t)j], (signed char)0, __ATOMIC_RELAXED);
+                else if (measure[(size_t)j] > mi_)
+                  lost = true;
+              } else {
+                if (cf_h[(size_t)h] != 0) continue;
+                if (mi_ > m_h[(size_t)h])
+                  __atomic_store_n(&lose_h[(size_t)h], 0, __ATOMIC_RELAXED);
+                else if (m_h[(size_t)h] > mi_)
+                  lost = true;
+              }
             }
+            if (lost) __atomic_store_n(&tmp[(size_t)g], (signed char)0, __ATOMIC_RELAXED);
           }
-        }
+        });
         {
           std::vector<int> keep((size_t)n, 1);
           ring.reverse(comm, lose_h, keep, [](int &mine, int v) { mine = std::min(mine, v); });
-          for (int g : graph)
-            if (!keep[(size_t)g]) tmp[(size_t)g] = 0;
+          parallel_for(ng, [&](int64_t b, int64_t en, int) {
+            for (int64_t q = b; q < en; q++) {
+              const int g = graph[(size_t)q];
+              if (!keep[(size_t)g]) tmp[(size_t)g] = 0;
+              if (tmp[(size_t)g] == 1) cf[(size_t)g] = C_PT;
+            }
+          });
         }
-        for (int g : graph)
-          if (tmp[(size_t)g] == 1) cf[(size_t)g] = C_PT;
         cf_h = ring.forward(comm, cf);
+        parallel_for(ng, [&](int64_t b, int64_t en, int) {
+          for (int64_t q = b; q < en; q++) {
+            const int g = graph[(size_t)q];
+            if (cf[(size_t)g] != 0) continue;
+            bool dep_c = false;
+            for (int64_t k = A.ia[(size_t)g]; k < A.ia[(size_t)g + 1] && !dep_c; k++) {
+              if (!Lv.strong[(size_t)k]) continue;
+              const int h = hslot[(size_t)k];
+              dep_c = h < 0 ? cf[(size_t)(A.gj[(size_t)k] - s)] == C_PT : cf_h[(size_t)h] == C_PT;
+            }
+            tmp[(size_t)g] = dep_c ? 2 : 3;  // 2: becomes F once the scan is over (the scan sees this round's C points only)
+          }
+        });
         std::vector<int> next;
         for (int g : graph) {
           if (cf[(size_t)g] != 0) continue;
-          bool dep_c = false;
-          for (int64_t k = A.ia[(size_t)g]; k < A.ia[(size_t)g + 1] && !dep_c; k++) {
-            if (!Lv.strong[(size_t)k]) continue;
-            const int h = hslot[(size_t)k];
-            dep_c = h < 0 ? cf[(size_t)(A.gj[(size_t)k] - s)] == C_PT : cf_h[(size_t)h] == C_PT;
-          }
-          if (dep_c)
-            tmp[(size_t)g] = 2;  // becomes F once the scan is over (the scan sees this round's C points only)
+          if (tmp[(size_t)g] == 2)
+            cf[(size_t)g] = F_PT;
           else
             next.push_back(g);
         }
-        for (int g : graph)
-          if (tmp[(size_t)g] == 2) cf[(size_t)g] = F_PT;
         graph.swap(next);
         cf_h = ring.forward(comm, cf);
       }
     }
+    lap("pmis: rounds");
     long long nc_loc = 0;
     for (int i = 0; i < n; i++) nc_loc += (cf[(size_t)i] == C_PT);
     long long nc_glob = nc_loc;
@@ -588,6 +647,7 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
     }
     const std::vector<gidx> cgid_h = ring.forward(comm, Lv.cgid);
 
+    tsub = wall_time();
     // ---- interpolation on the extended sub-problem
     // rows of the halo points with, per entry, strength flag, C/F state and coarse id of the column
     std::vector<std::vector<char>> hrows = ring.forward_records(comm, [&](int row, std::vector<char> &buf) {
@@ -602,6 +662,7 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
         put1<gidx>(buf, h < 0 ? Lv.cgid[(size_t)(A.gj[(size_t)k] - s)] : cgid_h[(size_t)h]);
       }
     });
+    lap("interp: fetch halo rows");
     struct HRow {
       std::vector<gidx> col, cg;
       std::vector<double> val;
@@ -631,6 +692,7 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
         }
       }
       std::vector<std::vector<char>>().swap(hrows);
+      lap("interp: unpack halo rows");
       sort_unique(X.remote);
       X.finish();
       const int ne = X.size();
@@ -646,16 +708,18 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
       std::vector<char> want((size_t)ne, 0);
       std::vector<int> hext((size_t)nh);
       for (int q = 0; q < nh; q++) hext[(size_t)q] = X.of(ring.ids[(size_t)q]);
-      for (int i = 0; i < n; i++) {
-        const int x = X.nbelow + i;
-        Ae.ia[(size_t)x + 1] = A.ia[(size_t)i + 1] - A.ia[(size_t)i];
-        int ns = 0;
-        for (int64_t k = A.ia[(size_t)i]; k < A.ia[(size_t)i + 1]; k++) ns += Lv.strong[(size_t)k];
-        Se.ia[(size_t)x + 1] = ns;
-        cfe[(size_t)x] = cf[(size_t)i];
-        cge[(size_t)x] = Lv.cgid[(size_t)i];
-        want[(size_t)x] = 1;
-      }
+      parallel_for(n, [&](int64_t b, int64_t en, int) {
+        for (int64_t i = b; i < en; i++) {
+          const int x = X.nbelow + (int)i;
+          Ae.ia[(size_t)x + 1] = A.ia[(size_t)i + 1] - A.ia[(size_t)i];
+          int ns = 0;
+          for (int64_t k = A.ia[(size_t)i]; k < A.ia[(size_t)i + 1]; k++) ns += Lv.strong[(size_t)k];
+          Se.ia[(size_t)x + 1] = ns;
+          cfe[(size_t)x] = cf[(size_t)i];
+          cge[(size_t)x] = Lv.cgid[(size_t)i];
+          want[(size_t)x] = 1;
+        }
+      });
       std::vector<char> known(want);  // own rows and first-ring halo points: state known from the exchanges above
       for (int q = 0; q < nh; q++) {
         const int x = hext[(size_t)q];
@@ -703,11 +767,13 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
         }
       }
       std::vector<HRow>().swap(H);
+      lap("interp: extended sub-problem");
       ParCSR Aw;
       as_single_rank(std::move(Ae), Aw);
       HostCSR Pe;
       int nce = 0;
       build_interp(Aw, Se, cfe, p.interp_type, p.trunc_factor, p.pmax_elmts, Pe, nce, &want);
+      lap("interp: build_interp");
       // extended coarse index -> global coarse id (both ascend with the fine id)
       std::vector<gidx> cmap((size_t)nce);
       {
@@ -723,23 +789,29 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
         P.ia[(size_t)i + 1] = P.ia[(size_t)i] + (Pe.ia[(size_t)(X.nbelow + i) + 1] - Pe.ia[(size_t)(X.nbelow + i)]);
       P.gj.resize((size_t)P.nnz());
       P.a.resize((size_t)P.nnz());
-      for (int i = 0; i < n; i++) {
-        int64_t w = P.ia[(size_t)i];
-        for (int64_t k = Pe.ia[(size_t)(X.nbelow + i)]; k < Pe.ia[(size_t)(X.nbelow + i) + 1]; k++, w++) {
-          P.gj[(size_t)w] = cmap[(size_t)Pe.ja[(size_t)k]];
-          MI_REQUIRE(P.gj[(size_t)w] >= 0, "distributed setup: interpolation from a point without a coarse id");
-          P.a[(size_t)w] = Pe.a[(size_t)k];
+      std::atomic<int> bad{0};
+      parallel_for(n, [&](int64_t b, int64_t en, int) {
+        for (int64_t i = b; i < en; i++) {
+          int64_t w = P.ia[(size_t)i];
+          for (int64_t k = Pe.ia[(size_t)(X.nbelow + i)]; k < Pe.ia[(size_t)(X.nbelow + i) + 1]; k++, w++) {
+            P.gj[(size_t)w] = cmap[(size_t)Pe.ja[(size_t)k]];
+            if (P.gj[(size_t)w] < 0) bad = 1;
+            P.a[(size_t)w] = Pe.a[(size_t)k];
+          }
         }
-      }
+      });
+      MI_REQUIRE(bad == 0, "distributed setup: interpolation from a point without a coarse id");
     }
     for (int i = 0; i < n; i++)
       if (cf[(size_t)i] == SF_PT) cf[(size_t)i] = F_PT;
     Lv.cf = cf;
     Lv.has_cf = true;
+    lap("interp: P to global ids");
     t_phase[2] += wall_time() - tp0;
 
     // ---- Galerkin product A_c = R (A P), every row in the single-rank order
     tp0 = wall_time();
+    tsub = tp0;
     const GlobCSR &P = Lv.P;
     GlobCSR AP;  // my fine rows x global coarse ids
     {
@@ -749,6 +821,7 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
         put(buf, P.gj.data() + b, (size_t)len);
         put(buf, P.a.data() + b, (size_t)len);
       });
+      lap("galerkin: fetch P rows");
       // P restricted to rows {own} u {halo of A}, in ascending global row order
       ExtIndex E1;
       E1.s = s, E1.e = e, E1.remote = ring.ids;
@@ -768,17 +841,24 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
           rd.get(hv[(size_t)q].data(), (size_t)len);
         }
       }
-      std::vector<gidx> CE(P.gj);
-      for (auto &v : hc) CE.insert(CE.end(), v.begin(), v.end());
-      sort_unique(CE);
-      auto cidx = [&](gidx g) { return (int)(std::lower_bound(CE.begin(), CE.end(), g) - CE.begin()); };
+      lap("galerkin: unpack P rows");
+      // coarse columns of the extended P: my whole coarse range plus the remote ids that occur (ascending global
+      // order, as in the single-rank product)
+      ExtIndex CE;
+      CE.s = cs, CE.e = cs + nc_loc;
+      append_outside(P.gj, CE.s, CE.e, CE.remote);
+      for (auto &v : hc) append_outside(v, CE.s, CE.e, CE.remote);
+      sort_unique(CE.remote);
+      CE.finish();
+      auto cidx = [&](gidx g) { return CE.of(g); };
+      lap("galerkin: coarse column set of P");
       for (int x = 0; x < n1; x++) {
         const gidx g = E1.global(x);
         const int64_t len = (g >= s && g < e) ? P.ia[(size_t)(g - s) + 1] - P.ia[(size_t)(g - s)]
                                                : (int64_t)hc[(size_t)ring.slot_of(g)].size();
         Pe.ia[(size_t)x + 1] = Pe.ia[(size_t)x] + len;
       }
-      Pe.ncols = (int)CE.size();
+      Pe.ncols = CE.size();
       Pe.ja.resize((size_t)Pe.nnz());
       Pe.a.resize((size_t)Pe.nnz());
       parallel_for(n1, [&](int64_t b, int64_t en, int) {
@@ -799,6 +879,7 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
           }
         }
       });
+      lap("galerkin: extended P");
       HostCSR Ae;
       Ae.nrows = n;
       Ae.ncols = n1;
@@ -812,14 +893,19 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
           for (int64_t k = A.ia[(size_t)i]; k < A.ia[(size_t)i + 1]; k++)
             Ae.ja[(size_t)k] = hslot[(size_t)k] < 0 ? E1.nbelow + (int)(A.gj[(size_t)k] - s) : hext[(size_t)hslot[(size_t)k]];
       });
+      lap("galerkin: A on extended columns");
       HostCSR APe;
       spgemm_auto(Ae, Pe, APe, device_min_rows);
+      lap("galerkin: A*P");
       AP.nrows = n;
       AP.ia = APe.ia;
       AP.a.swap(APe.a);
       AP.gj.resize(APe.ja.size());
-      for (size_t k = 0; k < APe.ja.size(); k++) AP.gj[k] = CE[(size_t)APe.ja[k]];
+      parallel_for((int64_t)APe.ja.size(), [&](int64_t b, int64_t en, int) {
+        for (int64_t k = b; k < en; k++) AP.gj[(size_t)k] = CE.global(APe.ja[(size_t)k]);
+      });
     }
+    lap("galerkin: A*P to global ids");
     // transpose exchange: P entries whose coarse column lives elsewhere travel to its owner together with the
     // (A P) row of their fine row
     struct Incoming {
@@ -885,6 +971,7 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
       }
       std::sort(inc.begin(), inc.end(), [](const Incoming &x, const Incoming &y) { return x.fine < y.fine; });
     }
+    lap("galerkin: transpose exchange");
     {
       const int ncl = (int)nc_loc;
       ExtIndex E2;  // fine rows that reach my coarse rows: own rows + the senders' rows
@@ -893,14 +980,18 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
       E2.finish();
       const int n2 = E2.size();
       g_ext_rows_max = std::max<long long>(g_ext_rows_max, n2);
-      std::vector<gidx> CE2(AP.gj);
-      for (auto &in : inc) CE2.insert(CE2.end(), in.ac.begin(), in.ac.end());
-      sort_unique(CE2);
-      auto cidx = [&](gidx g) { return (int)(std::lower_bound(CE2.begin(), CE2.end(), g) - CE2.begin()); };
+      ExtIndex CE2;  // coarse columns of the extended A*P: my coarse range plus the remote ids that occur
+      CE2.s = cs, CE2.e = cs + nc_loc;
+      append_outside(AP.gj, CE2.s, CE2.e, CE2.remote);
+      for (auto &in : inc) append_outside(in.ac, CE2.s, CE2.e, CE2.remote);
+      sort_unique(CE2.remote);
+      CE2.finish();
+      auto cidx = [&](gidx g) { return CE2.of(g); };
+      lap("galerkin: coarse column set of A*P");
       // (A P) on the extended fine rows
       HostCSR APe;
       APe.nrows = n2;
-      APe.ncols = (int)CE2.size();
+      APe.ncols = CE2.size();
       APe.ia.assign((size_t)n2 + 1, 0);
       auto inc_of = [&](int x) -> const Incoming & { return inc[(size_t)(x < E2.nbelow ? x : x - n)]; };
       for (int x = 0; x < n2; x++) {
@@ -928,6 +1019,7 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
           }
         }
       });
+      lap("galerkin: extended A*P");
       // R = P^T restricted to my coarse rows, columns = extended fine rows (ascending)
       HostCSR Re;
       Re.nrows = ncl;
@@ -956,20 +1048,27 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
           Re.a[(size_t)pos[(size_t)r]++] = v;
         });
       }
+      lap("galerkin: R = P^T");
       HostCSR Ace;
       spgemm_auto(Re, APe, Ace, device_min_rows);
+      lap("galerkin: R*(A*P)");
       GlobCSR &Ac = Ln.A;
       Ac.nrows = ncl;
       Ac.ia = Ace.ia;
       Ac.a.swap(Ace.a);
       Ac.gj.resize(Ace.ja.size());
-      for (size_t k = 0; k < Ace.ja.size(); k++) Ac.gj[k] = CE2[(size_t)Ace.ja[k]];
+      parallel_for((int64_t)Ace.ja.size(), [&](int64_t b, int64_t en, int) {
+        for (int64_t k = b; k < en; k++) Ac.gj[(size_t)k] = CE2.global(Ace.ja[(size_t)k]);
+      });
       GlobCSR &R = Lv.R;
       R.nrows = ncl;
       R.ia = Re.ia;
       R.a.swap(Re.a);
       R.gj.resize(Re.ja.size());
-      for (size_t k = 0; k < Re.ja.size(); k++) R.gj[k] = E2.global(Re.ja[k]);
+      parallel_for((int64_t)Re.ja.size(), [&](int64_t b, int64_t en, int) {
+        for (int64_t k = b; k < en; k++) R.gj[(size_t)k] = E2.global(Re.ja[(size_t)k]);
+      });
+      lap("galerkin: results to global ids");
     }
     t_phase[3] += wall_time() - tp0;
     l++;
@@ -978,6 +1077,7 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
 
   // ---- C-first ordering of every level with a splitting, and the final ParCSR blocks
   tp0 = wall_time();
+  tsub = tp0;
   std::vector<std::vector<int>> pos(nlev), perm(nlev);
   for (size_t li = 0; li < nlev; li++) {
     const DLevel &Lv = D[li];
@@ -1028,9 +1128,14 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
     AmgLevel &Out = L[li];
     const int n = Lv.A.nrows;
     const bool ring_ok = Lv.has_cf;  // the halo ring of A was built in the coarsening loop
-    Out.A_own = assemble_rows(Lv.A, perm[li], translate(Lv.A, li, ring_ok ? &Lv.ring : nullptr), Lv.starts, Lv.starts, rank);
+    std::vector<gidx> newcol_a = translate(Lv.A, li, ring_ok ? &Lv.ring : nullptr);
+    lap("ordering: translate A");
+    Out.A_own = assemble_rows(Lv.A, perm[li], newcol_a, Lv.starts, Lv.starts, rank);
+    std::vector<gidx>().swap(newcol_a);
+    lap("ordering: assemble A");
     Out.A = Out.A_own.get();
     Out.A->build_halo_plan(comm);
+    lap("ordering: halo plans");
     Out.has_cf = Lv.has_cf;
     if (Lv.has_cf) {
       Out.perm = perm[li];
@@ -1040,11 +1145,22 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
         Out.cf[(size_t)q] = Lv.cf[(size_t)perm[li][(size_t)q]];
         Out.nc += (Out.cf[(size_t)q] == C_PT);
       }
-      Out.Pm = assemble_rows(Lv.P, perm[li], translate(Lv.P, li + 1, nullptr), Lv.starts, D[li + 1].starts, rank);
+      lap("ordering: cf");
+      std::vector<gidx> newcol_p = translate(Lv.P, li + 1, nullptr);
+      lap("ordering: translate P");
+      Out.Pm = assemble_rows(Lv.P, perm[li], newcol_p, Lv.starts, D[li + 1].starts, rank);
+      std::vector<gidx>().swap(newcol_p);
+      lap("ordering: assemble P");
       // with a redundant tail the coarse correction is whole on every rank: no exchange for the last P
       if (!(has_tail && li + 2 == nlev)) Out.Pm->build_halo_plan(comm);
-      Out.Rm = assemble_rows(Lv.R, perm[li + 1], translate(Lv.R, li, nullptr), D[li + 1].starts, Lv.starts, rank);
+      lap("ordering: halo plans");
+      std::vector<gidx> newcol_r = translate(Lv.R, li, nullptr);
+      lap("ordering: translate R");
+      Out.Rm = assemble_rows(Lv.R, perm[li + 1], newcol_r, D[li + 1].starts, Lv.starts, rank);
+      std::vector<gidx>().swap(newcol_r);
+      lap("ordering: assemble R");
       Out.Rm->build_halo_plan(comm);
+      lap("ordering: halo plans");
     }
   }
   if (!input_order.empty()) {  // level-0 rows -> caller rows
@@ -1054,6 +1170,7 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
     else
       for (int &q : L0.perm) q = input_order[(size_t)q];
   }
+  lap("ordering: rest");
   if (has_tail) {
     // the first redundant level: gathered once, then one single-rank hierarchy per rank (as before)
     const DLevel &Ls = D[nlev - 1];
@@ -1117,6 +1234,8 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
     tail_map_host.swap(map);
   }
   t_phase[4] += wall_time() - tp0;
+  if (sub_timing)
+    for (auto &kv : sub_times) printf("   distributed setup, %-40s %.2f s\n", kv.first.c_str(), kv.second);
   if (p.print_level > 0 && rank == 0)
     printf("mi_hypre BoomerAMG: distributed setup on %d ranks (%zu distributed levels%s; largest per-rank sub-problem %lld "
            "rows of %lld global)\n",
