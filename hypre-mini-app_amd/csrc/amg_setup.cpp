@@ -2057,7 +2057,10 @@ void BoomerAMG::setup_device() {
     // tiles (4x the vector's bytes at 512^3).  R is therefore stored with its rows in the order the coarse points
     // have on the FINE level (= the coarse level's ordering before its own C-first step) and writes through a row map.
     static const bool natural_r = !(getenv("MI_HYPRE_NATURAL_R") && atoi(getenv("MI_HYPRE_NATURAL_R")) == 0);
-    if (Lv.Rm && natural_r && li + 1 < L.size() && Lv.oR.nrows == Lv.Rm->nrows && Lv.Rm->host_diag_stale &&
+    const bool r_on_device = Lv.Rm && Lv.oR.nrows == Lv.Rm->nrows && Lv.Rm->host_diag_stale;  // built there
+    static const long long nat_min = getenv("MI_HYPRE_NATURAL_R_MIN_NNZ") ? atoll(getenv("MI_HYPRE_NATURAL_R_MIN_NNZ")) : 4000000;
+    const bool r_large_host = Lv.Rm && !Lv.Rm->host_diag_stale && Lv.Rm->diag.nnz() >= nat_min;  // e.g. distributed setup
+    if (Lv.Rm && natural_r && li + 1 < L.size() && (r_on_device || r_large_host) &&
         L[li + 1].perm.size() == (size_t)Lv.Rm->nrows && Lv.Rm->nrows > 0) {
       const std::vector<int> &cperm = L[li + 1].perm;  // stored position -> position before the C-first step
       std::vector<int> cpos(cperm.size());
@@ -2065,8 +2068,14 @@ void BoomerAMG::setup_device() {
       DVec<int> dpos;
       dpos.upload(cpos);
       sk::DCsr nat;
-      sk::permute(Lv.oR, dpos.p, nullptr, nat, s);
-      Lv.oR.release();
+      if (r_on_device) {
+        sk::permute(Lv.oR, dpos.p, nullptr, nat, s);
+        Lv.oR.release();
+      } else {
+        sk::DCsr raw;
+        raw.upload(Lv.Rm->diag, s);
+        sk::permute(raw, dpos.p, nullptr, nat, s);
+      }
       sk::to_solve_format(nat, Lv.Rm->d_diag, s);
       Lv.Rm->d_diag.rowmap = std::move(dpos);
       Lv.Rm->to_device_halo();

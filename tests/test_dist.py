@@ -24,6 +24,7 @@ def _run(nproc, mode, n, stencil, port, staging="host", seq=-1, devmin=None, gol
         env["MI_HYPRE_DEVICE_SETUP_MIN_ROWS"] = str(devmin)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["MI_HYPRE_HOST_THREADS"] = "2"
+    env["MI_HYPRE_NATURAL_R_MIN_NNZ"] = "0"  # restriction blocks of these small grids also take the row-map path
     env["OMP_NUM_THREADS"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), WORKER, "--mode", mode, "--grid", str(n),
