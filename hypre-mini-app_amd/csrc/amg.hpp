@@ -29,13 +29,20 @@ struct AmgParams {
   int agg_num_levels = 0, agg_interp_type = 4, agg_pmax_elmts = 0, keep_transpose = 0, rap2 = 0;
   double agg_trunc_factor = 0.0;
   int smooth_num_sweeps = 1;
+  // complex smoother on levels < smooth_num_levels (src/HypreSystem.cpp:235-320): 5 = ILU is implemented (block-Jacobi
+  // ILU(0), the IluSolver behind HYPRE_ILU); library defaults as in HYPRE
+  int smooth_type = 6, smooth_num_levels = 0;
+  int ilu_type = 0, ilu_level = 0, ilu_max_iter = 1, ilu_tri_solve = 1, ilu_lower_it = 5, ilu_upper_it = 5;
   // N > 1 ranks: levels >= 1 with at most this many global rows are kept whole on every rank and cycled
   // redundantly, without halo exchanges (HYPRE_BoomerAMGSetSeqThreshold); -1 = MI_HYPRE_REDUNDANT_ROWS or 200000
   long long redundant_rows = -1;
 };
 
+struct IluSolver;
+
 struct AmgLevel {
   ParCSR *A = nullptr;
+  std::shared_ptr<IluSolver> smoother;  // complex smoother of this level (smooth_type 5 on levels < smooth_num_levels)
   std::unique_ptr<ParCSR> A_own;
   int n = 0;
   HostCSR P, R;  // interpolation / restriction while the hierarchy is being built (moved into Pm / Rm)

@@ -17,6 +17,7 @@
 #include "amg.hpp"
 #include "amg_setup_internal.hpp"
 #include "kernels.hpp"
+#include "solvers.hpp"
 
 namespace mi {
 
@@ -1355,6 +1356,12 @@ void BoomerAMG::setup_host(ParCSR &A0) {
   if (p.agg_num_levels > 0 && p.agg_interp_type != 4)
     fail(4, "BoomerAMGSetup: agg_interp_type " + std::to_string(p.agg_interp_type) +
                 " is not implemented (4 = multipass is); refusing to substitute another one");
+  if (p.smooth_num_levels > 0 && p.smooth_type != 5)
+    fail(4, "BoomerAMGSetup: smooth_type " + std::to_string(p.smooth_type) + " on " + std::to_string(p.smooth_num_levels) +
+                " level(s) is not implemented (5 = ILU is); refusing to smooth with something else");
+  if (p.smooth_num_levels > 0 && (p.ilu_type != 0 || p.ilu_level != 0))
+    fail(4, "BoomerAMGSetup: ILU smoother type " + std::to_string(p.ilu_type) + " / level of fill " +
+                std::to_string(p.ilu_level) + " is not implemented (block-Jacobi ILU(0) = type 0, level 0 is)");
   if (comm.size > 1) input_order.clear();
   if (comm.size > 1 && can_build_distributed()) {
     build_distributed(A0);
@@ -1992,6 +1999,8 @@ void BoomerAMG::build_replicated(ParCSR &A0) {
     tail->p = p;
     tail->p.print_level = 0;
     tail->p.max_levels = std::max(1, p.max_levels - (int)(nlev - 1));
+    tail->p.smooth_num_levels = std::max(0, p.smooth_num_levels - (int)(nlev - 1));
+    tail->p.agg_num_levels = std::max(0, p.agg_num_levels - (int)(nlev - 1));
     tail->device_min_rows = device_min_rows;
     tail->use_private_self_comm();
     tail->setup_host(*tail_A);
@@ -2131,6 +2140,25 @@ void BoomerAMG::setup_device() {
       zero_on_stream(Lv.tmp.p, (size_t)Lv.n * sizeof(double));
       zero_on_stream(Lv.snap.p, (size_t)Lv.n * sizeof(double));
     }
+  }
+  // complex smoother (smooth_type 5 = ILU) on levels < smooth_num_levels, never on the last level (which is the
+  // coarse solve, or the hand-over to the redundant tail): one block-Jacobi ILU(0) of the level's diag block each
+  for (size_t li = 0; li < L.size(); li++) {
+    AmgLevel &Lv = L[li];
+    Lv.smoother.reset();
+    if (p.smooth_type != 5 || (int)li >= p.smooth_num_levels || li + 1 >= L.size()) continue;
+    ensure_host((int)li);
+    auto ilu = std::make_shared<IluSolver>();
+    ilu->ilu_type = p.ilu_type;
+    ilu->level_of_fill = p.ilu_level;
+    ilu->tri_solve = p.ilu_tri_solve;
+    ilu->lower_it = p.ilu_lower_it;
+    ilu->upper_it = p.ilu_upper_it;
+    ilu->max_iter = p.ilu_max_iter;
+    ilu->tol = 0.0;
+    ilu->print_level = (p.print_level > 0 && comm.rank == 0) ? 1 : 0;
+    ilu->setup(*Lv.A);
+    Lv.smoother = std::move(ilu);
   }
   AmgLevel &Lc = L.back();
   if (Lc.dense) {

@@ -1221,6 +1221,8 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
     tail->p = p;
     tail->p.print_level = 0;
     tail->p.max_levels = std::max(1, p.max_levels - (int)(nlev - 1));
+    tail->p.smooth_num_levels = std::max(0, p.smooth_num_levels - (int)(nlev - 1));
+    tail->p.agg_num_levels = std::max(0, p.agg_num_levels - (int)(nlev - 1));
     tail->device_min_rows = device_min_rows;
     tail->use_private_self_comm();
     tail->setup_host(*tail_A);

@@ -15,6 +15,7 @@
 #include "amg.hpp"
 #include "kernels.hpp"
 #include "profile.hpp"
+#include "solvers.hpp"
 
 namespace mi {
 
@@ -261,6 +262,28 @@ void BoomerAMG::relax_pair(int level, int type, int first, const double *f, bool
 void BoomerAMG::relax_sweeps(int level, int which, const double *f, bool u_is_zero) {
   const int type = p.relax_type[which];
   const bool has_cf = L[(size_t)level].has_cf;
+  if (L[(size_t)level].smoother && which != 2) {
+    // complex smoother (par_cycle.c: smooth_num_levels > level, smooth_type 5): per sweep ilu_max_iter times
+    // u += (LU)^-1 (f - A u); on a zero guess the first residual is f itself
+    AmgLevel &Lv = L[(size_t)level];
+    IluSolver &ilu = *Lv.smoother;
+    Comm &comm = my_comm();
+    hipStream_t s = ctx().stream;
+    Lv.t_valid = false;
+    bool zero = u_is_zero;
+    for (int sw = 0; sw < p.num_sweeps[which]; sw++)
+      for (int it = 0; it < ilu.max_iter; it++) {
+        if (zero) {
+          ilu.apply(f, Lv.u.p);
+        } else {
+          Lv.A->matvec(comm, -1.0, Lv.u.p, 1.0, f, Lv.tmp.p, s, k::prof_level(k::PROF_LVL_RELAX, level));
+          ilu.apply(Lv.tmp.p, Lv.snap.p);
+          k::axpy(1.0, Lv.snap.p, Lv.u.p, Lv.n, s);
+        }
+        zero = false;
+      }
+    return;
+  }
   for (int sw = 0; sw < p.num_sweeps[which]; sw++) {
     const bool zero = u_is_zero && sw == 0;
     if (which == 2 || p.relax_order != 1 || !has_cf)

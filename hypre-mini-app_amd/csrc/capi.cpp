@@ -232,6 +232,17 @@ HYPRE_Int HYPRE_ClearAllErrors(void) {
   return 0;
 }
 const char *HYPRE_MI_LastErrorMessage(void) { return g_last_error.c_str(); }
+void HYPRE_DescribeError(HYPRE_Int errorcode, char *descr) {
+  if (!descr) return;
+  std::string t;
+  if (errorcode == 0) t = "[No error] ";
+  if (errorcode & HYPRE_ERROR_GENERIC) t += "[Generic error] ";
+  if (errorcode & HYPRE_ERROR_MEMORY) t += "[Memory error] ";
+  if (errorcode & HYPRE_ERROR_ARG) t += "[Error in argument] ";
+  if (errorcode & HYPRE_ERROR_CONV) t += "[Method did not converge] ";
+  if (errorcode != 0 && !g_last_error.empty()) t += g_last_error;
+  snprintf(descr, 256, "%s", t.c_str());
+}
 
 HYPRE_Int HYPRE_SetMemoryLocation(HYPRE_MemoryLocation loc) {
   if (loc != HYPRE_MEMORY_DEVICE)
@@ -738,21 +749,21 @@ AMG_SET(KeepTranspose, HYPRE_Int, p.keep_transpose = v)
 AMG_SET(RAP2, HYPRE_Int, p.rap2 = v)
 AMG_SET(Variant, HYPRE_Int, if (v != 0) warn_ignored("variant", v))
 AMG_SET(NonGalerkinTol, HYPRE_Real, if (v != 0.0) warn_ignored("non_galerkin_tol", v))
-AMG_SET(SmoothType, HYPRE_Int, (void)v)  /* only acts through smooth_num_levels > 0 */
-AMG_SET(SmoothNumLevels, HYPRE_Int, if (v > 0) warn_ignored("smooth_num_levels (complex smoothers)", v))
-AMG_SET(ILUType, HYPRE_Int, (void)v)
-AMG_SET(ILULevel, HYPRE_Int, (void)v)
+AMG_SET(SmoothType, HYPRE_Int, p.smooth_type = v)  /* acts through smooth_num_levels > 0; checked at Setup */
+AMG_SET(SmoothNumLevels, HYPRE_Int, p.smooth_num_levels = v)
+AMG_SET(ILUType, HYPRE_Int, p.ilu_type = v)
+AMG_SET(ILULevel, HYPRE_Int, p.ilu_level = v)
 AMG_SET(ILULocalReordering, HYPRE_Int, (void)v)
 AMG_SET(ILUMaxRowNnz, HYPRE_Int, (void)v)
-AMG_SET(ILUMaxIter, HYPRE_Int, (void)v)
+AMG_SET(ILUMaxIter, HYPRE_Int, if (v < 1) fail(HYPRE_ERROR_ARG, "ilu_max_iter < 1"); p.ilu_max_iter = v)
 AMG_SET(ILUDroptol, HYPRE_Real, (void)v)
 AMG_SET(ILUIterSetupType, HYPRE_Int, (void)v)
 AMG_SET(ILUIterSetupOption, HYPRE_Int, (void)v)
 AMG_SET(ILUIterSetupMaxIter, HYPRE_Int, (void)v)
 AMG_SET(ILUIterSetupTolerance, HYPRE_Real, (void)v)
-AMG_SET(ILUTriSolve, HYPRE_Int, (void)v)
-AMG_SET(ILULowerJacobiIters, HYPRE_Int, (void)v)
-AMG_SET(ILUUpperJacobiIters, HYPRE_Int, (void)v)
+AMG_SET(ILUTriSolve, HYPRE_Int, p.ilu_tri_solve = v)
+AMG_SET(ILULowerJacobiIters, HYPRE_Int, p.ilu_lower_it = v)
+AMG_SET(ILUUpperJacobiIters, HYPRE_Int, p.ilu_upper_it = v)
 #undef AMG_SET
 HYPRE_Int HYPRE_BoomerAMGSetLevelNonGalerkinTol(HYPRE_Solver solver, HYPRE_Real tol, HYPRE_Int) {
   API_BEGIN

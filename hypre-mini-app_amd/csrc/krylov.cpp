@@ -12,7 +12,18 @@
 #include "kernels.hpp"
 #include "solvers.hpp"
 
+extern "C" const char *HYPRE_MI_LastErrorMessage(void);
+
 namespace mi {
+
+// the preconditioner's Setup (HYPRE_BoomerAMGSetup, HYPRE_ILUSetup ...) through the function pointer the caller
+// registered; its failure is this Setup's failure (HYPRE reports it through the global error flag)
+void KrylovSolver::run_precond_setup(ParCSR &A, ParVector &b, ParVector &x) {
+  if (!precond_setup) return;
+  const int rc = precond_setup(precond_data, &A, &b, &x);
+  if (rc) fail(rc, std::string("preconditioner setup failed: ") + HYPRE_MI_LastErrorMessage());
+}
+
 
 void KrylovSolver::apply_precond(ParCSR &A, ParVector &rhs, ParVector &out) {
   hipStream_t s = ctx().stream;
@@ -130,7 +141,7 @@ void GmresSolver::setup(ParCSR &A, ParVector &b, ParVector &x) {
   // Solve, src/HypreSystem.cpp:692 inside the loop at :681); another shape starts afresh
   if (!p.empty() && (p[0]->n != b.n || p[0]->ncomp != b.ncomp || p[0]->start != b.start)) p.clear();
   if (!z.empty() && (z[0]->n != b.n || z[0]->ncomp != b.ncomp || z[0]->start != b.start)) z.clear();
-  if (precond_setup) precond_setup(precond_data, &A, &b, &x);
+  run_precond_setup(A, b, x);
 }
 
 int GmresSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
@@ -359,7 +370,7 @@ void PcgSolver::setup(ParCSR &A, ParVector &b, ParVector &x) {
   ensure_init();
   MI_REQUIRE(b.ncomp == x.ncomp, "PCG: b and x differ in their number of components");
   for (ParVector *v : {&r, &pv, &sv}) v->init(b.start, b.end, b.ncomp);
-  if (precond_setup) precond_setup(precond_data, &A, &b, &x);
+  run_precond_setup(A, b, x);
 }
 
 // hypre_PCGSolve (krylov/pcg.c), default options: two_norm 0 (the convergence
@@ -445,7 +456,7 @@ void BicgstabSolver::setup(ParCSR &A, ParVector &b, ParVector &x) {
   ensure_init();
   MI_REQUIRE(b.ncomp == x.ncomp, "BiCGSTAB: b and x differ in their number of components");
   for (ParVector *v : {&r0, &r, &pv, &v, &q, &sv, &t}) v->init(b.start, b.end, b.ncomp);
-  if (precond_setup) precond_setup(precond_data, &A, &b, &x);
+  run_precond_setup(A, b, x);
 }
 
 int BicgstabSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {

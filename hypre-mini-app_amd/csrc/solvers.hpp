@@ -22,6 +22,7 @@ struct KrylovSolver : SolverBase {
   double tol = 1e-6, atol = 0.0;
   int max_iter = 1000, min_iter = 0, k_dim = 5, print_level = 0, logging = 0;
   ParSolverFcn precond_solve = nullptr, precond_setup = nullptr;
+  void run_precond_setup(ParCSR &A, ParVector &b, ParVector &x);
   void *precond_data = nullptr;
   int num_iterations = 0;
   double rel_residual_norm = 0.0;

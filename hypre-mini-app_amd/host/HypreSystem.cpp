@@ -637,7 +637,12 @@ void HypreSystem::solve() {
     if (i == 0) {
       if (usePrecond_) solverPrecondPtr_(solver_, precondSolvePtr_, precondSetupPtr_, precond_);
       if (iproc_ == 0) printf("Setting up solver\n");
-      solverSetupPtr_(solver_, parMat_, parRhs_[(size_t)i], parSln_[(size_t)i]);
+      const HYPRE_Int setup_rc = solverSetupPtr_(solver_, parMat_, parRhs_[(size_t)i], parSln_[(size_t)i]);
+      if (setup_rc) {  // e.g. a setting the library refuses: solving with a half-built preconditioner helps nobody
+        char what[256] = {0};
+        HYPRE_DescribeError(setup_rc, what);
+        throw std::runtime_error(std::string("solver / preconditioner setup failed: ") + what);
+      }
       checkMemory();
     }
     MPI_Barrier(comm_);

@@ -268,6 +268,15 @@ class BoomerAMG:
                               ("trunc_factor", "HYPRE_BoomerAMGSetTruncFactor", float),
                               ("keep_transpose", "HYPRE_BoomerAMGSetKeepTranspose", int),
                               ("rap2", "HYPRE_BoomerAMGSetRAP2", int),
+                              ("smooth_type", "HYPRE_BoomerAMGSetSmoothType", int),  # HypreSystem.cpp:235-320
+                              ("smooth_num_sweeps", "HYPRE_BoomerAMGSetSmoothNumSweeps", int),
+                              ("smooth_num_levels", "HYPRE_BoomerAMGSetSmoothNumLevels", int),
+                              ("ilu_type", "HYPRE_BoomerAMGSetILUType", int),
+                              ("ilu_level", "HYPRE_BoomerAMGSetILULevel", int),
+                              ("ilu_max_iter", "HYPRE_BoomerAMGSetILUMaxIter", int),
+                              ("ilu_tri_solve", "HYPRE_BoomerAMGSetILUTriSolve", int),
+                              ("ilu_lower_jacobi_iters", "HYPRE_BoomerAMGSetILULowerJacobiIters", int),
+                              ("ilu_upper_jacobi_iters", "HYPRE_BoomerAMGSetILUUpperJacobiIters", int),
                               ("true_pmax_elmts", "HYPRE_BoomerAMGSetPMaxElmts", int)):
             if key in cfg:
                 call(fn, s, conv(cfg[key]))

@@ -48,6 +48,9 @@ HYPRE_Int HYPRE_Initialized(void);
 
 HYPRE_Int HYPRE_GetError(void);
 HYPRE_Int HYPRE_ClearAllErrors(void);
+/* HYPRE's own error text call (utilities/error.c): which flags `errorcode` holds, written into descr (the caller
+ * provides >= 256 bytes); this library appends the message of the last failure */
+void HYPRE_DescribeError(HYPRE_Int errorcode, char *descr);
 /* text of the last failure (not part of HYPRE; valid until the next call) */
 const char *HYPRE_MI_LastErrorMessage(void);
 

@@ -263,6 +263,7 @@ typedef struct olevel {
   int *perm; /* new -> old row of the C-first ordering (NULL = identity) */
   double *u, *f, *tmp, *old; /* work vectors (u,f unused on level 0) */
   double *Cinv;              /* dense inverse of the coarsest operator (relax 9) */
+  struct oilu *smoother;     /* complex smoother of this level (smooth_type 5, levels < smooth_num_levels) */
 } olevel;
 
 struct oamg {
@@ -299,6 +300,11 @@ void oamg_default_params(oamg_params *p) {
   p->agg_interp_type = 4;
   p->agg_pmax_elmts = 0;
   p->agg_trunc_factor = 0.0;
+  p->smooth_type = 6;
+  p->smooth_num_levels = 0;
+  p->ilu_max_iter = 1;
+  p->ilu_tri_solve = 1;
+  p->ilu_lower_it = p->ilu_upper_it = 5;
 }
 
 static int *part_of_rows(int n, int nparts, const obig *ps) {
@@ -1214,6 +1220,9 @@ static void finish_levels(oamg *h) {
     L->tmp = (double *)xcalloc((size_t)n, sizeof(double));
     L->old = (double *)xcalloc((size_t)n, sizeof(double));
     if (L->P) L->R = ocsr_transpose(L->P);
+    /* par_amg_setup.c: HYPRE_ILUCreate/Setup per level j < smooth_num_levels (not the coarsest) */
+    if (h->p.smooth_type == 5 && l < h->p.smooth_num_levels && l < h->nlev - 1)
+      L->smoother = oilu_setup(L->A, h->p.nparts, L->part_starts, h->p.ilu_tri_solve, h->p.ilu_lower_it, h->p.ilu_upper_it);
   }
   olevel *Lc = &h->L[h->nlev - 1];
   if (h->p.relax_type[2] == 9 && Lc->A->nrows <= ORACLE_MAX_DENSE) {
@@ -1450,6 +1459,7 @@ void oamg_free(oamg *h) {
     free(L->l1jac);
     free(L->part_starts);
     free(L->perm);
+    oilu_free(L->smoother);
     free(L->u);
     free(L->f);
     free(L->tmp);
@@ -1544,6 +1554,19 @@ static void relax_sweeps(const oamg *h, int l, int which, const double *f, doubl
   /* which: 0 down, 1 up, 2 coarsest; par_cycle.c / hypre_BoomerAMGRelaxIF:
    * relax_order 1 => C then F going down, F then C going up, all on coarsest */
   const int type = h->p.relax_type[which];
+  const olevel *L = &h->L[l];
+  if (L->smoother && which != 2) {
+    /* par_cycle.c: smooth_num_levels > level && smooth_type == 5: HYPRE_ILUSolve(smoother[level], A, F, U) per sweep */
+    const int n = L->A->nrows;
+    for (int s = 0; s < h->p.num_sweeps[which]; s++)
+      for (int it = 0; it < h->p.ilu_max_iter; it++) {
+        ocsr_matvec(-1.0, L->A, u, 1.0, f, L->tmp);
+        memset(L->old, 0, sizeof(double) * (size_t)n);
+        oilu_apply(L->smoother, L->tmp, L->old);
+        for (int i = 0; i < n; i++) u[i] += L->old[i];
+      }
+    return;
+  }
   for (int s = 0; s < h->p.num_sweeps[which]; s++) {
     if (which == 2 || h->p.relax_order != 1 || !h->L[l].cf) {
       oamg_relax(h, l, type, 0, f, u);

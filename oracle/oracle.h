@@ -81,6 +81,14 @@ typedef struct oamg_params {
   int agg_interp_type;     /* 4 multipass */
   int agg_pmax_elmts;      /* 0 = no limit (the YAML key `pmax_elmts` lands here, HypreSystem.cpp:210-213) */
   double agg_trunc_factor; /* 0 */
+  /* complex smoother on levels < smooth_num_levels (src/HypreSystem.cpp:235-320): only smooth_type 5 = block-Jacobi
+   * ILU(0) is restated; a smoothing step is ilu_max_iter times  u += (LU)^-1 (f - A u)  (par_cycle.c: HYPRE_ILUSolve
+   * on the level's vectors), once per sweep, on the down and the up leg, regardless of relax_order */
+  int smooth_type;         /* 6 library default (Schwarz: not restated) */
+  int smooth_num_levels;   /* 0 */
+  int ilu_max_iter;        /* 1 */
+  int ilu_tri_solve;       /* 1 exact triangular solves, 0 Jacobi iterations */
+  int ilu_lower_it, ilu_upper_it; /* 5, 5 */
 } oamg_params;
 
 void oamg_default_params(oamg_params *p);

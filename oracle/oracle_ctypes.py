@@ -48,6 +48,12 @@ class AmgParams(C.Structure):
         ("agg_interp_type", C.c_int),
         ("agg_pmax_elmts", C.c_int),
         ("agg_trunc_factor", C.c_double),
+        ("smooth_type", C.c_int),
+        ("smooth_num_levels", C.c_int),
+        ("ilu_max_iter", C.c_int),
+        ("ilu_tri_solve", C.c_int),
+        ("ilu_lower_it", C.c_int),
+        ("ilu_upper_it", C.c_int),
     ]
 
 

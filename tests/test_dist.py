@@ -17,7 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
 
 
-def _run(nproc, mode, n, stencil, port, staging="host", seq=-1, devmin=None, golden="", replicated=False, locality=0):
+def _run(nproc, mode, n, stencil, port, staging="host", seq=-1, devmin=None, golden="", replicated=False, locality=0,
+         smooth=0):
     env = dict(os.environ)
     env["MI_HYPRE_REPLICATED_SETUP"] = "1" if replicated else "0"
     if devmin is not None:  # levels with at least this many rows are built (and sliced) on the device
@@ -33,6 +34,8 @@ def _run(nproc, mode, n, stencil, port, staging="host", seq=-1, devmin=None, gol
         cmd += ["--golden", golden]
     if locality:
         cmd += ["--locality", "1"]
+    if smooth:
+        cmd += ["--smooth", str(smooth)]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-4000:]
     return p.stdout
@@ -94,6 +97,15 @@ def test_distributed_setup_device_spgemm_shared_gpu(nproc, n, stencil, seq):
 @pytest.mark.parametrize("nproc,n,stencil,seq", [(2, 16, 7, -1), (3, 12, 27, 0), (4, 16, 7, 1000)])
 def test_device_solve_with_locality_numbering_shared_gpu(nproc, n, stencil, seq):
     out = _run(nproc, "solve", n, stencil, 29871 + nproc + n, seq=seq, locality=1)
+    assert "dist solve ok" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,n,seq,smooth", [(2, 16, -1, 1), (3, 14, 300, 3), (4, 12, 0, 2)])
+def test_device_solve_with_ilu_complex_smoother_shared_gpu(nproc, n, seq, smooth):
+    """smooth_type 5 on the first `smooth` levels (src/HypreSystem.cpp:235-320): every rank smooths with the ILU(0) of
+    its own diag block, also on redundant levels (one block there), as the oracle's emulation does."""
+    out = _run(nproc, "solve", n, 7, 29991 + nproc + n, seq=seq, smooth=smooth)
     assert "dist solve ok" in out
 
 

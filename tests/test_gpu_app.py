@@ -178,6 +178,42 @@ solver_settings:
     assert m and int(m.group(1)) < 40 and float(m.group(2)) <= 1e-10
 
 
+def test_ilu_complex_smoother_keys_through_driver(tmp_path):
+    """The smoother keys the reference driver reads (src/HypreSystem.cpp:235-320): ILU(0) as the smoother of the two
+    finest levels, Jacobi iterations for its triangular solves; an unimplemented smoother type is an error exit."""
+    head = """
+linear_system:
+  type: laplace_3d
+  nx: 20
+  ny: 20
+  nz: 20
+  stencil: 7
+
+solver_settings:
+  method: gmres
+  preconditioner: boomeramg
+  tolerance: 1.0e-9
+  max_iterations: 100
+  kspace: 50
+  print_level: 2
+
+boomeramg_settings:
+  print_level: 1
+  coarsen_type: 8
+  smooth_num_levels: 2
+"""
+    out = _run(tmp_path, head + "  smooth_type: 5\n  ilu_tri_solve: 0\n  ilu_lower_jacobi_iters: 4\n  ilu_upper_jacobi_iters: 4\n")
+    assert out.count("mi_hypre ILU(0):") == 2 and "Jacobi triangular solves" in out, out[-2000:]
+    m = re.search(r"max \|x - 1\| = ([0-9.eE+-]+)", out)
+    assert m and float(m.group(1)) < 1e-6, out[-2000:]
+    m = re.search(r"Solve 0 : (\d+) iterations", out)
+    assert m and int(m.group(1)) < 30
+    inp = tmp_path / "bad.yaml"
+    inp.write_text(head + "  smooth_type: 6\n")
+    p = subprocess.run([APP, str(inp)], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode != 0 and "smooth_type 6" in p.stdout and "not implemented" in p.stdout, p.stdout[-2000:]
+
+
 @pytest.mark.parametrize("method", ["cg", "fgmres", "cogmres", "boomeramg"])
 def test_other_methods_through_driver(tmp_path, method):
     out = _run(tmp_path, f"""
