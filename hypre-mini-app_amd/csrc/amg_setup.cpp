@@ -1516,6 +1516,8 @@ void BoomerAMG::build_natural(ParCSR &A0) {
     if (!p_on_device) {
       if (aggressive)
         build_multipass(A, S, cf, p.agg_trunc_factor, p.agg_pmax_elmts, Lv.P, nc);
+      else if (p.interp_type == 4)  // multipass interpolation on an ordinary splitting (its first pass is all there is
+        build_multipass(A, S, cf, p.trunc_factor, p.pmax_elmts, Lv.P, nc);  // unless F points lack a strong C point)
       else
         build_interp(A, S, cf, p.interp_type, p.trunc_factor, p.pmax_elmts, Lv.P, nc);
     }

@@ -733,7 +733,7 @@ AMG_SET(RelaxOrder, HYPRE_Int, p.relax_order = v)
 AMG_SET(MaxLevels, HYPRE_Int, if (v < 1) fail(HYPRE_ERROR_ARG, "max_levels < 1"); p.max_levels = v)
 AMG_SET(StrongThreshold, HYPRE_Real, p.strong_threshold = v)
 AMG_SET(MaxRowSum, HYPRE_Real, p.max_row_sum = v)
-AMG_SET(InterpType, HYPRE_Int, if (v != 0 && v != 3 && v != 6) fprintf(stderr, "mi_hypre BoomerAMG: interp_type %d is not restated; using extended+i (6)\n", v); p.interp_type = (v == 0 || v == 3) ? v : 6)
+AMG_SET(InterpType, HYPRE_Int, if (v != 0 && v != 3 && v != 4 && v != 6) fprintf(stderr, "mi_hypre BoomerAMG: interp_type %d is not restated; using extended+i (6)\n", v); p.interp_type = (v == 0 || v == 3 || v == 4) ? v : 6)
 AMG_SET(TruncFactor, HYPRE_Real, p.trunc_factor = v)
 AMG_SET(PMaxElmts, HYPRE_Int, p.pmax_elmts = v)
 AMG_SET(MinCoarseSize, HYPRE_Int, p.min_coarse_size = v)

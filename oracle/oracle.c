@@ -1373,7 +1373,9 @@ oamg *oamg_setup(const ocsr *A0, const oamg_params *p) {
     }
     int nc2;
     ocsr *P = aggressive ? build_multipass(A, Sia, Sja, cf, p->agg_trunc_factor, p->agg_pmax_elmts, &nc2)
-                         : build_interp(A, Sia, Sja, cf, one_part, p->interp_type, p->trunc_factor, p->pmax_elmts, &nc2);
+              : p->interp_type == 4 /* multipass on an ordinary splitting */
+                  ? build_multipass(A, Sia, Sja, cf, p->trunc_factor, p->pmax_elmts, &nc2)
+                  : build_interp(A, Sia, Sja, cf, one_part, p->interp_type, p->trunc_factor, p->pmax_elmts, &nc2);
     free(one_part);
     L->cf = cf;
     L->P = P;

@@ -54,7 +54,7 @@ double oracle_rand(void);
 
 typedef struct oamg_params {
   int coarsen_type;        /* 8 PMIS (HypreSystem.cpp:126); 10 HMIS, 11 one-pass RS; 6 Falgout, 1 RS, 3 RS3 (two-pass RS) */
-  int interp_type;         /* 6 ext+i (library default), 3 direct, 0 classical modified */
+  int interp_type;         /* 6 ext+i (library default), 3 direct, 0 classical modified, 4 multipass */
   double strong_threshold; /* 0.57 (HypreSystem.cpp:159) */
   double max_row_sum;      /* 0.9 library default */
   double trunc_factor;     /* 0 */

@@ -30,7 +30,10 @@ def _host_amg(mi, n, stencil, **kw):
                                           (14, 7, dict(agg_num_levels=1, agg_pmax_elmts=4)),
                                           (14, 7, dict(agg_num_levels=1, agg_trunc_factor=0.3)),
                                           (14, 7, dict(agg_num_levels=1, coarsen_type=10)),
-                                          (13, 7, dict(agg_num_levels=1, coarsen_type=6, interp_type=0))])
+                                          (13, 7, dict(agg_num_levels=1, coarsen_type=6, interp_type=0)),
+                                          # multipass interpolation on ordinary splittings (interp_type 4)
+                                          (12, 7, dict(interp_type=4)), (9, 27, dict(interp_type=4, coarsen_type=10)),
+                                          (12, 7, dict(interp_type=4, trunc_factor=0.2))])
 def test_host_setup_equals_oracle(mi_lib, oc, n, stencil, kw):
     mi = mi_lib
     A, amg = _host_amg(mi, n, stencil, **kw)
