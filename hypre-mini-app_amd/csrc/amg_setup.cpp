@@ -522,7 +522,100 @@ void ruge_stueben(int n, const Strength &S, bool second_pass, std::vector<int> &
 }
 
 bool coarsen_type_restated(int type) {
-  return type == 8 || type == 10 || type == 11 || type == 6 || type == 1 || type == 3;
+  return type == 8 || type == 9 || type == 10 || type == 11 || type == 6 || type == 1 || type == 3 || type == 0 || type == 7;
+}
+
+// CLJP (par_coarsen.c hypre_BoomerAMGCoarsen; oracle/oracle.c cljp for the statement of the algorithm):
+// w = |S^T row| + the global Park-Miller stream; rounds of { independent set of the undecided points -> C;
+// H1: edges out of a new C point leave, w-- at their undecided ends; H2: an undecided row loses its edges to C
+// points, and the edges to undecided points that share one of its C points, w-- there; w < 1 -> F }.
+// Within a round every step reads what the previous step left (counts and flags commute): host threads.
+void cljp(int n, const Strength &S, std::vector<int> &cf) {
+  const int64_t nnz = (int64_t)S.ja.size();
+  std::vector<char> gone((size_t)nnz, 0);
+  std::vector<int> dec((size_t)n, 0);  // pending decrements of a round (integers: order does not matter)
+  std::vector<double> measure((size_t)n, 0.0);
+  for (int64_t k = 0; k < nnz; k++) measure[(size_t)S.ja[(size_t)k]] += 1.0;
+  ParkMiller rng(2747);
+  for (int i = 0; i < n; i++) measure[(size_t)i] += rng.next();
+  cf.assign((size_t)n, 0);
+  std::vector<int> graph;
+  graph.reserve((size_t)n);
+  for (int i = 0; i < n; i++) {
+    if (measure[(size_t)i] < 1.0)
+      cf[(size_t)i] = (S.ia[(size_t)i + 1] == S.ia[(size_t)i]) ? SF_PT : F_PT;
+    else
+      graph.push_back(i);
+  }
+  std::vector<signed char> tmp((size_t)n, 0);
+  const int nt = host_threads();
+  std::vector<std::vector<int>> common((size_t)nt);  // per thread: common[c] == i + 1: C point c is in the row of i
+  while (!graph.empty()) {
+    const int64_t ng = (int64_t)graph.size();
+    parallel_for(ng, [&](int64_t b, int64_t e, int) {
+      for (int64_t g = b; g < e; g++) tmp[(size_t)graph[(size_t)g]] = 1;
+    });
+    parallel_for(ng, [&](int64_t b, int64_t e, int) {
+      for (int64_t g = b; g < e; g++) {
+        const int i = graph[(size_t)g];
+        for (int64_t k = S.ia[(size_t)i]; k < S.ia[(size_t)i + 1]; k++) {
+          const int j = S.ja[(size_t)k];
+          if (cf[(size_t)j] != 0) continue;
+          if (measure[(size_t)i] > measure[(size_t)j])
+            __atomic_store_n(&tmp[(size_t)j], (signed char)0, __ATOMIC_RELAXED);
+          else if (measure[(size_t)j] > measure[(size_t)i])
+            __atomic_store_n(&tmp[(size_t)i], (signed char)0, __ATOMIC_RELAXED);
+        }
+      }
+    });
+    parallel_for(ng, [&](int64_t b, int64_t e, int) {
+      for (int64_t g = b; g < e; g++)
+        if (tmp[(size_t)graph[(size_t)g]] == 1) cf[(size_t)graph[(size_t)g]] = C_PT;
+    });
+    // H1 (rows of the new C points) and H2 (undecided rows): disjoint rows, decrements collected in `dec`
+    parallel_for(ng, [&](int64_t b, int64_t e, int t) {
+      std::vector<int> &cm = common[(size_t)t];
+      if (cm.size() != (size_t)n) cm.assign((size_t)n, 0);
+      for (int64_t g = b; g < e; g++) {
+        const int i = graph[(size_t)g];
+        if (cf[(size_t)i] == C_PT) {
+          for (int64_t k = S.ia[(size_t)i]; k < S.ia[(size_t)i + 1]; k++) {
+            if (gone[(size_t)k]) continue;
+            gone[(size_t)k] = 1;
+            if (cf[(size_t)S.ja[(size_t)k]] == 0) __atomic_fetch_add(&dec[(size_t)S.ja[(size_t)k]], 1, __ATOMIC_RELAXED);
+          }
+          continue;
+        }
+        for (int64_t k = S.ia[(size_t)i]; k < S.ia[(size_t)i + 1]; k++)
+          if (cf[(size_t)S.ja[(size_t)k]] == C_PT) {
+            gone[(size_t)k] = 1;
+            cm[(size_t)S.ja[(size_t)k]] = i + 1;
+          }
+        for (int64_t k = S.ia[(size_t)i]; k < S.ia[(size_t)i + 1]; k++) {
+          const int j = S.ja[(size_t)k];
+          if (gone[(size_t)k] || cf[(size_t)j] != 0) continue;
+          for (int64_t kk = S.ia[(size_t)j]; kk < S.ia[(size_t)j + 1]; kk++)
+            if (cm[(size_t)S.ja[(size_t)kk]] == i + 1) {
+              gone[(size_t)k] = 1;
+              __atomic_fetch_add(&dec[(size_t)j], 1, __ATOMIC_RELAXED);
+              break;
+            }
+        }
+      }
+    });
+    std::vector<int> next;
+    next.reserve(graph.size());
+    for (int64_t g = 0; g < ng; g++) {
+      const int i = graph[(size_t)g];
+      if (cf[(size_t)i] == C_PT) continue;
+      for (; dec[(size_t)i] > 0; dec[(size_t)i]--) measure[(size_t)i] -= 1.0;  // one at a time, as the oracle does
+      if (measure[(size_t)i] < 1.0)
+        cf[(size_t)i] = F_PT;
+      else
+        next.push_back(i);
+    }
+    graph.swap(next);
+  }
 }
 
 // HYPRE_BoomerAMGSetCoarsenType (src/HypreSystem.cpp:125-126): 8 PMIS; 10 HMIS / 11 = one-pass Ruge-Stueben;
@@ -530,14 +623,16 @@ bool coarsen_type_restated(int type) {
 // pass leaves undecided; coarsening sees the whole graph here, where nothing is left --
 // as on a single HYPRE rank.
 void coarsen_by_type(int type, int n, const Strength &S, std::vector<int> &cf) {
-  if (type == 8)
+  if (type == 8 || type == 9)  // 9 = PMIS with one global random stream: what 8 is here anyway
     pmis(n, S, 0, cf);
+  else if (type == 0 || type == 7)  // 7 = CLJP with one global random stream: the only kind this library draws
+    cljp(n, S, cf);
   else if (type == 10 || type == 11)
     ruge_stueben(n, S, false, cf);
   else if (type == 6 || type == 1 || type == 3)
     ruge_stueben(n, S, true, cf);
   else
-    fail(4, "BoomerAMG: coarsen_type " + std::to_string(type) + " is not implemented (8, 10, 11, 6, 1, 3 are)");
+    fail(4, "BoomerAMG: coarsen_type " + std::to_string(type) + " is not implemented (8, 10, 11, 6, 1, 3, 0, 7 are)");
 }
 
 // hypre_BoomerAMGCreate2ndS, num_paths 1: graph on the C points of the first coarsening; C point i depends on
@@ -1352,7 +1447,7 @@ void BoomerAMG::setup_host(ParCSR &A0) {
   MI_REQUIRE(!A0.row_starts.empty(), "BoomerAMGSetup: matrix is not assembled");
   if (!coarsen_type_restated(p.coarsen_type))
     fail(4, "BoomerAMGSetup: coarsen_type " + std::to_string(p.coarsen_type) +
-                " is not implemented (8 PMIS, 10 HMIS, 11, 6 Falgout, 1, 3 are); refusing to substitute another one");
+                " is not implemented (8 PMIS, 10 HMIS, 11, 6 Falgout, 1, 3, 0 CLJP, 7 are); refusing to substitute another one");
   if (p.agg_num_levels > 0 && p.agg_interp_type != 4)
     fail(4, "BoomerAMGSetup: agg_interp_type " + std::to_string(p.agg_interp_type) +
                 " is not implemented (4 = multipass is); refusing to substitute another one");
@@ -1437,7 +1532,7 @@ void BoomerAMG::build_natural(ParCSR &A0) {
     // aggressive coarsening (level < agg_num_levels) and the Ruge-Stueben family are host algorithms: on a level
     // the device builds, the strength graph still comes from the device and the Galerkin product stays there
     const bool aggressive = l < p.agg_num_levels;
-    const bool host_coarsen = aggressive || p.coarsen_type != 8;
+    const bool host_coarsen = aggressive || (p.coarsen_type != 8 && p.coarsen_type != 9);
     Strength S;
     std::vector<int> cf;
     sk::DCsr dS;

@@ -360,7 +360,7 @@ void dist_setup_counters_reset() { g_ext_rows_max = g_global_rows_gathered = g_d
 
 bool BoomerAMG::can_build_distributed() const {
   static const bool forced_off = getenv("MI_HYPRE_REPLICATED_SETUP") && atoi(getenv("MI_HYPRE_REPLICATED_SETUP")) != 0;
-  return !forced_off && p.coarsen_type == 8 && p.agg_num_levels <= 0 && p.interp_type != 4;  // (multipass: host passes)
+  return !forced_off && (p.coarsen_type == 8 || p.coarsen_type == 9) && p.agg_num_levels <= 0 && p.interp_type != 4;  // (multipass: host passes)
 }
 
 void BoomerAMG::build_distributed(ParCSR &A0) {

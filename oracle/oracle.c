@@ -621,9 +621,104 @@ static void ruge_stueben(int n, const obig *Sia, const int *Sja, int second_pass
 
 /* Coarsening by type (HYPRE_BoomerAMGSetCoarsenType, src/HypreSystem.cpp:125-126; the sample input asks for 6,
  * etc/hypre_app.yaml:35).  Returns 0, or -1 for a type that is not restated (0 CLJP, 7, 9, 21, 22). */
+/* CLJP coarsening (par_coarsen.c hypre_BoomerAMGCoarsen; Cleary, Luby, Jones, Plassmann): coarsen_type 0, and 7 =
+ * its variant with ONE global random stream, which is what this specification always draws from (as PMIS does).
+ *   w(i) = |S^T_i| + Park-Miller(2747) element i;  points nobody depends on (w < 1) are F from the start
+ *   repeat: D = undecided points whose w beats every undecided neighbour's (neighbours through S in either
+ *           direction, the comparisons run along the rows of S as in hypre_BoomerAMGIndepSet) -> new C points
+ *     H1: a C point does not interpolate: the edges c -> j leave the graph, w(j)-- for undecided j
+ *     H2: for an undecided i, the edges to its C points leave the graph; an undecided j in S_i that shares one of
+ *         those C points (j depends on it too) is no longer needed by i: edge i -> j leaves, w(j)--
+ *     undecided points with w < 1 become F
+ * Every F point with a non-empty row ends with a C point in it: an edge i -> j that is still there keeps w(j) >= 1,
+ * so j stays undecided until it is picked. */
+static void cljp(int n, const obig *Sia, const int *Sja, int *cf) {
+  const obig nnz = Sia[n];
+  char *gone = (char *)xcalloc((size_t)(nnz ? nnz : 1), 1);
+  double *measure = (double *)xcalloc((size_t)n, sizeof(double));
+  for (obig k = 0; k < nnz; k++) measure[Sja[k]] += 1.0;
+  oracle_rand_seed(2747);
+  for (int i = 0; i < n; i++) measure[i] += oracle_rand();
+  int *graph = (int *)xmalloc(sizeof(int) * (size_t)n);
+  int *tmp = (int *)xcalloc((size_t)n, sizeof(int));
+  int *common = (int *)xcalloc((size_t)n, sizeof(int)); /* common[c] == i + 1: C point c is in the row of i */
+  int ng = 0;
+  for (int i = 0; i < n; i++) {
+    if (measure[i] < 1.0)
+      cf[i] = (Sia[i + 1] == Sia[i]) ? SF_PT : F_PT;
+    else {
+      cf[i] = 0;
+      graph[ng++] = i;
+    }
+  }
+  while (ng > 0) {
+    for (int g = 0; g < ng; g++) tmp[graph[g]] = 1;
+    for (int g = 0; g < ng; g++) {
+      const int i = graph[g];
+      for (obig k = Sia[i]; k < Sia[i + 1]; k++) {
+        const int j = Sja[k];
+        if (cf[j] != 0) continue;
+        if (measure[i] > measure[j])
+          tmp[j] = 0;
+        else if (measure[j] > measure[i])
+          tmp[i] = 0;
+      }
+    }
+    for (int g = 0; g < ng; g++)
+      if (tmp[graph[g]] == 1) cf[graph[g]] = C_PT;
+    for (int g = 0; g < ng; g++) { /* H1 */
+      const int i = graph[g];
+      if (cf[i] != C_PT) continue;
+      for (obig k = Sia[i]; k < Sia[i + 1]; k++) {
+        if (gone[k]) continue;
+        gone[k] = 1;
+        if (cf[Sja[k]] == 0) measure[Sja[k]] -= 1.0;
+      }
+    }
+    for (int g = 0; g < ng; g++) { /* H2 */
+      const int i = graph[g];
+      if (cf[i] != 0) continue;
+      for (obig k = Sia[i]; k < Sia[i + 1]; k++)
+        if (cf[Sja[k]] == C_PT) {
+          gone[k] = 1;
+          common[Sja[k]] = i + 1;
+        }
+      for (obig k = Sia[i]; k < Sia[i + 1]; k++) {
+        const int j = Sja[k];
+        if (gone[k] || cf[j] != 0) continue;
+        for (obig kk = Sia[j]; kk < Sia[j + 1]; kk++)
+          if (common[Sja[kk]] == i + 1) {
+            gone[k] = 1;
+            measure[j] -= 1.0;
+            break;
+          }
+      }
+    }
+    int m = 0;
+    for (int g = 0; g < ng; g++) {
+      const int i = graph[g];
+      if (cf[i] == C_PT) continue;
+      if (measure[i] < 1.0)
+        cf[i] = F_PT;
+      else
+        graph[m++] = i;
+    }
+    ng = m;
+  }
+  free(gone);
+  free(measure);
+  free(graph);
+  free(tmp);
+  free(common);
+}
+
 static void pmis(int n, const obig *Sia, const int *Sja, const int *part_of, int nparts, const obig *ps, int *cf);
 static int coarsen_by_type(int type, int n, const obig *Sia, const int *Sja, int *cf) {
-  if (type == 8) {
+  if (type == 0 || type == 7) {
+    cljp(n, Sia, Sja, cf);
+    return 0;
+  }
+  if (type == 8 || type == 9) { /* 9 = PMIS with one global random stream: what 8 is here anyway */
     int *one_part = (int *)xcalloc((size_t)n, sizeof(int));
     pmis(n, Sia, Sja, one_part, 1, NULL, cf);
     free(one_part);

@@ -53,7 +53,8 @@ void oracle_rand_seed(int seed);
 double oracle_rand(void);
 
 typedef struct oamg_params {
-  int coarsen_type;        /* 8 PMIS (HypreSystem.cpp:126); 10 HMIS, 11 one-pass RS; 6 Falgout, 1 RS, 3 RS3 (two-pass RS) */
+  int coarsen_type;        /* 8 PMIS (HypreSystem.cpp:126); 10 HMIS, 11 one-pass RS; 6 Falgout, 1 RS, 3 RS3 (two-pass RS);
+                            * 0 CLJP, 7 CLJP with one global random stream (the same thing here) */
   int interp_type;         /* 6 ext+i (library default), 3 direct, 0 classical modified, 4 multipass */
   double strong_threshold; /* 0.57 (HypreSystem.cpp:159) */
   double max_row_sum;      /* 0.9 library default */

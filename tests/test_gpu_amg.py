@@ -137,6 +137,7 @@ def test_relax_other_chunk_sizes(mi, oc, chunk):
                                 dict(coarsen_type=6, relax_type=6, num_sweeps=2, interp_type=0),
                                 dict(coarsen_type=10), dict(agg_num_levels=1), dict(agg_num_levels=2, cycle_type=2),
                                 dict(interp_type=4),  # multipass interpolation on ordinary splittings
+                                dict(coarsen_type=0), dict(coarsen_type=7, max_levels=6),  # CLJP
                                 # complex smoother (src/HypreSystem.cpp:235-320): ILU(0) on the finest level(s)
                                 dict(smooth_type=5, smooth_num_levels=1), dict(smooth_type=5, smooth_num_levels=3, num_sweeps=2),
                                 dict(smooth_type=5, smooth_num_levels=2, ilu_max_iter=2, cycle_type=2),

@@ -31,6 +31,9 @@ def _host_amg(mi, n, stencil, **kw):
                                           (14, 7, dict(agg_num_levels=1, agg_trunc_factor=0.3)),
                                           (14, 7, dict(agg_num_levels=1, coarsen_type=10)),
                                           (13, 7, dict(agg_num_levels=1, coarsen_type=6, interp_type=0)),
+                                          # CLJP (0; 7 = its one-global-stream variant, the same thing here)
+                                          (12, 7, dict(coarsen_type=0)), (9, 27, dict(coarsen_type=7, interp_type=0)),
+                                          (12, 7, dict(coarsen_type=0, agg_num_levels=1)), (11, 7, dict(coarsen_type=9)),
                                           # multipass interpolation on ordinary splittings (interp_type 4)
                                           (12, 7, dict(interp_type=4)), (9, 27, dict(interp_type=4, coarsen_type=10)),
                                           (12, 7, dict(interp_type=4, trunc_factor=0.2))])
@@ -122,11 +125,11 @@ def test_empty_and_tiny_systems_host(mi_lib, oc):
 
 
 def test_unrestated_settings_are_refused_not_substituted(mi_lib):
-    """CLJP (0) and the two-stage aggressive interpolations are not implemented: Setup says so instead of
-    silently building a PMIS / multipass hierarchy."""
+    """The CGC coarsenings (21, 22) and the two-stage aggressive interpolations are not implemented: Setup says so
+    instead of silently building a PMIS / multipass hierarchy."""
     mi = mi_lib
     A, rhs = mi.build_laplace_system_host(6, 6, 6, 7, 0, 1)
-    for kw in (dict(coarsen_type=0), dict(coarsen_type=21), dict(agg_num_levels=1, agg_interp_type=1)):
+    for kw in (dict(coarsen_type=21), dict(coarsen_type=22), dict(agg_num_levels=1, agg_interp_type=1)):
         amg = mi.BoomerAMG(print_level=0, **kw)
         with pytest.raises(mi.HypreError, match="not implemented"):
             mi.call("HYPRE_MI_BoomerAMGSetupHostOnly", amg.h, A.par)
@@ -145,7 +148,8 @@ def test_random_mmatrix_coarsening_types_host(mi_lib, oc):
     M.sort_indices()
     coo = M.tocoo()
     for kw in (dict(coarsen_type=10), dict(coarsen_type=6), dict(agg_num_levels=1), dict(agg_num_levels=1, coarsen_type=6),
-               dict(strong_threshold=0.25, coarsen_type=6, interp_type=0)):
+               dict(strong_threshold=0.25, coarsen_type=6, interp_type=0), dict(coarsen_type=0),
+               dict(coarsen_type=0, strong_threshold=0.25, interp_type=0), dict(coarsen_type=0, agg_num_levels=1)):
         A = mi.IJMatrix.__new__(mi.IJMatrix)
         A.h = mi.vp()
         mi.call("HYPRE_IJMatrixCreate", 0, mi.c_big(0), mi.c_big(n - 1), mi.c_big(0), mi.c_big(n - 1), mi.C.byref(A.h))
