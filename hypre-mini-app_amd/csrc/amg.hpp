@@ -88,6 +88,7 @@ struct AmgLevel {
   std::vector<double> diag, l1gs, l1jac;
   DVec<double> d_diag, d_l1gs, d_l1jac;
   DVec<double> u, f, tmp, snap;
+  DVec<double> ts_work;  // second work vector of the two-stage Gauss-Seidel (relax types 11 / 12), on first use
   // coarsest level dense solve (relax type 9)
   std::vector<double> Cinv_host;
   DVec<double> Cinv;    // n_local x (size*slot) padded inverse rows

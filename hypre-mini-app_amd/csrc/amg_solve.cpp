@@ -44,9 +44,12 @@ int relax_prof_id(int level, bool zero_guess) {
 }
 struct GsKind {
   bool jacobi, l1, fwd, bwd;
+  int two_stage;  // relax types 11 / 12: inner iterations of the two-stage Gauss-Seidel
 };
 GsKind classify(int type) {
   GsKind g{};
+  g.two_stage = (type == 11) ? 1 : (type == 12) ? 2 : 0;
+  if (g.two_stage) return g;
   g.jacobi = (type == 0 || type == 7 || type == 18);
   g.l1 = (type == 8 || type == 13 || type == 14 || type == 18);
   g.fwd = (type == 3 || type == 6 || type == 8 || type == 13);
@@ -185,6 +188,21 @@ void BoomerAMG::relax(int level, int type, int points, const double *f, bool u_i
   const bool has_cf = Lv.has_cf && !Lv.cf.empty();
   const signed char *cf = has_cf ? Lv.d_cf.p : nullptr;
   if (!has_cf) points = 0;
+  if (g.two_stage) {
+    // par_relax.c hypre_BoomerAMGRelax11/12TwoStageGaussSeidel: r = w (f - A u); z_0 = D^-1 r; z_k = D^-1 L z_(k-1)
+    // (L: strictly lower part of this rank's diag block); u += z_0 - z_1 (+ z_2).  The C/F marker plays no part.
+    if (Lv.ts_work.n != (size_t)Lv.n) Lv.ts_work.alloc((size_t)Lv.n);
+    A.matvec(comm, -w, u, w, f, Lv.tmp.p, s, prof);
+    double *z = Lv.snap.p, *zn = Lv.ts_work.p;
+    k::two_stage_first(Lv.tmp.p, Lv.d_diag.p, z, u, Lv.n, s);
+    double sign = -1.0;
+    for (int it = 0; it < g.two_stage; it++) {
+      k::two_stage_lower(A.d_diag, Lv.d_diag.p, z, sign, zn, u, s);
+      std::swap(z, zn);
+      sign = -sign;
+    }
+    return;
+  }
   if (g.jacobi) {
     // a zero vector has a zero halo: no exchange, no halo contribution
     const double *offc = u_is_zero ? nullptr : A.offd_contrib(comm, u, s);
@@ -217,7 +235,7 @@ void BoomerAMG::relax(int level, int type, int points, const double *f, bool u_i
 void BoomerAMG::relax_pair(int level, int type, int first, const double *f, bool u_is_zero) {
   AmgLevel &Lv = L[(size_t)level];
   const GsKind g = classify(type);
-  if (g.jacobi || Lv.cf.empty() || Lv.nc == 0 || Lv.nc == Lv.n) {
+  if (g.jacobi || g.two_stage || Lv.cf.empty() || Lv.nc == 0 || Lv.nc == Lv.n) {
     relax(level, type, first, f, u_is_zero);
     relax(level, type, -first, f, false);
     return;

@@ -1122,6 +1122,32 @@ __global__ __launch_bounds__(256) void scatter_k(double *__restrict__ x, const i
 }
 
 // u = M f for the coarsest level (relax type 9: M = dense inverse, n small)
+// two-stage Gauss-Seidel (relax types 11 / 12): z = r / d, u += z; then z_out = (L z_in) / d with L the strictly
+// lower part of the block, u += sign * z_out.  One lane per row: these smoothers are not on the benchmark path.
+__global__ __launch_bounds__(256) void two_stage_first_k(int n, const double *__restrict__ r, const double *__restrict__ d,
+                                                         double *__restrict__ z, double *__restrict__ u) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double zi = (d[i] != 0.0) ? r[i] / d[i] : 0.0;
+  z[i] = zi;
+  u[i] += zi;
+}
+__global__ __launch_bounds__(256) void two_stage_lower_k(int n, const int *__restrict__ ia, const int *__restrict__ ja,
+                                                         const double *__restrict__ a, const double *__restrict__ d,
+                                                         const double *__restrict__ zin, double sign,
+                                                         double *__restrict__ zout, double *__restrict__ u) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int k = ia[i]; k < ia[i + 1]; k++) {
+    const int j = ja[k];
+    if (j < i) s += a[k] * zin[j];
+  }
+  const double zi = (d[i] != 0.0) ? s / d[i] : 0.0;
+  zout[i] = zi;
+  u[i] += sign * zi;
+}
+
 __global__ __launch_bounds__(256) void dense_matvec_k(const double *__restrict__ M, const double *__restrict__ f,
                                                       double *__restrict__ u, int n, int m) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1533,6 +1559,17 @@ void scatter_add(double *x, const int *idx, const double *vals, int n, hipStream
   hipLaunchKernelGGL(scatter_k<1>, dim3((n + 255) / 256), dim3(256), 0, s, x, idx, vals, n);
   MI_HIP(hipGetLastError());
 }
+void two_stage_first(const double *r, const double *d, double *z, double *u, int n, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(two_stage_first_k, dim3((n + 255) / 256), dim3(256), 0, s, n, r, d, z, u);
+}
+void two_stage_lower(const DevCSR &A, const double *d, const double *zin, double sign, double *zout, double *u,
+                     hipStream_t s) {
+  if (A.nrows <= 0) return;
+  hipLaunchKernelGGL(two_stage_lower_k, dim3((A.nrows + 255) / 256), dim3(256), 0, s, A.nrows, A.ia.p, A.ja.p, A.a.p, d,
+                     zin, sign, zout, u);
+}
+
 void dense_matvec(const double *M, const double *f, double *u, int n, int m, hipStream_t s) {
   if (n == 0) return;
   hipLaunchKernelGGL(dense_matvec_k, dim3((n + 255) / 256), dim3(256), 0, s, M, f, u, n, m);

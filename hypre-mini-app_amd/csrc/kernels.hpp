@@ -93,6 +93,10 @@ void copy(const double *x, double *y, int n, hipStream_t s);
 void gather(const double *x, const int *map, double *out, int n, hipStream_t s);
 // out[i] = (map[i] < split ? lo : hi)[map[i]]
 void gather2(const double *lo, const double *hi, int split, const int *map, double *out, int n, hipStream_t s);
+// two-stage Gauss-Seidel pieces (relax types 11 / 12): z = r / d, u += z;  zout = (L zin) / d, u += sign * zout
+void two_stage_first(const double *r, const double *d, double *z, double *u, int n, hipStream_t s);
+void two_stage_lower(const DevCSR &A, const double *d, const double *zin, double sign, double *zout, double *u,
+                     hipStream_t s);
 // u = M f, M dense n x m row-major
 void dense_matvec(const double *M, const double *f, double *u, int n, int m, hipStream_t s);
 

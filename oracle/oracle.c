@@ -1610,6 +1610,39 @@ void oamg_relax(const oamg *h, int level, int type, int points, const double *f,
     }
     return;
   }
+  if (type == 11 || type == 12) {
+    /* two-stage Gauss-Seidel (par_relax.c hypre_BoomerAMGRelax11/12TwoStageGaussSeidel): the forward solve with
+     * D + L of the rank's diag block, replaced by 1 (type 11) or 2 (type 12) further terms of its Neumann series
+     *     r = w (f - A u);  z_0 = D^-1 r;  z_k = D^-1 L z_(k-1);  u += z_0 - z_1 (+ z_2)
+     * L = strictly lower part inside the row's partition.  The routine does not look at the C/F marker: every
+     * point takes part whatever `points` says (with relax_order 1 a sweep therefore applies it twice). */
+    const int inner = (type == 11) ? 1 : 2;
+    double *z = old, *zn = L->tmp;
+    const int *part_of = part_of_rows(n, h->p.nparts, L->part_starts);
+    for (int i = 0; i < n; i++) {
+      double res = f[i];
+      for (obig k = A->ia[i]; k < A->ia[i + 1]; k++) res -= A->a[k] * u[A->ja[k]];
+      zn[i] = (L->diag[i] != 0.0) ? w * res / L->diag[i] : 0.0;
+    }
+    for (int i = 0; i < n; i++) u[i] += zn[i];
+    double sign = -1.0;
+    for (int it = 0; it < inner; it++) {
+      double *t = z;
+      z = zn;
+      zn = t;
+      for (int i = 0; i < n; i++) {
+        double sum = 0.0;
+        const obig lo = L->part_starts[part_of[i]];
+        for (obig k = A->ia[i]; k < A->ia[i + 1]; k++)
+          if (A->ja[k] < i && A->ja[k] >= lo) sum += A->a[k] * z[A->ja[k]];
+        zn[i] = (L->diag[i] != 0.0) ? sum / L->diag[i] : 0.0;
+        u[i] += sign * zn[i];
+      }
+      sign = -sign;
+    }
+    free((void *)part_of);
+    return;
+  }
   const int l1 = (type == 8 || type == 13 || type == 14);
   const int fwd = (type == 3 || type == 6 || type == 8 || type == 13);
   const int bwd = (type == 4 || type == 6 || type == 8 || type == 14);

@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--locality", type=int, default=0,
                     help="1: force the per-rank internal locality numbering (MI_HYPRE_LOCALITY_ORDER=1); the oracle then "
                          "works on the globally permuted system")
+    ap.add_argument("--relax", type=int, default=0, help="relax_type of the down / up sweeps (0 = library default)")
     ap.add_argument("--smooth", type=int, default=0,
                     help="levels with the ILU complex smoother (smooth_type 5): block-Jacobi ILU(0) per rank")
     args = ap.parse_args()
@@ -79,6 +80,8 @@ def main():
     mi.call("HYPRE_MI_GetGSChunk", mi.C.byref(chunk))
     seq = args.seq if args.seq >= 0 else 200000
     smooth_o = dict(smooth_type=5, smooth_num_levels=args.smooth) if args.smooth else {}
+    if args.relax:
+        smooth_o["relax_type"] = args.relax
     oamg = oc.Amg(Ao, oc.default_params(gs_chunk=chunk.value, part_starts=starts, redundant_rows=seq, **smooth_o))
 
     if args.mode == "host":
@@ -297,9 +300,10 @@ def main():
             cnt[name] = v.value
         if size > 1 and os.environ.get("MI_HYPRE_OVERLAP_HALO", "1") != "0":
             assert cnt["matvec_overlapped"] > 0, cnt
-            if not args.smooth:  # (levels with the ILU complex smoother run no Gauss-Seidel passes)
+            no_gs = bool(args.smooth) or args.relax in (11, 12, 7, 18)
+            if not no_gs:  # (the ILU complex smoother and the two-stage / Jacobi smoothers run no Gauss-Seidel passes)
                 assert cnt["gs_overlapped"] + cnt["gs_in_order"] > 0, cnt
-            if size == 2 and n >= 12 and not args.smooth:  # slabs of >= 6 planes with one neighbour: most rows are halo-free
+            if size == 2 and n >= 12 and not no_gs:  # slabs of >= 6 planes with one neighbour: most rows are halo-free
                 assert cnt["gs_overlapped"] > 0, cnt
         if rank == 0:
             print(f"overlap counters rank 0: {cnt}")

@@ -18,7 +18,7 @@ WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
 
 
 def _run(nproc, mode, n, stencil, port, staging="host", seq=-1, devmin=None, golden="", replicated=False, locality=0,
-         smooth=0):
+         smooth=0, relax=0):
     env = dict(os.environ)
     env["MI_HYPRE_REPLICATED_SETUP"] = "1" if replicated else "0"
     if devmin is not None:  # levels with at least this many rows are built (and sliced) on the device
@@ -36,6 +36,8 @@ def _run(nproc, mode, n, stencil, port, staging="host", seq=-1, devmin=None, gol
         cmd += ["--locality", "1"]
     if smooth:
         cmd += ["--smooth", str(smooth)]
+    if relax:
+        cmd += ["--relax", str(relax)]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-4000:]
     return p.stdout
@@ -106,6 +108,14 @@ def test_device_solve_with_ilu_complex_smoother_shared_gpu(nproc, n, seq, smooth
     """smooth_type 5 on the first `smooth` levels (src/HypreSystem.cpp:235-320): every rank smooths with the ILU(0) of
     its own diag block, also on redundant levels (one block there), as the oracle's emulation does."""
     out = _run(nproc, "solve", n, 7, 29991 + nproc + n, seq=seq, smooth=smooth)
+    assert "dist solve ok" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,n,seq,relax", [(2, 16, -1, 11), (3, 14, 300, 12), (4, 12, 0, 18)])
+def test_device_solve_other_smoothers_shared_gpu(nproc, n, seq, relax):
+    """Two-stage Gauss-Seidel (11 / 12: the lower triangle of each rank's diag block) and l1-Jacobi (18) on N ranks."""
+    out = _run(nproc, "solve", n, 7, 30031 + nproc + n, seq=seq, relax=relax)
     assert "dist solve ok" in out
 
 

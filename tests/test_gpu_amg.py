@@ -79,6 +79,22 @@ def test_relax_matches_oracle(mi, oc, rtype, points):
             assert np.array_equal(got[cf != points], u0[cf != points])
 
 
+@pytest.mark.parametrize("rtype", [11, 12])
+def test_two_stage_gauss_seidel_matches_oracle(mi, oc, rtype):
+    """Relax types 11 / 12 (two-stage Gauss-Seidel: 1 / 2 Neumann terms for the forward solve): one call on two levels;
+    the routine ignores the C/F marker, so every point moves whatever `points` says."""
+    A, b, x, amg, Ao, bo, oamg = _setup(mi, oc, 14)
+    rng = np.random.default_rng(200 + rtype)
+    for level in (0, 1):
+        nl = oamg.level_A(level).shape[0]
+        f, u0 = rng.standard_normal(nl), rng.standard_normal(nl)
+        for points in (0, 1):
+            got = amg.relax_level(level, rtype, points, f, u0)
+            ref = oamg.relax(level, rtype, points, f, u0)
+            assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+            assert np.all(got != u0)
+
+
 @pytest.mark.parametrize("density,longrow", [(0.004, None), (0.02, None), (0.05, (40, 1500)), (0.12, None)])
 def test_relax_irregular_rows(mi, oc, density, longrow):
     """Ragged / long rows: every lanes-per-chunk variant of the cooperative GS kernel and its
@@ -138,6 +154,7 @@ def test_relax_other_chunk_sizes(mi, oc, chunk):
                                 dict(coarsen_type=10), dict(agg_num_levels=1), dict(agg_num_levels=2, cycle_type=2),
                                 dict(interp_type=4),  # multipass interpolation on ordinary splittings
                                 dict(coarsen_type=0), dict(coarsen_type=7, max_levels=6),  # CLJP
+                                dict(relax_type=11, relax_order=0, num_sweeps=2), dict(relax_type=12),  # two-stage GS
                                 # complex smoother (src/HypreSystem.cpp:235-320): ILU(0) on the finest level(s)
                                 dict(smooth_type=5, smooth_num_levels=1), dict(smooth_type=5, smooth_num_levels=3, num_sweeps=2),
                                 dict(smooth_type=5, smooth_num_levels=2, ilu_max_iter=2, cycle_type=2),
