@@ -1451,6 +1451,14 @@ void BoomerAMG::setup_host(ParCSR &A0) {
   if (p.agg_num_levels > 0 && p.agg_interp_type != 4)
     fail(4, "BoomerAMGSetup: agg_interp_type " + std::to_string(p.agg_interp_type) +
                 " is not implemented (4 = multipass is); refusing to substitute another one");
+  for (int k = 0; k < 3; k++) {
+    const int t = p.relax_type[k];
+    const bool known = t == 0 || t == 7 || t == 18 || t == 3 || t == 4 || t == 6 || t == 8 || t == 13 || t == 14 ||
+                       t == 11 || t == 12 || t == 9;
+    if (!known)
+      fail(4, "BoomerAMGSetup: relax_type " + std::to_string(t) +
+                  " is not implemented (0, 3, 4, 6, 7, 8, 9, 11, 12, 13, 14, 18 are); refusing to smooth with something else");
+  }
   if (p.smooth_num_levels > 0 && p.smooth_type != 5)
     fail(4, "BoomerAMGSetup: smooth_type " + std::to_string(p.smooth_type) + " on " + std::to_string(p.smooth_num_levels) +
                 " level(s) is not implemented (5 = ILU is); refusing to smooth with something else");

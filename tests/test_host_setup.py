@@ -129,7 +129,8 @@ def test_unrestated_settings_are_refused_not_substituted(mi_lib):
     instead of silently building a PMIS / multipass hierarchy."""
     mi = mi_lib
     A, rhs = mi.build_laplace_system_host(6, 6, 6, 7, 0, 1)
-    for kw in (dict(coarsen_type=21), dict(coarsen_type=22), dict(agg_num_levels=1, agg_interp_type=1)):
+    for kw in (dict(coarsen_type=21), dict(coarsen_type=22), dict(agg_num_levels=1, agg_interp_type=1),
+               dict(relax_type=16)):
         amg = mi.BoomerAMG(print_level=0, **kw)
         with pytest.raises(mi.HypreError, match="not implemented"):
             mi.call("HYPRE_MI_BoomerAMGSetupHostOnly", amg.h, A.par)
