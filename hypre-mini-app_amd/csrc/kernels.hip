@@ -155,8 +155,8 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream(int nb, int xchunk, co
 // kernel is not bound by this chain alone -- VALU, LDS and the L1 gather path are each 25-30 % busy.)
 // VAL8: the operator has a value dictionary (DevCSR::vidx / vlut): the stream is one byte per value, looked up in
 // a 2 KB LDS copy of the table
-template <int EPI, int TAG, bool VAL8>
-__global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream_xc(int nb, int xchunk, const int *__restrict__ tdesc,
+template <int EPI, int TAG, bool VAL8, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void spmv_stream_xc(int nb, int xchunk, const int *__restrict__ tdesc,
                                                              const int *__restrict__ ia, const int *__restrict__ ja,
                                                              const double *__restrict__ av,
                                                              const int *__restrict__ ucols,
@@ -164,41 +164,46 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream_xc(int nb, int xchunk,
                                                              const double *__restrict__ x, double *__restrict__ y,
                                                              EpiArgs e, const unsigned char *__restrict__ vidx,
                                                              const double *__restrict__ vlut) {
-  __shared__ double prod[SPMV_TILE];
+  constexpr int TILE = 8 * BLOCK;  // TILE / TILE_WIDE
+  __shared__ double prod[TILE];
   __shared__ double slut[VAL8 ? 256 : 1];
   double *xs = prod;
   const int blk = xcd_remap(blockIdx.x, xchunk);
   if (blk >= nb) return;
   const int tid = threadIdx.x;
-  if (VAL8) slut[tid] = vlut[tid];  // visible after the first barrier below
+  if (VAL8 && tid < 256) slut[tid] = vlut[tid];  // visible after the first barrier below
   const int4 d0 = reinterpret_cast<const int4 *>(tdesc)[2 * blk];
   const int4 d1 = reinterpret_cast<const int4 *>(tdesc)[2 * blk + 1];
   const int r0 = d0.x, r1 = d0.y, base = d0.z, end = d0.w, u0 = d1.x, nu = d1.y;
-  if (end - base >= SPMV_TILE) {
+  if (end - base >= TILE) {
     double s = 0.0;
-    for (int k = base + tid; k < end; k += SPMV_BLOCK) s += av[k] * x[ja[k]];
+    for (int k = base + tid; k < end; k += BLOCK) s += av[k] * x[ja[k]];
     s = wave_sum(s);
     if ((tid & 63) == 0) prod[tid >> 6] = s;
     __syncthreads();
-    if (tid == 0) epilogue<EPI>(r0, prod[0] + prod[1] + prod[2] + prod[3], x, y, e);
+    if (tid == 0) {
+      double tot = prod[0] + prod[1] + prod[2] + prod[3];
+      for (int wv = 4; wv < BLOCK / 64; wv++) tot += prod[wv];
+      epilogue<EPI>(r0, tot, x, y, e);
+    }
     return;
   }
-  constexpr int NU = SPMV_TILE / SPMV_BLOCK;
+  constexpr int NU = TILE / BLOCK;
   int uc[NU];
 #pragma unroll
   for (int q = 0; q < NU; q++) {
-    const int k = tid + q * SPMV_BLOCK;
+    const int k = tid + q * BLOCK;
     uc[q] = (k < nu) ? ucols[u0 + k] : 0;
   }
   const int base_al = base & ~1;
   const int cnt = end - base_al;
-  constexpr int NIT = SPMV_TILE / (2 * SPMV_BLOCK);
+  constexpr int NIT = TILE / (2 * BLOCK);
   d2_t vv[NIT];
   us2_t cc[NIT];
   uc2_t vi[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; it++) {
-    const int k = 2 * tid + it * 2 * SPMV_BLOCK;
+    const int k = 2 * tid + it * 2 * BLOCK;
     if (k < cnt) {
       if (VAL8)
         vi[it] = *reinterpret_cast<const uc2_t *>(vidx + base_al + k);
@@ -208,11 +213,11 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream_xc(int nb, int xchunk,
     }
   }
   // the entry range of the first row a thread sums travels with the other loads (operators that the tile
-  // Gauss-Seidel kernel also sweeps have <= SPMV_BLOCK rows per tile: one row per thread; SpMV-only operators
-  // with short rows -- P, R, the residual sub-operator -- get up to 4 x SPMV_BLOCK rows to fill their tiles)
+  // Gauss-Seidel kernel also sweeps have <= BLOCK rows per tile: one row per thread; SpMV-only operators
+  // with short rows -- P, R, the residual sub-operator -- get up to 4 x BLOCK rows to fill their tiles)
   const int nr = r1 - r0;
   int G = 1;
-  while (G < 64 && nr * G * 2 <= SPMV_BLOCK) G <<= 1;
+  while (G < 64 && nr * G * 2 <= BLOCK) G <<= 1;
   const int lane = tid & (G - 1);
   const int rr = tid / G;
   int s0 = 0, s1 = 0;
@@ -226,13 +231,13 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream_xc(int nb, int xchunk,
   }
 #pragma unroll
   for (int q = 0; q < NU; q++) {
-    const int k = tid + q * SPMV_BLOCK;
+    const int k = tid + q * BLOCK;
     if (k < nu) xs[k] = x[uc[q]];
   }
   __syncthreads();
 #pragma unroll
   for (int it = 0; it < NIT; it++) {
-    const int k = 2 * tid + it * 2 * SPMV_BLOCK;
+    const int k = 2 * tid + it * 2 * BLOCK;
     if (k < cnt) {
       const bool ok0 = (base_al + k >= base);
       const bool ok1 = (base_al + k + 1 < end);
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream_xc(int nb, int xchunk,
   __syncthreads();  // every x-cache read is done: the array becomes the product buffer
 #pragma unroll
   for (int it = 0; it < NIT; it++) {
-    const int k = 2 * tid + it * 2 * SPMV_BLOCK;
+    const int k = 2 * tid + it * 2 * BLOCK;
     if (k < cnt) {
       prod[k] = vv[it].x;
       prod[k + 1] = vv[it].y;
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(SPMV_BLOCK) void spmv_stream_xc(int nb, int xchunk,
     }
   }
   // tiles with more rows than threads (G == 1 there): the remaining rows, one lane each
-  for (int r2 = tid + SPMV_BLOCK; r2 < nr; r2 += SPMV_BLOCK) {
+  for (int r2 = tid + BLOCK; r2 < nr; r2 += BLOCK) {
     const int a0 = ia[r0 + r2] - base_al, a1 = ia[r0 + r2 + 1] - base_al;
     double s = 0.0;
     for (int k = a0; k < a1; k++) s += prod[k];
@@ -719,8 +724,8 @@ __global__ __launch_bounds__(256) void gs_dense_k(int n, int chunk0, int nchunks
 // products out of LDS, picks its in-chunk coefficients by the code bits of the
 // 16-bit column entries, and runs the dense 8x8 sweep of gs_dense_k.
 // ---------------------------------------------------------------------------
-template <bool VAL8>
-__global__ __launch_bounds__(SPMV_BLOCK) void gs_tile_k(int blk0, int nblk, const int *__restrict__ tdesc,
+template <bool VAL8, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void gs_tile_k(int blk0, int nblk, const int *__restrict__ tdesc,
                                                         const int *__restrict__ ia, const double *__restrict__ av,
                                                         const int *__restrict__ ucols,
                                                         const unsigned short *__restrict__ lcol,
@@ -735,15 +740,16 @@ __global__ __launch_bounds__(SPMV_BLOCK) void gs_tile_k(int blk0, int nblk, cons
                                                         const unsigned char *__restrict__ vidx,
                                                         const double *__restrict__ vlut) {
 #define UOLD(j) (((j) < split ? u_lo : u_hi)[(j)])
-  __shared__ double buf[SPMV_TILE];           // x cache, then products / in-chunk coefficients
-  __shared__ unsigned short code[SPMV_TILE];  // the entries' lcol words
+  constexpr int TILE = 8 * BLOCK;        // TILE / TILE_WIDE
+  __shared__ double buf[TILE];           // x cache, then products / in-chunk coefficients
+  __shared__ unsigned short code[TILE];  // the entries' lcol words
   // value dictionary (see spmv_stream_xc): lives in the first 2 KB of `code`, which is only written after the last
   // lookup (second barrier) -- no LDS beyond the 20 KB that allow 8 workgroups per CU
   double *slut = reinterpret_cast<double *>(code);
   if ((int)blockIdx.x >= nblk) return;
   const int blk = blk0 + blockIdx.x;
   const int tid = threadIdx.x;
-  if (VAL8) slut[tid] = vlut[tid];
+  if (VAL8 && tid < 256) slut[tid] = vlut[tid];
   // one descriptor load, then the loads in the order of their dependent chains (see spmv_stream_xc): column
   // list, matrix stream, per-row data; the gathers start when the column ids are back
   const int4 d0 = reinterpret_cast<const int4 *>(tdesc)[2 * blk];
@@ -752,24 +758,24 @@ __global__ __launch_bounds__(SPMV_BLOCK) void gs_tile_k(int blk0, int nblk, cons
   // columns >= zero_from hold zeros by contract (first sweep on a zero guess): nothing to gather there --
   // the unique columns ascend, so for zero_from == 0 not even the ids are read
   const bool all_zero = zero_from <= 0;
-  constexpr int NU = SPMV_TILE / SPMV_BLOCK;
+  constexpr int NU = TILE / BLOCK;
   int ucid[NU];
   if (!all_zero) {
 #pragma unroll
     for (int q = 0; q < NU; q++) {
-      const int k = tid + q * SPMV_BLOCK;
+      const int k = tid + q * BLOCK;
       ucid[q] = (k < nu) ? ucols[u0 + k] : 0;
     }
   }
   const int base_al = base & ~1;
   const int cnt = end - base_al;
-  constexpr int NIT = SPMV_TILE / (2 * SPMV_BLOCK);
+  constexpr int NIT = TILE / (2 * BLOCK);
   d2_t vv[NIT];
   us2_t cc[NIT];
   uc2_t vi[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; it++) {
-    const int k = 2 * tid + it * 2 * SPMV_BLOCK;
+    const int k = 2 * tid + it * 2 * BLOCK;
     if (k < cnt) {
       if (VAL8)
         vi[it] = *reinterpret_cast<const uc2_t *>(vidx + base_al + k);
@@ -781,7 +787,7 @@ __global__ __launch_bounds__(SPMV_BLOCK) void gs_tile_k(int blk0, int nblk, cons
   // LPR lanes per row, as many as this tile's row count leaves room for (uniform in the workgroup);
   // 8 * LPR consecutive lanes = one chunk; all lanes of a row carry its state, the first one writes it back
   const int nr = r1 - r0;
-  const int LPR = nr <= 32 ? 8 : nr <= 64 ? 4 : nr <= 128 ? 2 : 1;
+  const int LPR = nr <= BLOCK / 8 ? 8 : nr <= BLOCK / 4 ? 4 : nr <= BLOCK / 2 ? 2 : 1;
   const int rl = tid / LPR, sub = tid % LPR;
   const int i = r0 + rl;
   double myu = 0.0, myrhs = 0.0, wd = 0.0;
@@ -803,7 +809,7 @@ __global__ __launch_bounds__(SPMV_BLOCK) void gs_tile_k(int blk0, int nblk, cons
   if (!all_zero) {
 #pragma unroll
     for (int q = 0; q < NU; q++) {
-      const int k = tid + q * SPMV_BLOCK;
+      const int k = tid + q * BLOCK;
       if (k < nu) {
         const int j = ucid[q];
         buf[k] = (j >= zero_from) ? 0.0 : UOLD(j);
@@ -813,7 +819,7 @@ __global__ __launch_bounds__(SPMV_BLOCK) void gs_tile_k(int blk0, int nblk, cons
   __syncthreads();
 #pragma unroll
   for (int it = 0; it < NIT; it++) {
-    const int k = 2 * tid + it * 2 * SPMV_BLOCK;
+    const int k = 2 * tid + it * 2 * BLOCK;
     if (k < cnt) {
       const bool ok0 = (base_al + k >= base);
       const bool ok1 = (base_al + k + 1 < end);
@@ -831,7 +837,7 @@ __global__ __launch_bounds__(SPMV_BLOCK) void gs_tile_k(int blk0, int nblk, cons
   __syncthreads();  // every x-cache read is done
 #pragma unroll
   for (int it = 0; it < NIT; it++) {
-    const int k = 2 * tid + it * 2 * SPMV_BLOCK;
+    const int k = 2 * tid + it * 2 * BLOCK;
     if (k < cnt) {
       buf[k] = vv[it].x;
       buf[k + 1] = vv[it].y;
@@ -846,7 +852,7 @@ __global__ __launch_bounds__(SPMV_BLOCK) void gs_tile_k(int blk0, int nblk, cons
   // run starts and which offsets occur; the coefficients are then read straight from the product buffer.
   double S = 0.0;
   unsigned inmask = 0;
-  int kin = SPMV_TILE;
+  int kin = TILE;
   if (rowsel) {
     for (int k = s0 + sub; k < s1; k += LPR) {
       const unsigned c = code[k];
@@ -1171,7 +1177,12 @@ inline int vec_grid(int n) {
 // Tiles of the SpMV / tile Gauss-Seidel kernels: <= 256 rows and < SPMV_TILE entries.  Whenever no 8-row
 // chunk exceeds a tile the blocks begin and end on multiples of 8 rows (the hybrid-GS chunks), which the
 // tile Gauss-Seidel kernel needs; *chunk_aligned says whether that held for the whole matrix.
-std::vector<int> build_row_blocks(int nrows, const int64_t *ia, bool *chunk_aligned, int row_cap) {
+int choose_tile_entries(int64_t nnz, int nrows) {
+  static const double wide_min = getenv("MI_HYPRE_WIDE_TILE_MIN_ROWLEN") ? atof(getenv("MI_HYPRE_WIDE_TILE_MIN_ROWLEN")) : 100.0;
+  return (nrows > 0 && wide_min > 0.0 && (double)nnz / (double)nrows >= wide_min) ? SPMV_TILE_WIDE : SPMV_TILE;
+}
+
+std::vector<int> build_row_blocks(int nrows, const int64_t *ia, bool *chunk_aligned, int row_cap, int tile_entries) {
   if (row_cap < SPMV_BLOCK) row_cap = SPMV_BLOCK;
   std::vector<int> rb;
   rb.reserve((size_t)nrows / 200 + 2);
@@ -1184,14 +1195,14 @@ std::vector<int> build_row_blocks(int nrows, const int64_t *ia, bool *chunk_alig
     if ((r & 7) == 0 && row_cap <= SPMV_BLOCK) {  // whole chunks while they fit (SpMV-only operators: any row)
       while (e < nrows && e - r < row_cap) {
         const int e2 = std::min(nrows, e + 8);
-        if (ia[e2] - start > SPMV_TILE - 1) break;
+        if (ia[e2] - start > tile_entries - 1) break;
         e = e2;
       }
     }
     if (e == r) {  // not even one chunk fits (or an unaligned start after such a chunk): row granularity
       aligned = false;
       // keep one slot of slack for the aligned-pair start
-      while (e < nrows && e - r < row_cap && ia[e + 1] - start <= SPMV_TILE - 1) e++;
+      while (e < nrows && e - r < row_cap && ia[e + 1] - start <= tile_entries - 1) e++;
       if (e == r) e = r + 1;  // a single row longer than the tile
     }
     rb.push_back(e);
@@ -1238,9 +1249,26 @@ static void launch_stream(int epi, const DevCSR &A, const double *x, double *y, 
   const int nb = A.nblocks;
   const int xchunk = (nb + 7) / 8;
   const dim3 grid(xchunk * 8), block(SPMV_BLOCK);
-  if (A.xcache) {
+  if (A.xcache && A.tile_entries == SPMV_TILE_WIDE) {
+    const dim3 wide(SPMV_BLOCK_WIDE);
+#define XC_LAUNCH_W(EPI_, V8_)                                                                                       \
+  hipLaunchKernelGGL((spmv_stream_xc<EPI_, 0, V8_, SPMV_BLOCK_WIDE>), grid, wide, 0, s, nb, xchunk, A.tdesc.p, A.ia.p, \
+                     A.ja.p, A.a.p, A.ucols.p, A.lcol.p, x, y, e, A.vidx.p, A.vlut.p)
+    if (A.val8) {
+      if (epi == 0)
+        XC_LAUNCH_W(0, true);
+      else
+        XC_LAUNCH_W(1, true);
+    } else {
+      if (epi == 0)
+        XC_LAUNCH_W(0, false);
+      else
+        XC_LAUNCH_W(1, false);
+    }
+#undef XC_LAUNCH_W
+  } else if (A.xcache) {
 #define XC_LAUNCH(EPI_, TAG_, V8_)                                                                                  \
-  hipLaunchKernelGGL((spmv_stream_xc<EPI_, TAG_, V8_>), grid, block, 0, s, nb, xchunk, A.tdesc.p, A.ia.p, A.ja.p, \
+  hipLaunchKernelGGL((spmv_stream_xc<EPI_, TAG_, V8_, SPMV_BLOCK>), grid, block, 0, s, nb, xchunk, A.tdesc.p, A.ia.p, A.ja.p, \
                      A.a.p, A.ucols.p, A.lcol.p, x, y, e, A.vidx.p, A.vlut.p)
     if (A.val8) {
       if (epi == 0 && level0)
@@ -1406,14 +1434,21 @@ void gs_hybrid(const DevCSR &A, const double *u_lo, const double *u_hi, int spli
     const int first_row = (int)(c0 * 8), last_row = (int)std::min<long long>(c1 * 8, A.nrows);
     const int b0 = (int)(std::upper_bound(rbh.begin(), rbh.end(), first_row) - rbh.begin()) - 1;
     const int b1 = (int)(std::lower_bound(rbh.begin(), rbh.end(), last_row) - rbh.begin());
-    if (b1 > b0 && A.val8)
-      hipLaunchKernelGGL(gs_tile_k<true>, dim3((unsigned)(b1 - b0)), dim3(SPMV_BLOCK), 0, s, b0, b1 - b0, A.tdesc.p,
-                         A.ia.p, A.a.p, A.ucols.p, A.lcol.p, cf, points, d, f, offc, u_lo, u_hi, split, out,
-                         fwd ? 1 : 0, bwd ? 1 : 0, w, first_row, last_row, zero_from, tout, t_from, A.vidx.p, A.vlut.p);
+#define GS_TILE_LAUNCH(V8_, BLOCK_)                                                                                  \
+  hipLaunchKernelGGL((gs_tile_k<V8_, BLOCK_>), dim3((unsigned)(b1 - b0)), dim3(BLOCK_), 0, s, b0, b1 - b0, A.tdesc.p, \
+                     A.ia.p, A.a.p, A.ucols.p, A.lcol.p, cf, points, d, f, offc, u_lo, u_hi, split, out, fwd ? 1 : 0,  \
+                     bwd ? 1 : 0, w, first_row, last_row, zero_from, tout, t_from, V8_ ? A.vidx.p : nullptr,          \
+                     V8_ ? A.vlut.p : nullptr)
+    const bool wide = A.tile_entries == SPMV_TILE_WIDE;
+    if (b1 > b0 && A.val8 && wide)
+      GS_TILE_LAUNCH(true, SPMV_BLOCK_WIDE);
+    else if (b1 > b0 && A.val8)
+      GS_TILE_LAUNCH(true, SPMV_BLOCK);
+    else if (b1 > b0 && wide)
+      GS_TILE_LAUNCH(false, SPMV_BLOCK_WIDE);
     else if (b1 > b0)
-      hipLaunchKernelGGL(gs_tile_k<false>, dim3((unsigned)(b1 - b0)), dim3(SPMV_BLOCK), 0, s, b0, b1 - b0, A.tdesc.p,
-                         A.ia.p, A.a.p, A.ucols.p, A.lcol.p, cf, points, d, f, offc, u_lo, u_hi, split, out,
-                         fwd ? 1 : 0, bwd ? 1 : 0, w, first_row, last_row, zero_from, tout, t_from, nullptr, nullptr);
+      GS_TILE_LAUNCH(false, SPMV_BLOCK);
+#undef GS_TILE_LAUNCH
   } else if (chunk == 8 && !gs_force_generic()) {
     const double avg = (double)A.nnz / (double)A.nrows;
     const int p95 = A.rowlen_p95;

@@ -8,6 +8,13 @@ namespace k {
 
 constexpr int SPMV_BLOCK = 256;   // threads per workgroup (4 wave64)
 constexpr int SPMV_TILE = 2048;   // LDS-staged products per workgroup
+// Operators with long rows (coarse Galerkin levels with 100-150 entries per row) get tiles of twice the entries,
+// run by twice the threads (same work per thread, 32 / 40 KB of LDS = still 32 waves per CU): an 8-row chunk of such
+// rows holds 800-1500 entries, so 2048-entry tiles close after one or two chunks, 2/3 full, and share few columns.
+// 512^3: level 3 / 4 / 5 relaxation 1.35 / 0.47 / 0.126 -> 1.23 / 0.42 / 0.103 ms; a level with 77 entries per row
+// LOSES 6 % (its 2048-entry tiles are 90 % full already), hence the threshold
+constexpr int SPMV_BLOCK_WIDE = 512;
+constexpr int SPMV_TILE_WIDE = 4096;
 constexpr int RED_MAX_BLOCKS = 2048;
 constexpr int MASS_NV = 8;        // vectors per pass of the block inner product / block update
 constexpr int GS_BLOCK = 256;     // chunks (lanes) per workgroup
@@ -35,9 +42,11 @@ inline int prof_level(int base, int level) { return level < PROF_LEVELS ? base +
 // host: row-block schedule for spmv_stream (<= 256 rows and < SPMV_TILE entries
 // per block, or exactly one longer row)
 std::vector<int> build_row_blocks(int nrows, const int64_t *ia, bool *chunk_aligned = nullptr,
-                                  int row_cap = SPMV_BLOCK);
+                                  int row_cap = SPMV_BLOCK, int tile_entries = SPMV_TILE);
+// tile size of an operator with nnz entries in nrows rows (MI_HYPRE_WIDE_TILE_MIN_ROWLEN, default 100 entries per row; 0 = never wide)
+int choose_tile_entries(int64_t nnz, int nrows);
 constexpr int SPMV_ONLY_ROW_CAP = 4 * SPMV_BLOCK;  // rows per tile of operators no Gauss-Seidel kernel sweeps
-constexpr int XC_ID_MASK = 0x7FF;   // block-local column id inside an lcol entry (SPMV_TILE <= 2048 ids)
+constexpr int XC_ID_MASK = 0xFFF;   // block-local column id inside an lcol entry (at most SPMV_TILE_WIDE = 4096 ids)
 constexpr int XC_INCH = 0x8000;     // the column lies in the row's own 8-row chunk ...
 constexpr int XC_OFF_SHIFT = 12;    // ... at this offset (3 bits)
 

@@ -111,6 +111,7 @@ struct DevCSR {
   // 8-row chunk exceeds a tile, and every lcol entry carries the in-chunk code in its upper bits
   // (bit 15: the column lies in the row's own chunk of 8 rows, bits 12-14: which of the 8)
   bool gs_tiles = false;
+  int tile_entries = 2048;  // entries per tile: k::SPMV_TILE, or k::SPMV_TILE_WIDE for operators with long rows
   int row_cap = 0;  // rows per tile (0 = SPMV_BLOCK; set before upload / to_solve_format; more only for SpMV-only operators)
   bool prefer_gs_tiles = false;  // sweep this operator with the tile kernel whatever its mean row length
   std::vector<int> rb_host;  // host copy of rb (row ranges -> tile ranges)

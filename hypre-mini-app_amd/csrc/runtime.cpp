@@ -150,7 +150,8 @@ void DevCSR::upload(const HostCSR &h) {
     }
   }
   bool aligned = false;
-  std::vector<int> blocks = k::build_row_blocks(nrows, h.ia.data(), &aligned, row_cap);
+  tile_entries = k::choose_tile_entries(nnz, nrows);
+  std::vector<int> blocks = k::build_row_blocks(nrows, h.ia.data(), &aligned, row_cap, tile_entries);
   if (row_cap > k::SPMV_BLOCK) aligned = false;  // such tiles are not for the tile Gauss-Seidel kernel
   nblocks = (int)blocks.size() - 1;
   rb.upload(blocks);
@@ -170,7 +171,7 @@ void DevCSR::upload(const HostCSR &h) {
       std::vector<int> tmp;
       for (int64_t b = b0; b < b1; b++) {
         const int64_t s = h.ia[(size_t)blocks[(size_t)b]], e = h.ia[(size_t)blocks[(size_t)b + 1]];
-        if (e - s >= k::SPMV_TILE) continue;  // single long row: direct gathers
+        if (e - s >= tile_entries) continue;  // single long row: direct gathers
         tmp.assign(h.ja.begin() + s, h.ja.begin() + e);
         std::sort(tmp.begin(), tmp.end());
         tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());

@@ -921,10 +921,10 @@ __global__ __launch_bounds__(BLK) void rowlen_hist_k(int n, const long long *__r
 
 // x cache of one row block (spmv_stream_xc): sorted unique columns of the block's entries and the
 // block-local id of every entry.  One workgroup per block, bitonic sort in LDS.
+template <int TILE>  // k::SPMV_TILE or k::SPMV_TILE_WIDE
 __global__ __launch_bounds__(BLK) void xcache_block_k(int nb, const int *__restrict__ rb, const int *__restrict__ ia,
                                                       const int *__restrict__ ja, int *__restrict__ ucnt,
                                                       int *__restrict__ uslack, unsigned short *__restrict__ lcol) {
-  constexpr int TILE = k::SPMV_TILE;
   __shared__ int key[TILE];
   __shared__ int uniq[TILE];
   __shared__ int wsum[BLK];
@@ -1341,7 +1341,8 @@ void to_solve_format(DCsr &src, DevCSR &dst, hipStream_t s) {
   MI_HIP(hipMemcpyAsync(hia.data(), src.ia.p, ((size_t)n + 1) * sizeof(long long), hipMemcpyDeviceToHost, s));
   MI_HIP(hipStreamSynchronize(s));
   bool aligned = false;
-  std::vector<int> blocks = k::build_row_blocks(n, hia.data(), &aligned, dst.row_cap);
+  dst.tile_entries = k::choose_tile_entries(dst.nnz, n);
+  std::vector<int> blocks = k::build_row_blocks(n, hia.data(), &aligned, dst.row_cap, dst.tile_entries);
   if (dst.row_cap > k::SPMV_BLOCK) aligned = false;  // such tiles are not for the tile Gauss-Seidel kernel
   std::vector<int64_t>().swap(hia);
   dst.nblocks = (int)blocks.size() - 1;
@@ -1359,7 +1360,10 @@ void to_solve_format(DCsr &src, DevCSR &dst, hipStream_t s) {
     DVec<int> ucnt((size_t)nb), uslack((size_t)dst.nnz);
     dst.lcol.alloc((size_t)dst.nnz);
     MI_HIP(hipMemsetAsync(dst.lcol.p, 0, (size_t)dst.nnz * sizeof(unsigned short), s));
-    xcache_block_k<<<(unsigned)nb, BLK, 0, s>>>(nb, dst.rb.p, dst.ia.p, dst.ja.p, ucnt.p, uslack.p, dst.lcol.p);
+    if (dst.tile_entries == k::SPMV_TILE_WIDE)
+      xcache_block_k<k::SPMV_TILE_WIDE><<<(unsigned)nb, BLK, 0, s>>>(nb, dst.rb.p, dst.ia.p, dst.ja.p, ucnt.p, uslack.p, dst.lcol.p);
+    else
+      xcache_block_k<k::SPMV_TILE><<<(unsigned)nb, BLK, 0, s>>>(nb, dst.rb.p, dst.ia.p, dst.ja.p, ucnt.p, uslack.p, dst.lcol.p);
     DVec<long long> uptr64((size_t)nb + 1);
     exclusive_scan(ucnt.p, uptr64.p, nb, s);
     long long tot = 0;
