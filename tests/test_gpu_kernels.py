@@ -40,7 +40,9 @@ def _ij_from_scipy(mi, M):
 
 
 @pytest.mark.parametrize("n,density,longrow", [(1, 1.0, None), (7, 0.5, None), (1000, 0.01, None),
-                                                (5000, 0.002, (17, 3000)), (20000, 0.0005, None)])
+                                                (5000, 0.002, (17, 3000)), (20000, 0.0005, None),
+                                                # >= 100 entries per row: the 4096-entry tiles run by 512 threads
+                                                (3000, 0.05, None), (2500, 0.06, (40, 2400)), (1500, 0.3, None)])
 def test_spmv_vs_oracle(mi, oc, n, density, longrow):
     M = _rand_dd_matrix(n, density, 1234 + n, longrow)
     A = _ij_from_scipy(mi, M)
