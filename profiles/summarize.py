@@ -46,7 +46,7 @@ def stats(src, out):
         f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu\n")
         f.write("#   (laplace_3d 512^3 7-pt, GMRES(50)+BoomerAMG, 1x MI355X; setup kernels + 3 solves in the trace)\n")
         f.write("# per (kernel, grid size) = per AMG level: calls, mean us, total ms, share of GPU time\n")
-        f.write("# spmv_stream_xc<0, 1, .> = the level-0 operator of the GMRES loop (C-first ordering of level 0): the kernel bench.py reports as \"roofline\"\n")
+        f.write("# spmv_stream_xc<0, 1, ., 256> = the level-0 operator of the GMRES loop (C-first ordering of level 0): the kernel bench.py reports as \"roofline\"\n")
         for (name, grid), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             if us / total < 2e-4:
                 continue
@@ -92,7 +92,7 @@ def pmc(fetch_dir, write_dir, out):
         "write_size_bytes": write,
         "kernel": key[0],
         "note": "FETCH_SIZE doubled per the gfx950 correction; separate --pmc passes; see profiles/%s_pmc512_fetch_write.txt. "
-                "A kernel name ending in <.., true> streams one-byte dictionary indices instead of 8-byte values (DESIGN.md "
+                "A kernel whose third template argument is true (spmv_stream_xc<EPI, TAG, VAL8, threads>) streams one-byte dictionary indices instead of 8-byte values (DESIGN.md "
                 "section 5): its traffic can be BELOW the algorithmic 12 nnz + 20 N, which prices 8-byte values" % tag}}
     path = os.path.join(os.path.dirname(out), "traffic_%s.json" % tag)
     json.dump(js, open(path, "w"), indent=1)
