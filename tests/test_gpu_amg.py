@@ -130,6 +130,53 @@ def test_relax_irregular_rows(mi, oc, density, longrow):
             assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("coarsen", [8, 6, 0])
+def test_gmres_amg_with_dirichlet_rows(mi, oc, coarsen):
+    """Identity rows (Dirichlet boundary values kept in the system, as application matrices have them) in a 3-D
+    convection-diffusion operator: points without strong connections through setup, cycle and GMRES."""
+    import scipy.sparse as sp
+
+    n = 14
+    N = n ** 3
+    T = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(n, n))
+    Cx = sp.diags([-0.4, 0.4], [-1, 0], shape=(n, n))
+    I = sp.identity(n)
+    M = (sp.kron(sp.kron(I, I), T + Cx) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(T, I), I)).tolil()
+    rng = np.random.default_rng(77)
+    fixed = np.sort(rng.choice(N, size=N // 9, replace=False))
+    for i in fixed:
+        M.rows[i] = [int(i)]
+        M.data[i] = [1.0]
+    M = M.tocsr()
+    M.sort_indices()
+    xs = rng.standard_normal(N)
+    bv = M @ xs
+    A = mi.IJMatrix(0, N - 1)
+    coo = M.tocoo()
+    A.set_values_coo(coo.row.astype(np.int64), coo.col.astype(np.int64), coo.data)
+    A.assemble()
+    b = mi.IJVector(0, N - 1, bv)
+    x = mi.IJVector(0, N - 1, np.zeros(N))
+    amg = mi.BoomerAMG(print_level=0, coarsen_type=coarsen)
+    gm = mi.GMRES(tolerance=1e-9, max_iterations=100, kspace=40, print_level=0)
+    gm.set_precond(amg)
+    gm.setup(A, b, x)
+    assert gm.solve(A, b, x) == 0
+    Ao = oc.Csr.from_scipy(M)
+    oamg = oc.Amg(Ao, oc.default_params(gs_chunk=_chunk(mi), coarsen_type=coarsen))
+    assert amg.num_levels == oamg.num_levels
+    cf = oamg.level_cf(0)  # in the level's C-first order
+    assert np.array_equal(amg.level_cf(0), cf)
+    if coarsen == 8:  # PMIS: a row without strong connections is a "special" F point, never a C point
+        cf_nat = np.empty_like(cf)
+        cf_nat[oamg.level_perm(0)] = cf
+        assert np.all(cf_nat[fixed] != 1)
+    xo, info = oc.gmres(Ao, bv, kdim=40, tol=1e-9, maxit=100, amg=oamg)
+    assert gm.num_iterations == info["iters"]
+    assert np.allclose(gm.residual_history(), info["norms"], rtol=1e-8, atol=1e-14 * info["norms"][0])
+    assert _allclose_ref(x.get(), xs, rtol=1e-5, atol=1e-7)
+
+
 @pytest.mark.parametrize("chunk", [1, 4, 16])
 def test_relax_other_chunk_sizes(mi, oc, chunk):
     """Chunk sizes other than 8 take the generic lane-per-chunk kernel."""
