@@ -768,11 +768,33 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
       }
       std::vector<HRow>().swap(H);
       lap("interp: extended sub-problem");
-      ParCSR Aw;
-      as_single_rank(std::move(Ae), Aw);
       HostCSR Pe;
       int nce = 0;
-      build_interp(Aw, Se, cfe, p.interp_type, p.trunc_factor, p.pmax_elmts, Pe, nce, &want);
+      bool p_on_device = false;
+      if (device_min_rows >= 0 && ne >= device_min_rows && ctx().inited && (p.interp_type == 6 || p.interp_type == 0)) {
+        // the device routine of the single-rank setup (bit-identical rows, tests/test_gpu_setup_kernels.py) on the
+        // extended sub-problem; it computes every row, the rows that are not wanted (halo rows, whose own
+        // neighbourhood is incomplete here) are simply not read below
+        hipStream_t st = ctx().stream;
+        sk::DCsr dA, dS, dP;
+        dA.upload(Ae, st);
+        dS.nrows = dS.ncols = ne;
+        dS.nnz = (int64_t)Se.ja.size();
+        dS.ia.alloc((size_t)ne + 1);
+        dS.ja.alloc(Se.ja.size());
+        MI_HIP(hipMemcpyAsync(dS.ia.p, Se.ia.data(), ((size_t)ne + 1) * sizeof(long long), hipMemcpyHostToDevice, st));
+        if (!Se.ja.empty())
+          MI_HIP(hipMemcpyAsync(dS.ja.p, Se.ja.data(), Se.ja.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        DVec<int> dcf;
+        dcf.upload(cfe);
+        p_on_device = sk::interp(dA, dS, dcf, p.interp_type, p.trunc_factor, p.pmax_elmts, dP, nce, st);
+        if (p_on_device) dP.download(Pe, st);
+      }
+      if (!p_on_device) {
+        ParCSR Aw;
+        as_single_rank(std::move(Ae), Aw);
+        build_interp(Aw, Se, cfe, p.interp_type, p.trunc_factor, p.pmax_elmts, Pe, nce, &want);
+      }
       lap("interp: build_interp");
       // extended coarse index -> global coarse id (both ascend with the fine id)
       std::vector<gidx> cmap((size_t)nce);
