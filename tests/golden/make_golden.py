@@ -34,6 +34,17 @@ CASES = [
     dict(name="lap7_12_bicgstab", n=12, stencil=7, kdim=50, tol=1e-8, nparts=1, method="bicgstab"),
     dict(name="lap7_10_ilu", n=10, stencil=7, kdim=50, tol=1e-8, nparts=1, method="gmres_ilu"),
     dict(name="lap7_14_p3_seq", n=14, stencil=7, kdim=50, tol=1e-8, nparts=3, redundant_rows=300),
+    # the other BoomerAMG choices (round 2): the upstream sample's block (/root/reference/etc/hypre_app.yaml:33-42),
+    # HMIS, CLJP, aggressive coarsening, multipass interpolation, the ILU complex smoother, two-stage Gauss-Seidel
+    dict(name="lap7_12_falgout_sgs", n=12, stencil=7, kdim=50, tol=1e-8, nparts=1,
+         amg=dict(coarsen_type=6, relax_type=6, num_sweeps=2, interp_type=0)),
+    dict(name="lap7_12_hmis", n=12, stencil=7, kdim=50, tol=1e-8, nparts=1, amg=dict(coarsen_type=10)),
+    dict(name="lap7_12_cljp", n=12, stencil=7, kdim=50, tol=1e-8, nparts=1, amg=dict(coarsen_type=0)),
+    dict(name="lap7_12_agg1", n=12, stencil=7, kdim=50, tol=1e-8, nparts=1, amg=dict(agg_num_levels=1)),
+    dict(name="lap7_12_multipass", n=12, stencil=7, kdim=50, tol=1e-8, nparts=1, amg=dict(interp_type=4)),
+    dict(name="lap7_12_ilu_smoother", n=12, stencil=7, kdim=50, tol=1e-8, nparts=1,
+         amg=dict(smooth_type=5, smooth_num_levels=2)),
+    dict(name="lap7_12_two_stage_gs", n=12, stencil=7, kdim=50, tol=1e-8, nparts=1, amg=dict(relax_type=11, relax_order=0)),
 ]
 
 
@@ -47,6 +58,7 @@ def run_case(c):
         kw["part_starts"] = [per * r + min(r, rem) for r in range(c["nparts"])] + [N]
     if "redundant_rows" in c:
         kw["redundant_rows"] = c["redundant_rows"]
+    kw.update(c.get("amg", {}))
     amg = oc.Amg(A, oc.default_params(**kw))
     method = c.get("method", "gmres")
     if method == "gmres":
@@ -68,9 +80,14 @@ def run_case(c):
 
 
 def main():
+    only = set(sys.argv[1:])  # optional: names of the fixtures to (re)generate
     for c in CASES:
+        if only and c["name"] not in only:
+            continue
         np.savez_compressed(os.path.join(HERE, c["name"] + ".npz"), **run_case(c))
         print("wrote", c["name"])
+    if only:
+        return
     # independent direct-solve fixture: random M-matrix, scipy spsolve
     rng = np.random.default_rng(20260101)
     n = 400

@@ -27,6 +27,15 @@ CASES = {
     "lap7_12_pcg": dict(n=12, stencil=7, kdim=50, tol=1e-8, method="pcg"),
     "lap7_12_bicgstab": dict(n=12, stencil=7, kdim=50, tol=1e-8, method="bicgstab"),
     "lap7_10_ilu": dict(n=10, stencil=7, kdim=50, tol=1e-8, method="gmres_ilu"),
+    "lap7_12_falgout_sgs": dict(n=12, stencil=7, kdim=50, tol=1e-8, method="gmres",
+                                amg=dict(coarsen_type=6, relax_type=6, num_sweeps=2, interp_type=0)),
+    "lap7_12_hmis": dict(n=12, stencil=7, kdim=50, tol=1e-8, method="gmres", amg=dict(coarsen_type=10)),
+    "lap7_12_cljp": dict(n=12, stencil=7, kdim=50, tol=1e-8, method="gmres", amg=dict(coarsen_type=0)),
+    "lap7_12_agg1": dict(n=12, stencil=7, kdim=50, tol=1e-8, method="gmres", amg=dict(agg_num_levels=1)),
+    "lap7_12_multipass": dict(n=12, stencil=7, kdim=50, tol=1e-8, method="gmres", amg=dict(interp_type=4)),
+    "lap7_12_ilu_smoother": dict(n=12, stencil=7, kdim=50, tol=1e-8, method="gmres",
+                                 amg=dict(smooth_type=5, smooth_num_levels=2)),
+    "lap7_12_two_stage_gs": dict(n=12, stencil=7, kdim=50, tol=1e-8, method="gmres", amg=dict(relax_type=11, relax_order=0)),
 }
 
 
@@ -51,7 +60,7 @@ def test_fixture(mi, name):
     assert chunk.value == 8  # the fixtures were made with 8-row hybrid-GS chunks
     A, b, x, rhs = mi.build_laplace_system(n, n, n, c["stencil"])
     assert np.array_equal(b.get(), g["rhs"])
-    amg = mi.BoomerAMG(print_level=0)
+    amg = mi.BoomerAMG(print_level=0, **c.get("amg", {}))
     method = c["method"]
     if method == "gmres_ilu":
         amg.setup(A)  # hierarchy shape only
