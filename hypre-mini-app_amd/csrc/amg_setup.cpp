@@ -1981,6 +1981,10 @@ void BoomerAMG::build_replicated(ParCSR &A0) {
   g.stop_rows = effective_redundant_rows();
   g.use_private_self_comm();
   g.build_natural(*Ag);
+  // a level below the threshold is redundant also when the coarsening ended on it (it is then the coarsest
+  // level, and its smoother -- if it is not the dense solve -- must not stop at rank boundaries either)
+  if (!g.stopped_by_rows && g.stop_rows > 0 && g.L.size() >= 2 && g.L.back().A->global_rows() <= g.stop_rows)
+    g.stopped_by_rows = true;
   const bool has_tail = g.stopped_by_rows && g.L.size() >= 2;
   if (g.L[0].sA.ia.p && g.L[0].sA.nrows == (int)N) {  // level 0 lives on the device: drop the host copy
     HostCSR &G0 = Ag->diag;

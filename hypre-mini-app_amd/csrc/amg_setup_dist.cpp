@@ -1095,6 +1095,8 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
     t_phase[3] += wall_time() - tp0;
     l++;
   }
+  // a level below the threshold is redundant also when the coarsening ended on it (see build_replicated)
+  if (!has_tail && red_rows > 0 && D.size() >= 2 && D.back().starts.back() <= red_rows) has_tail = true;
   const size_t nlev = D.size();
 
   // ---- C-first ordering of every level with a splitting, and the final ParCSR blocks

@@ -56,6 +56,8 @@ def main():
                     help="1: force the per-rank internal locality numbering (MI_HYPRE_LOCALITY_ORDER=1); the oracle then "
                          "works on the globally permuted system")
     ap.add_argument("--relax", type=int, default=0, help="relax_type of the down / up sweeps (0 = library default)")
+    ap.add_argument("--combo", type=int, default=-1,
+                    help="seed of a combination of BoomerAMG choices (tests/test_gpu_amg.py::_combo) applied to both sides")
     ap.add_argument("--smooth", type=int, default=0,
                     help="levels with the ILU complex smoother (smooth_type 5): block-Jacobi ILU(0) per rank")
     args = ap.parse_args()
@@ -82,6 +84,11 @@ def main():
     smooth_o = dict(smooth_type=5, smooth_num_levels=args.smooth) if args.smooth else {}
     if args.relax:
         smooth_o["relax_type"] = args.relax
+    if args.combo >= 0:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from test_gpu_amg import _combo
+
+        smooth_o.update(_combo(args.combo))
     oamg = oc.Amg(Ao, oc.default_params(gs_chunk=chunk.value, part_starts=starts, redundant_rows=seq, **smooth_o))
 
     if args.mode == "host":
@@ -141,6 +148,9 @@ def main():
         return v.value
 
     replicated = os.environ.get("MI_HYPRE_REPLICATED_SETUP", "0") not in ("", "0")
+    # everything but plain PMIS with ext+i / classical / direct interpolation is built by the replicated setup
+    if smooth_o.get("coarsen_type", 8) not in (8, 9) or smooth_o.get("agg_num_levels", 0) > 0 or smooth_o.get("interp_type", 6) == 4:
+        replicated = True
     if size > 1 and not replicated:
         assert counter("setup_distributed") >= 1, "the distributed setup did not run"
         # per-rank memory: the largest extended sub-problem is this rank's rows plus two halo rings (for z-slabs of
@@ -166,13 +176,15 @@ def main():
     for l in range(amg.num_levels):
         OA = oamg.level_A(l).to_scipy()
         ps = oamg.level_part_starts(l)
-        redundant = size > 1 and l >= 1 and ps[1] == ps[-1]  # the oracle keeps a redundant level whole in part 0
+        # the oracle keeps a redundant level whole in part 0 (a small level whose C points all belong to rank 0 looks
+        # the same but is distributed: the row threshold tells them apart)
+        redundant = size > 1 and l >= 1 and ps[1] == ps[-1] and 0 < OA.shape[0] <= seq
         last = l == amg.num_levels - 1
         if redundant:
             # every rank holds the whole level in the single-part C-first ordering
             n_redundant += 1
             ia, ja, a, shape = amg.level_csr(l, 0)
-            assert shape == OA.shape and amg.level_csr(l, 1)[3][1] == 0
+            assert shape == OA.shape and amg.level_csr(l, 1)[3][1] == 0, (l, rank, shape, OA.shape, amg.level_csr(l, 1)[3])
             assert same_matrix(sp.csr_matrix((a, ja, ia), shape=shape), OA, 1e-12), (l, rank)
             if not last:
                 assert np.array_equal(amg.level_cf(l), oamg.level_cf(l)), (l, rank)
@@ -236,8 +248,9 @@ def main():
             # halo updates per cycle and distributed level: <= 2 sweeps x 2 passes + residual + restriction +
             # prolongation (the first pass of the down leg starts from zero and exchanges nothing); + 1 GMRES matvec
             per_cycle = (c1["halo_exchange"] - c0["halo_exchange"]) / cycles
-            assert per_cycle <= 7 * n_dist + 2, (per_cycle, n_dist)
-            assert (c1["allgather"] - c0["allgather"]) <= cycles  # coarsest gather or redundant tail: one per cycle
+            if args.combo < 0 and not args.smooth and not args.relax:  # (the counts below are those of a V(1,1) cycle)
+                assert per_cycle <= 7 * n_dist + 2, (per_cycle, n_dist)
+                assert (c1["allgather"] - c0["allgather"]) <= cycles  # coarsest gather or redundant tail: one per cycle
             # COGMRES (method: cogmres, src/HypreSystem.cpp:372-388): one block all-reduce + the norm per step
             x.fill(0.0)
             cg = mi.COGMRES(tolerance=1e-8, max_iterations=60, kspace=20, print_level=0)
@@ -300,7 +313,7 @@ def main():
             cnt[name] = v.value
         if size > 1 and os.environ.get("MI_HYPRE_OVERLAP_HALO", "1") != "0":
             assert cnt["matvec_overlapped"] > 0, cnt
-            no_gs = bool(args.smooth) or args.relax in (11, 12, 7, 18)
+            no_gs = bool(args.smooth) or args.relax in (11, 12, 7, 18) or args.combo >= 0
             if not no_gs:  # (the ILU complex smoother and the two-stage / Jacobi smoothers run no Gauss-Seidel passes)
                 assert cnt["gs_overlapped"] + cnt["gs_in_order"] > 0, cnt
             if size == 2 and n >= 12 and not no_gs:  # slabs of >= 6 planes with one neighbour: most rows are halo-free

@@ -18,7 +18,7 @@ WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
 
 
 def _run(nproc, mode, n, stencil, port, staging="host", seq=-1, devmin=None, golden="", replicated=False, locality=0,
-         smooth=0, relax=0):
+         smooth=0, relax=0, combo=-1):
     env = dict(os.environ)
     env["MI_HYPRE_REPLICATED_SETUP"] = "1" if replicated else "0"
     if devmin is not None:  # levels with at least this many rows are built (and sliced) on the device
@@ -38,6 +38,8 @@ def _run(nproc, mode, n, stencil, port, staging="host", seq=-1, devmin=None, gol
         cmd += ["--smooth", str(smooth)]
     if relax:
         cmd += ["--relax", str(relax)]
+    if combo >= 0:
+        cmd += ["--combo", str(combo)]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-4000:]
     return p.stdout
@@ -67,6 +69,15 @@ def test_host_setup_replicated_path_gloo(nproc, n, stencil, seq):
     """The replicated setup (every rank builds the global hierarchy and keeps its slices) stays the path of the
     Ruge-Stueben family and of aggressive coarsening on N > 1; MI_HYPRE_REPLICATED_SETUP=1 forces it."""
     out = _run(nproc, "host", n, stencil, 29911 + nproc + n, seq=seq, replicated=True)
+    assert "dist host setup ok" in out
+
+
+@pytest.mark.parametrize("nproc,n,seq,combo", [(2, 14, 300, 1), (3, 12, 100, 15), (2, 14, 0, 17), (2, 12, 150, 11)])
+def test_host_setup_parameter_combinations_gloo(nproc, n, seq, combo):
+    """Seeded combinations of the BoomerAMG choices on N ranks (host half): Ruge-Stueben / CLJP coarsening, aggressive
+    levels that reach into the redundant tail, multipass interpolation; a coarsest level below the redundancy
+    threshold is held whole by every rank, as in the oracle's emulation."""
+    out = _run(nproc, "host", n, 7, 30111 + nproc + n + combo, seq=seq, combo=combo)
     assert "dist host setup ok" in out
 
 
@@ -116,6 +127,17 @@ def test_device_solve_with_ilu_complex_smoother_shared_gpu(nproc, n, seq, smooth
 def test_device_solve_other_smoothers_shared_gpu(nproc, n, seq, relax):
     """Two-stage Gauss-Seidel (11 / 12: the lower triangle of each rank's diag block) and l1-Jacobi (18) on N ranks."""
     out = _run(nproc, "solve", n, 7, 30031 + nproc + n, seq=seq, relax=relax)
+    assert "dist solve ok" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,n,seq,combo", [(2, 14, 300, 1), (3, 12, 100, 15), (2, 14, 0, 17), (4, 12, 200, 19),
+                                                (3, 13, -1, 0), (2, 12, 150, 11)])
+def test_device_solve_parameter_combinations_shared_gpu(nproc, n, seq, combo):
+    """Seeded combinations of the BoomerAMG choices (test_gpu_amg.py::_combo: Ruge-Stueben / CLJP coarsening,
+    aggressive levels, multipass, complex smoother, W cycles ...) on N ranks: the replicated setup for everything
+    but plain PMIS, aggressive levels and smoothed levels that reach into the redundant tail."""
+    out = _run(nproc, "solve", n, 7, 30071 + nproc + n + combo, seq=seq, combo=combo)
     assert "dist solve ok" in out
 
 

@@ -551,3 +551,56 @@ def test_unimplemented_complex_smoother_is_refused(mi):
         assert "not implemented" in str(e.value)
     amg = mi.BoomerAMG(print_level=0, smooth_type=6)  # no levels: the type alone has no effect
     amg.setup(A)
+
+
+def _combo(seed):
+    """One seeded combination of the BoomerAMG choices this library implements."""
+    rng = np.random.default_rng(1000 + seed)
+    kw = dict(coarsen_type=int(rng.choice([8, 8, 10, 6, 0, 3])), interp_type=int(rng.choice([6, 6, 0, 3, 4])),
+              relax_type=int(rng.choice([8, 8, 6, 3, 13, 18, 11, 7])), cycle_type=int(rng.choice([1, 1, 2])),
+              num_sweeps=int(rng.choice([1, 1, 2])), relax_order=int(rng.choice([1, 1, 0])),
+              strong_threshold=float(rng.choice([0.25, 0.5, 0.57])))
+    if rng.random() < 0.3:
+        kw["agg_num_levels"] = int(rng.choice([1, 2]))
+    if rng.random() < 0.25:
+        kw.update(smooth_type=5, smooth_num_levels=int(rng.choice([1, 2])))
+    if rng.random() < 0.3:
+        kw["max_coarse_size"] = int(rng.choice([40, 150]))
+    return kw
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_seeded_parameter_combinations_match_oracle(mi, oc, seed):
+    """Interactions of the implemented BoomerAMG choices (coarsening x interpolation x smoother x cycle x aggressive
+    levels x complex smoother) on a non-symmetric convection-diffusion operator: hierarchy, iteration count,
+    residual history and solution against the oracle for 20 seeded combinations."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from systems import convection_diffusion_3d
+
+    kw = _combo(seed)
+    n = 13
+    M = convection_diffusion_3d(n, seed=50 + seed)
+    N = M.shape[0]
+    rng = np.random.default_rng(seed)
+    xs = rng.standard_normal(N)
+    bv = M @ xs
+    A = mi.matrix_from_scipy(M)
+    b = mi.IJVector(0, N - 1, bv)
+    x = mi.IJVector(0, N - 1, np.zeros(N))
+    amg = mi.BoomerAMG(print_level=0, **kw)
+    gm = mi.GMRES(tolerance=1e-8, max_iterations=80, kspace=30, print_level=0)
+    gm.set_precond(amg)
+    gm.setup(A, b, x)
+    rc = gm.solve(A, b, x)
+    Ao = oc.Csr.from_scipy(M)
+    oamg = oc.Amg(Ao, oc.default_params(gs_chunk=_chunk(mi), **kw))
+    xo, info = oc.gmres(Ao, bv, kdim=30, tol=1e-8, maxit=80, amg=oamg)
+    assert amg.num_levels == oamg.num_levels, kw
+    assert np.array_equal(amg.level_cf(0), oamg.level_cf(0)), kw
+    assert gm.num_iterations == info["iters"], (kw, gm.num_iterations, info["iters"])
+    assert np.allclose(gm.residual_history(), info["norms"], rtol=1e-7, atol=1e-13 * info["norms"][0]), kw
+    if info["rel_res"] <= 1e-8:
+        assert rc == 0 and _allclose_ref(x.get(), xs, rtol=1e-4, atol=1e-6), kw
