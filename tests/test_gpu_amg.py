@@ -569,7 +569,7 @@ def _combo(seed):
     return kw
 
 
-@pytest.mark.parametrize("seed", range(20))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MI_TEST_COMBOS", "20"))))
 def test_seeded_parameter_combinations_match_oracle(mi, oc, seed):
     """Interactions of the implemented BoomerAMG choices (coarsening x interpolation x smoother x cycle x aggressive
     levels x complex smoother) on a non-symmetric convection-diffusion operator: hierarchy, iteration count,
