@@ -604,3 +604,54 @@ def test_seeded_parameter_combinations_match_oracle(mi, oc, seed):
     assert np.allclose(gm.residual_history(), info["norms"], rtol=1e-7, atol=1e-13 * info["norms"][0]), kw
     if info["rel_res"] <= 1e-8:
         assert rc == 0 and _allclose_ref(x.get(), xs, rtol=1e-4, atol=1e-6), kw
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MI_TEST_RANDOM_SYSTEMS", "10"))))
+def test_seeded_random_systems_match_oracle(mi, oc, seed):
+    """Irregular graphs: seeded random M-matrices (5 to 250 entries per row -- narrow rows, rows longer than a chunk's
+    share of a tile, the wide tiles), some with identity rows, under seeded combinations of the BoomerAMG choices:
+    hierarchy, iterations, residual history and solution against the oracle."""
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.integers(400, 2600))
+    per_row = float(rng.choice([5, 12, 30, 80, 150, 250]))
+    M = sp.random(n, n, density=min(0.5, per_row / n), random_state=rng, format="csr")
+    M = (M + M.T).tocsr() if rng.random() < 0.5 else M
+    M = (M - sp.diags(M.diagonal())).tocsr()
+    M.eliminate_zeros()
+    M = (-abs(M) + sp.diags(abs(M).sum(axis=1).A1 * float(rng.choice([1.0, 1.02, 1.3])) + 1e-3)).tolil()
+    if rng.random() < 0.4:
+        for i in rng.choice(n, size=n // 12, replace=False):
+            M.rows[i] = [int(i)]
+            M.data[i] = [1.0]
+    M = M.tocsr()
+    M.sort_indices()
+    kw = _combo(500 + seed)
+    xs = rng.standard_normal(n)
+    bv = M @ xs
+    A = mi.matrix_from_scipy(M)
+    b = mi.IJVector(0, n - 1, bv)
+    x = mi.IJVector(0, n - 1, np.zeros(n))
+    amg = mi.BoomerAMG(print_level=0, **kw)
+    gm = mi.GMRES(tolerance=1e-8, max_iterations=60, kspace=30, print_level=0)
+    gm.set_precond(amg)
+    gm.setup(A, b, x)
+    rc = gm.solve(A, b, x)
+    Ao = oc.Csr.from_scipy(M)
+    oamg = oc.Amg(Ao, oc.default_params(gs_chunk=_chunk(mi), **kw))
+    xo, info = oc.gmres(Ao, bv, kdim=30, tol=1e-8, maxit=60, amg=oamg)
+    what = (seed, n, per_row, kw)
+    assert amg.num_levels == oamg.num_levels, what
+    if amg.num_levels > 1:
+        assert np.array_equal(amg.level_cf(0), oamg.level_cf(0)), what
+    assert gm.num_iterations == info["iters"], (what, gm.num_iterations, info["iters"])
+    hist, ref = np.asarray(gm.residual_history()), np.asarray(info["norms"])
+    if info["rel_res"] <= 1e-8:  # converged: the whole history, and the solution against the oracle's
+        assert rc == 0 and np.allclose(hist, ref, rtol=1e-7, atol=1e-13 * ref[0]), what
+        assert _allclose_ref(x.get(), xo, rtol=1e-5, atol=1e-7), what
+    else:
+        # nearly singular draws under a smoother that does not converge on them stagnate (seed 130: identical
+        # hierarchy, one cycle equal to 2e-14, yet the Arnoldi vectors cancel to ~1e-9 of their size and the
+        # histories part in the third step): only the start is comparable, and both sides must have stalled
+        assert np.allclose(hist[:2], ref[:2], rtol=1e-7, atol=0.0) and hist[-1] > 1e-8 * hist[0], what
