@@ -655,3 +655,58 @@ def test_seeded_random_systems_match_oracle(mi, oc, seed):
         # hierarchy, one cycle equal to 2e-14, yet the Arnoldi vectors cancel to ~1e-9 of their size and the
         # histories part in the third step): only the start is comparable, and both sides must have stalled
         assert np.allclose(hist[:2], ref[:2], rtol=1e-7, atol=0.0) and hist[-1] > 1e-8 * hist[0], what
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MI_TEST_SOLVER_COMBOS", "12"))))
+def test_seeded_solver_families_match_oracle(mi, oc, seed):
+    """The other Krylov families (src/HypreSystem.cpp:372-497: bicg, fgmres, cogmres, cg) behind seeded combinations of
+    the BoomerAMG choices, on the non-symmetric convection-diffusion operator (cg: the 7-point Laplacian)."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from systems import convection_diffusion_3d
+
+    rng = np.random.default_rng(9000 + seed)
+    method = ["bicgstab", "fgmres", "cogmres", "pcg"][seed % 4]
+    kw = _combo(800 + seed)
+    n = int(rng.integers(10, 15))
+    if method == "pcg":
+        Ao, _ = oc.Csr.laplace(n, n, n, 7)
+        M = Ao.to_scipy().tocsr()
+        kw["relax_type"] = int(rng.choice([6, 8, 18, 7]))  # a symmetric smoother keeps the preconditioner SPD
+        kw.pop("smooth_type", None), kw.pop("smooth_num_levels", None)
+    else:
+        M = convection_diffusion_3d(n, seed=300 + seed)
+    N = M.shape[0]
+    xs = rng.standard_normal(N)
+    bv = M @ xs
+    A = mi.matrix_from_scipy(M)
+    b = mi.IJVector(0, N - 1, bv)
+    x = mi.IJVector(0, N - 1, np.zeros(N))
+    amg = mi.BoomerAMG(print_level=0, **kw)
+    Ao = oc.Csr.from_scipy(M)
+    oamg = oc.Amg(Ao, oc.default_params(gs_chunk=_chunk(mi), **kw))
+    kdim = int(rng.choice([6, 20, 40]))
+    if method == "bicgstab":
+        s = mi.BiCGSTAB(tolerance=1e-8, max_iterations=60, print_level=0)
+        xo, info = oc.bicgstab(Ao, bv, tol=1e-8, maxit=60, amg=oamg)
+    elif method == "fgmres":
+        s = mi.FlexGMRES(tolerance=1e-8, max_iterations=60, kspace=kdim, print_level=0)
+        xo, info = oc.fgmres(Ao, bv, kdim=kdim, tol=1e-8, maxit=60, amg=oamg)
+    elif method == "cogmres":
+        s = mi.COGMRES(tolerance=1e-8, max_iterations=60, kspace=kdim, print_level=0)
+        cgs = int(rng.choice([0, 2]))
+        mi.call("HYPRE_ParCSRCOGMRESSetCGS", s.h, cgs)
+        xo, info = oc.cogmres(Ao, bv, kdim=kdim, cgs=cgs, tol=1e-8, maxit=60, amg=oamg)
+    else:
+        s = mi.PCG(tolerance=1e-8, max_iterations=60, print_level=0)
+        xo, info = oc.pcg(Ao, bv, tol=1e-8, maxit=60, amg=oamg)
+    s.set_precond(amg)
+    s.setup(A, b, x)
+    rc = s.solve(A, b, x)
+    what = (seed, method, n, kdim, kw)
+    assert s.num_iterations == info["iters"], (what, s.num_iterations, info["iters"])
+    if info["iters"] < 60:
+        assert rc == 0 and abs(s.final_rel_res - info["rel_res"]) <= 1e-9, what
+        assert _allclose_ref(x.get(), xo, rtol=1e-5, atol=1e-7), what
