@@ -27,14 +27,40 @@ double wall_time() {
   return duration<double>(steady_clock::now().time_since_epoch()).count();
 }
 
+// CPUs this process may use: the cgroup quota (v2 cpu.max, v1 cfs quota) when there is one, else what the OS shows
+static int usable_cpus() {
+  int n = (int)std::thread::hardware_concurrency();
+  if (n < 1) n = 1;
+  long long quota = -1, period = -1;
+  if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[64] = {0};
+    if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+    fclose(f);
+  } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+    if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+    fclose(g);
+    if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+      if (fscanf(h, "%lld", &period) != 1) period = -1;
+      fclose(h);
+    }
+  }
+  if (quota > 0 && period > 0) n = std::min<long long>(n, std::max<long long>(1, (quota + period - 1) / period));
+  return n;
+}
+
+// MI_HYPRE_HOST_THREADS, or this rank's share of the usable CPUs (LOCAL_WORLD_SIZE ranks per node under torchrun),
+// between 2 and 32: the host phases of the (distributed) setup are memory-bound loops that stop scaling there
 int host_threads() {
   static int n = 0;
   if (n == 0) {
     const char *e = getenv("MI_HYPRE_HOST_THREADS");
-    n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
-    if (n < 1) n = 1;
-    if (!e && n > 16) n = 16;  // one GPU's CPU share on the target nodes
-    if (n > 64) n = 64;
+    if (e) {
+      n = std::max(1, std::min(64, atoi(e)));
+    } else {
+      const char *lw = getenv("LOCAL_WORLD_SIZE");
+      const int ranks_here = std::max(1, lw ? atoi(lw) : 1);
+      n = std::max(2, std::min(32, usable_cpus() / ranks_here));
+    }
   }
   return n;
 }
