@@ -1893,11 +1893,10 @@ void BoomerAMG::build_replicated(ParCSR &A0) {
                              (A0.offd.ia[(size_t)i + 1] - A0.offd.ia[(size_t)i]));
       tot += (size_t)len[(size_t)i];
     }
-    mine.resize(sizeof(int) * (size_t)n + tot * (sizeof(int) + sizeof(double)));
-    char *w = mine.data();
-    memcpy(w, len.data(), sizeof(int) * (size_t)n);
-    int *cj = reinterpret_cast<int *>(w + sizeof(int) * (size_t)n);
-    double *cv = reinterpret_cast<double *>(w + sizeof(int) * (size_t)n + tot * sizeof(int));
+    // packed as [row lengths | columns | values]: the value section need not be 8-byte aligned, so the arrays are
+    // filled on their own and copied in
+    std::vector<int> cj(tot);
+    std::vector<double> cv(tot);
     size_t q = 0;
     for (int i = 0; i < n; i++) {
       for (int64_t k = A0.diag.ia[(size_t)i]; k < A0.diag.ia[(size_t)i + 1]; k++, q++) {
@@ -1908,6 +1907,13 @@ void BoomerAMG::build_replicated(ParCSR &A0) {
         cj[q] = (int)A0.col_map_offd[(size_t)A0.offd.ja[(size_t)k]];
         cv[q] = A0.offd.a[(size_t)k];
       }
+    }
+    mine.resize(sizeof(int) * (size_t)n + tot * (sizeof(int) + sizeof(double)));
+    char *w = mine.data();
+    if (n) memcpy(w, len.data(), sizeof(int) * (size_t)n);
+    if (tot) {
+      memcpy(w + sizeof(int) * (size_t)n, cj.data(), tot * sizeof(int));
+      memcpy(w + sizeof(int) * (size_t)n + tot * sizeof(int), cv.data(), tot * sizeof(double));
     }
   }
   std::vector<size_t> offs;

@@ -1297,8 +1297,8 @@ HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSR(HYPRE_Solver solver, HYPRE_Int level, HY
     return 0;
   }
   for (int i = 0; i <= c.nrows; i++) ia[i] = c.ia[(size_t)i];
-  memcpy(ja, c.ja.data(), c.ja.size() * sizeof(int));
-  memcpy(a, c.a.data(), c.a.size() * sizeof(double));
+  if (!c.ja.empty()) memcpy(ja, c.ja.data(), c.ja.size() * sizeof(int));
+  if (!c.a.empty()) memcpy(a, c.a.data(), c.a.size() * sizeof(double));
   API_END
 }
 HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCF(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int *cf) {
