@@ -122,7 +122,13 @@ def main():
         amg.setup(A)
     order = np.arange(starts[rank + 1] - starts[rank])
     Ao_used, bo_used = Ao, bo
-    if args.locality:
+    # (the replicated setup -- everything but plain PMIS -- does not renumber on N > 1 ranks)
+    by_replication = size > 1 and (smooth_o.get("coarsen_type", 8) not in (8, 9) or smooth_o.get("agg_num_levels", 0) > 0
+                                   or smooth_o.get("interp_type", 6) == 4
+                                   or os.environ.get("MI_HYPRE_REPLICATED_SETUP", "0") not in ("", "0"))
+    if args.locality and by_replication:
+        assert not amg.input_ordering()[0]
+    if args.locality and not by_replication:
         # every rank renumbered its rows (clusters of its diag-block graph, rows with halo entries last): the oracle
         # gets the globally permuted system with the same row partition
         applied, order = amg.input_ordering()
