@@ -1458,7 +1458,15 @@ void BoomerAMG::setup_host(ParCSR &A0) {
     if (!known)
       fail(4, "BoomerAMGSetup: relax_type " + std::to_string(t) +
                   " is not implemented (0, 3, 4, 6, 7, 8, 9, 11, 12, 13, 14, 18 are); refusing to smooth with something else");
+    // 9 = direct solve: the coarsest level only (BoomerAMG::relax would otherwise have to smooth the other
+    // levels with something else, or fail inside the Krylov loop)
+    if (t == 9 && k < 2)
+      fail(4, std::string("BoomerAMGSetup: relax_type 9 (Gaussian elimination) is implemented for the coarsest level only, not as the ") +
+                  (k == 0 ? "down" : "up") + " smoother; refusing to smooth with something else");
   }
+  if (p.interp_type != 0 && p.interp_type != 3 && p.interp_type != 4 && p.interp_type != 6)
+    fail(4, "BoomerAMGSetup: interp_type " + std::to_string(p.interp_type) +
+                " is not implemented (0 classical modified, 3 direct, 4 multipass, 6 extended+i are); refusing to substitute another one");
   if (p.smooth_num_levels > 0 && p.smooth_type != 5)
     fail(4, "BoomerAMGSetup: smooth_type " + std::to_string(p.smooth_type) + " on " + std::to_string(p.smooth_num_levels) +
                 " level(s) is not implemented (5 = ILU is); refusing to smooth with something else");

@@ -240,8 +240,10 @@ void HYPRE_DescribeError(HYPRE_Int errorcode, char *descr) {
   if (errorcode & HYPRE_ERROR_MEMORY) t += "[Memory error] ";
   if (errorcode & HYPRE_ERROR_ARG) t += "[Error in argument] ";
   if (errorcode & HYPRE_ERROR_CONV) t += "[Method did not converge] ";
+  // HYPRE's own texts are short fixed strings (its longest fits 128 bytes): a caller's HYPRE-sized buffer must not
+  // overflow, so the appended message of the last failure is cut to what is left of 128 bytes
   if (errorcode != 0 && !g_last_error.empty()) t += g_last_error;
-  snprintf(descr, 256, "%s", t.c_str());
+  snprintf(descr, 128, "%s", t.c_str());
 }
 
 HYPRE_Int HYPRE_SetMemoryLocation(HYPRE_MemoryLocation loc) {
@@ -733,7 +735,7 @@ AMG_SET(RelaxOrder, HYPRE_Int, p.relax_order = v)
 AMG_SET(MaxLevels, HYPRE_Int, if (v < 1) fail(HYPRE_ERROR_ARG, "max_levels < 1"); p.max_levels = v)
 AMG_SET(StrongThreshold, HYPRE_Real, p.strong_threshold = v)
 AMG_SET(MaxRowSum, HYPRE_Real, p.max_row_sum = v)
-AMG_SET(InterpType, HYPRE_Int, if (v != 0 && v != 3 && v != 4 && v != 6) fprintf(stderr, "mi_hypre BoomerAMG: interp_type %d is not restated; using extended+i (6)\n", v); p.interp_type = (v == 0 || v == 3 || v == 4) ? v : 6)
+AMG_SET(InterpType, HYPRE_Int, p.interp_type = v)  /* unknown types are refused at Setup, like every other choice */
 AMG_SET(TruncFactor, HYPRE_Real, p.trunc_factor = v)
 AMG_SET(PMaxElmts, HYPRE_Int, p.pmax_elmts = v)
 AMG_SET(MinCoarseSize, HYPRE_Int, p.min_coarse_size = v)
@@ -753,11 +755,11 @@ AMG_SET(SmoothType, HYPRE_Int, p.smooth_type = v)  /* acts through smooth_num_le
 AMG_SET(SmoothNumLevels, HYPRE_Int, p.smooth_num_levels = v)
 AMG_SET(ILUType, HYPRE_Int, p.ilu_type = v)
 AMG_SET(ILULevel, HYPRE_Int, p.ilu_level = v)
-AMG_SET(ILULocalReordering, HYPRE_Int, (void)v)
-AMG_SET(ILUMaxRowNnz, HYPRE_Int, (void)v)
+AMG_SET(ILULocalReordering, HYPRE_Int, if (v != 0) warn_ignored("ilu_reordering_type", v))
+AMG_SET(ILUMaxRowNnz, HYPRE_Int, warn_ignored("ilu_max_row_nnz", v))
 AMG_SET(ILUMaxIter, HYPRE_Int, if (v < 1) fail(HYPRE_ERROR_ARG, "ilu_max_iter < 1"); p.ilu_max_iter = v)
-AMG_SET(ILUDroptol, HYPRE_Real, (void)v)
-AMG_SET(ILUIterSetupType, HYPRE_Int, (void)v)
+AMG_SET(ILUDroptol, HYPRE_Real, if (v != 0.0) warn_ignored("ilu_droptol", v))
+AMG_SET(ILUIterSetupType, HYPRE_Int, if (v != 0) warn_ignored("iterative_ilu_algorithm_type", v))
 AMG_SET(ILUIterSetupOption, HYPRE_Int, (void)v)
 AMG_SET(ILUIterSetupMaxIter, HYPRE_Int, (void)v)
 AMG_SET(ILUIterSetupTolerance, HYPRE_Real, (void)v)

@@ -115,13 +115,17 @@ int IluSolver::solve(ParCSR &A, ParVector &b, ParVector &x) {
   const double bn = (tol > 0.0) ? std::sqrt(par_dot_host(comm, b.all(), b.all(), b.len(), s)) : 0.0;
   int it = 0;
   double rel = 0.0;
+  // with a tolerance the residuals of all components are needed BEFORE the update (one norm over the multivector):
+  // they are kept (rall: nc * n, allocated on first use) and reused by the update instead of being recomputed
+  if (tol > 0.0 && nc > 1 && rall.n != (size_t)nc * (size_t)n) rall.alloc((size_t)nc * (size_t)n);
   while (it < max_iter) {
     if (tol > 0.0) {
       double rr = 0.0;
       for (int c = 0; c < nc; c++) {
         const size_t o = (size_t)c * (size_t)n;
-        A.matvec(comm, -1.0, x.all() + o, 1.0, b.all() + o, r.p, s);
-        rr += par_dot_host(comm, r.p, r.p, n, s);
+        double *rc = (nc > 1) ? rall.p + o : r.p;
+        A.matvec(comm, -1.0, x.all() + o, 1.0, b.all() + o, rc, s);
+        rr += par_dot_host(comm, rc, rc, n, s);
       }
       const double rn = std::sqrt(rr);
       rel = (bn > 0.0) ? rn / bn : rn;
@@ -129,8 +133,9 @@ int IluSolver::solve(ParCSR &A, ParVector &b, ParVector &x) {
     }
     for (int c = 0; c < nc; c++) {
       const size_t o = (size_t)c * (size_t)n;
-      A.matvec(comm, -1.0, x.all() + o, 1.0, b.all() + o, r.p, s);
-      apply(r.p, z.p);
+      double *rc = (tol > 0.0 && nc > 1) ? rall.p + o : r.p;
+      if (!(tol > 0.0)) A.matvec(comm, -1.0, x.all() + o, 1.0, b.all() + o, rc, s);
+      apply(rc, z.p);
       k::axpy(1.0, z.p, x.all() + o, n, s);
     }
     it++;

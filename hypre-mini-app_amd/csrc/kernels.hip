@@ -742,10 +742,13 @@ __global__ __launch_bounds__(BLOCK) void gs_tile_k(int blk0, int nblk, const int
 #define UOLD(j) (((j) < split ? u_lo : u_hi)[(j)])
   constexpr int TILE = 8 * BLOCK;        // TILE / TILE_WIDE
   __shared__ double buf[TILE];           // x cache, then products / in-chunk coefficients
-  __shared__ unsigned short code[TILE];  // the entries' lcol words
-  // value dictionary (see spmv_stream_xc): lives in the first 2 KB of `code`, which is only written after the last
-  // lookup (second barrier) -- no LDS beyond the 20 KB that allow 8 workgroups per CU
-  double *slut = reinterpret_cast<double *>(code);
+  // the entries' lcol words.  The value dictionary (see spmv_stream_xc) lives in the first 2 KB of the same bytes,
+  // which are only written as `code` after the last lookup (second barrier) -- no LDS beyond the 20 KB that allow
+  // 8 workgroups per CU.  One 8-byte-aligned byte array with two typed views.
+  __shared__ __attribute__((aligned(8))) unsigned char code_bytes[TILE * sizeof(unsigned short)];
+  static_assert(TILE * sizeof(unsigned short) >= 256 * sizeof(double), "the value table must fit the code array");
+  unsigned short *code = reinterpret_cast<unsigned short *>(code_bytes);
+  double *slut = reinterpret_cast<double *>(code_bytes);
   if ((int)blockIdx.x >= nblk) return;
   const int blk = blk0 + blockIdx.x;
   const int tid = threadIdx.x;

@@ -91,6 +91,7 @@ struct IluSolver : SolverBase {
   DVec<int> order_l, order_u;            // rows sorted by level set
   std::vector<int> lptr, uptr;           // level set boundaries in order_l / order_u
   DVec<double> y, t, r, z;
+  DVec<double> rall;  // residuals of all components of a multivector solve with a tolerance (on first use)
   int num_iterations = 0;
   double final_rel_res = 0.0;
   IluSolver() : SolverBase(K_ILU) {}

@@ -10,4 +10,4 @@ for seed in $(seq ${FUZZ_FROM:-20} ${FUZZ_TO:-59}); do
   rc=$?
   if grep -q "dist solve ok" gpurun_out/fuzz_$seed.log; then echo "seed $seed np $np n $n seq $sq ok"; rm -f gpurun_out/fuzz_$seed.log; else echo "seed $seed np $np n $n seq $sq FAILED rc $rc"; fail=1; grep "rank[0-9]\]:.*Error\|AssertionError" gpurun_out/fuzz_$seed.log | head -3 | cut -c1-300; fi
 done
-exit 0
+exit $fail

@@ -130,11 +130,29 @@ def test_unrestated_settings_are_refused_not_substituted(mi_lib):
     mi = mi_lib
     A, rhs = mi.build_laplace_system_host(6, 6, 6, 7, 0, 1)
     for kw in (dict(coarsen_type=21), dict(coarsen_type=22), dict(agg_num_levels=1, agg_interp_type=1),
-               dict(relax_type=16)):
+               dict(relax_type=16), dict(interp_type=18), dict(interp_type=7), dict(interp_type=14)):
         amg = mi.BoomerAMG(print_level=0, **kw)
         with pytest.raises(mi.HypreError, match="not implemented"):
             mi.call("HYPRE_MI_BoomerAMGSetupHostOnly", amg.h, A.par)
         mi.call("HYPRE_ClearAllErrors")
+
+
+def test_direct_solve_as_down_or_up_smoother_is_refused_at_setup(mi_lib):
+    """relax type 9 exists for the coarsest level only: SetCycleRelaxType(9, 1 or 2) is refused at Setup (ADVICE r2:
+    it used to be replaced by relax_type[0] on the other levels, or to throw inside the Krylov loop); as the
+    coarsest-level choice (k = 3, what HYPRE_BoomerAMGSetRelaxType selects by itself) it is accepted."""
+    mi = mi_lib
+    A, rhs = mi.build_laplace_system_host(6, 6, 6, 7, 0, 1)
+    for k in (1, 2):
+        amg = mi.BoomerAMG(print_level=0)
+        mi.call("HYPRE_BoomerAMGSetCycleRelaxType", amg.h, 9, k)
+        with pytest.raises(mi.HypreError, match="coarsest level only"):
+            mi.call("HYPRE_MI_BoomerAMGSetupHostOnly", amg.h, A.par)
+        mi.call("HYPRE_ClearAllErrors")
+    amg = mi.BoomerAMG(print_level=0)
+    mi.call("HYPRE_BoomerAMGSetCycleRelaxType", amg.h, 9, 3)
+    mi.call("HYPRE_MI_BoomerAMGSetupHostOnly", amg.h, A.par)
+    assert amg.num_levels >= 2
 
 
 def test_random_mmatrix_coarsening_types_host(mi_lib, oc):
