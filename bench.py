@@ -42,6 +42,8 @@ def parse():
                     help="grid side of the bounded CPU-baseline sample (0 = skip; default: 256 = BASELINE.json "
                          "config 2 when the host has the memory, else 128)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-general", action="store_true",
+                    help="skip the general-operator leg (second setup with the value dictionary off + 3 solves)")
     ap.add_argument("--workload", choices=("laplace", "convdiff3"), default="laplace",
                     help="laplace = the headline (BASELINE.json configs 2/3: strong scaling of one n^3 grid); convdiff3 = "
                          "side-line for config 5: 3-component non-symmetric convection-diffusion system, BiCGSTAB + "
@@ -398,6 +400,8 @@ def main():
     cap = 8192
     mi.profile_enable(mi.PROF_SPMV_L0, cap)
     mi.profile_enable(mi.PROF_RELAX_L0, cap)
+    mi.profile_enable(mi.PROF_DOT, 4 * cap)   # fused Gram-Schmidt steps (axpy + inner product) and norms
+    mi.profile_enable(mi.PROF_AXPY, cap)
     barrier()
     t0 = time.perf_counter()
     iters_total = 0
@@ -412,6 +416,10 @@ def main():
 
     spmv_n, spmv_ms, spmv_min = mi.profile_get(mi.PROF_SPMV_L0)
     rel_n, rel_ms, rel_min = mi.profile_get(mi.PROF_RELAX_L0)
+    dot_n, dot_ms, _ = mi.profile_get(mi.PROF_DOT)
+    axpy_n, axpy_ms, _ = mi.profile_get(mi.PROF_AXPY)
+    spmv_kernel = mi.profile_kernel_name(mi.PROF_SPMV_L0)
+    relax_kernel = mi.profile_kernel_name(mi.PROF_RELAX_L0)
     rel_res = gm.final_rel_res
     iters = gm.num_iterations
     xs = x.get()
@@ -420,37 +428,43 @@ def main():
     opcx = amg.operator_complexity
 
     # algorithmic bytes of one level-0 launch on this rank (DESIGN.md "Kernels")
-    ia, ja, av, shape = (None, None, None, None)
     nr, nc, nnz = C.c_int(), C.c_int(), C.c_longlong()
     mi.call("HYPRE_MI_BoomerAMGGetLevelCSRSize", amg.h, 0, 0, C.byref(nr), C.byref(nc), C.byref(nnz))
     nloc, nnz_loc = nr.value, nnz.value
     spmv_bytes = 12.0 * nnz_loc + 20.0 * nloc
-    # one relaxation launch updates the C or the F half: the selected rows' entries once
-    # (forward+backward sweep out of one read), u_old in, u_new out, f and divisor of the
-    # selected rows, the C/F marker
-    relax_bytes = 12.0 * nnz_loc / 2 + 16.0 * nloc + 16.0 * nloc / 2 + nloc
+    # one relaxation launch sweeps the C rows or the F rows (C-first ordering: rows [0, n_C) / [n_C, n)): the swept
+    # rows' entries once (forward + backward sweep out of one read), u_old in (16 N: the gathers' source, read as a
+    # whole vector, and the copy-through), u_new out / f / divisor of the swept rows (16 N_sel), the C/F marker (N).
+    # C and F launches alternate (F then C in every up leg), so the per-launch mean is the mean of the two
+    mi.call("HYPRE_MI_BoomerAMGGetLevelCSRSize", amg.h, 0, 9, C.byref(nr), C.byref(nc), C.byref(nnz))
+    n_c, nnz_c = nr.value, nnz.value
+    n_f, nnz_f = nloc - n_c, nnz_loc - nnz_c
+    relax_bytes_c = 12.0 * nnz_c + 16.0 * nloc + 16.0 * n_c + nloc
+    relax_bytes_f = 12.0 * nnz_f + 16.0 * nloc + 16.0 * n_f + nloc
+    relax_bytes = 0.5 * (relax_bytes_c + relax_bytes_f)
 
-    out = None
+    out, roof = None, None
     if rank == 0:
         # HBM traffic per launch comes from a separate rocprofv3 --pmc pass (the counters cannot be read from
         # inside this process): the newest recorded figure for this configuration, labelled as recorded
-        traffic, traffic_source = None, None
-        for tname in ("traffic_r02.json", "traffic_r01.json"):
-            tpath = os.path.join(ROOT, "profiles", tname)
-            if traffic is None and os.path.exists(tpath):
-                try:
-                    tj = json.load(open(tpath))
-                    key = f"{n}^3/{args.stencil}pt/{world}gpu"
-                    traffic = tj.get(key, {}).get("spmv_hbm_bytes_per_launch")
-                    if traffic is not None:
-                        traffic_source = (f"RECORDED in profiles/{tname} by a separate rocprofv3 --pmc pass "
-                                          "(FETCH_SIZE x2 + WRITE_SIZE per launch), not observed by this run")
-                except Exception:
-                    traffic = None
-        roof = None
+        def recorded_traffic(field):
+            for tname in ("traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
+                tpath = os.path.join(ROOT, "profiles", tname)
+                if os.path.exists(tpath):
+                    try:
+                        v = json.load(open(tpath)).get(f"{n}^3/{args.stencil}pt/{world}gpu", {}).get(field)
+                    except Exception:
+                        v = None
+                    if v is not None:
+                        return v, (f"RECORDED in profiles/{tname} by a separate rocprofv3 --pmc pass "
+                                   "(FETCH_SIZE x2 + WRITE_SIZE per launch), not observed by this run")
+            return None, None
+
+        traffic, traffic_source = recorded_traffic("spmv_hbm_bytes_per_launch")
         if spmv_n:
             a = spmv_bytes / (spmv_ms / spmv_n * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "spmv_stream_xc<0, 1> (level-0 CSR SpMV of the GMRES loop, LDS x-cache variant; the loop "
+            roof = {"bound": "hbm", "kernel": f"{spmv_kernel} (level-0 CSR SpMV of the GMRES loop, LDS x-cache variant; template "
+                              "flags <epilogue, level-0 tag, one-byte value dictionary, workgroup size>; the loop "
                               "runs in the preconditioner's own ordering of level 0 -- graph-clustered internal numbering, C points "
                               "first -- so a V-cycle needs no gather / scatter)", "achieved": a,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": traffic,
@@ -463,12 +477,32 @@ def main():
         roof_relax = None
         if rel_n and world == 1:  # N > 1 cuts a pass into up to three launches (halo overlap): no per-launch figure
             a = relax_bytes / (rel_ms / rel_n * 1e-3) / 1e9
-            roof_relax = {"bound": "hbm", "kernel": "gs_tile_k (level-0 l1 hybrid GS, one C or F pass over the full operator = the up-leg "
-                                    "sweeps; the down leg's sweep starts from a zero guess, runs on the zero-guess "
+            roof_relax = {"bound": "hbm", "kernel": f"{relax_kernel} (level-0 l1 hybrid GS, one C or F pass over the full operator = the "
+                                    "up-leg sweeps; the down leg's sweep starts from a zero guess, runs on the zero-guess "
                                     "sub-operator and is not counted here)",
                           "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
                           "launches": rel_n, "avg_ms": rel_ms / rel_n, "min_ms": rel_min,
-                          "algorithmic_bytes_per_launch": relax_bytes}
+                          "algorithmic_bytes_per_launch": relax_bytes,
+                          "byte_model": {"formula": "12 nnz_sel + 16 N + 16 N_sel + N per pass; mean of the C pass and the F pass "
+                                                    "(they alternate); counts from HYPRE_MI_BoomerAMGGetLevelCSRSize(which=9)",
+                                         "n_C": n_c, "nnz_C_rows": nnz_c, "n_F": n_f, "nnz_F_rows": nnz_f,
+                                         "bytes_C_pass": relax_bytes_c, "bytes_F_pass": relax_bytes_f}}
+        # modified Gram-Schmidt of the GMRES loop (second-largest block of a solve after level 0): the fused
+        # axpy + inner-product steps and norms (class "dot"), and the plain axpys of the solution update
+        gram = None
+        if dot_n and world == 1:
+            # step i of a cycle: i fused steps of 32 N bytes (read p_j, read + write p_i, 8 N each; <p_j+1, p_i> rides on
+            # the same pass) + the norm; one solve of m steps: m(m+1)/2 fused steps + ~m + 3 norms / dots of 8..16 N
+            m_it = iters
+            gs_bytes = (m_it * (m_it + 1) / 2.0) * 32.0 * nloc + (m_it + 3) * 16.0 * nloc
+            per_solve_ms = dot_ms / args.steps
+            gram = {"what": "modified Gram-Schmidt + norms of one solve (HIP events of the fused axpy+dot / dot launches)",
+                    "ms_per_solve": per_solve_ms, "launches_per_solve": dot_n / args.steps,
+                    "share_of_solve": per_solve_ms / (elapsed / args.steps * 1e3),
+                    "algorithmic_bytes_per_solve": gs_bytes,
+                    "achieved": gs_bytes / (per_solve_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": gs_bytes / (per_solve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "axpy_ms_per_solve": axpy_ms / args.steps}
         chunk = C.c_int()
         mi.call("HYPRE_MI_GetGSChunk", C.byref(chunk))
         out = {
@@ -502,9 +536,50 @@ def main():
             "build_s": t_build,
             "roofline": roof,
             "roofline_relax": roof_relax,
+            "gram_schmidt": gram,
         }
         if rehearsal:
             out["rehearsal"] = True
+    # ---- general-operator leg (N = 1): the headline operator has two distinct values (6, -1), so its level-0 kernels
+    # stream one-byte dictionary indices; a variable-coefficient operator (BASELINE.json configs 4 / 5) cannot.  The
+    # same problem is set up again with the dictionary off and the same kernel classes are timed on a few solves:
+    # "roofline_general" is what a general matrix of this size and sparsity gets.  Outside the timed region.
+    if world == 1 and not args.no_general and roof is not None:
+        gm.destroy()
+        amg.destroy()
+        mi.call("HYPRE_MI_SetValueDictionary", 0)
+        amg = mi.BoomerAMG(print_level=0, **amg_kw)
+        gm = mi.GMRES(tolerance=args.tol, max_iterations=args.max_iter, kspace=args.kdim, print_level=0)
+        gm.set_precond(amg)
+        t0 = time.time()
+        gm.setup(A, b, x)
+        t_setup_g = time.time() - t0
+        one_solve()
+        mi.profile_reset()
+        barrier()
+        t0 = time.perf_counter()
+        g_steps = 3
+        g_iters = sum(one_solve() for _ in range(g_steps))
+        barrier()
+        g_elapsed = time.perf_counter() - t0
+        gs_n, gs_ms, gs_min = mi.profile_get(mi.PROF_SPMV_L0)
+        gr_n, gr_ms, gr_min = mi.profile_get(mi.PROF_RELAX_L0)
+        g_traffic, g_src = recorded_traffic("spmv_general_hbm_bytes_per_launch")
+        a = spmv_bytes / (gs_ms / gs_n * 1e-3) / 1e9
+        ar = relax_bytes / (gr_ms / gr_n * 1e-3) / 1e9
+        out["roofline_general"] = {
+            "what": "the same solve with the value dictionary off (HYPRE_MI_SetValueDictionary(0)): 8-byte values in the "
+                    "level-0 matrix stream, as for any variable-coefficient operator; results identical bit for bit",
+            "bound": "hbm", "kernel": mi.profile_kernel_name(mi.PROF_SPMV_L0), "achieved": a, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": g_traffic, "traffic_source": g_src,
+            "launches": gs_n, "avg_ms": gs_ms / gs_n, "min_ms": gs_min, "algorithmic_bytes_per_launch": spmv_bytes,
+            "relax": {"kernel": mi.profile_kernel_name(mi.PROF_RELAX_L0), "achieved": ar, "frac": ar / HBM_PEAK_GBS,
+                      "launches": gr_n, "avg_ms": gr_ms / gr_n, "algorithmic_bytes_per_launch": relax_bytes},
+            "ms_per_step": g_elapsed / g_steps * 1e3, "value_gdofs": ndof * g_iters / g_elapsed / 1e9,
+            "iterations_per_solve": gm.num_iterations, "final_rel_residual": gm.final_rel_res, "steps": g_steps,
+            "setup_s": t_setup_g}
+        mi.call("HYPRE_MI_SetValueDictionary", 1)
+    if rank == 0:
         if not args.no_cpu and args.cpu_n != 0 and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, chunk.value)
         else:

@@ -1182,6 +1182,11 @@ HYPRE_Int HYPRE_MI_SetZeroGuessMode(HYPRE_Int mode) {
   set_zero_skip_mode(mode);
   API_END
 }
+HYPRE_Int HYPRE_MI_SetValueDictionary(HYPRE_Int on) {
+  API_BEGIN
+  k::set_value_dictionary(on != 0);
+  API_END
+}
 HYPRE_Int HYPRE_MI_GetGSChunk(HYPRE_Int *rows) {
   *rows = ctx().gs_chunk;
   return 0;
@@ -1260,6 +1265,15 @@ HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSRSize(HYPRE_Solver solver, HYPRE_Int level
     *nnz = L.has_Ar ? L.Ar.nnz : 0;
     return 0;
   }
+  if (which == 9) {  // the C rows of the diag block (the level's C-first ordering: rows [0, nc))
+    *nrows = L.nc;
+    *ncols = L.A->diag.ncols;
+    int e = 0;
+    if (L.nc > 0 && L.A->d_diag.ia.p) MI_HIP(hipMemcpy(&e, L.A->d_diag.ia.p + L.nc, sizeof(int), hipMemcpyDeviceToHost));
+    else if (L.nc > 0 && !L.A->diag.ia.empty()) e = (int)L.A->diag.ia[(size_t)L.nc];
+    *nnz = e;
+    return 0;
+  }
   if (which == 7) {  // x cache of the level operator: tiles, 0, total unique columns over the tiles
     *nrows = L.A->d_diag.nblocks;
     *ncols = 0;
@@ -1274,7 +1288,7 @@ HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSRSize(HYPRE_Solver solver, HYPRE_Int level
     case 4: M = L.Pm.get(); break;
     case 3:
     case 5: M = L.Rm.get(); break;
-    default: fail(HYPRE_ERROR_ARG, "which must be 0..8");
+    default: fail(HYPRE_ERROR_ARG, "which must be 0..9");
   }
   if (!M) {
     *nrows = *ncols = 0;
@@ -1380,6 +1394,13 @@ HYPRE_Int HYPRE_MI_ProfileEnable(HYPRE_Int id, HYPRE_Int capacity) {
   if (id < 0 || id >= k::PROF_COUNT) fail(HYPRE_ERROR_ARG, "ProfileEnable: bad id");
   if (!ctx().timer) ctx().timer = new KernelTimer();
   ctx().timer->enable(id, (size_t)capacity);
+  API_END
+}
+HYPRE_Int HYPRE_MI_ProfileKernelName(HYPRE_Int id, char *name, HYPRE_Int max_len) {
+  API_BEGIN
+  if (!name || max_len < 1) fail(HYPRE_ERROR_ARG, "ProfileKernelName: no buffer");
+  const char *n = (ctx().timer && id >= 0 && id < k::PROF_COUNT && ctx().timer->kernel_name[id]) ? ctx().timer->kernel_name[id] : "";
+  snprintf(name, (size_t)max_len, "%s", n);
   API_END
 }
 HYPRE_Int HYPRE_MI_ProfileReset(void) {

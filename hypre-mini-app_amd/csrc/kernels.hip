@@ -1246,56 +1246,69 @@ static bool gs_force_generic() {
   return v == 1;
 }
 
-static void launch_stream(int epi, const DevCSR &A, const double *x, double *y, const EpiArgs &e, hipStream_t s,
-                          bool level0 = false) {
-  if (A.nrows == 0) return;
+// returns the name of the instantiation it launched (as rocprofv3's kernel statistics spell it)
+static const char *launch_stream(int epi, const DevCSR &A, const double *x, double *y, const EpiArgs &e, hipStream_t s,
+                                 bool level0 = false) {
+  if (A.nrows == 0) return "";
+  const char *name = "";
   const int nb = A.nblocks;
   const int xchunk = (nb + 7) / 8;
   const dim3 grid(xchunk * 8), block(SPMV_BLOCK);
   if (A.xcache && A.tile_entries == SPMV_TILE_WIDE) {
     const dim3 wide(SPMV_BLOCK_WIDE);
 #define XC_LAUNCH_W(EPI_, V8_)                                                                                       \
+  name = "spmv_stream_xc<" #EPI_ ", 0, " #V8_ ", 512>";                                                              \
   hipLaunchKernelGGL((spmv_stream_xc<EPI_, 0, V8_, SPMV_BLOCK_WIDE>), grid, wide, 0, s, nb, xchunk, A.tdesc.p, A.ia.p, \
                      A.ja.p, A.a.p, A.ucols.p, A.lcol.p, x, y, e, A.vidx.p, A.vlut.p)
     if (A.val8) {
-      if (epi == 0)
+      if (epi == 0) {
         XC_LAUNCH_W(0, true);
-      else
+      } else {
         XC_LAUNCH_W(1, true);
+      }
     } else {
-      if (epi == 0)
+      if (epi == 0) {
         XC_LAUNCH_W(0, false);
-      else
+      } else {
         XC_LAUNCH_W(1, false);
+      }
     }
 #undef XC_LAUNCH_W
   } else if (A.xcache) {
 #define XC_LAUNCH(EPI_, TAG_, V8_)                                                                                  \
+  name = "spmv_stream_xc<" #EPI_ ", " #TAG_ ", " #V8_ ", 256>";                                                       \
   hipLaunchKernelGGL((spmv_stream_xc<EPI_, TAG_, V8_, SPMV_BLOCK>), grid, block, 0, s, nb, xchunk, A.tdesc.p, A.ia.p, A.ja.p, \
                      A.a.p, A.ucols.p, A.lcol.p, x, y, e, A.vidx.p, A.vlut.p)
     if (A.val8) {
-      if (epi == 0 && level0)
+      if (epi == 0 && level0) {
         XC_LAUNCH(0, 1, true);
-      else if (epi == 0)
+      } else if (epi == 0) {
         XC_LAUNCH(0, 0, true);
-      else
+      } else {
         XC_LAUNCH(1, 0, true);
+      }
     } else {
-      if (epi == 0 && level0)
+      if (epi == 0 && level0) {
         XC_LAUNCH(0, 1, false);
-      else if (epi == 0)
+      } else if (epi == 0) {
         XC_LAUNCH(0, 0, false);
-      else
+      } else {
         XC_LAUNCH(1, 0, false);
+      }
     }
 #undef XC_LAUNCH
-  } else if (epi == 0 && level0)
+  } else if (epi == 0 && level0) {
+    name = "spmv_stream<0, 1>";
     hipLaunchKernelGGL((spmv_stream<0, 1>), grid, block, 0, s, nb, xchunk, A.rb.p, A.ia.p, A.ja.p, A.a.p, x, y, e);
-  else if (epi == 0)
+  } else if (epi == 0) {
+    name = "spmv_stream<0, 0>";
     hipLaunchKernelGGL((spmv_stream<0, 0>), grid, block, 0, s, nb, xchunk, A.rb.p, A.ia.p, A.ja.p, A.a.p, x, y, e);
-  else
+  } else {
+    name = "spmv_stream<1, 0>";
     hipLaunchKernelGGL((spmv_stream<1, 0>), grid, block, 0, s, nb, xchunk, A.rb.p, A.ia.p, A.ja.p, A.a.p, x, y, e);
+  }
   MI_HIP(hipGetLastError());
+  return name;
 }
 
 namespace {
@@ -1324,6 +1337,13 @@ __global__ __launch_bounds__(256) void value_index_k(long long n, const double *
 }
 }  // namespace
 
+static int g_value_dict = -1;
+bool value_dictionary_enabled() {
+  if (g_value_dict < 0) g_value_dict = (getenv("MI_HYPRE_VALUE_DICT") && atoi(getenv("MI_HYPRE_VALUE_DICT")) == 0) ? 0 : 1;
+  return g_value_dict == 1;
+}
+void set_value_dictionary(bool on) { g_value_dict = on ? 1 : 0; }
+
 // Value dictionary of an operator in the solve format: distinct values (bit patterns) of a sample, at most 256;
 // one pass then encodes every entry or finds one that is not in the table (the operator keeps the plain stream).
 // MI_HYPRE_VALUE_DICT=0 switches it off.
@@ -1331,8 +1351,7 @@ void build_value_dictionary(DevCSR &A, hipStream_t s) {
   A.val8 = false;
   A.vidx.release();
   A.vlut.release();
-  static const bool enabled = !(getenv("MI_HYPRE_VALUE_DICT") && atoi(getenv("MI_HYPRE_VALUE_DICT")) == 0);
-  if (!enabled || !A.xcache || A.nnz < (1 << 16) || !A.a.p) return;
+  if (!value_dictionary_enabled() || !A.xcache || A.nnz < (1 << 16) || !A.a.p) return;
   // a strided sample over the whole array (the leading rows alone are not representative: the C rows of a
   // zero-guess sub-operator hold nothing but their diagonal); enough to see > 256 distinct values at once
   const size_t sample = (size_t)std::min<int64_t>(A.nnz, 1 << 16);
@@ -1384,7 +1403,7 @@ void spmv(const DevCSR &A, const double *x, double alpha, double beta, const dou
   e.b = b;
   e.rowmap = A.rowmap.p;
   prof_begin(prof, s);
-  launch_stream(0, A, x, y, e, s, prof == PROF_SPMV_L0);
+  prof_name(prof, launch_stream(0, A, x, y, e, s, prof == PROF_SPMV_L0));
   prof_end(prof, s);
 }
 
@@ -1398,7 +1417,7 @@ void jacobi(const DevCSR &A, const double *u_old, double *u_new, const double *f
   e.cf = cf;
   e.points = points;
   prof_begin(prof, s);
-  launch_stream(1, A, u_old, u_new, e, s);
+  prof_name(prof, launch_stream(1, A, u_old, u_new, e, s));
   prof_end(prof, s);
 }
 
@@ -1438,21 +1457,25 @@ void gs_hybrid(const DevCSR &A, const double *u_lo, const double *u_hi, int spli
     const int b0 = (int)(std::upper_bound(rbh.begin(), rbh.end(), first_row) - rbh.begin()) - 1;
     const int b1 = (int)(std::lower_bound(rbh.begin(), rbh.end(), last_row) - rbh.begin());
 #define GS_TILE_LAUNCH(V8_, BLOCK_)                                                                                  \
+  prof_name(prof, V8_ ? (BLOCK_ == 512 ? "gs_tile_k<true, 512>" : "gs_tile_k<true, 256>")                             \
+                      : (BLOCK_ == 512 ? "gs_tile_k<false, 512>" : "gs_tile_k<false, 256>"));                         \
   hipLaunchKernelGGL((gs_tile_k<V8_, BLOCK_>), dim3((unsigned)(b1 - b0)), dim3(BLOCK_), 0, s, b0, b1 - b0, A.tdesc.p, \
                      A.ia.p, A.a.p, A.ucols.p, A.lcol.p, cf, points, d, f, offc, u_lo, u_hi, split, out, fwd ? 1 : 0,  \
                      bwd ? 1 : 0, w, first_row, last_row, zero_from, tout, t_from, V8_ ? A.vidx.p : nullptr,          \
                      V8_ ? A.vlut.p : nullptr)
     const bool wide = A.tile_entries == SPMV_TILE_WIDE;
-    if (b1 > b0 && A.val8 && wide)
+    if (b1 > b0 && A.val8 && wide) {
       GS_TILE_LAUNCH(true, SPMV_BLOCK_WIDE);
-    else if (b1 > b0 && A.val8)
+    } else if (b1 > b0 && A.val8) {
       GS_TILE_LAUNCH(true, SPMV_BLOCK);
-    else if (b1 > b0 && wide)
+    } else if (b1 > b0 && wide) {
       GS_TILE_LAUNCH(false, SPMV_BLOCK_WIDE);
-    else if (b1 > b0)
+    } else if (b1 > b0) {
       GS_TILE_LAUNCH(false, SPMV_BLOCK);
+    }
 #undef GS_TILE_LAUNCH
   } else if (chunk == 8 && !gs_force_generic()) {
+    prof_name(prof, "gs_group_k / gs_dense_k (chunk kernels)");
     const double avg = (double)A.nnz / (double)A.nrows;
     const int p95 = A.rowlen_p95;
 #define GS_LAUNCH_K(KERNEL, LPC, E)                                                                             \
@@ -1486,6 +1509,7 @@ void gs_hybrid(const DevCSR &A, const double *u_lo, const double *u_hi, int spli
 #undef GS_LAUNCH
   } else {
     const size_t lds = (size_t)chunk * GS_BLOCK * sizeof(double);
+    prof_name(prof, "gs_hybrid_k");
     hipLaunchKernelGGL(gs_hybrid_k, dim3((unsigned)((nch + GS_BLOCK - 1) / GS_BLOCK)), dim3(GS_BLOCK), lds, s,
                        A.nrows, (int)c0, (int)c1, chunk, A.ia.p, A.ja.p, A.a.p, cf, points, d, f, offc, u_lo, u_hi,
                        split, out, fwd ? 1 : 0, bwd ? 1 : 0, w);

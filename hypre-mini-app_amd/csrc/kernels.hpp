@@ -55,6 +55,9 @@ constexpr int XC_OFF_SHIFT = 12;    // ... at this offset (3 bits)
 void build_tile_desc(DevCSR &A, hipStream_t s);
 // value dictionary of an operator with at most 256 distinct values (called by build_tile_desc)
 void build_value_dictionary(DevCSR &A, hipStream_t s);
+// MI_HYPRE_VALUE_DICT / HYPRE_MI_SetValueDictionary: applies to operators put into the solve format afterwards
+bool value_dictionary_enabled();
+void set_value_dictionary(bool on);
 // y = alpha*A*x + beta*b   (b may alias y)
 void spmv(const DevCSR &A, const double *x, double alpha, double beta, const double *b, double *y, hipStream_t s,
           int prof = PROF_NONE);

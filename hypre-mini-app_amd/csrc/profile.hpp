@@ -11,6 +11,8 @@ struct KernelTimer {
   std::vector<hipEvent_t> start[k::PROF_COUNT], stop[k::PROF_COUNT];
   size_t used[k::PROF_COUNT] = {};
   size_t dropped[k::PROF_COUNT] = {};
+  // instantiation (template flags included) of the kernel last launched under the class, as rocprofv3 names it
+  const char *kernel_name[k::PROF_COUNT] = {};
   void enable(int id, size_t capacity);
   void reset();
   // (launch count, total milliseconds) of completed pairs; synchronises the stream
@@ -27,6 +29,11 @@ inline void prof_begin(int id, hipStream_t s) {
     return;
   }
   (void)hipEventRecord(t->start[id][t->used[id]], s);
+}
+inline void prof_name(int id, const char *name) {
+  if (id < 0) return;
+  KernelTimer *t = ctx().timer;
+  if (t && t->enabled[id]) t->kernel_name[id] = name;
 }
 inline void prof_end(int id, hipStream_t s) {
   if (id < 0) return;

@@ -545,6 +545,13 @@ def profile_reset():
     call("HYPRE_MI_ProfileReset")
 
 
+def profile_kernel_name(pid):
+    """instantiation (template flags included) of the kernel last launched under the class."""
+    buf = C.create_string_buffer(128)
+    call("HYPRE_MI_ProfileKernelName", pid, buf, 128)
+    return buf.value.decode()
+
+
 def profile_get(pid):
     n, tot, mn = C.c_longlong(), c_dbl(), c_dbl()
     call("HYPRE_MI_ProfileGet", pid, C.byref(n), C.byref(tot), C.byref(mn))

@@ -55,6 +55,12 @@ HYPRE_Int HYPRE_MI_GetGSChunk(HYPRE_Int *rows_per_chunk);
  * (default, env MI_HYPRE_GS_ZERO_SKIP) the residual that follows also reuses the F pass's product with the C values
  * and reads the F rows without their C columns.  Same result up to summation order. */
 HYPRE_Int HYPRE_MI_SetZeroGuessMode(HYPRE_Int mode);
+/* Value dictionary of operators with at most 256 distinct values (constant-coefficient stencils such as the
+ * reference generator's 26 / -1, /root/reference/src/laplace_3d_weak_scaling.hpp:558,600): one byte per entry instead
+ * of the 8-byte value in the matrix stream; same doubles, same results.  on = 0 keeps the plain stream -- what a
+ * general (variable-coefficient) operator gets anyway; applies to hierarchies set up afterwards (env
+ * MI_HYPRE_VALUE_DICT).  bench.py uses it to report the general-operator roofline beside the headline. */
+HYPRE_Int HYPRE_MI_SetValueDictionary(HYPRE_Int on);
 /* Counters of the multi-rank choreography since the library was loaded: "matvec_overlapped" (SpMVs whose
  * neighbour exchange ran beside the diag-block product), "gs_overlapped" / "gs_in_order" (relaxation passes that
  * swept their halo-free rows while the halo travelled / that waited for it first); collectives of the solve phase
@@ -93,7 +99,8 @@ HYPRE_Int HYPRE_MI_BoomerAMGGetSetupSeconds(HYPRE_Solver solver, HYPRE_Real *sec
  * GetLevelCSRSize also takes which = 6: the level's zero-guess sub-operator (the entries of the diag block a
  * first sweep on a zero guess can meet with a non-zero; 0 x 0 when the level has none), and which = 7: the x cache
  * of the level's diag block (nrows = number of tiles, nnz = unique columns summed over the tiles); which = 8: the
- * operator of the residual after a zero-guess sweep (0 x 0 when the level has none). */
+ * operator of the residual after a zero-guess sweep (0 x 0 when the level has none); which = 9: the C rows of the diag
+ * block (nrows = number of C points, nnz = their entries: what a C pass of the relaxation streams). */
 HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSRSize(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int which, HYPRE_Int *nrows,
                                             HYPRE_Int *ncols, HYPRE_BigInt *nnz);
 HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSR(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int which, HYPRE_BigInt *ia,
@@ -122,6 +129,9 @@ HYPRE_Int HYPRE_MI_BoomerAMGRelaxLevel(HYPRE_Solver solver, HYPRE_Int level, HYP
  * 4 + l residual SpMV of the cycle, 20 + l relaxation passes, 36 + l restriction, 52 + l prolongation */
 HYPRE_Int HYPRE_MI_ProfileEnable(HYPRE_Int id, HYPRE_Int capacity);
 HYPRE_Int HYPRE_MI_ProfileReset(void);
+/* instantiation (template flags included, as rocprofv3's kernel statistics spell it) of the kernel last launched
+ * under the class; empty when none was */
+HYPRE_Int HYPRE_MI_ProfileKernelName(HYPRE_Int id, char *name, HYPRE_Int max_len);
 HYPRE_Int HYPRE_MI_ProfileGet(HYPRE_Int id, long long *launches, double *total_ms, double *min_ms);
 
 /* ---- synthetic problem: n^3-type Laplacian, true lexicographic global numbering

@@ -30,6 +30,20 @@ def test_bench_single_gpu_contract():
     assert j["vs_baseline"] is None and j["dtype"] == "f64" and j["data"] == "synthetic" and "workload" in j["config"]
     r = j["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # the kernel name comes from the launch itself, template flags included (value dictionary on for the 6 / -1 stencil)
+    assert r["kernel"].startswith("spmv_stream_xc<0, 1, true, 256>")
+    rr = j["roofline_relax"]
+    bm = rr["byte_model"]
+    assert bm["n_C"] + bm["n_F"] == 64 ** 3 and bm["nnz_C_rows"] + bm["nnz_F_rows"] == 7 * 64 ** 3 - 6 * 64 ** 2
+    assert abs(rr["algorithmic_bytes_per_launch"] - 0.5 * (bm["bytes_C_pass"] + bm["bytes_F_pass"])) < 1.0
+    assert rr["kernel"].startswith("gs_tile_k<true, 256>")
+    # general-operator leg: dictionary off, same iterations and residual (same doubles), plain-stream kernels
+    g = j["roofline_general"]
+    assert g["kernel"].startswith("spmv_stream_xc<0, 1, false, 256>") and g["relax"]["kernel"].startswith("gs_tile_k<false, 256>")
+    assert g["iterations_per_solve"] == j["iterations_per_solve"] and g["final_rel_residual"] == j["final_rel_residual"]
+    assert abs(g["frac"] - g["achieved"] / g["peak"]) < 1e-12 and g["algorithmic_bytes_per_launch"] == r["algorithmic_bytes_per_launch"]
+    ms = j["gram_schmidt"]
+    assert ms["ms_per_solve"] > 0 and 0 < ms["share_of_solve"] < 1
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert 5 <= j["iterations_per_solve"] <= 30 and j["final_rel_residual"] <= 1e-8
