@@ -188,6 +188,10 @@ struct BoomerAMG {
   void relax_pair(int level, int type, int first, const double *f, bool u_is_zero = false);
   void relax_sweeps(int level, int which, const double *f, bool u_is_zero = false);
   void cycle(int level, bool u_is_zero = false);
+  // cycle(level, true) never reads Lv.u before it has overwritten every row (one rank, Gauss-Seidel down sweep on
+  // the zero-skipping kernels, or the dense coarsest solve): the caller need not zero-fill u first -- at 512^3 the
+  // fills of a cycle are 1.6 GB of writes, 0.8 % of the solve, and one launch per level
+  bool zero_cycle_ignores_u(int level);
   // renumber every level C-first (host, collective); called at the end of setup_host
   void apply_cf_ordering();
   double operator_complexity() const;

@@ -311,6 +311,29 @@ void BoomerAMG::relax_sweeps(int level, int which, const double *f, bool u_is_ze
   }
 }
 
+bool BoomerAMG::zero_cycle_ignores_u(int level) {
+  static const bool enabled = !(getenv("MI_HYPRE_SKIP_ZERO_FILL") && atoi(getenv("MI_HYPRE_SKIP_ZERO_FILL")) == 0);
+  if (!enabled || my_comm().size != 1) return false;  // N > 1: the second pass sends pre-sweep (zero) values of its halo rows
+  const int nlev = (int)L.size();
+  AmgLevel &Lv = L[(size_t)level];
+  if (level == nlev - 1) {
+    if (tail) return false;
+    return p.relax_type[2] == 9 && Lv.dense && p.num_sweeps[2] > 0;  // u = C^-1 f
+  }
+  if (Lv.smoother || p.num_sweeps[0] < 1 || zero_skip_mode() < 1) return false;
+  const int type = p.relax_type[0];
+  if (type == 9 || type == 11 || type == 12) return false;
+  const GsKind g = classify(type);
+  if (g.jacobi || !(g.fwd || g.bwd)) return false;
+  const int ch = chunk();
+  const bool use_Az = Lv.has_Az && Lv.Az_chunk == ch;
+  const bool has_cf = Lv.has_cf && !Lv.cf.empty();
+  if (p.relax_order == 1 && has_cf && (Lv.nc == 0 || Lv.nc == Lv.n)) return false;  // degenerate pair: two lone passes
+  // C-then-F pair: both passes run on Az when the level has one; a lone full sweep likewise
+  const DevCSR &M = use_Az ? Lv.Az : Lv.A->d_diag;
+  return k::gs_ignores_zero_vector(M, ch);
+}
+
 // one cycle on the level's own f (Lv.f) and u (Lv.u)
 void BoomerAMG::cycle(int level, bool u_is_zero) {
   const int nlev = (int)L.size();
@@ -333,7 +356,7 @@ void BoomerAMG::cycle(int level, bool u_is_zero) {
     Lv.A->matvec(comm, -1.0, Lv.u.p, 1.0, Lv.f.p, Lv.tmp.p, s, k::prof_level(k::PROF_LVL_RESID, level));
   Lv.t_valid = false;
   Lv.Rm->matvec(comm, 1.0, Lv.tmp.p, 0.0, nullptr, Ln.f.p, s, k::prof_level(k::PROF_LVL_RESTRICT, level));
-  k::fill(Ln.u.p, Ln.n, 0.0, s);
+  if (!zero_cycle_ignores_u(level + 1)) k::fill(Ln.u.p, Ln.n, 0.0, s);
   // the coarsest level is visited once per cycle; with a redundant tail the count continues into the tail
   const bool tail_next = tail && level + 1 == nlev - 1;
   const bool next_is_coarsest = tail_next ? tail->L.size() == 1 : level + 1 == nlev - 1;
@@ -375,9 +398,9 @@ void BoomerAMG::apply_global(const double *f, double *e, bool zero_guess) {
     k::gather(f, L0.d_perm.p, L0.f.p, L0.n, s);
   else
     k::copy(f, L0.f.p, L0.n, s);
-  if (zero_guess)
-    k::fill(L0.u.p, L0.n, 0.0, s);
-  else if (permuted)
+  if (zero_guess) {
+    if (!zero_cycle_ignores_u(0)) k::fill(L0.u.p, L0.n, 0.0, s);
+  } else if (permuted)
     k::gather(e, L0.d_perm.p, L0.u.p, L0.n, s);
   else
     k::copy(e, L0.u.p, L0.n, s);
@@ -416,9 +439,9 @@ void BoomerAMG::solve(ParCSR &A, ParVector &b, ParVector &x) {
         else
           k::copy(bc, L0.f.p, n, s);
       }
-      if (zero)
-        k::fill(L0.u.p, n, 0.0, s);
-      else if (permuted)
+      if (zero) {
+        if (!zero_cycle_ignores_u(0)) k::fill(L0.u.p, n, 0.0, s);
+      } else if (permuted)
         k::gather(xc, L0.d_perm.p, L0.u.p, n, s);
       else
         k::copy(xc, L0.u.p, n, s);

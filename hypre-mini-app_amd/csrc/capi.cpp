@@ -217,6 +217,7 @@ HYPRE_Int HYPRE_Finalize(void) {
     c.comm.reset();
     c.red_partials.release();
     c.red_out.release();
+    c.red_ticket.release();
     if (c.h_pinned) (void)hipHostFree(c.h_pinned);
     c.h_pinned = nullptr;
     if (c.stream) (void)hipStreamDestroy(c.stream);

@@ -911,8 +911,41 @@ __global__ __launch_bounds__(BLOCK) void gs_tile_k(int blk0, int nblk, const int
 // ---------------------------------------------------------------------------
 // BLAS-1
 // ---------------------------------------------------------------------------
+// Second stage of the two-stage reductions inside the first-stage kernel: every block leaves its partial sum, takes a
+// ticket, and the block that draws the last one adds the partials up -- in a fixed order
+// (thread t takes partials t, t + 256, ...; wave shuffles; (w0 + w1) + (w2 + w3)), so the result does not depend on
+// which block comes last and equals the two-launch form bit for bit.  One launch per inner product instead of two
+// (a GMRES solve of m steps issues m(m+1)/2 + 2m + 3 of them).  The ticket counter is reset by the last block;
+// reductions are serialised on the library stream, so one counter serves them all.
+__device__ __forceinline__ void finish_reduction(double block_sum, double *__restrict__ partials,
+                                                 unsigned *__restrict__ ticket, double *__restrict__ out, double *ws) {
+  __shared__ unsigned s_last;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    __hip_atomic_store(partials + blockIdx.x, block_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();  // the partial is visible device-wide before the ticket is
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == gridDim.x - 1) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  const int nb = (int)gridDim.x;
+  double s = 0.0;
+  for (int i = tid; i < nb; i += 256) s += __hip_atomic_load(partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  s = wave_sum(s);
+  __syncthreads();  // ws is reused
+  if ((tid & 63) == 0) ws[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) {
+    out[0] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 __global__ __launch_bounds__(256) void dot_partial_k(const double *__restrict__ x, const double *__restrict__ y, int n,
-                                                     double *__restrict__ partials) {
+                                                     double *__restrict__ partials, unsigned *__restrict__ ticket,
+                                                     double *__restrict__ out) {
   __shared__ double ws[4];
   const int tid = threadIdx.x;
   double s = 0.0;
@@ -927,7 +960,7 @@ __global__ __launch_bounds__(256) void dot_partial_k(const double *__restrict__ 
   s = wave_sum(s);
   if ((tid & 63) == 0) ws[tid >> 6] = s;
   __syncthreads();
-  if (tid == 0) partials[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+  finish_reduction((ws[0] + ws[1]) + (ws[2] + ws[3]), partials, ticket, out, ws);
 }
 
 // fused modified-Gram-Schmidt step: y += a*xa (a = scale * *alpha_dev), then the
@@ -937,7 +970,8 @@ __global__ __launch_bounds__(256) void dot_partial_k(const double *__restrict__ 
 __global__ __launch_bounds__(256) void axpy_dot_partial_k(const double *__restrict__ alpha_dev, double scale,
                                                           const double *__restrict__ xa, double *__restrict__ y,
                                                           const double *__restrict__ xd, int n,
-                                                          double *__restrict__ partials) {
+                                                          double *__restrict__ partials, unsigned *__restrict__ ticket,
+                                                          double *__restrict__ out) {
   __shared__ double ws[4];
   const int tid = threadIdx.x;
   const double a = scale * alpha_dev[0];
@@ -963,20 +997,9 @@ __global__ __launch_bounds__(256) void axpy_dot_partial_k(const double *__restri
   s = wave_sum(s);
   if ((tid & 63) == 0) ws[tid >> 6] = s;
   __syncthreads();
-  if (tid == 0) partials[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+  finish_reduction((ws[0] + ws[1]) + (ws[2] + ws[3]), partials, ticket, out, ws);
 }
 
-__global__ __launch_bounds__(256) void reduce_final_k(const double *__restrict__ partials, int nb,
-                                                      double *__restrict__ out) {
-  __shared__ double ws[4];
-  const int tid = threadIdx.x;
-  double s = 0.0;
-  for (int i = tid; i < nb; i += 256) s += partials[i];
-  s = wave_sum(s);
-  if ((tid & 63) == 0) ws[tid >> 6] = s;
-  __syncthreads();
-  if (tid == 0) out[0] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
-}
 
 
 // ---- block Gram-Schmidt pieces of COGMRES: up to MASS_NV inner products off one vector in one pass, and the
@@ -1438,6 +1461,15 @@ bool gs_uses_tiles(const DevCSR &A, int chunk) {
   return chunk == 8 && A.gs_tiles && A.xcache && gs_tile_mode(A) && !gs_force_generic() && !gs_use_old();
 }
 
+// whether a sweep of A with zero_from == 0 never reads the pre-sweep vector (the tile kernel and the shuffle kernel
+// skip every gather and take 0 for the rows' own values; the dense-chunk and the generic kernel read real zeros)
+bool gs_ignores_zero_vector(const DevCSR &A, int chunk) {
+  if (A.nrows == 0) return false;
+  if (gs_uses_tiles(A, chunk)) return true;
+  if (chunk != 8 || gs_force_generic()) return false;
+  return (double)A.nnz / (double)A.nrows <= 8.0;  // gs_group_k (see the dispatch in gs_hybrid)
+}
+
 void gs_hybrid(const DevCSR &A, const double *u_lo, const double *u_hi, int split, double *out, const double *f,
                const double *offc, const double *d, const signed char *cf, int points, int chunk, bool fwd, bool bwd,
                double w, int row_begin, int row_end, hipStream_t s, int prof, int zero_from, double *tout,
@@ -1522,8 +1554,7 @@ void dot(const double *x, const double *y, int n, double *out_dev, hipStream_t s
   const int g = vec_grid(n);
   double *partials = ctx().red_partials.p;
   prof_begin(PROF_DOT, s);
-  hipLaunchKernelGGL(dot_partial_k, dim3(g), dim3(256), 0, s, x, y, n, partials);
-  hipLaunchKernelGGL(reduce_final_k, dim3(1), dim3(256), 0, s, partials, g, out_dev);
+  hipLaunchKernelGGL(dot_partial_k, dim3(g), dim3(256), 0, s, x, y, n, partials, ctx().red_ticket.p, out_dev);
   prof_end(PROF_DOT, s);
   MI_HIP(hipGetLastError());
 }
@@ -1533,8 +1564,8 @@ void axpy_dot(const double *alpha_dev, double scale_, const double *xa, double *
   const int g = vec_grid(n);
   double *partials = ctx().red_partials.p;
   prof_begin(PROF_DOT, s);
-  hipLaunchKernelGGL(axpy_dot_partial_k, dim3(g), dim3(256), 0, s, alpha_dev, scale_, xa, y, xd, n, partials);
-  hipLaunchKernelGGL(reduce_final_k, dim3(1), dim3(256), 0, s, partials, g, out_dev);
+  hipLaunchKernelGGL(axpy_dot_partial_k, dim3(g), dim3(256), 0, s, alpha_dev, scale_, xa, y, xd, n, partials,
+                     ctx().red_ticket.p, out_dev);
   prof_end(PROF_DOT, s);
   MI_HIP(hipGetLastError());
 }

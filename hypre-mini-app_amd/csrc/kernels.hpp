@@ -81,6 +81,8 @@ constexpr int GS_NO_ZEROS = 0x7fffffff;
 // whether gs_hybrid sweeps A tile by tile (A.rb_host boundaries) rather than chunk by chunk: a caller that
 // splits one pass into several launches must cut at the unit the kernel writes back
 bool gs_uses_tiles(const DevCSR &A, int chunk);
+// whether a sweep with zero_from == 0 leaves the pre-sweep vector unread (its zero-fill can then be skipped)
+bool gs_ignores_zero_vector(const DevCSR &A, int chunk);
 void gs_hybrid(const DevCSR &A, const double *u_lo, const double *u_hi, int split, double *out, const double *f,
                const double *offc, const double *d, const signed char *cf, int points, int chunk, bool fwd, bool bwd,
                double w, int row_begin, int row_end, hipStream_t s, int prof = PROF_NONE, int zero_from = GS_NO_ZEROS,

@@ -116,7 +116,7 @@ const double *KrylovSolver::precond_in_order(BoomerAMG *amg, ParCSR &A, ParVecto
   for (int c = 0; c < nc; c++) {  // one cycle per component of a multivector
     const size_t o = (size_t)c * (size_t)n;
     L0.f.p = rhs.all() + o;  // read-only inside the cycle
-    k::fill(L0.u.p, n, 0.0, s);
+    if (!amg->zero_cycle_ignores_u(0)) k::fill(L0.u.p, n, 0.0, s);
     try {
       amg->cycle(0, true);
     } catch (...) {

@@ -215,6 +215,7 @@ struct Ctx {
   // scratch for two-stage reductions
   DVec<double> red_partials;  // MAX_RED_BLOCKS * MAX_RED_SLOTS
   DVec<double> red_out;       // result slots (device scalars)
+  DVec<unsigned> red_ticket;  // ticket counter of the reductions' last-block stage (kernels.hip finish_reduction)
   double *h_pinned = nullptr; // pinned host mirror of result slots
   int gs_chunk = 8;
   int verbose = 0;

@@ -112,6 +112,8 @@ void ensure_init() {
   MI_HIP(hipEventCreateWithFlags(&c.ev_halo, hipEventDisableTiming));
   c.red_partials.alloc((size_t)k::RED_MAX_BLOCKS * k::MASS_NV);
   c.red_out.alloc(256);
+  c.red_ticket.alloc(4);
+  MI_HIP(hipMemset(c.red_ticket.p, 0, 4 * sizeof(unsigned)));
   MI_HIP(hipHostMalloc((void **)&c.h_pinned, 256 * sizeof(double), hipHostMallocDefault));
   if (!c.comm) c.comm = make_self_comm();
   const char *ch = getenv("MI_HYPRE_GS_CHUNK");
