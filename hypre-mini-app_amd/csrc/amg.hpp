@@ -144,6 +144,14 @@ struct BoomerAMG {
   std::vector<int> tail_map_host;
   DVec<int> tail_map, tail_pcol;    // natural id -> all-gather position; halo columns of the last P
   void tail_cycle(bool zero_guess);
+  // ---- collapsed coarse tail (one rank, or the redundant tail hierarchy of N > 1): a cycle that starts from a zero
+  // guess is a LINEAR map f -> u, so for the first level with at most MI_HYPRE_DENSE_TAIL_ROWS (default 1024) rows the
+  // map of the whole sub-cycle (that level and everything below it) is tabulated at Setup by cycling the unit
+  // vectors, and the cycle multiplies by it: one launch instead of ~9 per level (at 512^3: levels 8-11, 36 of the
+  // ~75 latency-bound launches of a cycle).  Same operator, other rounding (1e-16 relative).
+  int collapsed_level = -1, collapsed_n = 0;
+  DVec<double> collapsed_Bt;  // column j of the map = row j here (n x n)
+  void build_collapsed_tail();
   void apply_global(const double *f, double *e, bool zero_guess);  // one cycle, caller (natural) ordering
   long long effective_redundant_rows() const;
   // levels of the whole hierarchy (the stub counts once, as the tail's fine level) and the owner of one

@@ -2309,6 +2309,13 @@ void BoomerAMG::setup_device() {
     tail_pcol.upload(pcol);
   }
   MI_HIP(hipDeviceSynchronize());
+  {
+    const double tc0 = wall_time();
+    build_collapsed_tail();
+    if (timing && collapsed_level >= 0)
+      printf("   collapsed coarse tail: levels %d.. as one %d x %d map, %.3f s\n", collapsed_level, collapsed_n, collapsed_n,
+             wall_time() - tc0);
+  }
   is_setup = true;
   setup_seconds = wall_time() - t_setup_start;
   if (timing) {

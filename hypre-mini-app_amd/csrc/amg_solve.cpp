@@ -316,6 +316,7 @@ bool BoomerAMG::zero_cycle_ignores_u(int level) {
   if (!enabled || my_comm().size != 1) return false;  // N > 1: the second pass sends pre-sweep (zero) values of its halo rows
   const int nlev = (int)L.size();
   AmgLevel &Lv = L[(size_t)level];
+  if (level == collapsed_level) return true;  // u = B f
   if (level == nlev - 1) {
     if (tail) return false;
     return p.relax_type[2] == 9 && Lv.dense && p.num_sweeps[2] > 0;  // u = C^-1 f
@@ -338,6 +339,10 @@ bool BoomerAMG::zero_cycle_ignores_u(int level) {
 void BoomerAMG::cycle(int level, bool u_is_zero) {
   const int nlev = (int)L.size();
   AmgLevel &Lv = L[(size_t)level];
+  if (level == collapsed_level && u_is_zero) {  // the tabulated map of this level's whole sub-cycle
+    k::dense_matvec_t(collapsed_Bt.p, Lv.f.p, Lv.u.p, collapsed_n, ctx().stream);
+    return;
+  }
   if (level == nlev - 1) {
     if (tail)
       tail_cycle(u_is_zero);
@@ -371,6 +376,50 @@ void BoomerAMG::cycle(int level, bool u_is_zero) {
     Lv.Pm->matvec(comm, 1.0, Ln.u.p, 1.0, Lv.u.p, Lv.u.p, s, k::prof_level(k::PROF_LVL_PROLONG, level));
   }
   relax_sweeps(level, 1, Lv.f.p, false);
+}
+
+void BoomerAMG::build_collapsed_tail() {
+  collapsed_level = -1;
+  collapsed_n = 0;
+  collapsed_Bt.release();
+  static const long long max_rows = getenv("MI_HYPRE_DENSE_TAIL_ROWS") ? atoll(getenv("MI_HYPRE_DENSE_TAIL_ROWS")) : 1024;
+  if (max_rows <= 0 || my_comm().size != 1 || tail) return;
+  const int nlev = (int)L.size();
+  int lt = -1;
+  for (int l = 1; l + 1 < nlev; l++)  // the coarsest level alone is one launch already
+    if (L[(size_t)l].n <= max_rows && L[(size_t)l].n > 0) {
+      lt = l;
+      break;
+    }
+  if (lt < 0) return;
+  AmgLevel &Lv = L[(size_t)lt];
+  const int n = Lv.n;
+  hipStream_t s = ctx().stream;
+  DVec<double> Bt((size_t)n * (size_t)n);
+  DVec<double> one(1);
+  const double h_one = 1.0;
+  MI_HIP(hipMemcpyAsync(one.p, &h_one, sizeof(double), hipMemcpyHostToDevice, s));
+  double *own_f = Lv.f.p;
+  DVec<double> e((size_t)n);
+  zero_on_stream(e.p, (size_t)n * sizeof(double));
+  Lv.f.p = e.p;
+  try {
+    for (int j = 0; j < n; j++) {
+      MI_HIP(hipMemcpyAsync(e.p + j, one.p, sizeof(double), hipMemcpyDeviceToDevice, s));
+      if (!zero_cycle_ignores_u(lt)) k::fill(Lv.u.p, n, 0.0, s);
+      cycle(lt, true);
+      MI_HIP(hipMemcpyAsync(Bt.p + (size_t)j * (size_t)n, Lv.u.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+      MI_HIP(hipMemsetAsync(e.p + j, 0, sizeof(double), s));
+    }
+    MI_HIP(hipStreamSynchronize(s));
+  } catch (...) {
+    Lv.f.p = own_f;
+    throw;
+  }
+  Lv.f.p = own_f;
+  collapsed_Bt = std::move(Bt);
+  collapsed_n = n;
+  collapsed_level = lt;
 }
 
 // the stub level's right-hand side (this rank's slice) -> whole level on every rank -> one cycle of the

@@ -917,19 +917,26 @@ __global__ __launch_bounds__(BLOCK) void gs_tile_k(int blk0, int nblk, const int
 // which block comes last and equals the two-launch form bit for bit.  One launch per inner product instead of two
 // (a GMRES solve of m steps issues m(m+1)/2 + 2m + 3 of them).  The ticket counter is reset by the last block;
 // reductions are serialised on the library stream, so one counter serves them all.
+// Ordering without a release fence: an agent-scope release would write this XCD's L2 back for EVERY block (the
+// vector the kernel has just stored included: measured +18 % on the fused Gram-Schmidt step).  Only the partial has
+// to be visible before the ticket, and both are agent-scope atomics executed at the device's coherence point: the
+// partial is stored by an exchange whose RETURN the lane waits for (s_waitcnt vmcnt(0): the operation has been
+// performed) before it draws the ticket; the last block reads the partials with agent-scope atomic loads after its
+// own ticket came back.
 __device__ __forceinline__ void finish_reduction(double block_sum, double *__restrict__ partials,
                                                  unsigned *__restrict__ ticket, double *__restrict__ out, double *ws) {
   __shared__ unsigned s_last;
   const int tid = threadIdx.x;
   if (tid == 0) {
-    __hip_atomic_store(partials + blockIdx.x, block_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();  // the partial is visible device-wide before the ticket is
-    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long *slot = reinterpret_cast<unsigned long long *>(partials + blockIdx.x);
+    const unsigned long long old =
+        __hip_atomic_exchange(slot, (unsigned long long)__double_as_longlong(block_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::"v"(old) : "memory");
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = (t == gridDim.x - 1) ? 1u : 0u;
   }
   __syncthreads();
   if (!s_last) return;
-  __threadfence();
   const int nb = (int)gridDim.x;
   double s = 0.0;
   for (int i = tid; i < nb; i += 256) s += __hip_atomic_load(partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1187,6 +1194,27 @@ __global__ __launch_bounds__(256) void dense_matvec_k(const double *__restrict__
   double s = 0.0;
   for (int j = 0; j < m; j++) s += M[(size_t)i * m + j] * f[j];
   u[i] = s;
+}
+
+// u[i] = sum_j Mt[j*n + i] * f[j]: a workgroup of 1024 lanes owns 64 consecutive rows i (lane & 63) and splits the
+// columns j over its 16 waves (coalesced 512-byte reads of Mt's rows); the 16 partial sums of a row are added in
+// wave order out of LDS -- a fixed order, the result does not depend on scheduling
+__global__ __launch_bounds__(1024) void dense_matvec_t_k(const double *__restrict__ Mt, const double *__restrict__ f,
+                                                         double *__restrict__ u, int n) {
+  __shared__ double part[16][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  double s = 0.0;
+  if (i < n)
+    for (int j = wv; j < n; j += 16) s += Mt[(size_t)j * (size_t)n + i] * f[j];
+  part[wv][lane] = s;
+  __syncthreads();
+  if (wv == 0 && i < n) {
+    double t = part[0][lane];
+#pragma unroll
+    for (int w = 1; w < 16; w++) t += part[w][lane];
+    u[i] = t;
+  }
 }
 
 inline int vec_grid(int n) {
@@ -1661,6 +1689,12 @@ void two_stage_lower(const DevCSR &A, const double *d, const double *zin, double
   if (A.nrows <= 0) return;
   hipLaunchKernelGGL(two_stage_lower_k, dim3((A.nrows + 255) / 256), dim3(256), 0, s, A.nrows, A.ia.p, A.ja.p, A.a.p, d,
                      zin, sign, zout, u);
+}
+
+void dense_matvec_t(const double *Mt, const double *f, double *u, int n, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(dense_matvec_t_k, dim3((n + 63) / 64), dim3(1024), 0, s, Mt, f, u, n);
+  MI_HIP(hipGetLastError());
 }
 
 void dense_matvec(const double *M, const double *f, double *u, int n, int m, hipStream_t s) {

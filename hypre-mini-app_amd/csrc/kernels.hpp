@@ -113,6 +113,8 @@ void two_stage_lower(const DevCSR &A, const double *d, const double *zin, double
                      hipStream_t s);
 // u = M f, M dense n x m row-major
 void dense_matvec(const double *M, const double *f, double *u, int n, int m, hipStream_t s);
+// u = sum_j f[j] * Mt[j][:], Mt n x n row-major (row j = column j of the map); fixed summation order
+void dense_matvec_t(const double *Mt, const double *f, double *u, int n, hipStream_t s);
 
 // IJ helpers
 void scatter_set(double *x, const int *idx, const double *vals, int n, hipStream_t s);

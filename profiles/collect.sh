@@ -12,12 +12,13 @@ mode=${1:-stats}
 cd /tmp
 if [ "$mode" = stats ]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof_stats" -- \
-    python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu > "$REPO/gpurun_out/prof_stats.log" 2>&1
+    python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu --no-general > "$REPO/gpurun_out/prof_stats.log" 2>&1
+  python3 "$REPO/profiles/gap_analysis.py" "$(ls -t "$REPO"/gpurun_out/prof_stats/*/*_kernel_trace.csv | head -1)" > "$REPO/gpurun_out/gaps_512.txt" 2>&1 || true
 else
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$REPO/gpurun_out/prof_fetch" -- \
-    python3 "$REPO/bench.py" --steps 1 --warmup 0 --no-cpu > "$REPO/gpurun_out/prof_fetch.log" 2>&1
+    python3 "$REPO/bench.py" --steps 1 --warmup 0 --no-cpu ${PMC_BENCH_ARGS:---no-general} > "$REPO/gpurun_out/prof_fetch.log" 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$REPO/gpurun_out/prof_write" -- \
-    python3 "$REPO/bench.py" --steps 1 --warmup 0 --no-cpu > "$REPO/gpurun_out/prof_write.log" 2>&1
+    python3 "$REPO/bench.py" --steps 1 --warmup 0 --no-cpu ${PMC_BENCH_ARGS:---no-general} > "$REPO/gpurun_out/prof_write.log" 2>&1
 fi
 find "$REPO/gpurun_out" -name "*.csv" -size +60M -delete   # keep the merge-back small
 ls -la "$REPO"/gpurun_out/prof_*/*/ 2>/dev/null | tail -20
