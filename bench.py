@@ -50,6 +50,9 @@ def parse():
                          "BoomerAMG, WEAK scaling (n^3 rows per rank, z-slabs stacked)")
     ap.add_argument("--segregated", type=int, default=0,
                     help="convdiff3: 1 = one solve per component (segregated_solve 1), 0 = one multivector solve")
+    ap.add_argument("--halo-transport", choices=("rccl", "ipc"), default=os.environ.get("MI_BENCH_HALO_TRANSPORT", "rccl"),
+                    help="N > 1: how the halo updates travel -- rccl = ncclSend/ncclRecv groups (default), ipc = peer stores into "
+                         "hipIpc-mapped mailboxes (HYPRE_MI_CommEnablePeerStoreExchange); reductions are RCCL either way")
     ap.add_argument("--amg", action="append", default=[], metavar="KEY=VALUE",
                     help="boomeramg_settings override for a side-line (e.g. --amg agg_num_levels=1); the headline "
                          "configuration is the one without overrides")
@@ -364,6 +367,10 @@ def main():
                 print("[bench] WARNING: falling back to the torch.distributed transport", file=sys.stderr, flush=True)
             mi.call("HYPRE_MI_CommFinalize")
             mi.init_comm_torch(dist, device=None)
+
+    if world > 1 and args.halo_transport == "ipc":
+        mi.call("HYPRE_MI_CommEnablePeerStoreExchange", mi.c_big(0))
+        transport = "halo updates: peer stores into hipIpc-mapped mailboxes (one launch per exchange); " + transport
 
     if args.workload == "convdiff3":
         return run_convdiff3(args, mi, dist, rank, world, transport, rehearsal, torch)

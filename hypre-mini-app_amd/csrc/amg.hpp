@@ -118,6 +118,7 @@ struct BoomerAMG {
   // gathers / scatters caller vectors as before.
   std::vector<int> input_order;
   std::unique_ptr<ParCSR> Aq_own;
+  sk::DCsr pending_sA0;  // Q A Q^T built on the device by setup_host, handed to level 0 by build_natural
   bool use_locality_order(const ParCSR &A) const;
   // the matrix HYPRE_BoomerAMGSetup was called with (and its assembly stamp): a Krylov solver may run on the
   // hierarchy's own level-0 copy only when it is handed that very matrix (krylov.cpp amg_in_level_order)

@@ -1249,145 +1249,133 @@ void BoomerAMG::apply_cf_ordering() {
 // The x-cache kernels gather, per tile of <= 256 consecutive rows, the tile's unique columns; with a lexicographic
 // numbering of a 3-D problem a tile is a piece of ONE grid line and gathers ~5 distinct columns per row, a
 // brick-shaped tile ~2.3 (profiles/run_numbering_experiment.py: numbering the same Laplacian by 8x8x8 bricks makes
-// the solve 10 % faster per iteration at 256^3).  The geometry is not known here, so bricks are grown on the
-// matrix graph: rows are cut into fixed segments of 2^20 consecutive rows (threads; the result does not depend on
-// the thread count), and inside a segment every still unassigned row, in ascending order, seeds a breadth-first
-// ball of up to 512 unassigned rows.  New order = clusters in seed order, natural order inside a cluster (a stable
-// sort by cluster label); the coarse levels inherit it, C points keeping their relative order.
+// the solve 10 % faster per iteration at 256^3).  The geometry is not known here, so compact clusters are grown on
+// the matrix graph.  Round 3: graph Voronoi cells instead of sequential breadth-first balls -- every row whose
+// hashed index is 0 modulo the cluster size (1024) is a seed, labelled by its rank among the seeds; in rounds, every
+// still unlabelled row takes the smallest label among its neighbours labelled in the PREVIOUS round (so the result
+// depends neither on threads nor on scheduling), until nothing changes (at most 64 rounds; what is farther than
+// that from every seed forms one last cluster in natural order).  New order = clusters in seed order, natural order
+// inside a cluster (a stable sort by label); the coarse levels inherit it, C points keeping their relative order.
+// Tile statistics equal those of the breadth-first balls of 512 rows within a few percent (U / entries at 96^3,
+// levels 0-3: 0.433 0.267 0.254 0.315 against 0.423 0.262 0.272 0.360; cells of 512: 0.432 0.265 0.273 0.357), but the rounds are plain data-parallel passes: 512^3 takes tens of
+// milliseconds on the device (sk::locality_labels) where the sequential balls took ~2 s of host threads, and the
+// permuted operator is built on the device from the copy HYPRE_IJMatrixAssemble left there (setup_host).
 namespace hs {
-constexpr int LOCALITY_SEGMENT = 1 << 20;
-const int LOCALITY_CLUSTER = getenv("MI_HYPRE_LOCALITY_CLUSTER") ? std::max(8, atoi(getenv("MI_HYPRE_LOCALITY_CLUSTER"))) : 512;
+const int LOCALITY_CLUSTER = getenv("MI_HYPRE_LOCALITY_CLUSTER") ? std::max(8, atoi(getenv("MI_HYPRE_LOCALITY_CLUSTER"))) : 1024;
+
+// seeds of the clustering in ascending order (exclude: rows that stay out); never empty unless every row is excluded
+std::vector<int> locality_seeds(int n, const std::vector<char> *exclude) {
+  const unsigned long long cl = (unsigned long long)LOCALITY_CLUSTER;
+  const int nt = std::max(1, host_threads());
+  std::vector<std::vector<int>> part((size_t)nt + 1);
+  parallel_for(n, [&](int64_t b, int64_t e, int t) {
+    std::vector<int> &mine = part[(size_t)t];
+    for (int64_t i = b; i < e; i++) {
+      if (exclude && (*exclude)[(size_t)i]) continue;
+      unsigned long long z = (unsigned long long)i + 0x9E3779B97F4A7C15ULL;  // splitmix64
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+      z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+      z ^= z >> 31;
+      if (z % cl == 0) mine.push_back((int)i);
+    }
+  });
+  std::vector<int> seeds;
+  for (auto &v : part) seeds.insert(seeds.end(), v.begin(), v.end());
+  std::sort(seeds.begin(), seeds.end());  // parallel_for hands out ascending ranges, but not necessarily thread 0 first
+  if (seeds.empty())
+    for (int i = 0; i < n; i++)
+      if (!exclude || !(*exclude)[(size_t)i]) {
+        seeds.push_back(i);
+        break;
+      }
+  return seeds;
+}
+
+// labels (seed rank, nseeds = farther than the round limit from every seed, LOCALITY_EXCLUDED) -> order[new] = old:
+// stable counting sort, the excluded rows last in natural order
+void locality_sort(const std::vector<int> &label, int nseeds, std::vector<int> &order) {
+  const int n = (int)label.size();
+  const int nlab = nseeds + 2;  // clusters, the unreached rest, the excluded rows
+  const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (int64_t)n / 65536 + 1));
+  std::vector<std::vector<int64_t>> hist((size_t)nt, std::vector<int64_t>((size_t)nlab, 0));
+  const int64_t per = ((int64_t)n + nt - 1) / nt;
+  auto lab = [&](int i) { return label[(size_t)i] == LOCALITY_EXCLUDED ? nseeds + 1 : label[(size_t)i]; };
+  {
+    std::vector<std::thread> th;
+    auto count = [&](int t) {
+      std::vector<int64_t> &h = hist[(size_t)t];
+      for (int64_t i = t * per; i < std::min<int64_t>(n, (t + 1) * per); i++) h[(size_t)lab((int)i)]++;
+    };
+    for (int t = 1; t < nt; t++) th.emplace_back(count, t);
+    count(0);
+    for (auto &x : th) x.join();
+  }
+  int64_t run = 0;
+  for (int c = 0; c < nlab; c++)
+    for (int t = 0; t < nt; t++) {
+      const int64_t h = hist[(size_t)t][(size_t)c];
+      hist[(size_t)t][(size_t)c] = run;
+      run += h;
+    }
+  order.resize((size_t)n);
+  {
+    std::vector<std::thread> th;
+    auto place = [&](int t) {
+      std::vector<int64_t> &h = hist[(size_t)t];
+      for (int64_t i = t * per; i < std::min<int64_t>(n, (t + 1) * per); i++) order[(size_t)h[(size_t)lab((int)i)]++] = (int)i;
+    };
+    for (int t = 1; t < nt; t++) th.emplace_back(place, t);
+    place(0);
+    for (auto &x : th) x.join();
+  }
+}
 
 // exclude (optional): rows that stay out of the clustering and come LAST, in natural order (rows with halo
 // entries on N > 1 ranks: the halo-free rows then form one stretch that is swept while the halo travels)
 void locality_order(const HostCSR &D, std::vector<int> &order, const std::vector<char> *exclude) {
   const int n = D.nrows;
+  const std::vector<int> seeds = locality_seeds(n, exclude);
+  const int nseeds = (int)seeds.size();
   std::vector<int> label((size_t)n, -1);
-  constexpr int EXCLUDED = 1 << 30;
   if (exclude)
-    for (int i = 0; i < n; i++)
-      if ((*exclude)[(size_t)i]) label[(size_t)i] = EXCLUDED;
-  const int nseg = (n + LOCALITY_SEGMENT - 1) / LOCALITY_SEGMENT;
-  std::vector<int> seg_clusters((size_t)nseg, 0);
-  // segments are independent: threads take them from a shared counter (parallel_for does not split short ranges)
-  std::atomic<int> next_seg(0);
-  // MI_HYPRE_LOCALITY_GROW=1 (experiment): instead of breadth-first order, always add the frontier row with the most
-  // neighbours already inside the cluster (ties: first come) -- grows bricks rather than diamonds on grid graphs
-  static const bool greedy_grow = getenv("MI_HYPRE_LOCALITY_GROW") && atoi(getenv("MI_HYPRE_LOCALITY_GROW")) != 0;
-  auto worker = [&]() {
-    std::vector<int> queue;
-    queue.reserve(LOCALITY_CLUSTER + 64);
-    constexpr int MAXC = 16;
-    std::vector<std::vector<int>> bucket(MAXC + 1);
-    std::vector<size_t> bhead(MAXC + 1, 0);
-    std::vector<unsigned char> cnt;
-    for (int sg = next_seg++; sg < nseg; sg = next_seg++) {
-      const int r0 = (int)((int64_t)sg * LOCALITY_SEGMENT), r1 = (int)std::min<int64_t>(n, ((int64_t)sg + 1) * LOCALITY_SEGMENT);
-      int ncl = 0;
-      if (greedy_grow) cnt.assign((size_t)(r1 - r0), 0);
-      for (int seed = r0; seed < r1; seed++) {
-        if (label[(size_t)seed] >= 0) continue;
-        if (greedy_grow) {
-          for (int c = 0; c <= MAXC; c++) bucket[(size_t)c].clear(), bhead[(size_t)c] = 0;
-          int size = 0, v = seed;
-          std::vector<int> touched;
-          for (;;) {
-            label[(size_t)v] = ncl;
-            size++;
-            if (size >= LOCALITY_CLUSTER) break;
-            for (int64_t k = D.ia[(size_t)v]; k < D.ia[(size_t)v + 1]; k++) {
-              const int j = D.ja[(size_t)k];
-              if (j < r0 || j >= r1 || label[(size_t)j] >= 0) continue;
-              unsigned char &c = cnt[(size_t)(j - r0)];
-              if (c == 0) touched.push_back(j);
-              if (c < MAXC) c++;
-              bucket[(size_t)c].push_back(j);
-            }
-            v = -1;
-            for (int c = MAXC; c >= 1 && v < 0; c--) {
-              std::vector<int> &b = bucket[(size_t)c];
-              size_t &h = bhead[(size_t)c];
-              while (h < b.size()) {
-                const int u = b[h++];
-                if (label[(size_t)u] < 0 && cnt[(size_t)(u - r0)] == c) {  // not stale
-                  v = u;
-                  break;
-                }
-              }
-            }
-            if (v < 0) break;
-          }
-          for (int u : touched) cnt[(size_t)(u - r0)] = 0;
-          ncl++;
-          continue;
+    parallel_for(n, [&](int64_t b, int64_t e, int) {
+      for (int64_t i = b; i < e; i++)
+        if ((*exclude)[(size_t)i]) label[(size_t)i] = LOCALITY_EXCLUDED;
+    });
+  for (int k = 0; k < nseeds; k++) label[(size_t)seeds[(size_t)k]] = k;
+  std::vector<int> active;
+  active.reserve((size_t)n);
+  for (int i = 0; i < n; i++)
+    if (label[(size_t)i] == -1) active.push_back(i);
+  std::vector<int> next;
+  for (int round = 0; round < LOCALITY_MAX_ROUNDS && !active.empty(); round++) {
+    next.assign(active.size(), -1);
+    parallel_for((int64_t)active.size(), [&](int64_t b, int64_t e, int) {
+      for (int64_t q = b; q < e; q++) {
+        const int i = active[(size_t)q];
+        int m = -1;
+        for (int64_t k = D.ia[(size_t)i]; k < D.ia[(size_t)i + 1]; k++) {
+          const int lj = label[(size_t)D.ja[(size_t)k]];
+          if (lj >= 0 && (m < 0 || lj < m)) m = lj;
         }
-        queue.clear();
-        queue.push_back(seed);
-        label[(size_t)seed] = ncl;
-        for (size_t head = 0; head < queue.size() && (int)queue.size() < LOCALITY_CLUSTER; head++) {
-          const int v = queue[head];
-          for (int64_t k = D.ia[(size_t)v]; k < D.ia[(size_t)v + 1]; k++) {
-            const int j = D.ja[(size_t)k];
-            if (j < r0 || j >= r1 || label[(size_t)j] >= 0) continue;
-            label[(size_t)j] = ncl;
-            queue.push_back(j);
-            if ((int)queue.size() >= LOCALITY_CLUSTER) break;
-          }
-        }
-        ncl++;
+        next[(size_t)q] = m;
       }
-      seg_clusters[(size_t)sg] = ncl;
+    });
+    size_t w = 0;
+    for (size_t q = 0; q < active.size(); q++) {
+      if (next[q] >= 0)
+        label[(size_t)active[q]] = next[q];
+      else
+        active[w++] = active[q];
     }
-  };
-  {
-    const int nt = std::max(1, std::min(nseg, host_threads()));
-    std::vector<std::thread> th;
-    for (int t = 1; t < nt; t++) th.emplace_back(worker);
-    worker();
-    for (auto &x : th) x.join();
+    if (w == active.size()) break;  // nothing changed
+    active.resize(w);
   }
-  // stable counting sort by (segment, cluster label): a segment's clustered rows stay inside one contiguous range
-  // of the new order (segments in order, the excluded rows after all of them), so every segment sorts its own
-  std::vector<int64_t> seg_rows((size_t)nseg + 1, 0);  // clustered (non-excluded) rows per segment, then prefix
-  std::vector<std::thread> th;
-  std::atomic<int> next2(0);
-  auto count_worker = [&]() {
-    for (int sg = next2++; sg < nseg; sg = next2++) {
-      const int r0 = (int)((int64_t)sg * LOCALITY_SEGMENT), r1 = (int)std::min<int64_t>(n, ((int64_t)sg + 1) * LOCALITY_SEGMENT);
-      int64_t c = 0;
-      for (int i = r0; i < r1; i++) c += (label[(size_t)i] != EXCLUDED);
-      seg_rows[(size_t)sg + 1] = c;
-    }
-  };
-  const int nt2 = std::max(1, std::min(nseg, host_threads()));
-  for (int t = 1; t < nt2; t++) th.emplace_back(count_worker);
-  count_worker();
-  for (auto &x : th) x.join();
-  th.clear();
-  for (int sg = 0; sg < nseg; sg++) seg_rows[(size_t)sg + 1] += seg_rows[(size_t)sg];
-  order.resize((size_t)n);
-  std::atomic<int> next3(0);
-  auto sort_worker = [&]() {
-    std::vector<int64_t> start;
-    for (int sg = next3++; sg < nseg; sg = next3++) {
-      const int r0 = (int)((int64_t)sg * LOCALITY_SEGMENT), r1 = (int)std::min<int64_t>(n, ((int64_t)sg + 1) * LOCALITY_SEGMENT);
-      start.assign((size_t)seg_clusters[(size_t)sg] + 1, 0);
-      for (int i = r0; i < r1; i++)
-        if (label[(size_t)i] != EXCLUDED) start[(size_t)label[(size_t)i] + 1]++;
-      start[0] = seg_rows[(size_t)sg];
-      for (size_t c = 0; c + 1 < start.size(); c++) start[c + 1] += start[c];
-      for (int i = r0; i < r1; i++)
-        if (label[(size_t)i] != EXCLUDED) order[(size_t)start[(size_t)label[(size_t)i]]++] = i;
-    }
-  };
-  for (int t = 1; t < nt2; t++) th.emplace_back(sort_worker);
-  sort_worker();
-  for (auto &x : th) x.join();
-  if (exclude) {  // the excluded rows last, natural order
-    int64_t w = seg_rows[(size_t)nseg];
-    for (int i = 0; i < n; i++)
-      if (label[(size_t)i] == EXCLUDED) order[(size_t)w++] = i;
-  }
+  parallel_for(n, [&](int64_t b, int64_t e, int) {
+    for (int64_t i = b; i < e; i++)
+      if (label[(size_t)i] == -1) label[(size_t)i] = nseeds;
+  });
+  locality_sort(label, nseeds, order);
 }
 
 // B = Q A Q^T: rows of A in `order` (new -> old), columns renumbered, rows re-sorted
@@ -1484,12 +1472,43 @@ void BoomerAMG::setup_host(ParCSR &A0) {
     input_order.clear();
     Aq_own.reset();
     ParCSR *Ain = &A0;
+    pending_sA0.release();
     if (use_locality_order(A0)) {
       const double tq0 = wall_time();
-      locality_order(A0.diag, input_order, nullptr);
       Aq_own.reset(new ParCSR());
       ParCSR &Q = *Aq_own;
-      permute_symmetric(A0.diag, input_order, Q.diag);
+      const int n0 = A0.nrows;
+      // on the device when the level will be built there anyway: the clustering rounds are data-parallel passes,
+      // and Q A Q^T is permuted from the copy HYPRE_IJMatrixAssemble left in HBM -- neither the host's copy of the
+      // permuted operator (0.94 G entries at 512^3) nor its upload exist any more
+      const bool on_dev = device_min_rows >= 0 && n0 >= device_min_rows && A0.on_device && A0.d_diag.nrows == n0 &&
+                          A0.d_diag.nnz == A0.diag.nnz() && !A0.d_diag.rowmap.p;
+      if (on_dev) {
+        hipStream_t s = ctx().stream;
+        sk::DCsr raw;
+        sk::from_solve_format(A0.d_diag, raw, s);
+        const std::vector<int> seeds = locality_seeds(n0, nullptr);
+        std::vector<int> label;
+        const int rounds = sk::locality_labels(raw, seeds.data(), (int)seeds.size(), nullptr, LOCALITY_MAX_ROUNDS, label, s);
+        const int nseeds = (int)seeds.size();
+        parallel_for(n0, [&](int64_t b, int64_t e, int) {
+          for (int64_t i = b; i < e; i++)
+            if (label[(size_t)i] < 0) label[(size_t)i] = nseeds;
+        });
+        locality_sort(label, nseeds, input_order);
+        DVec<int> dorder, dpos((size_t)n0);
+        dorder.upload(input_order);
+        sk::invert_permutation(dorder.p, n0, dpos.p, s);
+        sk::permute(raw, dorder.p, dpos.p, pending_sA0, s);
+        MI_HIP(hipStreamSynchronize(s));
+        Q.diag.nrows = Q.diag.ncols = n0;
+        Q.host_diag_stale = true;
+        Q.dev_diag_nnz = pending_sA0.nnz;
+        if (getenv("MI_HYPRE_SETUP_TIMING")) printf("   locality numbering on the device: %d seeds, %d rounds\n", nseeds, rounds);
+      } else {
+        locality_order(A0.diag, input_order, nullptr);
+        permute_symmetric(A0.diag, input_order, Q.diag);
+      }
       Q.nrows = A0.nrows;
       Q.row_start = A0.row_start;
       Q.row_end = A0.row_end;
@@ -1533,6 +1552,8 @@ void BoomerAMG::build_natural(ParCSR &A0) {
   L.reserve((size_t)std::max(1, p.max_levels));
   L.emplace_back();
   L[0].A = &A0;
+  if (pending_sA0.nrows == A0.nrows && pending_sA0.nrows > 0 && A0.host_diag_stale) L[0].sA = std::move(pending_sA0);
+  pending_sA0.release();
 
   int l = 0;
   stopped_by_rows = false;

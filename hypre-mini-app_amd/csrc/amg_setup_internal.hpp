@@ -22,6 +22,12 @@ void build_interp(const ParCSR &A, const Strength &S, std::vector<int> &cf, int 
 
 // locality numbering of a block's rows (amg_setup.cpp): order[new] = old; excluded rows (optional) come last
 void locality_order(const HostCSR &D, std::vector<int> &order, const std::vector<char> *exclude);
+// its pieces, shared with the device path: the seeds (ascending), and the stable sort of the final labels
+// (seed rank; nseeds = never reached; LOCALITY_EXCLUDED)
+constexpr int LOCALITY_EXCLUDED = -2;
+constexpr int LOCALITY_MAX_ROUNDS = 64;
+std::vector<int> locality_seeds(int n, const std::vector<char> *exclude);
+void locality_sort(const std::vector<int> &label, int nseeds, std::vector<int> &order);
 
 }  // namespace hs
 }  // namespace mi

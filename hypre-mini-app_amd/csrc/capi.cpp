@@ -1105,6 +1105,41 @@ HYPRE_Int HYPRE_MI_CommInitCallbacks(void *cctx, HYPRE_MI_AllreduceFn ar, HYPRE_
   ctx().comm = make_callback_comm(cb, rank, size);
   API_END
 }
+HYPRE_Int HYPRE_MI_CommEnablePeerStoreExchange(HYPRE_BigInt slot_bytes) {
+  API_BEGIN
+  ensure_init();
+  if (!ctx().comm || ctx().comm->size == 1) return 0;
+  if (slot_bytes <= 0) slot_bytes = getenv("MI_HYPRE_IPC_SLOT_BYTES") ? atoll(getenv("MI_HYPRE_IPC_SLOT_BYTES")) : (4 << 20);
+  if (slot_bytes % 16) fail(HYPRE_ERROR_ARG, "CommEnablePeerStoreExchange: the slot size must be a multiple of 16 bytes");
+  MI_HIP(hipDeviceSynchronize());
+  ctx().comm = make_ipc_exchange_comm(std::move(ctx().comm), (size_t)slot_bytes);
+  API_END
+}
+HYPRE_Int HYPRE_MI_CommExchangeDevice(HYPRE_Int nsend, const HYPRE_Int *send_peers, void *const *send_ptrs,
+                                      const size_t *send_bytes, HYPRE_Int nrecv, const HYPRE_Int *recv_peers,
+                                      void *const *recv_ptrs, const size_t *recv_bytes) {
+  API_BEGIN
+  ensure_init();
+  std::vector<PeerBuf> sb, rb;
+  for (int i = 0; i < nsend; i++) sb.push_back({send_peers[i], send_ptrs[i], send_bytes[i]});
+  for (int i = 0; i < nrecv; i++) rb.push_back({recv_peers[i], recv_ptrs[i], recv_bytes[i]});
+  hipStream_t s = ctx().stream;
+  current_comm().exchange_dev(sb, rb, s);
+  MI_HIP(hipStreamSynchronize(s));
+  comm_check_transport_error(current_comm(), s);
+  API_END
+}
+HYPRE_Int HYPRE_MI_CommCheck(void) {
+  API_BEGIN
+  if (ctx().inited && ctx().comm) comm_check_transport_error(*ctx().comm, ctx().stream);
+  API_END
+}
+HYPRE_Int HYPRE_MI_CommName(char *name, HYPRE_Int max_len) {
+  API_BEGIN
+  if (!name || max_len < 1) fail(HYPRE_ERROR_ARG, "CommName: no buffer");
+  snprintf(name, (size_t)max_len, "%s", current_comm().name());
+  API_END
+}
 HYPRE_Int HYPRE_MI_CommFinalize(void) {
   API_BEGIN
   if (ctx().inited) MI_HIP(hipDeviceSynchronize());

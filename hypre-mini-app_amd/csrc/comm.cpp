@@ -21,6 +21,7 @@
 
 #include <cstring>
 
+#include "kernels.hpp"
 #include "mi_internal.hpp"
 
 namespace mi {
@@ -317,7 +318,175 @@ struct CallbackComm : Comm {
     MI_HIP(hipStreamSynchronize(s));
   }
 };
+// ------------------------------------------------------------------ peer-store exchange over IPC-mapped mailboxes
+// The neighbour exchange of the halo updates without ncclSend/ncclRecv: every rank owns a mailbox arena in its HBM
+// (per peer: two slots of slot_bytes, a flag word and an ack word per slot), exported with hipIpcGetMemHandle and
+// mapped by every other rank (hipIpcOpenMemHandle: peer memory over xGMI, or the same device when ranks share a
+// GPU).  One kernel launch per exchange (k::ipc_exchange): the sender stores its packed halo straight into the
+// receiver's slot and publishes the message number; the receiver waits for it, copies the slot to its x_ext and
+// acknowledges.  Two slots per directed pair: message k + 2 waits for the acknowledgement of message k, which the
+// receiver posted long ago -- the sender practically never waits.  Everything else (all-reduce, all-gather, host
+// collectives, the bootstrap of the handles) goes through the communicator this one wraps (RCCL, or the caller's
+// callbacks).  Waits are bounded (MI_HYPRE_IPC_TIMEOUT_MS, default 20 s): a missing peer becomes an error, not a hang.
+struct IpcExchangeComm : Comm {
+  std::unique_ptr<Comm> inner;
+  size_t slot_bytes = 0;
+  char *arena = nullptr;                 // my mailboxes: [flags: size*2][acks: size*2][slots: size*2*slot_bytes]
+  std::vector<char *> peer_arena;        // every rank's arena as mapped here (self: my own pointer)
+  std::vector<unsigned long long> send_seq, recv_seq;
+  DVec<unsigned> tickets;
+  DVec<int> error_flag;
+  unsigned long long spin_limit = 0;
+  long long n_launch = 0;
+  std::string label;
+
+  size_t header_bytes() const { return (size_t)size * 4 * sizeof(unsigned long long); }
+  unsigned long long *flag_word(char *base, int from, int slot) const {
+    return reinterpret_cast<unsigned long long *>(base) + (size_t)from * 2 + slot;
+  }
+  unsigned long long *ack_word(char *base, int from, int slot) const {
+    return reinterpret_cast<unsigned long long *>(base) + (size_t)size * 2 + (size_t)from * 2 + slot;
+  }
+  char *slot_ptr(char *base, int from, int slot) const {
+    return base + ((header_bytes() + 255) / 256) * 256 + ((size_t)from * 2 + slot) * slot_bytes;
+  }
+
+  IpcExchangeComm(std::unique_ptr<Comm> in, size_t slot) : inner(std::move(in)), slot_bytes(slot) {
+    ensure_init();
+    rank = inner->rank;
+    size = inner->size;
+    label = std::string("ipc-peer-store + ") + inner->name();
+    const char *tm = getenv("MI_HYPRE_IPC_TIMEOUT_MS");
+    spin_limit = (unsigned long long)(tm ? atoll(tm) : 20000) * 100000ull;  // wall_clock64 ticks at 100 MHz
+    const size_t total = ((header_bytes() + 255) / 256) * 256 + (size_t)size * 2 * slot_bytes;
+    MI_HIP(hipMalloc((void **)&arena, total));
+    MI_HIP(hipMemset(arena, 0, total));
+    MI_HIP(hipDeviceSynchronize());
+    hipIpcMemHandle_t mine;
+    MI_HIP(hipIpcGetMemHandle(&mine, arena));
+    std::vector<hipIpcMemHandle_t> all((size_t)size);
+    inner->allgather_host(&mine, all.data(), sizeof(hipIpcMemHandle_t));
+    peer_arena.assign((size_t)size, nullptr);
+    for (int r = 0; r < size; r++) {
+      if (r == rank) {
+        peer_arena[(size_t)r] = arena;
+        continue;
+      }
+      void *p = nullptr;
+      MI_HIP(hipIpcOpenMemHandle(&p, all[(size_t)r], hipIpcMemLazyEnablePeerAccess));
+      peer_arena[(size_t)r] = (char *)p;
+    }
+    send_seq.assign((size_t)size, 0);
+    recv_seq.assign((size_t)size, 0);
+    tickets.alloc((size_t)k::IPC_MAX_TRANSFERS);
+    MI_HIP(hipMemset(tickets.p, 0, (size_t)k::IPC_MAX_TRANSFERS * sizeof(unsigned)));
+    error_flag.alloc(1);
+    MI_HIP(hipMemset(error_flag.p, 0, sizeof(int)));
+    MI_HIP(hipDeviceSynchronize());
+    inner->barrier();  // every arena is mapped everywhere before the first message
+  }
+  ~IpcExchangeComm() override {
+    (void)hipDeviceSynchronize();
+    for (int r = 0; r < size; r++)
+      if (r != rank && peer_arena[(size_t)r]) (void)hipIpcCloseMemHandle(peer_arena[(size_t)r]);
+    if (arena) (void)hipFree(arena);
+  }
+  const char *name() const override { return label.c_str(); }
+  bool host_transport() const override { return inner->host_transport(); }
+  void allreduce_dev(void *buf, size_t count, CommDType t, CommOp op, hipStream_t s) override {
+    inner->allreduce_dev(buf, count, t, op, s);
+  }
+  void allgather_dev(const void *send, void *recv, size_t bytes, hipStream_t s) override {
+    inner->allgather_dev(send, recv, bytes, s);
+  }
+  void allreduce_host(void *buf, size_t count, CommDType t, CommOp op) override { inner->allreduce_host(buf, count, t, op); }
+  void allgather_host(const void *send, void *recv, size_t bytes) override { inner->allgather_host(send, recv, bytes); }
+  void exchange_host_fixed(const std::vector<PeerBuf> &sends, const std::vector<PeerBuf> &recvs) override {
+    inner->exchange_host_fixed(sends, recvs);
+  }
+  void check_error(hipStream_t s) {
+    int e = 0;
+    MI_HIP(hipMemcpyAsync(&e, error_flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    if (e) fail(1, "peer-store exchange: a neighbour's message did not arrive within the time limit (MI_HYPRE_IPC_TIMEOUT_MS)");
+  }
+  // messages larger than a slot travel in slot-sized parts, each with its own sequence number (both sides know the
+  // sizes, so they agree on the parts)
+  void exchange_dev(const std::vector<PeerBuf> &sends, const std::vector<PeerBuf> &recvs, hipStream_t s) override {
+    if (sends.empty() && recvs.empty()) return;
+    k::IpcBatch B;
+    B.n = 0;
+    auto flush = [&]() {
+      if (B.n == 0) return;
+      k::ipc_exchange(B, spin_limit, error_flag.p, s);
+      n_launch++;
+      B.n = 0;
+    };
+    auto push = [&](const k::IpcTransfer &t) {
+      // one launch holds every part it can; a ticket slot belongs to one transfer of the launch
+      if (B.n == k::IPC_MAX_TRANSFERS) flush();
+      B.t[B.n] = t;
+      B.t[B.n].ticket = tickets.p + B.n;
+      B.n++;
+    };
+    auto blocks_for = [](size_t bytes) { return bytes >= (1u << 20) ? 4 : bytes >= (1u << 18) ? 2 : 1; };
+    // sends first: a launch's workgroups start in order, and nobody's receive can complete before the sends are out
+    for (const auto &b : sends) {
+      MI_REQUIRE(b.peer >= 0 && b.peer < size && b.peer != rank, "peer-store exchange: bad peer");
+      for (size_t off = 0; off < b.bytes || (b.bytes == 0 && off == 0); off += slot_bytes) {
+        const size_t part = std::min(slot_bytes, b.bytes - off);
+        const unsigned long long seq = ++send_seq[(size_t)b.peer];
+        const int slot = (int)(seq & 1);
+        k::IpcTransfer t{};
+        t.kind = 0;
+        t.nblocks = blocks_for(part);
+        t.bytes = part;
+        t.src = (const char *)b.ptr + off;
+        t.dst = slot_ptr(peer_arena[(size_t)b.peer], rank, slot);
+        t.wait_word = ack_word(arena, b.peer, slot);  // the peer acknowledges in MY arena
+        t.wait_value = seq >= 2 ? seq - 2 : 0;
+        t.post_word = flag_word(peer_arena[(size_t)b.peer], rank, slot);
+        t.post_value = seq;
+        push(t);
+        if (b.bytes == 0) break;
+      }
+    }
+    for (const auto &b : recvs) {
+      MI_REQUIRE(b.peer >= 0 && b.peer < size && b.peer != rank, "peer-store exchange: bad peer");
+      for (size_t off = 0; off < b.bytes || (b.bytes == 0 && off == 0); off += slot_bytes) {
+        const size_t part = std::min(slot_bytes, b.bytes - off);
+        const unsigned long long seq = ++recv_seq[(size_t)b.peer];
+        const int slot = (int)(seq & 1);
+        k::IpcTransfer t{};
+        t.kind = 1;
+        t.nblocks = blocks_for(part);
+        t.bytes = part;
+        t.src = slot_ptr(arena, b.peer, slot);
+        t.dst = (char *)b.ptr + off;
+        t.wait_word = flag_word(arena, b.peer, slot);
+        t.wait_value = seq;
+        t.post_word = ack_word(peer_arena[(size_t)b.peer], rank, slot);
+        t.post_value = seq;
+        push(t);
+        if (b.bytes == 0) break;
+      }
+    }
+    flush();
+  }
+};
 }  // namespace
+
+std::unique_ptr<Comm> make_ipc_exchange_comm(std::unique_ptr<Comm> inner, size_t slot_bytes) {
+  if (inner->size == 1) return inner;
+  return std::unique_ptr<Comm>(new IpcExchangeComm(std::move(inner), slot_bytes));
+}
+bool comm_check_transport_error(Comm &c, hipStream_t s) {
+  if (auto *ipc = dynamic_cast<IpcExchangeComm *>(&c)) {
+    ipc->check_error(s);
+    return true;
+  }
+  return false;
+}
 
 std::unique_ptr<Comm> make_self_comm() { return std::unique_ptr<Comm>(new SelfComm()); }
 std::unique_ptr<Comm> make_rccl_comm(const void *id, int rank, int size) {

@@ -1217,6 +1217,58 @@ __global__ __launch_bounds__(1024) void dense_matvec_t_k(const double *__restric
   }
 }
 
+// peer-store neighbour exchange: see kernels.hpp.  blockIdx.x walks the transfers' workgroups in order.
+__global__ __launch_bounds__(1024) void ipc_exchange_k(IpcBatch B, unsigned long long spin_limit, int *error_flag) {
+  __shared__ int s_ok;
+  int blk = (int)blockIdx.x, ti = 0;
+  while (ti < B.n && blk >= B.t[ti].nblocks) blk -= B.t[ti++].nblocks;
+  if (ti >= B.n) return;
+  const IpcTransfer &T = B.t[ti];
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    int ok = 1;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(T.wait_word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < T.wait_value) {
+      if (wall_clock64() - t0 > spin_limit) {  // the peer never arrived: say so and fall through (no hang)
+        ok = 0;
+        atomicExch(error_flag, 1);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    s_ok = ok;
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // what the peer stored before its flag is visible
+  if (s_ok) {
+    const unsigned long long n16 = T.bytes / 16;
+    const bool al = ((((unsigned long long)T.src) | ((unsigned long long)T.dst)) & 15ull) == 0;
+    const unsigned long long stride = (unsigned long long)T.nblocks * 1024ull;
+    if (al) {
+      const d2_t *sp = reinterpret_cast<const d2_t *>(T.src);
+      d2_t *dp = reinterpret_cast<d2_t *>(T.dst);
+      for (unsigned long long i = (unsigned long long)blk * 1024ull + tid; i < n16; i += stride) dp[i] = sp[i];
+      const unsigned char *sb = reinterpret_cast<const unsigned char *>(T.src);
+      unsigned char *db = reinterpret_cast<unsigned char *>(T.dst);
+      for (unsigned long long i = n16 * 16 + (unsigned long long)blk * 1024ull + tid; i < T.bytes; i += stride) db[i] = sb[i];
+    } else {
+      const unsigned char *sb = reinterpret_cast<const unsigned char *>(T.src);
+      unsigned char *db = reinterpret_cast<unsigned char *>(T.dst);
+      for (unsigned long long i = (unsigned long long)blk * 1024ull + tid; i < T.bytes; i += stride) db[i] = sb[i];
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // this workgroup's stores are out
+    const unsigned done = __hip_atomic_fetch_add(T.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == (unsigned)T.nblocks - 1) {
+      __hip_atomic_store(T.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "");
+      __hip_atomic_store(T.post_word, T.post_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 inline int vec_grid(int n) {
   long long want = ((long long)n + 511) / 512;
   if (want < 1) want = 1;
@@ -1689,6 +1741,14 @@ void two_stage_lower(const DevCSR &A, const double *d, const double *zin, double
   if (A.nrows <= 0) return;
   hipLaunchKernelGGL(two_stage_lower_k, dim3((A.nrows + 255) / 256), dim3(256), 0, s, A.nrows, A.ia.p, A.ja.p, A.a.p, d,
                      zin, sign, zout, u);
+}
+
+void ipc_exchange(const IpcBatch &b, unsigned long long spin_limit, int *error_flag, hipStream_t s) {
+  int nb = 0;
+  for (int i = 0; i < b.n; i++) nb += b.t[i].nblocks;
+  if (nb == 0) return;
+  hipLaunchKernelGGL(ipc_exchange_k, dim3((unsigned)nb), dim3(1024), 0, s, b, spin_limit, error_flag);
+  MI_HIP(hipGetLastError());
 }
 
 void dense_matvec_t(const double *Mt, const double *f, double *u, int n, hipStream_t s) {

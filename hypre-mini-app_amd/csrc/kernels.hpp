@@ -116,6 +116,31 @@ void dense_matvec(const double *M, const double *f, double *u, int n, int m, hip
 // u = sum_j f[j] * Mt[j][:], Mt n x n row-major (row j = column j of the map); fixed summation order
 void dense_matvec_t(const double *Mt, const double *f, double *u, int n, hipStream_t s);
 
+// ---- peer-store neighbour exchange (comm.cpp IpcExchangeComm): one launch moves every message of a halo update.
+// A SEND copies local data into the mailbox slot the peer holds for this rank (an IPC-mapped pointer: stores over
+// xGMI) and then publishes the message's sequence number in the peer's flag word; a RECV waits for its flag word,
+// copies its own mailbox slot to the destination and acknowledges in the peer's ack word, which is what the
+// sender's NEXT use of that slot waits for.  Every wait is bounded (spin_limit ticks of the 100 MHz wall clock):
+// a peer that never arrives sets *error_flag instead of hanging the GPU.
+struct IpcTransfer {
+  int kind;                      // 0 send, 1 recv
+  int nblocks;                   // workgroups that share the copy
+  unsigned long long bytes;
+  const void *src;               // send: local data; recv: my mailbox slot
+  void *dst;                     // send: the peer's mailbox slot; recv: local destination
+  unsigned long long *wait_word; // send: my ack word for this slot (peer wrote it); recv: my flag word
+  unsigned long long wait_value; // proceed when *wait_word >= wait_value
+  unsigned long long *post_word; // send: the peer's flag word; recv: the peer's ack word
+  unsigned long long post_value;
+  unsigned *ticket;              // per-transfer counter of finished workgroups (self-resetting)
+};
+constexpr int IPC_MAX_TRANSFERS = 16;
+struct IpcBatch {
+  IpcTransfer t[IPC_MAX_TRANSFERS];
+  int n;
+};
+void ipc_exchange(const IpcBatch &b, unsigned long long spin_limit, int *error_flag, hipStream_t s);
+
 // IJ helpers
 void scatter_set(double *x, const int *idx, const double *vals, int n, hipStream_t s);
 void scatter_add(double *x, const int *idx, const double *vals, int n, hipStream_t s);

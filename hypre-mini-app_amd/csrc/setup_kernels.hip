@@ -892,6 +892,37 @@ __global__ __launch_bounds__(BLK) void ia_to_64_k(long long n1, const int *__res
   if (i < n1) ia[i] = ia32[i];
 }
 
+// ---- internal locality numbering (amg_setup.cpp: graph Voronoi cells): one round -- every unlabelled row (-1) takes
+// the smallest label among its neighbours labelled in the previous round; labelled and excluded (-2) rows are copied
+__global__ __launch_bounds__(BLK) void locality_round_k(int n, const long long *__restrict__ ia, const int *__restrict__ ja,
+                                                        const int *__restrict__ in, int *__restrict__ out,
+                                                        int *__restrict__ changed) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  int li = in[i];
+  if (li == -1) {
+    int m = -1;
+    const long long k1 = ia[i + 1];
+    for (long long k = ia[i]; k < k1; k++) {
+      const int lj = in[ja[k]];
+      if (lj >= 0 && (m < 0 || lj < m)) m = lj;
+    }
+    if (m >= 0) {
+      li = m;
+      *changed = 1;  // every writer stores the same value
+    }
+  }
+  out[i] = li;
+}
+__global__ __launch_bounds__(BLK) void locality_seed_k(int nseeds, const int *__restrict__ seeds, int *__restrict__ label) {
+  const int k = blockIdx.x * BLK + threadIdx.x;
+  if (k < nseeds) label[seeds[k]] = k;
+}
+__global__ __launch_bounds__(BLK) void invert_perm_k(int n, const int *__restrict__ order, int *__restrict__ pos) {
+  const int q = blockIdx.x * BLK + threadIdx.x;
+  if (q < n) pos[order[q]] = q;
+}
+
 constexpr int LEN_BINS = 4096;
 // every thread walks RUN consecutive rows and merges equal neighbours before it touches the (LDS) histogram:
 // uniform row lengths (stencil matrices) would otherwise serialise on one counter
@@ -1450,6 +1481,63 @@ void solve_format_to_host(const DevCSR &src, HostCSR &h, hipStream_t s) {
     }
     h = std::move(o);
   }
+}
+
+void from_solve_format(const DevCSR &src, DCsr &dst, hipStream_t s) {
+  MI_REQUIRE(!src.rowmap.p, "from_solve_format: the operator's rows are stored in another order");
+  const int n = src.nrows;
+  dst.nrows = n;
+  dst.ncols = src.ncols;
+  dst.nnz = src.nnz;
+  dst.ia.alloc((size_t)n + 1);
+  dst.ja.alloc((size_t)src.nnz);
+  dst.a.alloc((size_t)src.nnz);
+  ia_to_64_k<<<(unsigned)((n + 1 + BLK - 1) / BLK), BLK, 0, s>>>((long long)n + 1, src.ia.p, dst.ia.p);
+  if (src.nnz) {
+    MI_HIP(hipMemcpyAsync(dst.ja.p, src.ja.p, (size_t)src.nnz * sizeof(int), hipMemcpyDeviceToDevice, s));
+    MI_HIP(hipMemcpyAsync(dst.a.p, src.a.p, (size_t)src.nnz * sizeof(double), hipMemcpyDeviceToDevice, s));
+  }
+  MI_HIP(hipGetLastError());
+}
+
+int locality_labels(const DCsr &A, const int *seeds_host, int nseeds, const unsigned char *exclude_host, int max_rounds,
+                    std::vector<int> &label_host, hipStream_t s) {
+  const int n = A.nrows;
+  label_host.assign((size_t)n, -1);
+  if (n == 0) return 0;
+  DVec<int> la((size_t)n), lb((size_t)n), dseeds((size_t)std::max(1, nseeds)), changed(1);
+  if (exclude_host) {  // -2 for the rows that stay out
+    for (int i = 0; i < n; i++)
+      if (exclude_host[i]) label_host[(size_t)i] = -2;
+    MI_HIP(hipMemcpyAsync(la.p, label_host.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+  } else {
+    MI_HIP(hipMemsetAsync(la.p, 0xFF, (size_t)n * sizeof(int), s));  // -1
+  }
+  if (nseeds) {
+    MI_HIP(hipMemcpyAsync(dseeds.p, seeds_host, (size_t)nseeds * sizeof(int), hipMemcpyHostToDevice, s));
+    locality_seed_k<<<(unsigned)((nseeds + BLK - 1) / BLK), BLK, 0, s>>>(nseeds, dseeds.p, la.p);
+  }
+  int *in = la.p, *out = lb.p;
+  int rounds = 0;
+  for (; rounds < max_rounds; rounds++) {
+    MI_HIP(hipMemsetAsync(changed.p, 0, sizeof(int), s));
+    locality_round_k<<<(unsigned)((n + BLK - 1) / BLK), BLK, 0, s>>>(n, A.ia.p, A.ja.p, in, out, changed.p);
+    int ch = 0;
+    MI_HIP(hipMemcpyAsync(&ch, changed.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    std::swap(in, out);
+    if (!ch) break;
+  }
+  MI_HIP(hipMemcpyAsync(label_host.data(), in, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+  MI_HIP(hipGetLastError());
+  return rounds;
+}
+
+void invert_permutation(const int *order, int n, int *pos, hipStream_t s) {
+  if (n == 0) return;
+  invert_perm_k<<<(unsigned)((n + BLK - 1) / BLK), BLK, 0, s>>>(n, order, pos);
+  MI_HIP(hipGetLastError());
 }
 
 void level_norms(const DCsr &A, const int *cf, int chunk, double *diag, double *l1gs, double *l1jac, hipStream_t s) {

@@ -25,6 +25,21 @@ typedef void (*HYPRE_MI_ExchangeFn)(void *ctx, int nsend, const int *send_peers,
                                     const size_t *recv_bytes);
 HYPRE_Int HYPRE_MI_CommInitCallbacks(void *ctx, HYPRE_MI_AllreduceFn ar, HYPRE_MI_AllgatherFn ag,
                                      HYPRE_MI_ExchangeFn ex, HYPRE_Int rank, HYPRE_Int size);
+/* Neighbour exchange (the halo updates) by peer stores instead of ncclSend/ncclRecv groups, on top of the
+ * communicator set up before (RCCL or callbacks; it keeps the reductions and gathers): every rank exports a mailbox
+ * arena with hipIpcGetMemHandle, maps the others' (xGMI peer memory; the same device when ranks share a GPU), and one
+ * kernel launch per exchange stores the packed halo into the receiver's slot, publishes a sequence number and takes
+ * the incoming messages out of its own slots.  slot_bytes: mailbox slot per directed pair and parity (0 = env
+ * MI_HYPRE_IPC_SLOT_BYTES or 4 MiB; larger messages travel in parts).  Collective.  Waits are bounded
+ * (MI_HYPRE_IPC_TIMEOUT_MS, default 20 000): HYPRE_MI_CommCheck reports a message that never arrived. */
+HYPRE_Int HYPRE_MI_CommEnablePeerStoreExchange(HYPRE_BigInt slot_bytes);
+HYPRE_Int HYPRE_MI_CommCheck(void);
+/* one neighbour exchange of DEVICE buffers through the current transport, on the library stream, completed on return
+ * (what a halo update does; for transport tests) */
+HYPRE_Int HYPRE_MI_CommExchangeDevice(HYPRE_Int nsend, const HYPRE_Int *send_peers, void *const *send_ptrs,
+                                      const size_t *send_bytes, HYPRE_Int nrecv, const HYPRE_Int *recv_peers,
+                                      void *const *recv_ptrs, const size_t *recv_bytes);
+HYPRE_Int HYPRE_MI_CommName(char *name, HYPRE_Int max_len);
 /* one-rank exercise of the RCCL transport (dlopen, init, all-reduce, all-gather, send/recv) */
 HYPRE_Int HYPRE_MI_CommSelfTestRCCL(void);
 HYPRE_Int HYPRE_MI_CommFinalize(void);

@@ -60,6 +60,9 @@ def main():
                     help="seed of a combination of BoomerAMG choices (tests/test_gpu_amg.py::_combo) applied to both sides")
     ap.add_argument("--smooth", type=int, default=0,
                     help="levels with the ILU complex smoother (smooth_type 5): block-Jacobi ILU(0) per rank")
+    ap.add_argument("--transport", default="callbacks",
+                    help="callbacks (gloo through host staging) | ipc (halo exchanges by peer stores into IPC-mapped "
+                         "mailboxes, HYPRE_MI_CommEnablePeerStoreExchange; reductions stay on the callbacks)")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -72,6 +75,12 @@ def main():
     if args.mode == "solve":
         mi.init()
     mi.init_comm_torch(dist, device="cuda" if args.staging == "cuda" else None)
+    if args.transport == "ipc":
+        assert args.mode == "solve"
+        mi.call("HYPRE_MI_CommEnablePeerStoreExchange", mi.c_big(1 << 16))  # small slots: large halos travel in parts
+        nm = mi.C.create_string_buffer(128)
+        mi.call("HYPRE_MI_CommName", nm, 128)
+        assert size == 1 or nm.value.decode().startswith("ipc-peer-store"), nm.value
     n, st = args.grid, args.stencil
     N = n ** 3
     starts = [mi.row_partition(N, size, r)[0] for r in range(size)] + [N]
@@ -331,6 +340,8 @@ def main():
                   f"{n_redundant} redundant levels")
     elif rank == 0:
         print(f"dist host setup ok: {size} ranks, {amg.num_levels} levels, {n_redundant} redundant")
+    if args.mode == "solve":
+        mi.call("HYPRE_MI_CommCheck")  # the peer-store transport: no wait ran into its time limit
     dist.barrier()
     mi.call("HYPRE_MI_CommFinalize")
     dist.destroy_process_group()

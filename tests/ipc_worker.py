@@ -1,0 +1,78 @@
+"""One rank of the peer-store transport test (launched by torch.distributed.run; the ranks share the visible GPU).
+
+Every rank exchanges device buffers of many sizes with every other rank through HYPRE_MI_CommExchangeDevice on the
+IPC-mailbox transport (HYPRE_MI_CommEnablePeerStoreExchange on top of gloo callbacks): empty messages, a few bytes,
+sizes that are not multiples of 16, messages of several mailbox slots, unaligned device pointers, many rounds in a row
+(slot reuse: message k + 2 waits for the acknowledgement of message k).  Payloads are a function of (sender, receiver,
+round, size), so a byte that lands in the wrong place or round is seen."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+
+def payload(src, dst, rnd, nbytes):
+    rng = np.random.default_rng(1000003 * src + 1009 * dst + rnd)
+    return rng.integers(0, 256, size=nbytes, dtype=np.uint8)
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group(backend="gloo")
+    rank, size = dist.get_rank(), dist.get_world_size()
+    mi = ge.load_binding()
+    mi.init()
+    mi.init_comm_torch(dist)
+    slot = 4096
+    mi.call("HYPRE_MI_CommEnablePeerStoreExchange", mi.c_big(slot))
+    C = mi.C
+    peers = [r for r in range(size) if r != rank]
+    sizes = [0, 1, 8, 24, 100, 4096, 4097, 3 * slot + 5, 65536 + 8]
+    rounds = 0
+    for rnd in range(3 * len(sizes)):
+        nbytes = sizes[rnd % len(sizes)]
+        off = rnd % 3  # 0: aligned; 1, 2: device pointers that are not multiples of 16 (byte-wise copy path)
+        sbuf = {p: torch.zeros(nbytes + 16, dtype=torch.uint8, device="cuda") for p in peers}
+        rbuf = {p: torch.full((nbytes + 16,), 255, dtype=torch.uint8, device="cuda") for p in peers}
+        for p in peers:
+            sbuf[p][off:off + nbytes] = torch.from_numpy(payload(rank, p, rnd, nbytes)).cuda()
+        torch.cuda.synchronize()
+        n = len(peers)
+        ip = (C.c_int * n)(*peers)
+        sp = (C.c_void_p * n)(*[sbuf[p].data_ptr() + off for p in peers])
+        rp = (C.c_void_p * n)(*[rbuf[p].data_ptr() + off for p in peers])
+        nb = (C.c_size_t * n)(*([nbytes] * n))
+        mi.call("HYPRE_MI_CommExchangeDevice", n, ip, sp, nb, n, ip, rp, nb)
+        for p in peers:
+            got = rbuf[p].cpu().numpy()
+            assert np.array_equal(got[off:off + nbytes], payload(p, rank, rnd, nbytes)), (rank, p, rnd, nbytes)
+            assert np.all(got[:off] == 255) and np.all(got[off + nbytes:] == 255), (rank, p, rnd, "wrote outside")
+        rounds += 1
+    # one-sided shapes: a ring (send to the right neighbour only, receive from the left one)
+    if size > 2:
+        right, left = (rank + 1) % size, (rank - 1) % size
+        for rnd in range(100, 104):
+            nbytes = 2 * slot + 40
+            s = torch.from_numpy(payload(rank, right, rnd, nbytes)).cuda()
+            r = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            mi.call("HYPRE_MI_CommExchangeDevice", 1, (C.c_int * 1)(right), (C.c_void_p * 1)(s.data_ptr()), (C.c_size_t * 1)(nbytes),
+                    1, (C.c_int * 1)(left), (C.c_void_p * 1)(r.data_ptr()), (C.c_size_t * 1)(nbytes))
+            assert np.array_equal(r.cpu().numpy(), payload(left, rank, rnd, nbytes))
+            rounds += 1
+    mi.call("HYPRE_MI_CommCheck")
+    if rank == 0:
+        print(f"ipc exchange ok: {size} ranks, {rounds} rounds")
+    dist.barrier()
+    mi.call("HYPRE_MI_CommFinalize")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

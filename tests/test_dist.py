@@ -18,7 +18,7 @@ WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
 
 
 def _run(nproc, mode, n, stencil, port, staging="host", seq=-1, devmin=None, golden="", replicated=False, locality=0,
-         smooth=0, relax=0, combo=-1):
+         smooth=0, relax=0, combo=-1, transport=""):
     env = dict(os.environ)
     env["MI_HYPRE_REPLICATED_SETUP"] = "1" if replicated else "0"
     if devmin is not None:  # levels with at least this many rows are built (and sliced) on the device
@@ -40,6 +40,8 @@ def _run(nproc, mode, n, stencil, port, staging="host", seq=-1, devmin=None, gol
         cmd += ["--relax", str(relax)]
     if combo >= 0:
         cmd += ["--combo", str(combo)]
+    if transport:
+        cmd += ["--transport", transport]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-4000:]
     return p.stdout
@@ -138,6 +140,31 @@ def test_device_solve_parameter_combinations_shared_gpu(nproc, n, seq, combo):
     aggressive levels, multipass, complex smoother, W cycles ...) on N ranks: the replicated setup for everything
     but plain PMIS, aggressive levels and smoothed levels that reach into the redundant tail."""
     out = _run(nproc, "solve", n, 7, 30071 + nproc + n + combo, seq=seq, combo=combo)
+    assert "dist solve ok" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc", [2, 3, 4])
+def test_peer_store_exchange_raw_shared_gpu(nproc):
+    """The hipIpc peer-store transport by itself (tests/ipc_worker.py): empty / tiny / unaligned / multi-slot messages
+    between every pair of ranks, many rounds, slot reuse; ranks share the test GPU (IPC handles work between
+    processes on one device, where RCCL refuses to run)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr",
+           "127.0.0.1", "--master-port", str(30211 + nproc), os.path.join(ROOT, "tests", "ipc_worker.py")]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-4000:]
+    assert f"ipc exchange ok: {nproc} ranks" in p.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,n,stencil,seq", [(2, 16, 7, -1), (3, 14, 7, 0), (4, 12, 27, 0), (4, 16, 7, 1000)])
+def test_device_solve_peer_store_transport_shared_gpu(nproc, n, stencil, seq):
+    """The whole distributed solve with its halo updates on the peer-store transport (64 KiB slots: the fine-level
+    halos travel in several parts): hierarchy, iteration count, residual history and solution against the oracle as in
+    the other transports, overlapped choreography included."""
+    out = _run(nproc, "solve", n, stencil, 30251 + nproc + n, seq=seq, transport="ipc")
     assert "dist solve ok" in out
 
 

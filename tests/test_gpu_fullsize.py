@@ -222,7 +222,7 @@ linear_system:
 solver_settings:
   method: gmres
   preconditioner: boomeramg
-  tolerance: 1.0e-8
+  tolerance: 1.0e-10
   max_iterations: 100
   kspace: 100
   print_level: 0
@@ -244,7 +244,8 @@ boomeramg_settings:
     out = p.stdout
     m = re.search(r"Solve 0 : (\d+) iterations, final relative residual ([0-9.eE+-]+)", out)
     assert m, out[-3000:]
-    assert 8 <= int(m.group(1)) <= 30 and float(m.group(2)) <= 1e-8
+    # (residual 1e-10: the closeness rule's rtol 1e-6 then has two digits of margin; at 1e-8 the error is ~1e-6)
+    assert 8 <= int(m.group(1)) <= 40 and float(m.group(2)) <= 1e-10
     assert "allClose=1" in out and "allClose=0" not in out, out[-2000:]
     lv = re.search(r"BoomerAMG setup: (\d+) levels, operator complexity ([0-9.]+)", out)
     assert lv and 6 <= int(lv.group(1)) <= 20 and 2.0 < float(lv.group(2)) < 5.0

@@ -181,3 +181,25 @@ def test_irregular_graph_with_locality_order(mi, oc, monkeypatch):
     assert np.abs(got[order] - xo).max() <= 1e-9 * np.abs(xo).max()
     xd = spl.spsolve(M.tocsc(), rhs)
     assert np.abs(got - xd).max() <= 1e-8 * np.abs(xd).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,stencil", [(30, 7), (28, 27)])
+def test_device_numbering_equals_host_numbering(mi, oc, n, stencil, monkeypatch):
+    """Levels the device builds (>= 20 000 rows) get their numbering from the device rounds (sk::locality_labels) and
+    Q A Q^T from a device permutation of the assembled matrix: the same Q as the host routine, and the hierarchy on
+    it equals the oracle's hierarchy of the permuted matrix bit for bit."""
+    A_host, rhs, amg_host = _amg_with_order(mi, n, stencil, True, monkeypatch)
+    (A, b, x), rhs, amg = _amg_with_order(mi, n, stencil, False, monkeypatch)
+    applied_h, order_h = amg_host.input_ordering()
+    applied, order = amg.input_ordering()
+    N = n ** 3
+    assert applied and applied_h and np.array_equal(order, order_h)
+    assert np.array_equal(np.sort(order), np.arange(N)) and not np.array_equal(order, np.arange(N))
+    Aq, bq, oamg = _permuted_oracle(oc, n, stencil, order)
+    assert amg.num_levels == oamg.num_levels and amg.num_levels > 2
+    for l in range(amg.num_levels):
+        ia, ja, a, shape = amg.level_csr(l, 0)
+        oia, oja, oa = oamg.level_A(l).arrays()
+        assert np.array_equal(ia, oia) and np.array_equal(ja, oja) and np.array_equal(a, oa), l
+    assert np.array_equal(amg.level_perm(0), order[oamg.level_perm(0)])
