@@ -411,7 +411,8 @@ struct IpcExchangeComm : Comm {
     if (e) fail(1, "peer-store exchange: a neighbour's message did not arrive within the time limit (MI_HYPRE_IPC_TIMEOUT_MS)");
   }
   // messages larger than a slot travel in slot-sized parts, each with its own sequence number (both sides know the
-  // sizes, so they agree on the parts)
+  // sizes, so they agree on the parts).  NOTE: two messages between the same pair in ONE call would interleave their
+  // parts differently on the two sides; a halo plan has one message per neighbour and direction (parcsr.cpp)
   void exchange_dev(const std::vector<PeerBuf> &sends, const std::vector<PeerBuf> &recvs, hipStream_t s) override {
     if (sends.empty() && recvs.empty()) return;
     k::IpcBatch B;
@@ -430,11 +431,24 @@ struct IpcExchangeComm : Comm {
       B.n++;
     };
     auto blocks_for = [](size_t bytes) { return bytes >= (1u << 20) ? 4 : bytes >= (1u << 18) ? 2 : 1; };
-    // sends first: a launch's workgroups start in order, and nobody's receive can complete before the sends are out
+    // Order of the transfers: part q of every send, then part q of every receive, q = 0, 1, ...  A send of part
+    // q + 2 waits for the peer's acknowledgement of part q, i.e. for a receive that stands EARLIER in the peer's own
+    // list and needs nothing but this rank's send of part q: every wait points to a smaller q, so there is no cycle,
+    // however the lists are cut into launches (all workgroups of a launch are resident together: <= 32 x 4).
+    auto parts_of = [&](size_t bytes) { return bytes == 0 ? (size_t)1 : (bytes + slot_bytes - 1) / slot_bytes; };
+    size_t max_parts = 0;
     for (const auto &b : sends) {
       MI_REQUIRE(b.peer >= 0 && b.peer < size && b.peer != rank, "peer-store exchange: bad peer");
-      for (size_t off = 0; off < b.bytes || (b.bytes == 0 && off == 0); off += slot_bytes) {
-        const size_t part = std::min(slot_bytes, b.bytes - off);
+      max_parts = std::max(max_parts, parts_of(b.bytes));
+    }
+    for (const auto &b : recvs) {
+      MI_REQUIRE(b.peer >= 0 && b.peer < size && b.peer != rank, "peer-store exchange: bad peer");
+      max_parts = std::max(max_parts, parts_of(b.bytes));
+    }
+    for (size_t q = 0; q < max_parts; q++) {
+      for (const auto &b : sends) {
+        if (q >= parts_of(b.bytes)) continue;
+        const size_t off = q * slot_bytes, part = std::min(slot_bytes, b.bytes - off);
         const unsigned long long seq = ++send_seq[(size_t)b.peer];
         const int slot = (int)(seq & 1);
         k::IpcTransfer t{};
@@ -448,13 +462,10 @@ struct IpcExchangeComm : Comm {
         t.post_word = flag_word(peer_arena[(size_t)b.peer], rank, slot);
         t.post_value = seq;
         push(t);
-        if (b.bytes == 0) break;
       }
-    }
-    for (const auto &b : recvs) {
-      MI_REQUIRE(b.peer >= 0 && b.peer < size && b.peer != rank, "peer-store exchange: bad peer");
-      for (size_t off = 0; off < b.bytes || (b.bytes == 0 && off == 0); off += slot_bytes) {
-        const size_t part = std::min(slot_bytes, b.bytes - off);
+      for (const auto &b : recvs) {
+        if (q >= parts_of(b.bytes)) continue;
+        const size_t off = q * slot_bytes, part = std::min(slot_bytes, b.bytes - off);
         const unsigned long long seq = ++recv_seq[(size_t)b.peer];
         const int slot = (int)(seq & 1);
         k::IpcTransfer t{};
@@ -468,7 +479,6 @@ struct IpcExchangeComm : Comm {
         t.post_word = ack_word(peer_arena[(size_t)b.peer], rank, slot);
         t.post_value = seq;
         push(t);
-        if (b.bytes == 0) break;
       }
     }
     flush();

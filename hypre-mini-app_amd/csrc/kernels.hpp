@@ -134,7 +134,7 @@ struct IpcTransfer {
   unsigned long long post_value;
   unsigned *ticket;              // per-transfer counter of finished workgroups (self-resetting)
 };
-constexpr int IPC_MAX_TRANSFERS = 16;
+constexpr int IPC_MAX_TRANSFERS = 32;
 struct IpcBatch {
   IpcTransfer t[IPC_MAX_TRANSFERS];
   int n;
