@@ -33,6 +33,21 @@ struct AmgParams {
   // ILU(0), the IluSolver behind HYPRE_ILU); library defaults as in HYPRE
   int smooth_type = 6, smooth_num_levels = 0;
   int ilu_type = 0, ilu_level = 0, ilu_max_iter = 1, ilu_tri_solve = 1, ilu_lower_it = 5, ilu_upper_it = 5;
+  // non-Galerkin coarse operators (src/HypreSystem.cpp:161-176): drop tolerance for the coarse operator built FROM
+  // level l (HYPRE's index): level_tol[l] when set (>= 0), else the global one; 0 = Galerkin
+  double non_galerkin_tol = 0.0;
+  std::vector<double> non_galerkin_level_tol;
+  double non_galerkin_tol_for(int level) const {
+    if (level < (int)non_galerkin_level_tol.size() && non_galerkin_level_tol[(size_t)level] >= 0.0)
+      return non_galerkin_level_tol[(size_t)level];
+    return non_galerkin_tol;
+  }
+  bool non_galerkin() const {
+    if (non_galerkin_tol > 0.0) return true;
+    for (double t : non_galerkin_level_tol)
+      if (t > 0.0) return true;
+    return false;
+  }
   // N > 1 ranks: levels >= 1 with at most this many global rows are kept whole on every rank and cycled
   // redundantly, without halo exchanges (HYPRE_BoomerAMGSetSeqThreshold); -1 = MI_HYPRE_REDUNDANT_ROWS or 200000
   long long redundant_rows = -1;

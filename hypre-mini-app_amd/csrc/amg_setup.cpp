@@ -1245,6 +1245,65 @@ void BoomerAMG::apply_cf_ordering() {
   }
 }
 
+// Non-Galerkin coarse operator (HYPRE_BoomerAMGSetNonGalerkinTol, src/HypreSystem.cpp:161-176): the simplified,
+// documented form shared with the oracle (oracle.c sparsify_non_galerkin; HYPRE's par_nongalerkn.c is not restated):
+// with m_i = max_{j != i} |a_ij|, an off-diagonal entry is dropped iff |a_ij| < tol * min(m_i, m_j) -- small against
+// both rows, so a symmetric operator stays symmetric -- and added to its row's diagonal in stored order (row sums
+// are kept).  Kept entries stay in stored order.
+namespace hs {
+void sparsify_non_galerkin(HostCSR &A, double tol) {
+  const int n = A.nrows;
+  if (n == 0 || !(tol > 0.0)) return;
+  std::vector<double> m((size_t)n, 0.0);
+  parallel_for(n, [&](int64_t b, int64_t e, int) {
+    for (int64_t i = b; i < e; i++) {
+      double mx = 0.0;
+      for (int64_t k = A.ia[(size_t)i]; k < A.ia[(size_t)i + 1]; k++)
+        if (A.ja[(size_t)k] != i && std::fabs(A.a[(size_t)k]) > mx) mx = std::fabs(A.a[(size_t)k]);
+      m[(size_t)i] = mx;
+    }
+  });
+  HostCSR B;
+  B.nrows = n;
+  B.ncols = A.ncols;
+  B.ia.assign((size_t)n + 1, 0);
+  auto keeps = [&](int64_t i, int64_t k) {
+    const int j = A.ja[(size_t)k];
+    const double lim = tol * std::min(m[(size_t)i], m[(size_t)j]);
+    return j == i || !(std::fabs(A.a[(size_t)k]) < lim);
+  };
+  parallel_for(n, [&](int64_t b, int64_t e, int) {
+    for (int64_t i = b; i < e; i++) {
+      int64_t c = 0;
+      for (int64_t k = A.ia[(size_t)i]; k < A.ia[(size_t)i + 1]; k++) c += keeps(i, k) ? 1 : 0;
+      B.ia[(size_t)i + 1] = c;
+    }
+  });
+  for (int i = 0; i < n; i++) B.ia[(size_t)i + 1] += B.ia[(size_t)i];
+  B.ja.resize((size_t)B.nnz());
+  B.a.resize((size_t)B.nnz());
+  parallel_for(n, [&](int64_t b, int64_t e, int) {
+    for (int64_t i = b; i < e; i++) {
+      int64_t w = B.ia[(size_t)i], dpos = -1;
+      double lump = 0.0;
+      bool first = true;
+      for (int64_t k = A.ia[(size_t)i]; k < A.ia[(size_t)i + 1]; k++) {
+        if (keeps(i, k)) {
+          if (A.ja[(size_t)k] == i) dpos = w;
+          B.ja[(size_t)w] = A.ja[(size_t)k];
+          B.a[(size_t)w++] = A.a[(size_t)k];
+        } else {
+          lump = first ? A.a[(size_t)k] : lump + A.a[(size_t)k];
+          first = false;
+        }
+      }
+      if (!first && dpos >= 0) B.a[(size_t)dpos] = B.a[(size_t)dpos] + lump;
+    }
+  });
+  A = std::move(B);
+}
+}  // namespace hs
+
 // ---- internal locality numbering ------------------------------------------------------------------------------
 // The x-cache kernels gather, per tile of <= 256 consecutive rows, the tile's unique columns; with a lexicographic
 // numbering of a 3-D problem a tile is a piece of ONE grid line and gathers ~5 distinct columns per row, a
@@ -1673,6 +1732,7 @@ void BoomerAMG::build_natural(ParCSR &A0) {
       L.emplace_back();  // the coarse operator is born on the device (L was reserved: references stay valid)
       sk::DCsr &dAc = L[(size_t)l + 1].sA;
       sk::spgemm(dR, dAP, dAc, s);
+      if (p.non_galerkin_tol_for(l) > 0.0) sk::sparsify_non_galerkin(dAc, p.non_galerkin_tol_for(l), s);
       if (nc < device_min_rows) {
         dAc.download(An->diag, s);  // the next level is built by the host routines
       } else {
@@ -1687,6 +1747,7 @@ void BoomerAMG::build_natural(ParCSR &A0) {
       HostCSR AP;
       host_spgemm(A.diag, Lv.P, AP);
       host_spgemm(Lv.R, AP, An->diag);
+      if (p.non_galerkin_tol_for(l) > 0.0) sparsify_non_galerkin(An->diag, p.non_galerkin_tol_for(l));
       L.emplace_back();
     }
     An->nrows = nc;
@@ -2145,6 +2206,11 @@ void BoomerAMG::build_replicated(ParCSR &A0) {
     tail->p.max_levels = std::max(1, p.max_levels - (int)(nlev - 1));
     tail->p.smooth_num_levels = std::max(0, p.smooth_num_levels - (int)(nlev - 1));
     tail->p.agg_num_levels = std::max(0, p.agg_num_levels - (int)(nlev - 1));
+    {  // the tail counts its levels from 0: level-specific non-Galerkin tolerances move with it
+      std::vector<double> shifted;
+      for (size_t q = nlev - 1; q < p.non_galerkin_level_tol.size(); q++) shifted.push_back(p.non_galerkin_level_tol[q]);
+      tail->p.non_galerkin_level_tol = shifted;
+    }
     tail->device_min_rows = device_min_rows;
     tail->use_private_self_comm();
     tail->setup_host(*tail_A);

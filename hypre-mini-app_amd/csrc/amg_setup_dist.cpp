@@ -360,7 +360,9 @@ void dist_setup_counters_reset() { g_ext_rows_max = g_global_rows_gathered = g_d
 
 bool BoomerAMG::can_build_distributed() const {
   static const bool forced_off = getenv("MI_HYPRE_REPLICATED_SETUP") && atoi(getenv("MI_HYPRE_REPLICATED_SETUP")) != 0;
-  return !forced_off && (p.coarsen_type == 8 || p.coarsen_type == 9) && p.agg_num_levels <= 0 && p.interp_type != 4;  // (multipass: host passes)
+  // (multipass: host passes; non-Galerkin operators: the drop rule reads the row maxima of halo columns -- replicated)
+  return !forced_off && (p.coarsen_type == 8 || p.coarsen_type == 9) && p.agg_num_levels <= 0 && p.interp_type != 4 &&
+         !p.non_galerkin();
 }
 
 void BoomerAMG::build_distributed(ParCSR &A0) {
@@ -1247,6 +1249,11 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
     tail->p.max_levels = std::max(1, p.max_levels - (int)(nlev - 1));
     tail->p.smooth_num_levels = std::max(0, p.smooth_num_levels - (int)(nlev - 1));
     tail->p.agg_num_levels = std::max(0, p.agg_num_levels - (int)(nlev - 1));
+    {  // the tail counts its levels from 0: level-specific non-Galerkin tolerances move with it
+      std::vector<double> shifted;
+      for (size_t q = nlev - 1; q < p.non_galerkin_level_tol.size(); q++) shifted.push_back(p.non_galerkin_level_tol[q]);
+      tail->p.non_galerkin_level_tol = shifted;
+    }
     tail->device_min_rows = device_min_rows;
     tail->use_private_self_comm();
     tail->setup_host(*tail_A);

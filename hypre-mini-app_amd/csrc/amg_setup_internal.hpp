@@ -20,6 +20,9 @@ void strength(const ParCSR &A, double theta, double max_row_sum, Strength &S);
 void build_interp(const ParCSR &A, const Strength &S, std::vector<int> &cf, int interp_type, double trunc_factor,
                   int pmax, HostCSR &P, int &nc_out, const std::vector<char> *want_rows = nullptr);
 
+// non-Galerkin sparsification of a square single-rank operator, in place (amg_setup.cpp)
+void sparsify_non_galerkin(HostCSR &A, double tol);
+
 // locality numbering of a block's rows (amg_setup.cpp): order[new] = old; excluded rows (optional) come last
 void locality_order(const HostCSR &D, std::vector<int> &order, const std::vector<char> *exclude);
 // its pieces, shared with the device path: the seeds (ascending), and the stable sort of the final labels

@@ -751,7 +751,7 @@ AMG_SET(AggTruncFactor, HYPRE_Real, p.agg_trunc_factor = v)
 AMG_SET(KeepTranspose, HYPRE_Int, p.keep_transpose = v)
 AMG_SET(RAP2, HYPRE_Int, p.rap2 = v)
 AMG_SET(Variant, HYPRE_Int, if (v != 0) warn_ignored("variant", v))
-AMG_SET(NonGalerkinTol, HYPRE_Real, if (v != 0.0) warn_ignored("non_galerkin_tol", v))
+AMG_SET(NonGalerkinTol, HYPRE_Real, if (v < 0.0 || v > 1.0) fail(HYPRE_ERROR_ARG, "non_galerkin_tol must be in [0, 1]"); p.non_galerkin_tol = v)
 AMG_SET(SmoothType, HYPRE_Int, p.smooth_type = v)  /* acts through smooth_num_levels > 0; checked at Setup */
 AMG_SET(SmoothNumLevels, HYPRE_Int, p.smooth_num_levels = v)
 AMG_SET(ILUType, HYPRE_Int, p.ilu_type = v)
@@ -768,10 +768,13 @@ AMG_SET(ILUTriSolve, HYPRE_Int, p.ilu_tri_solve = v)
 AMG_SET(ILULowerJacobiIters, HYPRE_Int, p.ilu_lower_it = v)
 AMG_SET(ILUUpperJacobiIters, HYPRE_Int, p.ilu_upper_it = v)
 #undef AMG_SET
-HYPRE_Int HYPRE_BoomerAMGSetLevelNonGalerkinTol(HYPRE_Solver solver, HYPRE_Real tol, HYPRE_Int) {
+HYPRE_Int HYPRE_BoomerAMGSetLevelNonGalerkinTol(HYPRE_Solver solver, HYPRE_Real tol, HYPRE_Int level) {
   API_BEGIN
-  (void)AMG(solver);
-  if (tol != 0.0) warn_ignored("non_galerkin_level_tols", tol);
+  AmgParams &p = AMG(solver)->amg.p;
+  if (tol < 0.0 || tol > 1.0) fail(HYPRE_ERROR_ARG, "non_galerkin_level_tols: a tolerance must be in [0, 1]");
+  if (level < 0 || level > 1000) fail(HYPRE_ERROR_ARG, "non_galerkin_level_tols: bad level");
+  if ((int)p.non_galerkin_level_tol.size() <= level) p.non_galerkin_level_tol.resize((size_t)level + 1, -1.0);
+  p.non_galerkin_level_tol[(size_t)level] = tol;
   API_END
 }
 HYPRE_Int HYPRE_BoomerAMGSetCycleRelaxType(HYPRE_Solver solver, HYPRE_Int relax_type, HYPRE_Int k) {

@@ -923,6 +923,51 @@ __global__ __launch_bounds__(BLK) void invert_perm_k(int n, const int *__restric
   if (q < n) pos[order[q]] = q;
 }
 
+// ---- non-Galerkin sparsification (one lane per row: a side-line of the setup, the arithmetic is the host's)
+__global__ __launch_bounds__(BLK) void ng_rowmax_k(int n, const long long *__restrict__ ia, const int *__restrict__ ja,
+                                                   const double *__restrict__ a, double *__restrict__ m) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  double mx = 0.0;
+  for (long long k = ia[i]; k < ia[i + 1]; k++)
+    if (ja[k] != i && fabs(a[k]) > mx) mx = fabs(a[k]);
+  m[i] = mx;
+}
+template <bool FILL>
+__global__ __launch_bounds__(BLK) void ng_drop_k(int n, const long long *__restrict__ ia, const int *__restrict__ ja,
+                                                 const double *__restrict__ a, const double *__restrict__ m, double tol,
+                                                 int *__restrict__ cnt, const long long *__restrict__ oia,
+                                                 int *__restrict__ oja, double *__restrict__ oa) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  const double mi = m[i];
+  long long w = FILL ? oia[i] : 0, dpos = -1;
+  int c = 0;
+  double lump = 0.0;
+  bool first = true;
+  for (long long k = ia[i]; k < ia[i + 1]; k++) {
+    const int j = ja[k];
+    const double mj = m[j];
+    const double lim = tol * (mi < mj ? mi : mj);
+    if (j == i || !(fabs(a[k]) < lim)) {
+      if (FILL) {
+        if (j == i) dpos = w;
+        oja[w] = j;
+        oa[w++] = a[k];
+      }
+      c++;
+    } else if (FILL) {
+      lump = first ? a[k] : lump + a[k];
+      first = false;
+    }
+  }
+  if (FILL) {
+    if (!first && dpos >= 0) oa[dpos] = oa[dpos] + lump;
+  } else {
+    cnt[i] = c;
+  }
+}
+
 constexpr int LEN_BINS = 4096;
 // every thread walks RUN consecutive rows and merges equal neighbours before it touches the (LDS) histogram:
 // uniform row lengths (stencil matrices) would otherwise serialise on one counter
@@ -1481,6 +1526,32 @@ void solve_format_to_host(const DevCSR &src, HostCSR &h, hipStream_t s) {
     }
     h = std::move(o);
   }
+}
+
+void sparsify_non_galerkin(DCsr &A, double tol, hipStream_t s) {
+  const int n = A.nrows;
+  if (n == 0 || !(tol > 0.0)) return;
+  MI_REQUIRE(A.nrows == A.ncols, "non-Galerkin sparsification: square operators only");
+  const unsigned grid = (unsigned)((n + BLK - 1) / BLK);
+  DVec<double> m((size_t)n);
+  DVec<int> cnt((size_t)n);
+  ng_rowmax_k<<<grid, BLK, 0, s>>>(n, A.ia.p, A.ja.p, A.a.p, m.p);
+  ng_drop_k<false><<<grid, BLK, 0, s>>>(n, A.ia.p, A.ja.p, A.a.p, m.p, tol, cnt.p, nullptr, nullptr, nullptr);
+  DCsr B;
+  B.nrows = n;
+  B.ncols = A.ncols;
+  B.ia.alloc((size_t)n + 1);
+  exclusive_scan(cnt.p, B.ia.p, n, s);
+  long long total = 0;
+  MI_HIP(hipMemcpyAsync(&total, B.ia.p + n, sizeof(long long), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+  B.nnz = total;
+  B.ja.alloc((size_t)total);
+  B.a.alloc((size_t)total);
+  ng_drop_k<true><<<grid, BLK, 0, s>>>(n, A.ia.p, A.ja.p, A.a.p, m.p, tol, nullptr, B.ia.p, B.ja.p, B.a.p);
+  MI_HIP(hipGetLastError());
+  MI_HIP(hipStreamSynchronize(s));
+  A = std::move(B);
 }
 
 void from_solve_format(const DevCSR &src, DCsr &dst, hipStream_t s) {

@@ -49,6 +49,11 @@ bool interp(const DCsr &A, const DCsr &S, DVec<int> &cf, int interp_type, double
 // oracle's ocsr_matmul; output columns ascending.
 void spgemm(const DCsr &A, const DCsr &B, DCsr &C, hipStream_t s);
 
+// Non-Galerkin sparsification of a square operator (amg_setup.cpp sparsify_non_galerkin, the oracle's function of the
+// same name): with m_i = max_{j != i} |a_ij|, off-diagonal entries with |a_ij| < tol * min(m_i, m_j) are dropped and
+// added to the row's diagonal in stored order.  In place (A is replaced).
+void sparsify_non_galerkin(DCsr &A, double tol, hipStream_t s);
+
 // T = A^T with ascending columns in every row (entries of one output row keep
 // the order of A's rows)
 void transpose(const DCsr &A, DCsr &T, hipStream_t s);

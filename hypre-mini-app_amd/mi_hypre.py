@@ -280,6 +280,13 @@ class BoomerAMG:
                               ("true_pmax_elmts", "HYPRE_BoomerAMGSetPMaxElmts", int)):
             if key in cfg:
                 call(fn, s, conv(cfg[key]))
+        # non_galerkin_tol + non_galerkin_level_tols {levels, tolerances}, HypreSystem.cpp:161-176
+        if "non_galerkin_tol" in cfg:
+            call("HYPRE_BoomerAMGSetNonGalerkinTol", s, float(cfg["non_galerkin_tol"]))
+            lt = cfg.get("non_galerkin_level_tols")
+            if lt:
+                for lev, tol in zip(lt["levels"], lt["tolerances"]):
+                    call("HYPRE_BoomerAMGSetLevelNonGalerkinTol", s, float(tol), int(lev))
 
     def setup(self, A):
         call("HYPRE_BoomerAMGSetup", self.h, A.par, None, None)

@@ -305,6 +305,8 @@ void oamg_default_params(oamg_params *p) {
   p->ilu_max_iter = 1;
   p->ilu_tri_solve = 1;
   p->ilu_lower_it = p->ilu_upper_it = 5;
+  p->non_galerkin_num_tol = 0;
+  p->non_galerkin_tol = NULL;
 }
 
 static int *part_of_rows(int n, int nparts, const obig *ps) {
@@ -1221,6 +1223,57 @@ static ocsr *build_multipass(const ocsr *A, const obig *Sia, const int *Sja, int
   return P;
 }
 
+/* Non-Galerkin coarse operator (HYPRE_BoomerAMGSetNonGalerkinTol, src/HypreSystem.cpp:161-176).  HYPRE's
+ * par_nongalerkn.c (Falgout / Schroder 2014) is NOT restated line by line -- it is not in the reference tree and
+ * the recollection of its lumping onto strong neighbours is not reliable enough; this is the documented simplified
+ * form both implementations share: with m_i = max_{j != i} |a_ij|, an off-diagonal entry is dropped iff
+ * |a_ij| < tol * min(m_i, m_j) -- small against BOTH rows, so a symmetric operator stays symmetric -- and every
+ * dropped entry is added to its row's diagonal in stored order (row sums, i.e. the action on constants, are kept).
+ * Kept entries stay in stored order. */
+static ocsr *sparsify_non_galerkin(const ocsr *A, double tol) {
+  const int n = A->nrows;
+  double *m = (double *)xcalloc((size_t)(n ? n : 1), sizeof(double));
+  for (int i = 0; i < n; i++) {
+    double mx = 0.0;
+    for (obig k = A->ia[i]; k < A->ia[i + 1]; k++)
+      if (A->ja[k] != i && fabs(A->a[k]) > mx) mx = fabs(A->a[k]);
+    m[i] = mx;
+  }
+  obig *ia = (obig *)xcalloc((size_t)n + 1, sizeof(obig));
+  for (int i = 0; i < n; i++) {
+    obig c = 0;
+    for (obig k = A->ia[i]; k < A->ia[i + 1]; k++) {
+      const int j = A->ja[k];
+      const double lim = tol * (m[i] < m[j] ? m[i] : m[j]);
+      if (j == i || !(fabs(A->a[k]) < lim)) c++;
+    }
+    ia[i + 1] = ia[i] + c;
+  }
+  ocsr *B = ocsr_new(n, A->ncols, ia[n]);
+  memcpy(B->ia, ia, sizeof(obig) * ((size_t)n + 1));
+  free(ia);
+  for (int i = 0; i < n; i++) {
+    obig w = B->ia[i], dpos = -1;
+    double lump = 0.0;
+    int first = 1;
+    for (obig k = A->ia[i]; k < A->ia[i + 1]; k++) {
+      const int j = A->ja[k];
+      const double lim = tol * (m[i] < m[j] ? m[i] : m[j]);
+      if (j == i || !(fabs(A->a[k]) < lim)) {
+        if (j == i) dpos = w;
+        B->ja[w] = j;
+        B->a[w++] = A->a[k];
+      } else {
+        lump = first ? A->a[k] : lump + A->a[k];
+        first = 0;
+      }
+    }
+    if (!first && dpos >= 0) B->a[dpos] = B->a[dpos] + lump;
+  }
+  free(m);
+  return B;
+}
+
 /* l1 norms.  l1gs: hypre_ParCSRComputeL1NormsThreads option 4 (par_relax_more.c),
  * "threads" = hybrid-GS chunks: |a_ii| + 0.5*sum |a_ij| over entries outside the
  * row's chunk (incl. other partitions) whose C/F type equals the row's (all of
@@ -1480,6 +1533,14 @@ oamg *oamg_setup(const ocsr *A0, const oamg_params *p) {
     ocsr *R = ocsr_transpose(P);
     ocsr *AP = ocsr_matmul(A, P);
     ocsr *Ac = ocsr_matmul(R, AP);
+    if (p->non_galerkin_num_tol > 0 && p->non_galerkin_tol) {
+      const int q = l < p->non_galerkin_num_tol ? l : p->non_galerkin_num_tol - 1;
+      if (p->non_galerkin_tol[q] > 0.0) {
+        ocsr *As = sparsify_non_galerkin(Ac, p->non_galerkin_tol[q]);
+        ocsr_free(Ac);
+        Ac = As;
+      }
+    }
     tph[3] += now_s() - tt;
     ocsr_free(AP);
     ocsr_free(R);

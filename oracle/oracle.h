@@ -90,6 +90,11 @@ typedef struct oamg_params {
   int ilu_max_iter;        /* 1 */
   int ilu_tri_solve;       /* 1 exact triangular solves, 0 Jacobi iterations */
   int ilu_lower_it, ilu_upper_it; /* 5, 5 */
+  /* non-Galerkin coarse operators (src/HypreSystem.cpp:161-176: HYPRE_BoomerAMGSetNonGalerkinTol /
+   * SetLevelNonGalerkinTol): entry l = drop tolerance applied to the coarse operator BUILT FROM level l (HYPRE's
+   * index); levels beyond the array take the last entry; NULL / 0 = Galerkin.  See sparsify_non_galerkin */
+  int non_galerkin_num_tol;
+  const double *non_galerkin_tol;
 } oamg_params;
 
 void oamg_default_params(oamg_params *p);

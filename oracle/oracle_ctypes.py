@@ -54,6 +54,8 @@ class AmgParams(C.Structure):
         ("ilu_tri_solve", C.c_int),
         ("ilu_lower_it", C.c_int),
         ("ilu_upper_it", C.c_int),
+        ("non_galerkin_num_tol", C.c_int),
+        ("non_galerkin_tol", C.POINTER(C.c_double)),
     ]
 
 
@@ -207,6 +209,11 @@ def default_params(**kw):
                 v = (v, v, getattr(p, k)[2])
             for i in range(3):
                 getattr(p, k)[i] = v[i]
+        elif k == "non_galerkin_tol":  # a number (every level) or a list indexed by the fine level (HYPRE's index)
+            arr = np.ascontiguousarray(np.atleast_1d(v), dtype=np.float64)
+            keep.append(arr)
+            p.non_galerkin_tol = arr.ctypes.data_as(C.POINTER(C.c_double))
+            p.non_galerkin_num_tol = len(arr)
         elif k == "part_starts":
             arr = np.ascontiguousarray(v, dtype=np.int64)
             keep.append(arr)

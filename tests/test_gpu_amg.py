@@ -35,7 +35,7 @@ def _setup(mi, oc, n, stencil=7, **amg_kw):
         okw["num_sweeps"] = amg_kw["num_sweeps"]
     for k in ("interp_type", "relax_order", "max_coarse_size", "strong_threshold", "cycle_type", "max_levels",
               "coarsen_type", "agg_num_levels", "agg_pmax_elmts", "agg_trunc_factor", "smooth_type",
-              "smooth_num_levels", "ilu_max_iter", "ilu_tri_solve"):
+              "smooth_num_levels", "ilu_max_iter", "ilu_tri_solve", "non_galerkin_tol"):
         if k in amg_kw:
             okw[k] = amg_kw[k]
     for k, ok in (("ilu_lower_jacobi_iters", "ilu_lower_it"), ("ilu_upper_jacobi_iters", "ilu_upper_it")):
@@ -305,7 +305,8 @@ def test_gmres_amg_matches_oracle(mi, oc, n, stencil, kdim, tol):
 
 @pytest.mark.parametrize("kw", [dict(coarsen_type=6, relax_type=6, num_sweeps=2, interp_type=0), dict(coarsen_type=10),
                                 dict(agg_num_levels=1), dict(agg_num_levels=1, agg_pmax_elmts=4, coarsen_type=10),
-                                dict(smooth_type=5, smooth_num_levels=2)])
+                                dict(smooth_type=5, smooth_num_levels=2),
+                                dict(non_galerkin_tol=0.05)])  # non-Galerkin coarse operators, HypreSystem.cpp:161-176
 def test_gmres_amg_other_hierarchies_match_oracle(mi, oc, kw):
     """GMRES behind the other coarsening choices (src/HypreSystem.cpp:125-126, :215-229): same bars as above."""
     n = 20

@@ -127,6 +127,9 @@ def _assert_same_hierarchy(amg, oamg):
     (18, 7, dict(agg_num_levels=1)),                               # A2 aggressive coarsening + multipass
     (16, 7, dict(agg_num_levels=2, agg_pmax_elmts=4)),
     (12, 27, dict(agg_num_levels=1, coarsen_type=10)),
+    # non-Galerkin coarse operators (src/HypreSystem.cpp:161-176): the device's drop-and-lump pass after the product
+    (16, 7, dict(non_galerkin_tol=0.05)),
+    (12, 27, dict(non_galerkin_tol=0.0, non_galerkin_level_tols=dict(levels=[1, 2, 3], tolerances=[0.05, 0.1, 0.2]))),
 ])
 def test_device_setup_hierarchy_is_bit_identical(mi, oc, n, stencil, kw, monkeypatch):
     """Strength, PMIS, interpolation, Galerkin products, transposes and the C-first renumbering of EVERY level on
@@ -139,6 +142,12 @@ def test_device_setup_hierarchy_is_bit_identical(mi, oc, n, stencil, kw, monkeyp
     chunk = mi.c_int()
     mi.call("HYPRE_MI_GetGSChunk", mi.C.byref(chunk))
     okw = {("pmax_elmts" if k == "true_pmax_elmts" else k): v for k, v in kw.items()}
+    if "non_galerkin_tol" in okw:  # the oracle takes one tolerance per fine level (HYPRE's index)
+        tols = [okw["non_galerkin_tol"]] * 12
+        lt = okw.pop("non_galerkin_level_tols", None)
+        for lev, t in zip(*(lt.values() if lt else ([], []))):
+            tols[lev] = t
+        okw["non_galerkin_tol"] = tols
     oamg = oc.Amg(Ao, oc.default_params(gs_chunk=chunk.value, **okw))
     assert amg.num_levels > 1
     _assert_same_hierarchy(amg, oamg)

@@ -189,3 +189,44 @@ def test_random_mmatrix_coarsening_types_host(mi_lib, oc):
                 pia, pja, pa, _ = amg.level_csr(l, 2)
                 qia, qja, qa = oamg.level_P(l).arrays()
                 assert np.array_equal(pia, qia) and np.array_equal(pja, qja) and np.array_equal(pa, qa)
+
+
+@pytest.mark.parametrize("n,stencil,ng", [(14, 7, dict(non_galerkin_tol=0.05)),
+                                          (10, 27, dict(non_galerkin_tol=0.1)),
+                                          (14, 7, dict(non_galerkin_tol=0.0, non_galerkin_level_tols=dict(levels=[1, 2], tolerances=[0.1, 0.3])))])
+def test_non_galerkin_coarse_operators_match_oracle_host(mi_lib, oc, n, stencil, ng):
+    """Non-Galerkin coarse operators (/root/reference/src/HypreSystem.cpp:161-176: non_galerkin_tol and the level-specific
+    tolerances): the documented drop-and-lump rule shared with the oracle -- hierarchies bit-identical; the sparsified
+    operators are smaller than the Galerkin ones, keep their row sums and stay symmetric."""
+    import scipy.sparse as sp
+
+    mi = mi_lib
+    A, rhs = mi.build_laplace_system_host(n, n, n, stencil, 0, 1)
+    amg = mi.BoomerAMG(print_level=0, **ng)
+    mi.call("HYPRE_MI_BoomerAMGSetupHostOnly", amg.h, A.par)
+    gal = mi.BoomerAMG(print_level=0)
+    mi.call("HYPRE_MI_BoomerAMGSetupHostOnly", gal.h, A.par)
+    Ao, bo = oc.Csr.laplace(n, n, n, stencil)
+    tols = [ng["non_galerkin_tol"]] * 8
+    for lev, t in zip(*(ng.get("non_galerkin_level_tols", dict(levels=[], tolerances=[])).values())):
+        tols[lev] = t
+    oamg = oc.Amg(Ao, oc.default_params(non_galerkin_tol=tols))
+    assert amg.num_levels == oamg.num_levels and amg.num_levels >= 3
+    for l in range(amg.num_levels):
+        ia, ja, a, shape = amg.level_csr(l, 0)
+        oia, oja, oa = oamg.level_A(l).arrays()
+        assert np.array_equal(ia, oia) and np.array_equal(ja, oja) and np.array_equal(a, oa), l
+    assert amg.operator_complexity < gal.operator_complexity
+    # level 1 of the sparsified hierarchy against the Galerkin product of ITS OWN level 0: same row sums, symmetric
+    ia, ja, a, shape = amg.level_csr(1, 0)
+    A1 = sp.csr_matrix((a, ja, ia), shape=shape)
+    pia, pja, pa, pshape = amg.level_csr(0, 2)
+    P = sp.csr_matrix((pa, pja, pia), shape=pshape)
+    a0 = amg.level_csr(0, 0)
+    A0 = sp.csr_matrix((a0[2], a0[1], a0[0]), shape=a0[3])
+    G = (P.T @ A0 @ P).tocsr()
+    if tols[0] > 0:
+        assert A1.nnz < G.nnz
+        assert np.abs(A1.sum(axis=1) - G.sum(axis=1)).max() < 1e-12 and abs(A1 - A1.T).max() < 1e-14
+    else:
+        assert A1.nnz == G.nnz
