@@ -50,6 +50,8 @@ def parse():
                          "BoomerAMG, WEAK scaling (n^3 rows per rank, z-slabs stacked)")
     ap.add_argument("--segregated", type=int, default=0,
                     help="convdiff3: 1 = one solve per component (segregated_solve 1), 0 = one multivector solve")
+    ap.add_argument("--sideline-non-galerkin", type=float, default=0.05,
+                    help="non_galerkin_tol of the side-line leg reported beside the headline at N = 1 (0 = skip)")
     ap.add_argument("--halo-transport", choices=("rccl", "ipc"), default=os.environ.get("MI_BENCH_HALO_TRANSPORT", "rccl"),
                     help="N > 1: how the halo updates travel -- rccl = ncclSend/ncclRecv groups (default), ipc = peer stores into "
                          "hipIpc-mapped mailboxes (HYPRE_MI_CommEnablePeerStoreExchange); reductions are RCCL either way")
@@ -586,6 +588,35 @@ def main():
             "iterations_per_solve": gm.num_iterations, "final_rel_residual": gm.final_rel_res, "steps": g_steps,
             "setup_s": t_setup_g}
         mi.call("HYPRE_MI_SetValueDictionary", 1)
+    # ---- side-line (N = 1): the reference's own knob against the hierarchy's weight, non_galerkin_tol
+    # (/root/reference/src/HypreSystem.cpp:161-176), on the same problem.  NOT the headline: `value` above is the
+    # Galerkin hierarchy of the app defaults.  Outside the timed region.
+    if world == 1 and not args.no_general and roof is not None and not amg_kw and args.sideline_non_galerkin > 0.0:
+        gm.destroy()
+        amg.destroy()
+        amg = mi.BoomerAMG(print_level=0, non_galerkin_tol=args.sideline_non_galerkin)
+        gm = mi.GMRES(tolerance=args.tol, max_iterations=args.max_iter, kspace=args.kdim, print_level=0)
+        gm.set_precond(amg)
+        t0 = time.time()
+        gm.setup(A, b, x)
+        t_setup_n = time.time() - t0
+        one_solve()
+        barrier()
+        t0 = time.perf_counter()
+        n_steps = 3
+        n_iters = sum(one_solve() for _ in range(n_steps))
+        barrier()
+        n_elapsed = time.perf_counter() - t0
+        xs_n = x.get()
+        out["sideline_non_galerkin"] = {
+            "what": f"SIDE-LINE, not the headline: the same solve with boomeramg_settings non_galerkin_tol = "
+                    f"{args.sideline_non_galerkin:g} (coarse operators sparsified after the Galerkin product: entries below "
+                    "tol * min(row maxima) lumped onto the diagonal, DESIGN.md section 9)",
+            "ms_per_step": n_elapsed / n_steps * 1e3, "iterations_per_solve": gm.num_iterations,
+            "value_gdofs": ndof * n_iters / n_elapsed / 1e9, "final_rel_residual": gm.final_rel_res,
+            "max_abs_error_vs_ones": float(np.abs(xs_n - 1.0).max()), "operator_complexity": amg.operator_complexity,
+            "amg_levels": amg.num_levels, "setup_s": t_setup_n, "steps": n_steps,
+            "time_to_solution_vs_headline": (n_elapsed / n_steps) / (elapsed / args.steps)}
     if rank == 0:
         if not args.no_cpu and args.cpu_n != 0 and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, chunk.value)

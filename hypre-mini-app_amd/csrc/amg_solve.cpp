@@ -265,7 +265,8 @@ void BoomerAMG::relax_pair(int level, int type, int first, const double *f, bool
   const double *lo = (first == 1) ? sn : u;
   const double *hi = (first == 1) ? u : sn;
   if (first == 1 && give_t) {
-    k::copy(f, Lv.tvec.p, std::min(Lv.t_from, n), ctx().stream);  // C rows and the chunk that straddles nc: f itself
+    // (rows before t_from -- the C rows and the chunk that straddles nc -- keep f itself: the residual reads them
+    // from f through its composite right-hand side, no copy)
     gs_pass(*this, Lv, A2, false, lo, hi, nc, sn, f, d, Lv.d_cf.p, -1, ch, g, w, nc, n, prof, z2, Lv.tvec.p, Lv.t_from);
     Lv.t_valid = true;
   } else if (first == 1)
@@ -356,7 +357,8 @@ void BoomerAMG::cycle(int level, bool u_is_zero) {
   relax_sweeps(level, 0, Lv.f.p, u_is_zero && p.num_sweeps[0] > 0);
   // r = f - A u ; f_c = P^T r ; u_c = 0
   if (Lv.t_valid && Lv.has_Ar)  // F rows: f - A_FC u_C is in tvec already, only their F columns are left
-    Lv.A->matvec(comm, -1.0, Lv.u.p, 1.0, Lv.tvec.p, Lv.tmp.p, s, k::prof_level(k::PROF_LVL_RESID, level), &Lv.Ar);
+    Lv.A->matvec(comm, -1.0, Lv.u.p, 1.0, Lv.tvec.p, Lv.tmp.p, s, k::prof_level(k::PROF_LVL_RESID, level), &Lv.Ar, Lv.f.p,
+                 std::min(Lv.t_from, Lv.n));
   else
     Lv.A->matvec(comm, -1.0, Lv.u.p, 1.0, Lv.f.p, Lv.tmp.p, s, k::prof_level(k::PROF_LVL_RESID, level));
   Lv.t_valid = false;

@@ -61,7 +61,10 @@ struct EpiArgs {
   const signed char *cf;   // EPI 1 (nullable)
   int points;              // EPI 1
   const int *rowmap;       // EPI 0 (nullable): stored row r is row rowmap[r] of y and b (DevCSR::rowmap)
+  const double *b_lo;      // EPI 0 (nullable): rows < b_split take their b entry from here (a composite right-hand
+  int b_split;             //   side: BoomerAMG's residual after a zero-guess sweep, f for the C rows, f - A_FC u_C after)
 };
+__device__ __forceinline__ double epi_b(const EpiArgs &e, int ro) { return ((e.b_lo && ro < e.b_split) ? e.b_lo : e.b)[ro]; }
 
 template <int EPI>
 __device__ __forceinline__ void epilogue(int r, double s, const double *__restrict__ x, double *__restrict__ y,
@@ -69,7 +72,7 @@ __device__ __forceinline__ void epilogue(int r, double s, const double *__restri
   if (EPI == 0) {
     // y is written once and next read by another kernel: keep it out of L2's way
     const int ro = e.rowmap ? e.rowmap[r] : r;
-    __builtin_nontemporal_store((e.beta == 0.0) ? e.alpha * s : e.alpha * s + e.beta * e.b[ro], y + ro);
+    __builtin_nontemporal_store((e.beta == 0.0) ? e.alpha * s : e.alpha * s + e.beta * epi_b(e, ro), y + ro);
   } else {
     const double xi = x[r];
     double out = xi;
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_xc(int nb, int xchunk, cons
     s0 = ia[r0 + rr] - base_al;
     s1 = ia[r0 + rr + 1] - base_al;
     if (EPI == 0 && e.rowmap && lane == 0) ro = e.rowmap[r0 + rr];
-    if (EPI == 0 && e.beta != 0.0 && lane == 0) bpre = e.b[ro];
+    if (EPI == 0 && e.beta != 0.0 && lane == 0) bpre = epi_b(e, ro);
   }
 #pragma unroll
   for (int q = 0; q < NU; q++) {
@@ -1196,23 +1199,25 @@ __global__ __launch_bounds__(256) void dense_matvec_k(const double *__restrict__
   u[i] = s;
 }
 
-// u[i] = sum_j Mt[j*n + i] * f[j]: a workgroup of 1024 lanes owns 64 consecutive rows i (lane & 63) and splits the
-// columns j over its 16 waves (coalesced 512-byte reads of Mt's rows); the 16 partial sums of a row are added in
-// wave order out of LDS -- a fixed order, the result does not depend on scheduling
+// u[i] = sum_j Mt[j*n + i] * f[j]: a workgroup of 1024 lanes owns 16 consecutive rows i (lane & 15) and splits the
+// columns j over its 64 lane groups (128-byte reads of Mt's rows; ~n/64 loads per lane, all independent: the kernel
+// is a latency chain, not a stream -- 47 workgroups and 12 loads per lane for the 753-row tail of the 512^3
+// hierarchy); the 64 partial sums of a row are added in group order out of LDS -- a fixed order, the result does
+// not depend on scheduling
 __global__ __launch_bounds__(1024) void dense_matvec_t_k(const double *__restrict__ Mt, const double *__restrict__ f,
                                                          double *__restrict__ u, int n) {
-  __shared__ double part[16][64];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + lane;
+  __shared__ double part[64][17];
+  const int r = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + r;
   double s = 0.0;
   if (i < n)
-    for (int j = wv; j < n; j += 16) s += Mt[(size_t)j * (size_t)n + i] * f[j];
-  part[wv][lane] = s;
+    for (int j = g; j < n; j += 64) s += Mt[(size_t)j * (size_t)n + i] * f[j];
+  part[g][r] = s;
   __syncthreads();
-  if (wv == 0 && i < n) {
-    double t = part[0][lane];
-#pragma unroll
-    for (int w = 1; w < 16; w++) t += part[w][lane];
+  if (g == 0 && i < n) {
+    double t = part[0][r];
+#pragma unroll 8
+    for (int w = 1; w < 64; w++) t += part[w][r];
     u[i] = t;
   }
 }
@@ -1499,11 +1504,13 @@ void build_tile_desc(DevCSR &A, hipStream_t s) {
 }
 
 void spmv(const DevCSR &A, const double *x, double alpha, double beta, const double *b, double *y, hipStream_t s,
-          int prof) {
+          int prof, const double *b_lo, int b_split) {
   EpiArgs e{};
   e.alpha = alpha;
   e.beta = beta;
   e.b = b;
+  e.b_lo = b_lo;
+  e.b_split = b_split;
   e.rowmap = A.rowmap.p;
   prof_begin(prof, s);
   prof_name(prof, launch_stream(0, A, x, y, e, s, prof == PROF_SPMV_L0));
@@ -1753,7 +1760,7 @@ void ipc_exchange(const IpcBatch &b, unsigned long long spin_limit, int *error_f
 
 void dense_matvec_t(const double *Mt, const double *f, double *u, int n, hipStream_t s) {
   if (n == 0) return;
-  hipLaunchKernelGGL(dense_matvec_t_k, dim3((n + 63) / 64), dim3(1024), 0, s, Mt, f, u, n);
+  hipLaunchKernelGGL(dense_matvec_t_k, dim3((n + 15) / 16), dim3(1024), 0, s, Mt, f, u, n);
   MI_HIP(hipGetLastError());
 }
 

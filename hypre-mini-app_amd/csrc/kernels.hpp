@@ -59,8 +59,9 @@ void build_value_dictionary(DevCSR &A, hipStream_t s);
 bool value_dictionary_enabled();
 void set_value_dictionary(bool on);
 // y = alpha*A*x + beta*b   (b may alias y)
+// b_lo (optional): rows < b_split take their b entry from b_lo instead of b
 void spmv(const DevCSR &A, const double *x, double alpha, double beta, const double *b, double *y, hipStream_t s,
-          int prof = PROF_NONE);
+          int prof = PROF_NONE, const double *b_lo = nullptr, int b_split = 0);
 // y[rows[k]] += alpha * (B*xext)[k]
 void spmv_offd_add(const DevOffd &B, const double *xext, double alpha, double *y, hipStream_t s);
 // out[rows[k]] = (B*xext)[k]   (other entries of out untouched)

@@ -390,7 +390,7 @@ std::vector<int> ParCSR::halo_exchange_host_int(Comm &comm, const std::vector<in
 }
 
 void ParCSR::matvec(Comm &comm, double alpha, const double *x, double beta, const double *b, double *y,
-                    hipStream_t s, int prof, const DevCSR *diag_op) {
+                    hipStream_t s, int prof, const DevCSR *diag_op, const double *b_lo, int b_split) {
   MI_REQUIRE(on_device, "matrix not assembled");
   const bool halo_on = comm.size > 1 && d_offd.nrows_c > 0;
   // The diag-block product does not need the halo: the neighbour exchange runs beside it on the side stream
@@ -404,7 +404,7 @@ void ParCSR::matvec(Comm &comm, double alpha, const double *x, double beta, cons
     halo_pack(x, s, nullptr, 0);
     MI_HIP(hipEventRecord(ctx().ev_packed, s));
   }
-  k::spmv(diag_op ? *diag_op : d_diag, x, alpha, beta, b, y, s, prof);
+  k::spmv(diag_op ? *diag_op : d_diag, x, alpha, beta, b, y, s, prof, b_lo, b_split);
   if (mine && overlap) {
     hipStream_t cs = ctx().comm_stream;
     MI_HIP(hipStreamWaitEvent(cs, ctx().ev_packed, 0));

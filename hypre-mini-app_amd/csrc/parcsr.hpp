@@ -77,8 +77,9 @@ struct ParCSR {
   // y = alpha*A*x + beta*b
   // diag_op (optional): another operator in place of the diag block (same rows and columns; BoomerAMG's residual
   // after a zero-guess sweep leaves out entries whose product it already has); the halo block is always this one's
+  // b_lo / b_split (optional): rows < b_split read their b entry from b_lo (composite right-hand side)
   void matvec(Comm &comm, double alpha, const double *x, double beta, const double *b, double *y, hipStream_t s,
-              int prof = -1, const DevCSR *diag_op = nullptr);
+              int prof = -1, const DevCSR *diag_op = nullptr, const double *b_lo = nullptr, int b_split = 0);
   // the same with the halo values already in halo.d_xext (no exchange)
   void matvec_ext_ready(double alpha, const double *x, double beta, const double *b, double *y, hipStream_t s);
   // offc[halo rows] = A_offd * x_ext(x)   (used by the smoothers)
