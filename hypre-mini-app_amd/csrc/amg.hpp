@@ -167,7 +167,11 @@ struct BoomerAMG {
   // ~75 latency-bound launches of a cycle).  Same operator, other rounding (1e-16 relative).
   int collapsed_level = -1, collapsed_n = 0;
   DVec<double> collapsed_Bt;  // column j of the map = row j here (n x n)
+  // second stage: the level above (at most MI_HYPRE_DENSE_TAIL_ROWS2 = 4608 rows), tabulated THROUGH the first map
+  int collapsed_level2 = -1, collapsed_n2 = 0;
+  DVec<double> collapsed_Bt2;
   void build_collapsed_tail();
+  void tabulate_cycle(int level, DVec<double> &Bt);
   void apply_global(const double *f, double *e, bool zero_guess);  // one cycle, caller (natural) ordering
   long long effective_redundant_rows() const;
   // levels of the whole hierarchy (the stub counts once, as the tail's fine level) and the owner of one

@@ -1741,8 +1741,8 @@ void BoomerAMG::build_natural(ParCSR &A0) {
         An->dev_diag_nnz = dAc.nnz;
       }
       if (getenv("MI_HYPRE_SETUP_TIMING"))
-        printf("   level %d: n %d  device Galerkin %.2f s (nnz AP %lld, A_c %lld)\n", l, n, wall_time() - tp0,
-               (long long)dAP.nnz, (long long)dAc.nnz);
+        printf("   level %d: n %d  device Galerkin %.2f s (nnz A %lld, P %lld, AP %lld, A_c %lld)\n", l, n, wall_time() - tp0,
+               (long long)Lv.sA.nnz, (long long)Lv.sP.nnz, (long long)dAP.nnz, (long long)dAc.nnz);
     } else {
       HostCSR AP;
       host_spgemm(A.diag, Lv.P, AP);
@@ -2400,7 +2400,9 @@ void BoomerAMG::setup_device() {
     const double tc0 = wall_time();
     build_collapsed_tail();
     if (timing && collapsed_level >= 0)
-      printf("   collapsed coarse tail: levels %d.. as one %d x %d map, %.3f s\n", collapsed_level, collapsed_n, collapsed_n,
+      printf("   collapsed coarse tail: levels %d.. as one %d x %d map%s, %.3f s\n", collapsed_level, collapsed_n, collapsed_n,
+             collapsed_level2 >= 0 ? (", and levels " + std::to_string(collapsed_level2) + ".. as one " +
+                                      std::to_string(collapsed_n2) + " x " + std::to_string(collapsed_n2) + " map").c_str() : "",
              wall_time() - tc0);
   }
   is_setup = true;

@@ -317,7 +317,7 @@ bool BoomerAMG::zero_cycle_ignores_u(int level) {
   if (!enabled || my_comm().size != 1) return false;  // N > 1: the second pass sends pre-sweep (zero) values of its halo rows
   const int nlev = (int)L.size();
   AmgLevel &Lv = L[(size_t)level];
-  if (level == collapsed_level) return true;  // u = B f
+  if (level == collapsed_level || level == collapsed_level2) return true;  // u = B f
   if (level == nlev - 1) {
     if (tail) return false;
     return p.relax_type[2] == 9 && Lv.dense && p.num_sweeps[2] > 0;  // u = C^-1 f
@@ -340,7 +340,11 @@ bool BoomerAMG::zero_cycle_ignores_u(int level) {
 void BoomerAMG::cycle(int level, bool u_is_zero) {
   const int nlev = (int)L.size();
   AmgLevel &Lv = L[(size_t)level];
-  if (level == collapsed_level && u_is_zero) {  // the tabulated map of this level's whole sub-cycle
+  if (level == collapsed_level2 && u_is_zero) {  // the tabulated map of this level's whole sub-cycle
+    k::dense_matvec_t(collapsed_Bt2.p, Lv.f.p, Lv.u.p, collapsed_n2, ctx().stream);
+    return;
+  }
+  if (level == collapsed_level && u_is_zero) {
     k::dense_matvec_t(collapsed_Bt.p, Lv.f.p, Lv.u.p, collapsed_n, ctx().stream);
     return;
   }
@@ -380,24 +384,12 @@ void BoomerAMG::cycle(int level, bool u_is_zero) {
   relax_sweeps(level, 1, Lv.f.p, false);
 }
 
-void BoomerAMG::build_collapsed_tail() {
-  collapsed_level = -1;
-  collapsed_n = 0;
-  collapsed_Bt.release();
-  static const long long max_rows = getenv("MI_HYPRE_DENSE_TAIL_ROWS") ? atoll(getenv("MI_HYPRE_DENSE_TAIL_ROWS")) : 1024;
-  if (max_rows <= 0 || my_comm().size != 1 || tail) return;
-  const int nlev = (int)L.size();
-  int lt = -1;
-  for (int l = 1; l + 1 < nlev; l++)  // the coarsest level alone is one launch already
-    if (L[(size_t)l].n <= max_rows && L[(size_t)l].n > 0) {
-      lt = l;
-      break;
-    }
-  if (lt < 0) return;
+// tabulate the map f -> u of cycle(lt, true) by cycling the unit vectors (row j of Bt = column j of the map)
+void BoomerAMG::tabulate_cycle(int lt, DVec<double> &Bt) {
   AmgLevel &Lv = L[(size_t)lt];
   const int n = Lv.n;
   hipStream_t s = ctx().stream;
-  DVec<double> Bt((size_t)n * (size_t)n);
+  Bt.alloc((size_t)n * (size_t)n);
   DVec<double> one(1);
   const double h_one = 1.0;
   MI_HIP(hipMemcpyAsync(one.p, &h_one, sizeof(double), hipMemcpyHostToDevice, s));
@@ -419,9 +411,38 @@ void BoomerAMG::build_collapsed_tail() {
     throw;
   }
   Lv.f.p = own_f;
+}
+
+void BoomerAMG::build_collapsed_tail() {
+  collapsed_level = collapsed_level2 = -1;
+  collapsed_n = collapsed_n2 = 0;
+  collapsed_Bt.release();
+  collapsed_Bt2.release();
+  static const long long max_rows = getenv("MI_HYPRE_DENSE_TAIL_ROWS") ? atoll(getenv("MI_HYPRE_DENSE_TAIL_ROWS")) : 1024;
+  static const long long max_rows2 = getenv("MI_HYPRE_DENSE_TAIL_ROWS2") ? atoll(getenv("MI_HYPRE_DENSE_TAIL_ROWS2")) : 4608;
+  if (max_rows <= 0 || my_comm().size != 1 || tail) return;
+  const int nlev = (int)L.size();
+  int lt = -1;
+  for (int l = 1; l + 1 < nlev; l++)  // the coarsest level alone is one launch already
+    if (L[(size_t)l].n <= max_rows && L[(size_t)l].n > 0) {
+      lt = l;
+      break;
+    }
+  if (lt < 0) return;
+  DVec<double> Bt;
+  tabulate_cycle(lt, Bt);
   collapsed_Bt = std::move(Bt);
-  collapsed_n = n;
+  collapsed_n = L[(size_t)lt].n;
   collapsed_level = lt;
+  // second stage: the level above, through the map just built (one sub-cycle = its own ~9 launches + one dense
+  // product: tabulating ~4000 columns costs a few tenths of a second; 512^3: level 7, 4303 rows, 148 MB)
+  if (lt - 1 >= 1 && L[(size_t)lt - 1].n <= max_rows2) {
+    DVec<double> Bt2;
+    tabulate_cycle(lt - 1, Bt2);
+    collapsed_Bt2 = std::move(Bt2);
+    collapsed_n2 = L[(size_t)lt - 1].n;
+    collapsed_level2 = lt - 1;
+  }
 }
 
 // the stub level's right-hand side (this rank's slice) -> whole level on every rank -> one cycle of the

@@ -1186,12 +1186,14 @@ HYPRE_Int HYPRE_MI_SetGSChunk(HYPRE_Int rows) {
   ctx().gs_chunk = rows;
   API_END
 }
-// the size check HYPRE_IJMatrixAssemble and the solve format apply to one rank's block, on a caller-supplied
-// row-pointer array (tests exercise the 32-bit boundary without building a 2^31-entry matrix)
+// the size check HYPRE_IJMatrixAssemble and the solve format apply to one rank's diagonal block, on a caller-supplied
+// row-pointer array (tests exercise the boundaries without building a 2^31-entry matrix): 32-bit local row ids,
+// 64-bit entry offsets, but no single row of 2^31 entries or more
 HYPRE_Int HYPRE_MI_CheckBlockRowPointers(HYPRE_BigInt nrows, const HYPRE_BigInt *row_ptr) {
   API_BEGIN
   if (nrows < 0 || (nrows > 0 && !row_ptr)) fail(HYPRE_ERROR_ARG, "CheckBlockRowPointers: bad argument");
-  require_int32_block(nrows, nrows > 0 ? row_ptr[nrows] : 0, "IJMatrixAssemble");
+  require_int32_block(nrows, 0, "IJMatrixAssemble");
+  for (HYPRE_BigInt i = 0; i < nrows; i++) require_int32_block(0, row_ptr[i + 1] - row_ptr[i], "IJMatrixAssemble (one row)");
   API_END
 }
 HYPRE_Int HYPRE_MI_GetCounter(const char *name, long long *value) {
@@ -1308,9 +1310,11 @@ HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSRSize(HYPRE_Solver solver, HYPRE_Int level
     *nrows = L.nc;
     *ncols = L.A->diag.ncols;
     int e = 0;
-    if (L.nc > 0 && L.A->d_diag.ia.p) MI_HIP(hipMemcpy(&e, L.A->d_diag.ia.p + L.nc, sizeof(int), hipMemcpyDeviceToHost));
-    else if (L.nc > 0 && !L.A->diag.ia.empty()) e = (int)L.A->diag.ia[(size_t)L.nc];
-    *nnz = e;
+    long long e64 = -1;
+    if (L.nc > 0 && L.A->d_diag.ia64.p) MI_HIP(hipMemcpy(&e64, L.A->d_diag.ia64.p + L.nc, sizeof(long long), hipMemcpyDeviceToHost));
+    else if (L.nc > 0 && L.A->d_diag.ia.p) MI_HIP(hipMemcpy(&e, L.A->d_diag.ia.p + L.nc, sizeof(int), hipMemcpyDeviceToHost));
+    else if (L.nc > 0 && !L.A->diag.ia.empty()) e64 = (long long)L.A->diag.ia[(size_t)L.nc];
+    *nnz = e64 >= 0 ? e64 : e;
     return 0;
   }
   if (which == 7) {  // x cache of the level operator: tiles, 0, total unique columns over the tiles

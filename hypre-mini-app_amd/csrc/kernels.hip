@@ -177,10 +177,12 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_xc(int nb, int xchunk, cons
   if (VAL8 && tid < 256) slut[tid] = vlut[tid];  // visible after the first barrier below
   const int4 d0 = reinterpret_cast<const int4 *>(tdesc)[2 * blk];
   const int4 d1 = reinterpret_cast<const int4 *>(tdesc)[2 * blk + 1];
-  const int r0 = d0.x, r1 = d0.y, base = d0.z, end = d0.w, u0 = d1.x, nu = d1.y;
-  if (end - base >= TILE) {
+  const int r0 = d0.x, r1 = d0.y, len = d0.w, u0 = d1.x, nu = d1.y;
+  // the tile's entry range starts at a 64-bit offset (operators beyond 2^31 entries); everything below is tile-local
+  const long long base64 = ((long long)d1.z << 32) | (long long)(unsigned)d0.z;
+  if (len >= TILE) {
     double s = 0.0;
-    for (int k = base + tid; k < end; k += BLOCK) s += av[k] * x[ja[k]];
+    for (long long k = base64 + tid; k < base64 + len; k += BLOCK) s += av[k] * x[ja[k]];
     s = wave_sum(s);
     if ((tid & 63) == 0) prod[tid >> 6] = s;
     __syncthreads();
@@ -198,8 +200,14 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_xc(int nb, int xchunk, cons
     const int k = tid + q * BLOCK;
     uc[q] = (k < nu) ? ucols[u0 + k] : 0;
   }
-  const int base_al = base & ~1;
-  const int cnt = end - base_al;
+  const long long base_al64 = base64 & ~1LL;
+  const int base = (int)(base64 - base_al64), base_al = 0;  // tile-local: the aligned start is 0, the first entry 0 or 1
+  const int end = base + len;
+  const int cnt = end;
+  const unsigned ia_off = (unsigned)base_al64;  // low word: (unsigned)ia[row] - ia_off = the row's tile-local offset
+  av += base_al64;
+  lcol += base_al64;
+  if (VAL8) vidx += base_al64;
   constexpr int NIT = TILE / (2 * BLOCK);
   d2_t vv[NIT];
   us2_t cc[NIT];
@@ -227,8 +235,8 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_xc(int nb, int xchunk, cons
   double bpre = 0.0;  // EPI 0 with beta != 0: the b entry of this thread's row, requested with the other loads
   int ro = r0 + rr;   // EPI 0: where this thread's row lands in y (operators stored in another row order)
   if (rr < nr) {
-    s0 = ia[r0 + rr] - base_al;
-    s1 = ia[r0 + rr + 1] - base_al;
+    s0 = (int)((unsigned)ia[r0 + rr] - ia_off);
+    s1 = (int)((unsigned)ia[r0 + rr + 1] - ia_off);
     if (EPI == 0 && e.rowmap && lane == 0) ro = e.rowmap[r0 + rr];
     if (EPI == 0 && e.beta != 0.0 && lane == 0) bpre = epi_b(e, ro);
   }
@@ -275,22 +283,24 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_xc(int nb, int xchunk, cons
   }
   // tiles with more rows than threads (G == 1 there): the remaining rows, one lane each
   for (int r2 = tid + BLOCK; r2 < nr; r2 += BLOCK) {
-    const int a0 = ia[r0 + r2] - base_al, a1 = ia[r0 + r2 + 1] - base_al;
+    const int a0 = (int)((unsigned)ia[r0 + r2] - ia_off), a1 = (int)((unsigned)ia[r0 + r2 + 1] - ia_off);
     double s = 0.0;
     for (int k = a0; k < a1; k++) s += prod[k];
     epilogue<EPI>(r0 + r2, s, x, y, e);
   }
 }
 
-__global__ __launch_bounds__(256) void tile_desc_k(int nb, const int *__restrict__ rb, const int *__restrict__ ia,
+__global__ __launch_bounds__(256) void tile_desc_k(int nb, const int *__restrict__ rb, const long long *__restrict__ ia,
                                                    const int *__restrict__ uptr, int *__restrict__ desc) {
   const int b = blockIdx.x * 256 + threadIdx.x;
   if (b >= nb) return;
   const int r0 = rb[b], r1 = rb[b + 1];
   int4 *d = reinterpret_cast<int4 *>(desc) + 2 * (size_t)b;
   const int u0 = uptr ? uptr[b] : 0, u1 = uptr ? uptr[b + 1] : 0;
-  d[0] = make_int4(r0, r1, ia[r0], ia[r1]);
-  d[1] = make_int4(u0, u1 - u0, 0, 0);
+  const long long base = ia[r0], len = ia[r1] - base;
+  // a single row longer than any tile (>= 2^31 entries it cannot be: such rows do not exist) keeps its true length
+  d[0] = make_int4(r0, r1, (int)(unsigned)(base & 0xffffffffLL), (int)(len > 0x7fffffffLL ? 0x7fffffffLL : len));
+  d[1] = make_int4(u0, u1 - u0, (int)(base >> 32), 0);
 }
 
 // compressed-row off-diagonal block: one lane per stored row (halo rows are few
@@ -760,7 +770,8 @@ __global__ __launch_bounds__(BLOCK) void gs_tile_k(int blk0, int nblk, const int
   // list, matrix stream, per-row data; the gathers start when the column ids are back
   const int4 d0 = reinterpret_cast<const int4 *>(tdesc)[2 * blk];
   const int4 d1 = reinterpret_cast<const int4 *>(tdesc)[2 * blk + 1];
-  const int r0 = d0.x, r1 = d0.y, base = d0.z, end = d0.w, u0 = d1.x, nu = d1.y;
+  const int r0 = d0.x, r1 = d0.y, len = d0.w, u0 = d1.x, nu = d1.y;
+  const long long base64 = ((long long)d1.z << 32) | (long long)(unsigned)d0.z;  // see spmv_stream_xc
   // columns >= zero_from hold zeros by contract (first sweep on a zero guess): nothing to gather there --
   // the unique columns ascend, so for zero_from == 0 not even the ids are read
   const bool all_zero = zero_from <= 0;
@@ -773,8 +784,14 @@ __global__ __launch_bounds__(BLOCK) void gs_tile_k(int blk0, int nblk, const int
       ucid[q] = (k < nu) ? ucols[u0 + k] : 0;
     }
   }
-  const int base_al = base & ~1;
-  const int cnt = end - base_al;
+  const long long base_al64 = base64 & ~1LL;
+  const int base = (int)(base64 - base_al64), base_al = 0;  // tile-local from here on
+  const int end = base + len;
+  const int cnt = end;
+  const unsigned ia_off = (unsigned)base_al64;
+  av += base_al64;
+  lcol += base_al64;
+  if (VAL8) vidx += base_al64;
   constexpr int NIT = TILE / (2 * BLOCK);
   d2_t vv[NIT];
   us2_t cc[NIT];
@@ -808,8 +825,8 @@ __global__ __launch_bounds__(BLOCK) void gs_tile_k(int blk0, int nblk, const int
       myrhs = f[i];
       if (offc) myrhs -= offc[i];
       if (myd != 0.0) wd = w / myd;
-      s0 = ia[i] - base_al;
-      s1 = ia[i + 1] - base_al;
+      s0 = (int)((unsigned)ia[i] - ia_off);
+      s1 = (int)((unsigned)ia[i + 1] - ia_off);
     }
   }
   if (!all_zero) {
@@ -1358,6 +1375,7 @@ static bool gs_force_generic() {
 static const char *launch_stream(int epi, const DevCSR &A, const double *x, double *y, const EpiArgs &e, hipStream_t s,
                                  bool level0 = false) {
   if (A.nrows == 0) return "";
+  MI_REQUIRE(A.xcache || !A.big(), "an operator with 2^31 entries or more must be in the x-cache tile format");
   const char *name = "";
   const int nb = A.nblocks;
   const int xchunk = (nb + 7) / 8;
@@ -1493,11 +1511,11 @@ void build_value_dictionary(DevCSR &A, hipStream_t s) {
   A.val8 = true;
 }
 
-void build_tile_desc(DevCSR &A, hipStream_t s) {
+void build_tile_desc(DevCSR &A, const long long *ia64, hipStream_t s) {
   A.tdesc.release();
   if (A.nblocks <= 0 || !A.rb.p) return;
   A.tdesc.alloc((size_t)A.nblocks * 8);
-  hipLaunchKernelGGL(tile_desc_k, dim3((unsigned)((A.nblocks + 255) / 256)), dim3(256), 0, s, A.nblocks, A.rb.p, A.ia.p,
+  hipLaunchKernelGGL(tile_desc_k, dim3((unsigned)((A.nblocks + 255) / 256)), dim3(256), 0, s, A.nblocks, A.rb.p, ia64,
                      A.xcache ? A.uptr.p : nullptr, A.tdesc.p);
   MI_HIP(hipGetLastError());
   build_value_dictionary(A, s);
@@ -1594,6 +1612,7 @@ void gs_hybrid(const DevCSR &A, const double *u_lo, const double *u_hi, int spli
     }
 #undef GS_TILE_LAUNCH
   } else if (chunk == 8 && !gs_force_generic()) {
+    MI_REQUIRE(!A.big(), "an operator with 2^31 entries or more is swept by the tile Gauss-Seidel kernel only");
     prof_name(prof, "gs_group_k / gs_dense_k (chunk kernels)");
     const double avg = (double)A.nnz / (double)A.nrows;
     const int p95 = A.rowlen_p95;
@@ -1627,6 +1646,7 @@ void gs_hybrid(const DevCSR &A, const double *u_lo, const double *u_hi, int spli
 #undef GS_LAUNCH_K
 #undef GS_LAUNCH
   } else {
+    MI_REQUIRE(!A.big(), "an operator with 2^31 entries or more is swept by the tile Gauss-Seidel kernel only");
     const size_t lds = (size_t)chunk * GS_BLOCK * sizeof(double);
     prof_name(prof, "gs_hybrid_k");
     hipLaunchKernelGGL(gs_hybrid_k, dim3((unsigned)((nch + GS_BLOCK - 1) / GS_BLOCK)), dim3(GS_BLOCK), lds, s,
@@ -1746,6 +1766,7 @@ void two_stage_first(const double *r, const double *d, double *z, double *u, int
 void two_stage_lower(const DevCSR &A, const double *d, const double *zin, double sign, double *zout, double *u,
                      hipStream_t s) {
   if (A.nrows <= 0) return;
+  MI_REQUIRE(!A.big(), "two-stage Gauss-Seidel: operators with 2^31 entries or more are not supported");
   hipLaunchKernelGGL(two_stage_lower_k, dim3((A.nrows + 255) / 256), dim3(256), 0, s, A.nrows, A.ia.p, A.ja.p, A.a.p, d,
                      zin, sign, zout, u);
 }

@@ -52,7 +52,8 @@ constexpr int XC_OFF_SHIFT = 12;    // ... at this offset (3 bits)
 
 // per-tile descriptors of the SpMV / tile-GS kernels (row range, entry range, column-list range: 8 ints per
 // tile); call after rb, ia and (x cache) uptr are in place
-void build_tile_desc(DevCSR &A, hipStream_t s);
+// ia64: the operator's 64-bit row pointers (device; the descriptors carry full 64-bit tile bases)
+void build_tile_desc(DevCSR &A, const long long *ia64, hipStream_t s);
 // value dictionary of an operator with at most 256 distinct values (called by build_tile_desc)
 void build_value_dictionary(DevCSR &A, hipStream_t s);
 // MI_HYPRE_VALUE_DICT / HYPRE_MI_SetValueDictionary: applies to operators put into the solve format afterwards

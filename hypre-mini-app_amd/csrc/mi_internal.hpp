@@ -93,11 +93,19 @@ struct HostCSR {
 };
 
 // ---------------------------------------------------------------- device CSR
-// int32 row pointers: every per-rank, per-level block must hold < 2^31 entries.
+// Row pointers: `ia` holds the LOW 32 bits of every entry offset (4 bytes per row in the solve kernels' streams).
+// The tile kernels (spmv_stream_xc, gs_tile_k) take a tile's full 64-bit base from its descriptor and form
+// tile-local offsets as (unsigned)ia[row] - (unsigned)base, which is exact because a tile holds < 2^16 entries -- so
+// an operator may hold more than 2^31 entries (the reference generator's 27-point operator at 512^3: 3.6e9,
+// /root/reference/src/laplace_3d_weak_scaling.hpp:558,600).  Such an operator ("big") also keeps the 64-bit row
+// pointers (`ia64`, 8 bytes per row, setup paths only) and must run on the tile kernels; the other kernels
+// (plain row-block SpMV, chunk Gauss-Seidel, two-stage sweeps) index with `ia` directly and refuse it.
 struct DevCSR {
   int nrows = 0, ncols = 0;
   int64_t nnz = 0;
   DVec<int> ia;
+  DVec<long long> ia64;  // only when nnz >= 2^31
+  bool big() const { return nnz >= (int64_t)2147483647; }
   DVec<int> ja;
   DVec<double> a;
   // row-block schedule of the LDS-staged SpMV (kernels.hip: spmv_stream)
@@ -130,7 +138,7 @@ struct DevCSR {
   // consecutive rows then gather neighbouring fine entries -- while the coarse level's vectors are in its own
   // C-first order (amg_setup.cpp: setup_device).  Empty = identity.
   DVec<int> rowmap;
-  DVec<int> tdesc;  // 8 ints per tile: r0, r1, ia[r0], ia[r1], uptr[b], #unique columns, 0, 0 (k::build_tile_desc)
+  DVec<int> tdesc;  // 8 ints per tile: r0, r1, low word of ia[r0], ia[r1] - ia[r0], uptr[b], #unique columns, high word of ia[r0], 0 (k::build_tile_desc)
   bool empty() const { return nrows == 0 || nnz == 0; }
   void upload(const HostCSR &h);
 };

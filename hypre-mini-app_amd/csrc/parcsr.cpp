@@ -31,13 +31,15 @@ void ParVector::init(gidx s, gidx e, int nc) {
   if (n) zero_on_stream(d.p, (size_t)n * ncomp * sizeof(double));
 }
 
+// nnz: entries of a block whose offsets stay 32-bit (the halo block; a single row); 0 = not checked -- the diagonal
+// block's entry offsets are 64-bit (tile descriptors carry the high word, DevCSR)
 void require_int32_block(int64_t nrows, int64_t nnz, const char *what) {
   if (nrows >= MAX_BLOCK_ENTRIES)
     fail(4, std::string(what) + ": " + std::to_string(nrows) +
                 " local rows exceed the 32-bit local row ids of the solve format; split the rows over more ranks");
   if (nnz >= MAX_BLOCK_ENTRIES)
-    fail(4, std::string(what) + ": " + std::to_string(nnz) + " entries in one rank's block exceed the 32-bit entry offsets "
-                "of the solve format (limit " + std::to_string(MAX_BLOCK_ENTRIES) + "); split the rows over more ranks");
+    fail(4, std::string(what) + ": " + std::to_string(nnz) + " entries exceed the 32-bit entry offsets of this block "
+                "(limit " + std::to_string(MAX_BLOCK_ENTRIES) + "); split the rows over more ranks");
 }
 
 // ------------------------------------------------------------------ IJ assembly
@@ -214,8 +216,7 @@ void assemble_parcsr(Comm &comm, gidx ilower, gidx iupper, gidx jlower, gidx jup
     D.ia[(size_t)i + 1] = D.ia[(size_t)i] + ndiag[(size_t)i];
     O.ia[(size_t)i + 1] = O.ia[(size_t)i] + noffd[(size_t)i];
   }
-  require_int32_block(nrows, D.nnz(), "IJMatrixAssemble (diagonal block)");
-  require_int32_block(nrows, O.nnz(), "IJMatrixAssemble (off-diagonal block)");
+  require_int32_block(nrows, O.nnz(), "IJMatrixAssemble (off-diagonal block)");  // the diagonal block: 64-bit offsets
   D.ja.resize((size_t)D.nnz());
   D.a.resize((size_t)D.nnz());
   O.ja.resize((size_t)O.nnz());

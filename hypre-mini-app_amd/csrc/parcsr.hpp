@@ -103,9 +103,10 @@ void assemble_parcsr(Comm &comm, gidx ilower, gidx iupper, gidx jlower, gidx jup
 
 bool is_device_pointer(const void *p);
 
-// The solve format keeps 32-bit local row ids and 32-bit entry offsets per rank and block (kernels.hip): a block
-// beyond that is refused with HYPRE_ERROR_ARG and a message, never wrapped around (e.g. the reference's 27-point
-// operator at 512^3 has 3.6e9 entries, /root/reference/src/laplace_3d_weak_scaling.hpp:558,600: two ranks or more)
+// The solve format keeps 32-bit local row ids per rank; a rank's DIAGONAL block may hold any number of entries (64-bit
+// tile bases, mi_internal.hpp DevCSR -- e.g. the reference's 27-point operator at 512^3, 3.6e9 entries on one rank,
+// /root/reference/src/laplace_3d_weak_scaling.hpp:558,600); the halo block and a single row keep 32-bit offsets.
+// Anything beyond that is refused with HYPRE_ERROR_ARG and a message, never wrapped around.
 constexpr int64_t MAX_BLOCK_ENTRIES = 2147483000LL;
 void require_int32_block(int64_t nrows, int64_t nnz, const char *what);
 

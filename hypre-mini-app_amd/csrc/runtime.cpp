@@ -162,7 +162,8 @@ void DevCSR::upload(const HostCSR &h) {
   nrows = h.nrows;
   ncols = h.ncols;
   nnz = h.nnz();
-  require_int32_block(nrows, nnz, "solve format");
+  require_int32_block(nrows, nnz, "solve format (host builder: small operators; large ones go through sk::to_solve_format)");
+  ia64.release();
   std::vector<int> ia32((size_t)nrows + 1);
   for (int i = 0; i <= nrows; i++) ia32[(size_t)i] = (int)h.ia[(size_t)i];
   ia.upload(ia32);
@@ -223,8 +224,14 @@ void DevCSR::upload(const HostCSR &h) {
     lcol.upload(lc);
     gs_tiles = aligned && nrows == ncols;
   }
-  k::build_tile_desc(*this, ctx().stream);
-  MI_HIP(hipStreamSynchronize(ctx().stream));
+  {
+    DVec<long long> wide;
+    std::vector<long long> hia(h.ia.begin(), h.ia.end());
+    if (hia.empty()) hia.assign((size_t)nrows + 1, 0);
+    wide.upload(hia);
+    k::build_tile_desc(*this, wide.p, ctx().stream);
+    MI_HIP(hipStreamSynchronize(ctx().stream));
+  }
 }
 
 void DevOffd::upload(int nrows, const HostCSR &h) {

@@ -26,6 +26,18 @@ namespace {
 constexpr int EMPTY = 0x7fffffff;
 constexpr int BLK = 256;
 
+// A launch may not exceed 2^32 - 1 threads per grid dimension.  Kernels that give a row 8 ... 256 lanes pass that with
+// tens of millions of rows (27-point operator at 400^3: 64 M rows x 256 lanes -- the launch silently ran on the
+// remainder modulo 2^32 and left most interpolation rows empty): such grids are folded into two dimensions, and the
+// kernels number their workgroups with bid().  Workgroups beyond the work fall out at the kernels' bounds checks.
+__device__ __forceinline__ long long bid() { return (long long)blockIdx.y * gridDim.x + blockIdx.x; }
+inline dim3 grid_for(long long nblocks) {
+  constexpr long long GX = 1 << 20;  // x 256 lanes = 2^28 threads per row of the grid
+  if (nblocks < 1) nblocks = 1;
+  if (nblocks <= GX) return dim3((unsigned)nblocks);
+  return dim3((unsigned)GX, (unsigned)((nblocks + GX - 1) / GX));
+}
+
 __device__ __forceinline__ bool hs_insert(int *tab, int log_h, int j) {
   const unsigned mask = (1u << log_h) - 1u;
   unsigned s = ((unsigned)j * 2654435761u) >> (32 - log_h);
@@ -74,7 +86,7 @@ __global__ __launch_bounds__(BLK) void row_products_k(int n, const long long *__
   if (threadIdx.x < 4) hist[threadIdx.x] = 0;
   if (threadIdx.x == 0) smax = 0;
   __syncthreads();
-  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  const long long i = bid() * BLK + threadIdx.x;
   if (i < n) {
     long long t = 0;
     for (long long ka = Aia[i]; ka < Aia[i + 1]; ka++) {
@@ -98,7 +110,7 @@ __global__ __launch_bounds__(BLK) void bin_fill_k(int n, const int *__restrict__
   __shared__ int hist[4], base[4];
   if (threadIdx.x < 4) hist[threadIdx.x] = 0;
   __syncthreads();
-  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  const long long i = bid() * BLK + threadIdx.x;
   int b = -1, off = 0;
   if (i < n) {
     const int ti = T[i];
@@ -128,7 +140,7 @@ __global__ __launch_bounds__(BLK) void spgemm_group_k(int nlist, const int *__re
   __shared__ int list[GP][CAP];
   __shared__ int cnt[GP];
   const int g = threadIdx.x / G, lane = threadIdx.x % G;
-  const long long gi = (long long)blockIdx.x * GP + g;
+  const long long gi = bid() * GP + g;
   const bool active = gi < nlist;
   const int row = active ? rows[gi] : 0;
   for (int t = lane; t < H; t += G) tab[g][t] = EMPTY;
@@ -284,7 +296,7 @@ __global__ __launch_bounds__(BLK) void scan_sums_k(long long ntiles, long long *
 
 __global__ __launch_bounds__(BLK) void scan_add_k(long long n, long long *__restrict__ out,
                                                   const long long *__restrict__ tile_sum, long long ntiles) {
-  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  const long long i = bid() * BLK + threadIdx.x;
   if (i < n) out[i] += tile_sum[i / SCAN_TILE];
   if (i == n) out[n] = tile_sum[ntiles];
 }
@@ -323,7 +335,7 @@ __global__ __launch_bounds__(BLK) void strength_k(int n, const long long *__rest
                                                   const double *__restrict__ a, double theta, double max_row_sum,
                                                   int *__restrict__ cnt, const long long *__restrict__ sia,
                                                   int *__restrict__ sja) {
-  const long long i = ((long long)blockIdx.x * BLK + threadIdx.x) / G;
+  const long long i = (bid() * BLK + threadIdx.x) / G;
   const int sub = threadIdx.x % G, lane = threadIdx.x & 63, gbase = lane - sub;
   const bool live = i < n;
   const long long k0 = live ? ia[i] : 0, k1 = live ? ia[i + 1] : 0;
@@ -399,7 +411,7 @@ __global__ __launch_bounds__(BLK) void pmis_init_k(int n, const long long *__res
                                                    const int *__restrict__ incoming, int seed0,
                                                    double *__restrict__ measure, int *__restrict__ cf,
                                                    int *__restrict__ undecided) {
-  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  const long long i = bid() * BLK + threadIdx.x;
   if (i >= n) return;
   // element i of the Park-Miller stream: seed0 * 16807^(i+1) mod (2^31 - 1)
   unsigned long long base = 16807ULL, acc = (unsigned long long)seed0, e = (unsigned long long)i + 1ULL;
@@ -420,7 +432,7 @@ __global__ __launch_bounds__(BLK) void pmis_init_k(int n, const long long *__res
 }
 
 __global__ __launch_bounds__(BLK) void pmis_mark_k(int n, const int *__restrict__ cf, signed char *__restrict__ tmp) {
-  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  const long long i = bid() * BLK + threadIdx.x;
   if (i < n) tmp[i] = (cf[i] == 0);
 }
 
@@ -428,7 +440,7 @@ __global__ __launch_bounds__(BLK) void pmis_compare_k(int n, const long long *__
                                                       const int *__restrict__ sja, const int *__restrict__ cf,
                                                       const double *__restrict__ measure,
                                                       signed char *__restrict__ tmp) {
-  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  const long long i = bid() * BLK + threadIdx.x;
   if (i >= n || cf[i] != 0) return;
   const double mi = measure[i];
   bool lose = false;
@@ -445,7 +457,7 @@ __global__ __launch_bounds__(BLK) void pmis_compare_k(int n, const long long *__
 }
 
 __global__ __launch_bounds__(BLK) void pmis_select_k(int n, int *__restrict__ cf, const signed char *__restrict__ tmp) {
-  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  const long long i = bid() * BLK + threadIdx.x;
   if (i < n && cf[i] == 0 && tmp[i]) cf[i] = C_PT;
 }
 
@@ -453,7 +465,7 @@ __global__ __launch_bounds__(BLK) void pmis_select_k(int n, int *__restrict__ cf
 __global__ __launch_bounds__(BLK) void pmis_fpoints_k(int n, const long long *__restrict__ sia,
                                                       const int *__restrict__ sja, int *__restrict__ cf,
                                                       int *__restrict__ undecided) {
-  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  const long long i = bid() * BLK + threadIdx.x;
   if (i >= n || cf[i] != 0) return;
   for (long long k = sia[i]; k < sia[i + 1]; k++)
     if (cf[sja[k]] == C_PT) {  // other rows only ever switch 0 -> F here, never to or from C
@@ -481,7 +493,7 @@ __global__ __launch_bounds__(BLK) void interp_bound_k(int n, const long long *__
   if (threadIdx.x < 4) hist[threadIdx.x] = 0;
   if (threadIdx.x == 0) smax = 0;
   __syncthreads();
-  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  const long long i = bid() * BLK + threadIdx.x;
   if (i < n) {
     const int c = cf[i];
     long long t = 0;
@@ -556,7 +568,7 @@ __global__ __launch_bounds__(BT) void interp_group_k(int nlist, const int *__res
   __shared__ InterpGroup<CAP> grp[GP];
   InterpGroup<CAP> &L = grp[threadIdx.x / G];
   const int lane = threadIdx.x % G;
-  const long long gi = (long long)blockIdx.x * GP + threadIdx.x / G;
+  const long long gi = bid() * GP + threadIdx.x / G;
   const bool active = gi < nlist;
   const int i = active ? rows[gi] : 0;
   const int mycf = active ? cf[i] : SF_PT;
@@ -789,7 +801,7 @@ __global__ __launch_bounds__(BLK) void compact_rows_k(int n, const long long *__
                                                       const int *__restrict__ sj, const double *__restrict__ sa,
                                                       const long long *__restrict__ ia, int *__restrict__ dj,
                                                       double *__restrict__ da) {
-  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  const long long i = bid() * BLK + threadIdx.x;
   if (i >= n) return;
   const long long s0 = slack_ia[i], d0 = ia[i];
   const int len = (int)(ia[i + 1] - d0);
@@ -800,7 +812,7 @@ __global__ __launch_bounds__(BLK) void compact_rows_k(int n, const long long *__
 }
 
 __global__ __launch_bounds__(BLK) void sf_to_f_k(int n, int *__restrict__ cf) {
-  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  const long long i = bid() * BLK + threadIdx.x;
   if (i < n && cf[i] == SF_PT) cf[i] = F_PT;
 }
 
@@ -810,7 +822,7 @@ template <int G>
 __global__ __launch_bounds__(BLK) void sort_rows_k(int n, const long long *__restrict__ ia, const int *__restrict__ sj,
                                                    const double *__restrict__ sa, int *__restrict__ dj,
                                                    double *__restrict__ da) {
-  const long long row = ((long long)blockIdx.x * BLK + threadIdx.x) / G;
+  const long long row = (bid() * BLK + threadIdx.x) / G;
   const int lane = threadIdx.x % G;
   if (row >= n) return;
   const long long b = ia[row];
@@ -829,7 +841,7 @@ void sort_rows(int n, int64_t nnz, const long long *ia, const int *sj, const dou
   if (n == 0 || nnz == 0) return;
   const double avg = (double)nnz / (double)n;
   const long long threads_needed = (long long)n * (avg <= 16 ? 8 : avg <= 48 ? 16 : 64);
-  const unsigned grid = (unsigned)((threads_needed + BLK - 1) / BLK);
+  const dim3 grid = grid_for((threads_needed + BLK - 1) / BLK);
   if (avg <= 16)
     sort_rows_k<8><<<grid, BLK, 0, s>>>(n, ia, sj, sa, dj, da);
   else if (avg <= 48)
@@ -839,7 +851,7 @@ void sort_rows(int n, int64_t nnz, const long long *ia, const int *sj, const dou
 }
 
 __global__ __launch_bounds__(BLK) void col_count_k(long long nnz, const int *__restrict__ ja, int *__restrict__ cnt) {
-  const long long k = (long long)blockIdx.x * BLK + threadIdx.x;
+  const long long k = bid() * BLK + threadIdx.x;
   if (k < nnz) atomicAdd(&cnt[ja[k]], 1);
 }
 
@@ -847,7 +859,7 @@ __global__ __launch_bounds__(BLK) void transpose_fill_k(int n, const long long *
                                                         const int *__restrict__ ja, const double *__restrict__ a,
                                                         const long long *__restrict__ tia, int *__restrict__ cursor,
                                                         int *__restrict__ tj, double *__restrict__ ta) {
-  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  const long long i = bid() * BLK + threadIdx.x;
   if (i >= n) return;
   for (long long k = ia[i]; k < ia[i + 1]; k++) {
     const int j = ja[k];
@@ -859,7 +871,7 @@ __global__ __launch_bounds__(BLK) void transpose_fill_k(int n, const long long *
 
 __global__ __launch_bounds__(BLK) void perm_len_k(int n, const long long *__restrict__ ia, const int *__restrict__ perm,
                                                   int *__restrict__ len) {
-  const long long q = (long long)blockIdx.x * BLK + threadIdx.x;
+  const long long q = bid() * BLK + threadIdx.x;
   if (q >= n) return;
   const int i = perm ? perm[q] : (int)q;
   len[q] = (int)(ia[i + 1] - ia[i]);
@@ -869,7 +881,7 @@ __global__ __launch_bounds__(BLK) void perm_copy_k(int n, const long long *__res
                                                    const double *__restrict__ a, const int *__restrict__ perm,
                                                    const int *__restrict__ colpos, const long long *__restrict__ bia,
                                                    int *__restrict__ bj, double *__restrict__ ba) {
-  const long long q = ((long long)blockIdx.x * BLK + threadIdx.x) / 8;
+  const long long q = (bid() * BLK + threadIdx.x) / 8;
   const int lane = threadIdx.x % 8;
   if (q >= n) return;
   const int i = perm ? perm[q] : (int)q;
@@ -884,11 +896,11 @@ __global__ __launch_bounds__(BLK) void perm_copy_k(int n, const long long *__res
 
 // ---------------------------------------------------------------- solve-phase format on the device
 __global__ __launch_bounds__(BLK) void ia_to_32_k(long long n1, const long long *__restrict__ ia, int *__restrict__ ia32) {
-  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  const long long i = bid() * BLK + threadIdx.x;
   if (i < n1) ia32[i] = (int)ia[i];
 }
 __global__ __launch_bounds__(BLK) void ia_to_64_k(long long n1, const int *__restrict__ ia32, long long *__restrict__ ia) {
-  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  const long long i = bid() * BLK + threadIdx.x;
   if (i < n1) ia[i] = ia32[i];
 }
 
@@ -976,7 +988,7 @@ __global__ __launch_bounds__(BLK) void rowlen_hist_k(int n, const long long *__r
   __shared__ int sh[LEN_BINS];
   for (int t = threadIdx.x; t < LEN_BINS; t += BLK) sh[t] = 0;
   __syncthreads();
-  const long long r0 = ((long long)blockIdx.x * BLK + threadIdx.x) * HIST_RUN;
+  const long long r0 = (bid() * BLK + threadIdx.x) * HIST_RUN;
   int cur = -1, cnt = 0;
   for (long long i = r0; i < r0 + HIST_RUN && i < n; i++) {
     const long long len = ia[i + 1] - ia[i];
@@ -998,7 +1010,7 @@ __global__ __launch_bounds__(BLK) void rowlen_hist_k(int n, const long long *__r
 // x cache of one row block (spmv_stream_xc): sorted unique columns of the block's entries and the
 // block-local id of every entry.  One workgroup per block, bitonic sort in LDS.
 template <int TILE>  // k::SPMV_TILE or k::SPMV_TILE_WIDE
-__global__ __launch_bounds__(BLK) void xcache_block_k(int nb, const int *__restrict__ rb, const int *__restrict__ ia,
+__global__ __launch_bounds__(BLK) void xcache_block_k(int nb, const int *__restrict__ rb, const long long *__restrict__ ia,
                                                       const int *__restrict__ ja, int *__restrict__ ucnt,
                                                       int *__restrict__ uslack, unsigned short *__restrict__ lcol) {
   __shared__ int key[TILE];
@@ -1007,8 +1019,8 @@ __global__ __launch_bounds__(BLK) void xcache_block_k(int nb, const int *__restr
   const int b = blockIdx.x;
   if (b >= nb) return;
   const int tid = threadIdx.x;
-  const int s0 = ia[rb[b]], e0 = ia[rb[b + 1]];
-  const int cnt = e0 - s0;
+  const long long s0 = ia[rb[b]], e0 = ia[rb[b + 1]];
+  const int cnt = (int)((e0 - s0) > (long long)TILE ? (long long)TILE : (e0 - s0));
   if (cnt >= TILE) {  // a single long row: direct gathers in the SpMV
     if (tid == 0) ucnt[b] = 0;
     return;
@@ -1072,17 +1084,17 @@ __global__ __launch_bounds__(BLK) void xcache_block_k(int nb, const int *__restr
 }
 
 // in-chunk code bits of the lcol entries (tile Gauss-Seidel kernel): thread per row
-__global__ __launch_bounds__(BLK) void lcol_code_k(int n, const int *__restrict__ ia, const int *__restrict__ ja,
+__global__ __launch_bounds__(BLK) void lcol_code_k(int n, const long long *__restrict__ ia, const int *__restrict__ ja,
                                                    unsigned short *__restrict__ lcol) {
-  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  const long long i = bid() * BLK + threadIdx.x;
   if (i >= n) return;
-  for (int q = ia[i]; q < ia[i + 1]; q++) {
+  for (long long q = ia[i]; q < ia[i + 1]; q++) {
     const int j = ja[q];
     if ((j >> 3) == (int)(i >> 3)) lcol[q] |= (unsigned short)(k::XC_INCH | ((j & 7) << k::XC_OFF_SHIFT));
   }
 }
 
-__global__ __launch_bounds__(BLK) void xcache_compact_k(int nb, const int *__restrict__ rb, const int *__restrict__ ia,
+__global__ __launch_bounds__(BLK) void xcache_compact_k(int nb, const int *__restrict__ rb, const long long *__restrict__ ia,
                                                         const long long *__restrict__ uptr64,
                                                         const int *__restrict__ uslack, int *__restrict__ uptr,
                                                         int *__restrict__ ucols) {
@@ -1090,7 +1102,7 @@ __global__ __launch_bounds__(BLK) void xcache_compact_k(int nb, const int *__res
   if (b >= nb) return;
   const long long u0 = uptr64[b];
   const int nu = (int)(uptr64[b + 1] - u0);
-  const int s0 = ia[rb[b]];
+  const long long s0 = ia[rb[b]];
   for (int t = threadIdx.x; t < nu; t += BLK) ucols[u0 + t] = uslack[s0 + t];
   if (threadIdx.x == 0) {
     uptr[b] = (int)u0;
@@ -1105,7 +1117,7 @@ __global__ __launch_bounds__(BLK) void level_norms_k(int n, const long long *__r
                                                      const double *__restrict__ a, const int *__restrict__ cf, int chunk,
                                                      double *__restrict__ diag, double *__restrict__ l1gs,
                                                      double *__restrict__ l1jac) {
-  const long long i = ((long long)blockIdx.x * BLK + threadIdx.x) / G;
+  const long long i = (bid() * BLK + threadIdx.x) / G;
   const int sub = threadIdx.x % G, lane = threadIdx.x & 63, gbase = lane - sub;
   const bool live = i < n;
   const long long k0 = live ? ia[i] : 0, k1 = live ? ia[i + 1] : 0;
@@ -1155,7 +1167,7 @@ __global__ __launch_bounds__(BLK) void level_norms_k(int n, const long long *__r
 // ---------------------------------------------------------------- ILU(0)
 __global__ __launch_bounds__(BLK) void ilu_dpos_k(int n, const long long *__restrict__ ia, const int *__restrict__ ja,
                                                   long long *__restrict__ dpos) {
-  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  const long long i = bid() * BLK + threadIdx.x;
   if (i >= n) return;
   long long d = -1;
   for (long long k = ia[i]; k < ia[i + 1]; k++)
@@ -1167,7 +1179,7 @@ __global__ __launch_bounds__(BLK) void ilu_dpos_k(int n, const long long *__rest
 __global__ __launch_bounds__(BLK) void ilu_factor_k(int nrows, const int *__restrict__ rows,
                                                     const long long *__restrict__ ia, const int *__restrict__ ja,
                                                     double *__restrict__ a, const long long *__restrict__ dpos) {
-  const long long t = (long long)blockIdx.x * BLK + threadIdx.x;
+  const long long t = bid() * BLK + threadIdx.x;
   if (t >= nrows) return;
   const int i = rows[t];
   const long long e = ia[i + 1];
@@ -1192,7 +1204,7 @@ __global__ __launch_bounds__(BLK) void ilu_lower_k(int nrows, const int *__restr
                                                    const long long *__restrict__ ia, const int *__restrict__ ja,
                                                    const double *__restrict__ a, const double *__restrict__ b,
                                                    double *__restrict__ y) {
-  const long long t = (long long)blockIdx.x * BLK + threadIdx.x;
+  const long long t = bid() * BLK + threadIdx.x;
   if (t >= nrows) return;
   const int i = rows ? rows[t] : (int)t;
   double s = b[i];
@@ -1204,7 +1216,7 @@ __global__ __launch_bounds__(BLK) void ilu_upper_k(int nrows, const int *__restr
                                                    const long long *__restrict__ ia, const int *__restrict__ ja,
                                                    const double *__restrict__ a, const long long *__restrict__ dpos,
                                                    const double *__restrict__ y, double *__restrict__ x) {
-  const long long t = (long long)blockIdx.x * BLK + threadIdx.x;
+  const long long t = bid() * BLK + threadIdx.x;
   if (t >= nrows) return;
   const int i = rows ? rows[t] : (int)t;
   double s = y[i];
@@ -1218,7 +1230,7 @@ __global__ __launch_bounds__(BLK) void ilu_lower_jac_k(int n, const long long *_
                                                        const int *__restrict__ ja, const double *__restrict__ a,
                                                        const double *__restrict__ b, const double *__restrict__ in,
                                                        double *__restrict__ out) {
-  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  const long long i = bid() * BLK + threadIdx.x;
   if (i >= n) return;
   double s = b[i];
   if (in)
@@ -1231,7 +1243,7 @@ __global__ __launch_bounds__(BLK) void ilu_upper_jac_k(int n, const long long *_
                                                        const long long *__restrict__ dpos,
                                                        const double *__restrict__ b, const double *__restrict__ in,
                                                        double *__restrict__ out) {
-  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  const long long i = bid() * BLK + threadIdx.x;
   if (i >= n) return;
   double s = b[i];
   const long long d = dpos[i];
@@ -1247,24 +1259,24 @@ __global__ __launch_bounds__(BLK) void ilu_upper_jac_k(int n, const long long *_
 // C columns -- the F pass has just formed exactly that part of the row's product (every C column lies outside the
 // row's chunk there) and hands it over as f - A_FC u_C; all other rows stay whole
 template <bool FILL, int MODE, int G>
-__global__ __launch_bounds__(BLK) void zero_guess_rows_k(int n, int nc, int chunk, const int *__restrict__ ia,
+__global__ __launch_bounds__(BLK) void zero_guess_rows_k(int n, int nc, int chunk, const long long *__restrict__ ia,
                                                          const int *__restrict__ ja, const double *__restrict__ a,
                                                          int *__restrict__ cnt, const long long *__restrict__ zia,
                                                          int *__restrict__ zja, double *__restrict__ za) {
   // G lanes per row: coalesced reads, kept entries written in stored order through a ballot prefix (see strength_k)
-  const int i = (int)(((long long)blockIdx.x * BLK + threadIdx.x) / G);
+  const int i = (int)((bid() * BLK + threadIdx.x) / G);
   const int sub = threadIdx.x % G, lane = threadIdx.x & 63, gbase = lane - sub;
   const bool live = i < n;
-  const int k0 = live ? ia[i] : 0, k1 = live ? ia[i + 1] : 0;
+  const long long k0 = live ? ia[i] : 0, k1 = live ? ia[i + 1] : 0;
   const int c0 = live ? (i / chunk) * chunk : 0, c1 = c0 + chunk;
   const bool frow = i >= nc;
   const bool drops_c = i >= (nc + chunk - 1) / chunk * chunk;  // MODE 1
   long long o = (FILL && live) ? zia[i] : 0;
   int c = 0;
-  int len = k1 - k0;
+  int len = (int)(k1 - k0);
   for (int m = G; m < 64; m <<= 1) len = max(len, __shfl_xor(len, m, 64));
   for (int t = 0; t < len; t += G) {
-    const int k = k0 + t + sub;
+    const long long k = k0 + t + sub;
     bool keep = false;
     int j = -1;
     double v = 0.0;
@@ -1367,13 +1379,13 @@ void launch_bins(const Bins &bins, const int *rows, const int *T, int S_hint, co
   const int n0 = bins.start[1] - bins.start[0], n1 = bins.start[2] - bins.start[1], n2 = bins.start[3] - bins.start[2],
             n3 = bins.start[4] - bins.start[3];
   if (n0)
-    spgemm_group_k<8, 32, NUMERIC><<<(unsigned)((n0 + 31) / 32), BLK, 0, s>>>(
+    spgemm_group_k<8, 32, NUMERIC><<<grid_for(((long long)n0 + 31) / 32), BLK, 0, s>>>(
         n0, rows + bins.start[0], std::min(S_hint, 8), A.ia.p, A.ja.p, A.a.p, B.ia.p, B.ja.p, B.a.p, nout, Cia, Cja, Ca);
   if (n1)
-    spgemm_group_k<16, 128, NUMERIC><<<(unsigned)((n1 + 15) / 16), BLK, 0, s>>>(
+    spgemm_group_k<16, 128, NUMERIC><<<grid_for(((long long)n1 + 15) / 16), BLK, 0, s>>>(
         n1, rows + bins.start[1], std::min(S_hint, 16), A.ia.p, A.ja.p, A.a.p, B.ia.p, B.ja.p, B.a.p, nout, Cia, Cja, Ca);
   if (n2)
-    spgemm_group_k<64, 512, NUMERIC><<<(unsigned)((n2 + 3) / 4), BLK, 0, s>>>(
+    spgemm_group_k<64, 512, NUMERIC><<<grid_for(((long long)n2 + 3) / 4), BLK, 0, s>>>(
         n2, rows + bins.start[2], std::min(S_hint, 64), A.ia.p, A.ja.p, A.a.p, B.ia.p, B.ja.p, B.a.p, nout, Cia, Cja, Ca);
   if (n3)
     spgemm_block_k<NUMERIC><<<(unsigned)std::min(n3, block_grid), BLK, 0, s>>>(
@@ -1386,12 +1398,13 @@ void launch_bins(const Bins &bins, const int *rows, const int *T, int S_hint, co
 
 void to_solve_format(DCsr &src, DevCSR &dst, hipStream_t s) {
   const int n = src.nrows;
-  require_int32_block(src.nrows, src.nnz, "solve format");
+  require_int32_block(src.nrows, 0, "solve format");
   dst.nrows = n;
   dst.ncols = src.ncols;
   dst.nnz = src.nnz;
   dst.ia.alloc((size_t)n + 1);
-  ia_to_32_k<<<(unsigned)((n + 1 + BLK - 1) / BLK), BLK, 0, s>>>((long long)n + 1, src.ia.p, dst.ia.p);
+  dst.ia64.release();
+  ia_to_32_k<<<(unsigned)((n + 1 + BLK - 1) / BLK), BLK, 0, s>>>((long long)n + 1, src.ia.p, dst.ia.p);  // low words
   // row-length percentile (GS kernel variant choice) from a device histogram
   dst.rowlen_p95 = 0;
   if (n) {
@@ -1437,9 +1450,9 @@ void to_solve_format(DCsr &src, DevCSR &dst, hipStream_t s) {
     dst.lcol.alloc((size_t)dst.nnz);
     MI_HIP(hipMemsetAsync(dst.lcol.p, 0, (size_t)dst.nnz * sizeof(unsigned short), s));
     if (dst.tile_entries == k::SPMV_TILE_WIDE)
-      xcache_block_k<k::SPMV_TILE_WIDE><<<(unsigned)nb, BLK, 0, s>>>(nb, dst.rb.p, dst.ia.p, dst.ja.p, ucnt.p, uslack.p, dst.lcol.p);
+      xcache_block_k<k::SPMV_TILE_WIDE><<<(unsigned)nb, BLK, 0, s>>>(nb, dst.rb.p, src.ia.p, dst.ja.p, ucnt.p, uslack.p, dst.lcol.p);
     else
-      xcache_block_k<k::SPMV_TILE><<<(unsigned)nb, BLK, 0, s>>>(nb, dst.rb.p, dst.ia.p, dst.ja.p, ucnt.p, uslack.p, dst.lcol.p);
+      xcache_block_k<k::SPMV_TILE><<<(unsigned)nb, BLK, 0, s>>>(nb, dst.rb.p, src.ia.p, dst.ja.p, ucnt.p, uslack.p, dst.lcol.p);
     DVec<long long> uptr64((size_t)nb + 1);
     exclusive_scan(ucnt.p, uptr64.p, nb, s);
     long long tot = 0;
@@ -1447,19 +1460,37 @@ void to_solve_format(DCsr &src, DevCSR &dst, hipStream_t s) {
     MI_HIP(hipStreamSynchronize(s));
     dst.uptr.alloc((size_t)nb + 1);
     dst.ucols.alloc((size_t)tot);
-    xcache_compact_k<<<(unsigned)nb, BLK, 0, s>>>(nb, dst.rb.p, dst.ia.p, uptr64.p, uslack.p, dst.uptr.p, dst.ucols.p);
+    MI_REQUIRE(tot < 2147483647LL, "solve format: the tiles' column lists exceed 2^31 entries");
+    xcache_compact_k<<<(unsigned)nb, BLK, 0, s>>>(nb, dst.rb.p, src.ia.p, uptr64.p, uslack.p, dst.uptr.p, dst.ucols.p);
     if (aligned && dst.nrows == dst.ncols) {
-      lcol_code_k<<<(unsigned)((n + BLK - 1) / BLK), BLK, 0, s>>>(n, dst.ia.p, dst.ja.p, dst.lcol.p);
+      lcol_code_k<<<(unsigned)((n + BLK - 1) / BLK), BLK, 0, s>>>(n, src.ia.p, dst.ja.p, dst.lcol.p);
       dst.gs_tiles = true;
     }
     MI_HIP(hipGetLastError());
     MI_HIP(hipStreamSynchronize(s));
   }
-  k::build_tile_desc(dst, s);
+  k::build_tile_desc(dst, src.ia.p, s);
   MI_HIP(hipStreamSynchronize(s));
+  if (dst.big()) {
+    // beyond 2^31 entries: the setup paths that read this operator again (zero-guess sub-operators, host copies) need
+    // the full row pointers; the solve runs on the tile kernels only
+    MI_REQUIRE(dst.xcache, "solve format: an operator with 2^31 entries or more needs the x-cache tile format");
+    dst.ia64 = std::move(src.ia);
+  }
   src.release();
   MI_HIP(hipGetLastError());
 }
+
+namespace {
+// 64-bit row pointers of an operator in the solve format: its own (big operators) or a widened temporary
+const long long *wide_row_pointers(const DevCSR &A, DVec<long long> &tmp, hipStream_t s) {
+  if (A.ia64.p) return A.ia64.p;
+  MI_REQUIRE(!A.big(), "solve format: 64-bit row pointers of a big operator are missing");
+  tmp.alloc((size_t)A.nrows + 1);
+  ia_to_64_k<<<(unsigned)((A.nrows + 1 + BLK - 1) / BLK), BLK, 0, s>>>((long long)A.nrows + 1, A.ia.p, tmp.p);
+  return tmp.p;
+}
+}  // namespace
 
 void zero_guess_operator(const DevCSR &A, int nc, int chunk, DCsr &Z, hipStream_t s, int mode) {
   const int n = A.nrows;
@@ -1468,12 +1499,14 @@ void zero_guess_operator(const DevCSR &A, int nc, int chunk, DCsr &Z, hipStream_
   Z.ncols = A.ncols;
   Z.ia.alloc((size_t)n + 1);
   DVec<int> cnt((size_t)n);
+  DVec<long long> ia_tmp;
+  const long long *Aia = n ? wide_row_pointers(A, ia_tmp, s) : nullptr;
   const int rg = row_group(A.nnz, n);
-  const unsigned grid = (unsigned)(((long long)n * rg + BLK - 1) / BLK);
+  const dim3 grid = grid_for(((long long)n * rg + BLK - 1) / BLK);
   if (n && mode == 0) {
-    MI_ROW_GROUP_DISPATCH(rg, (zero_guess_rows_k<false, 0, G><<<grid, BLK, 0, s>>>(n, nc, chunk, A.ia.p, A.ja.p, A.a.p, cnt.p, nullptr, nullptr, nullptr)))
+    MI_ROW_GROUP_DISPATCH(rg, (zero_guess_rows_k<false, 0, G><<<grid, BLK, 0, s>>>(n, nc, chunk, Aia, A.ja.p, A.a.p, cnt.p, nullptr, nullptr, nullptr)))
   } else if (n) {
-    MI_ROW_GROUP_DISPATCH(rg, (zero_guess_rows_k<false, 1, G><<<grid, BLK, 0, s>>>(n, nc, chunk, A.ia.p, A.ja.p, A.a.p, cnt.p, nullptr, nullptr, nullptr)))
+    MI_ROW_GROUP_DISPATCH(rg, (zero_guess_rows_k<false, 1, G><<<grid, BLK, 0, s>>>(n, nc, chunk, Aia, A.ja.p, A.a.p, cnt.p, nullptr, nullptr, nullptr)))
   }
   exclusive_scan(cnt.p, Z.ia.p, n, s);
   long long total = 0;
@@ -1483,9 +1516,9 @@ void zero_guess_operator(const DevCSR &A, int nc, int chunk, DCsr &Z, hipStream_
   Z.ja.alloc((size_t)total);
   Z.a.alloc((size_t)total);
   if (n && total && mode == 0) {
-    MI_ROW_GROUP_DISPATCH(rg, (zero_guess_rows_k<true, 0, G><<<grid, BLK, 0, s>>>(n, nc, chunk, A.ia.p, A.ja.p, A.a.p, nullptr, Z.ia.p, Z.ja.p, Z.a.p)))
+    MI_ROW_GROUP_DISPATCH(rg, (zero_guess_rows_k<true, 0, G><<<grid, BLK, 0, s>>>(n, nc, chunk, Aia, A.ja.p, A.a.p, nullptr, Z.ia.p, Z.ja.p, Z.a.p)))
   } else if (n && total) {
-    MI_ROW_GROUP_DISPATCH(rg, (zero_guess_rows_k<true, 1, G><<<grid, BLK, 0, s>>>(n, nc, chunk, A.ia.p, A.ja.p, A.a.p, nullptr, Z.ia.p, Z.ja.p, Z.a.p)))
+    MI_ROW_GROUP_DISPATCH(rg, (zero_guess_rows_k<true, 1, G><<<grid, BLK, 0, s>>>(n, nc, chunk, Aia, A.ja.p, A.a.p, nullptr, Z.ia.p, Z.ja.p, Z.a.p)))
   }
   MI_HIP(hipGetLastError());
   MI_HIP(hipStreamSynchronize(s));
@@ -1499,9 +1532,9 @@ void solve_format_to_host(const DevCSR &src, HostCSR &h, hipStream_t s) {
   h.ja.resize((size_t)src.nnz);
   h.a.resize((size_t)src.nnz);
   if (src.ia.p) {
-    DVec<long long> ia64((size_t)n + 1);
-    ia_to_64_k<<<(unsigned)((n + 1 + BLK - 1) / BLK), BLK, 0, s>>>((long long)n + 1, src.ia.p, ia64.p);
-    MI_HIP(hipMemcpyAsync(h.ia.data(), ia64.p, ((size_t)n + 1) * sizeof(long long), hipMemcpyDeviceToHost, s));
+    DVec<long long> ia_tmp;
+    const long long *ia64 = wide_row_pointers(src, ia_tmp, s);
+    MI_HIP(hipMemcpyAsync(h.ia.data(), ia64, ((size_t)n + 1) * sizeof(long long), hipMemcpyDeviceToHost, s));
     if (src.nnz) {
       MI_HIP(hipMemcpyAsync(h.ja.data(), src.ja.p, (size_t)src.nnz * sizeof(int), hipMemcpyDeviceToHost, s));
       MI_HIP(hipMemcpyAsync(h.a.data(), src.a.p, (size_t)src.nnz * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -1563,7 +1596,10 @@ void from_solve_format(const DevCSR &src, DCsr &dst, hipStream_t s) {
   dst.ia.alloc((size_t)n + 1);
   dst.ja.alloc((size_t)src.nnz);
   dst.a.alloc((size_t)src.nnz);
-  ia_to_64_k<<<(unsigned)((n + 1 + BLK - 1) / BLK), BLK, 0, s>>>((long long)n + 1, src.ia.p, dst.ia.p);
+  if (src.ia64.p)
+    MI_HIP(hipMemcpyAsync(dst.ia.p, src.ia64.p, ((size_t)n + 1) * sizeof(long long), hipMemcpyDeviceToDevice, s));
+  else
+    ia_to_64_k<<<(unsigned)((n + 1 + BLK - 1) / BLK), BLK, 0, s>>>((long long)n + 1, src.ia.p, dst.ia.p);
   if (src.nnz) {
     MI_HIP(hipMemcpyAsync(dst.ja.p, src.ja.p, (size_t)src.nnz * sizeof(int), hipMemcpyDeviceToDevice, s));
     MI_HIP(hipMemcpyAsync(dst.a.p, src.a.p, (size_t)src.nnz * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -1615,7 +1651,7 @@ void level_norms(const DCsr &A, const int *cf, int chunk, double *diag, double *
   const int n = A.nrows;
   if (n == 0) return;
   const int rg = row_group(A.nnz, n);
-  const unsigned grid = (unsigned)(((long long)n * rg + BLK - 1) / BLK);
+  const dim3 grid = grid_for(((long long)n * rg + BLK - 1) / BLK);
   MI_ROW_GROUP_DISPATCH(rg, (level_norms_k<G><<<grid, BLK, 0, s>>>(n, A.ia.p, A.ja.p, A.a.p, cf, chunk, diag, l1gs, l1jac)))
   MI_HIP(hipGetLastError());
 }
@@ -1628,7 +1664,7 @@ void strength(const DCsr &A, double theta, double max_row_sum, DCsr &S, hipStrea
   S.ia.alloc((size_t)n + 1);
   DVec<int> cnt((size_t)n);
   const int rg = row_group(A.nnz, n);
-  const unsigned grid = (unsigned)(((long long)n * rg + BLK - 1) / BLK);
+  const dim3 grid = grid_for(((long long)n * rg + BLK - 1) / BLK);
   if (n) {
     MI_ROW_GROUP_DISPATCH(rg, (strength_k<false, G><<<grid, BLK, 0, s>>>(n, A.ia.p, A.ja.p, A.a.p, theta, max_row_sum, cnt.p, nullptr, nullptr)))
   }
@@ -1655,7 +1691,7 @@ void pmis(const DCsr &S, int seed, DVec<int> &cf, hipStream_t s) {
   DVec<signed char> tmp((size_t)n);
   MI_HIP(hipMemsetAsync(incoming.p, 0, (size_t)n * sizeof(int), s));
   MI_HIP(hipMemsetAsync(counter.p, 0, sizeof(int), s));
-  if (S.nnz) col_count_k<<<(unsigned)((S.nnz + BLK - 1) / BLK), BLK, 0, s>>>(S.nnz, S.ja.p, incoming.p);
+  if (S.nnz) col_count_k<<<grid_for((S.nnz + BLK - 1) / BLK), BLK, 0, s>>>(S.nnz, S.ja.p, incoming.p);
   pmis_init_k<<<grid, BLK, 0, s>>>(n, S.ia.p, incoming.p, seed ? seed : 13579, measure.p, cf.p, counter.p);
   int undecided = 0;
   MI_HIP(hipMemcpyAsync(&undecided, counter.p, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1708,19 +1744,19 @@ bool interp(const DCsr &A, const DCsr &S, DVec<int> &cf, int interp_type, double
   const int n0 = bins.start[1] - bins.start[0], n1 = bins.start[2] - bins.start[1], n2 = bins.start[3] - bins.start[2],
             n3 = bins.start[4] - bins.start[3];
   if (n3)  // up to 1024 candidates: one workgroup per row
-    interp_group_k<256, 1024, 256><<<(unsigned)n3, 256, 0, s>>>(
+    interp_group_k<256, 1024, 256><<<grid_for(n3), 256, 0, s>>>(
         n3, rows.p + bins.start[3], ext, A.ia.p, A.ja.p, A.a.p, S.ia.p, S.ja.p, cf.p, f2c.p, trunc_factor, pmax,
         slack_ia.p, sj.p, sa.p, len.p);
   if (n0)
-    interp_group_k<8, 32, 256><<<(unsigned)((n0 + 31) / 32), 256, 0, s>>>(
+    interp_group_k<8, 32, 256><<<grid_for(((long long)n0 + 31) / 32), 256, 0, s>>>(
         n0, rows.p + bins.start[0], ext, A.ia.p, A.ja.p, A.a.p, S.ia.p, S.ja.p, cf.p, f2c.p, trunc_factor, pmax,
         slack_ia.p, sj.p, sa.p, len.p);
   if (n1)
-    interp_group_k<16, 128, 128><<<(unsigned)((n1 + 7) / 8), 128, 0, s>>>(
+    interp_group_k<16, 128, 128><<<grid_for(((long long)n1 + 7) / 8), 128, 0, s>>>(
         n1, rows.p + bins.start[1], ext, A.ia.p, A.ja.p, A.a.p, S.ia.p, S.ja.p, cf.p, f2c.p, trunc_factor, pmax,
         slack_ia.p, sj.p, sa.p, len.p);
   if (n2)
-    interp_group_k<64, 512, 128><<<(unsigned)((n2 + 1) / 2), 128, 0, s>>>(
+    interp_group_k<64, 512, 128><<<grid_for(((long long)n2 + 1) / 2), 128, 0, s>>>(
         n2, rows.p + bins.start[2], ext, A.ia.p, A.ja.p, A.a.p, S.ia.p, S.ja.p, cf.p, f2c.p, trunc_factor, pmax,
         slack_ia.p, sj.p, sa.p, len.p);
   MI_HIP(hipGetLastError());
@@ -1812,7 +1848,7 @@ void transpose(const DCsr &A, DCsr &T, hipStream_t s) {
   T.a.alloc((size_t)A.nnz);
   DVec<int> cnt((size_t)T.nrows);
   if (T.nrows) MI_HIP(hipMemsetAsync(cnt.p, 0, (size_t)T.nrows * sizeof(int), s));
-  if (A.nnz) col_count_k<<<(unsigned)((A.nnz + BLK - 1) / BLK), BLK, 0, s>>>(A.nnz, A.ja.p, cnt.p);
+  if (A.nnz) col_count_k<<<grid_for((A.nnz + BLK - 1) / BLK), BLK, 0, s>>>(A.nnz, A.ja.p, cnt.p);
   exclusive_scan(cnt.p, T.ia.p, T.nrows, s);
   if (A.nnz == 0) return;
   MI_HIP(hipMemsetAsync(cnt.p, 0, (size_t)T.nrows * sizeof(int), s));
@@ -1840,7 +1876,7 @@ void permute(const DCsr &A, const int *perm, const int *colpos, DCsr &B, hipStre
   if (A.nnz == 0) return;
   DVec<int> tj((size_t)A.nnz);
   DVec<double> ta((size_t)A.nnz);
-  perm_copy_k<<<(unsigned)(((long long)n * 8 + BLK - 1) / BLK), BLK, 0, s>>>(n, A.ia.p, A.ja.p, A.a.p, perm, colpos,
+  perm_copy_k<<<grid_for(((long long)n * 8 + BLK - 1) / BLK), BLK, 0, s>>>(n, A.ia.p, A.ja.p, A.a.p, perm, colpos,
                                                                              B.ia.p, tj.p, ta.p);
   sort_rows(n, A.nnz, B.ia.p, tj.p, ta.p, B.ja.p, B.a.p, s);
   MI_HIP(hipGetLastError());
@@ -1864,7 +1900,7 @@ void extract_rows(const DCsr &A, const int *rows, int nout, const int *colpos, D
   if (total == 0) return;
   DVec<int> tj((size_t)total);
   DVec<double> ta((size_t)total);
-  perm_copy_k<<<(unsigned)(((long long)nout * 8 + BLK - 1) / BLK), BLK, 0, s>>>(nout, A.ia.p, A.ja.p, A.a.p, rows, colpos,
+  perm_copy_k<<<grid_for(((long long)nout * 8 + BLK - 1) / BLK), BLK, 0, s>>>(nout, A.ia.p, A.ja.p, A.a.p, rows, colpos,
                                                                                 B.ia.p, tj.p, ta.p);
   sort_rows(nout, total, B.ia.p, tj.p, ta.p, B.ja.p, B.a.p, s);
   MI_HIP(hipGetLastError());

@@ -85,10 +85,11 @@ HYPRE_Int HYPRE_MI_SetValueDictionary(HYPRE_Int on);
  * "setup_distributed" (count), "setup_ext_rows_max" (largest per-rank extended sub-problem, rows),
  * "setup_global_rows_gathered" (rows gathered on every rank: the redundant tail only). */
 HYPRE_Int HYPRE_MI_GetCounter(const char *name, long long *value);
-/* One rank's block keeps 32-bit local row ids and entry offsets in the solve format: HYPRE_IJMatrixAssemble
- * refuses (HYPRE_ERROR_ARG + message) a block with >= 2147483000 rows or entries -- e.g. the reference's 27-point
- * operator at 512^3 (3.6e9 entries, /root/reference/src/laplace_3d_weak_scaling.hpp:558,600) on ONE rank -- instead
- * of wrapping around.  This applies the same check to a row-pointer array (row_ptr[nrows] = entries). */
+/* One rank's block keeps 32-bit local row ids in the solve format; the entry offsets of its diagonal block are 64-bit
+ * (the reference's 27-point operator at 512^3 -- 3.6e9 entries, /root/reference/src/laplace_3d_weak_scaling.hpp:558,600
+ * -- assembles and solves on ONE rank, as with HYPRE's bigint / mixedint builds, /root/reference/src/HypreSystem.h:174-219).
+ * HYPRE_IJMatrixAssemble refuses (HYPRE_ERROR_ARG + message, never a wrap-around) >= 2147483000 local rows, a halo
+ * block or a single row with that many entries.  This applies the same check to a row-pointer array. */
 HYPRE_Int HYPRE_MI_CheckBlockRowPointers(HYPRE_BigInt nrows, const HYPRE_BigInt *row_ptr);
 
 /* ---- results the driver never asks HYPRE for */

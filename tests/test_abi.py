@@ -102,17 +102,16 @@ def test_row_partition_matches_reference_rule(mi_lib):
 
 
 def test_block_size_boundary(mi_lib):
-    """64-bit safety: 27-pt rows of a 512^3 grid on one rank are 3.6e9 entries -- refused with HYPRE_ERROR_ARG
-    and a message at Assemble, never wrapped to int32; the 7-pt operator (0.94e9) passes."""
+    """64-bit safety: the diagonal block's entry offsets are 64-bit (27-pt rows of a 512^3 grid on one rank are 3.6e9
+    entries and pass); local row ids are 32-bit and a single row of >= 2^31 entries is refused with HYPRE_ERROR_ARG and
+    a message, never wrapped to int32."""
     import numpy as np
 
     mi = mi_lib
     n = 512 ** 3
-    ok = np.array([0, 937951232], dtype=np.int64)  # 7-pt 512^3: the whole block in one "row" of the synthetic array
-    mi.call("HYPRE_MI_CheckBlockRowPointers", mi.c_big(1), ok)
-    edge = np.array([0, 2147482999], dtype=np.int64)
-    mi.call("HYPRE_MI_CheckBlockRowPointers", mi.c_big(1), edge)
-    for bad in (2147483000, 2 ** 31, 3609741304):
+    for total in (937951232, 2147482999, 2147483000, 2 ** 31, 3609741304):  # spread over two rows: fine
+        mi.call("HYPRE_MI_CheckBlockRowPointers", mi.c_big(2), np.array([0, total // 2, total], dtype=np.int64))
+    for bad in (2147483000, 2 ** 31, 3609741304):  # ... in ONE row: refused
         with __import__("pytest").raises(mi.HypreError, match="split the rows over more ranks"):
             mi.call("HYPRE_MI_CheckBlockRowPointers", mi.c_big(1), np.array([0, bad], dtype=np.int64))
         mi.call("HYPRE_ClearAllErrors")
