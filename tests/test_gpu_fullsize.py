@@ -307,3 +307,41 @@ def test_two_ranks_distributed_setup_and_solve_128(mi):
     assert gm.solve(A, b, x) == 0
     assert abs(gm.num_iterations - it2) <= 1, (gm.num_iterations, it2)
     assert rr2 <= 1e-8 and gm.final_rel_res <= 1e-8
+
+
+def test_bigint_block_27pt_432(mi):
+    """More than 2^31 entries in one rank's block: the reference generator's own 27-point operator
+    (/root/reference/src/laplace_3d_weak_scaling.hpp:558,600) at 432^3 -- 80.6 M rows, 2.17e9 entries (HYPRE needs its
+    bigint / mixedint build for this, /root/reference/src/HypreSystem.h:174-219, etc/build_script_tmpl.sh:20) -- through
+    IJ assembly, setup and GMRES + BoomerAMG on one MI355X.  A*1 = b exactly (integer sums: every entry is read at its
+    64-bit offset), x* = 1, true residual, identical repeat solve.  512^3 (3.6e9 entries): profiles/r03_bigint_27pt_512.txt."""
+    n = 432
+    N = n ** 3
+    A, b, x, rhs = mi.build_laplace_system(n, n, n, 27)
+    amg = mi.BoomerAMG(print_level=0)
+    gm = mi.GMRES(tolerance=1e-8, max_iterations=100, kspace=50, print_level=0)
+    gm.set_precond(amg)
+    gm.setup(A, b, x)
+    nr, nc, nnz = mi.c_int(), mi.c_int(), mi.C.c_longlong()
+    mi.call("HYPRE_MI_BoomerAMGGetLevelCSRSize", amg.h, 0, 0, mi.C.byref(nr), mi.C.byref(nc), mi.C.byref(nnz))
+    assert nr.value == N and nnz.value == 2166720184 and nnz.value > 2 ** 31
+    mi.call("HYPRE_MI_BoomerAMGGetLevelCSRSize", amg.h, 1, 0, mi.C.byref(nr), mi.C.byref(nc), mi.C.byref(nnz))
+    assert 40 < nnz.value / nr.value < 80  # a 27-point coarse grid: ~60 entries per row (interpolation rows not empty)
+    ones = mi.IJVector(0, N - 1, np.ones(N))
+    y = mi.IJVector(0, N - 1, np.zeros(N))
+    mi.call("HYPRE_ParCSRMatrixMatvec", 1.0, A.par, ones.par, 0.0, y.par)
+    assert np.array_equal(y.get(), rhs)
+    del ones, y
+    hists = []
+    for _ in range(2):
+        x.fill(0.0)
+        assert gm.solve(A, b, x) == 0
+        hists.append(np.array(gm.residual_history()))
+    assert np.array_equal(hists[0], hists[1]) and 8 <= gm.num_iterations <= 30
+    xs = x.get()
+    assert np.abs(xs - 1.0).max() < 1e-5
+    del xs
+    r = mi.IJVector(0, N - 1, rhs)
+    mi.call("HYPRE_ParCSRMatrixMatvec", -1.0, A.par, x.par, 1.0, r.par)
+    rn = np.linalg.norm(r.get()) / np.linalg.norm(rhs)
+    assert rn <= 1e-8 and abs(rn - gm.final_rel_res) <= 1e-10
