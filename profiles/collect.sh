@@ -19,6 +19,13 @@ else
     python3 "$REPO/bench.py" --steps 1 --warmup 0 --no-cpu ${PMC_BENCH_ARGS:---no-general} > "$REPO/gpurun_out/prof_fetch.log" 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$REPO/gpurun_out/prof_write" -- \
     python3 "$REPO/bench.py" --steps 1 --warmup 0 --no-cpu ${PMC_BENCH_ARGS:---no-general} > "$REPO/gpurun_out/prof_write.log" 2>&1
+  # the same two passes for a general operator (value dictionary off: 8-byte values in the level-0 stream)
+  export MI_HYPRE_VALUE_DICT=0
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$REPO/gpurun_out/prof_fetch_g" -- \
+    python3 "$REPO/bench.py" --steps 1 --warmup 0 --no-cpu --no-general > "$REPO/gpurun_out/prof_fetch_g.log" 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$REPO/gpurun_out/prof_write_g" -- \
+    python3 "$REPO/bench.py" --steps 1 --warmup 0 --no-cpu --no-general > "$REPO/gpurun_out/prof_write_g.log" 2>&1
+  unset MI_HYPRE_VALUE_DICT
 fi
 find "$REPO/gpurun_out" -name "*.csv" -size +60M -delete   # keep the merge-back small
 ls -la "$REPO"/gpurun_out/prof_*/*/ 2>/dev/null | tail -20

@@ -4,7 +4,7 @@ csv files back under gpurun_out/).
 
   python profiles/summarize.py stats gpurun_out/prof_stats  profiles/rNN   -> rNN_bench512_kernel_stats.csv,
                                                                               rNN_bench512_by_kernel_and_grid.txt
-  python profiles/summarize.py pmc gpurun_out/prof_fetch gpurun_out/prof_write profiles/rNN
+  python profiles/summarize.py pmc gpurun_out/prof_fetch gpurun_out/prof_write profiles/rNN [gpurun_out/prof_fetch_g gpurun_out/prof_write_g]
                                                                            -> rNN_pmc512_fetch_write.txt, traffic_rNN.json
 """
 import csv
@@ -66,7 +66,7 @@ def counter_means(src, counter):
     return {k: (n, v / n) for k, (n, v) in agg.items()}
 
 
-def pmc(fetch_dir, write_dir, out):
+def pmc(fetch_dir, write_dir, out, fetch_g=None, write_g=None):
     fe = counter_means(fetch_dir, "FETCH_SIZE")
     wr = counter_means(write_dir, "WRITE_SIZE")
     tag = os.path.basename(out)
@@ -94,6 +94,21 @@ def pmc(fetch_dir, write_dir, out):
         "note": "FETCH_SIZE doubled per the gfx950 correction; separate --pmc passes; see profiles/%s_pmc512_fetch_write.txt. "
                 "A kernel whose third template argument is true (spmv_stream_xc<EPI, TAG, VAL8, threads>) streams one-byte dictionary indices instead of 8-byte values (DESIGN.md "
                 "section 5): its traffic can be BELOW the algorithmic 12 nnz + 20 N, which prices 8-byte values" % tag}}
+    if fetch_g and write_g:
+        # the same kernels with the value dictionary off (MI_HYPRE_VALUE_DICT=0): what a general operator moves
+        feg = counter_means(fetch_g, "FETCH_SIZE")
+        wrg = counter_means(write_g, "WRITE_SIZE")
+        with open(out + "_pmc512_fetch_write.txt", "a") as f:
+            f.write("\n# ---- value dictionary OFF (MI_HYPRE_VALUE_DICT=0): the general-operator stream of level 0\n")
+            for k2, (n, kb) in sorted(feg.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+                f_gb = kb * 1024 / 1e9
+                w_gb = wrg.get(k2, (0, 0.0))[1] * 1024 / 1e9
+                if n * f_gb < 0.5:
+                    continue
+                f.write(f"{k2[0]:28s} grid {k2[1]:<10d} n={n:4d}  FETCH_raw {f_gb:8.3f} GB  x2 {2 * f_gb:8.3f} GB  WRITE {w_gb:7.3f} GB\n")
+        kg = next(k2 for k2 in feg if k2[0].startswith("spmv_stream_xc<0, 1") or k2[0].startswith("spmv_stream<0, 1"))
+        js["512^3/7pt/1gpu"]["spmv_general_hbm_bytes_per_launch"] = 2 * feg[kg][1] * 1024 + wrg[kg][1] * 1024
+        js["512^3/7pt/1gpu"]["general_kernel"] = kg[0]
     path = os.path.join(os.path.dirname(out), "traffic_%s.json" % tag)
     json.dump(js, open(path, "w"), indent=1)
     print("wrote", out + "_pmc512_fetch_write.txt", path)
@@ -103,4 +118,4 @@ if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     else:
-        pmc(sys.argv[2], sys.argv[3], sys.argv[4])
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4], *(sys.argv[5:7] if len(sys.argv) >= 7 else ()))
