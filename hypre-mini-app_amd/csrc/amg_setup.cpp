@@ -1309,52 +1309,100 @@ void sparsify_non_galerkin(HostCSR &A, double tol) {
 // numbering of a 3-D problem a tile is a piece of ONE grid line and gathers ~5 distinct columns per row, a
 // brick-shaped tile ~2.3 (profiles/run_numbering_experiment.py: numbering the same Laplacian by 8x8x8 bricks makes
 // the solve 10 % faster per iteration at 256^3).  The geometry is not known here, so compact clusters are grown on
-// the matrix graph.  Round 3: graph Voronoi cells instead of sequential breadth-first balls -- every row whose
-// hashed index is 0 modulo the cluster size (1024) is a seed, labelled by its rank among the seeds; in rounds, every
-// still unlabelled row takes the smallest label among its neighbours labelled in the PREVIOUS round (so the result
-// depends neither on threads nor on scheduling), until nothing changes (at most 64 rounds; what is farther than
-// that from every seed forms one last cluster in natural order).  New order = clusters in seed order, natural order
-// inside a cluster (a stable sort by label); the coarse levels inherit it, C points keeping their relative order.
-// Tile statistics equal those of the breadth-first balls of 512 rows within a few percent (U / entries at 96^3,
-// levels 0-3: 0.433 0.267 0.254 0.315 against 0.423 0.262 0.272 0.360; cells of 512: 0.432 0.265 0.273 0.357), but the rounds are plain data-parallel passes: 512^3 takes tens of
-// milliseconds on the device (sk::locality_labels) where the sequential balls took ~2 s of host threads, and the
-// permuted operator is built on the device from the copy HYPRE_IJMatrixAssemble left there (setup_host).
+// the matrix graph.  Round 3: graph Voronoi cells instead of sequential breadth-first balls -- rows are cut into
+// segments of 2^k consecutive rows (k from the matrix: about four times the typical largest column offset, i.e. four
+// z-planes of a lexicographic grid; locality_segment_shift); every row whose hashed index is 0 modulo the cluster size
+// (512) is a seed; in rounds, every still unlabelled row takes the smallest label among its neighbours OF ITS SEGMENT
+// labelled in the PREVIOUS round (so the result depends neither on threads nor on scheduling), until nothing changes
+// (at most 64 rounds; what is farther than that from every seed forms one last cluster in natural order).  The cells
+// are then ranked by their smallest row -- a sweep through each segment, so that cells sharing columns stay a few
+// cells apart (L2 reuse between neighbouring tiles: a first version ranked the cells by their seeds' indices, which
+// scatters neighbouring cells over the whole slab and cost 3.5 GB more HBM traffic per level-0 SpMV at 512^3) -- and
+// the rows sorted by cell rank, natural order inside a cell; the coarse levels inherit the order, C points keeping
+// their relative order.  Tile statistics equal those of the round-2 balls; the rounds are plain data-parallel
+// passes: 512^3 takes tens of milliseconds on the device (sk::locality_labels) where the sequential balls took ~2 s
+// of host threads, and the permuted operator is built on the device from the copy HYPRE_IJMatrixAssemble left there.
 namespace hs {
-const int LOCALITY_CLUSTER = getenv("MI_HYPRE_LOCALITY_CLUSTER") ? std::max(8, atoi(getenv("MI_HYPRE_LOCALITY_CLUSTER"))) : 1024;
+const int LOCALITY_CLUSTER = getenv("MI_HYPRE_LOCALITY_CLUSTER") ? std::max(8, atoi(getenv("MI_HYPRE_LOCALITY_CLUSTER"))) : 512;
 
-// seeds of the clustering in ascending order (exclude: rows that stay out); never empty unless every row is excluded
-std::vector<int> locality_seeds(int n, const std::vector<char> *exclude) {
+// Segment length (a power of two, as a shift): about four times the typical largest column offset of a row -- for a
+// lexicographic n^3 grid four z-planes.  Cells are confined to segments and ranked in sweep order inside them (below).
+int locality_segment_shift(const HostCSR &D) {
+  const int n = D.nrows;
+  if (getenv("MI_HYPRE_LOCALITY_SEGMENT")) return std::max(8, std::min(30, atoi(getenv("MI_HYPRE_LOCALITY_SEGMENT"))));
+  std::vector<int64_t> off;
+  const int samples = std::min(n, 4096);
+  for (int q = 0; q < samples; q++) {
+    const int i = (int)((int64_t)q * n / samples);
+    int64_t mx = 0;
+    for (int64_t k = D.ia[(size_t)i]; k < D.ia[(size_t)i + 1]; k++)
+      mx = std::max<int64_t>(mx, std::llabs((int64_t)D.ja[(size_t)k] - i));
+    off.push_back(mx);
+  }
+  if (off.empty()) return 20;
+  std::nth_element(off.begin(), off.begin() + (long)off.size() / 2, off.end());
+  const int64_t want = 4 * std::max<int64_t>(1, off[off.size() / 2]);
+  int sh = 14;
+  while (sh < 22 && ((int64_t)1 << sh) < want) sh++;
+  return sh;
+}
+
+// seeds of the clustering in ascending order (exclude: rows that stay out): rows whose hashed index is 0 modulo the
+// cluster size; a segment without any gets its first row that takes part
+std::vector<int> locality_seeds(int n, int segshift, const std::vector<char> *exclude) {
   const unsigned long long cl = (unsigned long long)LOCALITY_CLUSTER;
-  const int nt = std::max(1, host_threads());
-  std::vector<std::vector<int>> part((size_t)nt + 1);
-  parallel_for(n, [&](int64_t b, int64_t e, int t) {
-    std::vector<int> &mine = part[(size_t)t];
-    for (int64_t i = b; i < e; i++) {
-      if (exclude && (*exclude)[(size_t)i]) continue;
-      unsigned long long z = (unsigned long long)i + 0x9E3779B97F4A7C15ULL;  // splitmix64
-      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-      z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-      z ^= z >> 31;
-      if (z % cl == 0) mine.push_back((int)i);
+  const int nseg = (int)((((int64_t)n - 1) >> segshift) + 1);
+  std::vector<std::vector<int>> per_seg((size_t)std::max(nseg, 0));
+  parallel_for(nseg, [&](int64_t b, int64_t e, int) {
+    for (int64_t sg = b; sg < e; sg++) {
+      std::vector<int> &mine = per_seg[(size_t)sg];
+      const int64_t r0 = sg << segshift, r1 = std::min<int64_t>(n, (sg + 1) << segshift);
+      int first = -1;
+      for (int64_t i = r0; i < r1; i++) {
+        if (exclude && (*exclude)[(size_t)i]) continue;
+        if (first < 0) first = (int)i;
+        unsigned long long z = (unsigned long long)i + 0x9E3779B97F4A7C15ULL;  // splitmix64
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        z ^= z >> 31;
+        if (z % cl == 0) mine.push_back((int)i);
+      }
+      if (mine.empty() && first >= 0) mine.push_back(first);
     }
   });
   std::vector<int> seeds;
-  for (auto &v : part) seeds.insert(seeds.end(), v.begin(), v.end());
-  std::sort(seeds.begin(), seeds.end());  // parallel_for hands out ascending ranges, but not necessarily thread 0 first
-  if (seeds.empty())
-    for (int i = 0; i < n; i++)
-      if (!exclude || !(*exclude)[(size_t)i]) {
-        seeds.push_back(i);
-        break;
-      }
+  for (auto &v : per_seg) seeds.insert(seeds.end(), v.begin(), v.end());
   return seeds;
 }
 
-// labels (seed rank, nseeds = farther than the round limit from every seed, LOCALITY_EXCLUDED) -> order[new] = old:
-// stable counting sort, the excluded rows last in natural order
-void locality_sort(const std::vector<int> &label, int nseeds, std::vector<int> &order) {
+// final labels (cell = seed rank, -1 = never reached, LOCALITY_EXCLUDED) -> order[new] = old.  Cells are ranked by their
+// SMALLEST ROW: scanning the rows in the caller's order, a cell takes the next rank when its first row appears.  With
+// cells confined to a segment that is a sweep through the segment -- on a lexicographic grid along x, then y, through
+// a slab of four planes -- so that cells which share columns are a few cells apart in the new order (what one L2 still
+// holds), as the round-2 breadth-first balls were.  Then a stable counting sort of the rows by cell rank; unreached
+// rows form one last cluster, excluded rows come last, both in natural order.
+void locality_sort(std::vector<int> &label, int nseeds, std::vector<int> &order) {
   const int n = (int)label.size();
-  const int nlab = nseeds + 2;  // clusters, the unreached rest, the excluded rows
+  std::vector<int> minrow((size_t)nseeds, n);
+  for (int i = n - 1; i >= 0; i--)
+    if (label[(size_t)i] >= 0) minrow[(size_t)label[(size_t)i]] = i;
+  std::vector<int> cells((size_t)nseeds);
+  for (int c = 0; c < nseeds; c++) cells[(size_t)c] = c;
+  std::sort(cells.begin(), cells.end(), [&](int a, int b) {
+    return minrow[(size_t)a] != minrow[(size_t)b] ? minrow[(size_t)a] < minrow[(size_t)b] : a < b;
+  });
+  std::vector<int> rank((size_t)nseeds);
+  for (int q = 0; q < nseeds; q++) rank[(size_t)cells[(size_t)q]] = q;
+  parallel_for(n, [&](int64_t b, int64_t e, int) {
+    for (int64_t i = b; i < e; i++) {
+      int &l = label[(size_t)i];
+      if (l >= 0)
+        l = rank[(size_t)l];
+      else if (l == -1)
+        l = nseeds;
+    }
+  });
+  const int nlab = nseeds + 2;  // cells, the unreached rest, the excluded rows
   const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (int64_t)n / 65536 + 1));
   std::vector<std::vector<int64_t>> hist((size_t)nt, std::vector<int64_t>((size_t)nlab, 0));
   const int64_t per = ((int64_t)n + nt - 1) / nt;
@@ -1393,7 +1441,8 @@ void locality_sort(const std::vector<int> &label, int nseeds, std::vector<int> &
 // entries on N > 1 ranks: the halo-free rows then form one stretch that is swept while the halo travels)
 void locality_order(const HostCSR &D, std::vector<int> &order, const std::vector<char> *exclude) {
   const int n = D.nrows;
-  const std::vector<int> seeds = locality_seeds(n, exclude);
+  const int segshift = locality_segment_shift(D);
+  const std::vector<int> seeds = locality_seeds(n, segshift, exclude);
   const int nseeds = (int)seeds.size();
   std::vector<int> label((size_t)n, -1);
   if (exclude)
@@ -1412,9 +1461,12 @@ void locality_order(const HostCSR &D, std::vector<int> &order, const std::vector
     parallel_for((int64_t)active.size(), [&](int64_t b, int64_t e, int) {
       for (int64_t q = b; q < e; q++) {
         const int i = active[(size_t)q];
+        const int sg = i >> segshift;
         int m = -1;
         for (int64_t k = D.ia[(size_t)i]; k < D.ia[(size_t)i + 1]; k++) {
-          const int lj = label[(size_t)D.ja[(size_t)k]];
+          const int j = D.ja[(size_t)k];
+          if ((j >> segshift) != sg) continue;  // cells do not cross segments
+          const int lj = label[(size_t)j];
           if (lj >= 0 && (m < 0 || lj < m)) m = lj;
         }
         next[(size_t)q] = m;
@@ -1430,10 +1482,6 @@ void locality_order(const HostCSR &D, std::vector<int> &order, const std::vector
     if (w == active.size()) break;  // nothing changed
     active.resize(w);
   }
-  parallel_for(n, [&](int64_t b, int64_t e, int) {
-    for (int64_t i = b; i < e; i++)
-      if (label[(size_t)i] == -1) label[(size_t)i] = nseeds;
-  });
   locality_sort(label, nseeds, order);
 }
 
@@ -1546,14 +1594,11 @@ void BoomerAMG::setup_host(ParCSR &A0) {
         hipStream_t s = ctx().stream;
         sk::DCsr raw;
         sk::from_solve_format(A0.d_diag, raw, s);
-        const std::vector<int> seeds = locality_seeds(n0, nullptr);
+        const int segshift = locality_segment_shift(A0.diag);
+        const std::vector<int> seeds = locality_seeds(n0, segshift, nullptr);
         std::vector<int> label;
-        const int rounds = sk::locality_labels(raw, seeds.data(), (int)seeds.size(), nullptr, LOCALITY_MAX_ROUNDS, label, s);
+        const int rounds = sk::locality_labels(raw, seeds.data(), (int)seeds.size(), nullptr, segshift, LOCALITY_MAX_ROUNDS, label, s);
         const int nseeds = (int)seeds.size();
-        parallel_for(n0, [&](int64_t b, int64_t e, int) {
-          for (int64_t i = b; i < e; i++)
-            if (label[(size_t)i] < 0) label[(size_t)i] = nseeds;
-        });
         locality_sort(label, nseeds, input_order);
         DVec<int> dorder, dpos((size_t)n0);
         dorder.upload(input_order);
@@ -1563,7 +1608,8 @@ void BoomerAMG::setup_host(ParCSR &A0) {
         Q.diag.nrows = Q.diag.ncols = n0;
         Q.host_diag_stale = true;
         Q.dev_diag_nnz = pending_sA0.nnz;
-        if (getenv("MI_HYPRE_SETUP_TIMING")) printf("   locality numbering on the device: %d seeds, %d rounds\n", nseeds, rounds);
+        if (getenv("MI_HYPRE_SETUP_TIMING"))
+          printf("   locality numbering on the device: segments of 2^%d rows, %d seeds, %d rounds\n", segshift, nseeds, rounds);
       } else {
         locality_order(A0.diag, input_order, nullptr);
         permute_symmetric(A0.diag, input_order, Q.diag);

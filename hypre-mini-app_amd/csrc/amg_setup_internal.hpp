@@ -29,8 +29,9 @@ void locality_order(const HostCSR &D, std::vector<int> &order, const std::vector
 // (seed rank; nseeds = never reached; LOCALITY_EXCLUDED)
 constexpr int LOCALITY_EXCLUDED = -2;
 constexpr int LOCALITY_MAX_ROUNDS = 64;
-std::vector<int> locality_seeds(int n, const std::vector<char> *exclude);
-void locality_sort(const std::vector<int> &label, int nseeds, std::vector<int> &order);
+int locality_segment_shift(const HostCSR &D);
+std::vector<int> locality_seeds(int n, int segshift, const std::vector<char> *exclude);
+void locality_sort(std::vector<int> &label, int nseeds, std::vector<int> &order);  // label: seed ranks, -1, EXCLUDED (overwritten)
 
 }  // namespace hs
 }  // namespace mi

@@ -908,15 +908,18 @@ __global__ __launch_bounds__(BLK) void ia_to_64_k(long long n1, const int *__res
 // the smallest label among its neighbours labelled in the previous round; labelled and excluded (-2) rows are copied
 __global__ __launch_bounds__(BLK) void locality_round_k(int n, const long long *__restrict__ ia, const int *__restrict__ ja,
                                                         const int *__restrict__ in, int *__restrict__ out,
-                                                        int *__restrict__ changed) {
+                                                        int *__restrict__ changed, int segshift) {
   const int i = blockIdx.x * BLK + threadIdx.x;
   if (i >= n) return;
   int li = in[i];
   if (li == -1) {
     int m = -1;
+    const int sg = i >> segshift;
     const long long k1 = ia[i + 1];
     for (long long k = ia[i]; k < k1; k++) {
-      const int lj = in[ja[k]];
+      const int j = ja[k];
+      if ((j >> segshift) != sg) continue;  // cells do not cross segments
+      const int lj = in[j];
       if (lj >= 0 && (m < 0 || lj < m)) m = lj;
     }
     if (m >= 0) {
@@ -1607,8 +1610,8 @@ void from_solve_format(const DevCSR &src, DCsr &dst, hipStream_t s) {
   MI_HIP(hipGetLastError());
 }
 
-int locality_labels(const DCsr &A, const int *seeds_host, int nseeds, const unsigned char *exclude_host, int max_rounds,
-                    std::vector<int> &label_host, hipStream_t s) {
+int locality_labels(const DCsr &A, const int *seeds_host, int nseeds, const unsigned char *exclude_host, int segshift,
+                    int max_rounds, std::vector<int> &label_host, hipStream_t s) {
   const int n = A.nrows;
   label_host.assign((size_t)n, -1);
   if (n == 0) return 0;
@@ -1628,7 +1631,7 @@ int locality_labels(const DCsr &A, const int *seeds_host, int nseeds, const unsi
   int rounds = 0;
   for (; rounds < max_rounds; rounds++) {
     MI_HIP(hipMemsetAsync(changed.p, 0, sizeof(int), s));
-    locality_round_k<<<(unsigned)((n + BLK - 1) / BLK), BLK, 0, s>>>(n, A.ia.p, A.ja.p, in, out, changed.p);
+    locality_round_k<<<(unsigned)((n + BLK - 1) / BLK), BLK, 0, s>>>(n, A.ia.p, A.ja.p, in, out, changed.p, segshift);
     int ch = 0;
     MI_HIP(hipMemcpyAsync(&ch, changed.p, sizeof(int), hipMemcpyDeviceToHost, s));
     MI_HIP(hipStreamSynchronize(s));

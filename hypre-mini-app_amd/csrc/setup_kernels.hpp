@@ -81,10 +81,11 @@ void zero_guess_operator(const DevCSR &A, int nc, int chunk, DCsr &Z, hipStream_
 void from_solve_format(const DevCSR &src, DCsr &dst, hipStream_t s);
 // Rounds of the internal locality numbering (amg_setup.cpp locality_order: graph Voronoi cells) on the device:
 // labels start as the seeds' ranks (seeds ascending), -2 for excluded rows, -1 elsewhere; in every round an
-// unlabelled row takes the smallest label among its neighbours labelled in the previous round.  Stops when a round
+// unlabelled row takes the smallest label among its neighbours of the same segment (row >> segshift) labelled in the
+// previous round.  Stops when a round
 // changes nothing or after max_rounds; label_host gets the result (-1 = never reached).  Returns the rounds run.
-int locality_labels(const DCsr &A, const int *seeds_host, int nseeds, const unsigned char *exclude_host, int max_rounds,
-                    std::vector<int> &label_host, hipStream_t s);
+int locality_labels(const DCsr &A, const int *seeds_host, int nseeds, const unsigned char *exclude_host, int segshift,
+                    int max_rounds, std::vector<int> &label_host, hipStream_t s);
 // pos[order[q]] = q
 void invert_permutation(const int *order, int n, int *pos, hipStream_t s);
 // back to host arrays (lazy host copies for the inspection API)

@@ -15,6 +15,10 @@ if [ "$mode" = stats ]; then
     python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu --no-general > "$REPO/gpurun_out/prof_stats.log" 2>&1
   python3 "$REPO/profiles/gap_analysis.py" "$(ls -t "$REPO"/gpurun_out/prof_stats/*/*_kernel_trace.csv | head -1)" > "$REPO/gpurun_out/gaps_512.txt" 2>&1 || true
 else
+  # counter passes: without the collapsed coarse tail -- tabulating it means ~50 000 tiny dispatches at Setup, and
+  # rocprofv3's counter collection crashed in that loop (segmentation fault inside its dispatch interception); the
+  # level-0 kernels whose traffic is measured here are the same either way
+  export MI_HYPRE_DENSE_TAIL_ROWS=0
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$REPO/gpurun_out/prof_fetch" -- \
     python3 "$REPO/bench.py" --steps 1 --warmup 0 --no-cpu ${PMC_BENCH_ARGS:---no-general} > "$REPO/gpurun_out/prof_fetch.log" 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$REPO/gpurun_out/prof_write" -- \

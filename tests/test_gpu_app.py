@@ -178,6 +178,43 @@ solver_settings:
     assert m and int(m.group(1)) < 40 and float(m.group(2)) <= 1e-10
 
 
+def test_non_galerkin_keys_through_driver(tmp_path):
+    """non_galerkin_tol and non_galerkin_level_tols {levels, tolerances} as the reference driver reads them
+    (/root/reference/src/HypreSystem.cpp:161-176): the hierarchy gets lighter than the Galerkin one, the solve still
+    reaches the known answer, nothing is reported as ignored."""
+    def run(extra):
+        out = _run(tmp_path, f"""
+linear_system:
+  type: laplace_3d
+  nx: 40
+  ny: 40
+  nz: 40
+  stencil: 7
+
+solver_settings:
+  method: gmres
+  preconditioner: boomeramg
+  tolerance: 1.0e-10
+  max_iterations: 100
+  kspace: 50
+  print_level: 2
+
+boomeramg_settings:
+  print_level: 1
+{extra}""")
+        cx = float(re.search(r"operator complexity ([0-9.]+)", out).group(1))
+        it = int(re.search(r"Solve 0 : (\d+) iterations", out).group(1))
+        err = float(re.search(r"max \|x - 1\| = ([0-9.eE+-]+)", out).group(1))
+        assert "NOT implemented" not in out
+        return cx, it, err
+
+    cx0, it0, err0 = run("")
+    cx1, it1, err1 = run("  non_galerkin_tol: 0.05\n")
+    cx2, it2, err2 = run("  non_galerkin_tol: 0.0\n  non_galerkin_level_tols:\n    levels: [1, 2, 3]\n    tolerances: [0.05, 0.1, 0.1]\n")
+    assert cx1 < 0.9 * cx0 and cx1 < cx2 < cx0
+    assert max(err0, err1, err2) < 1e-7 and max(it1, it2) <= it0 + 3
+
+
 def test_ilu_complex_smoother_keys_through_driver(tmp_path):
     """The smoother keys the reference driver reads (src/HypreSystem.cpp:235-320): ILU(0) as the smoother of the two
     finest levels, Jacobi iterations for its triangular solves; an unimplemented smoother type is an error exit."""
