@@ -505,10 +505,14 @@ __global__ __launch_bounds__(BLK) void interp_bound_k(int n, const long long *__
       for (long long k = sia[i]; k < sia[i + 1]; k++) {
         const int i1 = sja[k];
         const int c1 = cf[i1];
-        if (c1 == C_PT)
+        if (c1 == C_PT) {
           trc++;
-        else if (c1 == F_PT && ext)
-          trc += sia[i1 + 1] - sia[i1];
+        } else if (c1 == F_PT && ext) {
+          // only the C points of a strong F neighbour's row are candidates (counting the whole row put every row of
+          // a 27-point operator -- 24 strong F neighbours x 26 -- into the one-workgroup-per-row bin: 19.6 s of the
+          // 512^3 27-point setup)
+          for (long long kk = sia[i1]; kk < sia[i1 + 1]; kk++) trc += (cf[sja[kk]] == C_PT);
+        }
       }
       t = max(trc, sia[i + 1] - sia[i]);
       const long long rowcap = pmax > 0 ? min(trc, (long long)pmax) : trc;
