@@ -62,3 +62,22 @@ def test_bench_two_ranks_rehearsal():
     assert j["n_gpus"] == 2 and j.get("rehearsal") is True and j["cpu_baseline"] is None
     assert 5 <= j["iterations_per_solve"] <= 30 and j["final_rel_residual"] <= 1e-8
     assert j["max_abs_error_vs_ones"] < 1e-5
+
+
+def test_bench_two_ranks_rehearsal_peer_store_halo():
+    """The same rehearsal with the halo updates on the hipIpc peer-store transport (`--halo-transport ipc`; reductions stay
+    on the gloo callbacks here, on RCCL in a real multi-GPU run): same iteration count and residual as over the callbacks."""
+    env = dict(os.environ)
+    env["MI_BENCH_SHARED_GPU"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    res = []
+    for port, extra in ((29793, []), (29795, ["--halo-transport", "ipc"])):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+               "--grid", "64", "--no-cpu"] + extra
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, cwd=ROOT)
+        assert p.returncode == 0, p.stdout[-3000:]
+        res.append(_json_line(p.stdout))
+    assert "hipIpc" in res[1]["config"]["transport"] and "hipIpc" not in res[0]["config"]["transport"]
+    assert res[0]["iterations_per_solve"] == res[1]["iterations_per_solve"]
+    assert res[0]["final_rel_residual"] == res[1]["final_rel_residual"]  # the transport moves the same bytes: bitwise
