@@ -399,3 +399,143 @@ def test_aggressive_coarsening_and_multipass_against_an_independent_restatement(
     # the slow convergence of the aggressive side-line is the method's, not a deviation of the restatement
     assert rho_plain < 0.25 and 0.3 < rho_agg < 0.65, (rho_plain, rho_agg)
     assert Po.nnz / N < 2.0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# PMIS and extended+i interpolation against independent statements of the published algorithms (the default
+# hierarchy of the benchmark): De Sterck / Yang / Heys 2006 (PMIS), De Sterck / Falgout / Nolting / Yang 2008
+# ("distance-two interpolation for parallel algebraic multigrid", the extended+i formula).  Written for the test,
+# sharing no code with oracle.c / amg_setup.cpp.
+# ---------------------------------------------------------------------------------------------------------------
+def _extended_i_reference(A, S, cf):
+    """P (no truncation) by the extended+i formula: for an F point i with strong C neighbours C_i, strong F neighbours
+    F_i and Chat_i = C_i U (U_{k in F_i} C_k):
+        w_ij = -(1 / att_i) (a_ij + sum_{k in F_i} a_ik abar_kj / d_ik),  j in Chat_i,
+        att_i = a_ii + sum_{n weak neighbour of i, n not in Chat_i} a_in + sum_{k in F_i} a_ik abar_ki / d_ik,
+        d_ik = sum_{l in Chat_i U {i}} abar_kl,   abar_kl = a_kl if its sign differs from a_kk's, else 0."""
+    A, S = A.tocsr(), S.tocsr()
+    n = A.shape[0]
+    rows = [dict(zip(A.indices[A.indptr[i]:A.indptr[i + 1]], A.data[A.indptr[i]:A.indptr[i + 1]])) for i in range(n)]
+    strong = [set(S.indices[S.indptr[i]:S.indptr[i + 1]]) for i in range(n)]
+    cidx = -np.ones(n, dtype=int)
+    cidx[cf == 1] = np.arange(int((cf == 1).sum()))
+    P = sp.lil_matrix((n, int((cf == 1).sum())))
+
+    def abar(k, l):
+        v = rows[k].get(l, 0.0)
+        return v if v * rows[k][k] < 0 else 0.0
+
+    for i in range(n):
+        if cf[i] == 1:
+            P[i, cidx[i]] = 1.0
+            continue
+        Ci = [j for j in strong[i] if cf[j] == 1]
+        Fi = [k for k in strong[i] if cf[k] != 1]
+        chat = set(Ci)
+        for k in Fi:
+            chat |= {j for j in strong[k] if cf[j] == 1}
+        if not chat:
+            continue
+        att = rows[i][i]
+        for nb, v in rows[i].items():
+            if nb != i and nb not in strong[i] and nb not in chat:
+                att += v
+        w = {j: rows[i].get(j, 0.0) for j in chat}
+        for k in Fi:
+            d = sum(abar(k, l) for l in chat | {i})
+            if d == 0.0:
+                att += rows[i][k]
+                continue
+            f = rows[i][k] / d
+            for j in chat:
+                w[j] += f * abar(k, j)
+            att += f * abar(k, i)
+        for j, v in w.items():
+            P[i, cidx[j]] = -v / att
+    return P.tocsr()
+
+
+@pytest.mark.parametrize("n,stencil", [(10, 7), (7, 27)])
+def test_pmis_and_extended_i_against_independent_statements(oc, n, stencil):
+    A, b = oc.Csr.laplace(n, n, n, stencil)
+    amg = oc.Amg(A, oc.default_params(pmax_elmts=0))  # no truncation: the formula itself
+    Al = amg.level_A(0).to_scipy().tocsr()
+    Al.sort_indices()
+    cf = np.asarray(amg.level_cf(0))
+    S = _strength_pattern(Al)
+    # ---- PMIS: the C points are an independent set of the symmetrised strength graph, and a maximal one: every F
+    # point depends strongly on a C point or influences one (De Sterck / Yang / Heys, properties of the splitting)
+    G = ((S + S.T) > 0).astype(int).tocsr()
+    C = cf == 1
+    assert G[C][:, C].nnz == 0
+    touches_c = np.asarray(G[:, C].sum(axis=1)).ravel() > 0
+    has_strong = np.asarray(G.sum(axis=1)).ravel() > 0
+    assert np.all(touches_c[~C] | ~has_strong[~C])
+    assert 0.05 < C.mean() < 0.5
+    # ---- extended+i weights
+    Po = amg.level_P(0).to_scipy().tocsr()
+    Pref = _extended_i_reference(Al, S, cf)
+    Pref = Pref.tocsc()[:, np.asarray(amg.level_perm(1))].tocsr()   # the oracle's columns are in level 1's own order
+    assert Po.shape == Pref.shape and abs(Po - Pref).max() < 1e-13, abs(Po - Pref).max()
+    # interior rows reproduce constants (zero row sums of A there)
+    interior = np.asarray(abs(Al.sum(axis=1))).ravel() < 1e-14
+    assert interior.any() and np.abs(np.asarray(Po.sum(axis=1)).ravel()[interior] - 1.0).max() < 1e-13
+
+
+def test_extended_i_with_weak_connections_and_classical_modified(oc):
+    """The same check on an anisotropic operator (z couplings 0.05: weak neighbours, which the formula lumps into the
+    diagonal unless they belong to the interpolatory set), and classical modified interpolation (interp_type 0) against
+    ITS published formula: w_ij = -(a_ij + sum_{k in F_i^s} a_ik abar_kj / sum_{m in C_i^s} abar_km) / (a_ii + sum_{weak n} a_in)
+    (Ruge / Stueben direct-neighbour interpolation with HYPRE's modification: a strong F neighbour without a common C
+    point is lumped into the diagonal)."""
+    n = 9
+    T = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(n, n))
+    I = sp.identity(n)
+    M = (sp.kron(sp.kron(I, I), T) + sp.kron(sp.kron(I, T), I) + 0.05 * sp.kron(sp.kron(T, I), I)).tocsr()
+    M.sort_indices()
+    A = oc.Csr.from_scipy(M)
+    # ---- extended+i
+    amg = oc.Amg(A, oc.default_params(pmax_elmts=0))
+    Al = amg.level_A(0).to_scipy().tocsr()
+    Al.sort_indices()
+    cf = np.asarray(amg.level_cf(0))
+    S = _strength_pattern(Al)
+    assert S.nnz < Al.nnz - Al.shape[0]  # some neighbours ARE weak
+    Pref = _extended_i_reference(Al, S, cf).tocsc()[:, np.asarray(amg.level_perm(1))].tocsr()
+    assert abs(amg.level_P(0).to_scipy() - Pref).max() < 1e-13
+    # ---- classical modified
+    amg0 = oc.Amg(A, oc.default_params(pmax_elmts=0, interp_type=0))
+    Al = amg0.level_A(0).to_scipy().tocsr()
+    Al.sort_indices()
+    cf = np.asarray(amg0.level_cf(0))
+    S = _strength_pattern(Al)
+    N = Al.shape[0]
+    rows = [dict(zip(Al.indices[Al.indptr[i]:Al.indptr[i + 1]], Al.data[Al.indptr[i]:Al.indptr[i + 1]])) for i in range(N)]
+    strong = [set(S.indices[S.indptr[i]:S.indptr[i + 1]]) for i in range(N)]
+    cidx = -np.ones(N, dtype=int)
+    cidx[cf == 1] = np.arange(int((cf == 1).sum()))
+    P = sp.lil_matrix((N, int((cf == 1).sum())))
+    for i in range(N):
+        if cf[i] == 1:
+            P[i, cidx[i]] = 1.0
+            continue
+        Ci = [j for j in strong[i] if cf[j] == 1]
+        if not Ci:
+            continue
+        diag = rows[i][i] + sum(v for nb, v in rows[i].items() if nb != i and nb not in strong[i])
+        w = {j: rows[i][j] for j in Ci}
+        for k in strong[i]:
+            if cf[k] == 1:
+                continue
+            d = sum(rows[k].get(m, 0.0) for m in Ci if rows[k].get(m, 0.0) * rows[k][k] < 0)
+            if d == 0.0:
+                diag += rows[i][k]
+                continue
+            for j in Ci:
+                v = rows[k].get(j, 0.0)
+                if v * rows[k][k] < 0:
+                    w[j] += rows[i][k] * v / d
+        for j, v in w.items():
+            P[i, cidx[j]] = -v / diag
+    Pref0 = P.tocsr().tocsc()[:, np.asarray(amg0.level_perm(1))].tocsr()
+    assert abs(amg0.level_P(0).to_scipy() - Pref0).max() < 1e-13
