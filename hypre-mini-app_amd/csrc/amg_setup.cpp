@@ -2442,6 +2442,7 @@ void BoomerAMG::setup_device() {
     tail_pcol.upload(pcol);
   }
   MI_HIP(hipDeviceSynchronize());
+  dev_pool_trim();  // the setup's transient buffers go back to the driver: the solve allocates its Krylov basis next
   {
     const double tc0 = wall_time();
     build_collapsed_tail();

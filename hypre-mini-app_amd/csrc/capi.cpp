@@ -218,6 +218,7 @@ HYPRE_Int HYPRE_Finalize(void) {
     c.red_partials.release();
     c.red_out.release();
     c.red_ticket.release();
+    dev_pool_trim();
     if (c.h_pinned) (void)hipHostFree(c.h_pinned);
     c.h_pinned = nullptr;
     if (c.stream) (void)hipStreamDestroy(c.stream);
@@ -1199,6 +1200,12 @@ HYPRE_Int HYPRE_MI_CheckBlockRowPointers(HYPRE_BigInt nrows, const HYPRE_BigInt 
 HYPRE_Int HYPRE_MI_GetCounter(const char *name, long long *value) {
   API_BEGIN
   const std::string n(name ? name : "");
+  if (n == "pool_cached_bytes" || n == "pool_hits" || n == "pool_misses") {
+    long long cb = 0, h = 0, m = 0;
+    dev_pool_stats(&cb, &h, &m);
+    *value = n == "pool_cached_bytes" ? cb : n == "pool_hits" ? h : m;
+    return 0;
+  }
   if (n == "matvec_overlapped")
     *value = ctx().n_matvec_overlapped;
   else if (n == "gs_overlapped")

@@ -38,6 +38,18 @@ struct Error : std::runtime_error {
   } while (0)
 
 // ---------------------------------------------------------------- device memory
+// Caching pool behind every DVec (runtime.cpp): a released block is kept and handed to the next request of a similar
+// size instead of going back to the driver.  The AMG setup allocates and frees hundreds of transient multi-GB
+// buffers; every hipFree synchronises the device and every fresh hipMalloc maps new VRAM pages, which on a freshly
+// booted box costs the FIRST process seconds (512^3 setup: 16.2 s in the first process of a box, 10.3 s in the second).
+// Reusing a cached block synchronises the library's streams first (what hipFree's implicit synchronisation gave).
+// Cached bytes are bounded (MI_HYPRE_POOL_MAX_GB, default 48); dev_pool_trim() -- end of Setup, allocation failure --
+// returns every cached block to the driver.  MI_HYPRE_POOL=0: plain hipMalloc / hipFree.
+void *dev_alloc(size_t bytes);
+void dev_free(void *p);
+void dev_pool_trim();
+void dev_pool_stats(long long *cached_bytes, long long *hits, long long *misses);
+
 template <class T>
 struct DVec {
   T *p = nullptr;
@@ -57,14 +69,14 @@ struct DVec {
   }
   ~DVec() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) dev_free((void *)p);
     p = nullptr, n = 0;
   }
   // pad elements are allocated and zeroed past n (kernels read whole vectors of 2)
   void alloc(size_t n_, size_t pad = 2) {
     release();
     n = n_;
-    MI_HIP(hipMalloc((void **)&p, (n + pad) * sizeof(T)));
+    p = (T *)dev_alloc((n + pad) * sizeof(T));
     if (pad) {  // finished before any stream can touch the allocation
       MI_HIP(hipMemsetAsync((void *)(p + n), 0, pad * sizeof(T), nullptr));
       MI_HIP(hipStreamSynchronize(nullptr));

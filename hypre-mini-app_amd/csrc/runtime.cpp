@@ -7,6 +7,10 @@
 #include <cstring>
 #include <thread>
 
+#include <map>
+#include <mutex>
+#include <unordered_map>
+
 #include "kernels.hpp"
 #include "mi_internal.hpp"
 #include "parcsr.hpp"
@@ -156,6 +160,126 @@ TraceRange::TraceRange(const char *name) {
 }
 TraceRange::~TraceRange() {
   if (on) roctx().pop();
+}
+
+// ---------------------------------------------------------------- caching device-memory pool (mi_internal.hpp)
+namespace {
+struct DevPool {
+  std::mutex m;
+  std::multimap<size_t, void *> free_blocks;     // size -> block
+  std::unordered_map<void *, size_t> size_of;    // every block the pool handed out or holds
+  size_t cached = 0;
+  long long hits = 0, misses = 0;
+  int enabled = -1;
+  size_t max_cached = 0;
+  void init() {
+    if (enabled >= 0) return;
+    enabled = (getenv("MI_HYPRE_POOL") && atoi(getenv("MI_HYPRE_POOL")) == 0) ? 0 : 1;
+    const double gb = getenv("MI_HYPRE_POOL_MAX_GB") ? atof(getenv("MI_HYPRE_POOL_MAX_GB")) : 48.0;
+    max_cached = (size_t)(gb * 1e9);
+  }
+};
+DevPool &pool() {
+  static DevPool *p = new DevPool();  // never destroyed: DVecs of static objects may be released at exit
+  return *p;
+}
+size_t pool_round(size_t bytes) {
+  if (bytes < 256) return 256;
+  if (bytes <= (1u << 20)) return (bytes + 4095) / 4096 * 4096;
+  return (bytes + ((size_t)2 << 20) - 1) / ((size_t)2 << 20) * ((size_t)2 << 20);
+}
+}  // namespace
+
+void dev_pool_trim() {
+  DevPool &P = pool();
+  std::vector<void *> blocks;
+  {
+    std::lock_guard<std::mutex> g(P.m);
+    for (auto &kv : P.free_blocks) {
+      blocks.push_back(kv.second);
+      P.size_of.erase(kv.second);
+    }
+    P.free_blocks.clear();
+    P.cached = 0;
+  }
+  for (void *b : blocks) (void)hipFree(b);
+}
+
+void dev_pool_stats(long long *cached_bytes, long long *hits, long long *misses) {
+  DevPool &P = pool();
+  std::lock_guard<std::mutex> g(P.m);
+  if (cached_bytes) *cached_bytes = (long long)P.cached;
+  if (hits) *hits = P.hits;
+  if (misses) *misses = P.misses;
+}
+
+void *dev_alloc(size_t bytes) {
+  DevPool &P = pool();
+  P.init();
+  void *p = nullptr;
+  if (!P.enabled) {
+    MI_HIP(hipMalloc(&p, bytes));
+    return p;
+  }
+  const size_t want = pool_round(bytes);
+  {
+    std::lock_guard<std::mutex> g(P.m);
+    auto it = P.free_blocks.lower_bound(want);
+    // a cached block serves a request it does not waste more than 1/8 of (small blocks: any of the same class)
+    if (it != P.free_blocks.end() && it->first <= want + std::max<size_t>(want / 8, 4096)) {
+      p = it->second;
+      P.cached -= it->first;
+      P.free_blocks.erase(it);
+      P.hits++;
+    } else {
+      P.misses++;
+    }
+  }
+  if (p) {
+    // the previous owner's kernels may still be running: what hipFree's implicit synchronisation took care of
+    Ctx &c = ctx();
+    if (c.inited) {
+      MI_HIP(hipStreamSynchronize(c.stream));
+      MI_HIP(hipStreamSynchronize(c.comm_stream));
+    } else {
+      MI_HIP(hipDeviceSynchronize());
+    }
+    return p;
+  }
+  hipError_t e = hipMalloc(&p, want);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    dev_pool_trim();  // the cached blocks may be what is missing
+    e = hipMalloc(&p, want);
+  }
+  if (e != hipSuccess)
+    fail(2, std::string("hipMalloc of ") + std::to_string(want) + " bytes failed: " + hipGetErrorString(e));
+  std::lock_guard<std::mutex> g(P.m);
+  P.size_of[p] = want;
+  return p;
+}
+
+void dev_free(void *p) {
+  if (!p) return;
+  DevPool &P = pool();
+  P.init();
+  if (!P.enabled) {
+    (void)hipFree(p);
+    return;
+  }
+  bool trim = false;
+  {
+    std::lock_guard<std::mutex> g(P.m);
+    auto it = P.size_of.find(p);
+    if (it == P.size_of.end()) {  // not ours (allocated while the pool was off)
+      (void)hipFree(p);
+      return;
+    }
+    P.free_blocks.insert({it->second, p});
+    P.cached += it->second;
+    trim = P.cached > P.max_cached;
+  }
+  if (trim) dev_pool_trim();
 }
 
 void DevCSR::upload(const HostCSR &h) {
