@@ -1,13 +1,13 @@
 #!/bin/bash
 # config 4 stand-in (BASELINE.json): a MatrixMarket system of ~10 M rows through the driver, on the GPU box:
-#   gpurun -- bash profiles/run_config4_mm.sh 216
+#   gpurun -- bash profiles/run_config4_mm.sh 216 [var]     (var: variable-coefficient diffusion, no value dictionary)
 set -e
 cd "${GRAFT_REPO_ROOT:-.}"
 N=${1:-216}
 D=/tmp/mm_$N
 mkdir -p $D
-gcc -O2 -o /tmp/gen_mm hypre-mini-app_amd/host/tools/gen_mm.c
-/tmp/gen_mm $N $D
+gcc -O2 -o /tmp/gen_mm hypre-mini-app_amd/host/tools/gen_mm.c -lm
+/tmp/gen_mm $N $D $2
 ls -la $D
 cat > $D/in.yaml <<YAML
 linear_system:
