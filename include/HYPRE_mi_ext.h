@@ -127,7 +127,7 @@ HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCF(HYPRE_Solver solver, HYPRE_Int level, HYP
 HYPRE_Int HYPRE_MI_BoomerAMGGetLevelPerm(HYPRE_Solver solver, HYPRE_Int level, HYPRE_Int *perm);
 /* Internal locality numbering of the input (one rank, large systems; MI_HYPRE_LOCALITY_ORDER = 0 off / 1 on, unset:
  * at least MI_HYPRE_LOCALITY_MIN_ROWS = 1e6 rows): the hierarchy is built on Q A Q^T where Q groups rows into
- * graph-compact clusters (breadth-first balls of 512 rows) so that tiles of consecutive rows gather few distinct
+ * graph-compact clusters (graph Voronoi cells of ~512 rows, ranked in sweep order) so that tiles of consecutive rows gather few distinct
  * columns.  order[new] = caller's local row (identity and *applied = 0 when not in use); GetLevelPerm(0) already
  * includes it (level-0 row -> caller row). */
 HYPRE_Int HYPRE_MI_BoomerAMGGetInputOrdering(HYPRE_Solver solver, HYPRE_Int *applied, HYPRE_Int *order);
