@@ -133,7 +133,7 @@ def main():
     Ao_used, bo_used = Ao, bo
     # (the replicated setup -- everything but plain PMIS -- does not renumber on N > 1 ranks)
     by_replication = size > 1 and (smooth_o.get("coarsen_type", 8) not in (8, 9) or smooth_o.get("agg_num_levels", 0) > 0
-                                   or smooth_o.get("interp_type", 6) == 4
+                                   or smooth_o.get("interp_type", 6) == 4 or smooth_o.get("non_galerkin_tol", 0.0) > 0.0
                                    or os.environ.get("MI_HYPRE_REPLICATED_SETUP", "0") not in ("", "0"))
     if args.locality and by_replication:
         assert not amg.input_ordering()[0]
@@ -164,7 +164,8 @@ def main():
 
     replicated = os.environ.get("MI_HYPRE_REPLICATED_SETUP", "0") not in ("", "0")
     # everything but plain PMIS with ext+i / classical / direct interpolation is built by the replicated setup
-    if smooth_o.get("coarsen_type", 8) not in (8, 9) or smooth_o.get("agg_num_levels", 0) > 0 or smooth_o.get("interp_type", 6) == 4:
+    if (smooth_o.get("coarsen_type", 8) not in (8, 9) or smooth_o.get("agg_num_levels", 0) > 0 or smooth_o.get("interp_type", 6) == 4
+            or smooth_o.get("non_galerkin_tol", 0.0) > 0.0):
         replicated = True
     if size > 1 and not replicated:
         assert counter("setup_distributed") >= 1, "the distributed setup did not run"

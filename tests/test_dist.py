@@ -74,7 +74,8 @@ def test_host_setup_replicated_path_gloo(nproc, n, stencil, seq):
     assert "dist host setup ok" in out
 
 
-@pytest.mark.parametrize("nproc,n,seq,combo", [(2, 14, 300, 1), (3, 12, 100, 15), (2, 14, 0, 17), (2, 12, 150, 11)])
+@pytest.mark.parametrize("nproc,n,seq,combo", [(2, 14, 300, 1), (3, 12, 100, 15), (2, 14, 0, 17), (2, 12, 150, 11),
+                                                (2, 13, 200, 18)])  # 18: non-Galerkin coarse operators (replicated setup)
 def test_host_setup_parameter_combinations_gloo(nproc, n, seq, combo):
     """Seeded combinations of the BoomerAMG choices on N ranks (host half): Ruge-Stueben / CLJP coarsening, aggressive
     levels that reach into the redundant tail, multipass interpolation; a coarsest level below the redundancy
@@ -134,7 +135,8 @@ def test_device_solve_other_smoothers_shared_gpu(nproc, n, seq, relax):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("nproc,n,seq,combo", [(2, 14, 300, 1), (3, 12, 100, 15), (2, 14, 0, 17), (4, 12, 200, 19),
-                                                (3, 13, -1, 0), (2, 12, 150, 11)])
+                                                (3, 13, -1, 0), (2, 12, 150, 11),
+                                                (2, 13, 200, 18), (3, 12, 0, 14)])  # 18, 14: non-Galerkin coarse operators
 def test_device_solve_parameter_combinations_shared_gpu(nproc, n, seq, combo):
     """Seeded combinations of the BoomerAMG choices (test_gpu_amg.py::_combo: Ruge-Stueben / CLJP coarsening,
     aggressive levels, multipass, complex smoother, W cycles ...) on N ranks: the replicated setup for everything

@@ -567,6 +567,10 @@ def _combo(seed):
         kw.update(smooth_type=5, smooth_num_levels=int(rng.choice([1, 2])))
     if rng.random() < 0.3:
         kw["max_coarse_size"] = int(rng.choice([40, 150]))
+    # (round 3; its own stream so that the combinations above stay what they were) non-Galerkin coarse operators
+    rng2 = np.random.default_rng(90000 + seed)
+    if rng2.random() < 0.3:
+        kw["non_galerkin_tol"] = float(rng2.choice([0.02, 0.05, 0.1]))
     return kw
 
 
