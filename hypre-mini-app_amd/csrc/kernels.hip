@@ -1291,10 +1291,18 @@ __global__ __launch_bounds__(1024) void ipc_exchange_k(IpcBatch B, unsigned long
   }
 }
 
+// Workgroups of the streaming vector kernels.  Measured at 512^3 (134 M doubles per vector, profiles/
+// r03_vector_grid_512.txt): the fused Gram-Schmidt step runs at 3.8 / 6.0 / 6.4 / 6.2 / 5.4 / 5.2 / 4.9 TB/s with
+// 256 / 512 / 768 / 1024 / 2048 / 4096 / 16384 workgroups of 256 lanes -- three per CU stream best (fewer, longer
+// streams keep DRAM pages open); more only adds concurrent streams.  MI_HYPRE_VEC_BLOCKS overrides.
+inline int vec_grid_cap() {
+  static const int cap = getenv("MI_HYPRE_VEC_BLOCKS") ? std::max(1, std::min(RED_MAX_BLOCKS, atoi(getenv("MI_HYPRE_VEC_BLOCKS")))) : 768;
+  return cap;
+}
 inline int vec_grid(int n) {
   long long want = ((long long)n + 511) / 512;
   if (want < 1) want = 1;
-  if (want > RED_MAX_BLOCKS) want = RED_MAX_BLOCKS;
+  if (want > vec_grid_cap()) want = vec_grid_cap();
   return (int)want;
 }
 
@@ -1657,8 +1665,17 @@ void gs_hybrid(const DevCSR &A, const double *u_lo, const double *u_hi, int spli
   prof_end(prof, s);
 }
 
+// workgroups of the inner-product kernels (MI_HYPRE_DOT_BLOCKS, at most RED_MAX_BLOCKS * MASS_NV partial slots)
+static int dot_grid(int n) {
+  static const int cap = getenv("MI_HYPRE_DOT_BLOCKS") ? std::max(1, std::min(RED_MAX_BLOCKS * MASS_NV, atoi(getenv("MI_HYPRE_DOT_BLOCKS")))) : vec_grid_cap();
+  long long want = ((long long)n + 511) / 512;
+  if (want < 1) want = 1;
+  if (want > cap) want = cap;
+  return (int)want;
+}
+
 void dot(const double *x, const double *y, int n, double *out_dev, hipStream_t s) {
-  const int g = vec_grid(n);
+  const int g = dot_grid(n);
   double *partials = ctx().red_partials.p;
   prof_begin(PROF_DOT, s);
   hipLaunchKernelGGL(dot_partial_k, dim3(g), dim3(256), 0, s, x, y, n, partials, ctx().red_ticket.p, out_dev);
@@ -1668,7 +1685,7 @@ void dot(const double *x, const double *y, int n, double *out_dev, hipStream_t s
 
 void axpy_dot(const double *alpha_dev, double scale_, const double *xa, double *y, const double *xd, int n,
               double *out_dev, hipStream_t s) {
-  const int g = vec_grid(n);
+  const int g = dot_grid(n);
   double *partials = ctx().red_partials.p;
   prof_begin(PROF_DOT, s);
   hipLaunchKernelGGL(axpy_dot_partial_k, dim3(g), dim3(256), 0, s, alpha_dev, scale_, xa, y, xd, n, partials,
