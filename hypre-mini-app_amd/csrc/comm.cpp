@@ -378,8 +378,8 @@ struct IpcExchangeComm : Comm {
     }
     send_seq.assign((size_t)size, 0);
     recv_seq.assign((size_t)size, 0);
-    tickets.alloc((size_t)k::IPC_MAX_TRANSFERS);
-    MI_HIP(hipMemset(tickets.p, 0, (size_t)k::IPC_MAX_TRANSFERS * sizeof(unsigned)));
+    tickets.alloc((size_t)k::IPC_MAX_TRANSFERS * 8);  // eight launches' worth: consecutive launches never share a slot
+    MI_HIP(hipMemset(tickets.p, 0, (size_t)k::IPC_MAX_TRANSFERS * 8 * sizeof(unsigned)));
     error_flag.alloc(1);
     MI_HIP(hipMemset(error_flag.p, 0, sizeof(int)));
     MI_HIP(hipDeviceSynchronize());
@@ -427,7 +427,7 @@ struct IpcExchangeComm : Comm {
       // one launch holds every part it can; a ticket slot belongs to one transfer of the launch
       if (B.n == k::IPC_MAX_TRANSFERS) flush();
       B.t[B.n] = t;
-      B.t[B.n].ticket = tickets.p + B.n;
+      B.t[B.n].ticket = tickets.p + (size_t)(n_launch % 8) * k::IPC_MAX_TRANSFERS + B.n;  // (also when two streams carry exchanges)
       B.n++;
     };
     auto blocks_for = [](size_t bytes) { return bytes >= (1u << 20) ? 4 : bytes >= (1u << 18) ? 2 : 1; };
