@@ -549,6 +549,33 @@ def main():
         }
         if rehearsal:
             out["rehearsal"] = True
+    # ---- side-line (N = 1): the reference's other Krylov choice on the SAME hierarchy, method: cogmres
+    # (/root/reference/src/HypreSystem.cpp:372-388) -- GMRES with block classical Gram-Schmidt: one pass of inner products
+    # and one block update per step instead of i dependent fused passes.  NOT the headline (the headline is method: gmres).
+    if world == 1 and not args.no_general and roof is not None:
+        cg = mi.COGMRES(tolerance=args.tol, max_iterations=args.max_iter, kspace=args.kdim, print_level=0)
+        cg.set_precond(amg)
+        cg.setup(A, b, x)
+
+        def cg_solve():
+            x.fill(0.0)
+            cg.solve(A, b, x)
+            return cg.num_iterations
+
+        cg_solve()
+        barrier()
+        t0 = time.perf_counter()
+        c_steps = 3
+        c_iters = sum(cg_solve() for _ in range(c_steps))
+        barrier()
+        c_elapsed = time.perf_counter() - t0
+        out["sideline_cogmres"] = {
+            "what": "SIDE-LINE, not the headline: solver_settings method cogmres on the same hierarchy",
+            "ms_per_step": c_elapsed / c_steps * 1e3, "iterations_per_solve": cg.num_iterations,
+            "value_gdofs": ndof * c_iters / c_elapsed / 1e9, "final_rel_residual": cg.final_rel_res,
+            "max_abs_error_vs_ones": float(np.abs(x.get() - 1.0).max()), "steps": c_steps,
+            "time_to_solution_vs_headline": (c_elapsed / c_steps) / (elapsed / args.steps)}
+        cg.destroy()
     # ---- general-operator leg (N = 1): the headline operator has two distinct values (6, -1), so its level-0 kernels
     # stream one-byte dictionary indices; a variable-coefficient operator (BASELINE.json configs 4 / 5) cannot.  The
     # same problem is set up again with the dictionary off and the same kernel classes are timed on a few solves:

@@ -42,6 +42,12 @@ def test_bench_single_gpu_contract():
     assert g["kernel"].startswith("spmv_stream_xc<0, 1, false, 256>") and g["relax"]["kernel"].startswith("gs_tile_k<false, 256>")
     assert g["iterations_per_solve"] == j["iterations_per_solve"] and g["final_rel_residual"] == j["final_rel_residual"]
     assert abs(g["frac"] - g["achieved"] / g["peak"]) < 1e-12 and g["algorithmic_bytes_per_launch"] == r["algorithmic_bytes_per_launch"]
+    # side-lines: the reference's other knobs on the same problem, labelled as such
+    for key in ("sideline_cogmres", "sideline_non_galerkin"):
+        sl = j[key]
+        assert sl["what"].startswith("SIDE-LINE") and sl["final_rel_residual"] <= 1e-8 and sl["max_abs_error_vs_ones"] < 1e-5
+        assert abs(sl["iterations_per_solve"] - j["iterations_per_solve"]) <= 4
+    assert j["sideline_non_galerkin"]["operator_complexity"] < j["operator_complexity"]
     ms = j["gram_schmidt"]
     assert ms["ms_per_solve"] > 0 and 0 < ms["share_of_solve"] < 1
     c = j["cpu_baseline"]
