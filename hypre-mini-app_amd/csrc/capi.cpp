@@ -1133,6 +1133,16 @@ HYPRE_Int HYPRE_MI_CommExchangeDevice(HYPRE_Int nsend, const HYPRE_Int *send_pee
   comm_check_transport_error(current_comm(), s);
   API_END
 }
+HYPRE_Int HYPRE_MI_CommAllreduceDevice(HYPRE_Real *dev_buf, HYPRE_Int count) {
+  API_BEGIN
+  ensure_init();
+  if (!dev_buf || count < 1) fail(HYPRE_ERROR_ARG, "CommAllreduceDevice: bad argument");
+  hipStream_t s = ctx().stream;
+  current_comm().allreduce_dev(dev_buf, (size_t)count, CommDType::F64, CommOp::SUM, s);
+  MI_HIP(hipStreamSynchronize(s));
+  comm_check_transport_error(current_comm(), s);
+  API_END
+}
 HYPRE_Int HYPRE_MI_CommCheck(void) {
   API_BEGIN
   if (ctx().inited && ctx().comm) comm_check_transport_error(*ctx().comm, ctx().stream);

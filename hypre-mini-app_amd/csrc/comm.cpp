@@ -341,6 +341,17 @@ struct IpcExchangeComm : Comm {
   std::string label;
 
   size_t header_bytes() const { return (size_t)size * 4 * sizeof(unsigned long long); }
+  // all-reduce area behind the message slots: [2][size] numbers, then [2][size][IPC_AR_MAX] values
+  size_t ar_offset() const { return ((header_bytes() + 255) / 256) * 256 + (size_t)size * 2 * slot_bytes; }
+  unsigned long long *ar_flags(char *base) const { return reinterpret_cast<unsigned long long *>(base + ar_offset()); }
+  double *ar_slots(char *base) const {
+    return reinterpret_cast<double *>(base + ar_offset() + ((size_t)2 * size * sizeof(unsigned long long) + 255) / 256 * 256);
+  }
+  size_t ar_bytes() const {
+    return ((size_t)2 * size * sizeof(unsigned long long) + 255) / 256 * 256 + (size_t)2 * size * k::IPC_AR_MAX * sizeof(double);
+  }
+  unsigned long long ar_seq = 0;
+  long long n_allreduce_ipc = 0;
   unsigned long long *flag_word(char *base, int from, int slot) const {
     return reinterpret_cast<unsigned long long *>(base) + (size_t)from * 2 + slot;
   }
@@ -358,7 +369,7 @@ struct IpcExchangeComm : Comm {
     label = std::string("ipc-peer-store + ") + inner->name();
     const char *tm = getenv("MI_HYPRE_IPC_TIMEOUT_MS");
     spin_limit = (unsigned long long)(tm ? atoll(tm) : 20000) * 100000ull;  // wall_clock64 ticks at 100 MHz
-    const size_t total = ((header_bytes() + 255) / 256) * 256 + (size_t)size * 2 * slot_bytes;
+    const size_t total = ar_offset() + ar_bytes();
     MI_HIP(hipMalloc((void **)&arena, total));
     MI_HIP(hipMemset(arena, 0, total));
     MI_HIP(hipDeviceSynchronize());
@@ -393,8 +404,28 @@ struct IpcExchangeComm : Comm {
   }
   const char *name() const override { return label.c_str(); }
   bool host_transport() const override { return inner->host_transport(); }
+  // the inner products of the Krylov loops (1 to 8 doubles, sum): one launch, peer stores + rank-ordered sum
+  // (MI_HYPRE_IPC_ALLREDUCE=0: through the wrapped communicator, like every other reduction)
   void allreduce_dev(void *buf, size_t count, CommDType t, CommOp op, hipStream_t s) override {
-    inner->allreduce_dev(buf, count, t, op, s);
+    static const bool on = !(getenv("MI_HYPRE_IPC_ALLREDUCE") && atoi(getenv("MI_HYPRE_IPC_ALLREDUCE")) == 0);
+    if (!on || t != CommDType::F64 || op != CommOp::SUM || count == 0 || count > (size_t)k::IPC_AR_MAX || size > 16) {
+      inner->allreduce_dev(buf, count, t, op, s);
+      return;
+    }
+    k::IpcAllreduce a{};
+    a.rank = rank;
+    a.size = size;
+    a.count = (int)count;
+    a.seq = ++ar_seq;
+    a.buf = (double *)buf;
+    a.my_slots = ar_slots(arena);
+    a.my_flags = ar_flags(arena);
+    for (int r = 0; r < size; r++) {
+      a.peer_slots[r] = ar_slots(peer_arena[(size_t)r]);
+      a.peer_flags[r] = ar_flags(peer_arena[(size_t)r]);
+    }
+    k::ipc_allreduce(a, spin_limit, error_flag.p, s);
+    n_allreduce_ipc++;
   }
   void allgather_dev(const void *send, void *recv, size_t bytes, hipStream_t s) override {
     inner->allgather_dev(send, recv, bytes, s);

@@ -1295,6 +1295,43 @@ __global__ __launch_bounds__(1024) void ipc_exchange_k(IpcBatch B, unsigned long
 // r03_vector_grid_512.txt): the fused Gram-Schmidt step runs at 3.8 / 6.0 / 6.4 / 6.2 / 5.4 / 5.2 / 4.9 TB/s with
 // 256 / 512 / 768 / 1024 / 2048 / 4096 / 16384 workgroups of 256 lanes -- three per CU stream best (fewer, longer
 // streams keep DRAM pages open); more only adds concurrent streams.  MI_HYPRE_VEC_BLOCKS overrides.
+// peer-store all-reduce: see kernels.hpp.  One workgroup of 64 lanes; lane r < size talks to rank r.
+__global__ __launch_bounds__(64) void ipc_allreduce_k(IpcAllreduce A, unsigned long long spin_limit, int *error_flag) {
+  __shared__ double mine[IPC_AR_MAX];
+  const int r = threadIdx.x;
+  const int par = (int)(A.seq & 1ull);
+  if (r < A.count) mine[r] = A.buf[r];
+  __syncthreads();
+  if (r < A.size && r != A.rank) {
+    double *dst = A.peer_slots[r] + ((size_t)par * A.size + A.rank) * IPC_AR_MAX;
+    for (int q = 0; q < A.count; q++) __hip_atomic_store(dst + q, mine[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(A.peer_flags[r] + (size_t)par * A.size + A.rank, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (r < A.size && r != A.rank) {
+    const unsigned long long *fl = A.my_flags + (size_t)par * A.size + r;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(fl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < A.seq) {
+      if (wall_clock64() - t0 > spin_limit) {
+        atomicExch(error_flag, 1);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  if (r < A.count) {
+    double sum = 0.0;
+    for (int q = 0; q < A.size; q++) {  // rank order: identical bits on every rank
+      const double v = (q == A.rank) ? mine[r]
+                                     : __hip_atomic_load(A.my_slots + ((size_t)par * A.size + q) * IPC_AR_MAX + r,
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      sum = (q == 0) ? v : sum + v;
+    }
+    A.buf[r] = sum;
+  }
+}
+
 inline int vec_grid_cap() {
   static const int cap = getenv("MI_HYPRE_VEC_BLOCKS") ? std::max(1, std::min(RED_MAX_BLOCKS, atoi(getenv("MI_HYPRE_VEC_BLOCKS")))) : 768;
   return cap;
@@ -1793,6 +1830,11 @@ void ipc_exchange(const IpcBatch &b, unsigned long long spin_limit, int *error_f
   for (int i = 0; i < b.n; i++) nb += b.t[i].nblocks;
   if (nb == 0) return;
   hipLaunchKernelGGL(ipc_exchange_k, dim3((unsigned)nb), dim3(1024), 0, s, b, spin_limit, error_flag);
+  MI_HIP(hipGetLastError());
+}
+
+void ipc_allreduce(const IpcAllreduce &a, unsigned long long spin_limit, int *error_flag, hipStream_t s) {
+  hipLaunchKernelGGL(ipc_allreduce_k, dim3(1), dim3(64), 0, s, a, spin_limit, error_flag);
   MI_HIP(hipGetLastError());
 }
 

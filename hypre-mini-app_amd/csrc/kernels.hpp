@@ -142,6 +142,21 @@ struct IpcBatch {
   int n;
 };
 void ipc_exchange(const IpcBatch &b, unsigned long long spin_limit, int *error_flag, hipStream_t s);
+// Peer-store all-reduce (sum) of up to IPC_AR_MAX doubles: every rank stores its values into every peer's mailbox
+// (slot [parity][rank]) and publishes the reduction's number; then it waits for all peers' numbers and adds the
+// size contributions IN RANK ORDER -- the same order on every rank, so all ranks get the same bits.  Two parities:
+// nobody can start reduction k + 2 before every rank has finished reduction k (it needs their k + 1 values first).
+constexpr int IPC_AR_MAX = 8;
+struct IpcAllreduce {
+  int rank, size, count;
+  unsigned long long seq;            // number of this reduction (1, 2, ...)
+  double *buf;                       // in: this rank's values; out: the sums
+  double *my_slots;                  // my arena: [2][size][IPC_AR_MAX]
+  unsigned long long *my_flags;      // my arena: [2][size]
+  double *peer_slots[16];            // every rank's slots / flags as mapped here (self: my own)
+  unsigned long long *peer_flags[16];
+};
+void ipc_allreduce(const IpcAllreduce &a, unsigned long long spin_limit, int *error_flag, hipStream_t s);
 
 // IJ helpers
 void scatter_set(double *x, const int *idx, const double *vals, int n, hipStream_t s);

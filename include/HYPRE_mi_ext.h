@@ -34,6 +34,10 @@ HYPRE_Int HYPRE_MI_CommInitCallbacks(void *ctx, HYPRE_MI_AllreduceFn ar, HYPRE_M
  * (MI_HYPRE_IPC_TIMEOUT_MS, default 20 000): HYPRE_MI_CommCheck reports a message that never arrived. */
 HYPRE_Int HYPRE_MI_CommEnablePeerStoreExchange(HYPRE_BigInt slot_bytes);
 HYPRE_Int HYPRE_MI_CommCheck(void);
+/* sum all-reduce of `count` doubles in DEVICE memory through the current transport (what an inner product of the
+ * Krylov loops does; completed on return).  On the peer-store transport up to 8 doubles take one launch: every rank
+ * stores its values into every peer's mailbox and adds the contributions in rank order (identical bits everywhere). */
+HYPRE_Int HYPRE_MI_CommAllreduceDevice(HYPRE_Real *dev_buf, HYPRE_Int count);
 /* one neighbour exchange of DEVICE buffers through the current transport, on the library stream, completed on return
  * (what a halo update does; for transport tests) */
 HYPRE_Int HYPRE_MI_CommExchangeDevice(HYPRE_Int nsend, const HYPRE_Int *send_peers, void *const *send_ptrs,

@@ -66,6 +66,22 @@ def main():
                     1, (C.c_int * 1)(left), (C.c_void_p * 1)(r.data_ptr()), (C.c_size_t * 1)(nbytes))
             assert np.array_equal(r.cpu().numpy(), payload(left, rank, rnd, nbytes))
             rounds += 1
+    # ---- scalar all-reduces (the Krylov loops' inner products): 1..8 doubles by peer stores, summed in rank order
+    # (so the bits are those of the loop below on every rank); 9 doubles go through the wrapped communicator
+    for rnd in range(40):
+        cnt = 1 + rnd % 9
+        vals = [np.random.default_rng(7919 * r + rnd).standard_normal(cnt) * 10.0 ** (rnd % 5) for r in range(size)]
+        t = torch.from_numpy(vals[rank].copy()).cuda()
+        torch.cuda.synchronize()
+        mi.call("HYPRE_MI_CommAllreduceDevice", C.c_void_p(t.data_ptr()), cnt)
+        got = t.cpu().numpy()
+        want = vals[0].copy()
+        for r in range(1, size):
+            want = want + vals[r]
+        if cnt <= 8:
+            assert np.array_equal(got, want), (rank, rnd, cnt, got, want)
+        else:
+            assert np.allclose(got, want, rtol=1e-14, atol=0.0), (rank, rnd, cnt)
     mi.call("HYPRE_MI_CommCheck")
     if rank == 0:
         print(f"ipc exchange ok: {size} ranks, {rounds} rounds")
