@@ -1824,12 +1824,26 @@ void BoomerAMG::finish_host() {
     if (A.host_diag_stale && Lv.oA.nrows == A.nrows) {
       // the level lives on the device: norms straight into the solve-phase vectors
       hipStream_t s = ctx().stream;
-      DVec<int> dcf;
+      DVec<int> dcf, dcf_ext;
       if (!Lv.cf.empty()) dcf.upload(Lv.cf);
       Lv.d_diag.alloc((size_t)Lv.n);
       Lv.d_l1gs.alloc((size_t)Lv.n);
       Lv.d_l1jac.alloc((size_t)Lv.n);
-      sk::level_norms(Lv.oA, Lv.cf.empty() ? nullptr : dcf.p, ch, Lv.d_diag.p, Lv.d_l1gs.p, Lv.d_l1jac.p, s);
+      // N > 1 (levels of the distributed setup that were built on the device): the halo block's entries count too
+      sk::DCsr dO;
+      if (comm.size > 1) {
+        std::vector<int> cf_ext;
+        if (Lv.has_cf) cf_ext = A.halo_exchange_host_int(comm, Lv.cf);  // collective: gated by the global flag
+        if (A.offd.nnz() > 0) {
+          HostCSR O = A.offd;
+          O.nrows = Lv.n;
+          O.ncols = (int)A.col_map_offd.size();
+          dO.upload(O, s);
+          dcf_ext.upload(cf_ext);
+        }
+      }
+      sk::level_norms(Lv.oA, Lv.cf.empty() ? nullptr : dcf.p, ch, Lv.d_diag.p, Lv.d_l1gs.p, Lv.d_l1jac.p, s,
+                      dO.nnz > 0 ? &dO : nullptr, dO.nnz > 0 ? dcf_ext.p : nullptr);
       MI_HIP(hipStreamSynchronize(s));
       continue;
     }

@@ -40,7 +40,7 @@ using namespace hs;
 
 namespace {
 
-long long g_ext_rows_max = 0, g_global_rows_gathered = 0, g_dist_setups = 0;
+long long g_ext_rows_max = 0, g_global_rows_gathered = 0, g_dist_setups = 0, g_dev_levels = 0;
 
 // this rank's rows of a distributed operator: GLOBAL column ids, ascending inside a row
 struct GlobCSR {
@@ -347,6 +347,682 @@ void spgemm_auto(const HostCSR &A, const HostCSR &B, HostCSR &C, long long devic
   host_spgemm(A, B, C);
 }
 
+
+// ============================================================================================================
+// Device-resident levels (round 3).  The levels of the distributed hierarchy whose per-rank pieces are large are
+// built without host copies of the operators: a rank keeps its rows of A, P and R on the device in EXTENDED index
+// spaces [remote ids below the own range | own range | remote ids above], ascending in the global id like the
+// single-rank numbering.  Every sum is therefore taken in the single-rank order, and the single-rank device
+// kernels (sk::strength, sk::interp, sk::spgemm, sk::transpose) run unchanged on the extended matrices; the PMIS
+// rounds run on the own rows with the halo state exchanged between the steps (sk::pmis_dist_*).  What crosses the
+// host are the halo-sized pieces only: the rows of the halo points, their P rows, the (A P) rows that travel to the
+// owners of remote coarse points, and per-point state.  Same hierarchy as build_distributed's host loop bit for bit
+// (tests/test_dist.py, device threshold 0).
+// ============================================================================================================
+struct DevLevel {
+  std::vector<gidx> starts;
+  ExtIndex E;   // column space of A: own rows + ring-1 halo ids
+  sk::DCsr A;   // n x E.size(), natural order
+  Ring ring1;   // over E.remote
+  ExtIndex CE;  // column space of P: own coarse range + remote coarse ids
+  sk::DCsr P;   // n x CE.size()
+  ExtIndex E2;  // column space of R: own fine rows + the fine rows of other ranks that reach my coarse points
+  sk::DCsr R;   // n_coarse x E2.size()
+};
+
+struct RowSet {  // rows with global column ids
+  std::vector<int64_t> ia{0};
+  std::vector<gidx> col;
+  std::vector<double> val;
+  int rows() const { return (int)ia.size() - 1; }
+};
+
+sk::ExtColMap identity_map(int ncols) {
+  sk::ExtColMap m;
+  m.nb_old = 0;
+  m.n_own = ncols;
+  m.own_new0 = 0;
+  return m;
+}
+
+// position in `to` of every id of `from_remote` (ascending remote ids of another extended space); -1 = not there
+void remote_table(const std::vector<gidx> &from_remote, const ExtIndex &to, DVec<int> &tab) {
+  std::vector<int> t(from_remote.size());
+  const int nown = (int)(to.e - to.s);
+  parallel_for((int64_t)from_remote.size(), [&](int64_t b, int64_t e, int) {
+    for (int64_t k = b; k < e; k++) {
+      const gidx g = from_remote[(size_t)k];
+      const size_t q = (size_t)(std::lower_bound(to.remote.begin(), to.remote.end(), g) - to.remote.begin());
+      const bool there = q < to.remote.size() && to.remote[q] == g;
+      t[(size_t)k] = !there ? -1 : (g < to.s ? (int)q : (int)q + nown);
+    }
+  });
+  tab.upload(t);
+}
+
+// own rows keep their place, remote columns move through `tab` (remote_table of from.remote in `to`)
+sk::ExtColMap ext_map(const ExtIndex &from, const ExtIndex &to, const DVec<int> &tab) {
+  sk::ExtColMap m;
+  m.nb_old = from.nbelow;
+  m.n_own = (int)(from.e - from.s);
+  m.own_new0 = to.nbelow;
+  m.below = tab.p;
+  m.above = tab.p + from.nbelow;
+  return m;
+}
+
+// The rows of M (own rows; row r of the partition is row r + row_shift of M; columns in `cols`) that the peers asked
+// for through `ring` travel to them as (lengths, global column ids, values); returns the rows of ring.ids (ascending).
+RowSet fetch_rows(Comm &comm, const Ring &ring, const sk::DCsr &M, int row_shift, const ExtIndex &cols, hipStream_t s) {
+  const int ns = (int)ring.send_map.size();
+  HostCSR h;
+  h.ia.assign(1, 0);
+  if (ns) {
+    std::vector<int> rows((size_t)ns);
+    for (int k = 0; k < ns; k++) rows[(size_t)k] = ring.send_map[(size_t)k] + row_shift;
+    DVec<int> d;
+    d.upload(rows);
+    sk::DCsr sel;
+    sk::select_rows(M, d.p, 0, ns, identity_map(M.ncols), M.ncols, false, sel, s);
+    sel.download(h, s);
+  }
+  std::vector<std::vector<char>> send(ring.send_peers.size());
+  for (size_t i = 0; i < ring.send_peers.size(); i++) {
+    const int b = ring.send_starts[i], e = ring.send_starts[i + 1];
+    std::vector<int> len((size_t)(e - b));
+    for (int k = b; k < e; k++) len[(size_t)(k - b)] = (int)(h.ia[(size_t)k + 1] - h.ia[(size_t)k]);
+    put(send[i], len.data(), len.size());
+    const int64_t e0 = h.ia[(size_t)b], e1 = h.ia[(size_t)e];
+    std::vector<gidx> g((size_t)(e1 - e0));
+    for (int64_t q = e0; q < e1; q++) g[(size_t)(q - e0)] = cols.global(h.ja[(size_t)q]);
+    put(send[i], g.data(), g.size());
+    put(send[i], h.a.data() + e0, (size_t)(e1 - e0));
+  }
+  std::vector<int> from;
+  std::vector<std::vector<char>> got;
+  comm.exchange_host(ring.send_peers, send, from, got);
+  std::vector<const std::vector<char> *> by(ring.recv_peers.size(), nullptr);
+  for (size_t i = 0; i < from.size(); i++) {
+    const size_t pi = (size_t)(std::find(ring.recv_peers.begin(), ring.recv_peers.end(), from[i]) - ring.recv_peers.begin());
+    MI_REQUIRE(pi < ring.recv_peers.size(), "distributed setup: unexpected sender");
+    by[pi] = &got[i];
+  }
+  RowSet out;
+  for (size_t pi = 0; pi < ring.recv_peers.size(); pi++) {
+    const size_t cnt = (size_t)(ring.recv_starts[pi + 1] - ring.recv_starts[pi]);
+    MI_REQUIRE(by[pi] != nullptr, "distributed setup: a halo owner sent no rows");
+    Reader rd(*by[pi]);
+    std::vector<int> len(cnt);
+    rd.get(len.data(), cnt);
+    size_t total = 0;
+    for (int l : len) total += (size_t)l;
+    const size_t off = out.col.size();
+    out.col.resize(off + total);
+    out.val.resize(off + total);
+    rd.get(out.col.data() + off, total);
+    rd.get(out.val.data() + off, total);
+    for (int l : len) out.ia.push_back(out.ia.back() + l);
+  }
+  MI_REQUIRE(out.rows() == (int)ring.ids.size(), "distributed setup: halo rows and halo ids disagree");
+  return out;
+}
+
+// The remote part of an extended ROW space (`space`: ascending remote ids, the first nbelow below the own range) as
+// two device blocks: the ids of `have` (an ascending subset) carry the rows of `rs`, the others are empty.
+template <class F>
+void remote_blocks(const std::vector<gidx> &space, int nbelow, const std::vector<gidx> &have, const RowSet &rs, int ncols,
+                   F colmap, sk::DCsr &below, sk::DCsr &above, hipStream_t s) {
+  HostCSR B[2];
+  B[0].nrows = nbelow;
+  B[1].nrows = (int)space.size() - nbelow;
+  for (int q = 0; q < 2; q++) {
+    B[q].ncols = ncols;
+    B[q].ia.assign((size_t)B[q].nrows + 1, 0);
+  }
+  size_t h = 0;
+  for (size_t x = 0; x < space.size(); x++) {
+    HostCSR &T = B[(int)x < nbelow ? 0 : 1];
+    const size_t r = (int)x < nbelow ? x : x - (size_t)nbelow;
+    int64_t len = 0;
+    if (h < have.size() && have[h] == space[x]) {
+      for (int64_t k = rs.ia[h]; k < rs.ia[h + 1]; k++) {
+        T.ja.push_back(colmap(rs.col[(size_t)k]));
+        T.a.push_back(rs.val[(size_t)k]);
+      }
+      len = rs.ia[h + 1] - rs.ia[h];
+      h++;
+    }
+    T.ia[r + 1] = T.ia[r] + len;
+  }
+  MI_REQUIRE(h == have.size(), "distributed setup: a fetched row has no place in the extended row space");
+  below.upload(B[0], s);
+  above.upload(B[1], s);
+}
+
+// halo exchange of per-point state that lives in a device vector over an extended space (ring.ids = its remote ids)
+struct DevHalo {
+  Comm &comm;
+  const Ring &ring;
+  int nb, n, ne;
+  hipStream_t s;
+  DVec<int> d_send;
+  DevHalo(Comm &c, const Ring &r, int nb_, int n_, int ne_, hipStream_t s_) : comm(c), ring(r), nb(nb_), n(n_), ne(ne_), s(s_) {
+    MI_REQUIRE((int)ring.ids.size() == ne - n, "distributed setup: halo ring and extended space disagree");
+    d_send.upload(ring.send_map);
+  }
+  // own values -> their copies on the ranks that hold them as remote points
+  template <class T>
+  void forward(T *vec) {
+    const int ns = (int)ring.send_map.size();
+    std::vector<T> sv((size_t)ns);
+    if (ns) {
+      DVec<T> tmp((size_t)ns);
+      sk::gather_elems(vec, d_send.p, nb, ns, (int)sizeof(T), tmp.p, s);
+      MI_HIP(hipMemcpyAsync(sv.data(), tmp.p, (size_t)ns * sizeof(T), hipMemcpyDeviceToHost, s));
+      MI_HIP(hipStreamSynchronize(s));
+    }
+    std::vector<std::vector<char>> send(ring.send_peers.size());
+    for (size_t i = 0; i < ring.send_peers.size(); i++)
+      put(send[i], sv.data() + ring.send_starts[i], (size_t)(ring.send_starts[i + 1] - ring.send_starts[i]));
+    std::vector<int> from;
+    std::vector<std::vector<char>> got;
+    comm.exchange_host(ring.send_peers, send, from, got);
+    std::vector<T> ext(ring.ids.size());
+    for (size_t i = 0; i < from.size(); i++) {
+      const size_t pi = (size_t)(std::find(ring.recv_peers.begin(), ring.recv_peers.end(), from[i]) - ring.recv_peers.begin());
+      MI_REQUIRE(pi < ring.recv_peers.size(), "distributed setup: unexpected sender");
+      const size_t cnt = (size_t)(ring.recv_starts[pi + 1] - ring.recv_starts[pi]);
+      MI_REQUIRE(got[i].size() == cnt * sizeof(T), "distributed setup: halo message of the wrong size");
+      memcpy(ext.data() + ring.recv_starts[pi], got[i].data(), got[i].size());
+    }
+    if (nb) MI_HIP(hipMemcpyAsync(vec, ext.data(), (size_t)nb * sizeof(T), hipMemcpyHostToDevice, s));
+    if (ne - n - nb) MI_HIP(hipMemcpyAsync(vec + nb + n, ext.data() + nb, (size_t)(ne - n - nb) * sizeof(T), hipMemcpyHostToDevice, s));
+    MI_HIP(hipStreamSynchronize(s));
+  }
+  // remote values -> the owners; returns, in send_map order, what the peers hold for my points (on the device)
+  template <class T>
+  void reverse(const T *vec, DVec<T> &at_send) {
+    std::vector<T> ext(ring.ids.size());
+    if (nb) MI_HIP(hipMemcpyAsync(ext.data(), vec, (size_t)nb * sizeof(T), hipMemcpyDeviceToHost, s));
+    if (ne - n - nb) MI_HIP(hipMemcpyAsync(ext.data() + nb, vec + nb + n, (size_t)(ne - n - nb) * sizeof(T), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    std::vector<std::vector<char>> send(ring.recv_peers.size());
+    for (size_t i = 0; i < ring.recv_peers.size(); i++)
+      put(send[i], ext.data() + ring.recv_starts[i], (size_t)(ring.recv_starts[i + 1] - ring.recv_starts[i]));
+    std::vector<int> from;
+    std::vector<std::vector<char>> got;
+    comm.exchange_host(ring.recv_peers, send, from, got);
+    std::vector<T> sv(ring.send_map.size());
+    for (size_t i = 0; i < from.size(); i++) {
+      const size_t pi = (size_t)(std::find(ring.send_peers.begin(), ring.send_peers.end(), from[i]) - ring.send_peers.begin());
+      MI_REQUIRE(pi < ring.send_peers.size(), "distributed setup: unexpected sender");
+      const size_t cnt = (size_t)(ring.send_starts[pi + 1] - ring.send_starts[pi]);
+      MI_REQUIRE(got[i].size() == cnt * sizeof(T), "distributed setup: reverse halo message of the wrong size");
+      memcpy(sv.data() + ring.send_starts[pi], got[i].data(), got[i].size());
+    }
+    at_send.upload(sv);
+  }
+};
+
+// sorted unique ids of v outside [lo, hi) appended to `out` (kept sorted unique)
+void merge_outside(const std::vector<gidx> &v, gidx lo, gidx hi, std::vector<gidx> &out) {
+  for (gidx g : v)
+    if (g < lo || g >= hi) out.push_back(g);
+  sort_unique(out);
+}
+
+struct DevBuild {
+  std::vector<DevLevel> lev;     // processed levels (each has a splitting, P and R)
+  std::vector<std::vector<int>> cf;  // their C/F splittings (special F already F), natural order
+  // the first level the device loop did not process: its operator is still on the device
+  std::vector<gidx> next_starts;
+  ExtIndex next_E;
+  sk::DCsr next_A;
+};
+
+// level 0 on the device: diag + halo blocks merged into rows of ascending (new) global column ids
+void dev_level0(Comm &comm, ParCSR &A0, const std::vector<int> &input_order, const std::vector<int> &newloc,
+                const std::vector<gidx> &newcol_h, sk::DCsr &dD, ExtIndex &E, sk::DCsr &A, hipStream_t s) {
+  (void)comm;
+  const int n = A0.nrows, nh = (int)A0.col_map_offd.size();
+  const bool renum = !input_order.empty();
+  const std::vector<gidx> &rg = renum ? newcol_h : A0.col_map_offd;
+  E.s = A0.row_start, E.e = A0.row_end;
+  E.remote = rg;
+  sort_unique(E.remote);
+  E.finish();
+  if (dD.nrows != n) dD.upload(A0.diag, s);
+  sk::DCsr dO, cat;
+  {
+    HostCSR O = A0.offd;  // full-length row pointers
+    O.nrows = n;
+    O.ncols = nh;
+    if (O.ia.empty()) O.ia.assign((size_t)n + 1, 0);
+    dO.upload(O, s);
+  }
+  dD.ncols = n;
+  sk::hstack(dD, dO, cat, s);
+  dD.release();
+  dO.release();
+  std::vector<int> colpos((size_t)n + (size_t)nh);
+  parallel_for(n, [&](int64_t b, int64_t e, int) {
+    for (int64_t j = b; j < e; j++) colpos[(size_t)j] = E.nbelow + (renum ? newloc[(size_t)j] : (int)j);
+  });
+  for (int k = 0; k < nh; k++) colpos[(size_t)n + (size_t)k] = E.of(rg[(size_t)k]);
+  DVec<int> dcol, dperm;
+  dcol.upload(colpos);
+  if (renum) dperm.upload(input_order);
+  sk::permute(cat, renum ? dperm.p : nullptr, dcol.p, A, s);
+  A.ncols = E.size();
+}
+
+// One level on the device.  In: Lv.starts, Lv.E, Lv.A.  Out: the splitting, Lv.P, Lv.R (+ their column spaces), and the
+// next level's partition / column space / operator.  Returns false when the coarsening stops here (nothing is built).
+bool dev_level(BoomerAMG &amg, Comm &comm, DevLevel &Lv, std::vector<int> &cf_host, std::vector<gidx> &next_starts,
+               ExtIndex &next_E, sk::DCsr &next_A, std::map<std::string, double> *sub_times) {
+  const AmgParams &p = amg.p;
+  hipStream_t s = ctx().stream;
+  const int rank = comm.rank, size = comm.size;
+  const gidx gs = Lv.starts[(size_t)rank], ge = Lv.starts[(size_t)rank + 1];
+  const gidx N = Lv.starts.back();
+  const int n = (int)(ge - gs);
+  const ExtIndex &E = Lv.E;
+  double tsub = wall_time();
+  auto lap = [&](const char *what) {
+    if (!sub_times) return;
+    MI_HIP(hipStreamSynchronize(s));
+    const double now = wall_time();
+    (*sub_times)[what] += now - tsub;
+    tsub = now;
+  };
+  double tp0 = wall_time();
+
+  // ---- the rows of the halo points, and with them the second ring: extended space X
+  Lv.ring1.build(comm, Lv.starts, E.remote);
+  const Ring &ring1 = Lv.ring1;
+  RowSet hrows = fetch_rows(comm, ring1, Lv.A, 0, E, s);
+  ExtIndex X;
+  X.s = gs, X.e = ge;
+  X.remote = E.remote;
+  merge_outside(hrows.col, gs, ge, X.remote);
+  X.finish();
+  const int ne = X.size(), nbX = X.nbelow;
+  g_ext_rows_max = std::max<long long>(g_ext_rows_max, ne);
+  sk::DCsr AownX, Ae;
+  {
+    DVec<int> tab;
+    remote_table(E.remote, X, tab);
+    sk::select_rows(Lv.A, nullptr, 0, n, ext_map(E, X, tab), ne, false, AownX, s);
+    sk::DCsr below, above;
+    remote_blocks(X.remote, nbX, E.remote, hrows, ne, [&](gidx g) { return X.of(g); }, below, above, s);
+    const sk::DCsr *parts[3] = {&below, &AownX, &above};
+    sk::vconcat(parts, 3, Ae, s);
+  }
+  hrows = RowSet();
+  lap("device: extended operator");
+
+  // ---- strength (row-local: exact for the own rows and the halo rows, which are whole)
+  sk::DCsr Se;
+  sk::strength(Ae, p.strong_threshold, p.max_row_sum, Se, s);
+  amg.t_phase[0] += wall_time() - tp0;
+  lap("device: strength");
+
+  // ---- PMIS on the own rows, halo state exchanged between the steps (see the host loop in build_distributed)
+  tp0 = wall_time();
+  Ring ring12;
+  ring12.build(comm, Lv.starts, X.remote);
+  DevHalo halo(comm, ring12, nbX, n, ne, s);
+  DVec<int> dcf((size_t)ne), counter(1);
+  {
+    DVec<int> cnt((size_t)ne);
+    DVec<double> measure((size_t)ne);
+    DVec<signed char> tmp((size_t)ne);
+    MI_HIP(hipMemsetAsync(cnt.p, 0, (size_t)ne * sizeof(int), s));
+    MI_HIP(hipMemsetAsync(dcf.p, 0, (size_t)ne * sizeof(int), s));
+    MI_HIP(hipMemsetAsync(measure.p, 0, (size_t)ne * sizeof(double), s));
+    sk::pmis_dist_counts(Se, nbX, n, cnt.p, s);
+    {
+      DVec<int> at_send;
+      halo.reverse(cnt.p, at_send);
+      sk::scatter_add_int(cnt.p, halo.d_send.p, nbX, at_send.p, (int)ring12.send_map.size(), s);
+      MI_HIP(hipStreamSynchronize(s));
+    }
+    long long left = sk::pmis_dist_init(Se, nbX, n, gs, 2747, cnt.p, measure.p, dcf.p, counter.p, s);
+    halo.forward(measure.p);
+    halo.forward(dcf.p);
+    int rounds = 0;
+    for (;;) {
+      long long glob = left;
+      comm.allreduce_host(&glob, 1, CommDType::I64, CommOp::SUM);
+      if (glob == 0) break;
+      MI_REQUIRE(++rounds <= 10000, "PMIS does not terminate");
+      sk::pmis_dist_compare(Se, nbX, n, ne, dcf.p, measure.p, tmp.p, s);
+      {
+        DVec<signed char> at_send;
+        halo.reverse(tmp.p, at_send);
+        sk::scatter_zero_flags(tmp.p, halo.d_send.p, nbX, at_send.p, (int)ring12.send_map.size(), s);
+        MI_HIP(hipStreamSynchronize(s));
+      }
+      sk::pmis_dist_select(nbX, n, dcf.p, tmp.p, s);
+      halo.forward(dcf.p);
+      left = sk::pmis_dist_fpoints(Se, nbX, n, dcf.p, counter.p, s);
+      halo.forward(dcf.p);
+    }
+  }
+  DVec<long long> crank;
+  const long long nc_loc = sk::count_c_points(dcf.p + nbX, n, crank, s);
+  long long nc_glob = nc_loc;
+  comm.allreduce_host(&nc_glob, 1, CommDType::I64, CommOp::SUM);
+  amg.t_phase[1] += wall_time() - tp0;
+  lap("device: pmis");
+  if (nc_glob == 0 || nc_glob == N || nc_glob < p.min_coarse_size) return false;
+
+  // ---- coarse partition and the coarse ids of every point of X
+  tp0 = wall_time();
+  {
+    std::vector<long long> all((size_t)size, 0);
+    comm.allgather_host(&nc_loc, all.data(), sizeof(long long));
+    next_starts.assign((size_t)size + 1, 0);
+    for (int r = 0; r < size; r++) next_starts[(size_t)r + 1] = next_starts[(size_t)r] + all[(size_t)r];
+  }
+  const gidx cs = next_starts[(size_t)rank];
+  const int ncl = (int)nc_loc;
+  ExtIndex CX;  // the C points of X by coarse id
+  CX.s = cs, CX.e = cs + nc_loc;
+  {
+    DVec<long long> cg((size_t)ne);
+    MI_HIP(hipMemsetAsync(cg.p, 0xff, (size_t)ne * sizeof(long long), s));  // -1
+    sk::fill_coarse_ids(dcf.p + nbX, crank.p, n, cs, cg.p + nbX, s);
+    halo.forward(cg.p);
+    std::vector<long long> cgr((size_t)(ne - n));
+    if (nbX) MI_HIP(hipMemcpyAsync(cgr.data(), cg.p, (size_t)nbX * sizeof(long long), hipMemcpyDeviceToHost, s));
+    if (ne - n - nbX)
+      MI_HIP(hipMemcpyAsync(cgr.data() + nbX, cg.p + nbX + n, (size_t)(ne - n - nbX) * sizeof(long long), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    for (long long g : cgr)
+      if (g >= 0) CX.remote.push_back(g);  // ascending: coarse ids ascend with the fine ids
+    CX.finish();
+  }
+  crank.release();
+
+  // ---- interpolation on the extended sub-problem (every row is computed, the own rows are the ones that count)
+  sk::DCsr Pe;
+  int nce = 0;
+  bool on_dev = (p.interp_type == 6 || p.interp_type == 0) &&
+                sk::interp(Ae, Se, dcf, p.interp_type, p.trunc_factor, p.pmax_elmts, Pe, nce, s);
+  if (!on_dev) {
+    // a row whose interpolatory set outgrows the kernels' tables (or another interpolation type): host routine
+    HostCSR Ah, Ph;
+    Ae.download(Ah, s);
+    Strength Sh;
+    Sh.ia.resize((size_t)ne + 1);
+    Sh.ja.resize((size_t)Se.nnz);
+    MI_HIP(hipMemcpyAsync(Sh.ia.data(), Se.ia.p, ((size_t)ne + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    if (Se.nnz) MI_HIP(hipMemcpyAsync(Sh.ja.data(), Se.ja.p, (size_t)Se.nnz * sizeof(int), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    std::vector<int> cfe = dcf.to_host();
+    cfe.resize((size_t)ne);
+    std::vector<char> want((size_t)ne, 0);
+    for (int i = 0; i < n; i++) want[(size_t)(nbX + i)] = 1;
+    ParCSR Aw;
+    Ah.nrows = Ah.ncols = ne;
+    as_single_rank(std::move(Ah), Aw);
+    build_interp(Aw, Sh, cfe, p.interp_type, p.trunc_factor, p.pmax_elmts, Ph, nce, &want);
+    for (int &c : cfe)
+      if (c == SF_PT) c = F_PT;
+    dcf.upload(cfe);
+    Ph.nrows = ne;
+    Ph.ncols = nce;
+    Pe.upload(Ph, s);
+  }
+  MI_REQUIRE(nce == CX.size(), "distributed setup: coarse point count of the extended sub-problem");
+  Se.release();
+  Ae.release();
+  cf_host.resize((size_t)n);
+  if (n) MI_HIP(hipMemcpyAsync(cf_host.data(), dcf.p + nbX, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+  for (int &c : cf_host)
+    if (c == SF_PT) c = F_PT;
+  dcf.release();
+  amg.t_phase[2] += wall_time() - tp0;
+  lap("device: interpolation");
+
+  // ---- Galerkin product, first half: A P with the P rows of the halo points fetched from their owners
+  tp0 = wall_time();
+  RowSet prow = fetch_rows(comm, ring1, Pe, nbX, CX, s);
+  ExtIndex &CE = Lv.CE;
+  CE.s = cs, CE.e = cs + nc_loc;
+  CE.remote = CX.remote;
+  merge_outside(prow.col, CE.s, CE.e, CE.remote);
+  CE.finish();
+  sk::DCsr AP;
+  {
+    DVec<int> tab;
+    remote_table(CX.remote, CE, tab);
+    sk::select_rows(Pe, nullptr, nbX, n, ext_map(CX, CE, tab), CE.size(), false, Lv.P, s);
+    Pe.release();
+    sk::DCsr below, above, P1;
+    remote_blocks(X.remote, nbX, E.remote, prow, CE.size(), [&](gidx g) { return CE.of(g); }, below, above, s);
+    const sk::DCsr *parts[3] = {&below, &Lv.P, &above};
+    sk::vconcat(parts, 3, P1, s);
+    sk::spgemm(AownX, P1, AP, s);
+  }
+  AownX.release();
+  lap("device: A*P");
+
+  // ---- transpose exchange: P entries whose coarse column lives elsewhere travel to its owner with the (A P) row
+  struct Incoming {
+    gidx fine;
+    std::vector<gidx> pc;
+    std::vector<double> pv;
+    std::vector<gidx> ac;
+    std::vector<double> av;
+  };
+  std::vector<Incoming> inc;
+  {
+    std::vector<int> brows;
+    const int nbr = sk::rows_with_columns_outside(Lv.P, CE.nbelow, CE.nbelow + ncl, brows, s);
+    HostCSR hp, ha;
+    hp.ia.assign(1, 0), ha.ia.assign(1, 0);
+    if (nbr) {
+      DVec<int> d;
+      d.upload(brows);
+      sk::DCsr sp, sa;
+      sk::select_rows(Lv.P, d.p, 0, nbr, identity_map(Lv.P.ncols), Lv.P.ncols, false, sp, s);
+      sk::select_rows(AP, d.p, 0, nbr, identity_map(AP.ncols), AP.ncols, false, sa, s);
+      sp.download(hp, s);
+      sa.download(ha, s);
+    }
+    std::vector<std::vector<char>> out((size_t)size);
+    std::vector<gidx> pc, acol;
+    std::vector<double> pv;
+    for (int q = 0; q < nbr; q++) {
+      const int i = brows[(size_t)q];
+      const int64_t ab = ha.ia[(size_t)q], alen = ha.ia[(size_t)q + 1] - ab;
+      acol.resize((size_t)alen);
+      for (int64_t k = 0; k < alen; k++) acol[(size_t)k] = CE.global(ha.ja[(size_t)(ab + k)]);
+      int64_t k = hp.ia[(size_t)q];
+      const int64_t ke = hp.ia[(size_t)q + 1];
+      while (k < ke) {
+        const gidx g0 = CE.global(hp.ja[(size_t)k]);
+        const int o = rank_of_id(next_starts, g0);
+        pc.clear(), pv.clear();
+        while (k < ke && CE.global(hp.ja[(size_t)k]) < next_starts[(size_t)o + 1]) {  // columns ascend: one owner's run
+          pc.push_back(CE.global(hp.ja[(size_t)k]));
+          pv.push_back(hp.a[(size_t)k]);
+          k++;
+        }
+        if (o == rank) continue;
+        std::vector<char> &buf = out[(size_t)o];
+        put1<gidx>(buf, gs + i);
+        put1<int>(buf, (int)pc.size());
+        put(buf, pc.data(), pc.size());
+        put(buf, pv.data(), pv.size());
+        put1<int>(buf, (int)alen);
+        put(buf, acol.data(), (size_t)alen);
+        put(buf, ha.a.data() + ab, (size_t)alen);
+      }
+    }
+    std::vector<int> peers;
+    std::vector<std::vector<char>> send;
+    for (int r = 0; r < size; r++)
+      if (!out[(size_t)r].empty()) {
+        peers.push_back(r);
+        send.emplace_back(std::move(out[(size_t)r]));
+      }
+    std::vector<int> from;
+    std::vector<std::vector<char>> got;
+    comm.exchange_host(peers, send, from, got);
+    for (auto &buf : got) {
+      Reader rd(buf);
+      while (!rd.done()) {
+        inc.emplace_back();
+        Incoming &in = inc.back();
+        in.fine = rd.get<gidx>();
+        const int np = rd.get<int>();
+        in.pc.resize((size_t)np), in.pv.resize((size_t)np);
+        rd.get(in.pc.data(), (size_t)np);
+        rd.get(in.pv.data(), (size_t)np);
+        const int na = rd.get<int>();
+        in.ac.resize((size_t)na), in.av.resize((size_t)na);
+        rd.get(in.ac.data(), (size_t)na);
+        rd.get(in.av.data(), (size_t)na);
+      }
+    }
+    std::sort(inc.begin(), inc.end(), [](const Incoming &x, const Incoming &y) { return x.fine < y.fine; });
+  }
+  lap("device: transpose exchange");
+
+  // ---- second half: R (A P) on my coarse rows
+  ExtIndex &E2 = Lv.E2;
+  E2.s = gs, E2.e = ge;
+  E2.remote.clear();
+  for (auto &in : inc) E2.remote.push_back(in.fine);
+  E2.finish();
+  const int n2 = E2.size();
+  g_ext_rows_max = std::max<long long>(g_ext_rows_max, n2);
+  ExtIndex CE2;
+  CE2.s = cs, CE2.e = cs + nc_loc;
+  CE2.remote = CE.remote;
+  for (auto &in : inc)
+    for (gidx g : in.ac)
+      if (g < CE2.s || g >= CE2.e) CE2.remote.push_back(g);
+  sort_unique(CE2.remote);
+  CE2.finish();
+  RowSet inc_ap, inc_p;
+  for (auto &in : inc) {
+    inc_ap.col.insert(inc_ap.col.end(), in.ac.begin(), in.ac.end());
+    inc_ap.val.insert(inc_ap.val.end(), in.av.begin(), in.av.end());
+    inc_ap.ia.push_back((int64_t)inc_ap.col.size());
+    inc_p.col.insert(inc_p.col.end(), in.pc.begin(), in.pc.end());
+    inc_p.val.insert(inc_p.val.end(), in.pv.begin(), in.pv.end());
+    inc_p.ia.push_back((int64_t)inc_p.col.size());
+  }
+  std::vector<Incoming>().swap(inc);
+  sk::DCsr Ac;
+  {
+    sk::DCsr APe2, P2;
+    {
+      DVec<int> tab;
+      remote_table(CE.remote, CE2, tab);
+      sk::DCsr own, below, above;
+      sk::select_rows(AP, nullptr, 0, n, ext_map(CE, CE2, tab), CE2.size(), false, own, s);
+      AP.release();
+      remote_blocks(E2.remote, E2.nbelow, E2.remote, inc_ap, CE2.size(), [&](gidx g) { return CE2.of(g); }, below, above, s);
+      const sk::DCsr *parts[3] = {&below, &own, &above};
+      sk::vconcat(parts, 3, APe2, s);
+    }
+    {
+      sk::ExtColMap m;  // own coarse columns only, as local coarse ids
+      m.nb_old = CE.nbelow;
+      m.n_own = ncl;
+      m.own_new0 = 0;
+      sk::DCsr own, below, above;
+      sk::select_rows(Lv.P, nullptr, 0, n, m, ncl, false, own, s);
+      remote_blocks(E2.remote, E2.nbelow, E2.remote, inc_p, ncl, [&](gidx g) { return (int)(g - cs); }, below, above, s);
+      const sk::DCsr *parts[3] = {&below, &own, &above};
+      sk::vconcat(parts, 3, P2, s);
+    }
+    sk::transpose(P2, Lv.R, s);  // my coarse rows x extended fine rows, ascending
+    P2.release();
+    sk::spgemm(Lv.R, APe2, Ac, s);
+  }
+  lap("device: R*(A*P)");
+
+  // ---- the next level's column space: the remote coarse ids that occur
+  next_E.s = cs, next_E.e = cs + nc_loc;
+  next_E.remote.clear();
+  {
+    DVec<unsigned char> used;
+    sk::mark_used_columns(Ac, used, s);
+    const int nrem = (int)CE2.remote.size();
+    std::vector<unsigned char> u((size_t)nrem);
+    if (CE2.nbelow) MI_HIP(hipMemcpyAsync(u.data(), used.p, (size_t)CE2.nbelow, hipMemcpyDeviceToHost, s));
+    if (nrem - CE2.nbelow)
+      MI_HIP(hipMemcpyAsync(u.data() + CE2.nbelow, used.p + CE2.nbelow + ncl, (size_t)(nrem - CE2.nbelow), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    for (int k = 0; k < nrem; k++)
+      if (u[(size_t)k]) next_E.remote.push_back(CE2.remote[(size_t)k]);
+    next_E.finish();
+    DVec<int> tab;
+    remote_table(CE2.remote, next_E, tab);
+    sk::select_rows(Ac, nullptr, 0, ncl, ext_map(CE2, next_E, tab), next_E.size(), false, next_A, s);
+  }
+  amg.t_phase[3] += wall_time() - tp0;
+  lap("device: next operator");
+  return true;
+}
+
+// A device level's operator M (rows: own rows of `row level`, columns: extended space `cols` of the `column level`) in
+// the final per-rank form: rows in `row_perm` order (empty = natural), own columns through `col_pos` (empty =
+// identity), remote columns to the new global ids `newg` (one per id of cols.remote), split into the diag block (on
+// the device, `diag_out`) and the halo block (host).  amg_setup_dist.cpp assemble_rows for operators that never were
+// on the host.
+std::unique_ptr<ParCSR> assemble_dev(const sk::DCsr &M, const ExtIndex &cols, const std::vector<int> &row_perm,
+                                     const std::vector<int> &col_pos, const std::vector<gidx> &newg,
+                                     const std::vector<gidx> &row_starts, const std::vector<gidx> &col_starts, int rank,
+                                     sk::DCsr &diag_out, hipStream_t s) {
+  std::unique_ptr<ParCSR> Q(new ParCSR());
+  const int n = M.nrows;
+  const int ncown = (int)(cols.e - cols.s);
+  Q->nrows = n;
+  Q->row_starts = row_starts;
+  Q->col_starts = col_starts;
+  Q->row_start = row_starts[(size_t)rank];
+  Q->row_end = row_starts[(size_t)rank + 1];
+  Q->col_map_offd = newg;
+  sort_unique(Q->col_map_offd);
+  std::vector<int> tab(newg.size());
+  for (size_t k = 0; k < newg.size(); k++)
+    tab[k] = (int)(std::lower_bound(Q->col_map_offd.begin(), Q->col_map_offd.end(), newg[k]) - Q->col_map_offd.begin());
+  DVec<int> dtab, dperm, dpos;
+  dtab.upload(tab);
+  if (!row_perm.empty()) dperm.upload(row_perm);
+  if (!col_pos.empty()) dpos.upload(col_pos);
+  sk::ExtColMap md;
+  md.nb_old = cols.nbelow;
+  md.n_own = ncown;
+  md.own_new0 = 0;
+  md.own_tab = col_pos.empty() ? nullptr : dpos.p;
+  sk::select_rows(M, row_perm.empty() ? nullptr : dperm.p, 0, n, md, ncown, !col_pos.empty(), diag_out, s);
+  sk::ExtColMap mo;
+  mo.nb_old = cols.nbelow;
+  mo.n_own = ncown;
+  mo.keep_own = false;
+  mo.below = dtab.p;
+  mo.above = dtab.p + cols.nbelow;
+  sk::DCsr off;
+  sk::select_rows(M, row_perm.empty() ? nullptr : dperm.p, 0, n, mo, (int)Q->col_map_offd.size(), true, off, s);
+  off.download(Q->offd, s);
+  Q->offd.nrows = n;
+  Q->offd.ncols = (int)Q->col_map_offd.size();
+  Q->diag.nrows = n;
+  Q->diag.ncols = ncown;
+  Q->host_diag_stale = true;
+  Q->dev_diag_nnz = diag_out.nnz;
+  return Q;
+}
+
 }  // namespace
 
 long long dist_setup_counter(const char *name) {
@@ -354,9 +1030,10 @@ long long dist_setup_counter(const char *name) {
   if (n == "setup_ext_rows_max") return g_ext_rows_max;
   if (n == "setup_global_rows_gathered") return g_global_rows_gathered;
   if (n == "setup_distributed") return g_dist_setups;
+  if (n == "setup_device_levels") return g_dev_levels;  // levels of the distributed setup that were built on the device
   return -1;
 }
-void dist_setup_counters_reset() { g_ext_rows_max = g_global_rows_gathered = g_dist_setups = 0; }
+void dist_setup_counters_reset() { g_ext_rows_max = g_global_rows_gathered = g_dist_setups = g_dev_levels = 0; }
 
 bool BoomerAMG::can_build_distributed() const {
   static const bool forced_off = getenv("MI_HYPRE_REPLICATED_SETUP") && atoi(getenv("MI_HYPRE_REPLICATED_SETUP")) != 0;
@@ -378,13 +1055,40 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
   input_order.clear();
   std::vector<int> newloc;       // old local row -> new local row
   std::vector<gidx> newcol_h;    // new GLOBAL id of every halo column of A0
+  // Large per-rank pieces are built on the device (DevLevel above): decided per level by the SMALLEST piece, so that
+  // every rank takes the same path; MI_HYPRE_DIST_DEVICE_SETUP=0 keeps every level on the host loop below
+  static const bool dev_enabled = !(getenv("MI_HYPRE_DIST_DEVICE_SETUP") && atoi(getenv("MI_HYPRE_DIST_DEVICE_SETUP")) == 0);
+  auto smallest_piece = [&](long long n) {
+    long long m = n;
+    comm.allreduce_host(&m, 1, CommDType::I64, CommOp::MIN);
+    return m;
+  };
+  const bool dev_candidate = dev_enabled && device_min_rows >= 0 && ctx().inited && (p.interp_type == 6 || p.interp_type == 0);
+  const bool dev_path = dev_candidate && smallest_piece(A0.nrows) >= std::max<long long>(1, device_min_rows);
+  sk::DCsr dD0;  // the diag block of A0 in the setup format, when the device path starts from the copy in HBM
+  if (dev_path && A0.on_device && A0.d_diag.nrows == A0.nrows && A0.d_diag.nnz == A0.diag.nnz() && !A0.d_diag.rowmap.p)
+    sk::from_solve_format(A0.d_diag, dD0, ctx().stream);
   if (use_locality_order(A0)) {
     const int n = A0.nrows;
     std::vector<char> has_halo((size_t)n, 0);
     for (int i = 0; i < n; i++) has_halo[(size_t)i] = A0.offd.ia[(size_t)i + 1] > A0.offd.ia[(size_t)i];
-    locality_order(A0.diag, input_order, &has_halo);
+    if (dev_path) {
+      // the clustering rounds on the device (same labels: tests/test_locality_order.py), rows with halo entries excluded
+      hipStream_t s = ctx().stream;
+      if (dD0.nrows != n) dD0.upload(A0.diag, s);
+      const int segshift = locality_segment_shift(A0.diag);
+      const std::vector<int> seeds = locality_seeds(n, segshift, &has_halo);
+      std::vector<int> label;
+      sk::locality_labels(dD0, seeds.data(), (int)seeds.size(), reinterpret_cast<const unsigned char *>(has_halo.data()), segshift,
+                          LOCALITY_MAX_ROUNDS, label, s);
+      locality_sort(label, (int)seeds.size(), input_order);
+    } else {
+      locality_order(A0.diag, input_order, &has_halo);
+    }
     newloc.resize((size_t)n);
-    for (int q = 0; q < n; q++) newloc[(size_t)input_order[(size_t)q]] = q;
+    parallel_for(n, [&](int64_t b, int64_t e, int) {
+      for (int64_t q = b; q < e; q++) newloc[(size_t)input_order[(size_t)q]] = (int)q;
+    });
     Ring r0;
     r0.build(comm, A0.row_starts, A0.col_map_offd);
     const std::vector<int> ext = r0.forward(comm, newloc);
@@ -392,7 +1096,57 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
     for (size_t k = 0; k < newcol_h.size(); k++)
       newcol_h[k] = A0.row_starts[(size_t)rank_of_id(A0.row_starts, A0.col_map_offd[k])] + ext[k];
   }
-  {  // level 0: diag + halo blocks merged into one row of ascending global columns
+  const bool sub_timing = getenv("MI_HYPRE_SETUP_TIMING") != nullptr && rank == 0;
+  std::map<std::string, double> sub_times;
+  const long long red_rows = effective_redundant_rows();
+  bool has_tail = false;
+  int l = 0;
+  DevBuild DB;
+  if (dev_path) {
+    // ---- the large levels, on the device
+    hipStream_t s = ctx().stream;
+    const double tl0 = wall_time();
+    DevLevel cur;
+    cur.starts = A0.row_starts;
+    dev_level0(comm, A0, input_order, newloc, newcol_h, dD0, cur.E, cur.A, s);
+    if (sub_timing) sub_times["device: level 0 from the assembled blocks"] += wall_time() - tl0;
+    while (l < p.max_levels - 1 && cur.starts.back() > p.max_coarse_size) {
+      if (red_rows > 0 && l >= 1 && cur.starts.back() <= red_rows) break;  // the host loop below sets has_tail
+      if (l > 0 && smallest_piece(cur.A.nrows) < std::max<long long>(1, device_min_rows)) break;
+      std::vector<int> cf;
+      DevLevel nxt;
+      if (!dev_level(*this, comm, cur, cf, nxt.starts, nxt.E, nxt.A, sub_timing ? &sub_times : nullptr)) break;
+      DB.lev.push_back(std::move(cur));
+      DB.cf.push_back(std::move(cf));
+      cur = std::move(nxt);
+      l++;
+    }
+    // the first level the device loop left alone goes to the host loop in global ids
+    D.resize((size_t)l + 1);
+    for (int q = 0; q < l; q++) {
+      D[(size_t)q].starts = DB.lev[(size_t)q].starts;
+      D[(size_t)q].cf = DB.cf[(size_t)q];
+      D[(size_t)q].has_cf = true;
+    }
+    DLevel &H = D[(size_t)l];
+    H.starts = cur.starts;
+    HostCSR h;
+    cur.A.download(h, s);
+    cur.A.release();
+    H.A.nrows = h.nrows;
+    H.A.ia.swap(h.ia);
+    H.A.a.swap(h.a);
+    H.A.gj.resize(h.ja.size());
+    const ExtIndex &Ec = cur.E;
+    parallel_for((int64_t)h.ja.size(), [&](int64_t b, int64_t e, int) {
+      for (int64_t k = b; k < e; k++) H.A.gj[(size_t)k] = Ec.global(h.ja[(size_t)k]);
+    });
+    if (H.A.ia.empty()) H.A.ia.assign(1, 0);
+  }
+  dD0.release();
+  const int n_dev_levels = l;
+  g_dev_levels += n_dev_levels;
+  if (!dev_path) {  // level 0: diag + halo blocks merged into one row of ascending global columns
     GlobCSR &G = D[0].A;
     const int n = A0.nrows;
     G.nrows = n;
@@ -425,12 +1179,7 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
       }
     });
   }
-  const long long red_rows = effective_redundant_rows();
-  bool has_tail = false;
-  int l = 0;
   double tp0;
-  const bool sub_timing = getenv("MI_HYPRE_SETUP_TIMING") != nullptr && rank == 0;
-  std::map<std::string, double> sub_times;
   double tsub = 0.0;
   auto lap = [&](const char *what) {
     if (!sub_timing) return;
@@ -1108,7 +1857,7 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
   for (size_t li = 0; li < nlev; li++) {
     const DLevel &Lv = D[li];
     if (!Lv.has_cf) continue;
-    const int n = Lv.A.nrows;
+    const int n = (int)Lv.cf.size();  // (the operator of a device-built level is not in Lv.A)
     pos[li].resize((size_t)n), perm[li].resize((size_t)n);
     int q = 0;
     for (int i = 0; i < n; i++)
@@ -1149,9 +1898,56 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
   L.resize(nlev);
   tail.reset();
   tail_A.reset();
+  // new global ids of the remote ids `ids` of level `lev` after its C-first renumbering (ring: over exactly these ids)
+  auto new_ids = [&](const std::vector<gidx> &ids, size_t lev, const Ring &rg) {
+    std::vector<gidx> out(ids);
+    if (pos[lev].empty()) return out;
+    const std::vector<gidx> &st = D[lev].starts;
+    const std::vector<int> pos_h = rg.forward(comm, pos[lev]);
+    for (size_t k = 0; k < ids.size(); k++) out[k] = st[(size_t)rank_of_id(st, ids[k])] + pos_h[k];
+    return out;
+  };
   for (size_t li = 0; li < nlev; li++) {
     DLevel &Lv = D[li];
     AmgLevel &Out = L[li];
+    if ((int)li < n_dev_levels) {
+      // a level that was built on the device: renumbered, split and kept there (Out.oA / oP / oR)
+      hipStream_t s = ctx().stream;
+      DevLevel &V = DB.lev[li];
+      const int n = (int)Lv.cf.size();
+      const std::vector<gidx> &cst = D[li + 1].starts;
+      Out.A_own = assemble_dev(V.A, V.E, perm[li], pos[li], new_ids(V.E.remote, li, V.ring1), Lv.starts, Lv.starts, rank, Out.oA, s);
+      V.A.release();
+      lap("ordering: device A");
+      Out.A = Out.A_own.get();
+      Out.A->build_halo_plan(comm);
+      Out.has_cf = true;
+      Out.perm = perm[li];
+      Out.cf.resize((size_t)n);
+      Out.nc = 0;
+      for (int q = 0; q < n; q++) {
+        Out.cf[(size_t)q] = Lv.cf[(size_t)perm[li][(size_t)q]];
+        Out.nc += (Out.cf[(size_t)q] == C_PT);
+      }
+      lap("ordering: cf");
+      {
+        Ring rp;
+        rp.build(comm, cst, V.CE.remote);
+        Out.Pm = assemble_dev(V.P, V.CE, perm[li], pos[li + 1], new_ids(V.CE.remote, li + 1, rp), Lv.starts, cst, rank, Out.oP, s);
+        V.P.release();
+      }
+      if (!(has_tail && li + 2 == nlev)) Out.Pm->build_halo_plan(comm);
+      lap("ordering: device P");
+      {
+        Ring rr;
+        rr.build(comm, Lv.starts, V.E2.remote);
+        Out.Rm = assemble_dev(V.R, V.E2, perm[li + 1], pos[li], new_ids(V.E2.remote, li, rr), cst, Lv.starts, rank, Out.oR, s);
+        V.R.release();
+      }
+      Out.Rm->build_halo_plan(comm);
+      lap("ordering: device R");
+      continue;
+    }
     const int n = Lv.A.nrows;
     const bool ring_ok = Lv.has_cf;  // the halo ring of A was built in the coarsening loop
     std::vector<gidx> newcol_a = translate(Lv.A, li, ring_ok ? &Lv.ring : nullptr);

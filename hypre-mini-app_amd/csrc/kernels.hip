@@ -1352,11 +1352,21 @@ inline int vec_grid(int n) {
 // tile Gauss-Seidel kernel needs; *chunk_aligned says whether that held for the whole matrix.
 int choose_tile_entries(int64_t nnz, int nrows) {
   static const double wide_min = getenv("MI_HYPRE_WIDE_TILE_MIN_ROWLEN") ? atof(getenv("MI_HYPRE_WIDE_TILE_MIN_ROWLEN")) : 100.0;
+  // very short rows (the fine level's zero-guess sub-operator: 3.5 entries per row) leave a 256-row tile half empty:
+  // MI_HYPRE_WIDE_TILE_MAX_SHORT = x gives operators with at most x entries per row the 512-row tiles too (experiment)
+  static const double short_max = getenv("MI_HYPRE_WIDE_TILE_MAX_SHORT") ? atof(getenv("MI_HYPRE_WIDE_TILE_MAX_SHORT")) : 0.0;
+  // (only operators that get the x-cache format: the plain stream kernel has 2048-entry tiles only)
+  static const int xc_min = getenv("MI_HYPRE_XCACHE_MIN") ? atoi(getenv("MI_HYPRE_XCACHE_MIN")) : 3;
+  if (nrows > 0 && short_max > 0.0 && (double)nnz / (double)nrows <= short_max && (double)nnz / (double)nrows >= (double)xc_min)
+    return SPMV_TILE_WIDE;
   return (nrows > 0 && wide_min > 0.0 && (double)nnz / (double)nrows >= wide_min) ? SPMV_TILE_WIDE : SPMV_TILE;
 }
 
 std::vector<int> build_row_blocks(int nrows, const int64_t *ia, bool *chunk_aligned, int row_cap, int tile_entries) {
-  if (row_cap < SPMV_BLOCK) row_cap = SPMV_BLOCK;
+  // rows per tile: at most one per thread of the kernel that runs the tile (256, or 512 for the wide tiles) when a
+  // Gauss-Seidel kernel sweeps the operator; SpMV-only operators pass a larger cap
+  const int block_rows = tile_entries == SPMV_TILE_WIDE ? SPMV_BLOCK_WIDE : SPMV_BLOCK;
+  if (row_cap < block_rows) row_cap = block_rows;
   std::vector<int> rb;
   rb.reserve((size_t)nrows / 200 + 2);
   rb.push_back(0);
@@ -1365,7 +1375,7 @@ std::vector<int> build_row_blocks(int nrows, const int64_t *ia, bool *chunk_alig
   while (r < nrows) {
     const int64_t start = ia[r];
     int e = r;
-    if ((r & 7) == 0 && row_cap <= SPMV_BLOCK) {  // whole chunks while they fit (SpMV-only operators: any row)
+    if ((r & 7) == 0 && row_cap <= block_rows) {  // whole chunks while they fit (SpMV-only operators: any row)
       while (e < nrows && e - r < row_cap) {
         const int e2 = std::min(nrows, e + 8);
         if (ia[e2] - start > tile_entries - 1) break;

@@ -305,7 +305,7 @@ void DevCSR::upload(const HostCSR &h) {
   bool aligned = false;
   tile_entries = k::choose_tile_entries(nnz, nrows);
   std::vector<int> blocks = k::build_row_blocks(nrows, h.ia.data(), &aligned, row_cap, tile_entries);
-  if (row_cap > k::SPMV_BLOCK) aligned = false;  // such tiles are not for the tile Gauss-Seidel kernel
+  if (row_cap > (tile_entries == k::SPMV_TILE_WIDE ? k::SPMV_BLOCK_WIDE : k::SPMV_BLOCK)) aligned = false;  // such tiles are not for the tile Gauss-Seidel kernel
   nblocks = (int)blocks.size() - 1;
   rb.upload(blocks);
   rb_host = blocks;

@@ -1123,7 +1123,9 @@ template <int G>
 __global__ __launch_bounds__(BLK) void level_norms_k(int n, const long long *__restrict__ ia, const int *__restrict__ ja,
                                                      const double *__restrict__ a, const int *__restrict__ cf, int chunk,
                                                      double *__restrict__ diag, double *__restrict__ l1gs,
-                                                     double *__restrict__ l1jac) {
+                                                     double *__restrict__ l1jac, const long long *__restrict__ oia,
+                                                     const int *__restrict__ oja, const double *__restrict__ oa,
+                                                     const int *__restrict__ cf_ext) {
   const long long i = (bid() * BLK + threadIdx.x) / G;
   const int sub = threadIdx.x % G, lane = threadIdx.x & 63, gbase = lane - sub;
   const bool live = i < n;
@@ -1161,6 +1163,13 @@ __global__ __launch_bounds__(BLK) void level_norms_k(int n, const long long *__r
     }
   }
   if (!live || sub != 0) return;
+  if (oia) {  // halo block of the row (N > 1), after the diag block like the host loop
+    for (long long k = oia[i]; k < oia[i + 1]; k++) {
+      const double av = fabs(oa[k]);
+      full += av;
+      if (!cf || cf_ext[oja[k]] == mycf) l1 += 0.5 * av;
+    }
+  }
   if (l1 <= 4.0 / 3.0 * fabs(d)) l1 = fabs(d);
   if (d < 0) {
     l1 = -l1;
@@ -1439,7 +1448,7 @@ void to_solve_format(DCsr &src, DevCSR &dst, hipStream_t s) {
   bool aligned = false;
   dst.tile_entries = k::choose_tile_entries(dst.nnz, n);
   std::vector<int> blocks = k::build_row_blocks(n, hia.data(), &aligned, dst.row_cap, dst.tile_entries);
-  if (dst.row_cap > k::SPMV_BLOCK) aligned = false;  // such tiles are not for the tile Gauss-Seidel kernel
+  if (dst.row_cap > (dst.tile_entries == k::SPMV_TILE_WIDE ? k::SPMV_BLOCK_WIDE : k::SPMV_BLOCK)) aligned = false;  // such tiles are not for the tile Gauss-Seidel kernel
   std::vector<int64_t>().swap(hia);
   dst.nblocks = (int)blocks.size() - 1;
   dst.rb.upload(blocks);
@@ -1654,12 +1663,16 @@ void invert_permutation(const int *order, int n, int *pos, hipStream_t s) {
   MI_HIP(hipGetLastError());
 }
 
-void level_norms(const DCsr &A, const int *cf, int chunk, double *diag, double *l1gs, double *l1jac, hipStream_t s) {
+void level_norms(const DCsr &A, const int *cf, int chunk, double *diag, double *l1gs, double *l1jac, hipStream_t s,
+                 const DCsr *halo, const int *cf_ext) {
   const int n = A.nrows;
   if (n == 0) return;
   const int rg = row_group(A.nnz, n);
   const dim3 grid = grid_for(((long long)n * rg + BLK - 1) / BLK);
-  MI_ROW_GROUP_DISPATCH(rg, (level_norms_k<G><<<grid, BLK, 0, s>>>(n, A.ia.p, A.ja.p, A.a.p, cf, chunk, diag, l1gs, l1jac)))
+  const long long *oia = (halo && halo->nnz > 0) ? halo->ia.p : nullptr;
+  const int *oja = oia ? halo->ja.p : nullptr;
+  const double *oa = oia ? halo->a.p : nullptr;
+  MI_ROW_GROUP_DISPATCH(rg, (level_norms_k<G><<<grid, BLK, 0, s>>>(n, A.ia.p, A.ja.p, A.a.p, cf, chunk, diag, l1gs, l1jac, oia, oja, oa, cf_ext)))
   MI_HIP(hipGetLastError());
 }
 
@@ -1941,6 +1954,410 @@ void ilu_upper_jacobi(const DCsr &LU, const long long *dpos, const double *b, co
                       hipStream_t s) {
   const int n = LU.nrows;
   if (n) ilu_upper_jac_k<<<(unsigned)((n + BLK - 1) / BLK), BLK, 0, s>>>(n, LU.ia.p, LU.ja.p, LU.a.p, dpos, b, in, out);
+}
+
+// ---------------------------------------------------------------- distributed setup on the device
+// (amg_setup_dist.cpp, BoomerAMG::build_distributed_device).  A rank's piece of a level lives in an EXTENDED index
+// space [remote ids below the own range | own range | remote ids above], ascending in the global id, so that stored
+// order, discovery order and every floating-point sum are those of the single-rank kernels above, which then run
+// unchanged on the extended matrices.  What is new here are the changes of index space (monotone three-piece column
+// maps with small tables for the remote part), stacking row blocks, and the PMIS rounds restricted to the own rows.
+namespace {
+
+__device__ __forceinline__ int ext_map_col(const ExtColMap &m, int c) {
+  if (c < m.nb_old) return m.below ? m.below[c] : -1;
+  const int o = c - m.nb_old;
+  if (o < m.n_own) {
+    if (!m.keep_own) return -1;
+    return m.own_tab ? m.own_tab[o] : m.own_new0 + o;
+  }
+  return m.above ? m.above[o - m.n_own] : -1;
+}
+
+// 8 lanes per output row; FILL = false: kept entries per row, FILL = true: copy them (stored order kept)
+template <bool FILL>
+__global__ __launch_bounds__(BLK) void select_rows_k(int nout, const int *__restrict__ rows, int row0,
+                                                     const long long *__restrict__ ia, const int *__restrict__ ja,
+                                                     const double *__restrict__ a, ExtColMap m, int *__restrict__ len,
+                                                     const long long *__restrict__ bia, int *__restrict__ bj,
+                                                     double *__restrict__ ba) {
+  const long long q = (bid() * BLK + threadIdx.x) / 8;
+  const int lane = threadIdx.x % 8, gbase = (threadIdx.x & 63) - lane;
+  if (q >= nout) return;  // whole groups leave together
+  const int i = rows ? rows[q] : row0 + (int)q;
+  const long long s0 = ia[i];
+  const int n = (int)(ia[i + 1] - s0);
+  long long d0 = FILL ? bia[q] : 0;
+  int kept = 0;
+  for (int e0 = 0; e0 < n; e0 += 8) {
+    const int e = e0 + lane;
+    int c = -1;
+    if (e < n) c = ext_map_col(m, ja[s0 + e]);
+    const unsigned long long bal = __ballot(c >= 0);
+    const unsigned mine = (unsigned)((bal >> gbase) & 0xffull);
+    if (FILL && c >= 0) {
+      const long long w = d0 + __popc(mine & ((1u << lane) - 1u));
+      bj[w] = c;
+      ba[w] = a[s0 + e];
+    }
+    const int add = __popc(mine);
+    d0 += add;
+    kept += add;
+  }
+  if (!FILL && lane == 0) len[q] = kept;
+}
+
+__global__ __launch_bounds__(BLK) void shift_ia_k(long long n1, const long long *__restrict__ src, long long add,
+                                                  long long *__restrict__ dst) {
+  const long long i = bid() * BLK + threadIdx.x;
+  if (i < n1) dst[i] = src[i] + add;
+}
+
+__global__ __launch_bounds__(BLK) void hstack_len_k(int n, const long long *__restrict__ aia, const long long *__restrict__ bia,
+                                                    int *__restrict__ len) {
+  const long long i = bid() * BLK + threadIdx.x;
+  if (i < n) len[i] = (int)(aia[i + 1] - aia[i]) + (int)(bia[i + 1] - bia[i]);
+}
+__global__ __launch_bounds__(BLK) void hstack_copy_k(int n, const long long *__restrict__ aia, const int *__restrict__ aja,
+                                                     const double *__restrict__ aa, const long long *__restrict__ bia,
+                                                     const int *__restrict__ bja, const double *__restrict__ ba, int shift,
+                                                     const long long *__restrict__ cia, int *__restrict__ cj,
+                                                     double *__restrict__ ca) {
+  const long long i = (bid() * BLK + threadIdx.x) / 8;
+  const int lane = threadIdx.x % 8;
+  if (i >= n) return;
+  const long long a0 = aia[i], b0 = bia[i], c0 = cia[i];
+  const int la = (int)(aia[i + 1] - a0), lb = (int)(bia[i + 1] - b0);
+  for (int e = lane; e < la; e += 8) {
+    cj[c0 + e] = aja[a0 + e];
+    ca[c0 + e] = aa[a0 + e];
+  }
+  for (int e = lane; e < lb; e += 8) {
+    cj[c0 + la + e] = bja[b0 + e] + shift;
+    ca[c0 + la + e] = ba[b0 + e];
+  }
+}
+
+// ---- PMIS rounds on the rows [row0, row0 + n) of the extended strength graph; vectors span the extended space
+__global__ __launch_bounds__(BLK) void pmisd_count_k(int n, int row0, const long long *__restrict__ sia,
+                                                     const int *__restrict__ sja, int *__restrict__ cnt) {
+  const long long i = bid() * BLK + threadIdx.x;
+  if (i >= n) return;
+  for (long long k = sia[row0 + i]; k < sia[row0 + i + 1]; k++) atomicAdd(&cnt[sja[k]], 1);
+}
+__global__ __launch_bounds__(BLK) void pmisd_init_k(int n, int row0, long long gid0, const long long *__restrict__ sia,
+                                                    const int *__restrict__ incoming, int seed0,
+                                                    double *__restrict__ measure, int *__restrict__ cf,
+                                                    int *__restrict__ undecided) {
+  const long long i = bid() * BLK + threadIdx.x;
+  if (i >= n) return;
+  const long long x = row0 + i;
+  // element gid0 + i of the ONE global Park-Miller stream (see pmis_init_k)
+  unsigned long long base = 16807ULL, acc = (unsigned long long)seed0, e = (unsigned long long)(gid0 + i) + 1ULL;
+  while (e) {
+    if (e & 1ULL) acc = mulmod31(acc, base);
+    base = mulmod31(base, base);
+    e >>= 1;
+  }
+  const double m = (double)incoming[x] + (double)(int)acc / 2147483647;
+  int c = 0;
+  if (sia[x + 1] == sia[x])
+    c = SF_PT;
+  else if (m < 1.0)
+    c = F_PT;
+  cf[x] = c;
+  measure[x] = c ? 0.0 : m;
+  if (c == 0) atomicAdd(undecided, 1);
+}
+__global__ __launch_bounds__(BLK) void pmisd_compare_k(int n, int row0, const long long *__restrict__ sia,
+                                                       const int *__restrict__ sja, const int *__restrict__ cf,
+                                                       const double *__restrict__ measure,
+                                                       signed char *__restrict__ tmp) {
+  const long long i = bid() * BLK + threadIdx.x;
+  if (i >= n) return;
+  const long long x = row0 + i;
+  if (cf[x] != 0) return;
+  const double mi = measure[x];
+  bool lose = false;
+  for (long long k = sia[x]; k < sia[x + 1]; k++) {
+    const int j = sja[k];
+    if (cf[j] != 0) continue;
+    const double mj = measure[j];
+    if (mi > mj)
+      tmp[j] = 0;
+    else if (mj > mi)
+      lose = true;
+  }
+  if (lose) tmp[x] = 0;
+}
+__global__ __launch_bounds__(BLK) void pmisd_select_k(int n, int row0, int *__restrict__ cf,
+                                                      const signed char *__restrict__ tmp) {
+  const long long i = bid() * BLK + threadIdx.x;
+  if (i < n && cf[row0 + i] == 0 && tmp[row0 + i]) cf[row0 + i] = C_PT;
+}
+__global__ __launch_bounds__(BLK) void pmisd_fpoints_k(int n, int row0, const long long *__restrict__ sia,
+                                                       const int *__restrict__ sja, int *__restrict__ cf,
+                                                       int *__restrict__ undecided) {
+  const long long i = bid() * BLK + threadIdx.x;
+  if (i >= n) return;
+  const long long x = row0 + i;
+  if (cf[x] != 0) return;
+  for (long long k = sia[x]; k < sia[x + 1]; k++)
+    if (cf[sja[k]] == C_PT) {
+      cf[x] = F_PT;
+      return;
+    }
+  atomicAdd(undecided, 1);
+}
+
+template <class T>
+__global__ __launch_bounds__(BLK) void gather_k(int n, const T *__restrict__ src, const int *__restrict__ idx, int shift,
+                                                T *__restrict__ dst) {
+  const long long k = bid() * BLK + threadIdx.x;
+  if (k < n) dst[k] = src[idx[k] + shift];
+}
+__global__ __launch_bounds__(BLK) void scatter_add_k(int n, int *__restrict__ dst, const int *__restrict__ idx, int shift,
+                                                     const int *__restrict__ v) {
+  const long long k = bid() * BLK + threadIdx.x;
+  if (k < n && v[k] != 0) atomicAdd(&dst[idx[k] + shift], v[k]);
+}
+__global__ __launch_bounds__(BLK) void scatter_zero_k(int n, signed char *__restrict__ dst, const int *__restrict__ idx,
+                                                      int shift, const signed char *__restrict__ v) {
+  const long long k = bid() * BLK + threadIdx.x;
+  if (k < n && v[k] == 0) dst[idx[k] + shift] = 0;
+}
+__global__ __launch_bounds__(BLK) void is_c_k(int n, const int *__restrict__ cf, int *__restrict__ flag) {
+  const long long i = bid() * BLK + threadIdx.x;
+  if (i < n) flag[i] = (cf[i] == C_PT);
+}
+__global__ __launch_bounds__(BLK) void fill_cgid_k(int n, const int *__restrict__ cf, const long long *__restrict__ rank,
+                                                   long long first, long long *__restrict__ cg) {
+  const long long i = bid() * BLK + threadIdx.x;
+  if (i < n) cg[i] = (cf[i] == C_PT) ? first + rank[i] : -1;
+}
+__global__ __launch_bounds__(BLK) void rows_outside_k(int n, const long long *__restrict__ ia, const int *__restrict__ ja,
+                                                      int c0, int c1, int *__restrict__ flag) {
+  const long long i = bid() * BLK + threadIdx.x;
+  if (i >= n) return;
+  int f = 0;
+  for (long long k = ia[i]; k < ia[i + 1] && !f; k++) f = (ja[k] < c0 || ja[k] >= c1);
+  flag[i] = f;
+}
+__global__ __launch_bounds__(BLK) void compact_fill_k(int n, const int *__restrict__ flag, const long long *__restrict__ pos,
+                                                      int *__restrict__ list) {
+  const long long i = bid() * BLK + threadIdx.x;
+  if (i < n && flag[i]) list[pos[i]] = (int)i;
+}
+__global__ __launch_bounds__(BLK) void mark_cols_k(long long nnz, const int *__restrict__ ja, unsigned char *__restrict__ used) {
+  const long long k = bid() * BLK + threadIdx.x;
+  if (k < nnz) used[ja[k]] = 1;
+}
+__global__ __launch_bounds__(BLK) void cfirst_pos_k(int n, const int *__restrict__ cf, const long long *__restrict__ crank,
+                                                    int nc, int *__restrict__ pos, int *__restrict__ perm) {
+  const long long i = bid() * BLK + threadIdx.x;
+  if (i >= n) return;
+  const int q = (cf[i] == C_PT) ? (int)crank[i] : nc + (int)(i - crank[i]);
+  pos[i] = q;
+  perm[q] = (int)i;
+}
+__global__ __launch_bounds__(BLK) void add_const_k(int n, int *__restrict__ v, int add) {
+  const long long i = bid() * BLK + threadIdx.x;
+  if (i < n) v[i] += add;
+}
+
+}  // namespace
+
+void select_rows(const DCsr &A, const int *rows, int row0, int nout, const ExtColMap &m, int new_ncols, bool sort,
+                 DCsr &B, hipStream_t s) {
+  B.release();
+  B.nrows = nout;
+  B.ncols = new_ncols;
+  B.ia.alloc((size_t)nout + 1);
+  DVec<int> len((size_t)nout);
+  const dim3 grid = grid_for(((long long)nout * 8 + BLK - 1) / BLK);
+  if (nout) select_rows_k<false><<<grid, BLK, 0, s>>>(nout, rows, row0, A.ia.p, A.ja.p, A.a.p, m, len.p, nullptr, nullptr, nullptr);
+  exclusive_scan(len.p, B.ia.p, nout, s);
+  long long total = 0;
+  MI_HIP(hipMemcpyAsync(&total, B.ia.p + nout, sizeof(long long), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+  B.nnz = total;
+  B.ja.alloc((size_t)total);
+  B.a.alloc((size_t)total);
+  if (total == 0) return;
+  if (!sort) {
+    select_rows_k<true><<<grid, BLK, 0, s>>>(nout, rows, row0, A.ia.p, A.ja.p, A.a.p, m, nullptr, B.ia.p, B.ja.p, B.a.p);
+  } else {
+    DVec<int> tj((size_t)total);
+    DVec<double> ta((size_t)total);
+    select_rows_k<true><<<grid, BLK, 0, s>>>(nout, rows, row0, A.ia.p, A.ja.p, A.a.p, m, nullptr, B.ia.p, tj.p, ta.p);
+    sort_rows(nout, total, B.ia.p, tj.p, ta.p, B.ja.p, B.a.p, s);
+    MI_HIP(hipGetLastError());
+    MI_HIP(hipStreamSynchronize(s));  // tj / ta are released on return
+  }
+  MI_HIP(hipGetLastError());
+  MI_HIP(hipStreamSynchronize(s));
+}
+
+void vconcat(const DCsr *const *parts, int nparts, DCsr &C, hipStream_t s) {
+  C.release();
+  long long rows = 0, nnz = 0;
+  int ncols = 0;
+  for (int q = 0; q < nparts; q++) {
+    rows += parts[q]->nrows;
+    nnz += parts[q]->nnz;
+    ncols = std::max(ncols, parts[q]->ncols);
+  }
+  MI_REQUIRE(rows < 2147483647LL, "vconcat: more than 2^31 rows");
+  C.nrows = (int)rows;
+  C.ncols = ncols;
+  C.nnz = nnz;
+  C.ia.alloc((size_t)rows + 1);
+  C.ja.alloc((size_t)nnz);
+  C.a.alloc((size_t)nnz);
+  long long r = 0, e = 0;
+  for (int q = 0; q < nparts; q++) {
+    const DCsr &P = *parts[q];
+    if (P.nrows) {
+      const long long n1 = (long long)P.nrows + (q == nparts - 1 ? 1 : 0);
+      shift_ia_k<<<grid_for((n1 + BLK - 1) / BLK), BLK, 0, s>>>(n1, P.ia.p, e, C.ia.p + r);
+    }
+    if (P.nnz) {
+      MI_HIP(hipMemcpyAsync(C.ja.p + e, P.ja.p, (size_t)P.nnz * sizeof(int), hipMemcpyDeviceToDevice, s));
+      MI_HIP(hipMemcpyAsync(C.a.p + e, P.a.p, (size_t)P.nnz * sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
+    r += P.nrows;
+    e += P.nnz;
+  }
+  // the closing row pointer when the last part has no rows (or there are no parts)
+  if (nparts == 0 || parts[nparts - 1]->nrows == 0)
+    MI_HIP(hipMemcpyAsync(C.ia.p + rows, &nnz, sizeof(long long), hipMemcpyHostToDevice, s));
+  MI_HIP(hipGetLastError());
+  MI_HIP(hipStreamSynchronize(s));
+}
+
+void hstack(const DCsr &A, const DCsr &B, DCsr &C, hipStream_t s) {
+  MI_REQUIRE(A.nrows == B.nrows, "hstack: row counts differ");
+  C.release();
+  const int n = A.nrows;
+  C.nrows = n;
+  C.ncols = A.ncols + B.ncols;
+  C.nnz = A.nnz + B.nnz;
+  C.ia.alloc((size_t)n + 1);
+  C.ja.alloc((size_t)C.nnz);
+  C.a.alloc((size_t)C.nnz);
+  DVec<int> len((size_t)n);
+  if (n) hstack_len_k<<<grid_for(((long long)n + BLK - 1) / BLK), BLK, 0, s>>>(n, A.ia.p, B.ia.p, len.p);
+  exclusive_scan(len.p, C.ia.p, n, s);
+  if (n && C.nnz)
+    hstack_copy_k<<<grid_for(((long long)n * 8 + BLK - 1) / BLK), BLK, 0, s>>>(n, A.ia.p, A.ja.p, A.a.p, B.ia.p, B.ja.p, B.a.p,
+                                                                                A.ncols, C.ia.p, C.ja.p, C.a.p);
+  MI_HIP(hipGetLastError());
+  MI_HIP(hipStreamSynchronize(s));
+}
+
+void pmis_dist_counts(const DCsr &S, int row0, int n, int *cnt, hipStream_t s) {
+  if (n) pmisd_count_k<<<grid_for(((long long)n + BLK - 1) / BLK), BLK, 0, s>>>(n, row0, S.ia.p, S.ja.p, cnt);
+  MI_HIP(hipGetLastError());
+}
+int pmis_dist_init(const DCsr &S, int row0, int n, long long gid0, int seed, const int *cnt, double *measure, int *cf,
+                   int *counter, hipStream_t s) {
+  MI_HIP(hipMemsetAsync(counter, 0, sizeof(int), s));
+  if (n)
+    pmisd_init_k<<<grid_for(((long long)n + BLK - 1) / BLK), BLK, 0, s>>>(n, row0, gid0, S.ia.p, cnt, seed ? seed : 13579, measure,
+                                                                          cf, counter);
+  int undecided = 0;
+  MI_HIP(hipMemcpyAsync(&undecided, counter, sizeof(int), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+  return undecided;
+}
+void pmis_dist_compare(const DCsr &S, int row0, int n, int ne, const int *cf, const double *measure, signed char *tmp,
+                       hipStream_t s) {
+  if (ne) MI_HIP(hipMemsetAsync(tmp, 1, (size_t)ne, s));
+  if (n) pmisd_compare_k<<<grid_for(((long long)n + BLK - 1) / BLK), BLK, 0, s>>>(n, row0, S.ia.p, S.ja.p, cf, measure, tmp);
+  MI_HIP(hipGetLastError());
+}
+void pmis_dist_select(int row0, int n, int *cf, const signed char *tmp, hipStream_t s) {
+  if (n) pmisd_select_k<<<grid_for(((long long)n + BLK - 1) / BLK), BLK, 0, s>>>(n, row0, cf, tmp);
+  MI_HIP(hipGetLastError());
+}
+int pmis_dist_fpoints(const DCsr &S, int row0, int n, int *cf, int *counter, hipStream_t s) {
+  MI_HIP(hipMemsetAsync(counter, 0, sizeof(int), s));
+  if (n) pmisd_fpoints_k<<<grid_for(((long long)n + BLK - 1) / BLK), BLK, 0, s>>>(n, row0, S.ia.p, S.ja.p, cf, counter);
+  int undecided = 0;
+  MI_HIP(hipMemcpyAsync(&undecided, counter, sizeof(int), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+  return undecided;
+}
+
+void gather_elems(const void *src, const int *idx, int shift, int n, int elem_bytes, void *dst, hipStream_t s) {
+  if (n == 0) return;
+  const dim3 grid = grid_for(((long long)n + BLK - 1) / BLK);
+  if (elem_bytes == 1)
+    gather_k<signed char><<<grid, BLK, 0, s>>>(n, (const signed char *)src, idx, shift, (signed char *)dst);
+  else if (elem_bytes == 4)
+    gather_k<int><<<grid, BLK, 0, s>>>(n, (const int *)src, idx, shift, (int *)dst);
+  else if (elem_bytes == 8)
+    gather_k<long long><<<grid, BLK, 0, s>>>(n, (const long long *)src, idx, shift, (long long *)dst);
+  else
+    MI_REQUIRE(false, "gather_elems: element size");
+  MI_HIP(hipGetLastError());
+}
+void scatter_add_int(int *dst, const int *idx, int shift, const int *v, int n, hipStream_t s) {
+  if (n) scatter_add_k<<<grid_for(((long long)n + BLK - 1) / BLK), BLK, 0, s>>>(n, dst, idx, shift, v);
+  MI_HIP(hipGetLastError());
+}
+void scatter_zero_flags(signed char *dst, const int *idx, int shift, const signed char *v, int n, hipStream_t s) {
+  if (n) scatter_zero_k<<<grid_for(((long long)n + BLK - 1) / BLK), BLK, 0, s>>>(n, dst, idx, shift, v);
+  MI_HIP(hipGetLastError());
+}
+
+long long count_c_points(const int *cf, int n, DVec<long long> &rank, hipStream_t s) {
+  rank.alloc((size_t)n + 1);
+  DVec<int> flag((size_t)n);
+  if (n) is_c_k<<<grid_for(((long long)n + BLK - 1) / BLK), BLK, 0, s>>>(n, cf, flag.p);
+  exclusive_scan(flag.p, rank.p, n, s);
+  long long nc = 0;
+  MI_HIP(hipMemcpyAsync(&nc, rank.p + n, sizeof(long long), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+  return nc;
+}
+void fill_coarse_ids(const int *cf, const long long *rank, int n, long long first, long long *cg, hipStream_t s) {
+  if (n) fill_cgid_k<<<grid_for(((long long)n + BLK - 1) / BLK), BLK, 0, s>>>(n, cf, rank, first, cg);
+  MI_HIP(hipGetLastError());
+}
+void cfirst_order(const int *cf, const long long *crank, int n, int nc, int *pos, int *perm, hipStream_t s) {
+  if (n) cfirst_pos_k<<<grid_for(((long long)n + BLK - 1) / BLK), BLK, 0, s>>>(n, cf, crank, nc, pos, perm);
+  MI_HIP(hipGetLastError());
+}
+int rows_with_columns_outside(const DCsr &P, int c0, int c1, std::vector<int> &rows_host, hipStream_t s) {
+  const int n = P.nrows;
+  rows_host.clear();
+  if (n == 0) return 0;
+  DVec<int> flag((size_t)n);
+  DVec<long long> pos((size_t)n + 1);
+  rows_outside_k<<<grid_for(((long long)n + BLK - 1) / BLK), BLK, 0, s>>>(n, P.ia.p, P.ja.p, c0, c1, flag.p);
+  exclusive_scan(flag.p, pos.p, n, s);
+  long long cnt = 0;
+  MI_HIP(hipMemcpyAsync(&cnt, pos.p + n, sizeof(long long), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+  if (cnt == 0) return 0;
+  DVec<int> list((size_t)cnt);
+  compact_fill_k<<<grid_for(((long long)n + BLK - 1) / BLK), BLK, 0, s>>>(n, flag.p, pos.p, list.p);
+  rows_host.resize((size_t)cnt);
+  MI_HIP(hipMemcpyAsync(rows_host.data(), list.p, (size_t)cnt * sizeof(int), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+  return (int)cnt;
+}
+void mark_used_columns(const DCsr &A, DVec<unsigned char> &used, hipStream_t s) {
+  used.alloc((size_t)A.ncols);
+  if (A.ncols) MI_HIP(hipMemsetAsync(used.p, 0, (size_t)A.ncols, s));
+  if (A.nnz) mark_cols_k<<<grid_for((A.nnz + BLK - 1) / BLK), BLK, 0, s>>>(A.nnz, A.ja.p, used.p);
+  MI_HIP(hipGetLastError());
+  MI_HIP(hipStreamSynchronize(s));
+}
+void add_to_ints(int *v, int n, int add, hipStream_t s) {
+  if (n && add) add_const_k<<<grid_for(((long long)n + BLK - 1) / BLK), BLK, 0, s>>>(n, v, add);
+  MI_HIP(hipGetLastError());
 }
 
 }  // namespace sk

@@ -93,7 +93,10 @@ void solve_format_to_host(const DevCSR &src, HostCSR &h, hipStream_t s);
 
 // diagonal, l1 norm of the hybrid-GS chunks (option 4, C/F aware) and full l1 norm per row (level_norms in
 // amg_setup.cpp) of a single-rank operator; cf may be null
-void level_norms(const DCsr &A, const int *cf, int chunk, double *diag, double *l1gs, double *l1jac, hipStream_t s);
+// halo (optional, N > 1): the level's halo block with full-length row pointers and the C/F type of its columns --
+// its entries follow the diag block's in every sum, like hs::level_norms
+void level_norms(const DCsr &A, const int *cf, int chunk, double *diag, double *l1gs, double *l1jac, hipStream_t s,
+                 const DCsr *halo = nullptr, const int *cf_ext = nullptr);
 
 // ---- ILU(0) of a single-rank block (HYPRE_ILU type 0, fill 0), level-scheduled
 // position of the diagonal entry of every row (-1: none)
@@ -110,6 +113,52 @@ void ilu_upper_level(const DCsr &LU, const long long *dpos, const int *rows, int
 // out = b - L_strict in   /   out = D^-1 (b - U_strict in) ; in == nullptr: out = b resp. D^-1 b
 void ilu_lower_jacobi(const DCsr &LU, const long long *dpos, const double *b, const double *in, double *out, hipStream_t s);
 void ilu_upper_jacobi(const DCsr &LU, const long long *dpos, const double *b, const double *in, double *out, hipStream_t s);
+
+// ---- distributed setup on the device (amg_setup_dist.cpp: BoomerAMG::build_distributed_device)
+// Column map between two extended index spaces [remote below | own range | remote above] (ascending global ids):
+// column c of the source becomes below[c] (c < nb_old), own_tab[c - nb_old] or own_new0 + (c - nb_old) (own range,
+// n_own columns), above[c - nb_old - n_own] (the rest); a missing table, keep_own == false or a negative table value
+// drops the entry.  Tables are device arrays.
+struct ExtColMap {
+  int nb_old = 0, n_own = 0;
+  bool keep_own = true;
+  int own_new0 = 0;
+  const int *own_tab = nullptr;
+  const int *below = nullptr;
+  const int *above = nullptr;
+};
+// B = rows rows[0..nout) of A (rows == null: row0, row0 + 1, ...) with the columns mapped (entries keep their stored
+// order; sort = true re-sorts every row by the new column)
+void select_rows(const DCsr &A, const int *rows, int row0, int nout, const ExtColMap &m, int new_ncols, bool sort,
+                 DCsr &B, hipStream_t s);
+// C = the parts' rows one block after the other (same column space)
+void vconcat(const DCsr *const *parts, int nparts, DCsr &C, hipStream_t s);
+// C = [A | B]: row i = A's entries, then B's with columns shifted by A.ncols
+void hstack(const DCsr &A, const DCsr &B, DCsr &C, hipStream_t s);
+// PMIS on the rows [row0, row0 + n) of an extended strength graph S; cnt / measure / cf / tmp span S.ncols entries,
+// the caller exchanges their remote parts between the steps (hs distributed PMIS, amg_setup_dist.cpp)
+void pmis_dist_counts(const DCsr &S, int row0, int n, int *cnt, hipStream_t s);  // cnt[col] += 1 per strong entry
+int pmis_dist_init(const DCsr &S, int row0, int n, long long gid0, int seed, const int *cnt, double *measure, int *cf,
+                   int *counter, hipStream_t s);  // returns the undecided own rows
+void pmis_dist_compare(const DCsr &S, int row0, int n, int ne, const int *cf, const double *measure, signed char *tmp,
+                       hipStream_t s);  // tmp = 1 everywhere, then 0 for the losers of this round's comparisons
+void pmis_dist_select(int row0, int n, int *cf, const signed char *tmp, hipStream_t s);
+int pmis_dist_fpoints(const DCsr &S, int row0, int n, int *cf, int *counter, hipStream_t s);  // returns undecided
+// dst[k] = src[idx[k] + shift] for elements of 1, 4 or 8 bytes; dst[idx[k] + shift] += v[k]; dst[idx[k] + shift] = 0 where v[k] == 0
+void gather_elems(const void *src, const int *idx, int shift, int n, int elem_bytes, void *dst, hipStream_t s);
+void scatter_add_int(int *dst, const int *idx, int shift, const int *v, int n, hipStream_t s);
+void scatter_zero_flags(signed char *dst, const int *idx, int shift, const signed char *v, int n, hipStream_t s);
+// rank[i] = number of C points before entry i of cf[0..n) (rank[n] = their count, returned)
+long long count_c_points(const int *cf, int n, DVec<long long> &rank, hipStream_t s);
+// cg[i] = first + rank[i] for C points, -1 otherwise
+void fill_coarse_ids(const int *cf, const long long *rank, int n, long long first, long long *cg, hipStream_t s);
+// C-first order of n rows: pos[i] = new position of row i (C points first, both groups in their old order), perm = its inverse
+void cfirst_order(const int *cf, const long long *crank, int n, int nc, int *pos, int *perm, hipStream_t s);
+// rows of P with at least one column outside [c0, c1), ascending, on the host
+int rows_with_columns_outside(const DCsr &P, int c0, int c1, std::vector<int> &rows_host, hipStream_t s);
+// used[c] = 1 for every column that occurs in A
+void mark_used_columns(const DCsr &A, DVec<unsigned char> &used, hipStream_t s);
+void add_to_ints(int *v, int n, int add, hipStream_t s);
 
 }  // namespace sk
 }  // namespace mi

@@ -87,7 +87,8 @@ HYPRE_Int HYPRE_MI_SetValueDictionary(HYPRE_Int on);
  * each coefficient depends on the previous update -- the block classical Gram-Schmidt of COGMRES 2 per step),
  * "halo_exchange" (neighbour send/recv groups), "allgather" (coarsest / redundant levels); the distributed setup:
  * "setup_distributed" (count), "setup_ext_rows_max" (largest per-rank extended sub-problem, rows),
- * "setup_global_rows_gathered" (rows gathered on every rank: the redundant tail only). */
+ * "setup_global_rows_gathered" (rows gathered on every rank: the redundant tail only), "setup_device_levels" (levels
+ * of the distributed setup whose per-rank pieces were built on the device). */
 HYPRE_Int HYPRE_MI_GetCounter(const char *name, long long *value);
 /* One rank's block keeps 32-bit local row ids in the solve format; the entry offsets of its diagonal block are 64-bit
  * (the reference's 27-point operator at 512^3 -- 3.6e9 entries, /root/reference/src/laplace_3d_weak_scaling.hpp:558,600

@@ -179,6 +179,13 @@ def main():
             assert counter("setup_ext_rows_max") < N
         gathered = counter("setup_global_rows_gathered")
         assert gathered <= max(seq, 0), (gathered, seq)
+        # threshold 0 on a GPU: the large levels of the distributed setup are built on the device (extended index
+        # spaces, amg_setup_dist.cpp DevLevel) -- at least level 0, where every rank has rows
+        if (args.mode == "solve" and os.environ.get("MI_HYPRE_DEVICE_SETUP_MIN_ROWS", "") == "0"
+                and os.environ.get("MI_HYPRE_DIST_DEVICE_SETUP", "1") != "0" and smooth_o.get("interp_type", 6) in (0, 6)):
+            assert counter("setup_device_levels") >= 1, "no level of the distributed setup was built on the device"
+            if rank == 0:
+                print("distributed setup: %d level(s) built on the device" % counter("setup_device_levels"))
     elif size > 1:
         assert counter("setup_distributed") == 0
 

@@ -110,6 +110,19 @@ def test_distributed_setup_device_spgemm_shared_gpu(nproc, n, stencil, seq):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nproc,n,stencil,seq,locality", [(2, 20, 7, 0, 0), (3, 16, 27, 0, 0), (4, 18, 7, 500, 1),
+                                                           (2, 24, 7, 0, 1), (3, 14, 27, 100, 1)])
+def test_distributed_setup_device_levels_shared_gpu(nproc, n, stencil, seq, locality):
+    """The device-resident levels of the distributed setup (extended index spaces; PMIS rounds, interpolation, both
+    Galerkin products, the C-first split into diag / halo blocks all on the device, halo-sized pieces through the
+    host): the same hierarchy as the oracle's, level by level, with and without the internal locality numbering,
+    down to the level where a rank runs out of rows (the host loop continues from there)."""
+    out = _run(nproc, "solve", n, stencil, 30011 + nproc + n, seq=seq, devmin=0, locality=locality)
+    assert "dist solve ok" in out
+    assert "built on the device" in out
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("nproc,n,stencil,seq", [(2, 16, 7, -1), (3, 12, 27, 0), (4, 16, 7, 1000)])
 def test_device_solve_with_locality_numbering_shared_gpu(nproc, n, stencil, seq):
     out = _run(nproc, "solve", n, stencil, 29871 + nproc + n, seq=seq, locality=1)
