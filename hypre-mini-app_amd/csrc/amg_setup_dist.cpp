@@ -638,9 +638,11 @@ bool dev_level(BoomerAMG &amg, Comm &comm, DevLevel &Lv, std::vector<int> &cf_ho
   double tp0 = wall_time();
 
   // ---- the rows of the halo points, and with them the second ring: extended space X
-  Lv.ring1.build(comm, Lv.starts, E.remote);
-  const Ring &ring1 = Lv.ring1;
+  Ring ring1;  // over the first ring (the remote columns of my rows)
+  ring1.build(comm, Lv.starts, E.remote);
+  const std::vector<gidx> ring1_ids = E.remote;
   RowSet hrows = fetch_rows(comm, ring1, Lv.A, 0, E, s);
+  lap("device: fetch halo rows");
   ExtIndex X;
   X.s = gs, X.e = ge;
   X.remote = E.remote;
@@ -648,13 +650,16 @@ bool dev_level(BoomerAMG &amg, Comm &comm, DevLevel &Lv, std::vector<int> &cf_ho
   X.finish();
   const int ne = X.size(), nbX = X.nbelow;
   g_ext_rows_max = std::max<long long>(g_ext_rows_max, ne);
-  sk::DCsr AownX, Ae;
+  sk::DCsr Ae;
+  sk::DCsr &AownX = Lv.A;  // from here on the level's rows live in X (in place: the map is monotone and drops nothing)
   {
     DVec<int> tab;
     remote_table(E.remote, X, tab);
-    sk::select_rows(Lv.A, nullptr, 0, n, ext_map(E, X, tab), ne, false, AownX, s);
+    sk::remap_columns(Lv.A, ext_map(E, X, tab), ne, s);
+    Lv.E = X;  // (E is Lv.E)
+    lap("device: own rows on the extended columns");
     sk::DCsr below, above;
-    remote_blocks(X.remote, nbX, E.remote, hrows, ne, [&](gidx g) { return X.of(g); }, below, above, s);
+    remote_blocks(X.remote, nbX, ring1_ids, hrows, ne, [&](gidx g) { return X.of(g); }, below, above, s);
     const sk::DCsr *parts[3] = {&below, &AownX, &above};
     sk::vconcat(parts, 3, Ae, s);
   }
@@ -669,7 +674,7 @@ bool dev_level(BoomerAMG &amg, Comm &comm, DevLevel &Lv, std::vector<int> &cf_ho
 
   // ---- PMIS on the own rows, halo state exchanged between the steps (see the host loop in build_distributed)
   tp0 = wall_time();
-  Ring ring12;
+  Ring &ring12 = Lv.ring1;  // over both rings: the halo ring of the level's operator as it is kept (columns in X)
   ring12.build(comm, Lv.starts, X.remote);
   DevHalo halo(comm, ring12, nbX, n, ne, s);
   DVec<int> dcf((size_t)ne), counter(1);
@@ -802,12 +807,11 @@ bool dev_level(BoomerAMG &amg, Comm &comm, DevLevel &Lv, std::vector<int> &cf_ho
     sk::select_rows(Pe, nullptr, nbX, n, ext_map(CX, CE, tab), CE.size(), false, Lv.P, s);
     Pe.release();
     sk::DCsr below, above, P1;
-    remote_blocks(X.remote, nbX, E.remote, prow, CE.size(), [&](gidx g) { return CE.of(g); }, below, above, s);
+    remote_blocks(X.remote, nbX, ring1_ids, prow, CE.size(), [&](gidx g) { return CE.of(g); }, below, above, s);
     const sk::DCsr *parts[3] = {&below, &Lv.P, &above};
     sk::vconcat(parts, 3, P1, s);
     sk::spgemm(AownX, P1, AP, s);
   }
-  AownX.release();
   lap("device: A*P");
 
   // ---- transpose exchange: P entries whose coarse column lives elsewhere travel to its owner with the (A P) row
@@ -925,12 +929,16 @@ bool dev_level(BoomerAMG &amg, Comm &comm, DevLevel &Lv, std::vector<int> &cf_ho
     {
       DVec<int> tab;
       remote_table(CE.remote, CE2, tab);
-      sk::DCsr own, below, above;
-      sk::select_rows(AP, nullptr, 0, n, ext_map(CE, CE2, tab), CE2.size(), false, own, s);
-      AP.release();
+      sk::DCsr below, above;
+      sk::remap_columns(AP, ext_map(CE, CE2, tab), CE2.size(), s);
       remote_blocks(E2.remote, E2.nbelow, E2.remote, inc_ap, CE2.size(), [&](gidx g) { return CE2.of(g); }, below, above, s);
-      const sk::DCsr *parts[3] = {&below, &own, &above};
-      sk::vconcat(parts, 3, APe2, s);
+      const sk::DCsr *parts[3] = {&below, &AP, &above};
+      if (E2.remote.empty()) {
+        APe2 = std::move(AP);  // nobody sent rows: the product itself
+      } else {
+        sk::vconcat(parts, 3, APe2, s);
+        AP.release();
+      }
     }
     {
       sk::ExtColMap m;  // own coarse columns only, as local coarse ids
@@ -966,7 +974,8 @@ bool dev_level(BoomerAMG &amg, Comm &comm, DevLevel &Lv, std::vector<int> &cf_ho
     next_E.finish();
     DVec<int> tab;
     remote_table(CE2.remote, next_E, tab);
-    sk::select_rows(Ac, nullptr, 0, ncl, ext_map(CE2, next_E, tab), next_E.size(), false, next_A, s);
+    sk::remap_columns(Ac, ext_map(CE2, next_E, tab), next_E.size(), s);  // (the unused columns have no image: they do not occur)
+    next_A = std::move(Ac);
   }
   amg.t_phase[3] += wall_time() - tp0;
   lap("device: next operator");
@@ -990,11 +999,24 @@ std::unique_ptr<ParCSR> assemble_dev(const sk::DCsr &M, const ExtIndex &cols, co
   Q->col_starts = col_starts;
   Q->row_start = row_starts[(size_t)rank];
   Q->row_end = row_starts[(size_t)rank + 1];
-  Q->col_map_offd = newg;
+  // halo columns = the remote ids that occur (the column space may hold more: second-ring points, coarse points
+  // nobody interpolates from)
+  std::vector<unsigned char> used(newg.size(), 0);
+  {
+    DVec<unsigned char> du;
+    sk::mark_used_columns(M, du, s);
+    const size_t nrem = newg.size(), nbl = (size_t)cols.nbelow;
+    if (nbl) MI_HIP(hipMemcpyAsync(used.data(), du.p, nbl, hipMemcpyDeviceToHost, s));
+    if (nrem - nbl) MI_HIP(hipMemcpyAsync(used.data() + nbl, du.p + nbl + (size_t)ncown, nrem - nbl, hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+  }
+  for (size_t k = 0; k < newg.size(); k++)
+    if (used[k]) Q->col_map_offd.push_back(newg[k]);
   sort_unique(Q->col_map_offd);
   std::vector<int> tab(newg.size());
   for (size_t k = 0; k < newg.size(); k++)
-    tab[k] = (int)(std::lower_bound(Q->col_map_offd.begin(), Q->col_map_offd.end(), newg[k]) - Q->col_map_offd.begin());
+    tab[k] = !used[k] ? -1
+                      : (int)(std::lower_bound(Q->col_map_offd.begin(), Q->col_map_offd.end(), newg[k]) - Q->col_map_offd.begin());
   DVec<int> dtab, dperm, dpos;
   dtab.upload(tab);
   if (!row_perm.empty()) dperm.upload(row_perm);
@@ -1053,6 +1075,7 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
   // internal locality numbering of this rank's rows (BoomerAMG::use_locality_order): clusters of the diag-block
   // graph, rows with halo entries last; the halo columns follow their owners' renumbering (one exchange)
   input_order.clear();
+  const double t_begin = wall_time();
   std::vector<int> newloc;       // old local row -> new local row
   std::vector<gidx> newcol_h;    // new GLOBAL id of every halo column of A0
   // Large per-rank pieces are built on the device (DevLevel above): decided per level by the SMALLEST piece, so that
@@ -1071,7 +1094,9 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
   if (use_locality_order(A0)) {
     const int n = A0.nrows;
     std::vector<char> has_halo((size_t)n, 0);
-    for (int i = 0; i < n; i++) has_halo[(size_t)i] = A0.offd.ia[(size_t)i + 1] > A0.offd.ia[(size_t)i];
+    parallel_for(n, [&](int64_t b, int64_t e, int) {
+      for (int64_t i = b; i < e; i++) has_halo[(size_t)i] = A0.offd.ia[(size_t)i + 1] > A0.offd.ia[(size_t)i];
+    });
     if (dev_path) {
       // the clustering rounds on the device (same labels: tests/test_locality_order.py), rows with halo entries excluded
       hipStream_t s = ctx().stream;
@@ -1106,6 +1131,7 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
     // ---- the large levels, on the device
     hipStream_t s = ctx().stream;
     const double tl0 = wall_time();
+    if (sub_timing) sub_times["prologue: locality numbering, new halo ids"] += tl0 - t_begin;
     DevLevel cur;
     cur.starts = A0.row_starts;
     dev_level0(comm, A0, input_order, newloc, newcol_h, dD0, cur.E, cur.A, s);
@@ -1125,11 +1151,12 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
     D.resize((size_t)l + 1);
     for (int q = 0; q < l; q++) {
       D[(size_t)q].starts = DB.lev[(size_t)q].starts;
-      D[(size_t)q].cf = DB.cf[(size_t)q];
+      D[(size_t)q].cf = std::move(DB.cf[(size_t)q]);
       D[(size_t)q].has_cf = true;
     }
     DLevel &H = D[(size_t)l];
     H.starts = cur.starts;
+    const double th0 = wall_time();
     HostCSR h;
     cur.A.download(h, s);
     cur.A.release();
@@ -1142,6 +1169,7 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
       for (int64_t k = b; k < e; k++) H.A.gj[(size_t)k] = Ec.global(h.ja[(size_t)k]);
     });
     if (H.A.ia.empty()) H.A.ia.assign(1, 0);
+    if (sub_timing) sub_times["device: hand-over of the first host level"] += wall_time() - th0;
   }
   dD0.release();
   const int n_dev_levels = l;
@@ -1859,13 +1887,32 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
     if (!Lv.has_cf) continue;
     const int n = (int)Lv.cf.size();  // (the operator of a device-built level is not in Lv.A)
     pos[li].resize((size_t)n), perm[li].resize((size_t)n);
-    int q = 0;
-    for (int i = 0; i < n; i++)
-      if (Lv.cf[(size_t)i] == C_PT) pos[li][(size_t)i] = q++;
-    for (int i = 0; i < n; i++)
-      if (Lv.cf[(size_t)i] != C_PT) pos[li][(size_t)i] = q++;
-    for (int i = 0; i < n; i++) perm[li][(size_t)pos[li][(size_t)i]] = i;
+    // C points first, both groups in their old order: per-block counts, then every block places its own rows
+    const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (int64_t)n / 65536 + 1));
+    const int64_t per = ((int64_t)n + nblk - 1) / nblk;
+    std::vector<int64_t> cnt_c((size_t)nblk + 1, 0);
+    parallel_for(nblk, [&](int64_t b, int64_t e, int) {
+      for (int64_t t = b; t < e; t++) {
+        int64_t c = 0;
+        for (int64_t i = t * per; i < std::min<int64_t>(n, (t + 1) * per); i++) c += (Lv.cf[(size_t)i] == C_PT);
+        cnt_c[(size_t)t + 1] = c;
+      }
+    });
+    for (int t = 0; t < nblk; t++) cnt_c[(size_t)t + 1] += cnt_c[(size_t)t];
+    const int64_t nc_all = cnt_c[(size_t)nblk];
+    std::vector<int> &ps = pos[li], &pm = perm[li];
+    parallel_for(nblk, [&](int64_t b, int64_t e, int) {
+      for (int64_t t = b; t < e; t++) {
+        int64_t qc = cnt_c[(size_t)t], qf = nc_all + (t * per - cnt_c[(size_t)t]);
+        for (int64_t i = t * per; i < std::min<int64_t>(n, (t + 1) * per); i++) {
+          const int64_t q = (Lv.cf[(size_t)i] == C_PT) ? qc++ : qf++;
+          ps[(size_t)i] = (int)q;
+          pm[(size_t)q] = (int)i;
+        }
+      }
+    });
   }
+  lap("ordering: C-first positions");
   // new global ids of the columns of M (ids of level `lev`)
   auto translate = [&](const GlobCSR &M, size_t lev, const Ring *known_ring) {
     std::vector<gidx> out(M.gj);
@@ -1924,10 +1971,17 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
       Out.has_cf = true;
       Out.perm = perm[li];
       Out.cf.resize((size_t)n);
-      Out.nc = 0;
-      for (int q = 0; q < n; q++) {
-        Out.cf[(size_t)q] = Lv.cf[(size_t)perm[li][(size_t)q]];
-        Out.nc += (Out.cf[(size_t)q] == C_PT);
+      {
+        std::atomic<long long> ncs{0};
+        parallel_for(n, [&](int64_t b, int64_t e, int) {
+          long long c = 0;
+          for (int64_t q = b; q < e; q++) {
+            Out.cf[(size_t)q] = Lv.cf[(size_t)perm[li][(size_t)q]];
+            c += (Out.cf[(size_t)q] == C_PT);
+          }
+          ncs += c;
+        });
+        Out.nc = (int)ncs.load();
       }
       lap("ordering: cf");
       {

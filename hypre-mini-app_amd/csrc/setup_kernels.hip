@@ -2160,6 +2160,13 @@ __global__ __launch_bounds__(BLK) void cfirst_pos_k(int n, const int *__restrict
   pos[i] = q;
   perm[q] = (int)i;
 }
+__global__ __launch_bounds__(BLK) void remap_cols_k(long long nnz, int *__restrict__ ja, ExtColMap m, int *__restrict__ bad) {
+  const long long k = bid() * BLK + threadIdx.x;
+  if (k >= nnz) return;
+  const int c = ext_map_col(m, ja[k]);
+  if (c < 0) *bad = 1;
+  ja[k] = c;
+}
 __global__ __launch_bounds__(BLK) void add_const_k(int n, int *__restrict__ v, int add) {
   const long long i = bid() * BLK + threadIdx.x;
   if (i < n) v[i] += add;
@@ -2196,6 +2203,17 @@ void select_rows(const DCsr &A, const int *rows, int row0, int nout, const ExtCo
   }
   MI_HIP(hipGetLastError());
   MI_HIP(hipStreamSynchronize(s));
+}
+
+void remap_columns(DCsr &A, const ExtColMap &m, int new_ncols, hipStream_t s) {
+  DVec<int> bad(1);
+  MI_HIP(hipMemsetAsync(bad.p, 0, sizeof(int), s));
+  if (A.nnz) remap_cols_k<<<grid_for((A.nnz + BLK - 1) / BLK), BLK, 0, s>>>(A.nnz, A.ja.p, m, bad.p);
+  int hbad = 0;
+  MI_HIP(hipMemcpyAsync(&hbad, bad.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+  MI_REQUIRE(hbad == 0, "remap_columns: a column has no image in the new index space");
+  A.ncols = new_ncols;
 }
 
 void vconcat(const DCsr *const *parts, int nparts, DCsr &C, hipStream_t s) {

@@ -131,6 +131,8 @@ struct ExtColMap {
 // order; sort = true re-sorts every row by the new column)
 void select_rows(const DCsr &A, const int *rows, int row0, int nout, const ExtColMap &m, int new_ncols, bool sort,
                  DCsr &B, hipStream_t s);
+// the same change of column space in place, for maps that drop nothing and keep the order (checked)
+void remap_columns(DCsr &A, const ExtColMap &m, int new_ncols, hipStream_t s);
 // C = the parts' rows one block after the other (same column space)
 void vconcat(const DCsr *const *parts, int nparts, DCsr &C, hipStream_t s);
 // C = [A | B]: row i = A's entries, then B's with columns shifted by A.ncols

@@ -33,6 +33,7 @@ def local_rows_global(amg, level, which_cols_global_n, rank, diag=0, offd=1, col
     if oshape[1] > 0 and len(oa):
         assert np.all(np.diff(cm) > 0)
         assert np.all((cm < col_start) | (cm >= col_start + shape[1]))  # halo columns are off-rank
+        assert len(np.unique(oja)) == len(cm), "a halo column that no entry uses"  # (it would be exchanged for nothing)
         O = sp.csr_matrix((oa, cm[oja], oia), shape=(n, which_cols_global_n))
         return (D + O).tocsr(), row_start
     return D, row_start
