@@ -370,11 +370,33 @@ struct IpcExchangeComm : Comm {
     const char *tm = getenv("MI_HYPRE_IPC_TIMEOUT_MS");
     spin_limit = (unsigned long long)(tm ? atoll(tm) : 20000) * 100000ull;  // wall_clock64 ticks at 100 MHz
     const size_t total = ar_offset() + ar_bytes();
-    MI_HIP(hipMalloc((void **)&arena, total));
+    // Fine-grained device memory: flags and payload are written by OTHER devices while this one's kernels poll them
+    // (system-scope atomics; coarse-grained memory may keep stale lines in this device's L2 until a kernel boundary).
+    // Where such an allocation cannot be had or exported -- the ranks then have to share one device, which is the
+    // only configuration this image's test box offers -- ordinary device memory is used (MI_HYPRE_IPC_FINEGRAINED=0
+    // forces that).
+    hipIpcMemHandle_t mine;
+    const bool want_fine = !(getenv("MI_HYPRE_IPC_FINEGRAINED") && atoi(getenv("MI_HYPRE_IPC_FINEGRAINED")) == 0);
+    bool fine = false;
+    if (want_fine && hipExtMallocWithFlags((void **)&arena, total, hipDeviceMallocFinegrained) == hipSuccess) {
+      if (hipIpcGetMemHandle(&mine, arena) == hipSuccess) {
+        fine = true;
+      } else {
+        (void)hipGetLastError();
+        (void)hipFree(arena);
+        arena = nullptr;
+      }
+    } else {
+      (void)hipGetLastError();
+      arena = nullptr;
+    }
+    if (!fine) {
+      MI_HIP(hipMalloc((void **)&arena, total));
+      MI_HIP(hipIpcGetMemHandle(&mine, arena));
+    }
+    label += fine ? " (fine-grained mailboxes)" : " (coarse-grained mailboxes)";
     MI_HIP(hipMemset(arena, 0, total));
     MI_HIP(hipDeviceSynchronize());
-    hipIpcMemHandle_t mine;
-    MI_HIP(hipIpcGetMemHandle(&mine, arena));
     std::vector<hipIpcMemHandle_t> all((size_t)size);
     inner->allgather_host(&mine, all.data(), sizeof(hipIpcMemHandle_t));
     peer_arena.assign((size_t)size, nullptr);

@@ -82,6 +82,8 @@ def main():
         nm = mi.C.create_string_buffer(128)
         mi.call("HYPRE_MI_CommName", nm, 128)
         assert size == 1 or nm.value.decode().startswith("ipc-peer-store"), nm.value
+        if rank == 0:
+            print("transport:", nm.value.decode())
     n, st = args.grid, args.stencil
     N = n ** 3
     starts = [mi.row_partition(N, size, r)[0] for r in range(size)] + [N]
