@@ -18,8 +18,13 @@
 //   Galerkin        A*P with the P rows of the halo columns fetched from their owners; P^T by an exchange of the
 //                   entries whose coarse column lives elsewhere, sent together with the (A*P) row they multiply:
 //                   the owner of a coarse row evaluates R*(A*P) itself, in the single-rank order (bit-identical)
+//   non-Galerkin    (optional) drop-and-lump on the owner's rows of R A P, with the row maxima of the halo columns
+//                   fetched from their owners
 //   ordering        C-first renumbering per rank; halo / transfer-operator columns are translated by asking
 //                   the owners for the new positions
+//
+// Levels whose per-rank pieces are large are built on the device (DevLevel below: the same steps on extended index
+// spaces, halo-sized pieces through the host); the host loop takes over at the first small level.
 //
 // Below the redundancy threshold (HYPRE_BoomerAMGSetSeqThreshold) the level is gathered and every rank builds
 // the small remaining hierarchy for itself, as before.  Ruge-Stueben coarsening and aggressive coarsening are
@@ -348,6 +353,68 @@ void spgemm_auto(const HostCSR &A, const HostCSR &B, HostCSR &C, long long devic
 }
 
 
+// Non-Galerkin sparsification of a distributed operator (hs::sparsify_non_galerkin on this rank's rows): the row maxima
+// m_j of the remote columns come from their owners; everything else is row-local, in stored order.
+void sparsify_non_galerkin_dist(Comm &comm, GlobCSR &A, const std::vector<gidx> &starts, double tol) {
+  const int n = A.nrows;
+  const gidx s = starts[(size_t)comm.rank], e = starts[(size_t)comm.rank + 1];
+  std::vector<double> m((size_t)n, 0.0);
+  parallel_for(n, [&](int64_t b, int64_t en, int) {
+    for (int64_t i = b; i < en; i++) {
+      double mx = 0.0;
+      for (int64_t k = A.ia[(size_t)i]; k < A.ia[(size_t)i + 1]; k++)
+        if (A.gj[(size_t)k] != s + i && std::fabs(A.a[(size_t)k]) > mx) mx = std::fabs(A.a[(size_t)k]);
+      m[(size_t)i] = mx;
+    }
+  });
+  Ring ring;
+  {
+    std::vector<gidx> need;
+    append_outside(A.gj, s, e, need);
+    sort_unique(need);
+    ring.build(comm, starts, std::move(need));
+  }
+  const std::vector<double> m_h = ring.forward(comm, m);
+  auto keeps = [&](int64_t i, int64_t k) {
+    const gidx j = A.gj[(size_t)k];
+    const double mj = (j >= s && j < e) ? m[(size_t)(j - s)] : m_h[(size_t)ring.slot_of(j)];
+    const double lim = tol * std::min(m[(size_t)i], mj);
+    return j == s + i || !(std::fabs(A.a[(size_t)k]) < lim);
+  };
+  GlobCSR B;
+  B.nrows = n;
+  B.ia.assign((size_t)n + 1, 0);
+  parallel_for(n, [&](int64_t b, int64_t en, int) {
+    for (int64_t i = b; i < en; i++) {
+      int64_t c = 0;
+      for (int64_t k = A.ia[(size_t)i]; k < A.ia[(size_t)i + 1]; k++) c += keeps(i, k) ? 1 : 0;
+      B.ia[(size_t)i + 1] = c;
+    }
+  });
+  for (int i = 0; i < n; i++) B.ia[(size_t)i + 1] += B.ia[(size_t)i];
+  B.gj.resize((size_t)B.nnz());
+  B.a.resize((size_t)B.nnz());
+  parallel_for(n, [&](int64_t b, int64_t en, int) {
+    for (int64_t i = b; i < en; i++) {
+      int64_t w = B.ia[(size_t)i], dpos = -1;
+      double lump = 0.0;
+      bool first = true;
+      for (int64_t k = A.ia[(size_t)i]; k < A.ia[(size_t)i + 1]; k++) {
+        if (keeps(i, k)) {
+          if (A.gj[(size_t)k] == s + i) dpos = w;
+          B.gj[(size_t)w] = A.gj[(size_t)k];
+          B.a[(size_t)w++] = A.a[(size_t)k];
+        } else {
+          lump = first ? A.a[(size_t)k] : lump + A.a[(size_t)k];
+          first = false;
+        }
+      }
+      if (!first && dpos >= 0) B.a[(size_t)dpos] = B.a[(size_t)dpos] + lump;
+    }
+  });
+  A = std::move(B);
+}
+
 // ============================================================================================================
 // Device-resident levels (round 3).  The levels of the distributed hierarchy whose per-rank pieces are large are
 // built without host copies of the operators: a rank keeps its rows of A, P and R on the device in EXTENDED index
@@ -618,7 +685,7 @@ void dev_level0(Comm &comm, ParCSR &A0, const std::vector<int> &input_order, con
 
 // One level on the device.  In: Lv.starts, Lv.E, Lv.A.  Out: the splitting, Lv.P, Lv.R (+ their column spaces), and the
 // next level's partition / column space / operator.  Returns false when the coarsening stops here (nothing is built).
-bool dev_level(BoomerAMG &amg, Comm &comm, DevLevel &Lv, std::vector<int> &cf_host, std::vector<gidx> &next_starts,
+bool dev_level(BoomerAMG &amg, Comm &comm, int level, DevLevel &Lv, std::vector<int> &cf_host, std::vector<gidx> &next_starts,
                ExtIndex &next_E, sk::DCsr &next_A, std::map<std::string, double> *sub_times) {
   const AmgParams &p = amg.p;
   hipStream_t s = ctx().stream;
@@ -956,6 +1023,18 @@ bool dev_level(BoomerAMG &amg, Comm &comm, DevLevel &Lv, std::vector<int> &cf_ho
     sk::spgemm(Lv.R, APe2, Ac, s);
   }
   lap("device: R*(A*P)");
+  if (p.non_galerkin_tol_for(level) > 0.0) {
+    // non-Galerkin coarse operator: the row maxima of the remote columns come from their owners
+    Ring rc;
+    rc.build(comm, next_starts, CE2.remote);
+    DevHalo hc(comm, rc, CE2.nbelow, ncl, CE2.size(), s);
+    DVec<double> m((size_t)CE2.size());
+    MI_HIP(hipMemsetAsync(m.p, 0, (size_t)CE2.size() * sizeof(double), s));
+    sk::non_galerkin_row_maxima(Ac, CE2.nbelow, m.p, s);
+    hc.forward(m.p);
+    sk::sparsify_non_galerkin(Ac, p.non_galerkin_tol_for(level), s, CE2.nbelow, m.p);
+    lap("device: non-Galerkin sparsification");
+  }
 
   // ---- the next level's column space: the remote coarse ids that occur
   next_E.s = cs, next_E.e = cs + nc_loc;
@@ -1059,9 +1138,9 @@ void dist_setup_counters_reset() { g_ext_rows_max = g_global_rows_gathered = g_d
 
 bool BoomerAMG::can_build_distributed() const {
   static const bool forced_off = getenv("MI_HYPRE_REPLICATED_SETUP") && atoi(getenv("MI_HYPRE_REPLICATED_SETUP")) != 0;
-  // (multipass: host passes; non-Galerkin operators: the drop rule reads the row maxima of halo columns -- replicated)
-  return !forced_off && (p.coarsen_type == 8 || p.coarsen_type == 9) && p.agg_num_levels <= 0 && p.interp_type != 4 &&
-         !p.non_galerkin();
+  // (multipass: host passes -- replicated; non-Galerkin operators are distributed since round 3: the row maxima of the
+  // halo columns are fetched from their owners)
+  return !forced_off && (p.coarsen_type == 8 || p.coarsen_type == 9) && p.agg_num_levels <= 0 && p.interp_type != 4;
 }
 
 void BoomerAMG::build_distributed(ParCSR &A0) {
@@ -1141,7 +1220,7 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
       if (l > 0 && smallest_piece(cur.A.nrows) < std::max<long long>(1, device_min_rows)) break;
       std::vector<int> cf;
       DevLevel nxt;
-      if (!dev_level(*this, comm, cur, cf, nxt.starts, nxt.E, nxt.A, sub_timing ? &sub_times : nullptr)) break;
+      if (!dev_level(*this, comm, l, cur, cf, nxt.starts, nxt.E, nxt.A, sub_timing ? &sub_times : nullptr)) break;
       DB.lev.push_back(std::move(cur));
       DB.cf.push_back(std::move(cf));
       cur = std::move(nxt);
@@ -1861,6 +1940,7 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
       parallel_for((int64_t)Ace.ja.size(), [&](int64_t b, int64_t en, int) {
         for (int64_t k = b; k < en; k++) Ac.gj[(size_t)k] = CE2.global(Ace.ja[(size_t)k]);
       });
+      if (p.non_galerkin_tol_for(l) > 0.0) sparsify_non_galerkin_dist(comm, Ac, Ln.starts, p.non_galerkin_tol_for(l));
       GlobCSR &R = Lv.R;
       R.nrows = ncl;
       R.ia = Re.ia;

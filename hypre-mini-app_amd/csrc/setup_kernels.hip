@@ -943,23 +943,26 @@ __global__ __launch_bounds__(BLK) void invert_perm_k(int n, const int *__restric
 }
 
 // ---- non-Galerkin sparsification (one lane per row: a side-line of the setup, the arithmetic is the host's)
-__global__ __launch_bounds__(BLK) void ng_rowmax_k(int n, const long long *__restrict__ ia, const int *__restrict__ ja,
+// (row0: the column of row 0's diagonal entry -- 0 for a square operator, the number of remote ids below the own range
+// for a rank's rows in an extended column space; m is indexed by column)
+__global__ __launch_bounds__(BLK) void ng_rowmax_k(int n, int row0, const long long *__restrict__ ia, const int *__restrict__ ja,
                                                    const double *__restrict__ a, double *__restrict__ m) {
   const int i = blockIdx.x * BLK + threadIdx.x;
   if (i >= n) return;
   double mx = 0.0;
   for (long long k = ia[i]; k < ia[i + 1]; k++)
-    if (ja[k] != i && fabs(a[k]) > mx) mx = fabs(a[k]);
-  m[i] = mx;
+    if (ja[k] != i + row0 && fabs(a[k]) > mx) mx = fabs(a[k]);
+  m[i + row0] = mx;
 }
 template <bool FILL>
-__global__ __launch_bounds__(BLK) void ng_drop_k(int n, const long long *__restrict__ ia, const int *__restrict__ ja,
+__global__ __launch_bounds__(BLK) void ng_drop_k(int n, int row0, const long long *__restrict__ ia, const int *__restrict__ ja,
                                                  const double *__restrict__ a, const double *__restrict__ m, double tol,
                                                  int *__restrict__ cnt, const long long *__restrict__ oia,
                                                  int *__restrict__ oja, double *__restrict__ oa) {
   const int i = blockIdx.x * BLK + threadIdx.x;
   if (i >= n) return;
-  const double mi = m[i];
+  const int di = i + row0;
+  const double mi = m[di];
   long long w = FILL ? oia[i] : 0, dpos = -1;
   int c = 0;
   double lump = 0.0;
@@ -968,9 +971,9 @@ __global__ __launch_bounds__(BLK) void ng_drop_k(int n, const long long *__restr
     const int j = ja[k];
     const double mj = m[j];
     const double lim = tol * (mi < mj ? mi : mj);
-    if (j == i || !(fabs(a[k]) < lim)) {
+    if (j == di || !(fabs(a[k]) < lim)) {
       if (FILL) {
-        if (j == i) dpos = w;
+        if (j == di) dpos = w;
         oja[w] = j;
         oa[w++] = a[k];
       }
@@ -1577,15 +1580,26 @@ void solve_format_to_host(const DevCSR &src, HostCSR &h, hipStream_t s) {
   }
 }
 
-void sparsify_non_galerkin(DCsr &A, double tol, hipStream_t s) {
+void non_galerkin_row_maxima(const DCsr &A, int row0, double *m, hipStream_t s) {
+  const int n = A.nrows;
+  if (n) ng_rowmax_k<<<(unsigned)((n + BLK - 1) / BLK), BLK, 0, s>>>(n, row0, A.ia.p, A.ja.p, A.a.p, m);
+  MI_HIP(hipGetLastError());
+}
+
+void sparsify_non_galerkin(DCsr &A, double tol, hipStream_t s, int row0, const double *maxima) {
   const int n = A.nrows;
   if (n == 0 || !(tol > 0.0)) return;
-  MI_REQUIRE(A.nrows == A.ncols, "non-Galerkin sparsification: square operators only");
+  MI_REQUIRE(maxima || A.nrows == A.ncols, "non-Galerkin sparsification: square operators only");
   const unsigned grid = (unsigned)((n + BLK - 1) / BLK);
-  DVec<double> m((size_t)n);
+  DVec<double> m_own;
+  if (!maxima) {
+    m_own.alloc((size_t)n);
+    ng_rowmax_k<<<grid, BLK, 0, s>>>(n, 0, A.ia.p, A.ja.p, A.a.p, m_own.p);
+    row0 = 0;
+  }
+  const double *mp = maxima ? maxima : m_own.p;
   DVec<int> cnt((size_t)n);
-  ng_rowmax_k<<<grid, BLK, 0, s>>>(n, A.ia.p, A.ja.p, A.a.p, m.p);
-  ng_drop_k<false><<<grid, BLK, 0, s>>>(n, A.ia.p, A.ja.p, A.a.p, m.p, tol, cnt.p, nullptr, nullptr, nullptr);
+  ng_drop_k<false><<<grid, BLK, 0, s>>>(n, row0, A.ia.p, A.ja.p, A.a.p, mp, tol, cnt.p, nullptr, nullptr, nullptr);
   DCsr B;
   B.nrows = n;
   B.ncols = A.ncols;
@@ -1597,7 +1611,7 @@ void sparsify_non_galerkin(DCsr &A, double tol, hipStream_t s) {
   B.nnz = total;
   B.ja.alloc((size_t)total);
   B.a.alloc((size_t)total);
-  ng_drop_k<true><<<grid, BLK, 0, s>>>(n, A.ia.p, A.ja.p, A.a.p, m.p, tol, nullptr, B.ia.p, B.ja.p, B.a.p);
+  ng_drop_k<true><<<grid, BLK, 0, s>>>(n, row0, A.ia.p, A.ja.p, A.a.p, mp, tol, nullptr, B.ia.p, B.ja.p, B.a.p);
   MI_HIP(hipGetLastError());
   MI_HIP(hipStreamSynchronize(s));
   A = std::move(B);

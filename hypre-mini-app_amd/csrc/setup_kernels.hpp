@@ -52,7 +52,11 @@ void spgemm(const DCsr &A, const DCsr &B, DCsr &C, hipStream_t s);
 // Non-Galerkin sparsification of a square operator (amg_setup.cpp sparsify_non_galerkin, the oracle's function of the
 // same name): with m_i = max_{j != i} |a_ij|, off-diagonal entries with |a_ij| < tol * min(m_i, m_j) are dropped and
 // added to the row's diagonal in stored order.  In place (A is replaced).
-void sparsify_non_galerkin(DCsr &A, double tol, hipStream_t s);
+// N > 1 (a rank's rows in an extended column space, diagonal of row i in column i + row0): `maxima` holds m for EVERY
+// column -- the own rows' from non_galerkin_row_maxima, the remote ones fetched from their owners by the caller.
+void sparsify_non_galerkin(DCsr &A, double tol, hipStream_t s, int row0 = 0, const double *maxima = nullptr);
+// m[row0 + i] = max_{j != row0 + i} |a_ij| for the rows of A
+void non_galerkin_row_maxima(const DCsr &A, int row0, double *m, hipStream_t s);
 
 // T = A^T with ascending columns in every row (entries of one output row keep
 // the order of A's rows)

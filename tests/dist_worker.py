@@ -57,6 +57,7 @@ def main():
                     help="1: force the per-rank internal locality numbering (MI_HYPRE_LOCALITY_ORDER=1); the oracle then "
                          "works on the globally permuted system")
     ap.add_argument("--relax", type=int, default=0, help="relax_type of the down / up sweeps (0 = library default)")
+    ap.add_argument("--ng", type=float, default=0.0, help="non_galerkin_tol (0 = Galerkin coarse operators)")
     ap.add_argument("--combo", type=int, default=-1,
                     help="seed of a combination of BoomerAMG choices (tests/test_gpu_amg.py::_combo) applied to both sides")
     ap.add_argument("--smooth", type=int, default=0,
@@ -96,6 +97,8 @@ def main():
     smooth_o = dict(smooth_type=5, smooth_num_levels=args.smooth) if args.smooth else {}
     if args.relax:
         smooth_o["relax_type"] = args.relax
+    if args.ng > 0.0:
+        smooth_o["non_galerkin_tol"] = args.ng
     if args.combo >= 0:
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
         from test_gpu_amg import _combo
@@ -136,7 +139,7 @@ def main():
     Ao_used, bo_used = Ao, bo
     # (the replicated setup -- everything but plain PMIS -- does not renumber on N > 1 ranks)
     by_replication = size > 1 and (smooth_o.get("coarsen_type", 8) not in (8, 9) or smooth_o.get("agg_num_levels", 0) > 0
-                                   or smooth_o.get("interp_type", 6) == 4 or smooth_o.get("non_galerkin_tol", 0.0) > 0.0
+                                   or smooth_o.get("interp_type", 6) == 4
                                    or os.environ.get("MI_HYPRE_REPLICATED_SETUP", "0") not in ("", "0"))
     if args.locality and by_replication:
         assert not amg.input_ordering()[0]
@@ -166,9 +169,9 @@ def main():
         return v.value
 
     replicated = os.environ.get("MI_HYPRE_REPLICATED_SETUP", "0") not in ("", "0")
-    # everything but plain PMIS with ext+i / classical / direct interpolation is built by the replicated setup
-    if (smooth_o.get("coarsen_type", 8) not in (8, 9) or smooth_o.get("agg_num_levels", 0) > 0 or smooth_o.get("interp_type", 6) == 4
-            or smooth_o.get("non_galerkin_tol", 0.0) > 0.0):
+    # everything but plain PMIS with ext+i / classical / direct interpolation (Galerkin or non-Galerkin coarse
+    # operators) is built by the replicated setup
+    if smooth_o.get("coarsen_type", 8) not in (8, 9) or smooth_o.get("agg_num_levels", 0) > 0 or smooth_o.get("interp_type", 6) == 4:
         replicated = True
     if size > 1 and not replicated:
         assert counter("setup_distributed") >= 1, "the distributed setup did not run"

@@ -18,7 +18,7 @@ WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
 
 
 def _run(nproc, mode, n, stencil, port, staging="host", seq=-1, devmin=None, golden="", replicated=False, locality=0,
-         smooth=0, relax=0, combo=-1, transport=""):
+         smooth=0, relax=0, combo=-1, transport="", ng=0.0):
     env = dict(os.environ)
     env["MI_HYPRE_REPLICATED_SETUP"] = "1" if replicated else "0"
     if devmin is not None:  # levels with at least this many rows are built (and sliced) on the device
@@ -42,6 +42,8 @@ def _run(nproc, mode, n, stencil, port, staging="host", seq=-1, devmin=None, gol
         cmd += ["--combo", str(combo)]
     if transport:
         cmd += ["--transport", transport]
+    if ng:
+        cmd += ["--ng", str(ng)]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-4000:]
     return p.stdout
@@ -63,6 +65,15 @@ def test_host_setup_with_locality_numbering_gloo(nproc, n, stencil, seq):
     """The per-rank internal locality numbering (clusters of the diag-block graph, rows with halo entries last) in
     the distributed setup: hierarchy equal to the oracle's on the globally permuted system, level-0 perm composed."""
     out = _run(nproc, "host", n, stencil, 29951 + nproc + n, seq=seq, locality=1)
+    assert "dist host setup ok" in out
+
+
+@pytest.mark.parametrize("nproc,n,stencil,seq,ng,locality", [(2, 14, 7, 0, 0.05, 0), (3, 12, 27, 100, 0.1, 0), (4, 10, 7, 0, 0.02, 1)])
+def test_host_setup_non_galerkin_distributed_gloo(nproc, n, stencil, seq, ng, locality):
+    """Non-Galerkin coarse operators (HYPRE_BoomerAMGSetNonGalerkinTol, /root/reference/src/HypreSystem.cpp:161-193) in the
+    DISTRIBUTED setup: the row maxima of the halo columns come from their owners, the drop-and-lump is row-local --
+    the same sparsified hierarchy as the oracle's, whatever the partition."""
+    out = _run(nproc, "host", n, stencil, 30111 + nproc + n, seq=seq, ng=ng, locality=locality)
     assert "dist host setup ok" in out
 
 
@@ -120,6 +131,15 @@ def test_distributed_setup_device_levels_shared_gpu(nproc, n, stencil, seq, loca
     out = _run(nproc, "solve", n, stencil, 30011 + nproc + n, seq=seq, devmin=0, locality=locality)
     assert "dist solve ok" in out
     assert "built on the device" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,n,stencil,seq,ng,devmin", [(2, 20, 7, 0, 0.05, 0), (3, 14, 27, 0, 0.1, 0), (4, 16, 7, 300, 0.02, None)])
+def test_distributed_setup_non_galerkin_shared_gpu(nproc, n, stencil, seq, ng, devmin):
+    """Non-Galerkin coarse operators on N > 1 ranks, device-resident levels (threshold 0) and the host loop: hierarchy
+    equal to the oracle's level by level, GMRES on it converges like the oracle's."""
+    out = _run(nproc, "solve", n, stencil, 30211 + nproc + n, seq=seq, ng=ng, devmin=devmin)
+    assert "dist solve ok" in out
 
 
 @pytest.mark.gpu
