@@ -1206,14 +1206,21 @@ void BoomerAMG::apply_cf_ordering() {
       std::vector<int> colpos(next);
       for (size_t k = 0; k < next; k++)
         colpos[k] = (int)(std::lower_bound(cm.begin(), cm.end(), newgid[k]) - cm.begin());
-      permute(A.offd, Lv.perm, next ? colpos.data() : nullptr, An->offd);
+      if (A.offd.nnz() == 0) {  // no halo block (one rank): nothing to permute -- not even the row pointers
+        An->offd.nrows = A.nrows;
+        An->offd.ia.assign((size_t)A.nrows + 1, 0);
+      } else {
+        permute(A.offd, Lv.perm, next ? colpos.data() : nullptr, An->offd);
+      }
       An->offd.ncols = (int)next;
       An->col_map_offd = cm;
       An->build_halo_plan(comm);
       Lv.A_own = std::move(An);
       Lv.A = Lv.A_own.get();
       std::vector<int> cf2(Lv.cf.size());
-      for (size_t q = 0; q < cf2.size(); q++) cf2[q] = Lv.cf[(size_t)Lv.perm[q]];
+      parallel_for((int64_t)cf2.size(), [&](int64_t b, int64_t e, int) {
+        for (int64_t q = b; q < e; q++) cf2[(size_t)q] = Lv.cf[(size_t)Lv.perm[(size_t)q]];
+      });
       Lv.cf.swap(cf2);
     }
     if (Lv.P.nrows > 0 && (!pos[l].empty() || (l + 1 < nlev && !pos[l + 1].empty()))) {
@@ -2456,6 +2463,7 @@ void BoomerAMG::setup_device() {
     tail_pcol.upload(pcol);
   }
   MI_HIP(hipDeviceSynchronize());
+  sk::release_host_scratch();
   dev_pool_trim();  // the setup's transient buffers go back to the driver: the solve allocates its Krylov basis next
   {
     const double tc0 = wall_time();

@@ -1415,6 +1415,14 @@ void launch_bins(const Bins &bins, const int *rows, const int *T, int S_hint, co
 }  // namespace
 
 
+namespace {
+std::vector<int64_t> &host_scratch_i64() {
+  static std::vector<int64_t> v;
+  return v;
+}
+}  // namespace
+void release_host_scratch() { std::vector<int64_t>().swap(host_scratch_i64()); }
+
 void to_solve_format(DCsr &src, DevCSR &dst, hipStream_t s) {
   const int n = src.nrows;
   require_int32_block(src.nrows, 0, "solve format");
@@ -1444,15 +1452,17 @@ void to_solve_format(DCsr &src, DevCSR &dst, hipStream_t s) {
       }
     }
   }
-  // greedy row-block schedule: sequential over the row pointers, on the host
-  std::vector<int64_t> hia((size_t)n + 1);
+  // greedy row-block schedule: sequential over the row pointers, on the host.  The host copy lands in a buffer that is
+  // kept between calls (a fresh gigabyte per operator costs more in page faults than the copy and the schedule
+  // together); release_host_scratch() returns it at the end of a setup.
+  std::vector<int64_t> &hia = host_scratch_i64();
+  if (hia.size() < (size_t)n + 1) hia.resize((size_t)n + 1);
   MI_HIP(hipMemcpyAsync(hia.data(), src.ia.p, ((size_t)n + 1) * sizeof(long long), hipMemcpyDeviceToHost, s));
   MI_HIP(hipStreamSynchronize(s));
   bool aligned = false;
   dst.tile_entries = k::choose_tile_entries(dst.nnz, n);
   std::vector<int> blocks = k::build_row_blocks(n, hia.data(), &aligned, dst.row_cap, dst.tile_entries);
   if (dst.row_cap > (dst.tile_entries == k::SPMV_TILE_WIDE ? k::SPMV_BLOCK_WIDE : k::SPMV_BLOCK)) aligned = false;  // such tiles are not for the tile Gauss-Seidel kernel
-  std::vector<int64_t>().swap(hia);
   dst.nblocks = (int)blocks.size() - 1;
   dst.rb.upload(blocks);
   dst.rb_host = blocks;

@@ -74,6 +74,8 @@ void extract_rows(const DCsr &A, const int *rows, int nout, const int *colpos, D
 // schedule and x cache of the SpMV (DevCSR::upload builds the same from host arrays).  src's column and
 // value arrays are MOVED into dst; only the row pointers travel to the host (for the greedy block schedule).
 void to_solve_format(DCsr &src, DevCSR &dst, hipStream_t s);
+// the host buffer to_solve_format keeps between calls goes back to the system (end of a setup)
+void release_host_scratch();
 // The part of a C-first ordered square block (C points = indices < nc) that a FIRST relaxation sweep on a
 // zero guess can touch: every row keeps the entries inside its own chunk of `chunk` rows, F rows also their C
 // columns (written by the C pass that precedes the F pass).  Everything else multiplies zeros.  Columns stay
