@@ -1726,7 +1726,15 @@ void BoomerAMG::build_natural(ParCSR &A0) {
       t_phase[1] += wall_time() - tp0;
     }
     long long nc_loc = 0;
-    for (int i = 0; i < n; i++) nc_loc += (cf[(size_t)i] == C_PT);
+    {
+      std::atomic<long long> acc{0};
+      parallel_for(n, [&](int64_t b, int64_t e, int) {
+        long long c = 0;
+        for (int64_t i = b; i < e; i++) c += (cf[(size_t)i] == C_PT);
+        acc += c;
+      });
+      nc_loc = acc.load();
+    }
     long long nc_glob = nc_loc;
     comm.allreduce_host(&nc_glob, 1, CommDType::I64, CommOp::SUM);
     if (nc_glob == 0 || nc_glob == A.global_rows() || nc_glob < p.min_coarse_size) break;
@@ -2403,7 +2411,9 @@ void BoomerAMG::setup_device() {
     }
     if (!Lv.cf.empty()) {
       std::vector<signed char> c8(Lv.cf.size());
-      for (size_t i = 0; i < c8.size(); i++) c8[i] = (signed char)Lv.cf[i];
+      parallel_for((int64_t)c8.size(), [&](int64_t b, int64_t e, int) {
+        for (int64_t i = b; i < e; i++) c8[(size_t)i] = (signed char)Lv.cf[(size_t)i];
+      });
       Lv.d_cf.upload(c8);
     }
     if (!Lv.perm.empty()) Lv.d_perm.upload(Lv.perm);
