@@ -55,10 +55,98 @@ def parse():
     ap.add_argument("--halo-transport", choices=("rccl", "ipc"), default=os.environ.get("MI_BENCH_HALO_TRANSPORT", "rccl"),
                     help="N > 1: how the halo updates travel -- rccl = ncclSend/ncclRecv groups (default), ipc = peer stores into "
                          "hipIpc-mapped mailboxes (HYPRE_MI_CommEnablePeerStoreExchange); reductions are RCCL either way")
+    ap.add_argument("--no-ipc-sideline", action="store_true",
+                    help="N > 1: skip the side-line leg that repeats the solves on the peer-store transport")
     ap.add_argument("--amg", action="append", default=[], metavar="KEY=VALUE",
                     help="boomeramg_settings override for a side-line (e.g. --amg agg_num_levels=1); the headline "
                          "configuration is the one without overrides")
     return ap.parse_args()
+
+
+def peer_store_sideline(mi, dist, torch, rank, world, one_solve, barrier, steps, head_iters, head_rel_res, head_s, ndof):
+    """The headline's solves again with neighbour exchanges and scalar all-reduces by peer stores (see the call site)."""
+    what = ("SIDE-LINE, not the headline: the same solves with halo updates and scalar all-reduces on the peer-store transport "
+            "(hipIpc-mapped fine-grained mailboxes, one launch per exchange; HYPRE_MI_CommEnablePeerStoreExchange)")
+
+    def agreed(ok):  # every rank continues, or none
+        f = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        return int(f.item()) == 1
+
+    def step(fn):
+        err = ""
+        try:
+            fn()
+        except Exception as e:  # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"[:300]
+        return err
+
+    os.environ["MI_HYPRE_IPC_TIMEOUT_MS"] = os.environ.get("MI_BENCH_IPC_PROBE_TIMEOUT_MS", "3000")
+    err = step(lambda: mi.call("HYPRE_MI_CommEnablePeerStoreExchange", mi.c_big(0)))
+    if not agreed(not err):
+        return {"what": what, "ran": False, "why": "the mailboxes could not be set up on every rank" + (": " + err if err else "")}
+    nm = C.create_string_buffer(160)
+    mi.call("HYPRE_MI_CommName", nm, 160)
+
+    def probe():
+        # patterned messages to both neighbours of a ring and back, several sizes and rounds (slot reuse), then scalar
+        # all-reduces whose rank-ordered sum every rank can predict
+        right, left = (rank + 1) % world, (rank - 1) % world
+        peers = sorted({right, left} - {rank})
+        for rnd in range(12):
+            nbytes = (8, 4096, 65536 + 24, 1 << 20)[rnd % 4]
+            sb = {q: torch.full((nbytes,), (17 * rank + 3 * q + rnd) % 251, dtype=torch.uint8, device="cuda") for q in peers}
+            rb = {q: torch.full((nbytes,), 255, dtype=torch.uint8, device="cuda") for q in peers}
+            torch.cuda.synchronize()
+            k = len(peers)
+            ip = (C.c_int * k)(*peers)
+            sp = (C.c_void_p * k)(*[sb[q].data_ptr() for q in peers])
+            rp = (C.c_void_p * k)(*[rb[q].data_ptr() for q in peers])
+            nb = (C.c_size_t * k)(*([nbytes] * k))
+            mi.call("HYPRE_MI_CommExchangeDevice", k, ip, sp, nb, k, ip, rp, nb)
+            for q in peers:
+                want = (17 * q + 3 * rank + rnd) % 251
+                got = rb[q]
+                if not bool((got == want).all().item()):
+                    raise RuntimeError(f"probe: wrong bytes from rank {q} in round {rnd} ({nbytes} bytes)")
+        for rnd in range(16):
+            cnt = 1 + rnd % 8
+            t = torch.tensor([float(rank + 1) * (rnd + 1) + 0.5 * j for j in range(cnt)], dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            mi.call("HYPRE_MI_CommAllreduceDevice", C.c_void_p(t.data_ptr()), cnt)
+            want = [sum(float(r + 1) * (rnd + 1) + 0.5 * j for r in range(world)) for j in range(cnt)]
+            if t.cpu().tolist() != want:
+                raise RuntimeError(f"probe: all-reduce {rnd} gave {t.cpu().tolist()} for {want}")
+        mi.call("HYPRE_MI_CommCheck")
+
+    err = step(probe)
+    if not agreed(not err):
+        return {"what": what, "ran": False, "transport": nm.value.decode(),
+                "why": "the probe (patterned ring exchanges + scalar all-reduces) failed on some rank" + (": " + err if err else "")}
+    state = {"iters": 0, "total": 0}
+
+    def timed():
+        one_solve()  # warm-up on the new transport
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            state["iters"] = one_solve()
+            state["total"] += state["iters"]
+        barrier()
+        state["elapsed"] = time.perf_counter() - t0
+        mi.call("HYPRE_MI_CommCheck")
+
+    err = step(timed)
+    if not agreed(not err):
+        return {"what": what, "ran": False, "transport": nm.value.decode(),
+                "why": "a solve on the peer-store transport failed on some rank" + (": " + err if err else "")}
+    t = torch.tensor([state["elapsed"]], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+    return {"what": what, "ran": True, "transport": nm.value.decode(), "ms_per_step": el / steps * 1e3,
+            "iterations_per_solve": state["iters"], "value_gdofs": ndof * state["total"] / el / 1e9, "steps": steps,
+            "same_iterations_as_headline": state["iters"] == head_iters,
+            "time_to_solution_vs_headline": (el / steps) / head_s}
 
 
 def build_convdiff3(mi, n, rank, world):
@@ -644,6 +732,15 @@ def main():
             "max_abs_error_vs_ones": float(np.abs(xs_n - 1.0).max()), "operator_complexity": amg.operator_complexity,
             "amg_levels": amg.num_levels, "setup_s": t_setup_n, "steps": n_steps,
             "time_to_solution_vs_headline": (n_elapsed / n_steps) / (elapsed / args.steps)}
+    # ---- side-line (N > 1, headline over RCCL / callbacks): the SAME solves with the halo updates and the scalar
+    # all-reduces on the peer-store transport (hipIpc mailboxes).  It runs LAST, behind a probe with a
+    # short bound on every wait and a collective go / no-go after each step, so that a transport that does not work on
+    # this machine costs a few seconds and one field of the JSON line, never the headline above.
+    if world > 1 and args.halo_transport == "rccl" and not args.no_ipc_sideline and not amg_kw:
+        side = peer_store_sideline(mi, dist, torch, rank, world, one_solve, barrier, args.steps, iters, rel_res,
+                                   elapsed / args.steps, ndof)
+        if rank == 0:
+            out["sideline_peer_store"] = side
     if rank == 0:
         if not args.no_cpu and args.cpu_n != 0 and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, chunk.value)

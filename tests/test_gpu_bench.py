@@ -58,6 +58,7 @@ def test_bench_single_gpu_contract():
 def test_bench_two_ranks_rehearsal():
     env = dict(os.environ)
     env["MI_BENCH_SHARED_GPU"] = "1"
+    env["MI_BENCH_IPC_PROBE_TIMEOUT_MS"] = "20000"  # two ranks time-slice one device here
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29791", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
@@ -68,6 +69,10 @@ def test_bench_two_ranks_rehearsal():
     assert j["n_gpus"] == 2 and j.get("rehearsal") is True and j["cpu_baseline"] is None
     assert 5 <= j["iterations_per_solve"] <= 30 and j["final_rel_residual"] <= 1e-8
     assert j["max_abs_error_vs_ones"] < 1e-5
+    # the N > 1 side-line: the same solves on the peer-store transport, behind its probe (bench.py peer_store_sideline)
+    side = j["sideline_peer_store"]
+    assert side["ran"] is True and side["same_iterations_as_headline"] is True, side
+    assert "ipc-peer-store" in side["transport"] and side["ms_per_step"] > 0
 
 
 def test_bench_two_ranks_rehearsal_peer_store_halo():
