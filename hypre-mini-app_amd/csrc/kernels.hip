@@ -40,6 +40,22 @@ __device__ __forceinline__ T nt_load(const T *p) {
   return __builtin_nontemporal_load(p);
 }
 
+// The tile kernels (spmv_stream_xc, gs_tile_k) read their matrix stream (values or value indices, 16-bit column words)
+// and their column lists exactly once, in whole lines per load instruction: non-temporal loads too, so that what stays
+// in L2 is the gathered vector, which neighbouring tiles share.  A/B at 512^3 on one box (profiles/r03_ab_stream_nt.txt):
+// stream alone -0.6 % per solve, with the lists -1 %, level-0 SpMV 2.77 -> 2.73 ms; same bits.  -DMI_STREAM_NT=0 /
+// -DMI_LIST_NT=0 build the plain loads.
+#if !defined(MI_STREAM_NT) || MI_STREAM_NT
+#define STREAM_LOAD(p) nt_load(p)
+#else
+#define STREAM_LOAD(p) (*(p))
+#endif
+#if !defined(MI_LIST_NT) || MI_LIST_NT
+#define LIST_LOAD(p) nt_load(p)
+#else
+#define LIST_LOAD(p) (*(p))
+#endif
+
 __device__ __forceinline__ int xcd_remap(int bid, int chunk) { return (bid & 7) * chunk + (bid >> 3); }
 
 // ---------------------------------------------------------------------------
@@ -198,7 +214,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_xc(int nb, int xchunk, cons
 #pragma unroll
   for (int q = 0; q < NU; q++) {
     const int k = tid + q * BLOCK;
-    uc[q] = (k < nu) ? ucols[u0 + k] : 0;
+    uc[q] = (k < nu) ? LIST_LOAD(ucols + u0 + k) : 0;
   }
   const long long base_al64 = base64 & ~1LL;
   const int base = (int)(base64 - base_al64), base_al = 0;  // tile-local: the aligned start is 0, the first entry 0 or 1
@@ -217,10 +233,10 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_xc(int nb, int xchunk, cons
     const int k = 2 * tid + it * 2 * BLOCK;
     if (k < cnt) {
       if (VAL8)
-        vi[it] = *reinterpret_cast<const uc2_t *>(vidx + base_al + k);
+        vi[it] = STREAM_LOAD(reinterpret_cast<const uc2_t *>(vidx + base_al + k));
       else
-        vv[it] = *reinterpret_cast<const d2_t *>(av + base_al + k);
-      cc[it] = *reinterpret_cast<const us2_t *>(lcol + base_al + k);
+        vv[it] = STREAM_LOAD(reinterpret_cast<const d2_t *>(av + base_al + k));
+      cc[it] = STREAM_LOAD(reinterpret_cast<const us2_t *>(lcol + base_al + k));
     }
   }
   // the entry range of the first row a thread sums travels with the other loads (operators that the tile
@@ -781,7 +797,7 @@ __global__ __launch_bounds__(BLOCK) void gs_tile_k(int blk0, int nblk, const int
 #pragma unroll
     for (int q = 0; q < NU; q++) {
       const int k = tid + q * BLOCK;
-      ucid[q] = (k < nu) ? ucols[u0 + k] : 0;
+      ucid[q] = (k < nu) ? LIST_LOAD(ucols + u0 + k) : 0;
     }
   }
   const long long base_al64 = base64 & ~1LL;
@@ -801,10 +817,10 @@ __global__ __launch_bounds__(BLOCK) void gs_tile_k(int blk0, int nblk, const int
     const int k = 2 * tid + it * 2 * BLOCK;
     if (k < cnt) {
       if (VAL8)
-        vi[it] = *reinterpret_cast<const uc2_t *>(vidx + base_al + k);
+        vi[it] = STREAM_LOAD(reinterpret_cast<const uc2_t *>(vidx + base_al + k));
       else
-        vv[it] = *reinterpret_cast<const d2_t *>(av + base_al + k);
-      cc[it] = *reinterpret_cast<const us2_t *>(lcol + base_al + k);
+        vv[it] = STREAM_LOAD(reinterpret_cast<const d2_t *>(av + base_al + k));
+      cc[it] = STREAM_LOAD(reinterpret_cast<const us2_t *>(lcol + base_al + k));
     }
   }
   // LPR lanes per row, as many as this tile's row count leaves room for (uniform in the workgroup);
