@@ -44,7 +44,8 @@ __device__ __forceinline__ T nt_load(const T *p) {
 // and their column lists exactly once, in whole lines per load instruction: non-temporal loads too, so that what stays
 // in L2 is the gathered vector, which neighbouring tiles share.  A/B at 512^3 on one box (profiles/r03_ab_stream_nt.txt):
 // stream alone -0.6 % per solve, with the lists -1 %, level-0 SpMV 2.77 -> 2.73 ms; same bits.  -DMI_STREAM_NT=0 /
-// -DMI_LIST_NT=0 build the plain loads.
+// -DMI_LIST_NT=0 build the plain loads.  (Also tried, no effect either way: non-temporal loads of the per-row vectors
+// f / d / b, non-temporal stores of the swept vector.)
 #if !defined(MI_STREAM_NT) || MI_STREAM_NT
 #define STREAM_LOAD(p) nt_load(p)
 #else
