@@ -1126,6 +1126,42 @@ __global__ __launch_bounds__(256) void mass_axpy_k(MassPtrs P, int m, const doub
   }
 }
 
+// w = c_0 p_0 (INIT) or w += c_0 p_0, then += c_1 p_1, ... in this order: the chain copy / scale / axpy / axpy ... of the
+// GMRES solution update in one pass over up to MASS_NV vectors (same operations per element in the same order)
+struct MassCoef {
+  double c[MASS_NV];
+};
+template <bool INIT>
+__global__ __launch_bounds__(256) void lin_comb_k(MassPtrs P, int m, MassCoef C, double *__restrict__ w, int n) {
+  const long long stride = (long long)gridDim.x * 512;
+  long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 2;
+  for (; i + 1 < n; i += stride) {
+    double2 wv;
+    if (INIT) {
+      const d2_t a = nt_load(reinterpret_cast<const d2_t *>(P.p[0] + i));
+      wv.x = C.c[0] * a.x;
+      wv.y = C.c[0] * a.y;
+    } else {
+      wv = *reinterpret_cast<double2 *>(w + i);
+    }
+#pragma unroll
+    for (int j = INIT ? 1 : 0; j < MASS_NV; j++)
+      if (j < m) {
+        const d2_t a = nt_load(reinterpret_cast<const d2_t *>(P.p[j] + i));
+        wv.x += C.c[j] * a.x;
+        wv.y += C.c[j] * a.y;
+      }
+    *reinterpret_cast<double2 *>(w + i) = wv;
+  }
+  if (i < n) {
+    double v = INIT ? C.c[0] * P.p[0][i] : w[i];
+#pragma unroll
+    for (int j = INIT ? 1 : 0; j < MASS_NV; j++)
+      if (j < m) v += C.c[j] * P.p[j][i];
+    w[i] = v;
+  }
+}
+
 // y += (scale * (alpha_dev ? *alpha_dev : 1)) * x
 __global__ __launch_bounds__(256) void axpy_k(const double *__restrict__ alpha_dev, double scale,
                                               const double *__restrict__ x, double *__restrict__ y, int n) {
@@ -1782,6 +1818,26 @@ void mass_axpy(const double *const *vecs, int m, const double *coef_dev, double 
     MassPtrs P;
     for (int j = 0; j < MASS_NV; j++) P.p[j] = vecs[j0 + (j < mm ? j : 0)];
     hipLaunchKernelGGL(mass_axpy_k, dim3(vec_grid(n)), dim3(256), 0, s, P, mm, coef_dev + j0, scale_, w, n);
+  }
+  prof_end(PROF_AXPY, s);
+  MI_HIP(hipGetLastError());
+}
+
+void lin_comb(const double *const *vecs, const double *coef_host, int m, bool init, double *w, int n, hipStream_t s) {
+  if (n == 0 || m == 0) return;
+  prof_begin(PROF_AXPY, s);
+  for (int j0 = 0; j0 < m; j0 += MASS_NV) {
+    const int mm = std::min(MASS_NV, m - j0);
+    MassPtrs P;
+    MassCoef C;
+    for (int j = 0; j < MASS_NV; j++) {
+      P.p[j] = vecs[j0 + (j < mm ? j : 0)];
+      C.c[j] = j < mm ? coef_host[j0 + j] : 0.0;
+    }
+    if (init && j0 == 0)
+      hipLaunchKernelGGL(lin_comb_k<true>, dim3(vec_grid(n)), dim3(256), 0, s, P, mm, C, w, n);
+    else
+      hipLaunchKernelGGL(lin_comb_k<false>, dim3(vec_grid(n)), dim3(256), 0, s, P, mm, C, w, n);
   }
   prof_end(PROF_AXPY, s);
   MI_HIP(hipGetLastError());

@@ -100,6 +100,9 @@ void axpy_dot(const double *alpha_dev, double scale, const double *xa, double *y
 // block Gram-Schmidt (COGMRES): out_dev[j] = <vecs[j], w> for j < m (local sums), and w += scale * sum_j coef_dev[j] vecs[j]
 void mass_dot(const double *const *vecs, int m, const double *w, int n, double *out_dev, hipStream_t s);
 void mass_axpy(const double *const *vecs, int m, const double *coef_dev, double scale, double *w, int n, hipStream_t s);
+// w = coef[0] vecs[0] (init) or w += coef[0] vecs[0]; then w += coef[j] vecs[j], j = 1 .. m-1 in this order (host
+// coefficients); MASS_NV vectors per pass
+void lin_comb(const double *const *vecs, const double *coef_host, int m, bool init, double *w, int n, hipStream_t s);
 void axpy(double alpha, const double *x, double *y, int n, hipStream_t s);
 void axpy_dev(const double *alpha_dev, double scale, const double *x, double *y, int n, hipStream_t s);
 void scale(double alpha, double *x, int n, hipStream_t s);

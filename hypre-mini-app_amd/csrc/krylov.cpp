@@ -316,10 +316,17 @@ int GmresSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
       // x += sum_j y_j z_j
       for (int j = i - 1; j >= 0; j--) k::axpy(y[(size_t)j], zvec(j).data(), x.all(), n, s);
     } else {
-      // w = sum_j y_j p_j ; x += M^-1 w
-      k::copy(basis(i - 1).data(), w.data(), n, s);
-      k::scale(y[(size_t)i - 1], w.data(), n, s);
-      for (int j = i - 2; j >= 0; j--) k::axpy(y[(size_t)j], basis(j).data(), w.data(), n, s);
+      // w = sum_j y_j p_j ; x += M^-1 w   (y_{i-1} p_{i-1} first, then the others in descending j, as gmres.c's
+      // copy / scale / axpy chain does -- in one or a few passes over the basis instead of i)
+      {
+        std::vector<const double *> vp((size_t)i);
+        std::vector<double> cf((size_t)i);
+        for (int j = i - 1, q = 0; j >= 0; j--, q++) {
+          vp[(size_t)q] = basis(j).data();
+          cf[(size_t)q] = y[(size_t)j];
+        }
+        k::lin_comb(vp.data(), cf.data(), i, true, w.data(), n, s);
+      }
       const double *mw = precond(w, r, false);
       k::axpy(1.0, mw, x.all(), n, s);
     }
