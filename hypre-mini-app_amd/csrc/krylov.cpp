@@ -354,11 +354,19 @@ int GmresSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
       rs[(size_t)j - 1] = -sn[(size_t)j - 1] * rs[(size_t)j];
       rs[(size_t)j] = cs[(size_t)j - 1] * rs[(size_t)j];
     }
-    if (i) k::scale(rs[(size_t)i], basis(i).data(), n, s);  // p_i += (rs_i - 1) p_i
-    for (int j = i - 1; j > 0; j--) k::axpy(rs[(size_t)j], basis(j).data(), basis(i).data(), n, s);
     if (i) {
-      k::scale(rs[0], basis(0).data(), n, s);
-      k::axpy(1.0, basis(i).data(), basis(0).data(), n, s);
+      // p_i = rs_i p_i + rs_{i-1} p_{i-1} + ... + rs_1 p_1 ; p_0 = rs_0 p_0 + p_i  (gmres.c's scale / axpy chain, the
+      // same products in the same order, in a few passes over the basis)
+      std::vector<const double *> vp;
+      std::vector<double> cf;
+      for (int j = i; j > 0; j--) {
+        vp.push_back(basis(j).data());
+        cf.push_back(rs[(size_t)j]);
+      }
+      k::lin_comb(vp.data(), cf.data(), (int)vp.size(), true, basis(i).data(), n, s);
+      const double *v0[2] = {basis(0).data(), basis(i).data()};
+      const double c0[2] = {rs[0], 1.0};
+      k::lin_comb(v0, c0, 2, true, basis(0).data(), n, s);
     }
   }
   leave_level_order(amg, x_in);
