@@ -191,7 +191,10 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_xc(int nb, int xchunk, cons
   const int blk = xcd_remap(blockIdx.x, xchunk);
   if (blk >= nb) return;
   const int tid = threadIdx.x;
-  if (VAL8 && tid < 256) slut[tid] = vlut[tid];  // visible after the first barrier below
+  // (the table entry waits in a register until the LDS writes before the first barrier: stored here, the kernel began
+  // with a load, a wait and a write before anything else was requested)
+  double lutv = 0.0;
+  if (VAL8 && tid < 256) lutv = vlut[tid];
   const int4 d0 = reinterpret_cast<const int4 *>(tdesc)[2 * blk];
   const int4 d1 = reinterpret_cast<const int4 *>(tdesc)[2 * blk + 1];
   const int r0 = d0.x, r1 = d0.y, len = d0.w, u0 = d1.x, nu = d1.y;
@@ -215,7 +218,11 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_xc(int nb, int xchunk, cons
 #pragma unroll
   for (int q = 0; q < NU; q++) {
     const int k = tid + q * BLOCK;
-    uc[q] = (k < nu) ? LIST_LOAD(ucols + u0 + k) : 0;
+    // (nothing that needs the loaded id inside the branch: written as a select, the compiler put the id's 64-bit
+    // extension there and with it a wait after every load -- up to eight SERIAL round trips per tile; check the ISA
+    // when this line changes: no s_waitcnt between the list loads)
+    uc[q] = 0;
+    if (k < nu) uc[q] = LIST_LOAD(ucols + u0 + k);
   }
   const long long base_al64 = base64 & ~1LL;
   const int base = (int)(base64 - base_al64), base_al = 0;  // tile-local: the aligned start is 0, the first entry 0 or 1
@@ -227,22 +234,31 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_xc(int nb, int xchunk, cons
   if (VAL8) vidx += base_al64;
   constexpr int NIT = TILE / (2 * BLOCK);
   d2_t vv[NIT];
-  us2_t cc[NIT];
-  uc2_t vi[NIT];
+  unsigned cw[NIT];  // two 16-bit column words, as loaded
+  unsigned vw[NIT];  // two value indices, as loaded, one register each (nothing is unpacked or packed inside the
+                     // branches: that makes the compiler wait for each load where it stands)
 #pragma unroll
   for (int it = 0; it < NIT; it++) {
     const int k = 2 * tid + it * 2 * BLOCK;
+    cw[it] = 0;
+    vw[it] = 0;
     if (k < cnt) {
       if (VAL8)
-        vi[it] = STREAM_LOAD(reinterpret_cast<const uc2_t *>(vidx + base_al + k));
+        vw[it] = STREAM_LOAD(reinterpret_cast<const unsigned short *>(vidx + base_al + k));
       else
         vv[it] = STREAM_LOAD(reinterpret_cast<const d2_t *>(av + base_al + k));
-      cc[it] = STREAM_LOAD(reinterpret_cast<const us2_t *>(lcol + base_al + k));
+      cw[it] = STREAM_LOAD(reinterpret_cast<const unsigned *>(lcol + base_al + k));
     }
   }
-  // the entry range of the first row a thread sums travels with the other loads (operators that the tile
-  // Gauss-Seidel kernel also sweeps have <= BLOCK rows per tile: one row per thread; SpMV-only operators
-  // with short rows -- P, R, the residual sub-operator -- get up to 4 x BLOCK rows to fill their tiles)
+  // the gathers: ALL of them in flight before the first LDS write, and before the loads below that depend on each other.
+  // (Written as `if (k < nu) xs[k] = x[uc[q]]`, every load sat in a branch of its own with its wait and its LDS write:
+  // up to eight serial round trips per tile.  Lanes beyond the list read x[0] -- uc is 0 there -- one cached sector.)
+  double xv[NU];
+#pragma unroll
+  for (int q = 0; q < NU; q++) xv[q] = x[uc[q]];
+  // the entry range of the first row a thread sums (operators that the tile Gauss-Seidel kernel also sweeps have
+  // <= BLOCK rows per tile: one row per thread; SpMV-only operators with short rows -- P, R, the residual
+  // sub-operator -- get up to 4 x BLOCK rows to fill their tiles)
   const int nr = r1 - r0;
   int G = 1;
   while (G < 64 && nr * G * 2 <= BLOCK) G <<= 1;
@@ -257,10 +273,11 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_xc(int nb, int xchunk, cons
     if (EPI == 0 && e.rowmap && lane == 0) ro = e.rowmap[r0 + rr];
     if (EPI == 0 && e.beta != 0.0 && lane == 0) bpre = epi_b(e, ro);
   }
+  if (VAL8 && tid < 256) slut[tid] = lutv;  // visible after the barrier below
 #pragma unroll
   for (int q = 0; q < NU; q++) {
     const int k = tid + q * BLOCK;
-    if (k < nu) xs[k] = x[uc[q]];
+    if (k < nu) xs[k] = xv[q];
   }
   __syncthreads();
 #pragma unroll
@@ -270,11 +287,11 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_xc(int nb, int xchunk, cons
       const bool ok0 = (base_al + k >= base);
       const bool ok1 = (base_al + k + 1 < end);
       if (VAL8) {
-        vv[it].x = slut[vi[it].x];
-        vv[it].y = slut[vi[it].y];
+        vv[it].x = slut[vw[it] & 0xffu];
+        vv[it].y = slut[vw[it] >> 8];
       }
-      vv[it].x = ok0 ? vv[it].x * xs[cc[it].x & XC_ID_MASK] : 0.0;
-      vv[it].y = ok1 ? vv[it].y * xs[cc[it].y & XC_ID_MASK] : 0.0;
+      vv[it].x = ok0 ? vv[it].x * xs[cw[it] & XC_ID_MASK] : 0.0;
+      vv[it].y = ok1 ? vv[it].y * xs[(cw[it] >> 16) & XC_ID_MASK] : 0.0;
     }
   }
   __syncthreads();  // every x-cache read is done: the array becomes the product buffer
@@ -755,7 +772,7 @@ __global__ __launch_bounds__(256) void gs_dense_k(int n, int chunk0, int nchunks
 // 16-bit column entries, and runs the dense 8x8 sweep of gs_dense_k.
 // ---------------------------------------------------------------------------
 template <bool VAL8, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void gs_tile_k(int blk0, int nblk, const int *__restrict__ tdesc,
+__global__ __launch_bounds__(BLOCK, 2048 / BLOCK) void gs_tile_k(int blk0, int nblk, const int *__restrict__ tdesc,
                                                         const int *__restrict__ ia, const double *__restrict__ av,
                                                         const int *__restrict__ ucols,
                                                         const unsigned short *__restrict__ lcol,
@@ -782,9 +799,11 @@ __global__ __launch_bounds__(BLOCK) void gs_tile_k(int blk0, int nblk, const int
   if ((int)blockIdx.x >= nblk) return;
   const int blk = blk0 + blockIdx.x;
   const int tid = threadIdx.x;
-  if (VAL8 && tid < 256) slut[tid] = vlut[tid];
+  double lutv = 0.0;  // stored to LDS with the x cache (see spmv_stream_xc)
+  if (VAL8 && tid < 256) lutv = vlut[tid];
   // one descriptor load, then the loads in the order of their dependent chains (see spmv_stream_xc): column
-  // list, matrix stream, per-row data; the gathers start when the column ids are back
+  // list, matrix stream, the gathers as soon as the column ids are back, then the per-row data (C/F mark -> row
+  // selected? -> divisor, right-hand side, row pointers: loads that wait for each other)
   const int4 d0 = reinterpret_cast<const int4 *>(tdesc)[2 * blk];
   const int4 d1 = reinterpret_cast<const int4 *>(tdesc)[2 * blk + 1];
   const int r0 = d0.x, r1 = d0.y, len = d0.w, u0 = d1.x, nu = d1.y;
@@ -798,7 +817,8 @@ __global__ __launch_bounds__(BLOCK) void gs_tile_k(int blk0, int nblk, const int
 #pragma unroll
     for (int q = 0; q < NU; q++) {
       const int k = tid + q * BLOCK;
-      ucid[q] = (k < nu) ? LIST_LOAD(ucols + u0 + k) : 0;
+      ucid[q] = 0;
+      if (k < nu) ucid[q] = LIST_LOAD(ucols + u0 + k);
     }
   }
   const long long base_al64 = base64 & ~1LL;
@@ -811,17 +831,31 @@ __global__ __launch_bounds__(BLOCK) void gs_tile_k(int blk0, int nblk, const int
   if (VAL8) vidx += base_al64;
   constexpr int NIT = TILE / (2 * BLOCK);
   d2_t vv[NIT];
-  us2_t cc[NIT];
-  uc2_t vi[NIT];
+  unsigned cw[NIT], vw[NIT];  // two 16-bit column words / two value indices, as loaded (see spmv_stream_xc)
 #pragma unroll
   for (int it = 0; it < NIT; it++) {
     const int k = 2 * tid + it * 2 * BLOCK;
+    cw[it] = 0;
+    vw[it] = 0;
     if (k < cnt) {
       if (VAL8)
-        vi[it] = STREAM_LOAD(reinterpret_cast<const uc2_t *>(vidx + base_al + k));
+        vw[it] = STREAM_LOAD(reinterpret_cast<const unsigned short *>(vidx + base_al + k));
       else
         vv[it] = STREAM_LOAD(reinterpret_cast<const d2_t *>(av + base_al + k));
-      cc[it] = STREAM_LOAD(reinterpret_cast<const us2_t *>(lcol + base_al + k));
+      cw[it] = STREAM_LOAD(reinterpret_cast<const unsigned *>(lcol + base_al + k));
+    }
+  }
+  // the gathers in flight together, before the first LDS write and before the per-row chain (see spmv_stream_xc); lanes
+  // beyond the list and columns from zero_from on read entry 0 and are overwritten / not stored.  With 8-byte values in
+  // registers all NU at once would cost 74 VGPRs (6 instead of 8 waves per SIMD): that variant takes them in two
+  // batches -- the first covers tiles of up to 4 * BLOCK unique columns, i.e. nearly all of them.
+  constexpr int GB = VAL8 ? NU : NU / 2;
+  double xv[GB];
+  if (!all_zero) {
+#pragma unroll
+    for (int q = 0; q < GB; q++) {
+      const int j = (ucid[q] >= zero_from) ? 0 : ucid[q];
+      xv[q] = UOLD(j);
     }
   }
   // LPR lanes per row, as many as this tile's row count leaves room for (uniform in the workgroup);
@@ -846,13 +880,23 @@ __global__ __launch_bounds__(BLOCK) void gs_tile_k(int blk0, int nblk, const int
       s1 = (int)((unsigned)ia[i + 1] - ia_off);
     }
   }
+  if (VAL8 && tid < 256) slut[tid] = lutv;
   if (!all_zero) {
 #pragma unroll
-    for (int q = 0; q < NU; q++) {
+    for (int q = 0; q < GB; q++) {
       const int k = tid + q * BLOCK;
-      if (k < nu) {
-        const int j = ucid[q];
-        buf[k] = (j >= zero_from) ? 0.0 : UOLD(j);
+      if (k < nu) buf[k] = (ucid[q] >= zero_from) ? 0.0 : xv[q];
+    }
+    if (GB < NU && nu > GB * BLOCK) {  // (uniform) the rare tile with more unique columns than the first batch holds
+#pragma unroll
+      for (int q = GB; q < NU; q++) {
+        const int j = (ucid[q] >= zero_from) ? 0 : ucid[q];
+        xv[q - GB] = UOLD(j);
+      }
+#pragma unroll
+      for (int q = GB; q < NU; q++) {
+        const int k = tid + q * BLOCK;
+        if (k < nu) buf[k] = (ucid[q] >= zero_from) ? 0.0 : xv[q - GB];
       }
     }
   }
@@ -863,10 +907,10 @@ __global__ __launch_bounds__(BLOCK) void gs_tile_k(int blk0, int nblk, const int
     if (k < cnt) {
       const bool ok0 = (base_al + k >= base);
       const bool ok1 = (base_al + k + 1 < end);
-      const unsigned c0 = cc[it].x, c1 = cc[it].y;
+      const unsigned c0 = cw[it] & 0xffffu, c1 = cw[it] >> 16;
       if (VAL8) {
-        vv[it].x = slut[vi[it].x];
-        vv[it].y = slut[vi[it].y];
+        vv[it].x = slut[vw[it] & 0xffu];
+        vv[it].y = slut[vw[it] >> 8];
       }
       // out-of-chunk: product with the snapshot value; in-chunk: the coefficient itself
       const double x0 = all_zero ? 0.0 : buf[c0 & XC_ID_MASK], x1 = all_zero ? 0.0 : buf[c1 & XC_ID_MASK];
@@ -881,8 +925,8 @@ __global__ __launch_bounds__(BLOCK) void gs_tile_k(int blk0, int nblk, const int
     if (k < cnt) {
       buf[k] = vv[it].x;
       buf[k + 1] = vv[it].y;
-      code[k] = cc[it].x;
-      code[k + 1] = cc[it].y;
+      code[k] = (unsigned short)(cw[it] & 0xffffu);
+      code[k + 1] = (unsigned short)(cw[it] >> 16);
     }
   }
   __syncthreads();
