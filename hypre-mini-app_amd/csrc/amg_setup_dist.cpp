@@ -27,8 +27,9 @@
 // spaces, halo-sized pieces through the host); the host loop takes over at the first small level.
 //
 // Below the redundancy threshold (HYPRE_BoomerAMGSetSeqThreshold) the level is gathered and every rank builds
-// the small remaining hierarchy for itself, as before.  Ruge-Stueben coarsening and aggressive coarsening are
-// sequential / two-generation algorithms on the global graph: on N > 1 they keep the replicated path.
+// the small remaining hierarchy for itself, as before.  Aggressive levels (second-generation PMIS on the C points,
+// multipass interpolation pass by pass with the halo rows of the previous pass) are distributed too (host loop).
+// Ruge-Stueben coarsening and CLJP are sequential sweeps over the global graph: on N > 1 they keep the replicated path.
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -1124,6 +1125,452 @@ std::unique_ptr<ParCSR> assemble_dev(const sk::DCsr &M, const ExtIndex &cols, co
   return Q;
 }
 
+
+// PMIS on a distributed graph (par_coarsen.c hypre_BoomerAMGCoarsenPMIS; oracle/oracle.c pmis): this rank's rows
+// [starts[rank], starts[rank+1]) with GLOBAL column ids, `strong` = per-entry flag (null: every entry counts), `ring` =
+// the plan over the remote columns, `hslot` = halo slot per entry (-1: own column).  One global random stream indexed
+// by the global row id, so the splitting does not depend on the partition.  Used on the strength graph of a level
+// and on the second-generation graph of an aggressive level.  Leaves cf (0 never; C_PT / F_PT / SF_PT) and the
+// halo copy cf_h.
+void dist_pmis(Comm &comm, const std::vector<gidx> &starts, int n, const std::vector<int64_t> &ia, const std::vector<gidx> &gj,
+               const char *strong, const Ring &ring, const std::vector<int> &hslot, std::vector<int> &cf, std::vector<int> &cf_h) {
+  const gidx s = starts[(size_t)comm.rank];
+  const int nh = (int)ring.ids.size();
+  cf.assign((size_t)n, 0);
+  // (integer counts and flags below are updated from several host threads with relaxed atomics: sums and
+  // "set to 0" stores commute, so the outcome does not depend on the schedule)
+  std::vector<int> cnt((size_t)n, 0), cnt_h((size_t)nh, 0);
+  parallel_for(n, [&](int64_t b, int64_t en, int) {
+    for (int64_t i = b; i < en; i++)
+      for (int64_t k = ia[(size_t)i]; k < ia[(size_t)i + 1]; k++) {
+        if (strong && !strong[(size_t)k]) continue;
+        int *slot = hslot[(size_t)k] < 0 ? &cnt[(size_t)(gj[(size_t)k] - s)] : &cnt_h[(size_t)hslot[(size_t)k]];
+        __atomic_fetch_add(slot, 1, __ATOMIC_RELAXED);
+      }
+  });
+  ring.reverse(comm, cnt_h, cnt, [](int &mine, int v) { mine += v; });
+  std::vector<double> measure((size_t)n, 0.0);
+  parallel_for(n, [&](int64_t b, int64_t en, int) {
+    if (b >= en) return;
+    int seed = park_miller_at(2747, s + b);  // element s + b of the stream; the following ones by the recurrence
+    for (int64_t i = b; i < en; i++) {
+      if (i > b) {
+        const int a = 16807, m = 2147483647, q = 127773, r = 2836;
+        const int lo = seed % q, hi = seed / q;
+        const int t = a * lo - r * hi;
+        seed = (t > 0) ? t : t + m;
+      }
+      measure[(size_t)i] = (double)cnt[(size_t)i] + (double)seed / 2147483647;
+    }
+  });
+  std::vector<int> graph;
+  parallel_for(n, [&](int64_t b, int64_t en, int) {
+    for (int64_t i = b; i < en; i++) {
+      bool any = false;
+      for (int64_t k = ia[(size_t)i]; k < ia[(size_t)i + 1] && !any; k++) any = !strong || strong[(size_t)k] != 0;
+      if (!any) {
+        cf[(size_t)i] = SF_PT;
+        measure[(size_t)i] = 0.0;
+      } else if (measure[(size_t)i] < 1.0) {
+        cf[(size_t)i] = F_PT;
+        measure[(size_t)i] = 0.0;
+      }
+    }
+  });
+  for (int i = 0; i < n; i++)
+    if (cf[(size_t)i] == 0) graph.push_back(i);
+  const std::vector<double> m_h = ring.forward(comm, measure);
+  cf_h = ring.forward(comm, cf);
+  std::vector<signed char> tmp((size_t)n, 0);
+  for (;;) {
+    long long left = (long long)graph.size();
+    comm.allreduce_host(&left, 1, CommDType::I64, CommOp::SUM);
+    if (left == 0) break;
+    std::vector<int> lose_h((size_t)nh, 1);  // 0: the halo point lost a comparison against one of my rows
+    const int64_t ng = (int64_t)graph.size();
+    parallel_for(ng, [&](int64_t b, int64_t en, int) {
+      for (int64_t q = b; q < en; q++) tmp[(size_t)graph[(size_t)q]] = 1;
+    });
+    parallel_for(ng, [&](int64_t b, int64_t en, int) {
+      for (int64_t q = b; q < en; q++) {
+        const int g = graph[(size_t)q];
+        const double mi_ = measure[(size_t)g];
+        bool lost = false;
+        for (int64_t k = ia[(size_t)g]; k < ia[(size_t)g + 1]; k++) {
+          if (strong && !strong[(size_t)k]) continue;
+          const int h = hslot[(size_t)k];
+          if (h < 0) {
+            const int j = (int)(gj[(size_t)k] - s);
+            if (cf[(size_t)j] != 0) continue;
+            if (mi_ > measure[(size_t)j])
+              __atomic_store_n(&tmp[(size_t)j], (signed char)0, __ATOMIC_RELAXED);
+            else if (measure[(size_t)j] > mi_)
+              lost = true;
+          } else {
+            if (cf_h[(size_t)h] != 0) continue;
+            if (mi_ > m_h[(size_t)h])
+              __atomic_store_n(&lose_h[(size_t)h], 0, __ATOMIC_RELAXED);
+            else if (m_h[(size_t)h] > mi_)
+              lost = true;
+          }
+        }
+        if (lost) __atomic_store_n(&tmp[(size_t)g], (signed char)0, __ATOMIC_RELAXED);
+      }
+    });
+    {
+      std::vector<int> keep((size_t)n, 1);
+      ring.reverse(comm, lose_h, keep, [](int &mine, int v) { mine = std::min(mine, v); });
+      parallel_for(ng, [&](int64_t b, int64_t en, int) {
+        for (int64_t q = b; q < en; q++) {
+          const int g = graph[(size_t)q];
+          if (!keep[(size_t)g]) tmp[(size_t)g] = 0;
+          if (tmp[(size_t)g] == 1) cf[(size_t)g] = C_PT;
+        }
+      });
+    }
+    cf_h = ring.forward(comm, cf);
+    parallel_for(ng, [&](int64_t b, int64_t en, int) {
+      for (int64_t q = b; q < en; q++) {
+        const int g = graph[(size_t)q];
+        if (cf[(size_t)g] != 0) continue;
+        bool dep_c = false;
+        for (int64_t k = ia[(size_t)g]; k < ia[(size_t)g + 1] && !dep_c; k++) {
+          if (strong && !strong[(size_t)k]) continue;
+          const int h = hslot[(size_t)k];
+          dep_c = h < 0 ? cf[(size_t)(gj[(size_t)k] - s)] == C_PT : cf_h[(size_t)h] == C_PT;
+        }
+        tmp[(size_t)g] = dep_c ? 2 : 3;  // 2: becomes F once the scan is over (the scan sees this round's C points only)
+      }
+    });
+    std::vector<int> next;
+    for (int g : graph) {
+      if (cf[(size_t)g] != 0) continue;
+      if (tmp[(size_t)g] == 2)
+        cf[(size_t)g] = F_PT;
+      else
+        next.push_back(g);
+    }
+    graph.swap(next);
+    cf_h = ring.forward(comm, cf);
+  }
+}
+
+
+// Second stage of aggressive coarsening on N ranks (par_strength.c hypre_BoomerAMGCreate2ndS with num_paths 1, then
+// hypre_BoomerAMGCorrectCFMarker; oracle/oracle.c second_strength / coarsen_aggressive; src/HypreSystem.cpp:215-219).
+// The C points of the first PMIS get global ids in fine order (owner of the point = owner of the id); C point i
+// depends on C point j != i iff j is in S_i or in S_k for some k in S_i.  The S rows of the halo points arrive as
+// lists of first-stage coarse ids; the graph's rows are sorted global ids, its remote columns (C points up to two
+// rings away) get a plan of their own, and the same distributed PMIS runs on it with the random stream indexed by
+// the coarse id.  A first-stage C point the second stage rejects takes the second stage's verdict.
+void dist_second_stage(Comm &comm, const std::vector<gidx> &starts, const GlobCSR &A, const std::vector<char> &strong,
+                       const Ring &ring, const std::vector<int> &hslot, std::vector<int> &cf, std::vector<int> &cf_h) {
+  const int rank = comm.rank, size = comm.size;
+  const int n = A.nrows;
+  const gidx s = starts[(size_t)rank];
+  const int nh = (int)ring.ids.size();
+  long long nc1 = 0;
+  for (int i = 0; i < n; i++) nc1 += (cf[(size_t)i] == C_PT);
+  std::vector<gidx> st1((size_t)size + 1, 0);
+  {
+    std::vector<long long> all((size_t)size, 0);
+    comm.allgather_host(&nc1, all.data(), sizeof(long long));
+    for (int r = 0; r < size; r++) st1[(size_t)r + 1] = st1[(size_t)r] + all[(size_t)r];
+  }
+  const gidx c0 = st1[(size_t)rank];
+  std::vector<gidx> cg1((size_t)n, -1);
+  std::vector<int> crow((size_t)nc1);
+  {
+    int q = 0;
+    for (int i = 0; i < n; i++)
+      if (cf[(size_t)i] == C_PT) {
+        crow[(size_t)q] = i;
+        cg1[(size_t)i] = c0 + q++;
+      }
+  }
+  const std::vector<gidx> cg1_h = ring.forward(comm, cg1);
+  auto cg_of = [&](int64_t k) {
+    const int h = hslot[(size_t)k];
+    return h < 0 ? cg1[(size_t)(A.gj[(size_t)k] - s)] : cg1_h[(size_t)h];
+  };
+  // the strong C neighbours of every halo point, as first-stage coarse ids
+  std::vector<int64_t> hoff((size_t)nh + 1, 0);
+  std::vector<gidx> hl;
+  {
+    const std::vector<std::vector<char>> rec = ring.forward_records(comm, [&](int row, std::vector<char> &buf) {
+      int cnt = 0;
+      for (int64_t k = A.ia[(size_t)row]; k < A.ia[(size_t)row + 1]; k++) cnt += (strong[(size_t)k] && cg_of(k) >= 0);
+      put1<int>(buf, cnt);
+      for (int64_t k = A.ia[(size_t)row]; k < A.ia[(size_t)row + 1]; k++)
+        if (strong[(size_t)k] && cg_of(k) >= 0) put1<gidx>(buf, cg_of(k));
+    });
+    for (size_t pi = 0; pi < rec.size(); pi++) {
+      Reader rd(rec[pi]);
+      for (int q = ring.recv_starts[pi]; q < ring.recv_starts[pi + 1]; q++) {
+        const int len = rd.get<int>();
+        hoff[(size_t)q + 1] = len;
+        const size_t o = hl.size();
+        hl.resize(o + (size_t)len);
+        rd.get(hl.data() + o, (size_t)len);
+      }
+    }
+    for (int q = 0; q < nh; q++) hoff[(size_t)q + 1] += hoff[(size_t)q];
+  }
+  // rows of the second-generation graph: sorted global coarse ids, the point itself left out
+  GlobCSR G;
+  G.nrows = (int)nc1;
+  G.ia.assign((size_t)nc1 + 1, 0);
+  std::vector<std::vector<gidx>> rows((size_t)nc1);
+  parallel_for(nc1, [&](int64_t b, int64_t en, int) {
+    for (int64_t ci = b; ci < en; ci++) {
+      const int i = crow[(size_t)ci];
+      const gidx me = c0 + ci;
+      std::vector<gidx> &row = rows[(size_t)ci];
+      for (int64_t k = A.ia[(size_t)i]; k < A.ia[(size_t)i + 1]; k++) {
+        if (!strong[(size_t)k]) continue;
+        const gidx g1 = cg_of(k);
+        if (g1 >= 0 && g1 != me) row.push_back(g1);
+        const int h = hslot[(size_t)k];
+        if (h < 0) {
+          const int j = (int)(A.gj[(size_t)k] - s);
+          for (int64_t kk = A.ia[(size_t)j]; kk < A.ia[(size_t)j + 1]; kk++) {
+            if (!strong[(size_t)kk]) continue;
+            const gidx g2 = cg_of(kk);
+            if (g2 >= 0 && g2 != me) row.push_back(g2);
+          }
+        } else {
+          for (int64_t t = hoff[(size_t)h]; t < hoff[(size_t)h + 1]; t++)
+            if (hl[(size_t)t] != me) row.push_back(hl[(size_t)t]);
+        }
+      }
+      std::sort(row.begin(), row.end());
+      row.erase(std::unique(row.begin(), row.end()), row.end());
+      G.ia[(size_t)ci + 1] = (int64_t)row.size();
+    }
+  });
+  for (long long q = 0; q < nc1; q++) G.ia[(size_t)q + 1] += G.ia[(size_t)q];
+  G.gj.resize((size_t)G.nnz());
+  parallel_for(nc1, [&](int64_t b, int64_t en, int) {
+    for (int64_t ci = b; ci < en; ci++)
+      if (!rows[(size_t)ci].empty())
+        memcpy(G.gj.data() + G.ia[(size_t)ci], rows[(size_t)ci].data(), rows[(size_t)ci].size() * sizeof(gidx));
+  });
+  std::vector<std::vector<gidx>>().swap(rows);
+  Ring ring2;
+  {
+    std::vector<gidx> need;
+    append_outside(G.gj, c0, c0 + nc1, need);
+    sort_unique(need);
+    ring2.build(comm, st1, std::move(need));
+  }
+  std::vector<int> hslot2((size_t)G.nnz(), -1);
+  parallel_for((int64_t)G.gj.size(), [&](int64_t b, int64_t en, int) {
+    for (int64_t k = b; k < en; k++)
+      if (G.gj[(size_t)k] < c0 || G.gj[(size_t)k] >= c0 + nc1) hslot2[(size_t)k] = ring2.slot_of(G.gj[(size_t)k]);
+  });
+  g_ext_rows_max = std::max<long long>(g_ext_rows_max, nc1 + (long long)ring2.ids.size());
+  std::vector<int> cf2, cf2_h;
+  dist_pmis(comm, st1, (int)nc1, G.ia, G.gj, nullptr, ring2, hslot2, cf2, cf2_h);
+  for (long long q = 0; q < nc1; q++)
+    if (cf2[(size_t)q] != C_PT) cf[(size_t)crow[(size_t)q]] = cf2[(size_t)q];
+  cf_h = ring.forward(comm, cf);
+}
+
+// Multipass interpolation on N ranks (par_multi_interp.c hypre_BoomerAMGBuildMultipass; formulas and order of
+// operations: oracle/oracle.c build_multipass; the interpolation of aggressive levels, agg_interp_type 4,
+// src/HypreSystem.cpp:220-224, and interp_type 4).  Pass k builds the rows of the F points with a strong neighbour
+// reached in pass k-1 THROUGH those neighbours' rows; for halo neighbours the rows (global coarse ids and weights in
+// discovery order, untruncated -- what the single-rank routine reads) and the pass numbers arrive after every pass.
+// Every row is accumulated by one thread in the column order of A's row (ascending global ids = the single-rank
+// order), so the weights are the single-rank ones bit for bit.  Truncation and the sort by coarse id follow the last pass.
+void dist_multipass(Comm &comm, const std::vector<gidx> &starts, const GlobCSR &A, const std::vector<char> &strong,
+                    const Ring &ring, const std::vector<int> &hslot, const std::vector<int> &cf, const std::vector<int> &cf_h,
+                    const std::vector<gidx> &cgid, const std::vector<gidx> &cgid_h, double trunc_factor, int pmax, GlobCSR &P) {
+  const int n = A.nrows;
+  const gidx s = starts[(size_t)comm.rank];
+  const int nh = (int)ring.ids.size();
+  std::vector<int> assigned((size_t)n, -1), assigned_h((size_t)nh, -1), rlen((size_t)n, 0), hlen((size_t)nh, 0);
+  std::vector<int64_t> rstart((size_t)n, 0), hstart((size_t)nh, 0);
+  std::vector<gidx> pool_c, hpool_c;  // own rows in the order they were built / halo rows of the previous pass
+  std::vector<double> pool_v, hpool_v;
+  pool_c.reserve((size_t)n);
+  pool_v.reserve((size_t)n);
+  for (int i = 0; i < n; i++)
+    if (cf[(size_t)i] == C_PT) {
+      assigned[(size_t)i] = 0;
+      rstart[(size_t)i] = (int64_t)pool_c.size();
+      rlen[(size_t)i] = 1;
+      pool_c.push_back(cgid[(size_t)i]);
+      pool_v.push_back(1.0);
+    }
+  for (int q = 0; q < nh; q++)
+    if (cf_h[(size_t)q] == C_PT) {
+      assigned_h[(size_t)q] = 0;
+      hstart[(size_t)q] = (int64_t)hpool_c.size();
+      hlen[(size_t)q] = 1;
+      hpool_c.push_back(cgid_h[(size_t)q]);
+      hpool_v.push_back(1.0);
+    }
+  const int nt = host_threads();
+  std::vector<int> list;
+  for (int pass = 1;; pass++) {
+    list.clear();
+    for (int i = 0; i < n; i++) {
+      if (assigned[(size_t)i] != -1 || cf[(size_t)i] == SF_PT) continue;
+      for (int64_t k = A.ia[(size_t)i]; k < A.ia[(size_t)i + 1]; k++) {
+        if (!strong[(size_t)k]) continue;
+        const int h = hslot[(size_t)k];
+        if ((h < 0 ? assigned[(size_t)(A.gj[(size_t)k] - s)] : assigned_h[(size_t)h]) == pass - 1) {
+          list.push_back(i);
+          break;
+        }
+      }
+    }
+    const int64_t nl = (int64_t)list.size();
+    long long nl_glob = nl;
+    comm.allreduce_host(&nl_glob, 1, CommDType::I64, CommOp::SUM);
+    if (nl_glob == 0) break;  // the rest cannot be reached along strong connections
+    std::vector<std::vector<gidx>> tc((size_t)nt);
+    std::vector<std::vector<double>> tv((size_t)nt);
+    std::vector<int> newlen((size_t)nl, 0);
+    std::vector<int64_t> tbeg((size_t)nt, 0);
+    std::vector<char> used((size_t)nt, 0);
+    parallel_for(nl, [&](int64_t b, int64_t e, int t) {
+      used[(size_t)t] = 1;
+      tbeg[(size_t)t] = b;
+      std::vector<gidx> &oc = tc[(size_t)t];
+      std::vector<double> &ov = tv[(size_t)t];
+      std::vector<std::pair<gidx, int>> seen;  // coarse id -> position in the row (rows are short: sorted insert)
+      for (int64_t q = b; q < e; q++) {
+        const int i = list[(size_t)q];
+        const size_t base = oc.size();
+        seen.clear();
+        double diagonal = 0.0, sum_N = 0.0, sum_J = 0.0;
+        for (int64_t k = A.ia[(size_t)i]; k < A.ia[(size_t)i + 1]; k++) {
+          if (A.gj[(size_t)k] == s + i) {
+            diagonal = A.a[(size_t)k];
+            continue;
+          }
+          sum_N += A.a[(size_t)k];
+          if (!strong[(size_t)k]) continue;
+          const int h = hslot[(size_t)k];
+          const gidx *rc;
+          const double *rv;
+          int len;
+          if (h < 0) {
+            const int j = (int)(A.gj[(size_t)k] - s);
+            if (assigned[(size_t)j] != pass - 1) continue;
+            rc = pool_c.data() + rstart[(size_t)j], rv = pool_v.data() + rstart[(size_t)j], len = rlen[(size_t)j];
+          } else {
+            if (assigned_h[(size_t)h] != pass - 1) continue;
+            rc = hpool_c.data() + hstart[(size_t)h], rv = hpool_v.data() + hstart[(size_t)h], len = hlen[(size_t)h];
+          }
+          sum_J += A.a[(size_t)k];
+          for (int w = 0; w < len; w++) {
+            const gidx c = rc[w];
+            auto it = std::lower_bound(seen.begin(), seen.end(), std::make_pair(c, -1));
+            int pos;
+            if (it == seen.end() || it->first != c) {
+              pos = (int)(oc.size() - base);
+              seen.insert(it, std::make_pair(c, pos));
+              oc.push_back(c);
+              ov.push_back(0.0);
+            } else
+              pos = it->second;
+            ov[base + (size_t)pos] += A.a[(size_t)k] * rv[w];
+          }
+        }
+        const double alfa = (sum_J * diagonal != 0.0) ? -sum_N / (sum_J * diagonal) : 0.0;
+        const int len = (int)(oc.size() - base);
+        for (int w = 0; w < len; w++) ov[base + (size_t)w] *= alfa;
+        newlen[(size_t)q] = len;
+      }
+    });
+    // append the pass's rows to the pool (list order) -- only now do its points count as reached
+    int64_t at = (int64_t)pool_c.size();
+    for (int64_t q = 0; q < nl; q++) {
+      rstart[(size_t)list[(size_t)q]] = at;
+      rlen[(size_t)list[(size_t)q]] = newlen[(size_t)q];
+      at += newlen[(size_t)q];
+    }
+    pool_c.resize((size_t)at);
+    pool_v.resize((size_t)at);
+    for (int t = 0; t < nt; t++)
+      if (used[(size_t)t] && !tc[(size_t)t].empty()) {
+        const int64_t off = rstart[(size_t)list[(size_t)tbeg[(size_t)t]]];
+        memcpy(pool_c.data() + off, tc[(size_t)t].data(), tc[(size_t)t].size() * sizeof(gidx));
+        memcpy(pool_v.data() + off, tv[(size_t)t].data(), tv[(size_t)t].size() * sizeof(double));
+      }
+    for (int64_t q = 0; q < nl; q++) assigned[(size_t)list[(size_t)q]] = pass;
+    // the halo points reached in this pass, with their rows
+    assigned_h = ring.forward(comm, assigned);
+    const std::vector<std::vector<char>> rec = ring.forward_records(comm, [&](int row, std::vector<char> &buf) {
+      const int len = assigned[(size_t)row] == pass ? rlen[(size_t)row] : 0;
+      put1<int>(buf, len);
+      put(buf, pool_c.data() + rstart[(size_t)row], (size_t)len);
+      put(buf, pool_v.data() + rstart[(size_t)row], (size_t)len);
+    });
+    hpool_c.clear(), hpool_v.clear();
+    for (size_t pi = 0; pi < rec.size(); pi++) {
+      Reader rd(rec[pi]);
+      for (int q = ring.recv_starts[pi]; q < ring.recv_starts[pi + 1]; q++) {
+        const int len = rd.get<int>();
+        const size_t o = hpool_c.size();
+        hstart[(size_t)q] = (int64_t)o;
+        hlen[(size_t)q] = len;
+        hpool_c.resize(o + (size_t)len);
+        hpool_v.resize(o + (size_t)len);
+        rd.get(hpool_c.data() + o, (size_t)len);
+        rd.get(hpool_v.data() + o, (size_t)len);
+      }
+    }
+  }
+  // truncation and sort row by row (in place in the pool), then compaction into P
+  std::vector<int> flen((size_t)n, 0);
+  parallel_for(n, [&](int64_t b, int64_t e, int) {
+    std::vector<char> keep;
+    std::vector<int> idx;
+    std::vector<gidx> tmpc;
+    for (int64_t i = b; i < e; i++) {
+      int len = rlen[(size_t)i];
+      gidx *rc = pool_c.data() + rstart[(size_t)i];
+      double *rv = pool_v.data() + rstart[(size_t)i];
+      if (cf[(size_t)i] != C_PT && len > 0) {
+        idx.resize((size_t)len);
+        for (int w = 0; w < len; w++) idx[(size_t)w] = w;
+        tmpc.assign(rc, rc + len);
+        len = truncate_row(len, idx.data(), rv, trunc_factor, pmax, keep);
+        for (int w = 0; w < len; w++) rc[w] = tmpc[(size_t)idx[(size_t)w]];
+      }
+      for (int a = 1; a < len; a++) {
+        const gidx c = rc[a];
+        const double v = rv[a];
+        int bb = a - 1;
+        while (bb >= 0 && rc[bb] > c) {
+          rc[bb + 1] = rc[bb];
+          rv[bb + 1] = rv[bb];
+          bb--;
+        }
+        rc[bb + 1] = c;
+        rv[bb + 1] = v;
+      }
+      flen[(size_t)i] = len;
+    }
+  });
+  P.nrows = n;
+  P.ia.assign((size_t)n + 1, 0);
+  for (int i = 0; i < n; i++) P.ia[(size_t)i + 1] = P.ia[(size_t)i] + flen[(size_t)i];
+  P.gj.resize((size_t)P.nnz());
+  P.a.resize((size_t)P.nnz());
+  parallel_for(n, [&](int64_t b, int64_t e, int) {
+    for (int64_t i = b; i < e; i++) {
+      if (!flen[(size_t)i]) continue;
+      memcpy(P.gj.data() + P.ia[(size_t)i], pool_c.data() + rstart[(size_t)i], (size_t)flen[(size_t)i] * sizeof(gidx));
+      memcpy(P.a.data() + P.ia[(size_t)i], pool_v.data() + rstart[(size_t)i], (size_t)flen[(size_t)i] * sizeof(double));
+    }
+  });
+}
+
 }  // namespace
 
 long long dist_setup_counter(const char *name) {
@@ -1138,9 +1585,10 @@ void dist_setup_counters_reset() { g_ext_rows_max = g_global_rows_gathered = g_d
 
 bool BoomerAMG::can_build_distributed() const {
   static const bool forced_off = getenv("MI_HYPRE_REPLICATED_SETUP") && atoi(getenv("MI_HYPRE_REPLICATED_SETUP")) != 0;
-  // (multipass: host passes -- replicated; non-Galerkin operators are distributed since round 3: the row maxima of the
-  // halo columns are fetched from their owners)
-  return !forced_off && (p.coarsen_type == 8 || p.coarsen_type == 9) && p.agg_num_levels <= 0 && p.interp_type != 4;
+  // PMIS splittings, every interpolation this library has (multipass and the second-generation PMIS of aggressive
+  // levels pass by pass with halo rows since round 3), Galerkin or non-Galerkin coarse operators.  The Ruge-Stueben
+  // family and CLJP are sequential sweeps over the GLOBAL graph in this library's specification: replicated.
+  return !forced_off && (p.coarsen_type == 8 || p.coarsen_type == 9);
 }
 
 void BoomerAMG::build_distributed(ParCSR &A0) {
@@ -1165,7 +1613,10 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
     comm.allreduce_host(&m, 1, CommDType::I64, CommOp::MIN);
     return m;
   };
-  const bool dev_candidate = dev_enabled && device_min_rows >= 0 && ctx().inited && (p.interp_type == 6 || p.interp_type == 0);
+  // (aggressive levels come first and are host passes -- second-generation PMIS, multipass interpolation -- and the
+  // device loop cannot resume after a host level: hierarchies with aggressive levels stay on the host loop)
+  const bool dev_candidate = dev_enabled && device_min_rows >= 0 && ctx().inited && (p.interp_type == 6 || p.interp_type == 0) &&
+                             p.agg_num_levels <= 0;
   const bool dev_path = dev_candidate && smallest_piece(A0.nrows) >= std::max<long long>(1, device_min_rows);
   sk::DCsr dD0;  // the diag block of A0 in the setup format, when the device path starts from the copy in HBM
   if (dev_path && A0.on_device && A0.d_diag.nrows == A0.nrows && A0.d_diag.nnz == A0.diag.nnz() && !A0.d_diag.rowmap.p)
@@ -1357,128 +1808,17 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
     // ---- PMIS on the global graph (par_coarsen.c), one global random stream
     tp0 = wall_time();
     tsub = tp0;
-    std::vector<int> cf((size_t)n, 0), cf_h;
-    {
-      // (integer counts and flags below are updated from several host threads with relaxed atomics: sums and
-      // "set to 0" stores commute, so the outcome does not depend on the schedule)
-      std::vector<int> cnt((size_t)n, 0), cnt_h((size_t)nh, 0);
-      parallel_for(n, [&](int64_t b, int64_t en, int) {
-        for (int64_t i = b; i < en; i++)
-          for (int64_t k = A.ia[(size_t)i]; k < A.ia[(size_t)i + 1]; k++) {
-            if (!Lv.strong[(size_t)k]) continue;
-            int *slot = hslot[(size_t)k] < 0 ? &cnt[(size_t)(A.gj[(size_t)k] - s)] : &cnt_h[(size_t)hslot[(size_t)k]];
-            __atomic_fetch_add(slot, 1, __ATOMIC_RELAXED);
-          }
-      });
-      ring.reverse(comm, cnt_h, cnt, [](int &mine, int v) { mine += v; });
-      std::vector<double> measure((size_t)n, 0.0);
-      parallel_for(n, [&](int64_t b, int64_t en, int) {
-        if (b >= en) return;
-        int seed = park_miller_at(2747, s + b);  // element s + b of the stream; the following ones by the recurrence
-        for (int64_t i = b; i < en; i++) {
-          if (i > b) {
-            const int a = 16807, m = 2147483647, q = 127773, r = 2836;
-            const int lo = seed % q, hi = seed / q;
-            const int t = a * lo - r * hi;
-            seed = (t > 0) ? t : t + m;
-          }
-          measure[(size_t)i] = (double)cnt[(size_t)i] + (double)seed / 2147483647;
-        }
-      });
-      lap("pmis: measures");
-      std::vector<int> graph;
-      parallel_for(n, [&](int64_t b, int64_t en, int) {
-        for (int64_t i = b; i < en; i++) {
-          bool any = false;
-          for (int64_t k = A.ia[(size_t)i]; k < A.ia[(size_t)i + 1] && !any; k++) any = Lv.strong[(size_t)k] != 0;
-          if (!any) {
-            cf[(size_t)i] = SF_PT;
-            measure[(size_t)i] = 0.0;
-          } else if (measure[(size_t)i] < 1.0) {
-            cf[(size_t)i] = F_PT;
-            measure[(size_t)i] = 0.0;
-          }
-        }
-      });
-      for (int i = 0; i < n; i++)
-        if (cf[(size_t)i] == 0) graph.push_back(i);
-      const std::vector<double> m_h = ring.forward(comm, measure);
-      cf_h = ring.forward(comm, cf);
-      std::vector<signed char> tmp((size_t)n, 0);
-      lap("pmis: initial graph");
-      for (;;) {
-        long long left = (long long)graph.size();
-        comm.allreduce_host(&left, 1, CommDType::I64, CommOp::SUM);
-        if (left == 0) break;
-        std::vector<int> lose_h((size_t)nh, 1);  // 0: the halo point lost a comparison against one of my rows
-        const int64_t ng = (int64_t)graph.size();
-        parallel_for(ng, [&](int64_t b, int64_t en, int) {
-          for (int64_t q = b; q < en; q++) tmp[(size_t)graph[(size_t)q]] = 1;
-        });
-        parallel_for(ng, [&](int64_t b, int64_t en, int) {
-          for (int64_t q = b; q < en; q++) {
-            const int g = graph[(size_t)q];
-            const double mi_ = measure[(size_t)g];
-            bool lost = false;
-            for (int64_t k = A.ia[(size_t)g]; k < A.ia[(size_t)g + 1]; k++) {
-              if (!Lv.strong[(size_t)k]) continue;
-              const int h = hslot[(size_t)k];
-              if (h < 0) {
-                const int j = (int)(A.gj[(size_t)k] - s);
-                if (cf[(size_t)j] != 0) continue;
-                if (mi_ > measure[(size_t)j])
-                  __atomic_store_n(&tmp[(size_t)j], (signed char)0, __ATOMIC_RELAXED);
-                else if (measure[(size_t)j] > mi_)
-                  lost = true;
-              } else {
-                if (cf_h[(size_t)h] != 0) continue;
-                if (mi_ > m_h[(size_t)h])
-                  __atomic_store_n(&lose_h[(size_t)h], 0, __ATOMIC_RELAXED);
-                else if (m_h[(size_t)h] > mi_)
-                  lost = true;
-              }
-            }
-            if (lost) __atomic_store_n(&tmp[(size_t)g], (signed char)0, __ATOMIC_RELAXED);
-          }
-        });
-        {
-          std::vector<int> keep((size_t)n, 1);
-          ring.reverse(comm, lose_h, keep, [](int &mine, int v) { mine = std::min(mine, v); });
-          parallel_for(ng, [&](int64_t b, int64_t en, int) {
-            for (int64_t q = b; q < en; q++) {
-              const int g = graph[(size_t)q];
-              if (!keep[(size_t)g]) tmp[(size_t)g] = 0;
-              if (tmp[(size_t)g] == 1) cf[(size_t)g] = C_PT;
-            }
-          });
-        }
-        cf_h = ring.forward(comm, cf);
-        parallel_for(ng, [&](int64_t b, int64_t en, int) {
-          for (int64_t q = b; q < en; q++) {
-            const int g = graph[(size_t)q];
-            if (cf[(size_t)g] != 0) continue;
-            bool dep_c = false;
-            for (int64_t k = A.ia[(size_t)g]; k < A.ia[(size_t)g + 1] && !dep_c; k++) {
-              if (!Lv.strong[(size_t)k]) continue;
-              const int h = hslot[(size_t)k];
-              dep_c = h < 0 ? cf[(size_t)(A.gj[(size_t)k] - s)] == C_PT : cf_h[(size_t)h] == C_PT;
-            }
-            tmp[(size_t)g] = dep_c ? 2 : 3;  // 2: becomes F once the scan is over (the scan sees this round's C points only)
-          }
-        });
-        std::vector<int> next;
-        for (int g : graph) {
-          if (cf[(size_t)g] != 0) continue;
-          if (tmp[(size_t)g] == 2)
-            cf[(size_t)g] = F_PT;
-          else
-            next.push_back(g);
-        }
-        graph.swap(next);
-        cf_h = ring.forward(comm, cf);
-      }
-    }
+    std::vector<int> cf, cf_h;
+    dist_pmis(comm, Lv.starts, n, A.ia, A.gj, Lv.strong.data(), ring, hslot, cf, cf_h);
     lap("pmis: rounds");
+    // aggressive level (level < agg_num_levels, src/HypreSystem.cpp:215-219): the C points are coarsened once more on
+    // the second-generation graph; interpolation is multipass there (and wherever interp_type 4 asks for it)
+    const bool aggressive = l < p.agg_num_levels;
+    const bool multipass = aggressive || p.interp_type == 4;
+    if (aggressive) {
+      dist_second_stage(comm, Lv.starts, A, Lv.strong, ring, hslot, cf, cf_h);
+      lap("pmis: second generation");
+    }
     long long nc_loc = 0;
     for (int i = 0; i < n; i++) nc_loc += (cf[(size_t)i] == C_PT);
     long long nc_glob = nc_loc;
@@ -1506,6 +1846,12 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
     const std::vector<gidx> cgid_h = ring.forward(comm, Lv.cgid);
 
     tsub = wall_time();
+    if (multipass) {
+      // ---- multipass interpolation, pass by pass with the halo rows of the previous pass
+      dist_multipass(comm, Lv.starts, A, Lv.strong, ring, hslot, cf, cf_h, Lv.cgid, cgid_h,
+                     aggressive ? p.agg_trunc_factor : p.trunc_factor, aggressive ? p.agg_pmax_elmts : p.pmax_elmts, Lv.P);
+      lap("interp: multipass");
+    } else {
     // ---- interpolation on the extended sub-problem
     // rows of the halo points with, per entry, strength flag, C/F state and coarse id of the column
     std::vector<std::vector<char>> hrows = ring.forward_records(comm, [&](int row, std::vector<char> &buf) {
@@ -1682,6 +2028,7 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
       });
       MI_REQUIRE(bad == 0, "distributed setup: interpolation from a point without a coarse id");
     }
+    }  // (extended sub-problem)
     for (int i = 0; i < n; i++)
       if (cf[(size_t)i] == SF_PT) cf[(size_t)i] = F_PT;
     Lv.cf = cf;

@@ -58,6 +58,10 @@ def main():
                          "works on the globally permuted system")
     ap.add_argument("--relax", type=int, default=0, help="relax_type of the down / up sweeps (0 = library default)")
     ap.add_argument("--ng", type=float, default=0.0, help="non_galerkin_tol (0 = Galerkin coarse operators)")
+    ap.add_argument("--agg", type=int, default=0, help="agg_num_levels (aggressive coarsening + multipass interpolation)")
+    ap.add_argument("--interp", type=int, default=-1, help="interp_type (-1 = library default)")
+    ap.add_argument("--aggtrunc", type=float, default=0.0, help="agg_trunc_factor")
+    ap.add_argument("--aggpmax", type=int, default=0, help="agg_pmax_elmts")
     ap.add_argument("--combo", type=int, default=-1,
                     help="seed of a combination of BoomerAMG choices (tests/test_gpu_amg.py::_combo) applied to both sides")
     ap.add_argument("--smooth", type=int, default=0,
@@ -99,6 +103,14 @@ def main():
         smooth_o["relax_type"] = args.relax
     if args.ng > 0.0:
         smooth_o["non_galerkin_tol"] = args.ng
+    if args.agg:
+        smooth_o["agg_num_levels"] = args.agg
+        if args.aggtrunc:
+            smooth_o["agg_trunc_factor"] = args.aggtrunc
+        if args.aggpmax:
+            smooth_o["agg_pmax_elmts"] = args.aggpmax
+    if args.interp >= 0:
+        smooth_o["interp_type"] = args.interp
     if args.combo >= 0:
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
         from test_gpu_amg import _combo
@@ -137,9 +149,8 @@ def main():
         amg.setup(A)
     order = np.arange(starts[rank + 1] - starts[rank])
     Ao_used, bo_used = Ao, bo
-    # (the replicated setup -- everything but plain PMIS -- does not renumber on N > 1 ranks)
-    by_replication = size > 1 and (smooth_o.get("coarsen_type", 8) not in (8, 9) or smooth_o.get("agg_num_levels", 0) > 0
-                                   or smooth_o.get("interp_type", 6) == 4
+    # (the replicated setup -- every coarsening but PMIS -- does not renumber on N > 1 ranks)
+    by_replication = size > 1 and (smooth_o.get("coarsen_type", 8) not in (8, 9)
                                    or os.environ.get("MI_HYPRE_REPLICATED_SETUP", "0") not in ("", "0"))
     if args.locality and by_replication:
         assert not amg.input_ordering()[0]
@@ -169,9 +180,9 @@ def main():
         return v.value
 
     replicated = os.environ.get("MI_HYPRE_REPLICATED_SETUP", "0") not in ("", "0")
-    # everything but plain PMIS with ext+i / classical / direct interpolation (Galerkin or non-Galerkin coarse
-    # operators) is built by the replicated setup
-    if smooth_o.get("coarsen_type", 8) not in (8, 9) or smooth_o.get("agg_num_levels", 0) > 0 or smooth_o.get("interp_type", 6) == 4:
+    # every coarsening but PMIS (the Ruge-Stueben family, CLJP: sequential sweeps over the global graph) is built by
+    # the replicated setup; PMIS with any interpolation, aggressive levels included, by the distributed one
+    if smooth_o.get("coarsen_type", 8) not in (8, 9):
         replicated = True
     if size > 1 and not replicated:
         assert counter("setup_distributed") >= 1, "the distributed setup did not run"
@@ -188,7 +199,8 @@ def main():
         # threshold 0 on a GPU: the large levels of the distributed setup are built on the device (extended index
         # spaces, amg_setup_dist.cpp DevLevel) -- at least level 0, where every rank has rows
         if (args.mode == "solve" and os.environ.get("MI_HYPRE_DEVICE_SETUP_MIN_ROWS", "") == "0"
-                and os.environ.get("MI_HYPRE_DIST_DEVICE_SETUP", "1") != "0" and smooth_o.get("interp_type", 6) in (0, 6)):
+                and os.environ.get("MI_HYPRE_DIST_DEVICE_SETUP", "1") != "0" and smooth_o.get("interp_type", 6) in (0, 6)
+                and smooth_o.get("agg_num_levels", 0) == 0):  # (aggressive levels are host passes and come first)
             assert counter("setup_device_levels") >= 1, "no level of the distributed setup was built on the device"
             if rank == 0:
                 print("distributed setup: %d level(s) built on the device" % counter("setup_device_levels"))

@@ -18,7 +18,7 @@ WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
 
 
 def _run(nproc, mode, n, stencil, port, staging="host", seq=-1, devmin=None, golden="", replicated=False, locality=0,
-         smooth=0, relax=0, combo=-1, transport="", ng=0.0):
+         smooth=0, relax=0, combo=-1, transport="", ng=0.0, agg=0, interp=-1, aggtrunc=0.0, aggpmax=0):
     env = dict(os.environ)
     env["MI_HYPRE_REPLICATED_SETUP"] = "1" if replicated else "0"
     if devmin is not None:  # levels with at least this many rows are built (and sliced) on the device
@@ -44,6 +44,10 @@ def _run(nproc, mode, n, stencil, port, staging="host", seq=-1, devmin=None, gol
         cmd += ["--transport", transport]
     if ng:
         cmd += ["--ng", str(ng)]
+    if agg:
+        cmd += ["--agg", str(agg), "--aggtrunc", str(aggtrunc), "--aggpmax", str(aggpmax)]
+    if interp >= 0:
+        cmd += ["--interp", str(interp)]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-4000:]
     return p.stdout
@@ -77,10 +81,28 @@ def test_host_setup_non_galerkin_distributed_gloo(nproc, n, stencil, seq, ng, lo
     assert "dist host setup ok" in out
 
 
+@pytest.mark.parametrize("nproc,n,stencil,seq,agg,interp,aggtrunc,aggpmax,ng,locality",
+                         [(2, 14, 7, 0, 1, -1, 0.0, 0, 0.0, 0), (3, 12, 27, 0, 2, -1, 0.0, 0, 0.0, 0),
+                          (4, 12, 7, 100, 1, -1, 0.2, 3, 0.0, 0),   # truncated aggressive rows, redundant tail below
+                          (2, 14, 7, 0, 0, 4, 0.0, 0, 0.0, 0),      # multipass as the ordinary interpolation
+                          (3, 14, 7, 300, 2, -1, 0.0, 0, 0.0, 1),   # aggressive levels reach into the redundant tail
+                          (8, 10, 7, 0, 1, -1, 0.0, 0, 0.0, 0),     # the node size of the benchmark
+                          (2, 16, 7, 0, 3, -1, 0.0, 0, 0.05, 0)])   # three aggressive levels, non-Galerkin operators
+def test_host_setup_aggressive_levels_distributed_gloo(nproc, n, stencil, seq, agg, interp, aggtrunc, aggpmax, ng, locality):
+    """Aggressive coarsening (agg_num_levels, /root/reference/src/HypreSystem.cpp:215-219) and multipass interpolation
+    (agg_interp_type 4 `:220-224`, interp_type 4) in the DISTRIBUTED setup: the first-stage C points get global ids,
+    the second-generation graph is built with the strong C neighbours of the halo points, the same distributed PMIS
+    runs on it, and multipass proceeds pass by pass with the halo rows of the previous pass -- the oracle's
+    partition-independent hierarchy level by level, per-rank sub-problems of local size (asserted by the worker)."""
+    out = _run(nproc, "host", n, stencil, 30411 + nproc + n + agg, seq=seq, agg=agg, interp=interp, aggtrunc=aggtrunc,
+               aggpmax=aggpmax, ng=ng, locality=locality)
+    assert "dist host setup ok" in out
+
+
 @pytest.mark.parametrize("nproc,n,stencil,seq", [(2, 12, 7, -1), (3, 10, 27, 0), (4, 6, 7, 0)])
 def test_host_setup_replicated_path_gloo(nproc, n, stencil, seq):
     """The replicated setup (every rank builds the global hierarchy and keeps its slices) stays the path of the
-    Ruge-Stueben family and of aggressive coarsening on N > 1; MI_HYPRE_REPLICATED_SETUP=1 forces it."""
+    Ruge-Stueben family and CLJP on N > 1; MI_HYPRE_REPLICATED_SETUP=1 forces it."""
     out = _run(nproc, "host", n, stencil, 29911 + nproc + n, seq=seq, replicated=True)
     assert "dist host setup ok" in out
 
@@ -88,9 +110,9 @@ def test_host_setup_replicated_path_gloo(nproc, n, stencil, seq):
 @pytest.mark.parametrize("nproc,n,seq,combo", [(2, 14, 300, 1), (3, 12, 100, 15), (2, 14, 0, 17), (2, 12, 150, 11),
                                                 (2, 13, 200, 18)])  # 18: non-Galerkin coarse operators (replicated setup)
 def test_host_setup_parameter_combinations_gloo(nproc, n, seq, combo):
-    """Seeded combinations of the BoomerAMG choices on N ranks (host half): Ruge-Stueben / CLJP coarsening, aggressive
-    levels that reach into the redundant tail, multipass interpolation; a coarsest level below the redundancy
-    threshold is held whole by every rank, as in the oracle's emulation."""
+    """Seeded combinations of the BoomerAMG choices on N ranks (host half): Ruge-Stueben / CLJP coarsening (replicated
+    setup), PMIS with aggressive levels that reach into the redundant tail and multipass interpolation (distributed
+    setup); a coarsest level below the redundancy threshold is held whole by every rank, as in the oracle's emulation."""
     out = _run(nproc, "host", n, 7, 30111 + nproc + n + combo, seq=seq, combo=combo)
     assert "dist host setup ok" in out
 
@@ -143,6 +165,16 @@ def test_distributed_setup_non_galerkin_shared_gpu(nproc, n, stencil, seq, ng, d
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nproc,n,stencil,seq,agg,interp,devmin", [(2, 20, 7, 0, 1, -1, 0), (3, 16, 27, 0, 2, -1, None),
+                                                                  (4, 16, 7, 500, 1, -1, None), (2, 16, 7, 0, 0, 4, 0)])
+def test_device_solve_aggressive_levels_distributed_shared_gpu(nproc, n, stencil, seq, agg, interp, devmin):
+    """Aggressive levels / multipass interpolation built by the distributed setup (host loop also with the device
+    threshold at 0), then the device solve on N ranks: hierarchy, iterations, residual history, solution vs the oracle."""
+    out = _run(nproc, "solve", n, stencil, 30451 + nproc + n + agg, seq=seq, agg=agg, interp=interp, devmin=devmin)
+    assert "dist solve ok" in out
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("nproc,n,stencil,seq", [(2, 16, 7, -1), (3, 12, 27, 0), (4, 16, 7, 1000)])
 def test_device_solve_with_locality_numbering_shared_gpu(nproc, n, stencil, seq):
     out = _run(nproc, "solve", n, stencil, 29871 + nproc + n, seq=seq, locality=1)
@@ -172,8 +204,8 @@ def test_device_solve_other_smoothers_shared_gpu(nproc, n, seq, relax):
                                                 (2, 13, 200, 18), (3, 12, 0, 14)])  # 18, 14: non-Galerkin coarse operators
 def test_device_solve_parameter_combinations_shared_gpu(nproc, n, seq, combo):
     """Seeded combinations of the BoomerAMG choices (test_gpu_amg.py::_combo: Ruge-Stueben / CLJP coarsening,
-    aggressive levels, multipass, complex smoother, W cycles ...) on N ranks: the replicated setup for everything
-    but plain PMIS, aggressive levels and smoothed levels that reach into the redundant tail."""
+    aggressive levels, multipass, complex smoother, W cycles ...) on N ranks: the replicated setup for every
+    coarsening but PMIS, aggressive levels and smoothed levels that reach into the redundant tail."""
     out = _run(nproc, "solve", n, 7, 30071 + nproc + n + combo, seq=seq, combo=combo)
     assert "dist solve ok" in out
 
