@@ -495,10 +495,11 @@ def main():
     for _ in range(args.warmup):
         one_solve()
     cap = 8192
+    # HIP events in the timed region only around the dominant kernel (the level-0 SpMV of the GMRES loop, ~20 launches
+    # per solve).  An event pair costs the queue ~10 us (profiles/r03_rank_size_proxy_256.txt: the gaps in front of every
+    # timed launch); around the ~270 relaxation and Gram-Schmidt launches of a solve that is 0.5 % of a 512^3 solve on
+    # one GPU but ~3 % of the same solve on 8 -- those classes are timed in one extra solve AFTER the timed region
     mi.profile_enable(mi.PROF_SPMV_L0, cap)
-    mi.profile_enable(mi.PROF_RELAX_L0, cap)
-    mi.profile_enable(mi.PROF_DOT, 4 * cap)   # fused Gram-Schmidt steps (axpy + inner product) and norms
-    mi.profile_enable(mi.PROF_AXPY, cap)
     barrier()
     t0 = time.perf_counter()
     iters_total = 0
@@ -512,13 +513,27 @@ def main():
         elapsed = float(t.item())
 
     spmv_n, spmv_ms, spmv_min = mi.profile_get(mi.PROF_SPMV_L0)
-    rel_n, rel_ms, rel_min = mi.profile_get(mi.PROF_RELAX_L0)
-    dot_n, dot_ms, _ = mi.profile_get(mi.PROF_DOT)
-    axpy_n, axpy_ms, _ = mi.profile_get(mi.PROF_AXPY)
     spmv_kernel = mi.profile_kernel_name(mi.PROF_SPMV_L0)
-    relax_kernel = mi.profile_kernel_name(mi.PROF_RELAX_L0)
     rel_res = gm.final_rel_res
     iters = gm.num_iterations
+    rel_n = rel_ms = rel_min = dot_n = dot_ms = axpy_n = axpy_ms = 0
+    relax_kernel = ""
+    extra_solves = 0
+    if world == 1:
+        # the other two classes of the record (level-0 relaxation, Gram-Schmidt), outside the timed region
+        mi.profile_enable(mi.PROF_SPMV_L0, 0)
+        mi.profile_enable(mi.PROF_RELAX_L0, cap)
+        mi.profile_enable(mi.PROF_DOT, 4 * cap)   # fused Gram-Schmidt steps (axpy + inner product) and norms
+        mi.profile_enable(mi.PROF_AXPY, cap)
+        extra_solves = 1
+        one_solve()
+        rel_n, rel_ms, rel_min = mi.profile_get(mi.PROF_RELAX_L0)
+        dot_n, dot_ms, _ = mi.profile_get(mi.PROF_DOT)
+        axpy_n, axpy_ms, _ = mi.profile_get(mi.PROF_AXPY)
+        relax_kernel = mi.profile_kernel_name(mi.PROF_RELAX_L0)
+        mi.profile_enable(mi.PROF_DOT, 0)
+        mi.profile_enable(mi.PROF_AXPY, 0)
+        mi.profile_enable(mi.PROF_SPMV_L0, cap)  # (the general-operator leg below reads classes 0 and 1)
     xs = x.get()
     err = float(np.abs(xs - 1.0).max()) if xs.size else 0.0
     nlev = amg.num_levels
@@ -576,7 +591,7 @@ def main():
             a = relax_bytes / (rel_ms / rel_n * 1e-3) / 1e9
             roof_relax = {"bound": "hbm", "kernel": f"{relax_kernel} (level-0 l1 hybrid GS, one C or F pass over the full operator = the "
                                     "up-leg sweeps; the down leg's sweep starts from a zero guess, runs on the zero-guess "
-                                    "sub-operator and is not counted here)",
+                                    "sub-operator and is not counted here; HIP events in one extra solve after the timed region)",
                           "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
                           "launches": rel_n, "avg_ms": rel_ms / rel_n, "min_ms": rel_min,
                           "algorithmic_bytes_per_launch": relax_bytes,
@@ -592,14 +607,15 @@ def main():
             # the same pass) + the norm; one solve of m steps: m(m+1)/2 fused steps + ~m + 3 norms / dots of 8..16 N
             m_it = iters
             gs_bytes = (m_it * (m_it + 1) / 2.0) * 32.0 * nloc + (m_it + 3) * 16.0 * nloc
-            per_solve_ms = dot_ms / args.steps
-            gram = {"what": "modified Gram-Schmidt + norms of one solve (HIP events of the fused axpy+dot / dot launches)",
-                    "ms_per_solve": per_solve_ms, "launches_per_solve": dot_n / args.steps,
+            per_solve_ms = dot_ms / extra_solves
+            gram = {"what": "modified Gram-Schmidt + norms of one solve (HIP events of the fused axpy+dot / dot launches, in one "
+                            "extra solve after the timed region)",
+                    "ms_per_solve": per_solve_ms, "launches_per_solve": dot_n / extra_solves,
                     "share_of_solve": per_solve_ms / (elapsed / args.steps * 1e3),
                     "algorithmic_bytes_per_solve": gs_bytes,
                     "achieved": gs_bytes / (per_solve_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": gs_bytes / (per_solve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "axpy_ms_per_solve": axpy_ms / args.steps}
+                    "axpy_ms_per_solve": axpy_ms / extra_solves}
         chunk = C.c_int()
         mi.call("HYPRE_MI_GetGSChunk", C.byref(chunk))
         out = {

@@ -385,7 +385,7 @@ void KernelTimer::enable(int id, size_t capacity) {
     start[id].push_back(a);
     stop[id].push_back(b);
   }
-  enabled[id] = true;
+  enabled[id] = capacity > 0;  // capacity 0 switches the class off again (no events around its launches)
   used[id] = 0;
   dropped[id] = 0;
 }
