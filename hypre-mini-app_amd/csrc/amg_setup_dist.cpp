@@ -2343,7 +2343,9 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
   // new global ids of the columns of M (ids of level `lev`)
   auto translate = [&](const GlobCSR &M, size_t lev, const Ring *known_ring) {
     std::vector<gidx> out(M.gj);
-    if (pos[lev].empty()) return out;
+    // (by the level's state, not by this rank's row count: a rank without rows on the level still takes part in the
+    // exchanges below)
+    if (!D[lev].has_cf) return out;
     const std::vector<gidx> &st = D[lev].starts;
     const gidx s = st[(size_t)rank], e = st[(size_t)rank + 1];
     Ring own;
@@ -2375,7 +2377,7 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
   // new global ids of the remote ids `ids` of level `lev` after its C-first renumbering (ring: over exactly these ids)
   auto new_ids = [&](const std::vector<gidx> &ids, size_t lev, const Ring &rg) {
     std::vector<gidx> out(ids);
-    if (pos[lev].empty()) return out;
+    if (!D[lev].has_cf) return out;
     const std::vector<gidx> &st = D[lev].starts;
     const std::vector<int> pos_h = rg.forward(comm, pos[lev]);
     for (size_t k = 0; k < ids.size(); k++) out[k] = st[(size_t)rank_of_id(st, ids[k])] + pos_h[k];

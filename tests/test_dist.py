@@ -87,7 +87,10 @@ def test_host_setup_non_galerkin_distributed_gloo(nproc, n, stencil, seq, ng, lo
                           (2, 14, 7, 0, 0, 4, 0.0, 0, 0.0, 0),      # multipass as the ordinary interpolation
                           (3, 14, 7, 300, 2, -1, 0.0, 0, 0.0, 1),   # aggressive levels reach into the redundant tail
                           (8, 10, 7, 0, 1, -1, 0.0, 0, 0.0, 0),     # the node size of the benchmark
-                          (2, 16, 7, 0, 3, -1, 0.0, 0, 0.05, 0)])   # three aggressive levels, non-Galerkin operators
+                          (2, 16, 7, 0, 3, -1, 0.0, 0, 0.05, 0),    # three aggressive levels, non-Galerkin operators
+                          (8, 8, 27, 0, 0, 4, 0.0, 0, 0.0, 0),      # ranks without rows on the coarse levels still take
+                          (8, 8, 27, 0, 0, 0, 0.0, 0, 0.0, 0),      # part in every exchange (classical interpolation too)
+                          (4, 6, 7, 0, 2, -1, 0.0, 0, 0.0, 0)])
 def test_host_setup_aggressive_levels_distributed_gloo(nproc, n, stencil, seq, agg, interp, aggtrunc, aggpmax, ng, locality):
     """Aggressive coarsening (agg_num_levels, /root/reference/src/HypreSystem.cpp:215-219) and multipass interpolation
     (agg_interp_type 4 `:220-224`, interp_type 4) in the DISTRIBUTED setup: the first-stage C points get global ids,
