@@ -1133,7 +1133,8 @@ std::unique_ptr<ParCSR> assemble_dev(const sk::DCsr &M, const ExtIndex &cols, co
 // and on the second-generation graph of an aggressive level.  Leaves cf (0 never; C_PT / F_PT / SF_PT) and the
 // halo copy cf_h.
 void dist_pmis(Comm &comm, const std::vector<gidx> &starts, int n, const std::vector<int64_t> &ia, const std::vector<gidx> &gj,
-               const char *strong, const Ring &ring, const std::vector<int> &hslot, std::vector<int> &cf, std::vector<int> &cf_h) {
+               const char *strong, const Ring &ring, const std::vector<int> &hslot, std::vector<int> &cf, std::vector<int> &cf_h,
+               const std::vector<int> *init = nullptr) {
   const gidx s = starts[(size_t)comm.rank];
   const int nh = (int)ring.ids.size();
   cf.assign((size_t)n, 0);
@@ -1166,10 +1167,19 @@ void dist_pmis(Comm &comm, const std::vector<gidx> &starts, int n, const std::ve
   std::vector<int> graph;
   parallel_for(n, [&](int64_t b, int64_t en, int) {
     for (int64_t i = b; i < en; i++) {
-      bool any = false;
-      for (int64_t k = ia[(size_t)i]; k < ia[(size_t)i + 1] && !any; k++) any = !strong || strong[(size_t)k] != 0;
+      bool any = false, boundary = false;
+      for (int64_t k = ia[(size_t)i]; k < ia[(size_t)i + 1] && !(any && (boundary || !init)); k++) {
+        if (strong && !strong[(size_t)k]) continue;
+        any = true;
+        boundary = boundary || hslot[(size_t)k] >= 0;
+      }
       if (!any) {
         cf[(size_t)i] = SF_PT;
+        measure[(size_t)i] = 0.0;
+      } else if (init && (*init)[(size_t)i] == C_PT && !boundary) {
+        // HMIS (CF_init = 1): an interior C point of the per-rank Ruge-Stueben pass is kept; boundary points -- rows
+        // with a strong connection to another rank -- and every F point are decided again by the rounds below
+        cf[(size_t)i] = C_PT;
         measure[(size_t)i] = 0.0;
       } else if (measure[(size_t)i] < 1.0) {
         cf[(size_t)i] = F_PT;
@@ -1182,6 +1192,32 @@ void dist_pmis(Comm &comm, const std::vector<gidx> &starts, int n, const std::ve
   const std::vector<double> m_h = ring.forward(comm, measure);
   cf_h = ring.forward(comm, cf);
   std::vector<signed char> tmp((size_t)n, 0);
+  if (init) {
+    // the kept C points are the first independent set: undecided points that strongly depend on one become F
+    const int64_t ng = (int64_t)graph.size();
+    parallel_for(ng, [&](int64_t b, int64_t en, int) {
+      for (int64_t q = b; q < en; q++) {
+        const int g = graph[(size_t)q];
+        bool dep_c = false;
+        for (int64_t k = ia[(size_t)g]; k < ia[(size_t)g + 1] && !dep_c; k++) {
+          if (strong && !strong[(size_t)k]) continue;
+          const int h = hslot[(size_t)k];
+          dep_c = h < 0 ? cf[(size_t)(gj[(size_t)k] - s)] == C_PT : cf_h[(size_t)h] == C_PT;
+        }
+        tmp[(size_t)g] = dep_c ? 2 : 3;
+      }
+    });
+    std::vector<int> next;
+    for (int g : graph) {
+      if (tmp[(size_t)g] == 2) {
+        cf[(size_t)g] = F_PT;
+        measure[(size_t)g] = 0.0;
+      } else
+        next.push_back(g);
+    }
+    graph.swap(next);
+    cf_h = ring.forward(comm, cf);
+  }
   for (;;) {
     long long left = (long long)graph.size();
     comm.allreduce_host(&left, 1, CommDType::I64, CommOp::SUM);
@@ -1256,6 +1292,45 @@ void dist_pmis(Comm &comm, const std::vector<gidx> &starts, int n, const std::ve
 }
 
 
+// Coarsening of a distributed graph by type.  8 / 9: PMIS.  The types HYPRE defines PER PROCESSOR (par_coarsen.c
+// hypre_BoomerAMGCoarsenRuge / ...HMIS; oracle/oracle.c coarsen_by_type_parts): 11 = first Ruge-Stueben pass and 1 = both
+// passes on this rank's own graph (strong connections between own points; no boundary treatment), 10 = HMIS = the
+// first pass per rank, then PMIS from that state on the global graph.  (6 / 3 -- Falgout, a third pass on the
+// boundary -- and CLJP keep their global, sequential form: replicated setup.)
+void dist_coarsen(Comm &comm, int type, const std::vector<gidx> &starts, int n, const std::vector<int64_t> &ia,
+                  const std::vector<gidx> &gj, const char *strong, const Ring &ring, const std::vector<int> &hslot,
+                  std::vector<int> &cf, std::vector<int> &cf_h) {
+  if (type == 8 || type == 9) {
+    dist_pmis(comm, starts, n, ia, gj, strong, ring, hslot, cf, cf_h);
+    return;
+  }
+  MI_REQUIRE(type == 10 || type == 11 || type == 1, "distributed setup: coarsening type without a distributed form");
+  const gidx s = starts[(size_t)comm.rank];
+  Strength Sl;
+  Sl.ia.assign((size_t)n + 1, 0);
+  for (int i = 0; i < n; i++) {
+    int64_t c = 0;
+    for (int64_t k = ia[(size_t)i]; k < ia[(size_t)i + 1]; k++) c += ((!strong || strong[(size_t)k]) && hslot[(size_t)k] < 0);
+    Sl.ia[(size_t)i + 1] = Sl.ia[(size_t)i] + c;
+  }
+  Sl.ja.resize((size_t)Sl.ia[(size_t)n]);
+  parallel_for(n, [&](int64_t b, int64_t en, int) {
+    for (int64_t i = b; i < en; i++) {
+      int64_t w = Sl.ia[(size_t)i];
+      for (int64_t k = ia[(size_t)i]; k < ia[(size_t)i + 1]; k++)
+        if ((!strong || strong[(size_t)k]) && hslot[(size_t)k] < 0) Sl.ja[(size_t)w++] = (int)(gj[(size_t)k] - s);
+    }
+  });
+  std::vector<int> cf0;
+  if (n > 0) ruge_stueben(n, Sl, type == 1, cf0);
+  if (type == 10) {
+    dist_pmis(comm, starts, n, ia, gj, strong, ring, hslot, cf, cf_h, &cf0);
+  } else {
+    cf.swap(cf0);
+    cf_h = ring.forward(comm, cf);
+  }
+}
+
 // Second stage of aggressive coarsening on N ranks (par_strength.c hypre_BoomerAMGCreate2ndS with num_paths 1, then
 // hypre_BoomerAMGCorrectCFMarker; oracle/oracle.c second_strength / coarsen_aggressive; src/HypreSystem.cpp:215-219).
 // The C points of the first PMIS get global ids in fine order (owner of the point = owner of the id); C point i
@@ -1263,7 +1338,7 @@ void dist_pmis(Comm &comm, const std::vector<gidx> &starts, int n, const std::ve
 // lists of first-stage coarse ids; the graph's rows are sorted global ids, its remote columns (C points up to two
 // rings away) get a plan of their own, and the same distributed PMIS runs on it with the random stream indexed by
 // the coarse id.  A first-stage C point the second stage rejects takes the second stage's verdict.
-void dist_second_stage(Comm &comm, const std::vector<gidx> &starts, const GlobCSR &A, const std::vector<char> &strong,
+void dist_second_stage(Comm &comm, int type, const std::vector<gidx> &starts, const GlobCSR &A, const std::vector<char> &strong,
                        const Ring &ring, const std::vector<int> &hslot, std::vector<int> &cf, std::vector<int> &cf_h) {
   const int rank = comm.rank, size = comm.size;
   const int n = A.nrows;
@@ -1370,7 +1445,7 @@ void dist_second_stage(Comm &comm, const std::vector<gidx> &starts, const GlobCS
   });
   g_ext_rows_max = std::max<long long>(g_ext_rows_max, nc1 + (long long)ring2.ids.size());
   std::vector<int> cf2, cf2_h;
-  dist_pmis(comm, st1, (int)nc1, G.ia, G.gj, nullptr, ring2, hslot2, cf2, cf2_h);
+  dist_coarsen(comm, type, st1, (int)nc1, G.ia, G.gj, nullptr, ring2, hslot2, cf2, cf2_h);
   for (long long q = 0; q < nc1; q++)
     if (cf2[(size_t)q] != C_PT) cf[(size_t)crow[(size_t)q]] = cf2[(size_t)q];
   cf_h = ring.forward(comm, cf);
@@ -1588,6 +1663,9 @@ bool BoomerAMG::can_build_distributed() const {
   // PMIS splittings, every interpolation this library has (multipass and the second-generation PMIS of aggressive
   // levels pass by pass with halo rows since round 3), Galerkin or non-Galerkin coarse operators.  The Ruge-Stueben
   // family and CLJP are sequential sweeps over the GLOBAL graph in this library's specification: replicated.
+  // Coarsening types 10 / 11 / 1 are PER-RANK algorithms by HYPRE's definition (dist_coarsen): only the distributed
+  // setup builds them on N > 1, whatever the switch says.
+  if (p.coarsen_type == 10 || p.coarsen_type == 11 || p.coarsen_type == 1) return true;
   return !forced_off && (p.coarsen_type == 8 || p.coarsen_type == 9);
 }
 
@@ -1616,7 +1694,7 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
   // (aggressive levels come first and are host passes -- second-generation PMIS, multipass interpolation -- and the
   // device loop cannot resume after a host level: hierarchies with aggressive levels stay on the host loop)
   const bool dev_candidate = dev_enabled && device_min_rows >= 0 && ctx().inited && (p.interp_type == 6 || p.interp_type == 0) &&
-                             p.agg_num_levels <= 0;
+                             p.agg_num_levels <= 0 && (p.coarsen_type == 8 || p.coarsen_type == 9);  // (PMIS is what the device loop runs)
   const bool dev_path = dev_candidate && smallest_piece(A0.nrows) >= std::max<long long>(1, device_min_rows);
   sk::DCsr dD0;  // the diag block of A0 in the setup format, when the device path starts from the copy in HBM
   if (dev_path && A0.on_device && A0.d_diag.nrows == A0.nrows && A0.d_diag.nnz == A0.diag.nnz() && !A0.d_diag.rowmap.p)
@@ -1809,14 +1887,14 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
     tp0 = wall_time();
     tsub = tp0;
     std::vector<int> cf, cf_h;
-    dist_pmis(comm, Lv.starts, n, A.ia, A.gj, Lv.strong.data(), ring, hslot, cf, cf_h);
+    dist_coarsen(comm, p.coarsen_type, Lv.starts, n, A.ia, A.gj, Lv.strong.data(), ring, hslot, cf, cf_h);
     lap("pmis: rounds");
     // aggressive level (level < agg_num_levels, src/HypreSystem.cpp:215-219): the C points are coarsened once more on
     // the second-generation graph; interpolation is multipass there (and wherever interp_type 4 asks for it)
     const bool aggressive = l < p.agg_num_levels;
     const bool multipass = aggressive || p.interp_type == 4;
     if (aggressive) {
-      dist_second_stage(comm, Lv.starts, A, Lv.strong, ring, hslot, cf, cf_h);
+      dist_second_stage(comm, p.coarsen_type, Lv.starts, A, Lv.strong, ring, hslot, cf, cf_h);
       lap("pmis: second generation");
     }
     long long nc_loc = 0;

@@ -20,6 +20,8 @@ void strength(const ParCSR &A, double theta, double max_row_sum, Strength &S);
 void build_interp(const ParCSR &A, const Strength &S, std::vector<int> &cf, int interp_type, double trunc_factor,
                   int pmax, HostCSR &P, int &nc_out, const std::vector<char> *want_rows = nullptr);
 
+// classical Ruge-Stueben coarsening of a graph (first pass; second_pass: strong F-F pairs must share a C point)
+void ruge_stueben(int n, const Strength &S, bool second_pass, std::vector<int> &cf);
 // truncation of one interpolation row in place (trunc_factor, pmax; rescaled to the row sum, stored order kept): new length
 int truncate_row(int len, int *cols, double *vals, double trunc_factor, int pmax, std::vector<char> &keep);
 

@@ -487,8 +487,9 @@ static void rs_remove(rs_lists *q, int m, int i) {
  * F point i the first strong F neighbour j without a common C point tentatively becomes C, a second one makes
  * i itself C and j F again.
  * coarsen_type 10 (HMIS) = first pass, then PMIS on what is left undecided, 6 (Falgout) = both passes, then
- * CLJP on what is left: coarsening here sees the whole graph (the hierarchy does not depend
- * on the row partition), where the first pass decides every point and nothing is left -- as on one HYPRE rank. */
+ * CLJP on what is left: on ONE part the first pass decides every point and nothing is left -- as on one HYPRE rank.
+ * On several parts 10 / 11 / 1 run this routine per part (coarsen_by_type_parts below, HYPRE's per-processor
+ * definition); 6 / 3 keep seeing the whole graph. */
 static void ruge_stueben(int n, const obig *Sia, const int *Sja, int second_pass, int *cf) {
   obig *Tia;
   int *Tja;
@@ -737,6 +738,128 @@ static int coarsen_by_type(int type, int n, const obig *Sia, const int *Sja, int
   return -1;
 }
 
+/* PMIS started from a given splitting (par_coarsen.c hypre_BoomerAMGCoarsenPMIS with CF_init = 1; the second half
+ * of HMIS): points marked C stay C unless they are BOUNDARY points -- rows with a strong connection into another
+ * part -- which, like every F point, become undecided again; the kept C points act as the first independent set
+ * (undecided points that strongly depend on one of them become F before the first selection), then the ordinary
+ * PMIS rounds run on what is left, on the GLOBAL graph with the one global random stream. */
+static void pmis_from(int n, const obig *Sia, const int *Sja, const int *part_of, int *cf) {
+  double *measure = (double *)xcalloc((size_t)n, sizeof(double));
+  for (int i = 0; i < n; i++)
+    for (obig k = Sia[i]; k < Sia[i + 1]; k++) measure[Sja[k]] += 1.0;
+  oracle_rand_seed(2747);
+  for (int i = 0; i < n; i++) measure[i] += oracle_rand();
+  int *graph = (int *)xmalloc(sizeof(int) * (size_t)n);
+  int *tmp = (int *)xmalloc(sizeof(int) * (size_t)n);
+  int ng = 0;
+  for (int i = 0; i < n; i++) {
+    int boundary = 0;
+    for (obig k = Sia[i]; k < Sia[i + 1]; k++)
+      if (part_of[Sja[k]] != part_of[i]) boundary = 1;
+    if (Sia[i + 1] == Sia[i]) {
+      cf[i] = SF_PT;
+      measure[i] = 0.0;
+    } else if (cf[i] == C_PT && !boundary) {
+      measure[i] = 0.0; /* kept */
+    } else if (measure[i] < 1.0) {
+      cf[i] = F_PT;
+      measure[i] = 0.0;
+    } else
+      cf[i] = 0;
+  }
+  for (int i = 0; i < n; i++) { /* the kept C points are the first independent set */
+    if (cf[i] != 0) continue;
+    int dep = 0;
+    for (obig k = Sia[i]; k < Sia[i + 1] && !dep; k++) dep = cf[Sja[k]] == C_PT;
+    if (dep) tmp[i] = 2;
+    else tmp[i] = 3;
+  }
+  for (int i = 0; i < n; i++) {
+    if (cf[i] != 0) continue;
+    if (tmp[i] == 2) {
+      cf[i] = F_PT;
+      measure[i] = 0.0;
+    } else
+      graph[ng++] = i;
+  }
+  while (ng > 0) {
+    for (int g = 0; g < ng; g++) tmp[graph[g]] = 1;
+    for (int g = 0; g < ng; g++) {
+      int i = graph[g];
+      for (obig k = Sia[i]; k < Sia[i + 1]; k++) {
+        int j = Sja[k];
+        if (cf[j] != 0) continue;
+        if (measure[i] > measure[j])
+          tmp[j] = 0;
+        else if (measure[j] > measure[i])
+          tmp[i] = 0;
+      }
+    }
+    for (int g = 0; g < ng; g++) {
+      int i = graph[g];
+      if (tmp[i] == 1) {
+        cf[i] = C_PT;
+        measure[i] = 0.0;
+      }
+    }
+    for (int g = 0; g < ng; g++) {
+      int i = graph[g];
+      if (cf[i] != 0) continue;
+      for (obig k = Sia[i]; k < Sia[i + 1]; k++)
+        if (cf[Sja[k]] == C_PT) {
+          tmp[i] = 2;
+          break;
+        }
+    }
+    int m = 0;
+    for (int g = 0; g < ng; g++) {
+      int i = graph[g];
+      if (cf[i] != 0) continue;
+      if (tmp[i] == 2) {
+        cf[i] = F_PT;
+        measure[i] = 0.0;
+      } else
+        graph[m++] = i;
+    }
+    ng = m;
+  }
+  free(measure);
+  free(graph);
+  free(tmp);
+}
+
+/* The coarsening types HYPRE defines PER PROCESSOR, on more than one part (par_coarsen.c hypre_BoomerAMGCoarsenRuge /
+ * hypre_BoomerAMGCoarsenHMIS): 11 = first Ruge-Stueben pass and 1 = both passes on every part's own graph (the strong
+ * connections inside the part; "no boundary treatment"), 10 = HMIS = the first pass per part, then PMIS from that
+ * state on the global graph (pmis_from).  On one part these are the global routines above.  Types 6 and 3 (Falgout,
+ * a third pass on the boundary) keep their global form here, as do PMIS and CLJP. */
+static int coarsen_by_type_parts(int type, int n, const obig *Sia, const int *Sja, const int *part_of, int nparts,
+                                 const obig *ps, int *cf) {
+  int used = 0;
+  for (int q = 0; q < nparts; q++) used += ps[q + 1] > ps[q];
+  if (used <= 1 || !(type == 10 || type == 11 || type == 1)) return coarsen_by_type(type, n, Sia, Sja, cf);
+  for (int q = 0; q < nparts; q++) {
+    const int lo = (int)ps[q], m = (int)(ps[q + 1] - ps[q]);
+    if (m == 0) continue;
+    obig *ia = (obig *)xcalloc((size_t)m + 1, sizeof(obig));
+    for (int i = 0; i < m; i++) {
+      obig c = 0;
+      for (obig k = Sia[lo + i]; k < Sia[lo + i + 1]; k++) c += (Sja[k] >= lo && Sja[k] < lo + m);
+      ia[i + 1] = ia[i] + c;
+    }
+    int *ja = (int *)xmalloc(sizeof(int) * (size_t)(ia[m] ? ia[m] : 1));
+    obig w = 0;
+    for (int i = 0; i < m; i++)
+      for (obig k = Sia[lo + i]; k < Sia[lo + i + 1]; k++)
+        if (Sja[k] >= lo && Sja[k] < lo + m) ja[w++] = Sja[k] - lo;
+    ruge_stueben(m, ia, ja, type == 1, cf + lo);
+    free(ia);
+    free(ja);
+  }
+  if (type == 10) pmis_from(n, Sia, Sja, part_of, cf);
+  return 0;
+}
+
 /* Second-generation strength graph of aggressive coarsening (par_strength.c hypre_BoomerAMGCreate2ndS,
  * num_paths 1 = "A2"): a graph on the C points of the first coarsening -- C point i depends on C point j != i
  * iff j is in S_i or in S_k for some k in S_i (a strong path of length at most two).  Rows and columns are
@@ -787,13 +910,28 @@ static void second_strength(int n, const obig *Sia, const int *Sja, const int *c
  * coarsen with S, coarsen the resulting C points again with the second-generation graph, and keep as C only
  * what survives both (hypre_BoomerAMGCorrectCFMarker); a first-stage C point the second stage rejects takes the
  * second stage's verdict (F, or special F when it has no second-generation connection). */
-static int coarsen_aggressive(int type, int n, const obig *Sia, const int *Sja, int *cf) {
-  if (coarsen_by_type(type, n, Sia, Sja, cf)) return -1;
+static int coarsen_aggressive(int type, int n, const obig *Sia, const int *Sja, const int *part_of, int nparts,
+                              const obig *ps, int *cf) {
+  if (coarsen_by_type_parts(type, n, Sia, Sja, part_of, nparts, ps, cf)) return -1;
   obig *S2ia;
   int *S2ja, nc;
   second_strength(n, Sia, Sja, cf, &S2ia, &S2ja, &nc);
   int *cf2 = (int *)xmalloc(sizeof(int) * (size_t)(nc ? nc : 1));
-  coarsen_by_type(type, nc, S2ia, S2ja, cf2);
+  /* the first-stage C points keep their owners: partition of the second-generation graph */
+  obig *ps2 = (obig *)xcalloc((size_t)nparts + 1, sizeof(obig));
+  int *part2 = (int *)xmalloc(sizeof(int) * (size_t)(nc ? nc : 1));
+  {
+    int q2 = 0;
+    for (int i = 0; i < n; i++)
+      if (cf[i] == C_PT) {
+        part2[q2++] = part_of[i];
+        ps2[part_of[i] + 1]++;
+      }
+    for (int q = 0; q < nparts; q++) ps2[q + 1] += ps2[q];
+  }
+  coarsen_by_type_parts(type, nc, S2ia, S2ja, part2, nparts, ps2, cf2);
+  free(ps2);
+  free(part2);
   int q = 0;
   for (int i = 0; i < n; i++)
     if (cf[i] == C_PT) {
@@ -1497,11 +1635,12 @@ oamg *oamg_setup(const ocsr *A0, const oamg_params *p) {
     tt = now_s();
     int *part_of = part_of_rows(n, nparts, L->part_starts);
     int *cf = (int *)xmalloc(sizeof(int) * (size_t)n);
-    /* coarsening and interpolation are GLOBAL algorithms (independent of the row partition) */
+    /* coarsening and interpolation are GLOBAL algorithms (independent of the row partition) -- but for the coarsening
+     * types HYPRE defines per processor (10, 11, 1: coarsen_by_type_parts) */
     int *one_part = (int *)xcalloc((size_t)n, sizeof(int));
     const int aggressive = l < p->agg_num_levels;
-    const int bad = aggressive ? coarsen_aggressive(p->coarsen_type, n, Sia, Sja, cf)
-                               : coarsen_by_type(p->coarsen_type, n, Sia, Sja, cf);
+    const int bad = aggressive ? coarsen_aggressive(p->coarsen_type, n, Sia, Sja, part_of, nparts, L->part_starts, cf)
+                               : coarsen_by_type_parts(p->coarsen_type, n, Sia, Sja, part_of, nparts, L->part_starts, cf);
     if (bad || (aggressive && p->agg_interp_type != 4)) {
       fprintf(stderr, "oracle: coarsen_type %d / agg_interp_type %d is not restated\n", p->coarsen_type,
               p->agg_interp_type);

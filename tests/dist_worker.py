@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--ng", type=float, default=0.0, help="non_galerkin_tol (0 = Galerkin coarse operators)")
     ap.add_argument("--agg", type=int, default=0, help="agg_num_levels (aggressive coarsening + multipass interpolation)")
     ap.add_argument("--interp", type=int, default=-1, help="interp_type (-1 = library default)")
+    ap.add_argument("--coarsen", type=int, default=-1, help="coarsen_type (-1 = library default)")
     ap.add_argument("--aggtrunc", type=float, default=0.0, help="agg_trunc_factor")
     ap.add_argument("--aggpmax", type=int, default=0, help="agg_pmax_elmts")
     ap.add_argument("--combo", type=int, default=-1,
@@ -111,6 +112,8 @@ def main():
             smooth_o["agg_pmax_elmts"] = args.aggpmax
     if args.interp >= 0:
         smooth_o["interp_type"] = args.interp
+    if args.coarsen >= 0:
+        smooth_o["coarsen_type"] = args.coarsen
     if args.combo >= 0:
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
         from test_gpu_amg import _combo
@@ -150,7 +153,7 @@ def main():
     order = np.arange(starts[rank + 1] - starts[rank])
     Ao_used, bo_used = Ao, bo
     # (the replicated setup -- every coarsening but PMIS -- does not renumber on N > 1 ranks)
-    by_replication = size > 1 and (smooth_o.get("coarsen_type", 8) not in (8, 9)
+    by_replication = size > 1 and (smooth_o.get("coarsen_type", 8) not in (8, 9, 10, 11, 1)
                                    or os.environ.get("MI_HYPRE_REPLICATED_SETUP", "0") not in ("", "0"))
     if args.locality and by_replication:
         assert not amg.input_ordering()[0]
@@ -180,10 +183,13 @@ def main():
         return v.value
 
     replicated = os.environ.get("MI_HYPRE_REPLICATED_SETUP", "0") not in ("", "0")
-    # every coarsening but PMIS (the Ruge-Stueben family, CLJP: sequential sweeps over the global graph) is built by
-    # the replicated setup; PMIS with any interpolation, aggressive levels included, by the distributed one
-    if smooth_o.get("coarsen_type", 8) not in (8, 9):
+    # Falgout / three-pass Ruge-Stueben and CLJP (sequential sweeps over the global graph) are built by the replicated
+    # setup; PMIS and the per-rank types (10 HMIS, 11 / 1 Ruge-Stueben on every rank's own graph) with any
+    # interpolation, aggressive levels included, by the distributed one -- the per-rank types whatever the switch says
+    if smooth_o.get("coarsen_type", 8) not in (8, 9, 10, 11, 1):
         replicated = True
+    if smooth_o.get("coarsen_type", 8) in (10, 11, 1):
+        replicated = False
     if size > 1 and not replicated:
         assert counter("setup_distributed") >= 1, "the distributed setup did not run"
         # per-rank memory: the largest extended sub-problem is this rank's rows plus two halo rings (for z-slabs of

@@ -18,7 +18,7 @@ WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
 
 
 def _run(nproc, mode, n, stencil, port, staging="host", seq=-1, devmin=None, golden="", replicated=False, locality=0,
-         smooth=0, relax=0, combo=-1, transport="", ng=0.0, agg=0, interp=-1, aggtrunc=0.0, aggpmax=0):
+         smooth=0, relax=0, combo=-1, transport="", ng=0.0, agg=0, interp=-1, aggtrunc=0.0, aggpmax=0, coarsen=-1):
     env = dict(os.environ)
     env["MI_HYPRE_REPLICATED_SETUP"] = "1" if replicated else "0"
     if devmin is not None:  # levels with at least this many rows are built (and sliced) on the device
@@ -48,6 +48,8 @@ def _run(nproc, mode, n, stencil, port, staging="host", seq=-1, devmin=None, gol
         cmd += ["--agg", str(agg), "--aggtrunc", str(aggtrunc), "--aggpmax", str(aggpmax)]
     if interp >= 0:
         cmd += ["--interp", str(interp)]
+    if coarsen >= 0:
+        cmd += ["--coarsen", str(coarsen)]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-4000:]
     return p.stdout
@@ -102,10 +104,27 @@ def test_host_setup_aggressive_levels_distributed_gloo(nproc, n, stencil, seq, a
     assert "dist host setup ok" in out
 
 
+@pytest.mark.parametrize("nproc,n,stencil,seq,coarsen,agg,interp,ng,locality",
+                         [(2, 12, 7, 0, 10, 0, -1, 0.0, 0), (2, 12, 7, 0, 11, 0, -1, 0.0, 0), (2, 12, 7, 0, 1, 0, -1, 0.0, 0),
+                          (3, 10, 27, 0, 10, 0, -1, 0.0, 0), (4, 12, 7, 100, 10, 1, -1, 0.0, 0),  # HMIS on the second-generation graph
+                          (8, 10, 7, 0, 10, 0, -1, 0.0, 0), (3, 12, 7, 0, 11, 0, 0, 0.0, 1),
+                          (4, 8, 27, 0, 1, 2, -1, 0.0, 0), (2, 14, 7, 200, 10, 0, -1, 0.05, 1)])
+def test_host_setup_per_rank_coarsening_types_distributed_gloo(nproc, n, stencil, seq, coarsen, agg, interp, ng, locality):
+    """The coarsening types HYPRE defines PER PROCESSOR (the reference passes coarsen_type through,
+    /root/reference/src/HypreSystem.cpp:126, etc/hypre_app.yaml:35): 11 / 1 = one / two Ruge-Stueben passes on every
+    rank's own graph, 10 = HMIS = the first pass per rank, then PMIS from that state on the global graph (interior C
+    points kept as the first independent set, boundary and F points decided again).  Built by the distributed setup
+    (local Ruge-Stueben + the distributed PMIS with an initial state); the oracle emulates the partition the same way."""
+    out = _run(nproc, "host", n, stencil, 30511 + nproc + n + coarsen, seq=seq, coarsen=coarsen, agg=agg, interp=interp, ng=ng,
+               locality=locality)
+    assert "dist host setup ok" in out
+
+
 @pytest.mark.parametrize("nproc,n,stencil,seq", [(2, 12, 7, -1), (3, 10, 27, 0), (4, 6, 7, 0)])
 def test_host_setup_replicated_path_gloo(nproc, n, stencil, seq):
     """The replicated setup (every rank builds the global hierarchy and keeps its slices) stays the path of the
-    Ruge-Stueben family and CLJP on N > 1; MI_HYPRE_REPLICATED_SETUP=1 forces it."""
+    global sequential coarsenings (Falgout / three-pass Ruge-Stueben 6 / 3, CLJP 0 / 7) on N > 1;
+    MI_HYPRE_REPLICATED_SETUP=1 forces it for PMIS."""
     out = _run(nproc, "host", n, stencil, 29911 + nproc + n, seq=seq, replicated=True)
     assert "dist host setup ok" in out
 
@@ -174,6 +193,15 @@ def test_device_solve_aggressive_levels_distributed_shared_gpu(nproc, n, stencil
     """Aggressive levels / multipass interpolation built by the distributed setup (host loop also with the device
     threshold at 0), then the device solve on N ranks: hierarchy, iterations, residual history, solution vs the oracle."""
     out = _run(nproc, "solve", n, stencil, 30451 + nproc + n + agg, seq=seq, agg=agg, interp=interp, devmin=devmin)
+    assert "dist solve ok" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,n,stencil,seq,coarsen,agg", [(2, 16, 7, 0, 10, 0), (3, 14, 27, 0, 11, 0), (4, 16, 7, 300, 10, 1)])
+def test_device_solve_per_rank_coarsening_types_shared_gpu(nproc, n, stencil, seq, coarsen, agg):
+    """HMIS / per-rank Ruge-Stueben hierarchies from the distributed setup, then the device solve on N ranks:
+    hierarchy, iterations, residual history, solution against the oracle's emulation of the partition."""
+    out = _run(nproc, "solve", n, stencil, 30551 + nproc + n + coarsen, seq=seq, coarsen=coarsen, agg=agg)
     assert "dist solve ok" in out
 
 
