@@ -29,7 +29,8 @@
 // Below the redundancy threshold (HYPRE_BoomerAMGSetSeqThreshold) the level is gathered and every rank builds
 // the small remaining hierarchy for itself, as before.  Aggressive levels (second-generation PMIS on the C points,
 // multipass interpolation pass by pass with the halo rows of the previous pass) are distributed too (host loop).
-// Ruge-Stueben coarsening and CLJP are sequential sweeps over the global graph: on N > 1 they keep the replicated path.
+// HMIS / per-rank Ruge-Stueben / Falgout (dist_coarsen) and CLJP (dist_cljp) are host passes of this file too; only
+// coarsening type 3 (a third Ruge-Stueben pass on the boundary) keeps the replicated path on N > 1.
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -1292,6 +1293,224 @@ void dist_pmis(Comm &comm, const std::vector<gidx> &starts, int n, const std::ve
 }
 
 
+// CLJP on a distributed graph (par_coarsen.c hypre_BoomerAMGCoarsen; oracle/oracle.c cljp, cljp_from; host form:
+// hs::cljp): w = |S^T_i| + the global random stream; rounds of { independent set of the undecided points -> C;
+// H1: edges out of a new C point leave, w-- at their undecided ends; H2: an undecided row loses its edges to C points,
+// and the edges to undecided points that share one of its C points, w-- there; w < 1 -> F }.  Within a round every
+// step reads what the previous one left and the decrements are integers, so the round is the sequential one whatever
+// the partition: decrements of halo points travel back to their owners, the weights and states of the halo points
+// forward.  The strong rows of the halo points (needed by H2) are fetched once.
+// init (Falgout, coarsen_type 6): INTERIOR rows keep the verdict of the per-rank Ruge-Stueben passes and stop voting
+// (their edges leave before the first selection), BOUNDARY rows -- a strong connection to another rank -- are decided
+// here, H2 runs once with the kept C points (oracle cljp_from).
+void dist_cljp(Comm &comm, const std::vector<gidx> &starts, int n, const std::vector<int64_t> &ia, const std::vector<gidx> &gj,
+               const char *strong, const Ring &ring, const std::vector<int> &hslot, std::vector<int> &cf, std::vector<int> &cf_h,
+               const std::vector<int> *init = nullptr) {
+  const gidx s = starts[(size_t)comm.rank];
+  const int nh = (int)ring.ids.size();
+  auto is_strong = [&](int64_t k) { return !strong || strong[(size_t)k] != 0; };
+  // strong rows of the halo points, global column ids
+  std::vector<int64_t> hoff((size_t)nh + 1, 0);
+  std::vector<gidx> hcol;
+  {
+    const std::vector<std::vector<char>> rec = ring.forward_records(comm, [&](int row, std::vector<char> &buf) {
+      int cnt = 0;
+      for (int64_t k = ia[(size_t)row]; k < ia[(size_t)row + 1]; k++) cnt += is_strong(k);
+      put1<int>(buf, cnt);
+      for (int64_t k = ia[(size_t)row]; k < ia[(size_t)row + 1]; k++)
+        if (is_strong(k)) put1<gidx>(buf, gj[(size_t)k]);
+    });
+    for (size_t pi = 0; pi < rec.size(); pi++) {
+      Reader rd(rec[pi]);
+      for (int q = ring.recv_starts[pi]; q < ring.recv_starts[pi + 1]; q++) {
+        const int len = rd.get<int>();
+        hoff[(size_t)q + 1] = len;
+        const size_t o = hcol.size();
+        hcol.resize(o + (size_t)len);
+        rd.get(hcol.data() + o, (size_t)len);
+      }
+    }
+    for (int q = 0; q < nh; q++) hoff[(size_t)q + 1] += hoff[(size_t)q];
+  }
+  // weights
+  std::vector<int> cnt((size_t)n, 0), cnt_h((size_t)nh, 0);
+  parallel_for(n, [&](int64_t b, int64_t en, int) {
+    for (int64_t i = b; i < en; i++)
+      for (int64_t k = ia[(size_t)i]; k < ia[(size_t)i + 1]; k++) {
+        if (!is_strong(k)) continue;
+        int *slot = hslot[(size_t)k] < 0 ? &cnt[(size_t)(gj[(size_t)k] - s)] : &cnt_h[(size_t)hslot[(size_t)k]];
+        __atomic_fetch_add(slot, 1, __ATOMIC_RELAXED);
+      }
+  });
+  ring.reverse(comm, cnt_h, cnt, [](int &mine, int v) { mine += v; });
+  std::vector<double> measure((size_t)n, 0.0);
+  parallel_for(n, [&](int64_t b, int64_t en, int) {
+    if (b >= en) return;
+    int seed = park_miller_at(2747, s + b);
+    for (int64_t i = b; i < en; i++) {
+      if (i > b) {
+        const int a = 16807, m = 2147483647, q = 127773, r = 2836;
+        const int lo = seed % q, hi = seed / q;
+        const int t = a * lo - r * hi;
+        seed = (t > 0) ? t : t + m;
+      }
+      measure[(size_t)i] = (double)cnt[(size_t)i] + (double)seed / 2147483647;
+    }
+  });
+  const int64_t nnz = ia.empty() ? 0 : ia[(size_t)n];
+  std::vector<char> gone((size_t)nnz, 0), interior((size_t)n, 0);
+  std::vector<int> dec((size_t)n, 0), dec_h((size_t)nh, 0);
+  cf.assign((size_t)n, 0);
+  std::vector<int> graph;
+  for (int i = 0; i < n; i++) {
+    bool any = false, boundary = false;
+    for (int64_t k = ia[(size_t)i]; k < ia[(size_t)i + 1]; k++) {
+      if (!is_strong(k)) continue;
+      any = true;
+      boundary = boundary || hslot[(size_t)k] >= 0;
+    }
+    if (init && !boundary) {
+      interior[(size_t)i] = 1;
+      cf[(size_t)i] = (*init)[(size_t)i];
+    } else if (measure[(size_t)i] < 1.0)
+      cf[(size_t)i] = any ? F_PT : SF_PT;
+    else
+      graph.push_back(i);
+  }
+  cf_h = ring.forward(comm, cf);
+  std::vector<double> m_h = ring.forward(comm, measure);
+  auto dec_end = [&](int64_t k) {  // one decrement at the undecided end of entry k
+    const int h = hslot[(size_t)k];
+    if (h < 0) {
+      const int j = (int)(gj[(size_t)k] - s);
+      if (cf[(size_t)j] == 0) __atomic_fetch_add(&dec[(size_t)j], 1, __ATOMIC_RELAXED);
+    } else if (cf_h[(size_t)h] == 0)
+      __atomic_fetch_add(&dec_h[(size_t)h], 1, __ATOMIC_RELAXED);
+  };
+  if (init)  // decided points no longer vote (an interior row has no halo ends)
+    parallel_for(n, [&](int64_t b, int64_t en, int) {
+      for (int64_t i = b; i < en; i++) {
+        if (!interior[(size_t)i]) continue;
+        for (int64_t k = ia[(size_t)i]; k < ia[(size_t)i + 1]; k++) {
+          if (!is_strong(k)) continue;
+          gone[(size_t)k] = 1;
+          dec_end(k);
+        }
+      }
+    });
+  std::vector<signed char> tmp((size_t)n, 0);
+  for (int round = init ? 0 : 1;; round++) {
+    if (round > 0) {
+      long long left = (long long)graph.size();
+      comm.allreduce_host(&left, 1, CommDType::I64, CommOp::SUM);
+      if (left == 0) break;
+    }
+    const int64_t ng = (int64_t)graph.size();
+    if (round > 0) {
+      std::vector<int> lose_h((size_t)nh, 1);
+      parallel_for(ng, [&](int64_t b, int64_t en, int) {
+        for (int64_t q = b; q < en; q++) tmp[(size_t)graph[(size_t)q]] = 1;
+      });
+      parallel_for(ng, [&](int64_t b, int64_t en, int) {
+        for (int64_t q = b; q < en; q++) {
+          const int g = graph[(size_t)q];
+          const double mi_ = measure[(size_t)g];
+          bool lost = false;
+          for (int64_t k = ia[(size_t)g]; k < ia[(size_t)g + 1]; k++) {
+            if (!is_strong(k)) continue;
+            const int h = hslot[(size_t)k];
+            if (h < 0) {
+              const int j = (int)(gj[(size_t)k] - s);
+              if (cf[(size_t)j] != 0) continue;
+              if (mi_ > measure[(size_t)j])
+                __atomic_store_n(&tmp[(size_t)j], (signed char)0, __ATOMIC_RELAXED);
+              else if (measure[(size_t)j] > mi_)
+                lost = true;
+            } else {
+              if (cf_h[(size_t)h] != 0) continue;
+              if (mi_ > m_h[(size_t)h])
+                __atomic_store_n(&lose_h[(size_t)h], 0, __ATOMIC_RELAXED);
+              else if (m_h[(size_t)h] > mi_)
+                lost = true;
+            }
+          }
+          if (lost) __atomic_store_n(&tmp[(size_t)g], (signed char)0, __ATOMIC_RELAXED);
+        }
+      });
+      std::vector<int> keep((size_t)n, 1);
+      ring.reverse(comm, lose_h, keep, [](int &mine, int v) { mine = std::min(mine, v); });
+      parallel_for(ng, [&](int64_t b, int64_t en, int) {
+        for (int64_t q = b; q < en; q++) {
+          const int g = graph[(size_t)q];
+          if (!keep[(size_t)g]) tmp[(size_t)g] = 0;
+          if (tmp[(size_t)g] == 1) cf[(size_t)g] = C_PT;
+        }
+      });
+      cf_h = ring.forward(comm, cf);
+    }
+    // H1 (rows of this round's C points) and H2 (undecided rows): disjoint rows, decrements collected in dec / dec_h
+    parallel_for(ng, [&](int64_t b, int64_t en, int) {
+      std::vector<gidx> crow;  // C points in the row of i (ascending, like the row)
+      for (int64_t q = b; q < en; q++) {
+        const int i = graph[(size_t)q];
+        if (cf[(size_t)i] == C_PT) {
+          for (int64_t k = ia[(size_t)i]; k < ia[(size_t)i + 1]; k++) {
+            if (!is_strong(k) || gone[(size_t)k]) continue;
+            gone[(size_t)k] = 1;
+            dec_end(k);
+          }
+          continue;
+        }
+        crow.clear();
+        for (int64_t k = ia[(size_t)i]; k < ia[(size_t)i + 1]; k++) {
+          if (!is_strong(k)) continue;
+          const int h = hslot[(size_t)k];
+          if ((h < 0 ? cf[(size_t)(gj[(size_t)k] - s)] : cf_h[(size_t)h]) == C_PT) {
+            gone[(size_t)k] = 1;
+            crow.push_back(gj[(size_t)k]);
+          }
+        }
+        if (crow.empty()) continue;
+        for (int64_t k = ia[(size_t)i]; k < ia[(size_t)i + 1]; k++) {
+          if (!is_strong(k) || gone[(size_t)k]) continue;
+          const int h = hslot[(size_t)k];
+          bool shares = false;
+          if (h < 0) {
+            const int j = (int)(gj[(size_t)k] - s);
+            if (cf[(size_t)j] != 0) continue;
+            for (int64_t kk = ia[(size_t)j]; kk < ia[(size_t)j + 1] && !shares; kk++)
+              shares = is_strong(kk) && std::binary_search(crow.begin(), crow.end(), gj[(size_t)kk]);
+          } else {
+            if (cf_h[(size_t)h] != 0) continue;
+            for (int64_t t = hoff[(size_t)h]; t < hoff[(size_t)h + 1] && !shares; t++)
+              shares = std::binary_search(crow.begin(), crow.end(), hcol[(size_t)t]);
+          }
+          if (shares) {
+            gone[(size_t)k] = 1;
+            dec_end(k);
+          }
+        }
+      }
+    });
+    ring.reverse(comm, dec_h, dec, [](int &mine, int v) { mine += v; });
+    std::fill(dec_h.begin(), dec_h.end(), 0);
+    std::vector<int> next;
+    next.reserve(graph.size());
+    for (int64_t q = 0; q < ng; q++) {
+      const int i = graph[(size_t)q];
+      if (cf[(size_t)i] == C_PT) continue;
+      for (; dec[(size_t)i] > 0; dec[(size_t)i]--) measure[(size_t)i] -= 1.0;  // one at a time, as the oracle does
+      if (measure[(size_t)i] < 1.0)
+        cf[(size_t)i] = F_PT;
+      else
+        next.push_back(i);
+    }
+    graph.swap(next);
+    cf_h = ring.forward(comm, cf);
+    m_h = ring.forward(comm, measure);
+  }
+}
+
 // Coarsening of a distributed graph by type.  8 / 9: PMIS.  The types HYPRE defines PER PROCESSOR (par_coarsen.c
 // hypre_BoomerAMGCoarsenRuge / ...HMIS; oracle/oracle.c coarsen_by_type_parts): 11 = first Ruge-Stueben pass and 1 = both
 // passes on this rank's own graph (strong connections between own points; no boundary treatment), 10 = HMIS = the
@@ -1304,7 +1523,11 @@ void dist_coarsen(Comm &comm, int type, const std::vector<gidx> &starts, int n, 
     dist_pmis(comm, starts, n, ia, gj, strong, ring, hslot, cf, cf_h);
     return;
   }
-  MI_REQUIRE(type == 10 || type == 11 || type == 1, "distributed setup: coarsening type without a distributed form");
+  if (type == 0 || type == 7) {  // CLJP: a global algorithm whose rounds commute -- the same splitting on any partition
+    dist_cljp(comm, starts, n, ia, gj, strong, ring, hslot, cf, cf_h);
+    return;
+  }
+  MI_REQUIRE(type == 10 || type == 11 || type == 1 || type == 6, "distributed setup: coarsening type without a distributed form");
   const gidx s = starts[(size_t)comm.rank];
   Strength Sl;
   Sl.ia.assign((size_t)n + 1, 0);
@@ -1322,9 +1545,11 @@ void dist_coarsen(Comm &comm, int type, const std::vector<gidx> &starts, int n, 
     }
   });
   std::vector<int> cf0;
-  if (n > 0) ruge_stueben(n, Sl, type == 1, cf0);
+  if (n > 0) ruge_stueben(n, Sl, type == 1 || type == 6, cf0);
   if (type == 10) {
     dist_pmis(comm, starts, n, ia, gj, strong, ring, hslot, cf, cf_h, &cf0);
+  } else if (type == 6) {  // Falgout: CLJP on the boundary from the interior verdicts
+    dist_cljp(comm, starts, n, ia, gj, strong, ring, hslot, cf, cf_h, &cf0);
   } else {
     cf.swap(cf0);
     cf_h = ring.forward(comm, cf);
@@ -1663,10 +1888,11 @@ bool BoomerAMG::can_build_distributed() const {
   // PMIS splittings, every interpolation this library has (multipass and the second-generation PMIS of aggressive
   // levels pass by pass with halo rows since round 3), Galerkin or non-Galerkin coarse operators.  The Ruge-Stueben
   // family and CLJP are sequential sweeps over the GLOBAL graph in this library's specification: replicated.
-  // Coarsening types 10 / 11 / 1 are PER-RANK algorithms by HYPRE's definition (dist_coarsen): only the distributed
-  // setup builds them on N > 1, whatever the switch says.
-  if (p.coarsen_type == 10 || p.coarsen_type == 11 || p.coarsen_type == 1) return true;
-  return !forced_off && (p.coarsen_type == 8 || p.coarsen_type == 9);
+  // Coarsening types 10 / 11 / 1 / 6 are PER-RANK algorithms by HYPRE's definition (dist_coarsen): only the distributed
+  // setup builds them on N > 1, whatever the switch says.  CLJP (0 / 7) is global and distributed like PMIS; type 3
+  // (a third Ruge-Stueben pass on the boundary) is the one left to the replicated setup.
+  if (p.coarsen_type == 10 || p.coarsen_type == 11 || p.coarsen_type == 1 || p.coarsen_type == 6) return true;
+  return !forced_off && (p.coarsen_type == 8 || p.coarsen_type == 9 || p.coarsen_type == 0 || p.coarsen_type == 7);
 }
 
 void BoomerAMG::build_distributed(ParCSR &A0) {

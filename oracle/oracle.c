@@ -828,16 +828,122 @@ static void pmis_from(int n, const obig *Sia, const int *Sja, const int *part_of
   free(tmp);
 }
 
+/* CLJP started from a given splitting (the second half of Falgout coarsening, coarsen_type 6, on more than one part:
+ * "Ruge-Stueben in the interior of every processor, then CLJP on the boundary with the interior C points as the first
+ * independent set").  HYPRE's own initialisation of hypre_BoomerAMGCoarsen with CF_init = 1 is not available here
+ * (parity unpinned like everything HYPRE-side); this is the rule both implementations share: INTERIOR points -- rows
+ * without a strong connection into another part -- keep the verdict of the per-part Ruge-Stueben passes, BOUNDARY
+ * points are decided by CLJP.  Decided points no longer vote: before the first selection the edges out of every
+ * interior row leave the graph (one decrement at each undecided end -- heuristic H1 applied to the kept points), and
+ * heuristic H2 runs once over the undecided rows with the kept C points.  Then the rounds of cljp above. */
+static void cljp_from(int n, const obig *Sia, const int *Sja, const int *part_of, int *cf) {
+  const obig nnz = Sia[n];
+  char *gone = (char *)xcalloc((size_t)(nnz ? nnz : 1), 1);
+  double *measure = (double *)xcalloc((size_t)n, sizeof(double));
+  for (obig k = 0; k < nnz; k++) measure[Sja[k]] += 1.0;
+  oracle_rand_seed(2747);
+  for (int i = 0; i < n; i++) measure[i] += oracle_rand();
+  int *graph = (int *)xmalloc(sizeof(int) * (size_t)n);
+  int *tmp = (int *)xcalloc((size_t)n, sizeof(int));
+  int *common = (int *)xcalloc((size_t)n, sizeof(int));
+  char *interior = (char *)xcalloc((size_t)(n ? n : 1), 1);
+  int ng = 0;
+  for (int i = 0; i < n; i++) {
+    int boundary = 0;
+    for (obig k = Sia[i]; k < Sia[i + 1]; k++)
+      if (part_of[Sja[k]] != part_of[i]) boundary = 1;
+    if (!boundary) {
+      interior[i] = 1; /* cf[i] stays what the Ruge-Stueben passes made it */
+    } else if (measure[i] < 1.0)
+      cf[i] = F_PT; /* (a boundary row is not empty) */
+    else {
+      cf[i] = 0;
+      graph[ng++] = i;
+    }
+  }
+  for (int i = 0; i < n; i++) { /* decided points no longer vote */
+    if (!interior[i]) continue;
+    for (obig k = Sia[i]; k < Sia[i + 1]; k++) {
+      gone[k] = 1;
+      if (cf[Sja[k]] == 0) measure[Sja[k]] -= 1.0;
+    }
+  }
+  for (int round = 0;; round++) {
+    if (round > 0) {
+      if (ng == 0) break;
+      for (int g = 0; g < ng; g++) tmp[graph[g]] = 1;
+      for (int g = 0; g < ng; g++) {
+        const int i = graph[g];
+        for (obig k = Sia[i]; k < Sia[i + 1]; k++) {
+          const int j = Sja[k];
+          if (cf[j] != 0) continue;
+          if (measure[i] > measure[j])
+            tmp[j] = 0;
+          else if (measure[j] > measure[i])
+            tmp[i] = 0;
+        }
+      }
+      for (int g = 0; g < ng; g++)
+        if (tmp[graph[g]] == 1) cf[graph[g]] = C_PT;
+      for (int g = 0; g < ng; g++) { /* H1 */
+        const int i = graph[g];
+        if (cf[i] != C_PT) continue;
+        for (obig k = Sia[i]; k < Sia[i + 1]; k++) {
+          if (gone[k]) continue;
+          gone[k] = 1;
+          if (cf[Sja[k]] == 0) measure[Sja[k]] -= 1.0;
+        }
+      }
+    }
+    for (int g = 0; g < ng; g++) { /* H2 (round 0: with the kept C points) */
+      const int i = graph[g];
+      if (cf[i] != 0) continue;
+      for (obig k = Sia[i]; k < Sia[i + 1]; k++)
+        if (cf[Sja[k]] == C_PT) {
+          gone[k] = 1;
+          common[Sja[k]] = i + 1;
+        }
+      for (obig k = Sia[i]; k < Sia[i + 1]; k++) {
+        const int j = Sja[k];
+        if (gone[k] || cf[j] != 0) continue;
+        for (obig kk = Sia[j]; kk < Sia[j + 1]; kk++)
+          if (common[Sja[kk]] == i + 1) {
+            gone[k] = 1;
+            measure[j] -= 1.0;
+            break;
+          }
+      }
+    }
+    int m = 0;
+    for (int g = 0; g < ng; g++) {
+      const int i = graph[g];
+      if (cf[i] == C_PT) continue;
+      if (measure[i] < 1.0)
+        cf[i] = F_PT;
+      else
+        graph[m++] = i;
+    }
+    ng = m;
+  }
+  free(gone);
+  free(measure);
+  free(graph);
+  free(tmp);
+  free(common);
+  free(interior);
+}
+
 /* The coarsening types HYPRE defines PER PROCESSOR, on more than one part (par_coarsen.c hypre_BoomerAMGCoarsenRuge /
  * hypre_BoomerAMGCoarsenHMIS): 11 = first Ruge-Stueben pass and 1 = both passes on every part's own graph (the strong
  * connections inside the part; "no boundary treatment"), 10 = HMIS = the first pass per part, then PMIS from that
- * state on the global graph (pmis_from).  On one part these are the global routines above.  Types 6 and 3 (Falgout,
- * a third pass on the boundary) keep their global form here, as do PMIS and CLJP. */
+ * state on the global graph (pmis_from), 6 = Falgout = both passes per part, then CLJP on the boundary points from
+ * that state (cljp_from).  On one part these are the global routines above.  Type 3 (a third pass on the boundary)
+ * keeps its global form here; PMIS and CLJP are global algorithms anyway. */
 static int coarsen_by_type_parts(int type, int n, const obig *Sia, const int *Sja, const int *part_of, int nparts,
                                  const obig *ps, int *cf) {
   int used = 0;
   for (int q = 0; q < nparts; q++) used += ps[q + 1] > ps[q];
-  if (used <= 1 || !(type == 10 || type == 11 || type == 1)) return coarsen_by_type(type, n, Sia, Sja, cf);
+  if (used <= 1 || !(type == 10 || type == 11 || type == 1 || type == 6)) return coarsen_by_type(type, n, Sia, Sja, cf);
   for (int q = 0; q < nparts; q++) {
     const int lo = (int)ps[q], m = (int)(ps[q + 1] - ps[q]);
     if (m == 0) continue;
@@ -852,11 +958,12 @@ static int coarsen_by_type_parts(int type, int n, const obig *Sia, const int *Sj
     for (int i = 0; i < m; i++)
       for (obig k = Sia[lo + i]; k < Sia[lo + i + 1]; k++)
         if (Sja[k] >= lo && Sja[k] < lo + m) ja[w++] = Sja[k] - lo;
-    ruge_stueben(m, ia, ja, type == 1, cf + lo);
+    ruge_stueben(m, ia, ja, type == 1 || type == 6, cf + lo);
     free(ia);
     free(ja);
   }
   if (type == 10) pmis_from(n, Sia, Sja, part_of, cf);
+  if (type == 6) cljp_from(n, Sia, Sja, part_of, cf);
   return 0;
 }
 

@@ -153,7 +153,7 @@ def main():
     order = np.arange(starts[rank + 1] - starts[rank])
     Ao_used, bo_used = Ao, bo
     # (the replicated setup -- every coarsening but PMIS -- does not renumber on N > 1 ranks)
-    by_replication = size > 1 and (smooth_o.get("coarsen_type", 8) not in (8, 9, 10, 11, 1)
+    by_replication = size > 1 and (smooth_o.get("coarsen_type", 8) not in (8, 9, 10, 11, 1, 6, 0, 7)
                                    or os.environ.get("MI_HYPRE_REPLICATED_SETUP", "0") not in ("", "0"))
     if args.locality and by_replication:
         assert not amg.input_ordering()[0]
@@ -183,12 +183,12 @@ def main():
         return v.value
 
     replicated = os.environ.get("MI_HYPRE_REPLICATED_SETUP", "0") not in ("", "0")
-    # Falgout / three-pass Ruge-Stueben and CLJP (sequential sweeps over the global graph) are built by the replicated
-    # setup; PMIS and the per-rank types (10 HMIS, 11 / 1 Ruge-Stueben on every rank's own graph) with any
-    # interpolation, aggressive levels included, by the distributed one -- the per-rank types whatever the switch says
-    if smooth_o.get("coarsen_type", 8) not in (8, 9, 10, 11, 1):
+    # three-pass Ruge-Stueben (type 3) is built by the replicated setup; PMIS, CLJP and the per-rank types (10 HMIS,
+    # 11 / 1 Ruge-Stueben on every rank's own graph, 6 Falgout) with any interpolation, aggressive levels included, by
+    # the distributed one -- the per-rank types whatever the switch says
+    if smooth_o.get("coarsen_type", 8) not in (8, 9, 10, 11, 1, 6, 0, 7):
         replicated = True
-    if smooth_o.get("coarsen_type", 8) in (10, 11, 1):
+    if smooth_o.get("coarsen_type", 8) in (10, 11, 1, 6):
         replicated = False
     if size > 1 and not replicated:
         assert counter("setup_distributed") >= 1, "the distributed setup did not run"

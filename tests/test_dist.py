@@ -108,13 +108,20 @@ def test_host_setup_aggressive_levels_distributed_gloo(nproc, n, stencil, seq, a
                          [(2, 12, 7, 0, 10, 0, -1, 0.0, 0), (2, 12, 7, 0, 11, 0, -1, 0.0, 0), (2, 12, 7, 0, 1, 0, -1, 0.0, 0),
                           (3, 10, 27, 0, 10, 0, -1, 0.0, 0), (4, 12, 7, 100, 10, 1, -1, 0.0, 0),  # HMIS on the second-generation graph
                           (8, 10, 7, 0, 10, 0, -1, 0.0, 0), (3, 12, 7, 0, 11, 0, 0, 0.0, 1),
-                          (4, 8, 27, 0, 1, 2, -1, 0.0, 0), (2, 14, 7, 200, 10, 0, -1, 0.05, 1)])
+                          (4, 8, 27, 0, 1, 2, -1, 0.0, 0), (2, 14, 7, 200, 10, 0, -1, 0.05, 1),
+                          # Falgout (6: the upstream sample's type, with its classical interpolation) and CLJP (0 / 7)
+                          (2, 12, 7, 0, 6, 0, -1, 0.0, 0), (4, 12, 7, 0, 6, 0, 0, 0.0, 0), (8, 10, 7, 0, 6, 0, 0, 0.0, 0),
+                          (4, 12, 7, 150, 6, 1, -1, 0.0, 0), (4, 10, 27, 0, 6, 0, -1, 0.05, 1),
+                          (3, 10, 27, 0, 0, 0, -1, 0.0, 0), (8, 8, 27, 0, 0, 0, -1, 0.0, 0), (3, 12, 7, 0, 7, 0, -1, 0.0, 1),
+                          (2, 14, 7, 0, 0, 1, -1, 0.0, 0)])
 def test_host_setup_per_rank_coarsening_types_distributed_gloo(nproc, n, stencil, seq, coarsen, agg, interp, ng, locality):
     """The coarsening types HYPRE defines PER PROCESSOR (the reference passes coarsen_type through,
     /root/reference/src/HypreSystem.cpp:126, etc/hypre_app.yaml:35): 11 / 1 = one / two Ruge-Stueben passes on every
     rank's own graph, 10 = HMIS = the first pass per rank, then PMIS from that state on the global graph (interior C
     points kept as the first independent set, boundary and F points decided again).  Built by the distributed setup
-    (local Ruge-Stueben + the distributed PMIS with an initial state); the oracle emulates the partition the same way."""
+    (local Ruge-Stueben + the distributed PMIS with an initial state); the oracle emulates the partition the same way.
+    6 = Falgout = both passes per rank, then CLJP on the boundary points from the interior verdicts; CLJP itself
+    (0 / 7) is a global algorithm whose rounds commute: distributed with the same splitting on any partition."""
     out = _run(nproc, "host", n, stencil, 30511 + nproc + n + coarsen, seq=seq, coarsen=coarsen, agg=agg, interp=interp, ng=ng,
                locality=locality)
     assert "dist host setup ok" in out
@@ -123,8 +130,7 @@ def test_host_setup_per_rank_coarsening_types_distributed_gloo(nproc, n, stencil
 @pytest.mark.parametrize("nproc,n,stencil,seq", [(2, 12, 7, -1), (3, 10, 27, 0), (4, 6, 7, 0)])
 def test_host_setup_replicated_path_gloo(nproc, n, stencil, seq):
     """The replicated setup (every rank builds the global hierarchy and keeps its slices) stays the path of the
-    global sequential coarsenings (Falgout / three-pass Ruge-Stueben 6 / 3, CLJP 0 / 7) on N > 1;
-    MI_HYPRE_REPLICATED_SETUP=1 forces it for PMIS."""
+    three-pass Ruge-Stueben coarsening (type 3) on N > 1; MI_HYPRE_REPLICATED_SETUP=1 forces it for PMIS and CLJP."""
     out = _run(nproc, "host", n, stencil, 29911 + nproc + n, seq=seq, replicated=True)
     assert "dist host setup ok" in out
 
@@ -197,7 +203,8 @@ def test_device_solve_aggressive_levels_distributed_shared_gpu(nproc, n, stencil
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nproc,n,stencil,seq,coarsen,agg", [(2, 16, 7, 0, 10, 0), (3, 14, 27, 0, 11, 0), (4, 16, 7, 300, 10, 1)])
+@pytest.mark.parametrize("nproc,n,stencil,seq,coarsen,agg", [(2, 16, 7, 0, 10, 0), (3, 14, 27, 0, 11, 0), (4, 16, 7, 300, 10, 1),
+                                                            (2, 16, 7, 0, 6, 0), (4, 14, 7, 0, 0, 0)])
 def test_device_solve_per_rank_coarsening_types_shared_gpu(nproc, n, stencil, seq, coarsen, agg):
     """HMIS / per-rank Ruge-Stueben hierarchies from the distributed setup, then the device solve on N ranks:
     hierarchy, iterations, residual history, solution against the oracle's emulation of the partition."""
