@@ -127,6 +127,7 @@ struct BoomerAMG {
   int num_iterations = 0;
   double final_rel_res = 0.0;
   double setup_seconds = 0.0;
+  double global_opcx = -1.0;  // N > 1: sum over ranks, taken at the end of the (collective) Setup
   // Internal locality numbering (single rank; amg_setup.cpp locality_order): the hierarchy is built on Q A Q^T,
   // where Q groups rows into graph-compact clusters so that a tile of consecutive rows touches few distinct columns.
   // input_order[new] = caller's row; empty = identity.  Level 0's perm is composed with it, so every solve path
@@ -223,6 +224,7 @@ struct BoomerAMG {
   // renumber every level C-first (host, collective); called at the end of setup_host
   void apply_cf_ordering();
   double operator_complexity() const;
+  void local_entry_counts(double &tot, double &base) const;  // this rank's share (redundant levels: 1 / size of them)
   // fill the host arrays of a level's A / P / R from the device (inspection API, coarse solve)
   void ensure_host(int level);
 };

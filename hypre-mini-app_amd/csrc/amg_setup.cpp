@@ -1037,8 +1037,17 @@ void BoomerAMG::ensure_host(int level) {
 
 int BoomerAMG::chunk() const { return p.gs_chunk > 0 ? p.gs_chunk : ctx().gs_chunk; }
 
+// Sum of the levels' entries over the entries of level 0.  On N > 1 ranks the GLOBAL figure (what HYPRE prints), summed
+// over the ranks once at the end of Setup, where every rank is present -- the getter itself is not collective.
 double BoomerAMG::operator_complexity() const {
   if (L.empty()) return 0.0;
+  if (global_opcx >= 0.0) return global_opcx;
+  double num = 0.0, den = 0.0;
+  local_entry_counts(num, den);
+  return den > 0 ? num / den : 0.0;
+}
+
+void BoomerAMG::local_entry_counts(double &tot_out, double &base_out) const {
   double tot = 0.0;
   const size_t own = tail ? L.size() - 1 : L.size();  // the stub's operator is the tail's fine level
   for (size_t l = 0; l < own; l++) tot += (double)(L[l].A->diag_nnz() + L[l].A->offd.nnz());
@@ -1047,8 +1056,8 @@ double BoomerAMG::operator_complexity() const {
     for (const auto &l : tail->L) t += (double)(l.A->diag_nnz() + l.A->offd.nnz());
     tot += t / (double)std::max(1, my_comm().size);  // this rank's share of the redundant levels
   }
-  const double base = (double)(L[0].A->diag_nnz() + L[0].A->offd.nnz());
-  return base > 0 ? tot / base : 0.0;
+  tot_out = tot;
+  base_out = (double)(L[0].A->diag_nnz() + L[0].A->offd.nnz());
 }
 
 // C-first ordering.  The hierarchy above is built in natural
@@ -1648,6 +1657,13 @@ void BoomerAMG::setup_host(ParCSR &A0) {
     t_phase[4] += wall_time() - tp0;
   }
   finish_host();
+  global_opcx = -1.0;
+  if (comm.size > 1 && !L.empty()) {  // the operator complexity HYPRE would print: summed over the ranks, here where all are present
+    double v[2] = {0.0, 0.0};
+    local_entry_counts(v[0], v[1]);
+    comm.allreduce_host(v, 2, CommDType::F64, CommOp::SUM);
+    global_opcx = v[1] > 0 ? v[0] / v[1] : 0.0;
+  }
   t_phase[5] = wall_time() - t_setup_start;
   host_ready = true;
   if (getenv("MI_HYPRE_SETUP_TIMING") && comm.rank == 0)

@@ -175,6 +175,9 @@ def main():
             nh = int(touches.sum())
             assert nh == 0 or (np.all(touches[order[-nh:]]) and not np.any(touches[order[:-nh]]))
     assert amg.num_levels == oamg.num_levels, (amg.num_levels, oamg.num_levels)
+    # the operator complexity every rank reports is the GLOBAL one (summed over the ranks at the end of Setup)
+    ocx = sum(oamg.level_A(l).to_scipy().nnz for l in range(oamg.num_levels)) / oamg.level_A(0).to_scipy().nnz
+    assert abs(amg.operator_complexity - ocx) <= 1e-12 * ocx, (rank, amg.operator_complexity, ocx)
 
     # ---- which setup ran, and what it held per rank (SURVEY 8e "coarse levels inherit the partition")
     def counter(name):
