@@ -1072,7 +1072,9 @@ HYPRE_Int HYPRE_MI_CommInitRCCL(const void *id128, HYPRE_Int rank, HYPRE_Int siz
 }
 HYPRE_Int HYPRE_MI_CommInitFromEnv(void) {
   API_BEGIN
-  ensure_init();
+  // (the TCP mesh is a host transport: it can be bound without a device, e.g. for the host-only setup entry points)
+  const char *tr = getenv("MI_HYPRE_TRANSPORT");
+  if (!(tr && std::string(tr) == "tcp")) ensure_init();
   ctx().comm = make_comm_from_env();
   API_END
 }

@@ -4,6 +4,8 @@
 //             dependency on it and a torch process shares torch's copy
 //   callback  caller-supplied host transport (tests: gloo; several ranks may then
 //             share one GPU, which RCCL refuses)
+//   tcp       MI_HYPRE_TRANSPORT=tcp: the callback transport over a mesh of TCP sockets on one node -- what the C++
+//             driver uses when several ranks share a GPU (tests) or librccl is not there; host-staged, not a fast path
 // The halo exchange is a neighbour send/recv group (<= 2 peers for slab
 // partitions), the dot products are 8-byte all-reduces: both latency-bound, so
 // what matters is how few of them the solver issues, not their algorithm.
@@ -13,6 +15,7 @@
 #include <netinet/in.h>
 #include <netinet/tcp.h>
 #include <rccl/rccl.h>
+#include <poll.h>
 #include <sys/socket.h>
 #include <unistd.h>
 
@@ -591,6 +594,195 @@ static void recv_all(int fd, void *buf, size_t n) {
     n -= (size_t)r;
   }
 }
+// ------------------------------------------------------------------ TCP mesh (single node, host-staged)
+// Every pair of ranks shares one socket; rank r listens on port base + r and connects to the lower ranks.  The three
+// callbacks of the host-staged transport run over it: reductions and gathers through rank 0 (contributions added in
+// rank order: identical bits on every rank), neighbour exchanges directly between the peers with poll()-driven
+// progress (no ordering of sends and receives can deadlock).  A pair's stream is FIFO and both ends issue their
+// common operations in the same program order, so messages need no tags; every message carries its length, which
+// the receiver checks.
+namespace {
+struct TcpMesh {
+  int rank = 0, size = 1;
+  std::vector<int> fd;
+  ~TcpMesh() {
+    for (int f : fd)
+      if (f >= 0) ::close(f);
+  }
+  void send_msg(int peer, const void *p, size_t n) {
+    const uint64_t len = n;
+    send_all(fd[(size_t)peer], &len, sizeof(len));
+    if (n) send_all(fd[(size_t)peer], p, n);
+  }
+  void recv_msg(int peer, void *p, size_t n) {
+    uint64_t len = 0;
+    recv_all(fd[(size_t)peer], &len, sizeof(len));
+    if (len != n) fail(1, "tcp transport: message of " + std::to_string(len) + " bytes where " + std::to_string(n) + " were expected");
+    if (n) recv_all(fd[(size_t)peer], p, n);
+  }
+  template <class T>
+  static void fold(T *acc, const T *v, size_t count, int op) {
+    for (size_t k = 0; k < count; k++)
+      acc[k] = op == (int)CommOp::SUM ? acc[k] + v[k] : (op == (int)CommOp::MIN ? std::min(acc[k], v[k]) : std::max(acc[k], v[k]));
+  }
+  void allreduce(void *buf, size_t count, int dtype, int op) {
+    if (size == 1 || count == 0) return;
+    const size_t bytes = count * dtype_size((CommDType)dtype);
+    if (rank != 0) {
+      send_msg(0, buf, bytes);
+      recv_msg(0, buf, bytes);
+      return;
+    }
+    std::vector<char> tmp(bytes);
+    for (int r = 1; r < size; r++) {
+      recv_msg(r, tmp.data(), bytes);
+      switch ((CommDType)dtype) {
+        case CommDType::F64: fold((double *)buf, (const double *)tmp.data(), count, op); break;
+        case CommDType::I64: fold((long long *)buf, (const long long *)tmp.data(), count, op); break;
+        case CommDType::I32: fold((int *)buf, (const int *)tmp.data(), count, op); break;
+        default: fold((unsigned char *)buf, (const unsigned char *)tmp.data(), count, op); break;
+      }
+    }
+    for (int r = 1; r < size; r++) send_msg(r, buf, bytes);
+  }
+  void allgather(const void *send, void *recv, size_t bytes) {
+    char *out = (char *)recv;
+    if (bytes) memcpy(out + (size_t)rank * bytes, send, bytes);
+    if (size == 1) return;
+    if (rank != 0) {
+      send_msg(0, send, bytes);
+      recv_msg(0, out, bytes * (size_t)size);
+      return;
+    }
+    for (int r = 1; r < size; r++) recv_msg(r, out + (size_t)r * bytes, bytes);
+    for (int r = 1; r < size; r++) send_msg(r, out, bytes * (size_t)size);
+  }
+  // one direction of one pair: header, then payload
+  struct Op {
+    int fd;
+    uint64_t len;
+    char *ptr;
+    size_t hdr_done = 0, done = 0;
+    bool finished() const { return hdr_done == sizeof(uint64_t) && done == len; }
+  };
+  void exchange(int nsend, const int *sp, void *const *sptr, const size_t *sby, int nrecv, const int *rp, void *const *rptr,
+                const size_t *rby) {
+    // per socket the operations run in list order; sockets progress independently
+    std::vector<std::vector<Op>> out((size_t)size), in((size_t)size);
+    std::vector<size_t> oi((size_t)size, 0), ii((size_t)size, 0);
+    for (int k = 0; k < nsend; k++) out[(size_t)sp[k]].push_back({fd[(size_t)sp[k]], (uint64_t)sby[k], (char *)sptr[k]});
+    for (int k = 0; k < nrecv; k++) in[(size_t)rp[k]].push_back({fd[(size_t)rp[k]], (uint64_t)rby[k], (char *)rptr[k]});
+    std::vector<uint64_t> rhdr((size_t)size, 0);
+    for (;;) {
+      std::vector<pollfd> pf;
+      std::vector<int> who;
+      for (int r = 0; r < size; r++) {
+        short ev = 0;
+        if (oi[(size_t)r] < out[(size_t)r].size()) ev |= POLLOUT;
+        if (ii[(size_t)r] < in[(size_t)r].size()) ev |= POLLIN;
+        if (ev) {
+          pf.push_back({fd[(size_t)r], ev, 0});
+          who.push_back(r);
+        }
+      }
+      if (pf.empty()) break;
+      if (::poll(pf.data(), (nfds_t)pf.size(), 60000) <= 0) fail(1, "tcp transport: neighbour exchange timed out");
+      for (size_t q = 0; q < pf.size(); q++) {
+        const int r = who[q];
+        if ((pf[q].revents & (POLLERR | POLLHUP | POLLNVAL)) && !(pf[q].revents & POLLIN)) fail(1, "tcp transport: peer closed the connection");
+        if ((pf[q].revents & POLLOUT) && oi[(size_t)r] < out[(size_t)r].size()) {
+          Op &o = out[(size_t)r][oi[(size_t)r]];
+          if (o.hdr_done < sizeof(uint64_t)) {
+            const ssize_t w = ::send(o.fd, (const char *)&o.len + o.hdr_done, sizeof(uint64_t) - o.hdr_done, MSG_DONTWAIT | MSG_NOSIGNAL);
+            if (w > 0) o.hdr_done += (size_t)w;
+          } else if (o.done < o.len) {
+            const ssize_t w = ::send(o.fd, o.ptr + o.done, o.len - o.done, MSG_DONTWAIT | MSG_NOSIGNAL);
+            if (w > 0) o.done += (size_t)w;
+          }
+          if (o.finished()) oi[(size_t)r]++;
+        }
+        if ((pf[q].revents & POLLIN) && ii[(size_t)r] < in[(size_t)r].size()) {
+          Op &o = in[(size_t)r][ii[(size_t)r]];
+          if (o.hdr_done < sizeof(uint64_t)) {
+            const ssize_t g = ::recv(o.fd, (char *)&rhdr[(size_t)r] + o.hdr_done, sizeof(uint64_t) - o.hdr_done, MSG_DONTWAIT);
+            if (g == 0) fail(1, "tcp transport: peer closed the connection");
+            if (g > 0) o.hdr_done += (size_t)g;
+            if (o.hdr_done == sizeof(uint64_t) && rhdr[(size_t)r] != o.len)
+              fail(1, "tcp transport: halo message of " + std::to_string(rhdr[(size_t)r]) + " bytes where " + std::to_string(o.len) + " were expected");
+          } else if (o.done < o.len) {
+            const ssize_t g = ::recv(o.fd, o.ptr + o.done, o.len - o.done, MSG_DONTWAIT);
+            if (g == 0) fail(1, "tcp transport: peer closed the connection");
+            if (g > 0) o.done += (size_t)g;
+          }
+          if (o.finished()) ii[(size_t)r]++;
+        }
+      }
+    }
+  }
+};
+void tcp_allreduce(void *c, void *buf, size_t count, int dtype, int op) { ((TcpMesh *)c)->allreduce(buf, count, dtype, op); }
+void tcp_allgather(void *c, const void *send, void *recv, size_t bytes) { ((TcpMesh *)c)->allgather(send, recv, bytes); }
+void tcp_exchange(void *c, int ns, const int *sp, void *const *sptr, const size_t *sby, int nr, const int *rp, void *const *rptr,
+                  const size_t *rby) {
+  ((TcpMesh *)c)->exchange(ns, sp, sptr, sby, nr, rp, rptr, rby);
+}
+
+std::unique_ptr<Comm> make_tcp_comm(int rank, int size, const char *addr, int base_port) {
+  TcpMesh *m = new TcpMesh();  // lives as long as the process (the communicator holds plain callbacks)
+  m->rank = rank, m->size = size;
+  m->fd.assign((size_t)size, -1);
+  int ls = ::socket(AF_INET, SOCK_STREAM, 0);
+  if (ls < 0) fail(1, "tcp transport: socket");
+  int one = 1;
+  setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+  sockaddr_in sa{};
+  sa.sin_family = AF_INET;
+  sa.sin_addr.s_addr = htonl(INADDR_ANY);
+  sa.sin_port = htons((uint16_t)(base_port + rank));
+  if (::bind(ls, (sockaddr *)&sa, sizeof(sa)) != 0 || ::listen(ls, size) != 0) {
+    ::close(ls);
+    fail(1, "tcp transport: cannot listen on port " + std::to_string(base_port + rank));
+  }
+  for (int q = 0; q < rank; q++) {  // connect to the lower ranks
+    addrinfo hints{}, *res = nullptr;
+    hints.ai_family = AF_INET;
+    hints.ai_socktype = SOCK_STREAM;
+    if (getaddrinfo(addr, std::to_string(base_port + q).c_str(), &hints, &res) != 0 || !res)
+      fail(1, std::string("tcp transport: cannot resolve ") + addr);
+    int f = -1;
+    for (int attempt = 0; attempt < 600; attempt++) {
+      f = ::socket(AF_INET, SOCK_STREAM, 0);
+      if (f >= 0 && ::connect(f, res->ai_addr, res->ai_addrlen) == 0) break;
+      if (f >= 0) ::close(f);
+      f = -1;
+      std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    }
+    freeaddrinfo(res);
+    if (f < 0) fail(1, "tcp transport: cannot reach rank " + std::to_string(q));
+    setsockopt(f, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+    const int me = rank;
+    send_all(f, &me, sizeof(me));
+    m->fd[(size_t)q] = f;
+  }
+  for (int k = rank + 1; k < size; k++) {  // the higher ranks connect to me, in any order
+    int f = ::accept(ls, nullptr, nullptr);
+    if (f < 0) fail(1, "tcp transport: accept");
+    setsockopt(f, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+    int who = -1;
+    recv_all(f, &who, sizeof(who));
+    if (who <= rank || who >= size || m->fd[(size_t)who] >= 0) fail(1, "tcp transport: unexpected peer");
+    m->fd[(size_t)who] = f;
+  }
+  ::close(ls);
+  CommCallbacks cb;
+  cb.ctx = m;
+  cb.allreduce = tcp_allreduce;
+  cb.allgather = tcp_allgather;
+  cb.exchange = tcp_exchange;
+  return make_callback_comm(cb, rank, size);
+}
+}  // namespace
+
 std::unique_ptr<Comm> make_comm_from_env() {
   const int size = env_int("WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE", 1);
   const int rank = env_int("RANK", "OMPI_COMM_WORLD_RANK", "PMI_RANK", 0);
@@ -598,6 +790,7 @@ std::unique_ptr<Comm> make_comm_from_env() {
   const char *addr = getenv("MASTER_ADDR") ? getenv("MASTER_ADDR") : "127.0.0.1";
   int port = getenv("MI_HYPRE_PORT") ? atoi(getenv("MI_HYPRE_PORT"))
                                      : (getenv("MASTER_PORT") ? atoi(getenv("MASTER_PORT")) + 17 : 29517);
+  if (getenv("MI_HYPRE_TRANSPORT") && std::string(getenv("MI_HYPRE_TRANSPORT")) == "tcp") return make_tcp_comm(rank, size, addr, port);
   unsigned char id[128];
   if (rank == 0) {
     rccl_get_unique_id(id);

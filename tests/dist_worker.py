@@ -69,7 +69,8 @@ def main():
                     help="levels with the ILU complex smoother (smooth_type 5): block-Jacobi ILU(0) per rank")
     ap.add_argument("--transport", default="callbacks",
                     help="callbacks (gloo through host staging) | ipc (halo exchanges by peer stores into IPC-mapped "
-                         "mailboxes, HYPRE_MI_CommEnablePeerStoreExchange; reductions stay on the callbacks)")
+                         "mailboxes, HYPRE_MI_CommEnablePeerStoreExchange; reductions stay on the callbacks) | tcp (the "
+                         "library's own TCP mesh, MI_HYPRE_TRANSPORT=tcp)")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -81,7 +82,14 @@ def main():
     oc = ge.load_oracle()
     if args.mode == "solve":
         mi.init()
-    mi.init_comm_torch(dist, device="cuda" if args.staging == "cuda" else None)
+    if args.transport == "tcp":
+        # the library's own host transport (csrc/comm.cpp TcpMesh: what the C++ driver uses when ranks share a GPU):
+        # bound from RANK / WORLD_SIZE / MASTER_ADDR like the RCCL one; torch.distributed only launches the ranks
+        os.environ["MI_HYPRE_TRANSPORT"] = "tcp"
+        os.environ["MI_HYPRE_PORT"] = str(int(os.environ["MASTER_PORT"]) + 100)
+        mi.call("HYPRE_MI_CommInitFromEnv")
+    else:
+        mi.init_comm_torch(dist, device="cuda" if args.staging == "cuda" else None)
     if args.transport == "ipc":
         assert args.mode == "solve"
         mi.call("HYPRE_MI_CommEnablePeerStoreExchange", mi.c_big(1 << 16))  # small slots: large halos travel in parts

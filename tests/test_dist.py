@@ -127,6 +127,15 @@ def test_host_setup_per_rank_coarsening_types_distributed_gloo(nproc, n, stencil
     assert "dist host setup ok" in out
 
 
+@pytest.mark.parametrize("nproc,n,stencil,seq,coarsen,agg", [(2, 12, 7, 0, -1, 0), (4, 12, 27, 100, 6, 0), (8, 10, 7, 0, -1, 1)])
+def test_host_setup_tcp_transport_gloo_free(nproc, n, stencil, seq, coarsen, agg):
+    """The library's own host transport (csrc/comm.cpp TcpMesh, MI_HYPRE_TRANSPORT=tcp, bound by
+    HYPRE_MI_CommInitFromEnv like the RCCL one): the distributed setup on 2 / 4 / 8 ranks over it -- all-reduces,
+    all-gathers and the variable-size neighbour exchanges of the setup -- against the oracle as over gloo."""
+    out = _run(nproc, "host", n, stencil, 30611 + nproc + n, seq=seq, coarsen=coarsen, agg=agg, transport="tcp")
+    assert "dist host setup ok" in out
+
+
 @pytest.mark.parametrize("nproc,n,stencil,seq", [(2, 12, 7, -1), (3, 10, 27, 0), (4, 6, 7, 0)])
 def test_host_setup_replicated_path_gloo(nproc, n, stencil, seq):
     """The replicated setup (every rank builds the global hierarchy and keeps its slices) stays the path of the
