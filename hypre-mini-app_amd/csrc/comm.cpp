@@ -686,7 +686,9 @@ struct TcpMesh {
         }
       }
       if (pf.empty()) break;
-      if (::poll(pf.data(), (nfds_t)pf.size(), 60000) <= 0) fail(1, "tcp transport: neighbour exchange timed out");
+      // (ranks reach an exchange at different times -- a peer may still be in a long host phase of the setup)
+      static const int wait_ms = getenv("MI_HYPRE_TCP_TIMEOUT_MS") ? atoi(getenv("MI_HYPRE_TCP_TIMEOUT_MS")) : 1800000;
+      if (::poll(pf.data(), (nfds_t)pf.size(), wait_ms) <= 0) fail(1, "tcp transport: neighbour exchange timed out");
       for (size_t q = 0; q < pf.size(); q++) {
         const int r = who[q];
         if ((pf[q].revents & (POLLERR | POLLHUP | POLLNVAL)) && !(pf[q].revents & POLLIN)) fail(1, "tcp transport: peer closed the connection");

@@ -615,3 +615,44 @@ solver_settings:
   print_level: 0
 """ + DEFAULT_AMG, 2, 29823)
     assert "allClose=1" in out and "allClose=0" not in out, out[-3000:]
+
+
+@pytest.mark.parametrize("segregated", [1, 0])
+def test_driver_on_several_ranks_three_component_bicgstab(tmp_path, segregated):
+    """BASELINE.json config 5's shape through the C++ driver on N > 1 ranks: 3-component IJ partition files
+    (`num_components: 3`, /root/reference/src/HypreSystem.cpp:1033-1036), BiCGSTAB + BoomerAMG, segregated and
+    multivector solves, 2 ranks sharing the GPU over the TCP transport; every component against scipy's direct solve
+    by the reference's closeness rule, one hierarchy for all components."""
+    from tests.systems import convection_diffusion_3d, three_component_rhs
+
+    A = convection_diffusion_3d(10)
+    B, _ = three_component_rhs(A)
+    lu = spl.splu(A.tocsc())
+    X = [lu.solve(B[c]) for c in range(3)]
+    vecs = {}
+    for c in range(3):
+        vecs[f"rhs{c}.ij"] = B[c]
+        vecs[f"sln{c}.ij"] = X[c]
+    _write_ij(str(tmp_path), A, vecs, 2)
+    files = "  matrix_file: mat.ij\n  num_partitions: 2\n" + "".join(
+        f"  rhs_file{c}: rhs{c}.ij\n  sln_file{c}: sln{c}.ij\n" for c in range(3))
+    out = _run_ranks(tmp_path, f"""
+linear_system:
+  type: hypre_ij
+{files}  num_components: 3
+  segregated_solve: {segregated}
+  rtol: 1.0e-6
+  atol: 1.0e-8
+
+solver_settings:
+  method: bicg
+  preconditioner: boomeramg
+  tolerance: 1.0e-11
+  max_iterations: 100
+  print_level: 0
+""" + DEFAULT_AMG, 2, 29831 + segregated)
+    assert "allClose=0" not in out and out.count("allClose=1") >= 3, out[-3000:]
+    assert out.count("mi_hypre BoomerAMG setup:") == 1
+    solves = re.findall(r"Solve (\d+) : (\d+) iterations, final relative residual ([0-9.eE+-]+)", out)
+    assert len(solves) == (3 if segregated else 1)
+    assert all(0 < int(it) < 40 and float(rr) <= 1e-11 for _, it, rr in solves)
