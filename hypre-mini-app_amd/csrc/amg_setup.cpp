@@ -1581,9 +1581,9 @@ void BoomerAMG::setup_host(ParCSR &A0) {
   if (p.smooth_num_levels > 0 && p.smooth_type != 5)
     fail(4, "BoomerAMGSetup: smooth_type " + std::to_string(p.smooth_type) + " on " + std::to_string(p.smooth_num_levels) +
                 " level(s) is not implemented (5 = ILU is); refusing to smooth with something else");
-  if (p.smooth_num_levels > 0 && (p.ilu_type != 0 || p.ilu_level != 0))
+  if (p.smooth_num_levels > 0 && (p.ilu_type != 0 || p.ilu_level < 0))
     fail(4, "BoomerAMGSetup: ILU smoother type " + std::to_string(p.ilu_type) + " / level of fill " +
-                std::to_string(p.ilu_level) + " is not implemented (block-Jacobi ILU(0) = type 0, level 0 is)");
+                std::to_string(p.ilu_level) + " is not implemented (block-Jacobi ILU(k) = type 0, level k >= 0 is)");
   if (comm.size > 1) input_order.clear();
   if (comm.size > 1 && can_build_distributed()) {
     build_distributed(A0);

@@ -1,4 +1,4 @@
-// Block-Jacobi ILU(0) (HYPRE_ILU type 0, level of fill 0): the preconditioner / solver behind
+// Block-Jacobi ILU(k) (HYPRE_ILU type 0, level of fill k >= 0): the preconditioner / solver behind
 // `preconditioner: ilu` and `method: ilu` of the driver (src/HypreSystem.cpp:328-370, :457-497).
 // Every rank factorises its own diagonal block in place; rows are grouped into level sets (row i is one
 // level above the deepest row it depends on), which order both the factorisation and the substitutions:
@@ -11,14 +11,75 @@
 
 namespace mi {
 
+namespace {
+// Symbolic ILU(k) of a rank's diagonal block (ilu.c hypre_ILUSetupILUKSymbolic; oracle/oracle.c ilu_symbolic; Saad,
+// Iterative Methods, alg. 10.5): row by row, level 0 on A's pattern; every kept lower entry (i,k), in ascending k,
+// lets every entry (k,j), j > k, of row k propose  lev(i,j) = lev(i,k) + lev(k,j) + 1,  merged into the row's sorted
+// list when that is <= fill.  Out: the pattern with A's values on A's positions and zeros on the fill.
+void ilu_symbolic(const HostCSR &B, int fill, HostCSR &F) {
+  const int n = B.nrows;
+  F.nrows = n;
+  F.ncols = B.ncols;
+  F.ia.assign((size_t)n + 1, 0);
+  F.ja.clear();
+  F.a.clear();
+  F.ja.reserve((size_t)B.nnz() * (size_t)(fill + 1));
+  F.a.reserve((size_t)B.nnz() * (size_t)(fill + 1));
+  std::vector<int> lv;  // level of every stored entry
+  lv.reserve((size_t)B.nnz() * (size_t)(fill + 1));
+  std::vector<int64_t> dpos((size_t)n, -1);
+  std::vector<int> next((size_t)n + 1, n), lev((size_t)n, 0);
+  std::vector<double> val((size_t)n, 0.0);
+  for (int i = 0; i < n; i++) {
+    int last = n;
+    next[(size_t)n] = n;
+    for (int64_t k = B.ia[(size_t)i]; k < B.ia[(size_t)i + 1]; k++) {  // columns ascend
+      const int j = B.ja[(size_t)k];
+      next[(size_t)last] = j;
+      next[(size_t)j] = n;
+      last = j;
+      lev[(size_t)j] = 0;
+      val[(size_t)j] = B.a[(size_t)k];
+    }
+    for (int k = next[(size_t)n]; k < i; k = next[(size_t)k]) {  // (k == n ends the list: n > i)
+      if (dpos[(size_t)k] < 0) continue;
+      int at = k;  // the columns row k proposes ascend
+      for (int64_t q = dpos[(size_t)k] + 1; q < F.ia[(size_t)k + 1]; q++) {
+        const int j = F.ja[(size_t)q];
+        const int nl = lev[(size_t)k] + lv[(size_t)q] + 1;
+        if (nl > fill) continue;
+        while (next[(size_t)at] != n && next[(size_t)at] < j) at = next[(size_t)at];
+        if (next[(size_t)at] == j) {
+          if (nl < lev[(size_t)j]) lev[(size_t)j] = nl;
+        } else {
+          next[(size_t)j] = next[(size_t)at];
+          next[(size_t)at] = j;
+          lev[(size_t)j] = nl;
+          val[(size_t)j] = 0.0;
+        }
+      }
+    }
+    for (int j = next[(size_t)n]; j != n; j = next[(size_t)j]) {
+      if (j == i) dpos[(size_t)i] = (int64_t)F.ja.size();
+      F.ja.push_back(j);
+      lv.push_back(lev[(size_t)j]);
+      F.a.push_back(val[(size_t)j]);
+    }
+    F.ia[(size_t)i + 1] = (int64_t)F.ja.size();
+  }
+}
+}  // namespace
+
 void IluSolver::setup(ParCSR &A) {
   ensure_init();
   hipStream_t s = ctx().stream;
-  if (ilu_type != 0 || level_of_fill != 0)
-    fail(1, "HYPRE_ILU: this variant is not implemented -- only type 0 (block Jacobi) with level of fill 0 is (got type " +
+  if (ilu_type != 0 || level_of_fill < 0)
+    fail(1, "HYPRE_ILU: this variant is not implemented -- only type 0 (block-Jacobi ILU(k)) is (got type " +
                 std::to_string(ilu_type) + ", fill " + std::to_string(level_of_fill) + ")");
   MI_REQUIRE(!A.host_diag_stale, "HYPRE_ILUSetup: the matrix has no host arrays");
-  const HostCSR &D = A.diag;
+  HostCSR filled;
+  if (level_of_fill > 0) ilu_symbolic(A.diag, level_of_fill, filled);  // the factors live on the ILU(k) pattern
+  const HostCSR &D = level_of_fill > 0 ? filled : A.diag;
   n = D.nrows;
   // level sets of the lower and of the upper factor
   std::vector<int> ll((size_t)n, 0), lu((size_t)n, 0);
@@ -65,7 +126,7 @@ void IluSolver::setup(ParCSR &A) {
   MI_HIP(hipStreamSynchronize(s));
   is_setup = true;
   if (print_level > 0 && current_comm().rank == 0)
-    printf("mi_hypre ILU(0): %d rows, %lld entries, %d lower / %d upper level sets, %s triangular solves\n", n,
+    printf("mi_hypre ILU(%d): %d rows, %lld entries, %d lower / %d upper level sets, %s triangular solves\n", level_of_fill, n,
            (long long)LU.nnz, nl, nu, tri_solve ? "exact" : "Jacobi");
 }
 

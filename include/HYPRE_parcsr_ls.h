@@ -111,7 +111,7 @@ HYPRE_Int HYPRE_ParCSRBiCGSTABGetNumIterations(HYPRE_Solver solver, HYPRE_Int *n
 HYPRE_Int HYPRE_ParCSRBiCGSTABGetFinalRelativeResidualNorm(HYPRE_Solver solver, HYPRE_Real *norm);
 
 /* ---------------------------------------------------------------- further Krylov families;
- * all implemented; HYPRE_ILU further down covers ILU(0) */
+ * all implemented; HYPRE_ILU further down covers block-Jacobi ILU(k) */
 #define MI_HYPRE_DECLARE_KRYLOV_FAMILY(NAME)                                                                           \
   HYPRE_Int HYPRE_ParCSR##NAME##Create(MPI_Comm comm, HYPRE_Solver *solver);                                         \
   HYPRE_Int HYPRE_ParCSR##NAME##Destroy(HYPRE_Solver solver);                                                        \
@@ -148,7 +148,7 @@ HYPRE_Int HYPRE_ParCSRCOGMRESSetLogging(HYPRE_Solver solver, HYPRE_Int logging);
 HYPRE_Int HYPRE_ParCSRCOGMRESGetNumIterations(HYPRE_Solver solver, HYPRE_Int *num_iterations);
 HYPRE_Int HYPRE_ParCSRCOGMRESGetFinalRelativeResidualNorm(HYPRE_Solver solver, HYPRE_Real *norm);
 
-/* ILU (src/HypreSystem.cpp:328-370, :457-497): type 0 (block Jacobi) with level of fill 0 -- ILU(0) of the rank's
+/* ILU (src/HypreSystem.cpp:328-370, :457-497): type 0 (block Jacobi) with level of fill k >= 0 -- ILU(k) of the rank's
  * diagonal block, exact (level-scheduled) or Jacobi-iterated triangular solves; other types / fill levels and the
  * iterative setup report an error at Setup */
 HYPRE_Int HYPRE_ILUCreate(HYPRE_Solver *solver);

@@ -307,6 +307,7 @@ void oamg_default_params(oamg_params *p) {
   p->ilu_lower_it = p->ilu_upper_it = 5;
   p->non_galerkin_num_tol = 0;
   p->non_galerkin_tol = NULL;
+  p->ilu_level = 0;
 }
 
 static int *part_of_rows(int n, int nparts, const obig *ps) {
@@ -1615,7 +1616,8 @@ static void finish_levels(oamg *h) {
     if (L->P) L->R = ocsr_transpose(L->P);
     /* par_amg_setup.c: HYPRE_ILUCreate/Setup per level j < smooth_num_levels (not the coarsest) */
     if (h->p.smooth_type == 5 && l < h->p.smooth_num_levels && l < h->nlev - 1)
-      L->smoother = oilu_setup(L->A, h->p.nparts, L->part_starts, h->p.ilu_tri_solve, h->p.ilu_lower_it, h->p.ilu_upper_it);
+      L->smoother = oilu_setup_k(L->A, h->p.nparts, L->part_starts, h->p.ilu_tri_solve, h->p.ilu_lower_it, h->p.ilu_upper_it,
+                                 h->p.ilu_level);
   }
   olevel *Lc = &h->L[h->nlev - 1];
   if (h->p.relax_type[2] == 9 && Lc->A->nrows <= ORACLE_MAX_DENSE) {
@@ -2125,7 +2127,90 @@ struct oilu {
   int tri_solve, lower_it, upper_it;
 };
 
+/* Symbolic ILU(k) of the block-diagonal part of A (ilu.c hypre_ILUSetupILUKSymbolic; Saad, Iterative Methods, alg.
+ * 10.5): row by row, lev = 0 on A's pattern; for every kept lower entry (i,k) in ascending k, every entry (k,j), j > k,
+ * of row k's upper part proposes lev(i,j) = lev(i,k) + lev(k,j) + 1 and is merged into row i when that is <= fill.
+ * Returns the pattern with A's values on A's positions and zeros on the fill (columns ascending). */
+static ocsr *ilu_symbolic(const ocsr *B, int fill) {
+  const int n = B->nrows;
+  obig cap = B->ia[n] * (fill + 1) + 16, w = 0;
+  obig *ia = (obig *)xcalloc((size_t)n + 1, sizeof(obig));
+  int *ja = (int *)xmalloc(sizeof(int) * (size_t)cap);
+  int *lv = (int *)xmalloc(sizeof(int) * (size_t)cap);
+  double *va = (double *)xmalloc(sizeof(double) * (size_t)cap);
+  obig *dpos = (obig *)xmalloc(sizeof(obig) * (size_t)(n ? n : 1));
+  int *next = (int *)xmalloc(sizeof(int) * ((size_t)n + 1)); /* sorted linked list of the row's columns, head = n */
+  int *lev = (int *)xmalloc(sizeof(int) * (size_t)(n ? n : 1));
+  double *val = (double *)xcalloc((size_t)(n ? n : 1), sizeof(double));
+  for (int i = 0; i < n; i++) {
+    int head = n, last = n, cnt = 0;
+    next[n] = n;
+    for (obig k = B->ia[i]; k < B->ia[i + 1]; k++) { /* columns ascend */
+      const int j = B->ja[k];
+      next[last] = j;
+      next[j] = n;
+      last = j;
+      lev[j] = 0;
+      val[j] = B->a[k];
+      cnt++;
+    }
+    head = next[n];
+    for (int k = head; k < i && k != n; k = next[k]) {
+      if (lev[k] > fill) continue; /* (never: only kept entries are in the list) */
+      if (dpos[k] < 0) continue;
+      int at = k; /* insertion cursor: the columns proposed by row k ascend */
+      for (obig q = dpos[k] + 1; q < ia[k + 1]; q++) {
+        const int j = ja[q];
+        const int nl = lev[k] + lv[q] + 1;
+        if (nl > fill) continue;
+        while (next[at] != n && next[at] < j) at = next[at];
+        if (next[at] == j) {
+          if (nl < lev[j]) lev[j] = nl;
+        } else {
+          next[j] = next[at];
+          next[at] = j;
+          lev[j] = nl;
+          val[j] = 0.0;
+          cnt++;
+        }
+      }
+    }
+    if (w + cnt > cap) {
+      cap = (w + cnt) * 2;
+      ja = (int *)realloc(ja, sizeof(int) * (size_t)cap);
+      lv = (int *)realloc(lv, sizeof(int) * (size_t)cap);
+      va = (double *)realloc(va, sizeof(double) * (size_t)cap);
+    }
+    dpos[i] = -1;
+    for (int j = next[n]; j != n; j = next[j]) {
+      if (j == i) dpos[i] = w;
+      ja[w] = j;
+      lv[w] = lev[j];
+      va[w] = val[j];
+      w++;
+    }
+    ia[i + 1] = w;
+  }
+  ocsr *F = ocsr_new(n, n, w);
+  memcpy(F->ia, ia, sizeof(obig) * ((size_t)n + 1));
+  memcpy(F->ja, ja, sizeof(int) * (size_t)w);
+  memcpy(F->a, va, sizeof(double) * (size_t)w);
+  free(ia);
+  free(ja);
+  free(lv);
+  free(va);
+  free(dpos);
+  free(next);
+  free(lev);
+  free(val);
+  return F;
+}
+
 oilu *oilu_setup(const ocsr *A, int nparts, const obig *part_starts, int tri_solve, int lower_it, int upper_it) {
+  return oilu_setup_k(A, nparts, part_starts, tri_solve, lower_it, upper_it, 0);
+}
+
+oilu *oilu_setup_k(const ocsr *A, int nparts, const obig *part_starts, int tri_solve, int lower_it, int upper_it, int level_of_fill) {
   const int n = A->nrows;
   oilu *h = (oilu *)xcalloc(1, sizeof(oilu));
   h->n = n;
@@ -2163,6 +2248,16 @@ oilu *oilu_setup(const ocsr *A, int nparts, const obig *part_starts, int tri_sol
           q++;
         }
     }
+  if (level_of_fill > 0) { /* the factors live on the ILU(k) pattern: zeros on the fill positions */
+    ocsr *F = ilu_symbolic(LU, level_of_fill);
+    ocsr_free(LU);
+    LU = F;
+    for (int i = 0; i < n; i++) {
+      h->dpos[i] = -1;
+      for (obig k = LU->ia[i]; k < LU->ia[i + 1]; k++)
+        if (LU->ja[k] == i) h->dpos[i] = k;
+    }
+  }
   /* IKJ: for k < i in row i (ascending): l_ik = a_ik / u_kk ; a_ij -= l_ik u_kj for j > k in both patterns */
   for (int i = 0; i < n; i++) {
     for (obig kk = LU->ia[i]; kk < LU->ia[i + 1]; kk++) {

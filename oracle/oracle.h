@@ -95,6 +95,7 @@ typedef struct oamg_params {
    * index); levels beyond the array take the last entry; NULL / 0 = Galerkin.  See sparsify_non_galerkin */
   int non_galerkin_num_tol;
   const double *non_galerkin_tol;
+  int ilu_level;           /* 0: level of fill k of the ILU(k) complex smoother (ilu_type 0; src/HypreSystem.cpp:258-262) */
 } oamg_params;
 
 void oamg_default_params(oamg_params *p);
@@ -139,6 +140,9 @@ void omulti_precond(void *ctx, const double *r, double *z);
  * triangular factor (HYPRE's GPU option).  HYPRE's ILU source is not available here: parity unpinned. */
 typedef struct oilu oilu;
 oilu *oilu_setup(const ocsr *A, int nparts, const obig *part_starts, int tri_solve, int lower_it, int upper_it);
+/* the same with level of fill k (HYPRE_ILUSetLevelOfFill, src/HypreSystem.cpp:345-349; ILU(k), Saad: an entry of the
+ * factors is kept when its level  lev(i,j) = min over k of lev(i,k) + lev(k,j) + 1  (0 on A's pattern) is <= k) */
+oilu *oilu_setup_k(const ocsr *A, int nparts, const obig *part_starts, int tri_solve, int lower_it, int upper_it, int level_of_fill);
 void oilu_free(oilu *h);
 const ocsr *oilu_factor(const oilu *h);                 /* L (unit, strictly lower part) and U in A's pattern */
 void oilu_apply(const oilu *h, const double *r, double *z); /* z = U^-1 L^-1 r */

@@ -56,6 +56,7 @@ class AmgParams(C.Structure):
         ("ilu_upper_it", C.c_int),
         ("non_galerkin_num_tol", C.c_int),
         ("non_galerkin_tol", C.POINTER(C.c_double)),
+        ("ilu_level", C.c_int),
     ]
 
 
@@ -128,6 +129,8 @@ def lib():
                                       C.c_void_p, C.c_void_p, P(KrylovResult), C.c_void_p]
         L.oilu_setup.restype = C.c_void_p
         L.oilu_setup.argtypes = [P(_Csr), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.oilu_setup_k.restype = C.c_void_p
+        L.oilu_setup_k.argtypes = [P(_Csr), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.oilu_free.argtypes = [C.c_void_p]
         L.oilu_factor.restype = P(_Csr)
         L.oilu_factor.argtypes = [C.c_void_p]
@@ -305,13 +308,13 @@ class Amg:
 
 
 class Ilu:
-    """Block-Jacobi ILU(0) of the oracle (part_starts: emulated rank partition)."""
+    """Block-Jacobi ILU(k) of the oracle (part_starts: emulated rank partition; level_of_fill k, 0 = ILU(0))."""
 
-    def __init__(self, A, part_starts=None, tri_solve=1, lower_it=5, upper_it=5):
+    def __init__(self, A, part_starts=None, tri_solve=1, lower_it=5, upper_it=5, level_of_fill=0):
         self.A = A
         ps = None if part_starts is None else np.ascontiguousarray(part_starts, dtype=np.int64)
         self._ps = ps
-        self.h = lib().oilu_setup(A.h, 0 if ps is None else len(ps) - 1, _ptr(ps), tri_solve, lower_it, upper_it)
+        self.h = lib().oilu_setup_k(A.h, 0 if ps is None else len(ps) - 1, _ptr(ps), tri_solve, lower_it, upper_it, level_of_fill)
         self.is_ilu = True
 
     def factor(self):

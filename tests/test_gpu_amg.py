@@ -35,7 +35,7 @@ def _setup(mi, oc, n, stencil=7, **amg_kw):
         okw["num_sweeps"] = amg_kw["num_sweeps"]
     for k in ("interp_type", "relax_order", "max_coarse_size", "strong_threshold", "cycle_type", "max_levels",
               "coarsen_type", "agg_num_levels", "agg_pmax_elmts", "agg_trunc_factor", "smooth_type",
-              "smooth_num_levels", "ilu_max_iter", "ilu_tri_solve", "non_galerkin_tol"):
+              "smooth_num_levels", "ilu_max_iter", "ilu_tri_solve", "non_galerkin_tol", "ilu_level"):
         if k in amg_kw:
             okw[k] = amg_kw[k]
     for k, ok in (("ilu_lower_jacobi_iters", "ilu_lower_it"), ("ilu_upper_jacobi_iters", "ilu_upper_it")):
@@ -207,6 +207,7 @@ def test_relax_other_chunk_sizes(mi, oc, chunk):
                                 dict(smooth_type=5, smooth_num_levels=2, ilu_max_iter=2, cycle_type=2),
                                 dict(smooth_type=5, smooth_num_levels=2, ilu_tri_solve=0, ilu_lower_jacobi_iters=3,
                                      ilu_upper_jacobi_iters=4),
+                                dict(smooth_type=5, smooth_num_levels=2, ilu_level=1),  # ILU(1) as the complex smoother
                                 dict(smooth_type=5, smooth_num_levels=50)])
 def test_vcycle_matches_oracle(mi, oc, kw):
     A, b, x, amg, Ao, bo, oamg = _setup(mi, oc, 16, **kw)
@@ -487,10 +488,40 @@ def test_ilu_unsupported_variants_report_errors(mi):
     with pytest.raises(mi.HypreError):
         ilu.setup(A)
     mi.call("HYPRE_ClearAllErrors")
-    ilu = mi.ILU(fill=2)
+    ilu = mi.ILU(fill=-1)
     with pytest.raises(mi.HypreError):
         ilu.setup(A)
     mi.call("HYPRE_ClearAllErrors")
+
+
+@pytest.mark.parametrize("n,stencil,fill,trisolve", [(12, 7, 1, 1), (10, 7, 2, 1), (8, 27, 1, 1), (12, 7, 2, 0)])
+def test_iluk_matches_oracle(mi, oc, n, stencil, fill, trisolve):
+    """HYPRE_ILU type 0 with level of fill k (HYPRE_ILUSetLevelOfFill, /root/reference/src/HypreSystem.cpp:345-349): the
+    symbolic pattern is built on the host, the numeric factorisation and the substitutions are the ILU(0) kernels on
+    that pattern -- application, GMRES preconditioning (fewer iterations than ILU(0)) against the oracle."""
+    A, b, x, rhs = mi.build_laplace_system(n, n, n, stencil)
+    Ao, bo = oc.Csr.laplace(n, n, n, stencil)
+    ilu = mi.ILU(max_iterations=1, tolerance=0.0, trisolve=trisolve, lower_jacobi_iters=6, upper_jacobi_iters=6, fill=fill)
+    oilu = oc.Ilu(Ao, tri_solve=trisolve, lower_it=6, upper_it=6, level_of_fill=fill)
+    ilu.setup(A)
+    rng = np.random.default_rng(40 + fill)
+    v = rng.standard_normal(n ** 3)
+    bv = mi.IJVector(0, n ** 3 - 1, v)
+    xv = mi.IJVector(0, n ** 3 - 1, np.zeros(n ** 3))
+    ilu.solve(A, bv, xv)
+    ref = oilu.apply(v)
+    assert np.allclose(xv.get(), ref, rtol=1e-13, atol=1e-13 * np.abs(ref).max())
+    gm = mi.GMRES(tolerance=1e-9, max_iterations=200, kspace=40, print_level=0)
+    gm.set_precond(ilu)
+    gm.setup(A, b, x)
+    assert gm.solve(A, b, x) == 0
+    xo, info = oc.gmres(Ao, bo, kdim=40, tol=1e-9, maxit=200, amg=oilu)
+    assert gm.num_iterations == info["iters"]
+    assert np.allclose(gm.residual_history(), info["norms"], rtol=1e-7)
+    assert _allclose_ref(x.get(), xo)
+    if trisolve:
+        x0, info0 = oc.gmres(Ao, bo, kdim=40, tol=1e-9, maxit=200, amg=oc.Ilu(Ao))
+        assert info["iters"] < info0["iters"]
 
 
 def _ij_from_scipy(mi, M):
@@ -542,10 +573,10 @@ def test_degenerate_systems(mi, case):
 
 def test_unimplemented_complex_smoother_is_refused(mi):
     """smooth_num_levels > 0 with a smoother other than ILU (HYPRE's default smooth_type is 6 = Schwarz), or an ILU
-    variant other than block-Jacobi ILU(0): Setup fails with HYPRE_ERROR_ARG instead of smoothing with something else."""
+    variant other than block-Jacobi ILU(k): Setup fails with HYPRE_ERROR_ARG instead of smoothing with something else."""
     A, b, x, rhs = mi.build_laplace_system(8, 8, 8, 7)
     for kw in (dict(smooth_num_levels=1), dict(smooth_type=6, smooth_num_levels=2),
-               dict(smooth_type=5, smooth_num_levels=1, ilu_type=10), dict(smooth_type=5, smooth_num_levels=1, ilu_level=1)):
+               dict(smooth_type=5, smooth_num_levels=1, ilu_type=10), dict(smooth_type=5, smooth_num_levels=1, ilu_level=-1)):
         amg = mi.BoomerAMG(print_level=0, **kw)
         with pytest.raises(mi.HypreError) as e:
             amg.setup(A)

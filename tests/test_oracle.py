@@ -270,6 +270,64 @@ def test_ilu0_factor_reproduces_the_pattern_entries(oc):
     assert si["rel_res"] <= 1e-8 and np.allclose(xs, 1.0, atol=1e-6)
 
 
+def _iluk_pattern_reference(S, fill):
+    """Level-of-fill pattern by the textbook definition on dense level tables (Saad, Iterative Methods, 10.3.3):
+    lev_ij = 0 on A's pattern, else inf; for i, for k < i with lev_ik <= p, for j > k: lev_ij = min(lev_ij,
+    lev_ik + lev_kj + 1); entries with lev > p are dropped as soon as row i is done."""
+    n = S.shape[0]
+    lev = np.full((n, n), np.inf)
+    coo = S.tocoo()
+    lev[coo.row, coo.col] = 0
+    for i in range(n):
+        for k in range(i):
+            if lev[i, k] > fill:
+                continue
+            for j in range(k + 1, n):
+                if lev[k, j] <= fill:
+                    lev[i, j] = min(lev[i, j], lev[i, k] + lev[k, j] + 1)
+        lev[i, lev[i] > fill] = np.inf
+    return lev <= fill
+
+
+@pytest.mark.parametrize("fill", [1, 2, 3])
+def test_iluk_pattern_factor_and_limit(oc, fill):
+    """ILU(k) (HYPRE_ILUSetLevelOfFill, /root/reference/src/HypreSystem.cpp:345-349, ilu_level :258-262): the pattern
+    against the textbook level-of-fill definition on dense tables; (L U)_ij == a_ij on that pattern (0 on the fill); block
+    Jacobi keeps the fill inside the parts; with enough levels the factorisation is the exact LU; GMRES needs fewer
+    iterations than with ILU(0)."""
+    rng = np.random.default_rng(10 + fill)
+    n = 60
+    M = sp.random(n, n, density=0.06, random_state=rng, format="csr")
+    M = (M + M.T).tocsr()
+    M = (-abs(M) + sp.diags(np.asarray(abs(M).sum(axis=1)).ravel() + 1.0)).tocsr()
+    M.sort_indices()
+    A = oc.Csr.from_scipy(M)
+    ilu = oc.Ilu(A, level_of_fill=fill)
+    F = ilu.factor().to_scipy()
+    F.sort_indices()
+    pat = np.zeros((n, n), dtype=bool)
+    Fc = F.tocoo()
+    pat[Fc.row, Fc.col] = True
+    assert np.array_equal(pat, _iluk_pattern_reference(M, fill))
+    L = (sp.tril(F, -1) + sp.eye(n)).toarray()
+    U = sp.triu(F, 0).toarray()
+    R = L @ U - M.toarray()
+    assert np.abs(R[pat]).max() <= 1e-12 * abs(M).max()
+    # block Jacobi: no fill across the parts
+    bj_ilu = oc.Ilu(A, part_starts=[0, n // 3, n], level_of_fill=fill)  # (kept alive: the factor is a view into it)
+    bj = bj_ilu.factor().to_scipy().tocoo()
+    assert not np.any((bj.row < n // 3) != (bj.col < n // 3))
+    # enough levels = the complete factorisation
+    full = oc.Ilu(A, level_of_fill=n)
+    b = rng.standard_normal(n)
+    assert np.allclose(full.apply(b), spl.spsolve(M.tocsc(), b), rtol=1e-10, atol=1e-12)
+    # a better preconditioner than ILU(0) on the 7-point operator
+    A3, b3 = oc.Csr.laplace(10, 10, 10, 7)
+    it0 = oc.gmres(A3, b3, kdim=40, tol=1e-9, maxit=200, amg=oc.Ilu(A3))[1]["iters"]
+    itk = oc.gmres(A3, b3, kdim=40, tol=1e-9, maxit=200, amg=oc.Ilu(A3, level_of_fill=fill))[1]["iters"]
+    assert itk < it0, (itk, it0)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # Aggressive coarsening + multipass interpolation against an independent restatement (VERDICT r2 item 8): the
 # product and the oracle share one author, so `second_strength` / `build_multipass` are checked here against a
