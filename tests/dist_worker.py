@@ -63,6 +63,10 @@ def main():
     ap.add_argument("--coarsen", type=int, default=-1, help="coarsen_type (-1 = library default)")
     ap.add_argument("--aggtrunc", type=float, default=0.0, help="agg_trunc_factor")
     ap.add_argument("--aggpmax", type=int, default=0, help="agg_pmax_elmts")
+    ap.add_argument("--random", type=int, default=0,
+                    help="host mode: instead of the grid operator a seeded random M-matrix with this many rows (a chain plus "
+                         "random long-range couplings: every rank is a neighbour of most others, halo points' neighbours "
+                         "live on third ranks); --grid is then the seed")
     ap.add_argument("--combo", type=int, default=-1,
                     help="seed of a combination of BoomerAMG choices (tests/test_gpu_amg.py::_combo) applied to both sides")
     ap.add_argument("--smooth", type=int, default=0,
@@ -99,11 +103,22 @@ def main():
         if rank == 0:
             print("transport:", nm.value.decode())
     n, st = args.grid, args.stencil
-    N = n ** 3
+    N = args.random if args.random else n ** 3
     starts = [mi.row_partition(N, size, r)[0] for r in range(size)] + [N]
 
     # ---- oracle emulation of the same partition (every rank computes it; it is small)
-    Ao, bo = oc.Csr.laplace(n, n, n, st)
+    if args.random:
+        assert args.mode == "host"
+        rng = np.random.default_rng(8800 + args.grid)
+        R = sp.random(N, N, density=min(0.5, 5.0 / N), random_state=rng, format="csr")
+        R = (R + R.T + sp.diags([np.ones(N - 1), np.ones(N - 1)], [-1, 1])).tocsr()
+        R = (R - sp.diags(R.diagonal())).tocsr()
+        R.eliminate_zeros()
+        Mr = (-abs(R) + sp.diags(np.asarray(abs(R).sum(axis=1)).ravel() * float(rng.choice([1.0, 1.02, 1.2])) + 1e-3)).tocsr()
+        Mr.sort_indices()
+        Ao, bo = oc.Csr.from_scipy(Mr), np.asarray(Mr @ np.ones(N))
+    else:
+        Ao, bo = oc.Csr.laplace(n, n, n, st)
     chunk = mi.c_int()
     mi.call("HYPRE_MI_GetGSChunk", mi.C.byref(chunk))
     seq = args.seq if args.seq >= 0 else 200000
@@ -129,18 +144,36 @@ def main():
         smooth_o.update(_combo(args.combo))
     oamg = oc.Amg(Ao, oc.default_params(gs_chunk=chunk.value, part_starts=starts, redundant_rows=seq, **smooth_o))
 
-    if args.mode == "host":
+    if args.random:
+        lo, hi = starts[rank], starts[rank + 1]
+        A = mi.IJMatrix.__new__(mi.IJMatrix)  # (host-only: no Initialize, which would ask for the device)
+        A.h = mi.vp()
+        A.ilower, A.iupper = lo, hi - 1
+        mi.call("HYPRE_IJMatrixCreate", 0, mi.c_big(lo), mi.c_big(hi - 1), mi.c_big(lo), mi.c_big(hi - 1), mi.C.byref(A.h))
+        mi.call("HYPRE_IJMatrixSetObjectType", A.h, mi.HYPRE_PARCSR)
+        A.par = mi.vp()
+        mi.call("HYPRE_IJMatrixGetObject", A.h, mi.C.byref(A.par))
+        coo = Mr[lo:hi].tocoo()
+        A.set_values_coo(coo.row.astype(np.int64) + lo, coo.col.astype(np.int64), coo.data)
+        mi.call("HYPRE_MI_IJMatrixAssembleHostOnly", A.h)
+        rhs = bo[lo:hi]
+    elif args.mode == "host":
         A, rhs = mi.build_laplace_system_host(n, n, n, st, rank, size)
     else:
         A, b, x, rhs = mi.build_laplace_system(n, n, n, st, rank, size)
     assert np.array_equal(rhs, bo[starts[rank]:starts[rank + 1]])
 
-    # ---- halo plan: z-slab neighbours only, what I send is what my neighbour receives
+    # ---- halo plan: the ranks whose columns my rows touch (z-slab neighbours for the grid operators), what I send is
+    # what my neighbour receives
     plan = mi.halo_plan(A)
-    expect = [r for r in (rank - 1, rank + 1) if 0 <= r < size]
+    S = Ao.to_scipy().tocsr()
+    mine = S[starts[rank]:starts[rank + 1]]
+    expect = [r for r in range(size) if r != rank and mine[:, starts[r]:starts[r + 1]].nnz > 0]
+    expect_send = [r for r in range(size) if r != rank and S[starts[r]:starts[r + 1], starts[rank]:starts[rank + 1]].nnz > 0]
+    if not args.random:
+        assert expect == [r for r in (rank - 1, rank + 1) if 0 <= r < size]
     assert list(plan["recv_peers"]) == expect, (rank, plan)
-    assert list(plan["send_peers"]) == expect, (rank, plan)
-    S = Ao.to_scipy()
+    assert list(plan["send_peers"]) == expect_send, (rank, plan)
     for i, p in enumerate(plan["recv_peers"]):
         # columns of peer p that my rows touch
         sub = S[starts[rank]:starts[rank + 1], starts[p]:starts[p + 1]]
@@ -208,9 +241,10 @@ def main():
         # whose stencils reach a few planes), never the global operator; only levels below the redundancy
         # threshold are gathered
         nloc0 = starts[rank + 1] - starts[rank]
-        assert counter("setup_ext_rows_max") <= nloc0 + 8 * n * n, (counter("setup_ext_rows_max"), nloc0, N)
-        if N >= 8 * (nloc0 + 8 * n * n) // 4:
-            assert counter("setup_ext_rows_max") < N
+        if not args.random:  # (a random operator's two halo rings are most of the system)
+            assert counter("setup_ext_rows_max") <= nloc0 + 8 * n * n, (counter("setup_ext_rows_max"), nloc0, N)
+            if N >= 8 * (nloc0 + 8 * n * n) // 4:
+                assert counter("setup_ext_rows_max") < N
         gathered = counter("setup_global_rows_gathered")
         assert gathered <= max(seq, 0), (gathered, seq)
         # threshold 0 on a GPU: the large levels of the distributed setup are built on the device (extended index

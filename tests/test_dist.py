@@ -18,7 +18,7 @@ WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
 
 
 def _run(nproc, mode, n, stencil, port, staging="host", seq=-1, devmin=None, golden="", replicated=False, locality=0,
-         smooth=0, relax=0, combo=-1, transport="", ng=0.0, agg=0, interp=-1, aggtrunc=0.0, aggpmax=0, coarsen=-1):
+         smooth=0, relax=0, combo=-1, transport="", ng=0.0, agg=0, interp=-1, aggtrunc=0.0, aggpmax=0, coarsen=-1, random=0):
     env = dict(os.environ)
     env["MI_HYPRE_REPLICATED_SETUP"] = "1" if replicated else "0"
     if devmin is not None:  # levels with at least this many rows are built (and sliced) on the device
@@ -50,6 +50,8 @@ def _run(nproc, mode, n, stencil, port, staging="host", seq=-1, devmin=None, gol
         cmd += ["--interp", str(interp)]
     if coarsen >= 0:
         cmd += ["--coarsen", str(coarsen)]
+    if random:
+        cmd += ["--random", str(random)]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-4000:]
     return p.stdout
@@ -124,6 +126,20 @@ def test_host_setup_per_rank_coarsening_types_distributed_gloo(nproc, n, stencil
     (0 / 7) is a global algorithm whose rounds commute: distributed with the same splitting on any partition."""
     out = _run(nproc, "host", n, stencil, 30511 + nproc + n + coarsen, seq=seq, coarsen=coarsen, agg=agg, interp=interp, ng=ng,
                locality=locality)
+    assert "dist host setup ok" in out
+
+
+@pytest.mark.parametrize("nproc,rows,seed,seq,coarsen,agg,interp,ng",
+                         [(3, 1200, 3, 0, 10, 0, -1, 0.0), (4, 1500, 4, 0, 6, 0, -1, 0.0), (5, 1800, 5, 0, 0, 0, -1, 0.0),
+                          (8, 2400, 6, 0, 10, 1, -1, 0.0), (4, 1600, 7, 100, 6, 0, 0, 0.0), (6, 2000, 8, 0, -1, 0, 4, 0.0),
+                          (8, 2500, 9, 0, -1, 2, -1, 0.0), (4, 1400, 11, 0, 1, 0, -1, 0.05)])
+def test_host_setup_random_operators_distributed_gloo(nproc, rows, seed, seq, coarsen, agg, interp, ng):
+    """The distributed setup on UNSTRUCTURED operators: a seeded random M-matrix (a chain plus random long-range
+    couplings) in contiguous row blocks -- every rank is a neighbour of most others, the neighbours of halo points and
+    the C points an interpolation row reaches live on third ranks, the second-generation graph's remote columns are
+    owned by ranks that are not neighbours in A.  PMIS / HMIS / Falgout / CLJP / per-rank Ruge-Stueben, aggressive
+    levels, multipass, classical interpolation, non-Galerkin operators: the oracle's hierarchy level by level."""
+    out = _run(nproc, "host", seed, 7, 30711 + nproc + seed, seq=seq, coarsen=coarsen, agg=agg, interp=interp, ng=ng, random=rows)
     assert "dist host setup ok" in out
 
 
