@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--aggtrunc", type=float, default=0.0, help="agg_trunc_factor")
     ap.add_argument("--aggpmax", type=int, default=0, help="agg_pmax_elmts")
     ap.add_argument("--random", type=int, default=0,
-                    help="host mode: instead of the grid operator a seeded random M-matrix with this many rows (a chain plus "
+                    help="instead of the grid operator a seeded random M-matrix with this many rows (a chain plus "
                          "random long-range couplings: every rank is a neighbour of most others, halo points' neighbours "
                          "live on third ranks); --grid is then the seed")
     ap.add_argument("--combo", type=int, default=-1,
@@ -108,7 +108,6 @@ def main():
 
     # ---- oracle emulation of the same partition (every rank computes it; it is small)
     if args.random:
-        assert args.mode == "host"
         rng = np.random.default_rng(8800 + args.grid)
         R = sp.random(N, N, density=min(0.5, 5.0 / N), random_state=rng, format="csr")
         R = (R + R.T + sp.diags([np.ones(N - 1), np.ones(N - 1)], [-1, 1])).tocsr()
@@ -144,7 +143,16 @@ def main():
         smooth_o.update(_combo(args.combo))
     oamg = oc.Amg(Ao, oc.default_params(gs_chunk=chunk.value, part_starts=starts, redundant_rows=seq, **smooth_o))
 
-    if args.random:
+    if args.random and args.mode != "host":
+        lo, hi = starts[rank], starts[rank + 1]
+        A = mi.IJMatrix(lo, hi - 1)
+        coo = Mr[lo:hi].tocoo()
+        A.set_values_coo(coo.row.astype(np.int64) + lo, coo.col.astype(np.int64), coo.data)
+        A.assemble()
+        rhs = bo[lo:hi]
+        b = mi.IJVector(lo, hi - 1, rhs)
+        x = mi.IJVector(lo, hi - 1, np.zeros(hi - lo))
+    elif args.random:
         lo, hi = starts[rank], starts[rank + 1]
         A = mi.IJMatrix.__new__(mi.IJMatrix)  # (host-only: no Initialize, which would ask for the device)
         A.h = mi.vp()
@@ -251,7 +259,8 @@ def main():
         # spaces, amg_setup_dist.cpp DevLevel) -- at least level 0, where every rank has rows
         if (args.mode == "solve" and os.environ.get("MI_HYPRE_DEVICE_SETUP_MIN_ROWS", "") == "0"
                 and os.environ.get("MI_HYPRE_DIST_DEVICE_SETUP", "1") != "0" and smooth_o.get("interp_type", 6) in (0, 6)
-                and smooth_o.get("agg_num_levels", 0) == 0):  # (aggressive levels are host passes and come first)
+                and smooth_o.get("agg_num_levels", 0) == 0  # (aggressive levels are host passes and come first)
+                and smooth_o.get("coarsen_type", 8) in (8, 9)):  # (PMIS is what the device loop runs)
             assert counter("setup_device_levels") >= 1, "no level of the distributed setup was built on the device"
             if rank == 0:
                 print("distributed setup: %d level(s) built on the device" % counter("setup_device_levels"))
@@ -408,7 +417,7 @@ def main():
             no_gs = bool(args.smooth) or args.relax in (11, 12, 7, 18) or args.combo >= 0
             if not no_gs:  # (the ILU complex smoother and the two-stage / Jacobi smoothers run no Gauss-Seidel passes)
                 assert cnt["gs_overlapped"] + cnt["gs_in_order"] > 0, cnt
-            if size == 2 and n >= 12 and not no_gs:  # slabs of >= 6 planes with one neighbour: most rows are halo-free
+            if size == 2 and n >= 12 and not no_gs and not args.random:  # slabs of >= 6 planes with one neighbour: most rows are halo-free
                 assert cnt["gs_overlapped"] > 0, cnt
         if rank == 0:
             print(f"overlap counters rank 0: {cnt}")

@@ -238,6 +238,18 @@ def test_device_solve_per_rank_coarsening_types_shared_gpu(nproc, n, stencil, se
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nproc,rows,seed,seq,devmin,coarsen,agg", [(3, 3000, 21, 0, 0, -1, 0), (4, 4000, 22, 300, None, -1, 0),
+                                                                   (4, 3500, 24, 0, 0, -1, 0), (2, 2500, 23, 0, 0, 6, 0),
+                                                                   (3, 3000, 25, 0, None, -1, 1)])
+def test_device_solve_random_operators_shared_gpu(nproc, rows, seed, seq, devmin, coarsen, agg):
+    """UNSTRUCTURED operators on N ranks (seeded random M-matrices in contiguous row blocks: many neighbours per rank,
+    third-rank owners) through the distributed setup -- device-resident levels with the threshold at 0, the host loop
+    otherwise -- and the device solve: hierarchy, halo plans, iterations, residual history, solution vs the oracle."""
+    out = _run(nproc, "solve", seed, 7, 30751 + nproc + seed, seq=seq, devmin=devmin, coarsen=coarsen, agg=agg, random=rows)
+    assert "dist solve ok" in out
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("nproc,n,stencil,seq", [(2, 16, 7, -1), (3, 12, 27, 0), (4, 16, 7, 1000)])
 def test_device_solve_with_locality_numbering_shared_gpu(nproc, n, stencil, seq):
     out = _run(nproc, "solve", n, stencil, 29871 + nproc + n, seq=seq, locality=1)
