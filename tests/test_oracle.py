@@ -597,3 +597,68 @@ def test_extended_i_with_weak_connections_and_classical_modified(oc):
             P[i, cidx[j]] = -v / diag
     Pref0 = P.tocsr().tocsc()[:, np.asarray(amg0.level_perm(1))].tocsr()
     assert abs(amg0.level_P(0).to_scipy() - Pref0).max() < 1e-13
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The coarsening types HYPRE defines per processor, on several parts (round 3: coarsen_by_type_parts, pmis_from,
+# cljp_from): properties that follow from their definitions, checked without sharing code with the routines.
+# ---------------------------------------------------------------------------------------------------------------
+def _natural_cf(amg):
+    """C/F marker of level 0 in the caller's row order."""
+    perm = np.asarray(amg.level_perm(0))
+    cf = np.empty(len(perm), dtype=int)
+    cf[perm] = np.asarray(amg.level_cf(0))
+    return cf
+
+
+def test_per_processor_coarsening_types_on_several_parts(oc):
+    n = 10
+    A, b = oc.Csr.laplace(n, n, n, 7)
+    N = n ** 3
+    M = A.to_scipy().tocsr()
+    S = _strength_pattern(M)                       # symmetric here (all couplings -1)
+    ps = np.array([0, 300, 640, N])                # cuts inside grid planes: irregular part boundaries
+    part = np.searchsorted(ps, np.arange(N), side="right") - 1
+    Sc = S.tocoo()
+    boundary = np.zeros(N, dtype=bool)
+    boundary[Sc.row[part[Sc.row] != part[Sc.col]]] = True
+    has_strong = np.asarray(S.sum(axis=1)).ravel() > 0
+
+    def cf_of(ctype, parts=True):
+        kw = dict(part_starts=ps, redundant_rows=0) if parts else {}
+        return _natural_cf(oc.Amg(A, oc.default_params(coarsen_type=ctype, **kw)))
+
+    cf = {t: cf_of(t) for t in (10, 6, 11, 1, 0)}
+    # 11 / 1: Ruge-Stueben on every part's own graph == the single-part routine on the part's diagonal block (whose
+    # strength pattern is the restriction of the global one for this operator)
+    for t in (11, 1):
+        for q in range(3):
+            lo, hi = ps[q], ps[q + 1]
+            sub = oc.Csr.from_scipy(M[lo:hi][:, lo:hi].tocsr())
+            assert np.array_equal(_strength_pattern(M[lo:hi][:, lo:hi]).toarray(), S[lo:hi][:, lo:hi].toarray())
+            alone = _natural_cf(oc.Amg(sub, oc.default_params(coarsen_type=t)))
+            assert np.array_equal(cf[t][lo:hi], alone), (t, q)
+    # partition dependence is real: the global first pass decides the points at the part boundaries otherwise
+    assert not np.array_equal(cf[11], cf_of(11, parts=False))
+    # 10 = HMIS: the interior C points of the per-part first pass stay, the rest is a PMIS splitting: independent C set,
+    # every F point with strong connections depends on a C point
+    C10 = cf[10] == 1
+    assert np.all(C10[(cf[11] == 1) & ~boundary])
+    assert S[C10][:, C10].nnz == 0
+    dep_c = np.asarray(S[:, C10].sum(axis=1)).ravel() > 0
+    assert np.all(dep_c[~C10 & has_strong])
+    # 6 = Falgout: interior points keep the verdict of the two passes per part, the boundary is decided by CLJP (which,
+    # unlike PMIS, promises neither an independent C set nor a C neighbour for every F point: a point turns F when
+    # nothing undecided depends on it any more, and C when it outweighs its undecided neighbours)
+    assert np.array_equal(cf[6][~boundary], cf[1][~boundary])
+    C6 = cf[6] == 1
+    assert (C6 & boundary).any() and (~C6 & boundary).any()
+    assert not np.array_equal(cf[6], cf_of(6, parts=False))
+    # 0 = CLJP is a global algorithm: parts do not matter
+    assert np.array_equal(cf[0], cf_of(0, parts=False))
+    # every variant coarsens at a sensible rate and the hierarchy solves the system
+    for t in (10, 6, 11, 1, 0):
+        assert 0.1 < (cf[t] == 1).mean() < 0.7, t  # (CLJP keeps 62 % of a structured grid: its known weakness)
+        amg = oc.Amg(A, oc.default_params(coarsen_type=t, part_starts=ps, redundant_rows=0))
+        x, info = oc.gmres(A, b, kdim=30, tol=1e-8, maxit=60, amg=amg)
+        assert info["converged"] and np.allclose(x, 1.0, atol=1e-6), t
