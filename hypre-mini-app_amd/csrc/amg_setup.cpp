@@ -2503,6 +2503,13 @@ void BoomerAMG::setup_device() {
   is_setup = true;
   setup_seconds = wall_time() - t_setup_start;
   if (timing) {
+    long long mp = 0, iu = 0, pm = 0, pu = 0, gr = 0, dr = 0;
+    double tg = 0.0, td = 0.0;
+    dev_arena_stats(&mp, &iu, &pm, &pu);
+    dev_arena_times(&tg, &td, &gr, &dr);
+    printf("   device arena (since the process started): %.1f GiB mapped (peak %.1f), %.1f GiB in use (peak %.1f); grown %lld times, %.2f s inside "
+           "hipMemCreate/Map; %lld stream drains before a reuse, %.2f s\n",
+           mp / 1073741824.0, pm / 1073741824.0, iu / 1073741824.0, pu / 1073741824.0, gr, tg, dr, td);
     printf("   value dictionaries (1-byte value stream):");
     for (size_t li = 0; li < L.size(); li++) {
       const AmgLevel &Lv = L[li];

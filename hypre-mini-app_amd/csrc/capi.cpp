@@ -1218,6 +1218,16 @@ HYPRE_Int HYPRE_MI_GetCounter(const char *name, long long *value) {
     *value = n == "pool_cached_bytes" ? cb : n == "pool_hits" ? h : m;
     return 0;
   }
+  if (n.rfind("arena_", 0) == 0) {
+    long long mp = 0, iu = 0, pm = 0, pu = 0;
+    dev_arena_stats(&mp, &iu, &pm, &pu);
+    if (n == "arena_mapped_bytes") *value = mp;
+    else if (n == "arena_in_use_bytes") *value = iu;
+    else if (n == "arena_peak_mapped_bytes") *value = pm;
+    else if (n == "arena_peak_in_use_bytes") *value = pu;
+    else fail(HYPRE_ERROR_ARG, "GetCounter: unknown counter " + n);
+    return 0;
+  }
   if (n == "matvec_overlapped")
     *value = ctx().n_matvec_overlapped;
   else if (n == "gs_overlapped")

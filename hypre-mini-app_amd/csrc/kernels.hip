@@ -1615,6 +1615,13 @@ __global__ __launch_bounds__(256) void value_index_k(long long n, const double *
 }
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void strided_sample_k(const double *__restrict__ a, size_t stride, int n, double *__restrict__ out) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k < n) out[k] = a[(size_t)k * stride];
+}
+}  // namespace
+
 static int g_value_dict = -1;
 bool value_dictionary_enabled() {
   if (g_value_dict < 0) g_value_dict = (getenv("MI_HYPRE_VALUE_DICT") && atoi(getenv("MI_HYPRE_VALUE_DICT")) == 0) ? 0 : 1;
@@ -1635,9 +1642,15 @@ void build_value_dictionary(DevCSR &A, hipStream_t s) {
   const size_t sample = (size_t)std::min<int64_t>(A.nnz, 1 << 16);
   const size_t stride = (size_t)A.nnz / sample;
   std::vector<double> hs(sample);
-  MI_HIP(hipMemcpy2DAsync(hs.data(), sizeof(double), A.a.p, stride * sizeof(double), sizeof(double), sample,
-                          hipMemcpyDeviceToHost, s));
-  MI_HIP(hipStreamSynchronize(s));
+  {
+    // (a kernel, not hipMemcpy2DAsync: the strided source may span several physical chunks of the device arena, which
+    // the 2-D copy refuses with "invalid argument")
+    DVec<double> dsample(sample);
+    hipLaunchKernelGGL(strided_sample_k, dim3((unsigned)((sample + 255) / 256)), dim3(256), 0, s, A.a.p, stride, (int)sample, dsample.p);
+    MI_HIP(hipGetLastError());
+    MI_HIP(hipMemcpyAsync(hs.data(), dsample.p, sample * sizeof(double), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+  }
   std::vector<long long> bits(sample);
   std::memcpy(bits.data(), hs.data(), sample * sizeof(double));
   std::sort(bits.begin(), bits.end());

@@ -38,17 +38,21 @@ struct Error : std::runtime_error {
   } while (0)
 
 // ---------------------------------------------------------------- device memory
-// Caching pool behind every DVec (runtime.cpp): a released block is kept and handed to the next request of a similar
-// size instead of going back to the driver.  The AMG setup allocates and frees hundreds of transient multi-GB
-// buffers; every hipFree synchronises the device and every fresh hipMalloc maps new VRAM pages, which on a freshly
-// booted box costs the FIRST process seconds (512^3 setup: 16.2 s in the first process of a box, 10.3 s in the second).
-// Reusing a cached block synchronises the library's streams first (what hipFree's implicit synchronisation gave).
-// Cached bytes are bounded (MI_HYPRE_POOL_MAX_GB, default 48); dev_pool_trim() -- end of Setup, allocation failure --
-// returns every cached block to the driver.  MI_HYPRE_POOL=0: plain hipMalloc / hipFree.
+// Behind every DVec (runtime.cpp): one growable arena in a reserved address range (HIP virtual-memory API; physical
+// 1 GiB chunks mapped at the top as it grows, best-fit free list with coalescing inside), so that memory the setup
+// releases is reused whatever the next request's size and never goes back to the driver while the library works --
+// the driver clears returned memory before handing it out again (30 ms per GiB inside hipMalloc: 11 of the 16 s of a
+// 512^3 setup in round 3, profiles/r04_setup_split_512_before.txt).  A block released since the library's streams were
+// last drained is handed out after draining them (what hipFree's implicit synchronisation gave).  dev_pool_trim() --
+// end of Setup, HYPRE_Finalize -- unmaps free chunks from the top beyond a quarter of what is in use.
+// MI_HYPRE_POOL: 2 = arena (default), 1 = the size-class block cache of round 3 (MI_HYPRE_POOL_MAX_GB, default 48; also
+// the fallback when the virtual-memory API is unavailable), 0 = plain hipMalloc / hipFree.
 void *dev_alloc(size_t bytes);
 void dev_free(void *p);
 void dev_pool_trim();
 void dev_pool_stats(long long *cached_bytes, long long *hits, long long *misses);
+void dev_arena_stats(long long *mapped, long long *in_use, long long *peak_mapped, long long *peak_in_use);
+void dev_arena_times(double *t_grow, double *t_drain, long long *grown, long long *drains);
 
 template <class T>
 struct DVec {

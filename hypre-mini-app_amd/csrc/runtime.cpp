@@ -9,6 +9,7 @@
 
 #include <map>
 #include <mutex>
+#include <set>
 #include <unordered_map>
 
 #include "kernels.hpp"
@@ -162,7 +163,24 @@ TraceRange::~TraceRange() {
   if (on) roctx().pop();
 }
 
-// ---------------------------------------------------------------- caching device-memory pool (mi_internal.hpp)
+// ---------------------------------------------------------------- device memory behind every DVec (mi_internal.hpp)
+// Round 4: ONE GROWABLE ARENA in a reserved address range (HIP virtual-memory API: hipMemAddressReserve, physical
+// chunks of 1 GiB created and mapped back to back at the top as the heap grows), with an ordinary best-fit free list
+// and coalescing of neighbouring free ranges inside it.  Why: a rocprofv3 trace of the 512^3 setup
+// (profiles/r04_setup_split_512_before.txt) showed the device busy 4.8 s of 16.4 s; 11 s of the rest sat in front
+// of the first kernel that touches a FRESH allocation, at a constant 30 ms per GiB -- memory that goes back to the
+// driver (hipFree, or the size-class cache of round 3 trimming itself at its cap) is cleared by the kernel driver before
+// it is handed out again, at ~35 GB/s, inside hipMalloc (profiles/debug/malloc_cost.py, vmm_probe.cpp: the first
+// 64-130 GiB of a fresh box are clean and cost nothing, everything after that 30.2 ms per GiB).  The setup allocates
+// and frees ~270 GB in hundreds of blocks of every size, so a cache that serves only requests of a similar size
+// (round 3) misses most of them.  The arena never gives memory back while it works: every byte is mapped (and, if
+// dirty, cleared) at most once, whatever the sequence of sizes; dev_pool_trim() -- end of Setup, HYPRE_Finalize --
+// unmaps whole chunks from the top that are free, keeping a quarter of what is in use (the Krylov basis is
+// allocated next).  MI_HYPRE_POOL: 2 (default) arena, falling back to 1 when the virtual-memory API is not
+// available; 1 the size-class cache of round 3 (MI_HYPRE_POOL_MAX_GB); 0 plain hipMalloc / hipFree.
+// A block is handed to a new owner without synchronisation unless part of it was released since the library's
+// streams were last drained (release epochs), in which case they are drained first: what hipFree's implicit
+// synchronisation gave, paid only when it is needed.
 namespace {
 struct DevPool {
   std::mutex m;
@@ -174,7 +192,9 @@ struct DevPool {
   size_t max_cached = 0;
   void init() {
     if (enabled >= 0) return;
-    enabled = (getenv("MI_HYPRE_POOL") && atoi(getenv("MI_HYPRE_POOL")) == 0) ? 0 : 1;
+    const char *e = getenv("MI_HYPRE_POOL");
+    enabled = e ? atoi(e) : 2;
+    if (enabled < 0 || enabled > 2) enabled = 2;
     const double gb = getenv("MI_HYPRE_POOL_MAX_GB") ? atof(getenv("MI_HYPRE_POOL_MAX_GB")) : 48.0;
     max_cached = (size_t)(gb * 1e9);
   }
@@ -188,10 +208,217 @@ size_t pool_round(size_t bytes) {
   if (bytes <= (1u << 20)) return (bytes + 4095) / 4096 * 4096;
   return (bytes + ((size_t)2 << 20) - 1) / ((size_t)2 << 20) * ((size_t)2 << 20);
 }
+
+void drain_library_streams() {
+  Ctx &c = ctx();
+  if (c.inited) {
+    MI_HIP(hipStreamSynchronize(c.stream));
+    MI_HIP(hipStreamSynchronize(c.comm_stream));
+  } else {
+    MI_HIP(hipDeviceSynchronize());
+  }
+}
+
+struct DevArena {
+  std::mutex m;
+  int state = 0;  // 0 untried, 1 working, -1 unavailable
+  char *base = nullptr;
+  size_t va_size = 0, chunk = 0, mapped = 0;
+  int device = 0;
+  std::vector<hipMemGenericAllocationHandle_t> handles;  // one per mapped chunk, bottom to top
+  struct Free {
+    size_t size;
+    unsigned long long epoch;  // newest release that went into this range
+  };
+  std::map<size_t, Free> free_by_off;                // offset -> range
+  std::set<std::pair<size_t, size_t>> free_by_size;  // (size, offset)
+  std::unordered_map<size_t, size_t> live;           // offset -> size
+  unsigned long long release_epoch = 0, drained_epoch = 0;
+  size_t in_use = 0, peak_in_use = 0, peak_mapped = 0;
+  long long served = 0, grown = 0, drains = 0;
+  double t_grow = 0.0, t_drain = 0.0;  // seconds inside hipMemCreate / Map / SetAccess, and waiting for the streams
+
+  bool init() {
+    if (state) return state > 0;
+    state = -1;
+    if (hipGetDevice(&device) != hipSuccess) return false;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) {
+      (void)hipGetLastError();
+      return false;
+    }
+    size_t want_chunk = (size_t)(getenv("MI_HYPRE_ARENA_CHUNK_MB") ? atoll(getenv("MI_HYPRE_ARENA_CHUNK_MB")) : 1024) << 20;
+    if (want_chunk < gran) want_chunk = gran;
+    chunk = (want_chunk + gran - 1) / gran * gran;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = (size_t)288 << 30;
+    va_size = ((2 * total_b + chunk - 1) / chunk + 1) * chunk;  // address space is free: twice the device's memory
+    void *b = nullptr;
+    if (hipMemAddressReserve(&b, va_size, 0, nullptr, 0) != hipSuccess || !b) {
+      (void)hipGetLastError();
+      return false;
+    }
+    base = (char *)b;
+    state = 1;
+    return true;
+  }
+  void put_free(size_t off, size_t size, unsigned long long epoch) {
+    // coalesce with the neighbours
+    auto next = free_by_off.lower_bound(off);
+    if (next != free_by_off.begin()) {
+      auto prev = std::prev(next);
+      if (prev->first + prev->second.size == off) {
+        off = prev->first;
+        size += prev->second.size;
+        epoch = std::max(epoch, prev->second.epoch);
+        free_by_size.erase({prev->second.size, prev->first});
+        free_by_off.erase(prev);
+      }
+    }
+    if (next != free_by_off.end() && off + size == next->first) {
+      size += next->second.size;
+      epoch = std::max(epoch, next->second.epoch);
+      free_by_size.erase({next->second.size, next->first});
+      free_by_off.erase(next);
+    }
+    free_by_off[off] = Free{size, epoch};
+    free_by_size.insert({size, off});
+  }
+  // map `n` more chunks at the top; false when the device has no memory left for them
+  bool grow(size_t n) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    const size_t old_mapped = mapped;
+    const double tg0 = wall_time();
+    for (size_t q = 0; q < n; q++) {
+      if (mapped + chunk > va_size) break;
+      hipMemGenericAllocationHandle_t h;
+      if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        break;
+      }
+      if (hipMemMap(base + mapped, chunk, 0, h, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipMemRelease(h);
+        break;
+      }
+      if (hipMemSetAccess(base + mapped, chunk, &acc, 1) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipMemUnmap(base + mapped, chunk);
+        (void)hipMemRelease(h);
+        break;
+      }
+      handles.push_back(h);
+      mapped += chunk;
+    }
+    if (mapped > old_mapped) put_free(old_mapped, mapped - old_mapped, 0);
+    peak_mapped = std::max(peak_mapped, mapped);
+    grown++;
+    t_grow += wall_time() - tg0;
+    return mapped - old_mapped == n * chunk;
+  }
+  void *alloc(size_t bytes) {
+    size_t want = bytes < 256 ? 256 : (bytes + 255) / 256 * 256;
+    if (want >= ((size_t)1 << 16)) want = (want + 4095) / 4096 * 4096;
+    auto it = free_by_size.lower_bound({want, 0});
+    if (it == free_by_size.end()) {
+      // the free range at the top (if any) counts towards the request
+      size_t top_free = 0;
+      if (!free_by_off.empty()) {
+        auto last = std::prev(free_by_off.end());
+        if (last->first + last->second.size == mapped) top_free = last->second.size;
+      }
+      const size_t need = want - std::min(want, top_free);
+      if (!grow((need + chunk - 1) / chunk)) return nullptr;
+      it = free_by_size.lower_bound({want, 0});
+      if (it == free_by_size.end()) return nullptr;
+    } else {
+      served++;
+    }
+    const size_t off = it->second, size = it->first;
+    const Free f = free_by_off[off];
+    free_by_size.erase(it);
+    free_by_off.erase(off);
+    if (size > want) {
+      free_by_off[off + want] = Free{size - want, f.epoch};
+      free_by_size.insert({size - want, off + want});
+    }
+    live[off] = want;
+    in_use += want;
+    peak_in_use = std::max(peak_in_use, in_use);
+    if (f.epoch > drained_epoch) {
+      // part of this range was released after the streams were last drained: its previous owner's kernels may
+      // still be running
+      const unsigned long long e = release_epoch;
+      const double td0 = wall_time();
+      drain_library_streams();
+      t_drain += wall_time() - td0;
+      drains++;
+      drained_epoch = e;
+    }
+    return base + off;
+  }
+  bool owns(const void *p) const { return state > 0 && (const char *)p >= base && (const char *)p < base + va_size; }
+  void release(void *p) {
+    const size_t off = (size_t)((char *)p - base);
+    auto it = live.find(off);
+    if (it == live.end()) return;  // (double release: ignored, as hipFree would report and the old pool ignored)
+    const size_t size = it->second;
+    live.erase(it);
+    in_use -= size;
+    put_free(off, size, ++release_epoch);
+  }
+  // unmap whole free chunks from the top, keeping `keep` bytes of free space there
+  void trim(size_t keep) {
+    if (state <= 0 || free_by_off.empty()) return;
+    auto last = std::prev(free_by_off.end());
+    if (last->first + last->second.size != mapped) return;
+    const size_t start = last->first + std::min(keep, last->second.size);
+    const size_t new_mapped = (start + chunk - 1) / chunk * chunk;
+    if (new_mapped >= mapped) return;
+    drain_library_streams();
+    drained_epoch = release_epoch;
+    const Free f = last->second;
+    const size_t off = last->first;
+    free_by_size.erase({f.size, off});
+    free_by_off.erase(last);
+    while (mapped > new_mapped) {
+      mapped -= chunk;
+      (void)hipMemUnmap(base + mapped, chunk);
+      (void)hipMemRelease(handles.back());
+      handles.pop_back();
+    }
+    if (mapped > off) {
+      free_by_off[off] = Free{mapped - off, f.epoch};
+      free_by_size.insert({mapped - off, off});
+    }
+  }
+};
+DevArena &arena() {
+  static DevArena *a = new DevArena();  // never destroyed (see pool())
+  return *a;
+}
 }  // namespace
 
 void dev_pool_trim() {
   DevPool &P = pool();
+  P.init();
+  if (P.enabled == 2) {
+    DevArena &A = arena();
+    std::lock_guard<std::mutex> g(A.m);
+    static const double keep_gb = getenv("MI_HYPRE_ARENA_KEEP_GB") ? atof(getenv("MI_HYPRE_ARENA_KEEP_GB")) : -1.0;
+    const size_t keep = keep_gb >= 0.0 ? (size_t)(keep_gb * 1073741824.0) : std::max<size_t>((size_t)2 << 30, A.in_use / 4);
+    A.trim(A.in_use == 0 ? 0 : keep);
+  }
   std::vector<void *> blocks;
   {
     std::lock_guard<std::mutex> g(P.m);
@@ -207,10 +434,37 @@ void dev_pool_trim() {
 
 void dev_pool_stats(long long *cached_bytes, long long *hits, long long *misses) {
   DevPool &P = pool();
+  P.init();
+  if (P.enabled == 2 && arena().state > 0) {
+    DevArena &A = arena();
+    std::lock_guard<std::mutex> g(A.m);
+    if (cached_bytes) *cached_bytes = (long long)(A.mapped - A.in_use);
+    if (hits) *hits = A.served;
+    if (misses) *misses = A.grown;
+    return;
+  }
   std::lock_guard<std::mutex> g(P.m);
   if (cached_bytes) *cached_bytes = (long long)P.cached;
   if (hits) *hits = P.hits;
   if (misses) *misses = P.misses;
+}
+
+void dev_arena_times(double *t_grow, double *t_drain, long long *grown, long long *drains) {
+  DevArena &A = arena();
+  std::lock_guard<std::mutex> g(A.m);
+  if (t_grow) *t_grow = A.t_grow;
+  if (t_drain) *t_drain = A.t_drain;
+  if (grown) *grown = A.grown;
+  if (drains) *drains = A.drains;
+}
+
+void dev_arena_stats(long long *mapped, long long *in_use, long long *peak_mapped, long long *peak_in_use) {
+  DevArena &A = arena();
+  std::lock_guard<std::mutex> g(A.m);
+  if (mapped) *mapped = (long long)A.mapped;
+  if (in_use) *in_use = (long long)A.in_use;
+  if (peak_mapped) *peak_mapped = (long long)A.peak_mapped;
+  if (peak_in_use) *peak_in_use = (long long)A.peak_in_use;
 }
 
 void *dev_alloc(size_t bytes) {
@@ -220,6 +474,19 @@ void *dev_alloc(size_t bytes) {
   if (!P.enabled) {
     MI_HIP(hipMalloc(&p, bytes));
     return p;
+  }
+  if (P.enabled == 2) {
+    DevArena &A = arena();
+    std::lock_guard<std::mutex> g(A.m);
+    if (A.init()) {
+      p = A.alloc(bytes);
+      if (!p)
+        fail(2, "device arena: cannot map " + std::to_string(bytes) + " more bytes (" + std::to_string(A.mapped) +
+                    " mapped, " + std::to_string(A.in_use) + " in use): out of device memory");
+      return p;
+    }
+    P.enabled = 1;  // no virtual-memory API here: the size-class cache
+    if (getenv("MI_HYPRE_VERBOSE")) fprintf(stderr, "mi_hypre: HIP virtual-memory API unavailable, using the block cache\n");
   }
   const size_t want = pool_round(bytes);
   {
@@ -237,13 +504,7 @@ void *dev_alloc(size_t bytes) {
   }
   if (p) {
     // the previous owner's kernels may still be running: what hipFree's implicit synchronisation took care of
-    Ctx &c = ctx();
-    if (c.inited) {
-      MI_HIP(hipStreamSynchronize(c.stream));
-      MI_HIP(hipStreamSynchronize(c.comm_stream));
-    } else {
-      MI_HIP(hipDeviceSynchronize());
-    }
+    drain_library_streams();
     return p;
   }
   hipError_t e = hipMalloc(&p, want);
@@ -266,6 +527,14 @@ void dev_free(void *p) {
   if (!P.enabled) {
     (void)hipFree(p);
     return;
+  }
+  {
+    DevArena &A = arena();
+    std::lock_guard<std::mutex> g(A.m);
+    if (A.owns(p)) {
+      A.release(p);
+      return;
+    }
   }
   bool trim = false;
   {

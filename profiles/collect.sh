@@ -14,6 +14,12 @@ if [ "$mode" = stats ]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof_stats" -- \
     python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu --no-general > "$REPO/gpurun_out/prof_stats.log" 2>&1
   python3 "$REPO/profiles/gap_analysis.py" "$(ls -t "$REPO"/gpurun_out/prof_stats/*/*_kernel_trace.csv | head -1)" > "$REPO/gpurun_out/gaps_512.txt" 2>&1 || true
+elif [ "$mode" = setup ]; then
+  # host-vs-device split of the setup (profiles/setup_split.py): kernel + copy + roctx marker traces of one setup and one solve
+  MI_HYPRE_SETUP_TIMING=1 MI_BENCH_VERBOSE=1 rocprofv3 --kernel-trace --memory-copy-trace --marker-trace --output-format csv \
+    -d "$REPO/gpurun_out/prof_setup" -- \
+    python3 "$REPO/bench.py" --steps 1 --warmup 0 --no-cpu --no-general --sideline-non-galerkin 0 > "$REPO/gpurun_out/prof_setup.log" 2>&1
+  python3 "$REPO/profiles/setup_split.py" "$REPO/gpurun_out/prof_setup" > "$REPO/gpurun_out/setup_split_512.txt" 2>&1 || true
 else
   # counter passes: without the collapsed coarse tail -- tabulating it means ~50 000 tiny dispatches at Setup, and
   # rocprofv3's counter collection crashed in that loop (segmentation fault inside its dispatch interception); the
