@@ -92,12 +92,12 @@ struct AmgLevel {
   std::vector<int> halo_rows;
   bool halo_rows_ready = false;
   std::vector<InteriorRange> interior_cache;
-  std::vector<int> cf;  // +1 C, -1 F (empty on the coarsest level)
+  LazyInts cf;  // +1 C, -1 F (empty on the coarsest level)
   bool has_cf = false;  // the level has a C/F splitting -- a GLOBAL fact (cf itself is empty on a rank without rows)
   DVec<signed char> d_cf;
   // C-first ordering of this level: perm[new] = old local row;
   // rows [0, nc) are the C points, [nc, n) the F points.  Empty = identity.
-  std::vector<int> perm;
+  LazyInts perm;
   DVec<int> d_perm;
   int nc = 0;
   std::vector<double> diag, l1gs, l1jac;
@@ -132,7 +132,7 @@ struct BoomerAMG {
   // where Q groups rows into graph-compact clusters so that a tile of consecutive rows touches few distinct columns.
   // input_order[new] = caller's row; empty = identity.  Level 0's perm is composed with it, so every solve path
   // gathers / scatters caller vectors as before.
-  std::vector<int> input_order;
+  LazyInts input_order;
   std::unique_ptr<ParCSR> Aq_own;
   sk::DCsr pending_sA0;  // Q A Q^T built on the device by setup_host, handed to level 0 by build_natural
   bool use_locality_order(const ParCSR &A) const;

@@ -1029,6 +1029,7 @@ void BoomerAMG::ensure_host(int level) {
     M->diag.nrows = nr;
     M->diag.ncols = ncl;
     M->host_diag_stale = false;
+    M->ensure_offd_rows();
   };
   fetch(Lv.A, Lv.oA);
   fetch(Lv.Pm.get(), Lv.oP);
@@ -1074,20 +1075,47 @@ void BoomerAMG::apply_cf_ordering() {
   const size_t nlev = L.size();
   const bool timing = getenv("MI_HYPRE_SETUP_TIMING") != nullptr && comm.rank == 0;
   double tcf0 = wall_time();
-  std::vector<std::vector<int>> pos(nlev);  // old -> new local row
+  std::unique_ptr<TraceRange> trace_pos(new TraceRange("C-first: positions"));
+  // old -> new local row, per level: on the device for the levels whose C/F marks live there (LazyInts: the levels
+  // the device built), on the host for the others; hpos() / dpos() hand out the other side's copy when somebody needs it
+  std::vector<std::vector<int>> pos(nlev);
+  std::vector<DVec<int>> posd(nlev);
+  std::vector<char> has_pos(nlev, 0);
+  auto hpos = [&](size_t l) -> const std::vector<int> & {
+    if (pos[l].empty() && posd[l].p && posd[l].n) pos[l] = posd[l].to_host();
+    return pos[l];
+  };
+  auto dpos = [&](size_t l) -> const int * {
+    if (!posd[l].p && !pos[l].empty()) posd[l].upload(pos[l]);
+    return posd[l].p;
+  };
   for (size_t l = 0; l < nlev; l++) {
     AmgLevel &Lv = L[l];
     if (Lv.cf.empty()) continue;
     const int n = Lv.A->nrows;
+    has_pos[l] = 1;
+    if (Lv.cf.on_device()) {
+      hipStream_t s = ctx().stream;
+      DVec<long long> crank;
+      const long long nc_tot = sk::count_c_points(Lv.cf.dev(), n, crank, s);
+      DVec<int> dperm((size_t)n);
+      posd[l].alloc((size_t)n);
+      sk::cfirst_order(Lv.cf.dev(), crank.p, n, (int)nc_tot, posd[l].p, dperm.p, s);
+      Lv.nc = (int)nc_tot;
+      Lv.perm.adopt_device(std::move(dperm), (size_t)n);
+      continue;
+    }
+    const std::vector<int> &cfh = Lv.cf.host();
     pos[l].resize((size_t)n);
-    Lv.perm.resize((size_t)n);
+    std::vector<int> &permh = Lv.perm.hostw();
+    permh.resize((size_t)n);
     // C points first, F points after, original order kept in both: the static partition of parallel_for is the
     // same in both passes (same n), so per-thread C counts give every thread its offsets
     const int nt = host_threads();
     std::vector<int64_t> cb((size_t)nt + 1, 0), ce((size_t)nt + 1, 0), ncnt((size_t)nt + 1, 0);
     parallel_for(n, [&](int64_t b, int64_t e, int t) {
       int64_t c = 0;
-      for (int64_t i = b; i < e; i++) c += (Lv.cf[(size_t)i] == C_PT);
+      for (int64_t i = b; i < e; i++) c += (cfh[(size_t)i] == C_PT);
       cb[(size_t)t] = b, ce[(size_t)t] = e, ncnt[(size_t)t] = c;
     });
     int64_t nc_tot = 0;
@@ -1105,12 +1133,13 @@ void BoomerAMG::apply_cf_ordering() {
     parallel_for(n, [&](int64_t b, int64_t e, int t) {
       int64_t c = coff[(size_t)t], f = foff[(size_t)t];
       for (int64_t i = b; i < e; i++) {
-        const int q = (int)((Lv.cf[(size_t)i] == C_PT) ? c++ : f++);
+        const int q = (int)((cfh[(size_t)i] == C_PT) ? c++ : f++);
         pos[l][(size_t)i] = q;
-        Lv.perm[(size_t)q] = (int)i;
+        permh[(size_t)q] = (int)i;
       }
     });
   }
+  trace_pos.reset();
   if (timing) printf("   C-first ordering: positions %.2f s\n", wall_time() - tcf0);
   auto sort_rows = [](HostCSR &M) {
     parallel_for(M.nrows, [&](int64_t b, int64_t e, int) {
@@ -1171,15 +1200,17 @@ void BoomerAMG::apply_cf_ordering() {
         if (on) printf("   C-first ordering: level %zu %.2f s\n", l, wall_time() - t0);
       }
     } level_timer{timing && l < 4, l, tl0};
-    if (pos[l].empty() && Lv.A->host_diag_stale && Lv.sA.nrows == Lv.A->nrows) {
+    TraceRange trace_lv(("C-first: level " + std::to_string(l)).c_str());
+    if (!has_pos[l] && Lv.A->host_diag_stale && Lv.sA.nrows == Lv.A->nrows) {
       // a level without C/F splitting (the coarsest) keeps its ordering: fetch it before sA goes away
       const int nr = Lv.A->diag.nrows, ncl = Lv.A->diag.ncols;
       Lv.sA.download(Lv.A->diag, ctx().stream);
       Lv.A->diag.nrows = nr;
       Lv.A->diag.ncols = ncl;
       Lv.A->host_diag_stale = false;
+      Lv.A->ensure_offd_rows();
     }
-    if (!pos[l].empty()) {
+    if (has_pos[l]) {
       ParCSR &A = *Lv.A;
       std::unique_ptr<ParCSR> An(new ParCSR());
       An->nrows = A.nrows;
@@ -1188,21 +1219,19 @@ void BoomerAMG::apply_cf_ordering() {
       An->row_starts = A.row_starts;
       if (Lv.sA.nnz > 0 && Lv.sA.nrows == A.nrows) {
         hipStream_t s = ctx().stream;
-        DVec<int> dperm, dpos;
-        dperm.upload(Lv.perm);
-        dpos.upload(pos[l]);
-        sk::permute(Lv.sA, dperm.p, dpos.p, Lv.oA, s);
+        sk::permute(Lv.sA, Lv.perm.dev(), dpos(l), Lv.oA, s);
         An->diag.nrows = An->diag.ncols = A.nrows;
         An->host_diag_stale = true;
         An->dev_diag_nnz = Lv.oA.nnz;
       } else {
         if (A.host_diag_stale) fail(1, "C-first ordering: a level has neither host nor device arrays");
-        permute(A.diag, Lv.perm, pos[l].data(), An->diag);
+        permute(A.diag, Lv.perm.host(), hpos(l).data(), An->diag);
       }
       Lv.sA.release();
       // halo columns: new global id = owner's start + owner's new position
-      std::vector<int> ext_pos = A.halo_exchange_host_int(comm, pos[l]);
       const size_t next = A.col_map_offd.size();
+      std::vector<int> ext_pos;
+      if (comm.size > 1 || next > 0) ext_pos = A.halo_exchange_host_int(comm, hpos(l));
       std::vector<gidx> newgid(next);
       for (size_t k = 0; k < next; k++) {
         const gidx g = A.col_map_offd[k];
@@ -1217,29 +1246,35 @@ void BoomerAMG::apply_cf_ordering() {
         colpos[k] = (int)(std::lower_bound(cm.begin(), cm.end(), newgid[k]) - cm.begin());
       if (A.offd.nnz() == 0) {  // no halo block (one rank): nothing to permute -- not even the row pointers
         An->offd.nrows = A.nrows;
-        An->offd.ia.assign((size_t)A.nrows + 1, 0);
+        if (!An->host_diag_stale) An->offd.ia.assign((size_t)A.nrows + 1, 0);  // (device-resident: ParCSR::ensure_offd_rows)
       } else {
-        permute(A.offd, Lv.perm, next ? colpos.data() : nullptr, An->offd);
+        permute(A.offd, Lv.perm.host(), next ? colpos.data() : nullptr, An->offd);
       }
       An->offd.ncols = (int)next;
       An->col_map_offd = cm;
       An->build_halo_plan(comm);
       Lv.A_own = std::move(An);
       Lv.A = Lv.A_own.get();
-      std::vector<int> cf2(Lv.cf.size());
-      parallel_for((int64_t)cf2.size(), [&](int64_t b, int64_t e, int) {
-        for (int64_t q = b; q < e; q++) cf2[(size_t)q] = Lv.cf[(size_t)Lv.perm[(size_t)q]];
-      });
-      Lv.cf.swap(cf2);
+      if (Lv.cf.on_device() && Lv.perm.on_device()) {
+        const size_t n = Lv.cf.size();
+        DVec<int> cf2(n);
+        sk::gather_elems(Lv.cf.dev(), Lv.perm.dev(), 0, (int)n, 4, cf2.p, ctx().stream);
+        MI_HIP(hipStreamSynchronize(ctx().stream));
+        Lv.cf.adopt_device(std::move(cf2), n);
+      } else {
+        const std::vector<int> &cfh = Lv.cf.host(), &permh = Lv.perm.host();
+        std::vector<int> cf2(cfh.size());
+        parallel_for((int64_t)cf2.size(), [&](int64_t b, int64_t e, int) {
+          for (int64_t q = b; q < e; q++) cf2[(size_t)q] = cfh[(size_t)permh[(size_t)q]];
+        });
+        Lv.cf = std::move(cf2);
+      }
     }
-    if (Lv.P.nrows > 0 && (!pos[l].empty() || (l + 1 < nlev && !pos[l + 1].empty()))) {
-      const bool map_cols = l + 1 < nlev && !pos[l + 1].empty();
+    if (Lv.P.nrows > 0 && (has_pos[l] || (l + 1 < nlev && has_pos[l + 1]))) {
+      const bool map_cols = l + 1 < nlev && has_pos[l + 1];
       if (Lv.sP.nnz > 0 && Lv.sP.nrows == Lv.P.nrows) {
         hipStream_t s = ctx().stream;
-        DVec<int> dperm, dpos;
-        if (!Lv.perm.empty()) dperm.upload(Lv.perm);
-        if (map_cols) dpos.upload(pos[l + 1]);
-        sk::permute(Lv.sP, Lv.perm.empty() ? nullptr : dperm.p, map_cols ? dpos.p : nullptr, Lv.oP, s);
+        sk::permute(Lv.sP, Lv.perm.empty() ? nullptr : Lv.perm.dev(), map_cols ? dpos(l + 1) : nullptr, Lv.oP, s);
         Lv.sP.release();
         sk::transpose(Lv.oP, Lv.oR, s);
         const int pr = Lv.P.nrows, pc = Lv.P.ncols;
@@ -1249,7 +1284,7 @@ void BoomerAMG::apply_cf_ordering() {
         Lv.P.ncols = Lv.R.nrows = pc;
       } else {
         HostCSR P2;
-        permute(Lv.P, Lv.perm, map_cols ? pos[l + 1].data() : nullptr, P2);
+        permute(Lv.P, Lv.perm.host(), map_cols ? hpos(l + 1).data() : nullptr, P2);
         Lv.P = std::move(P2);
         host_transpose(Lv.P, Lv.R);
       }
@@ -1584,6 +1619,7 @@ void BoomerAMG::setup_host(ParCSR &A0) {
   if (p.smooth_num_levels > 0 && (p.ilu_type != 0 || p.ilu_level < 0))
     fail(4, "BoomerAMGSetup: ILU smoother type " + std::to_string(p.ilu_type) + " / level of fill " +
                 std::to_string(p.ilu_level) + " is not implemented (block-Jacobi ILU(k) = type 0, level k >= 0 is)");
+  if (device_min_rows >= 0) dev_arena_hint((size_t)13 * 12 * (size_t)(A0.diag_nnz() + A0.offd.nnz()));
   if (comm.size > 1) input_order.clear();
   if (comm.size > 1 && can_build_distributed()) {
     build_distributed(A0);
@@ -1597,6 +1633,7 @@ void BoomerAMG::setup_host(ParCSR &A0) {
     ParCSR *Ain = &A0;
     pending_sA0.release();
     if (use_locality_order(A0)) {
+      TraceRange trace_q("setup: internal numbering");
       const double tq0 = wall_time();
       Aq_own.reset(new ParCSR());
       ParCSR &Q = *Aq_own;
@@ -1609,26 +1646,39 @@ void BoomerAMG::setup_host(ParCSR &A0) {
       if (on_dev) {
         hipStream_t s = ctx().stream;
         sk::DCsr raw;
+        std::unique_ptr<TraceRange> tr(new TraceRange("numbering: plain CSR copy + segment length"));
         sk::from_solve_format(A0.d_diag, raw, s);
         const int segshift = locality_segment_shift(A0.diag);
-        const std::vector<int> seeds = locality_seeds(n0, segshift, nullptr);
-        std::vector<int> label;
-        const int rounds = sk::locality_labels(raw, seeds.data(), (int)seeds.size(), nullptr, segshift, LOCALITY_MAX_ROUNDS, label, s);
-        const int nseeds = (int)seeds.size();
-        locality_sort(label, nseeds, input_order);
-        DVec<int> dorder, dpos((size_t)n0);
-        dorder.upload(input_order);
+        tr.reset(), tr.reset(new TraceRange("numbering: seeds, label rounds, order (device)"));
+        // seeds, rounds, cell ranks and the rows' order all on the device (round 4; the labels used to travel to the host
+        // for a counting sort there, the order back: ~0.6 s of host time at 512^3)
+        DVec<int> dorder;
+        int nseeds = 0, rounds = 0;
+        if (!sk::locality_order_device(raw, segshift, LOCALITY_CLUSTER, LOCALITY_MAX_ROUNDS, dorder, nseeds, rounds, s)) {
+          const std::vector<int> seeds = locality_seeds(n0, segshift, nullptr);
+          std::vector<int> label, order_h;
+          rounds = sk::locality_labels(raw, seeds.data(), (int)seeds.size(), nullptr, segshift, LOCALITY_MAX_ROUNDS, label, s);
+          nseeds = (int)seeds.size();
+          locality_sort(label, nseeds, order_h);
+          dorder.upload(order_h);
+        }
+        tr.reset(), tr.reset(new TraceRange("numbering: Q A Q^T"));
+        DVec<int> dpos((size_t)n0);
         sk::invert_permutation(dorder.p, n0, dpos.p, s);
         sk::permute(raw, dorder.p, dpos.p, pending_sA0, s);
         MI_HIP(hipStreamSynchronize(s));
+        input_order.adopt_device(std::move(dorder), (size_t)n0);
+        tr.reset();
         Q.diag.nrows = Q.diag.ncols = n0;
         Q.host_diag_stale = true;
         Q.dev_diag_nnz = pending_sA0.nnz;
         if (getenv("MI_HYPRE_SETUP_TIMING"))
           printf("   locality numbering on the device: segments of 2^%d rows, %d seeds, %d rounds\n", segshift, nseeds, rounds);
       } else {
-        locality_order(A0.diag, input_order, nullptr);
-        permute_symmetric(A0.diag, input_order, Q.diag);
+        std::vector<int> order_h;
+        locality_order(A0.diag, order_h, nullptr);
+        permute_symmetric(A0.diag, order_h, Q.diag);
+        input_order = std::move(order_h);
       }
       Q.nrows = A0.nrows;
       Q.row_start = A0.row_start;
@@ -1636,27 +1686,45 @@ void BoomerAMG::setup_host(ParCSR &A0) {
       Q.row_starts = A0.row_starts;
       Q.offd.nrows = A0.nrows;
       Q.offd.ncols = 0;
-      Q.offd.ia.assign((size_t)A0.nrows + 1, 0);
+      if (!Q.host_diag_stale) Q.offd.ia.assign((size_t)A0.nrows + 1, 0);  // (device-resident: ParCSR::ensure_offd_rows)
       Q.build_halo_plan(comm);
       Ain = Aq_own.get();
       if (getenv("MI_HYPRE_SETUP_TIMING")) printf("   locality numbering of the input: %.2f s\n", wall_time() - tq0);
     }
     build_natural(*Ain);
     const double tp0 = wall_time();
-    apply_cf_ordering();
+    {
+      TraceRange tr("setup: C-first ordering");
+      apply_cf_ordering();
+    }
+    TraceRange trace_w("setup: transfer operator wrappers + level-0 permutation");
     make_local_transfer_operators();
     if (!input_order.empty()) {
       // level 0 rows -> caller rows
       AmgLevel &L0 = L[0];
-      if (L0.perm.empty())
-        L0.perm = input_order;
-      else
-        for (int &q : L0.perm) q = input_order[(size_t)q];
+      if (L0.perm.empty()) {
+        L0.perm = input_order.host();
+      } else if (L0.perm.on_device() && input_order.on_device()) {
+        const size_t n = L0.perm.size();
+        DVec<int> composed(n);
+        sk::gather_elems(input_order.dev(), L0.perm.dev(), 0, (int)n, 4, composed.p, ctx().stream);
+        MI_HIP(hipStreamSynchronize(ctx().stream));
+        L0.perm.adopt_device(std::move(composed), n);
+      } else {
+        const std::vector<int> &oh = input_order.host();
+        std::vector<int> &ph = L0.perm.hostw();
+        parallel_for((int64_t)ph.size(), [&](int64_t b, int64_t e, int) {
+          for (int64_t q = b; q < e; q++) ph[(size_t)q] = oh[(size_t)ph[(size_t)q]];
+        });
+      }
       if (L0.A != Aq_own.get()) Aq_own.reset();  // level 0 is its C-first copy: the intermediate matrix can go
     }
     t_phase[4] += wall_time() - tp0;
   }
-  finish_host();
+  {
+    TraceRange tr("setup: norms + coarsest inverse");
+    finish_host();
+  }
   global_opcx = -1.0;
   if (comm.size > 1 && !L.empty()) {  // the operator complexity HYPRE would print: summed over the ranks, here where all are present
     double v[2] = {0.0, 0.0};
@@ -1702,6 +1770,8 @@ void BoomerAMG::build_natural(ParCSR &A0) {
     std::vector<int> cf;
     sk::DCsr dS;
     DVec<int> dcf;
+    const std::string lname = "level " + std::to_string(l) + ": ";
+    std::unique_ptr<TraceRange> trace_level(new TraceRange((lname + "strength + coarsening").c_str()));
     double tp0 = wall_time();
     auto strength_to_host = [&](hipStream_t s) {
       S.ia.resize((size_t)n + 1);
@@ -1725,10 +1795,7 @@ void BoomerAMG::build_natural(ParCSR &A0) {
           coarsen_by_type(p.coarsen_type, n, S, cf);
         dcf.upload(cf);
       } else {
-        sk::pmis(dS, 2747, dcf, s);
-        cf.resize((size_t)n);
-        MI_HIP(hipMemcpyAsync(cf.data(), dcf.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
-        MI_HIP(hipStreamSynchronize(s));
+        sk::pmis(dS, 2747, dcf, s);  // (the marks stay on the device: LazyInts)
       }
       t_phase[1] += wall_time() - tp0;
     } else {
@@ -1742,7 +1809,10 @@ void BoomerAMG::build_natural(ParCSR &A0) {
       t_phase[1] += wall_time() - tp0;
     }
     long long nc_loc = 0;
-    {
+    if (on_device && cf.empty() && dcf.p) {
+      DVec<long long> crank;
+      nc_loc = sk::count_c_points(dcf.p, n, crank, ctx().stream);
+    } else {
       std::atomic<long long> acc{0};
       parallel_for(n, [&](int64_t b, int64_t e, int) {
         long long c = 0;
@@ -1757,6 +1827,7 @@ void BoomerAMG::build_natural(ParCSR &A0) {
 
     int nc = 0;
     tp0 = wall_time();
+    trace_level.reset(), trace_level.reset(new TraceRange((lname + "interpolation").c_str()));
     bool p_on_device = false;
     if (on_device) {
       hipStream_t s = ctx().stream;
@@ -1767,19 +1838,22 @@ void BoomerAMG::build_natural(ParCSR &A0) {
         Lv.P = HostCSR();
         Lv.P.nrows = n;
         Lv.P.ncols = nc;
-        MI_HIP(hipMemcpyAsync(cf.data(), dcf.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
-        MI_HIP(hipStreamSynchronize(s));
       } else {
         // multipass or direct interpolation, or a row whose interpolatory set outgrows the kernels' tables:
         // host routine
         if (A.host_diag_stale) {
           Lv.sA.download(A.diag, s);
           A.host_diag_stale = false;
+          A.ensure_offd_rows();
         }
         if (!host_coarsen) strength_to_host(s);
+        if (cf.empty() && dcf.p) {
+          cf.resize((size_t)n);
+          MI_HIP(hipMemcpy(cf.data(), dcf.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+        }
+        dcf.release();
       }
       dS.release();
-      dcf.release();
     }
     if (!p_on_device) {
       if (aggressive)
@@ -1789,11 +1863,15 @@ void BoomerAMG::build_natural(ParCSR &A0) {
       else
         build_interp(A, S, cf, p.interp_type, p.trunc_factor, p.pmax_elmts, Lv.P, nc);
     }
-    Lv.cf = cf;
+    if (p_on_device)
+      Lv.cf.adopt_device(std::move(dcf), (size_t)n);  // (interpolation has updated the marks there: -3 -> -1)
+    else
+      Lv.cf = cf;
     Lv.has_cf = true;
     if (!on_device) host_transpose(Lv.P, Lv.R);
     t_phase[2] += wall_time() - tp0;
     tp0 = wall_time();
+    trace_level.reset(), trace_level.reset(new TraceRange((lname + "Galerkin product").c_str()));
 
     // Galerkin product on the (single-rank) operator: A_c = R (A P)
     std::unique_ptr<ParCSR> An(new ParCSR());
@@ -1833,11 +1911,12 @@ void BoomerAMG::build_natural(ParCSR &A0) {
     An->row_starts = {0, (gidx)nc};
     An->offd.nrows = nc;
     An->offd.ncols = 0;
-    An->offd.ia.assign((size_t)nc + 1, 0);
+    if (!An->host_diag_stale) An->offd.ia.assign((size_t)nc + 1, 0);  // (device-resident: ParCSR::ensure_offd_rows)
     An->build_halo_plan(comm);
     t_phase[3] += wall_time() - tp0;
     L[(size_t)l + 1].A_own = std::move(An);
     L[(size_t)l + 1].A = L[(size_t)l + 1].A_own.get();
+    trace_level.reset();
     l++;
   }
 
@@ -1855,8 +1934,7 @@ void BoomerAMG::finish_host() {
     if (A.host_diag_stale && Lv.oA.nrows == A.nrows) {
       // the level lives on the device: norms straight into the solve-phase vectors
       hipStream_t s = ctx().stream;
-      DVec<int> dcf, dcf_ext;
-      if (!Lv.cf.empty()) dcf.upload(Lv.cf);
+      DVec<int> dcf_ext;
       Lv.d_diag.alloc((size_t)Lv.n);
       Lv.d_l1gs.alloc((size_t)Lv.n);
       Lv.d_l1jac.alloc((size_t)Lv.n);
@@ -1864,7 +1942,7 @@ void BoomerAMG::finish_host() {
       sk::DCsr dO;
       if (comm.size > 1) {
         std::vector<int> cf_ext;
-        if (Lv.has_cf) cf_ext = A.halo_exchange_host_int(comm, Lv.cf);  // collective: gated by the global flag
+        if (Lv.has_cf) cf_ext = A.halo_exchange_host_int(comm, Lv.cf.host());  // collective: gated by the global flag
         if (A.offd.nnz() > 0) {
           HostCSR O = A.offd;
           O.nrows = Lv.n;
@@ -1873,14 +1951,14 @@ void BoomerAMG::finish_host() {
           dcf_ext.upload(cf_ext);
         }
       }
-      sk::level_norms(Lv.oA, Lv.cf.empty() ? nullptr : dcf.p, ch, Lv.d_diag.p, Lv.d_l1gs.p, Lv.d_l1jac.p, s,
+      sk::level_norms(Lv.oA, Lv.cf.empty() ? nullptr : Lv.cf.dev(), ch, Lv.d_diag.p, Lv.d_l1gs.p, Lv.d_l1jac.p, s,
                       dO.nnz > 0 ? &dO : nullptr, dO.nnz > 0 ? dcf_ext.p : nullptr);
       MI_HIP(hipStreamSynchronize(s));
       continue;
     }
     std::vector<int> cf_ext;
-    if (Lv.has_cf) cf_ext = A.halo_exchange_host_int(comm, Lv.cf);  // collective: gated by the global flag
-    level_norms(A, Lv.cf, cf_ext, ch, Lv.diag, Lv.l1gs, Lv.l1jac);
+    if (Lv.has_cf) cf_ext = A.halo_exchange_host_int(comm, Lv.cf.host());  // collective: gated by the global flag
+    level_norms(A, Lv.cf.host(), cf_ext, ch, Lv.diag, Lv.l1gs, Lv.l1jac);
   }
   ensure_host((int)L.size() - 1);
 
@@ -1952,7 +2030,7 @@ void BoomerAMG::finish_host() {
 namespace {
 // wrap a local CSR block as a (possibly rectangular) ParCSR without halo columns
 std::unique_ptr<ParCSR> wrap_local(HostCSR &&M, const std::vector<gidx> &row_starts, const std::vector<gidx> &col_starts,
-                                   int rank) {
+                                   int rank, bool device_resident = false) {
   std::unique_ptr<ParCSR> Q(new ParCSR());
   Q->nrows = M.nrows;
   Q->row_starts = row_starts;
@@ -1961,7 +2039,7 @@ std::unique_ptr<ParCSR> wrap_local(HostCSR &&M, const std::vector<gidx> &row_sta
   Q->row_end = row_starts[(size_t)rank + 1];
   Q->offd.nrows = M.nrows;
   Q->offd.ncols = 0;
-  Q->offd.ia.assign((size_t)M.nrows + 1, 0);
+  if (!device_resident) Q->offd.ia.assign((size_t)M.nrows + 1, 0);  // (else: ParCSR::ensure_offd_rows)
   Q->diag = std::move(M);
   return Q;
 }
@@ -2035,8 +2113,8 @@ void BoomerAMG::make_local_transfer_operators() {
   for (size_t l = 0; l + 1 < L.size(); l++) {
     AmgLevel &Lv = L[l];
     if (Lv.P.nrows == 0 && Lv.cf.empty()) continue;
-    Lv.Pm = wrap_local(std::move(Lv.P), Lv.A->row_starts, L[l + 1].A->row_starts, comm.rank);
-    Lv.Rm = wrap_local(std::move(Lv.R), L[l + 1].A->row_starts, Lv.A->row_starts, comm.rank);
+    Lv.Pm = wrap_local(std::move(Lv.P), Lv.A->row_starts, L[l + 1].A->row_starts, comm.rank, Lv.oP.nrows > 0);
+    Lv.Rm = wrap_local(std::move(Lv.R), L[l + 1].A->row_starts, Lv.A->row_starts, comm.rank, Lv.oP.nrows > 0);
     if (Lv.oP.nrows > 0) {  // built on the device: host arrays on demand
       Lv.Pm->host_diag_stale = Lv.Rm->host_diag_stale = true;
       Lv.Pm->dev_diag_nnz = Lv.oP.nnz;
@@ -2251,13 +2329,15 @@ void BoomerAMG::build_replicated(ParCSR &A0) {
     Lv.A->build_halo_plan(comm);
     Lv.has_cf = !G.cf.empty();
     if (Lv.has_cf) {
-      Lv.cf.resize((size_t)nloc);
-      Lv.perm.resize((size_t)nloc);
+      const std::vector<int> &gcf = G.cf.host();
+      std::vector<int> &lcf = Lv.cf.hostw(), &lperm = Lv.perm.hostw();
+      lcf.resize((size_t)nloc);
+      lperm.resize((size_t)nloc);
       Lv.nc = 0;
       for (int q = 0; q < nloc; q++) {
-        Lv.cf[(size_t)q] = G.cf[(size_t)rows_old[q]];
-        Lv.perm[(size_t)q] = (int)(rows_old[q] - r0);
-        Lv.nc += (Lv.cf[(size_t)q] == C_PT);
+        lcf[(size_t)q] = gcf[(size_t)rows_old[q]];
+        lperm[(size_t)q] = (int)(rows_old[q] - r0);
+        Lv.nc += (lcf[(size_t)q] == C_PT);
       }
       // P: my fine rows x coarse columns; R = P^T: my coarse rows x fine columns
       Lv.Pm = slice(G.sP, G.P, !G.P.ia.empty(), rows_old, nloc, pos[l + 1], starts[l], starts[l + 1]);
@@ -2289,6 +2369,7 @@ void BoomerAMG::build_replicated(ParCSR &A0) {
       tail_A->diag.nrows = nr;
       tail_A->diag.ncols = ncl;
       tail_A->host_diag_stale = false;
+      tail_A->ensure_offd_rows();
     }
     g.L.back().sA.release();
     tail.reset(new BoomerAMG());
@@ -2347,6 +2428,8 @@ void BoomerAMG::setup_device() {
         }
       }
     } level_timer{timing && li < 4, li, tdev0};
+    const std::string fname = "format: level " + std::to_string(li) + " ";
+    std::unique_ptr<TraceRange> trace_f(new TraceRange((fname + "A").c_str()));
     auto place = [&](ParCSR &M, sk::DCsr &dev) {
       if (dev.nrows == M.nrows && M.host_diag_stale) {  // built on the device: no host round trip
         sk::to_solve_format(dev, M.d_diag, s);
@@ -2360,7 +2443,9 @@ void BoomerAMG::setup_device() {
     static const int spmv_cap = getenv("MI_HYPRE_SPMV_ROW_CAP") ? atoi(getenv("MI_HYPRE_SPMV_ROW_CAP")) : k::SPMV_ONLY_ROW_CAP;
     if (Lv.Pm) Lv.Pm->d_diag.row_cap = spmv_cap;
     if (Lv.Rm) Lv.Rm->d_diag.row_cap = spmv_cap;
+    trace_f.reset(), trace_f.reset(new TraceRange((fname + "P").c_str()));
     if (Lv.Pm) place(*Lv.Pm, Lv.oP);
+    trace_f.reset(), trace_f.reset(new TraceRange((fname + "R").c_str()));
     // Restriction: the coarse vectors live in the coarse level's C-first order, in which neighbouring rows of R are
     // NOT neighbouring coarse points of the fine level (first the coarse level's C points, then its F points): a
     // tile of R then gathers a thinned-out stretch of the fine vector, and every line of it is fetched by several
@@ -2372,11 +2457,9 @@ void BoomerAMG::setup_device() {
     const bool r_large_host = Lv.Rm && !Lv.Rm->host_diag_stale && Lv.Rm->diag.nnz() >= nat_min;  // e.g. distributed setup
     if (Lv.Rm && natural_r && li + 1 < L.size() && (r_on_device || r_large_host) &&
         L[li + 1].perm.size() == (size_t)Lv.Rm->nrows && Lv.Rm->nrows > 0) {
-      const std::vector<int> &cperm = L[li + 1].perm;  // stored position -> position before the C-first step
-      std::vector<int> cpos(cperm.size());
-      for (size_t q = 0; q < cperm.size(); q++) cpos[(size_t)cperm[q]] = (int)q;
-      DVec<int> dpos;
-      dpos.upload(cpos);
+      // L[li + 1].perm: stored position -> position before the C-first step; its inverse orders the rows of R
+      DVec<int> dpos(L[li + 1].perm.size());
+      sk::invert_permutation(L[li + 1].perm.dev(), (int)L[li + 1].perm.size(), dpos.p, s);
       sk::DCsr nat;
       if (r_on_device) {
         sk::permute(Lv.oR, dpos.p, nullptr, nat, s);
@@ -2394,6 +2477,7 @@ void BoomerAMG::setup_device() {
       place(*Lv.Rm, Lv.oR);
     }
     // the down leg starts every level from u = 0: its sweep runs on the entries that can see non-zeros
+    trace_f.reset(), trace_f.reset(new TraceRange((fname + "zero-guess sub-operators").c_str()));
     Lv.has_Az = false;
     Lv.Az = DevCSR();
     const int t0 = p.relax_type[0];
@@ -2420,19 +2504,20 @@ void BoomerAMG::setup_device() {
         Lv.Az.prefer_gs_tiles = true;  // only the tile kernel hands the F pass's C-column product over
       }
     }
+    trace_f.reset(), trace_f.reset(new TraceRange((fname + "vectors, C/F marks, permutation").c_str()));
     if (!Lv.d_diag.p || Lv.d_diag.n != (size_t)Lv.n) {
       Lv.d_diag.upload(Lv.diag);
       Lv.d_l1gs.upload(Lv.l1gs);
       Lv.d_l1jac.upload(Lv.l1jac);
     }
     if (!Lv.cf.empty()) {
-      std::vector<signed char> c8(Lv.cf.size());
-      parallel_for((int64_t)c8.size(), [&](int64_t b, int64_t e, int) {
-        for (int64_t i = b; i < e; i++) c8[(size_t)i] = (signed char)Lv.cf[(size_t)i];
-      });
-      Lv.d_cf.upload(c8);
+      Lv.d_cf.alloc(Lv.cf.size());
+      sk::ints_to_i8(Lv.cf.dev(), (long long)Lv.cf.size(), Lv.d_cf.p, s);
     }
-    if (!Lv.perm.empty()) Lv.d_perm.upload(Lv.perm);
+    if (!Lv.perm.empty()) {
+      Lv.d_perm.alloc(Lv.perm.size());
+      MI_HIP(hipMemcpyAsync(Lv.d_perm.p, Lv.perm.dev(), Lv.perm.size() * sizeof(int), hipMemcpyDeviceToDevice, s));
+    }
     Lv.u.alloc((size_t)Lv.n);
     Lv.f.alloc((size_t)Lv.n);
     Lv.tmp.alloc((size_t)Lv.n);
@@ -2492,6 +2577,7 @@ void BoomerAMG::setup_device() {
   sk::release_host_scratch();
   dev_pool_trim();  // the setup's transient buffers go back to the driver: the solve allocates its Krylov basis next
   {
+    TraceRange tr("format: collapsed coarse tail");
     const double tc0 = wall_time();
     build_collapsed_tail();
     if (timing && collapsed_level >= 0)
@@ -2504,12 +2590,12 @@ void BoomerAMG::setup_device() {
   setup_seconds = wall_time() - t_setup_start;
   if (timing) {
     long long mp = 0, iu = 0, pm = 0, pu = 0, gr = 0, dr = 0;
-    double tg = 0.0, td = 0.0;
+    double tg = 0.0, td = 0.0, tw = 0.0;
     dev_arena_stats(&mp, &iu, &pm, &pu);
-    dev_arena_times(&tg, &td, &gr, &dr);
-    printf("   device arena (since the process started): %.1f GiB mapped (peak %.1f), %.1f GiB in use (peak %.1f); grown %lld times, %.2f s inside "
-           "hipMemCreate/Map; %lld stream drains before a reuse, %.2f s\n",
-           mp / 1073741824.0, pm / 1073741824.0, iu / 1073741824.0, pu / 1073741824.0, gr, tg, dr, td);
+    dev_arena_times(&tg, &td, &gr, &dr, &tw);
+    printf("   device arena (since the process started): %.1f GiB mapped (peak %.1f), %.1f GiB in use (peak %.1f); %lld chunks mapped, %.2f s inside "
+           "hipMemCreate/Map (grow-ahead thread), requests waited %.2f s for it; %lld stream drains before a reuse, %.2f s\n",
+           mp / 1073741824.0, pm / 1073741824.0, iu / 1073741824.0, pu / 1073741824.0, gr, tg, tw, dr, td);
     printf("   value dictionaries (1-byte value stream):");
     for (size_t li = 0; li < L.size(); li++) {
       const AmgLevel &Lv = L[li];

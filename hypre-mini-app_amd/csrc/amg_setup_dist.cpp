@@ -1906,6 +1906,7 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
   // internal locality numbering of this rank's rows (BoomerAMG::use_locality_order): clusters of the diag-block
   // graph, rows with halo entries last; the halo columns follow their owners' renumbering (one exchange)
   input_order.clear();
+  std::vector<int> order_h;  // (host vector while the hierarchy is built; BoomerAMG::input_order at the end)
   const double t_begin = wall_time();
   std::vector<int> newloc;       // old local row -> new local row
   std::vector<gidx> newcol_h;    // new GLOBAL id of every halo column of A0
@@ -1940,13 +1941,13 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
       std::vector<int> label;
       sk::locality_labels(dD0, seeds.data(), (int)seeds.size(), reinterpret_cast<const unsigned char *>(has_halo.data()), segshift,
                           LOCALITY_MAX_ROUNDS, label, s);
-      locality_sort(label, (int)seeds.size(), input_order);
+      locality_sort(label, (int)seeds.size(), order_h);
     } else {
-      locality_order(A0.diag, input_order, &has_halo);
+      locality_order(A0.diag, order_h, &has_halo);
     }
     newloc.resize((size_t)n);
     parallel_for(n, [&](int64_t b, int64_t e, int) {
-      for (int64_t q = b; q < e; q++) newloc[(size_t)input_order[(size_t)q]] = (int)q;
+      for (int64_t q = b; q < e; q++) newloc[(size_t)order_h[(size_t)q]] = (int)q;
     });
     Ring r0;
     r0.build(comm, A0.row_starts, A0.col_map_offd);
@@ -1968,7 +1969,7 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
     if (sub_timing) sub_times["prologue: locality numbering, new halo ids"] += tl0 - t_begin;
     DevLevel cur;
     cur.starts = A0.row_starts;
-    dev_level0(comm, A0, input_order, newloc, newcol_h, dD0, cur.E, cur.A, s);
+    dev_level0(comm, A0, order_h, newloc, newcol_h, dD0, cur.E, cur.A, s);
     if (sub_timing) sub_times["device: level 0 from the assembled blocks"] += wall_time() - tl0;
     while (l < p.max_levels - 1 && cur.starts.back() > p.max_coarse_size) {
       if (red_rows > 0 && l >= 1 && cur.starts.back() <= red_rows) break;  // the host loop below sets has_tail
@@ -2013,9 +2014,9 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
     const int n = A0.nrows;
     G.nrows = n;
     G.ia.assign((size_t)n + 1, 0);
-    const bool renum = !input_order.empty();
+    const bool renum = !order_h.empty();
     for (int q = 0; q < n; q++) {
-      const int i = renum ? input_order[(size_t)q] : q;
+      const int i = renum ? order_h[(size_t)q] : q;
       G.ia[(size_t)q + 1] = G.ia[(size_t)q] + (A0.diag.ia[(size_t)i + 1] - A0.diag.ia[(size_t)i]) +
                             (A0.offd.ia[(size_t)i + 1] - A0.offd.ia[(size_t)i]);
     }
@@ -2024,7 +2025,7 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
     parallel_for(n, [&](int64_t b, int64_t e, int) {
       std::vector<std::pair<gidx, double>> row;
       for (int64_t q = b; q < e; q++) {
-        const int i = renum ? input_order[(size_t)q] : (int)q;
+        const int i = renum ? order_h[(size_t)q] : (int)q;
         row.clear();
         for (int64_t k = A0.diag.ia[(size_t)i]; k < A0.diag.ia[(size_t)i + 1]; k++)
           row.push_back({A0.row_start + (renum ? newloc[(size_t)A0.diag.ja[(size_t)k]] : A0.diag.ja[(size_t)k]), A0.diag.a[(size_t)k]});
@@ -2703,14 +2704,15 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
       Out.A->build_halo_plan(comm);
       Out.has_cf = true;
       Out.perm = perm[li];
-      Out.cf.resize((size_t)n);
+      std::vector<int> &ocf = Out.cf.hostw();
+      ocf.resize((size_t)n);
       {
         std::atomic<long long> ncs{0};
         parallel_for(n, [&](int64_t b, int64_t e, int) {
           long long c = 0;
           for (int64_t q = b; q < e; q++) {
-            Out.cf[(size_t)q] = Lv.cf[(size_t)perm[li][(size_t)q]];
-            c += (Out.cf[(size_t)q] == C_PT);
+            ocf[(size_t)q] = Lv.cf[(size_t)perm[li][(size_t)q]];
+            c += (ocf[(size_t)q] == C_PT);
           }
           ncs += c;
         });
@@ -2748,11 +2750,12 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
     Out.has_cf = Lv.has_cf;
     if (Lv.has_cf) {
       Out.perm = perm[li];
-      Out.cf.resize((size_t)n);
+      std::vector<int> &ocf = Out.cf.hostw();
+      ocf.resize((size_t)n);
       Out.nc = 0;
       for (int q = 0; q < n; q++) {
-        Out.cf[(size_t)q] = Lv.cf[(size_t)perm[li][(size_t)q]];
-        Out.nc += (Out.cf[(size_t)q] == C_PT);
+        ocf[(size_t)q] = Lv.cf[(size_t)perm[li][(size_t)q]];
+        Out.nc += (ocf[(size_t)q] == C_PT);
       }
       lap("ordering: cf");
       std::vector<gidx> newcol_p = translate(Lv.P, li + 1, nullptr);
@@ -2772,12 +2775,14 @@ void BoomerAMG::build_distributed(ParCSR &A0) {
       lap("ordering: halo plans");
     }
   }
-  if (!input_order.empty()) {  // level-0 rows -> caller rows
+  if (!order_h.empty()) {  // level-0 rows -> caller rows
     AmgLevel &L0 = L[0];
-    if (L0.perm.empty())
-      L0.perm = input_order;
-    else
-      for (int &q : L0.perm) q = input_order[(size_t)q];
+    if (L0.perm.empty()) {
+      L0.perm = order_h;
+    } else {
+      for (int &q : L0.perm.hostw()) q = order_h[(size_t)q];
+    }
+    input_order = std::move(order_h);
   }
   lap("ordering: rest");
   if (has_tail) {

@@ -381,6 +381,9 @@ HYPRE_Int HYPRE_IJMatrixAssemble(HYPRE_IJMatrix matrix) {
     m->par.build_halo_plan(comm);
     m->assembled = true;
   }
+  // what a BoomerAMG hierarchy of this operator will need (operator complexity 3-4, sub-operators, transfer operators,
+  // the setup's transients: ~13x the operator's bytes at 512^3): mapped in the background from now on
+  dev_arena_hint((size_t)13 * 12 * (size_t)(m->par.diag.nnz() + m->par.offd.nnz()));
   if (!m->par.on_device) m->par.to_device();
   API_END
 }

@@ -1470,21 +1470,8 @@ std::vector<int> build_row_blocks(int nrows, const int64_t *ia, bool *chunk_alig
   bool aligned = true;
   int r = 0;
   while (r < nrows) {
-    const int64_t start = ia[r];
-    int e = r;
-    if ((r & 7) == 0 && row_cap <= block_rows) {  // whole chunks while they fit (SpMV-only operators: any row)
-      while (e < nrows && e - r < row_cap) {
-        const int e2 = std::min(nrows, e + 8);
-        if (ia[e2] - start > tile_entries - 1) break;
-        e = e2;
-      }
-    }
-    if (e == r) {  // not even one chunk fits (or an unaligned start after such a chunk): row granularity
-      aligned = false;
-      // keep one slot of slack for the aligned-pair start
-      while (e < nrows && e - r < row_cap && ia[e + 1] - start <= tile_entries - 1) e++;
-      if (e == r) e = r + 1;  // a single row longer than the tile
-    }
+    const int limit = (int)std::min<long long>(nrows, ((long long)r / TILE_SUPER_ROWS + 1) * TILE_SUPER_ROWS);
+    const int e = tile_end(r, limit, ia, row_cap, block_rows, tile_entries, aligned);
     rb.push_back(e);
     r = e;
   }

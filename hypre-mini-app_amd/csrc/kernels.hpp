@@ -39,8 +39,33 @@ enum ProfId {
 };
 inline int prof_level(int base, int level) { return level < PROF_LEVELS ? base + level : PROF_NONE; }
 
-// host: row-block schedule for spmv_stream (<= 256 rows and < SPMV_TILE entries
-// per block, or exactly one longer row)
+// Row-block (tile) schedule of the SpMV / tile Gauss-Seidel kernels: <= row_cap rows and < tile_entries entries per
+// tile, or exactly one longer row; greedy, whole 8-row chunks while they fit.  Round 4: tiles never cross a multiple of
+// TILE_SUPER_ROWS rows, so the schedule of every such super-block is independent of the others -- the device builds it
+// with one thread per super-block (sk::to_solve_format) instead of the host walking the row pointers of the whole
+// operator (1 GB of them per operator at 512^3, copied over PCIe first); the price is one underfull tile per 8192 rows.
+// tile_end(): one step of the schedule, shared by the host routine and the device kernel.
+constexpr int TILE_SUPER_ROWS = 8192;
+template <class IA>
+__host__ __device__ inline int tile_end(int r, int limit, const IA *ia, int row_cap, int block_rows, int tile_entries,
+                                        bool &aligned) {
+  const long long start = (long long)ia[r];
+  int e = r;
+  if ((r & 7) == 0 && row_cap <= block_rows) {  // whole chunks while they fit (SpMV-only operators: any row)
+    while (e < limit && e - r < row_cap) {
+      const int e2 = (e + 8 < limit) ? e + 8 : limit;
+      if ((long long)ia[e2] - start > tile_entries - 1) break;
+      e = e2;
+    }
+  }
+  if (e == r) {  // not even one chunk fits (or an unaligned start after such a chunk): row granularity
+    aligned = false;
+    // keep one slot of slack for the aligned-pair start
+    while (e < limit && e - r < row_cap && (long long)ia[e + 1] - start <= tile_entries - 1) e++;
+    if (e == r) e = r + 1;  // a single row longer than the tile
+  }
+  return e;
+}
 std::vector<int> build_row_blocks(int nrows, const int64_t *ia, bool *chunk_aligned = nullptr,
                                   int row_cap = SPMV_BLOCK, int tile_entries = SPMV_TILE);
 // tile size of an operator with nnz entries in nrows rows (MI_HYPRE_WIDE_TILE_MIN_ROWLEN, default 100 entries per row; 0 = never wide)

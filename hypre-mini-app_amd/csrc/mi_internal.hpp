@@ -51,8 +51,9 @@ void *dev_alloc(size_t bytes);
 void dev_free(void *p);
 void dev_pool_trim();
 void dev_pool_stats(long long *cached_bytes, long long *hits, long long *misses);
+void dev_arena_hint(size_t bytes_more);
 void dev_arena_stats(long long *mapped, long long *in_use, long long *peak_mapped, long long *peak_in_use);
-void dev_arena_times(double *t_grow, double *t_drain, long long *grown, long long *drains);
+void dev_arena_times(double *t_grow, double *t_drain, long long *grown, long long *drains, double *t_wait = nullptr);
 
 template <class T>
 struct DVec {
@@ -96,6 +97,75 @@ struct DVec {
     std::vector<T> h(n);
     if (n) download(h.data(), n);
     return h;
+  }
+};
+
+// A per-row integer array of a level (C/F marks, the C-first permutation, the internal numbering) that is born on the
+// device when the device builds the level and whose host copy is made only when somebody asks for it (the inspection
+// API of the parity tests, the host routines of small levels, the multi-rank setup): at 512^3 every such array is
+// 0.5 GB, and copying them to the host, looping over them there and uploading the results was ~1.5 s of a setup in
+// which the device waited (round 4, profiles/r04_setup_split_512_arena.txt).  Reads look like a const vector.
+struct LazyInts {
+  mutable std::vector<int> h;
+  mutable bool host_ok = true;  // h holds the data (an empty array is host_ok with h empty)
+  mutable DVec<int> d;
+  mutable bool dev_ok = false;
+  mutable size_t nd = 0;  // length of the device copy
+  size_t size() const { return host_ok ? h.size() : nd; }
+  bool empty() const { return size() == 0; }
+  const std::vector<int> &host() const {
+    if (!host_ok) {
+      h.resize(nd);
+      if (nd) MI_HIP(hipMemcpy(h.data(), d.p, nd * sizeof(int), hipMemcpyDeviceToHost));
+      host_ok = true;
+    }
+    return h;
+  }
+  // the host copy for writing: whatever the device holds is dropped afterwards
+  std::vector<int> &hostw() {
+    (void)host();
+    d.release();
+    dev_ok = false;
+    nd = 0;
+    return h;
+  }
+  int operator[](size_t i) const { return host()[i]; }
+  void clear() {
+    h.clear();
+    h.shrink_to_fit();
+    host_ok = true;
+    d.release();
+    dev_ok = false;
+    nd = 0;
+  }
+  LazyInts &operator=(const std::vector<int> &v) {
+    clear();
+    h = v;
+    return *this;
+  }
+  LazyInts &operator=(std::vector<int> &&v) {
+    clear();
+    h = std::move(v);
+    return *this;
+  }
+  // take a device array of n entries: it is the data now
+  void adopt_device(DVec<int> &&v, size_t n) {
+    h.clear();
+    h.shrink_to_fit();
+    d = std::move(v);
+    nd = n;
+    dev_ok = true;
+    host_ok = (n == 0);
+  }
+  bool on_device() const { return dev_ok; }
+  // device copy (uploaded when only the host has the data); null for an empty array
+  const int *dev() const {
+    if (!dev_ok && !h.empty()) {
+      d.upload(h);
+      nd = h.size();
+      dev_ok = true;
+    }
+    return dev_ok ? d.p : nullptr;
   }
 };
 

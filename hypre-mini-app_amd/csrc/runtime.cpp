@@ -8,6 +8,7 @@
 #include <thread>
 
 #include <map>
+#include <condition_variable>
 #include <mutex>
 #include <set>
 #include <unordered_map>
@@ -237,6 +238,26 @@ struct DevArena {
   size_t in_use = 0, peak_in_use = 0, peak_mapped = 0;
   long long served = 0, grown = 0, drains = 0;
   double t_grow = 0.0, t_drain = 0.0;  // seconds inside hipMemCreate / Map / SetAccess, and waiting for the streams
+  double t_wait = 0.0;                 // seconds an allocation waited for the grow-ahead thread
+  // Grow-ahead thread: where the driver has to clear the memory first (30 ms per GiB, see above) a chunk is worth
+  // having BEFORE a request needs it.  The thread keeps `headroom()` bytes of mapped, free space at the top; a request
+  // that does not fit wakes it and waits for chunks (the only writer of `mapped` is then the thread).  MI_HYPRE_ARENA_AHEAD=0:
+  // no thread, growth inside the request.
+  std::thread grower;
+  std::condition_variable cv_work, cv_done;
+  bool grower_on = false, grower_stop = false, grower_busy = false, oom = false;
+  size_t demand = 0;  // bytes a waiting request still needs mapped at the top
+  size_t target = 0;  // dev_arena_hint(): map up to here in the background whatever the headroom
+  size_t top_free() const {
+    if (free_by_off.empty()) return 0;
+    auto last = std::prev(free_by_off.end());
+    return last->first + last->second.size == mapped ? last->second.size : 0;
+  }
+  size_t headroom() const {
+    static const double gb = getenv("MI_HYPRE_ARENA_AHEAD_GB") ? atof(getenv("MI_HYPRE_ARENA_AHEAD_GB")) : 16.0;
+    const size_t cap = (size_t)(gb * 1073741824.0);
+    return std::min(cap, std::max<size_t>(chunk, in_use / 4));
+  }
 
   bool init() {
     if (state) return state > 0;
@@ -264,8 +285,73 @@ struct DevArena {
     }
     base = (char *)b;
     state = 1;
+    if (!(getenv("MI_HYPRE_ARENA_AHEAD") && atoi(getenv("MI_HYPRE_ARENA_AHEAD")) == 0)) {
+      grower_on = true;
+      grower = std::thread([this] { grow_ahead_loop(); });
+      grower.detach();  // lives as long as the process (the arena is never destroyed)
+    }
     return true;
   }
+  // one chunk, created and mapped WITHOUT the lock held (this is where the driver may take 30 ms per GiB)
+  bool map_one(size_t at) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    hipMemGenericAllocationHandle_t h;
+    if (at + chunk > va_size) return false;
+    if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    if (hipMemMap(base + at, chunk, 0, h, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipMemRelease(h);
+      return false;
+    }
+    if (hipMemSetAccess(base + at, chunk, &acc, 1) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipMemUnmap(base + at, chunk);
+      (void)hipMemRelease(h);
+      return false;
+    }
+    pending_handle = h;
+    return true;
+  }
+  hipMemGenericAllocationHandle_t pending_handle{};
+  void grow_ahead_loop() {
+    (void)hipSetDevice(device);
+    std::unique_lock<std::mutex> lk(m);
+    for (;;) {
+      cv_work.wait(lk, [this] { return grower_stop || (!paused && !oom && (demand > 0 || mapped < target || (in_use > 0 && top_free() < headroom()))); });
+      if (grower_stop) return;
+      grower_busy = true;
+      const size_t at = mapped;
+      lk.unlock();
+      const double t0 = wall_time();
+      const bool ok = map_one(at);
+      const double dt = wall_time() - t0;
+      lk.lock();
+      grower_busy = false;
+      t_grow += dt;
+      if (ok) {
+        handles.push_back(pending_handle);
+        mapped += chunk;
+        put_free(at, chunk, 0);
+        peak_mapped = std::max(peak_mapped, mapped);
+        grown++;
+        demand = demand > chunk ? demand - chunk : 0;
+      } else {
+        oom = true;  // a request that needs more fails; cleared when memory is released or trimmed
+        demand = 0;
+      }
+      cv_done.notify_all();
+    }
+  }
+  bool paused = false;
   void put_free(size_t off, size_t size, unsigned long long epoch) {
     // coalesce with the neighbours
     auto next = free_by_off.lower_bound(off);
@@ -326,21 +412,28 @@ struct DevArena {
     t_grow += wall_time() - tg0;
     return mapped - old_mapped == n * chunk;
   }
-  void *alloc(size_t bytes) {
+  void *alloc(size_t bytes, std::unique_lock<std::mutex> &lk) {
     size_t want = bytes < 256 ? 256 : (bytes + 255) / 256 * 256;
     if (want >= ((size_t)1 << 16)) want = (want + 4095) / 4096 * 4096;
     auto it = free_by_size.lower_bound({want, 0});
     if (it == free_by_size.end()) {
-      // the free range at the top (if any) counts towards the request
-      size_t top_free = 0;
-      if (!free_by_off.empty()) {
-        auto last = std::prev(free_by_off.end());
-        if (last->first + last->second.size == mapped) top_free = last->second.size;
+      if (grower_on) {
+        // the free range at the top (if any) counts towards the request; the thread maps the rest chunk by chunk
+        const double tw0 = wall_time();
+        while ((it = free_by_size.lower_bound({want, 0})) == free_by_size.end()) {
+          if (oom) return nullptr;
+          const size_t tf = top_free();
+          demand = std::max(demand, want - std::min(want, tf));
+          cv_work.notify_one();
+          cv_done.wait(lk);
+        }
+        t_wait += wall_time() - tw0;
+      } else {
+        const size_t need = want - std::min(want, top_free());
+        if (!grow((need + chunk - 1) / chunk)) return nullptr;
+        it = free_by_size.lower_bound({want, 0});
+        if (it == free_by_size.end()) return nullptr;
       }
-      const size_t need = want - std::min(want, top_free);
-      if (!grow((need + chunk - 1) / chunk)) return nullptr;
-      it = free_by_size.lower_bound({want, 0});
-      if (it == free_by_size.end()) return nullptr;
     } else {
       served++;
     }
@@ -365,6 +458,7 @@ struct DevArena {
       drains++;
       drained_epoch = e;
     }
+    if (grower_on && !oom && top_free() < headroom()) cv_work.notify_one();
     return base + off;
   }
   bool owns(const void *p) const { return state > 0 && (const char *)p >= base && (const char *)p < base + va_size; }
@@ -376,10 +470,20 @@ struct DevArena {
     live.erase(it);
     in_use -= size;
     put_free(off, size, ++release_epoch);
+    oom = false;
   }
   // unmap whole free chunks from the top, keeping `keep` bytes of free space there
-  void trim(size_t keep) {
-    if (state <= 0 || free_by_off.empty()) return;
+  void trim(size_t keep, std::unique_lock<std::mutex> &lk) {
+    if (state <= 0) return;
+    // the grow-ahead thread must not be mapping at the top meanwhile
+    paused = true;
+    while (grower_busy) cv_done.wait(lk);
+    struct Resume {
+      DevArena &a;
+      ~Resume() { a.paused = false; a.oom = false; }
+    } resume{*this};
+    target = 0;
+    if (free_by_off.empty()) return;
     auto last = std::prev(free_by_off.end());
     if (last->first + last->second.size != mapped) return;
     const size_t start = last->first + std::min(keep, last->second.size);
@@ -414,10 +518,10 @@ void dev_pool_trim() {
   P.init();
   if (P.enabled == 2) {
     DevArena &A = arena();
-    std::lock_guard<std::mutex> g(A.m);
+    std::unique_lock<std::mutex> g(A.m);
     static const double keep_gb = getenv("MI_HYPRE_ARENA_KEEP_GB") ? atof(getenv("MI_HYPRE_ARENA_KEEP_GB")) : -1.0;
     const size_t keep = keep_gb >= 0.0 ? (size_t)(keep_gb * 1073741824.0) : std::max<size_t>((size_t)2 << 30, A.in_use / 4);
-    A.trim(A.in_use == 0 ? 0 : keep);
+    A.trim(A.in_use == 0 ? 0 : keep, g);
   }
   std::vector<void *> blocks;
   {
@@ -449,9 +553,30 @@ void dev_pool_stats(long long *cached_bytes, long long *hits, long long *misses)
   if (misses) *misses = P.misses;
 }
 
-void dev_arena_times(double *t_grow, double *t_drain, long long *grown, long long *drains) {
+// Expected growth, from whoever knows it (IJMatrixAssemble and BoomerAMGSetup: a multiple of the operator's bytes): the
+// grow-ahead thread maps up to in_use + bytes in the background, capped at half of what the device has free now.
+void dev_arena_hint(size_t bytes_more) {
+  DevPool &P = pool();
+  P.init();
+  if (P.enabled != 2) return;
+  DevArena &A = arena();
+  std::unique_lock<std::mutex> g(A.m);
+  if (!A.init() || !A.grower_on) return;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+    (void)hipGetLastError();
+    return;
+  }
+  const size_t want = A.in_use + bytes_more;
+  const size_t cap = A.mapped + free_b / 2;
+  A.target = std::max(A.target, std::min(want, cap));
+  A.cv_work.notify_one();
+}
+
+void dev_arena_times(double *t_grow, double *t_drain, long long *grown, long long *drains, double *t_wait) {
   DevArena &A = arena();
   std::lock_guard<std::mutex> g(A.m);
+  if (t_wait) *t_wait = A.t_wait;
   if (t_grow) *t_grow = A.t_grow;
   if (t_drain) *t_drain = A.t_drain;
   if (grown) *grown = A.grown;
@@ -477,9 +602,9 @@ void *dev_alloc(size_t bytes) {
   }
   if (P.enabled == 2) {
     DevArena &A = arena();
-    std::lock_guard<std::mutex> g(A.m);
+    std::unique_lock<std::mutex> g(A.m);
     if (A.init()) {
-      p = A.alloc(bytes);
+      p = A.alloc(bytes, g);
       if (!p)
         fail(2, "device arena: cannot map " + std::to_string(bytes) + " more bytes (" + std::to_string(A.mapped) +
                     " mapped, " + std::to_string(A.in_use) + " in use): out of device memory");
@@ -631,7 +756,7 @@ void DevOffd::upload(int nrows, const HostCSR &h) {
   next = h.ncols;
   std::vector<int> r, ia32;
   ia32.push_back(0);
-  for (int i = 0; i < nrows; i++)
+  for (int i = 0; h.nnz() > 0 && i < nrows; i++)  // (a block without entries may come without row pointers)
     if (h.ia[(size_t)i + 1] > h.ia[(size_t)i]) {
       r.push_back(i);
       ia32.push_back((int)h.ia[(size_t)i + 1]);

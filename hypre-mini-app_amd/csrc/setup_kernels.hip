@@ -1423,6 +1423,32 @@ std::vector<int64_t> &host_scratch_i64() {
 }  // namespace
 void release_host_scratch() { std::vector<int64_t>().swap(host_scratch_i64()); }
 
+namespace {
+// tile schedule, one thread per super-block of k::TILE_SUPER_ROWS rows (k::tile_end is the host routine's step):
+// FILL = false counts the super-block's tiles, FILL = true writes their ends behind start[sb]
+template <bool FILL>
+__global__ __launch_bounds__(BLK) void tile_schedule_k(int n, int nsb, const long long *__restrict__ ia, int row_cap,
+                                                       int block_rows, int tile_entries, int *__restrict__ count,
+                                                       const long long *__restrict__ start, int *__restrict__ rb,
+                                                       int *__restrict__ unaligned) {
+  const int sb = blockIdx.x * BLK + threadIdx.x;
+  if (sb >= nsb) return;
+  int r = sb * k::TILE_SUPER_ROWS;
+  const int limit = (int)min((long long)n, (long long)r + k::TILE_SUPER_ROWS);
+  bool aligned = true;
+  int c = 0;
+  long long w = FILL ? start[sb] + 1 : 0;
+  while (r < limit) {
+    const int e = k::tile_end(r, limit, ia, row_cap, block_rows, tile_entries, aligned);
+    if (FILL) rb[w++] = e;
+    c++;
+    r = e;
+  }
+  if (!FILL) count[sb] = c;
+  if (!FILL && !aligned) *unaligned = 1;
+}
+}  // namespace
+
 void to_solve_format(DCsr &src, DevCSR &dst, hipStream_t s) {
   const int n = src.nrows;
   require_int32_block(src.nrows, 0, "solve format");
@@ -1452,19 +1478,41 @@ void to_solve_format(DCsr &src, DevCSR &dst, hipStream_t s) {
       }
     }
   }
-  // greedy row-block schedule: sequential over the row pointers, on the host.  The host copy lands in a buffer that is
-  // kept between calls (a fresh gigabyte per operator costs more in page faults than the copy and the schedule
-  // together); release_host_scratch() returns it at the end of a setup.
-  std::vector<int64_t> &hia = host_scratch_i64();
-  if (hia.size() < (size_t)n + 1) hia.resize((size_t)n + 1);
-  MI_HIP(hipMemcpyAsync(hia.data(), src.ia.p, ((size_t)n + 1) * sizeof(long long), hipMemcpyDeviceToHost, s));
-  MI_HIP(hipStreamSynchronize(s));
-  bool aligned = false;
+  // greedy row-block schedule, super-block by super-block on the device (k::tile_end; round 3 copied the row pointers
+  // to the host -- 1 GB per operator of 134 M rows -- and walked them there)
+  bool aligned = true;
   dst.tile_entries = k::choose_tile_entries(dst.nnz, n);
-  std::vector<int> blocks = k::build_row_blocks(n, hia.data(), &aligned, dst.row_cap, dst.tile_entries);
+  std::vector<int> blocks;
+  {
+    const int block_rows = dst.tile_entries == k::SPMV_TILE_WIDE ? k::SPMV_BLOCK_WIDE : k::SPMV_BLOCK;
+    const int row_cap = std::max(dst.row_cap, block_rows);
+    const int nsb = (int)(((long long)n + k::TILE_SUPER_ROWS - 1) / k::TILE_SUPER_ROWS);
+    if (nsb > 0) {
+      DVec<int> cnt((size_t)nsb), unal(1);
+      DVec<long long> st((size_t)nsb + 1);
+      MI_HIP(hipMemsetAsync(unal.p, 0, sizeof(int), s));
+      const unsigned g = (unsigned)((nsb + BLK - 1) / BLK);
+      tile_schedule_k<false><<<g, BLK, 0, s>>>(n, nsb, src.ia.p, row_cap, block_rows, dst.tile_entries, cnt.p, nullptr, nullptr, unal.p);
+      exclusive_scan(cnt.p, st.p, nsb, s);
+      long long nt = 0;
+      int un = 0;
+      MI_HIP(hipMemcpyAsync(&nt, st.p + nsb, sizeof(long long), hipMemcpyDeviceToHost, s));
+      MI_HIP(hipMemcpyAsync(&un, unal.p, sizeof(int), hipMemcpyDeviceToHost, s));
+      MI_HIP(hipStreamSynchronize(s));
+      aligned = un == 0;
+      dst.rb.alloc((size_t)nt + 1);
+      MI_HIP(hipMemsetAsync(dst.rb.p, 0, sizeof(int), s));
+      tile_schedule_k<true><<<g, BLK, 0, s>>>(n, nsb, src.ia.p, row_cap, block_rows, dst.tile_entries, nullptr, st.p, dst.rb.p, nullptr);
+      blocks.resize((size_t)nt + 1);
+      MI_HIP(hipMemcpyAsync(blocks.data(), dst.rb.p, ((size_t)nt + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+      MI_HIP(hipStreamSynchronize(s));
+    } else {
+      blocks.assign(1, 0);
+      dst.rb.upload(blocks);
+    }
+  }
   if (dst.row_cap > (dst.tile_entries == k::SPMV_TILE_WIDE ? k::SPMV_BLOCK_WIDE : k::SPMV_BLOCK)) aligned = false;  // such tiles are not for the tile Gauss-Seidel kernel
   dst.nblocks = (int)blocks.size() - 1;
-  dst.rb.upload(blocks);
   dst.rb_host = blocks;
   dst.gs_tiles = false;
   dst.max_tile_rows = 1;
@@ -1679,6 +1727,175 @@ int locality_labels(const DCsr &A, const int *seeds_host, int nseeds, const unsi
   MI_HIP(hipStreamSynchronize(s));
   MI_HIP(hipGetLastError());
   return rounds;
+}
+
+// ---- the whole internal numbering on the device (single rank, nothing excluded): seeds, label rounds, cells ranked by
+// their smallest row, rows by cell rank in natural order.  Same result as hs::locality_order (amg_setup.cpp), which
+// stays the routine of the host-only and the multi-rank setup (tests/test_locality_order.py compares the two).
+namespace {
+__global__ __launch_bounds__(BLK) void loc_seed_flag_k(int n, unsigned long long cluster, int segshift, int *__restrict__ flag,
+                                                       int *__restrict__ seg_has) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long z = (unsigned long long)i + 0x9E3779B97F4A7C15ULL;  // splitmix64, as hs::locality_seeds
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  z ^= z >> 31;
+  const int f = (z % cluster == 0) ? 1 : 0;
+  flag[i] = f;
+  if (f) seg_has[i >> segshift] = 1;  // (every writer stores the same value)
+}
+__global__ __launch_bounds__(BLK) void loc_seg_fix_k(int nseg, int segshift, const int *__restrict__ seg_has, int *__restrict__ flag) {
+  const int sg = blockIdx.x * BLK + threadIdx.x;
+  if (sg < nseg && !seg_has[sg]) flag[(size_t)sg << segshift] = 1;  // a segment without a seed: its first row
+}
+__global__ __launch_bounds__(BLK) void loc_seed_label_k(int n, const int *__restrict__ flag, const long long *__restrict__ rank,
+                                                        int *__restrict__ label) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i < n) label[i] = flag[i] ? (int)rank[i] : -1;
+}
+__global__ __launch_bounds__(BLK) void loc_minrow_k(int n, const int *__restrict__ label, int *__restrict__ minrow) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i < n && label[i] >= 0) atomicMin(minrow + label[i], i);
+}
+// key = rank of the row's cell (unreached rows: the last cluster), counted per key
+__global__ __launch_bounds__(BLK) void loc_key_count_k(int n, int nseeds, const int *__restrict__ label,
+                                                       const int *__restrict__ cell_rank, int *__restrict__ key,
+                                                       int *__restrict__ count) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  const int l = label[i];
+  const int kq = l >= 0 ? cell_rank[l] : nseeds;
+  key[i] = kq;
+  atomicAdd(count + kq, 1);
+}
+__global__ __launch_bounds__(BLK) void loc_scatter_k(int n, const int *__restrict__ key, const long long *__restrict__ start,
+                                                     int *__restrict__ cursor, int *__restrict__ order) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  const int kq = key[i];
+  order[start[kq] + atomicAdd(cursor + kq, 1)] = i;  // any order inside the cell: sorted next
+}
+// one workgroup per cell: its rows ascending (bitonic sort in LDS); cells beyond LOC_SORT_CAP rows are left to
+// loc_big_* below
+constexpr int LOC_SORT_CAP = 4096;
+__global__ __launch_bounds__(BLK) void loc_sort_cells_k(int ncells, const long long *__restrict__ start, int *__restrict__ order) {
+  __shared__ int v[LOC_SORT_CAP];
+  const int c = blockIdx.x;
+  if (c >= ncells) return;
+  const long long b = start[c];
+  const int len = (int)(start[c + 1] - b);
+  if (len <= 1 || len > LOC_SORT_CAP) return;
+  int m = 1;
+  while (m < len) m <<= 1;
+  for (int k = threadIdx.x; k < m; k += BLK) v[k] = k < len ? order[b + k] : 0x7fffffff;
+  __syncthreads();
+  for (int size = 2; size <= m; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < (m >> 1); t += BLK) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool up = ((lo & size) == 0);
+        const int a = v[lo], bb = v[hi];
+        if ((a > bb) == up) {
+          v[lo] = bb;
+          v[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  for (int k = threadIdx.x; k < len; k += BLK) order[b + k] = v[k];
+}
+__global__ __launch_bounds__(BLK) void loc_key_eq_k(int n, const int *__restrict__ key, int kq, int *__restrict__ flag) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i < n) flag[i] = key[i] == kq;
+}
+__global__ __launch_bounds__(BLK) void loc_big_place_k(int n, const int *__restrict__ flag, const long long *__restrict__ rank,
+                                                       long long base, int *__restrict__ order) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i < n && flag[i]) order[base + rank[i]] = i;
+}
+}  // namespace
+
+bool locality_order_device(const DCsr &A, int segshift, int cluster, int max_rounds, DVec<int> &order, int &nseeds,
+                           int &rounds, hipStream_t s) {
+  const int n = A.nrows;
+  nseeds = rounds = 0;
+  order.alloc((size_t)n);
+  if (n == 0) return true;
+  const unsigned gn = (unsigned)((n + BLK - 1) / BLK);
+  const int nseg = (int)((((long long)n - 1) >> segshift) + 1);
+  DVec<int> la((size_t)n), lb((size_t)n);
+  {
+    DVec<int> flag((size_t)n), seg_has((size_t)nseg);
+    DVec<long long> rank((size_t)n + 1);
+    MI_HIP(hipMemsetAsync(seg_has.p, 0, (size_t)nseg * sizeof(int), s));
+    loc_seed_flag_k<<<gn, BLK, 0, s>>>(n, (unsigned long long)cluster, segshift, flag.p, seg_has.p);
+    loc_seg_fix_k<<<(unsigned)((nseg + BLK - 1) / BLK), BLK, 0, s>>>(nseg, segshift, seg_has.p, flag.p);
+    exclusive_scan(flag.p, rank.p, n, s);
+    long long ns = 0;
+    MI_HIP(hipMemcpyAsync(&ns, rank.p + n, sizeof(long long), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    nseeds = (int)ns;
+    loc_seed_label_k<<<gn, BLK, 0, s>>>(n, flag.p, rank.p, la.p);
+  }
+  int *in = la.p, *out = lb.p;
+  DVec<int> changed(1);
+  for (; rounds < max_rounds; rounds++) {
+    MI_HIP(hipMemsetAsync(changed.p, 0, sizeof(int), s));
+    locality_round_k<<<gn, BLK, 0, s>>>(n, A.ia.p, A.ja.p, in, out, changed.p, segshift);
+    int ch = 0;
+    MI_HIP(hipMemcpyAsync(&ch, changed.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    std::swap(in, out);
+    if (!ch) break;
+  }
+  // cells ranked by their smallest row (a cell always holds its seed, so every cell has one); the sort of the ~n/512
+  // (smallest row, cell) pairs is host work of a millisecond
+  DVec<int> minrow((size_t)nseeds);
+  {
+    std::vector<int> init((size_t)nseeds, n);
+    MI_HIP(hipMemcpyAsync(minrow.p, init.data(), (size_t)nseeds * sizeof(int), hipMemcpyHostToDevice, s));
+    MI_HIP(hipStreamSynchronize(s));
+  }
+  loc_minrow_k<<<gn, BLK, 0, s>>>(n, in, minrow.p);
+  MI_HIP(hipStreamSynchronize(s));
+  const std::vector<int> mr = minrow.to_host();
+  std::vector<int> cells((size_t)nseeds), crank((size_t)nseeds);
+  for (int c = 0; c < nseeds; c++) cells[(size_t)c] = c;
+  std::sort(cells.begin(), cells.end(), [&](int a, int b) { return mr[(size_t)a] != mr[(size_t)b] ? mr[(size_t)a] < mr[(size_t)b] : a < b; });
+  for (int q = 0; q < nseeds; q++) crank[(size_t)cells[(size_t)q]] = q;
+  DVec<int> dcrank;
+  dcrank.upload(crank);
+  const int ncells = nseeds + 1;  // + the unreached rest
+  DVec<int> key((size_t)n), count((size_t)ncells), cursor((size_t)ncells);
+  DVec<long long> start((size_t)ncells + 1);
+  MI_HIP(hipMemsetAsync(count.p, 0, (size_t)ncells * sizeof(int), s));
+  MI_HIP(hipMemsetAsync(cursor.p, 0, (size_t)ncells * sizeof(int), s));
+  loc_key_count_k<<<gn, BLK, 0, s>>>(n, nseeds, in, dcrank.p, key.p, count.p);
+  exclusive_scan(count.p, start.p, ncells, s);
+  loc_scatter_k<<<gn, BLK, 0, s>>>(n, key.p, start.p, cursor.p, order.p);
+  loc_sort_cells_k<<<(unsigned)ncells, BLK, 0, s>>>(ncells, start.p, order.p);
+  // cells too large for the LDS sort (rare: the unreached rest of a disconnected graph): their rows by one flagged scan each
+  MI_HIP(hipStreamSynchronize(s));
+  const std::vector<int> hc = count.to_host();
+  std::vector<int> big;
+  for (int c = 0; c < ncells; c++)
+    if (hc[(size_t)c] > LOC_SORT_CAP) big.push_back(c);
+  if (big.size() > 8) return false;  // (the caller takes the host routine)
+  if (!big.empty()) {
+    std::vector<long long> hs_ = start.to_host();
+    DVec<int> flag((size_t)n);
+    DVec<long long> rank((size_t)n + 1);
+    for (int c : big) {
+      loc_key_eq_k<<<gn, BLK, 0, s>>>(n, key.p, c, flag.p);
+      exclusive_scan(flag.p, rank.p, n, s);
+      loc_big_place_k<<<gn, BLK, 0, s>>>(n, flag.p, rank.p, hs_[(size_t)c], order.p);
+    }
+  }
+  MI_HIP(hipGetLastError());
+  MI_HIP(hipStreamSynchronize(s));
+  return true;
 }
 
 void invert_permutation(const int *order, int n, int *pos, hipStream_t s) {
@@ -2353,6 +2570,16 @@ void scatter_zero_flags(signed char *dst, const int *idx, int shift, const signe
   MI_HIP(hipGetLastError());
 }
 
+namespace {
+__global__ __launch_bounds__(BLK) void ints_to_i8_k(long long n, const int *__restrict__ in, signed char *__restrict__ out) {
+  const long long i = bid() * BLK + threadIdx.x;
+  if (i < n) out[i] = (signed char)in[i];
+}
+}  // namespace
+void ints_to_i8(const int *in, long long n, signed char *out, hipStream_t s) {
+  if (n) ints_to_i8_k<<<grid_for((n + BLK - 1) / BLK), BLK, 0, s>>>(n, in, out);
+  MI_HIP(hipGetLastError());
+}
 long long count_c_points(const int *cf, int n, DVec<long long> &rank, hipStream_t s) {
   rank.alloc((size_t)n + 1);
   DVec<int> flag((size_t)n);

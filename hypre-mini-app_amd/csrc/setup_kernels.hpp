@@ -92,6 +92,12 @@ void from_solve_format(const DevCSR &src, DCsr &dst, hipStream_t s);
 // changes nothing or after max_rounds; label_host gets the result (-1 = never reached).  Returns the rounds run.
 int locality_labels(const DCsr &A, const int *seeds_host, int nseeds, const unsigned char *exclude_host, int segshift,
                     int max_rounds, std::vector<int> &label_host, hipStream_t s);
+// The whole internal numbering on the device (one rank, no excluded rows): order[new] = old, exactly hs::locality_order's
+// result.  false (nothing usable in `order`) when more than a handful of cells outgrow the in-LDS sort.
+bool locality_order_device(const DCsr &A, int segshift, int cluster, int max_rounds, DVec<int> &order, int &nseeds,
+                           int &rounds, hipStream_t s);
+// out[i] = (signed char)in[i]
+void ints_to_i8(const int *in, long long n, signed char *out, hipStream_t s);
 // pos[order[q]] = q
 void invert_permutation(const int *order, int n, int *pos, hipStream_t s);
 // back to host arrays (lazy host copies for the inspection API)

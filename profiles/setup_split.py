@@ -39,10 +39,12 @@ if mc:
             ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "copy " + r.get("Direction", "")))
 ev.sort()
 windows = []
+marks = []  # every roctx range: (start, end, name)
 mk = find("*marker_api_trace.csv")
 if mk:
     with open(mk) as f:
         for r in csv.DictReader(f):
+            marks.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Function"]))
             if any("BoomerAMGSetup" in str(v) for v in r.values()):
                 windows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), [v for v in r.values() if "BoomerAMGSetup" in str(v)][0]))
 if not windows:
@@ -95,4 +97,34 @@ for w0, w1, name in windows:
     print(f"  gaps of at least {min_gap/1e6:.0f} ms (offset into the range, length, after -> before):")
     for g, off, a, b in sorted(big, key=lambda x: x[1]):
         print(f"     +{off/1e9:7.3f} s  {g/1e6:8.1f} ms   {a}  ->  {b}")
+
+
+def busy_in(w0, w1):
+    b = 0
+    cur = w0
+    for s_, e_, _ in ev:
+        if e_ <= w0:
+            continue
+        if s_ >= w1:
+            break
+        a = max(s_, cur)
+        z = min(e_, w1)
+        if z > a:
+            b += z - a
+            cur = z
+    return b
+
+
+if windows and marks:
+    lo, hi = windows[0][0], windows[-1][1]
+    sub = sorted(m for m in marks if m[0] >= lo and m[1] <= hi)
+    print("\nevery roctx range inside the setup, in time order (indent = nesting): span, device busy, device idle = host")
+    stack = []
+    tot_idle = {}
+    for s_, e_, nm in sub:
+        while stack and s_ >= stack[-1]:
+            stack.pop()
+        b = busy_in(s_, e_)
+        print(f"   {'  ' * len(stack)}{nm:{66 - 2 * len(stack)}s} {(e_-s_)/1e9:7.3f} s   busy {b/1e9:7.3f}   idle {(e_-s_-b)/1e9:7.3f}")
+        stack.append(e_)
 print(f"\nsetup ranges together: span {tot_span/1e9:.3f} s, device busy {tot_busy/1e9:.3f} s, device idle (host) {(tot_span-tot_busy)/1e9:.3f} s")
