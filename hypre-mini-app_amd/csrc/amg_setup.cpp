@@ -1776,8 +1776,8 @@ void BoomerAMG::build_natural(ParCSR &A0) {
     auto strength_to_host = [&](hipStream_t s) {
       S.ia.resize((size_t)n + 1);
       S.ja.resize((size_t)dS.nnz);
-      MI_HIP(hipMemcpyAsync(S.ia.data(), dS.ia.p, ((size_t)n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-      if (dS.nnz) MI_HIP(hipMemcpyAsync(S.ja.data(), dS.ja.p, (size_t)dS.nnz * sizeof(int), hipMemcpyDeviceToHost, s));
+      d2h(S.ia.data(), dS.ia.p, ((size_t)n + 1) * sizeof(int64_t), s);
+      if (dS.nnz) d2h(S.ja.data(), dS.ja.p, (size_t)dS.nnz * sizeof(int), s);
       MI_HIP(hipStreamSynchronize(s));
     };
     if (on_device) {
@@ -1849,7 +1849,7 @@ void BoomerAMG::build_natural(ParCSR &A0) {
         if (!host_coarsen) strength_to_host(s);
         if (cf.empty() && dcf.p) {
           cf.resize((size_t)n);
-          MI_HIP(hipMemcpy(cf.data(), dcf.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+          d2h(cf.data(), dcf.p, (size_t)n * sizeof(int), nullptr);
         }
         dcf.release();
       }

@@ -587,7 +587,7 @@ struct DevHalo {
     if (ns) {
       DVec<T> tmp((size_t)ns);
       sk::gather_elems(vec, d_send.p, nb, ns, (int)sizeof(T), tmp.p, s);
-      MI_HIP(hipMemcpyAsync(sv.data(), tmp.p, (size_t)ns * sizeof(T), hipMemcpyDeviceToHost, s));
+      d2h(sv.data(), tmp.p, (size_t)ns * sizeof(T), s);
       MI_HIP(hipStreamSynchronize(s));
     }
     std::vector<std::vector<char>> send(ring.send_peers.size());
@@ -612,8 +612,8 @@ struct DevHalo {
   template <class T>
   void reverse(const T *vec, DVec<T> &at_send) {
     std::vector<T> ext(ring.ids.size());
-    if (nb) MI_HIP(hipMemcpyAsync(ext.data(), vec, (size_t)nb * sizeof(T), hipMemcpyDeviceToHost, s));
-    if (ne - n - nb) MI_HIP(hipMemcpyAsync(ext.data() + nb, vec + nb + n, (size_t)(ne - n - nb) * sizeof(T), hipMemcpyDeviceToHost, s));
+    if (nb) d2h(ext.data(), vec, (size_t)nb * sizeof(T), s);
+    if (ne - n - nb) d2h(ext.data() + nb, vec + nb + n, (size_t)(ne - n - nb) * sizeof(T), s);
     MI_HIP(hipStreamSynchronize(s));
     std::vector<std::vector<char>> send(ring.recv_peers.size());
     for (size_t i = 0; i < ring.recv_peers.size(); i++)
@@ -809,9 +809,9 @@ bool dev_level(BoomerAMG &amg, Comm &comm, int level, DevLevel &Lv, std::vector<
     sk::fill_coarse_ids(dcf.p + nbX, crank.p, n, cs, cg.p + nbX, s);
     halo.forward(cg.p);
     std::vector<long long> cgr((size_t)(ne - n));
-    if (nbX) MI_HIP(hipMemcpyAsync(cgr.data(), cg.p, (size_t)nbX * sizeof(long long), hipMemcpyDeviceToHost, s));
+    if (nbX) d2h(cgr.data(), cg.p, (size_t)nbX * sizeof(long long), s);
     if (ne - n - nbX)
-      MI_HIP(hipMemcpyAsync(cgr.data() + nbX, cg.p + nbX + n, (size_t)(ne - n - nbX) * sizeof(long long), hipMemcpyDeviceToHost, s));
+      d2h(cgr.data() + nbX, cg.p + nbX + n, (size_t)(ne - n - nbX) * sizeof(long long), s);
     MI_HIP(hipStreamSynchronize(s));
     for (long long g : cgr)
       if (g >= 0) CX.remote.push_back(g);  // ascending: coarse ids ascend with the fine ids
@@ -831,8 +831,8 @@ bool dev_level(BoomerAMG &amg, Comm &comm, int level, DevLevel &Lv, std::vector<
     Strength Sh;
     Sh.ia.resize((size_t)ne + 1);
     Sh.ja.resize((size_t)Se.nnz);
-    MI_HIP(hipMemcpyAsync(Sh.ia.data(), Se.ia.p, ((size_t)ne + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    if (Se.nnz) MI_HIP(hipMemcpyAsync(Sh.ja.data(), Se.ja.p, (size_t)Se.nnz * sizeof(int), hipMemcpyDeviceToHost, s));
+    d2h(Sh.ia.data(), Se.ia.p, ((size_t)ne + 1) * sizeof(int64_t), s);
+    if (Se.nnz) d2h(Sh.ja.data(), Se.ja.p, (size_t)Se.nnz * sizeof(int), s);
     MI_HIP(hipStreamSynchronize(s));
     std::vector<int> cfe = dcf.to_host();
     cfe.resize((size_t)ne);
@@ -853,7 +853,7 @@ bool dev_level(BoomerAMG &amg, Comm &comm, int level, DevLevel &Lv, std::vector<
   Se.release();
   Ae.release();
   cf_host.resize((size_t)n);
-  if (n) MI_HIP(hipMemcpyAsync(cf_host.data(), dcf.p + nbX, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+  if (n) d2h(cf_host.data(), dcf.p + nbX, (size_t)n * sizeof(int), s);
   MI_HIP(hipStreamSynchronize(s));
   for (int &c : cf_host)
     if (c == SF_PT) c = F_PT;
@@ -1046,9 +1046,9 @@ bool dev_level(BoomerAMG &amg, Comm &comm, int level, DevLevel &Lv, std::vector<
     sk::mark_used_columns(Ac, used, s);
     const int nrem = (int)CE2.remote.size();
     std::vector<unsigned char> u((size_t)nrem);
-    if (CE2.nbelow) MI_HIP(hipMemcpyAsync(u.data(), used.p, (size_t)CE2.nbelow, hipMemcpyDeviceToHost, s));
+    if (CE2.nbelow) d2h(u.data(), used.p, (size_t)CE2.nbelow, s);
     if (nrem - CE2.nbelow)
-      MI_HIP(hipMemcpyAsync(u.data() + CE2.nbelow, used.p + CE2.nbelow + ncl, (size_t)(nrem - CE2.nbelow), hipMemcpyDeviceToHost, s));
+      d2h(u.data() + CE2.nbelow, used.p + CE2.nbelow + ncl, (size_t)(nrem - CE2.nbelow), s);
     MI_HIP(hipStreamSynchronize(s));
     for (int k = 0; k < nrem; k++)
       if (u[(size_t)k]) next_E.remote.push_back(CE2.remote[(size_t)k]);
@@ -1087,8 +1087,8 @@ std::unique_ptr<ParCSR> assemble_dev(const sk::DCsr &M, const ExtIndex &cols, co
     DVec<unsigned char> du;
     sk::mark_used_columns(M, du, s);
     const size_t nrem = newg.size(), nbl = (size_t)cols.nbelow;
-    if (nbl) MI_HIP(hipMemcpyAsync(used.data(), du.p, nbl, hipMemcpyDeviceToHost, s));
-    if (nrem - nbl) MI_HIP(hipMemcpyAsync(used.data() + nbl, du.p + nbl + (size_t)ncown, nrem - nbl, hipMemcpyDeviceToHost, s));
+    if (nbl) d2h(used.data(), du.p, nbl, s);
+    if (nrem - nbl) d2h(used.data() + nbl, du.p + nbl + (size_t)ncown, nrem - nbl, s);
     MI_HIP(hipStreamSynchronize(s));
   }
   for (size_t k = 0; k < newg.size(); k++)

@@ -86,7 +86,7 @@ void fetch(const T *src, size_t n, std::vector<T> &dst) {
   dst.resize(n);
   if (!n) return;
   if (is_device_pointer(src))
-    MI_HIP(hipMemcpy(dst.data(), src, n * sizeof(T), hipMemcpyDeviceToHost));
+    d2h(dst.data(), src, n * sizeof(T), nullptr);
   else
     memcpy(dst.data(), src, n * sizeof(T));
 }
@@ -601,7 +601,7 @@ HYPRE_Int HYPRE_IJVectorPrint(HYPRE_IJVector vector, const char *filename) {
   std::vector<double> h((size_t)v->par.n);
   if (v->par.n) {
     MI_HIP(hipStreamSynchronize(ctx().stream));  // blocking copies are not ordered against the library stream
-    MI_HIP(hipMemcpy(h.data(), v->par.data(), h.size() * sizeof(double), hipMemcpyDeviceToHost));
+    d2h(h.data(), v->par.data(), h.size() * sizeof(double), nullptr);
   }
   char fn[2048];
   snprintf(fn, sizeof(fn), "%s.%05d", filename, current_comm().rank);
@@ -1343,8 +1343,8 @@ HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSRSize(HYPRE_Solver solver, HYPRE_Int level
     *ncols = L.A->diag.ncols;
     int e = 0;
     long long e64 = -1;
-    if (L.nc > 0 && L.A->d_diag.ia64.p) MI_HIP(hipMemcpy(&e64, L.A->d_diag.ia64.p + L.nc, sizeof(long long), hipMemcpyDeviceToHost));
-    else if (L.nc > 0 && L.A->d_diag.ia.p) MI_HIP(hipMemcpy(&e, L.A->d_diag.ia.p + L.nc, sizeof(int), hipMemcpyDeviceToHost));
+    if (L.nc > 0 && L.A->d_diag.ia64.p) d2h(&e64, L.A->d_diag.ia64.p + L.nc, sizeof(long long), nullptr);
+    else if (L.nc > 0 && L.A->d_diag.ia.p) d2h(&e, L.A->d_diag.ia.p + L.nc, sizeof(int), nullptr);
     else if (L.nc > 0 && !L.A->diag.ia.empty()) e64 = (long long)L.A->diag.ia[(size_t)L.nc];
     *nnz = e64 >= 0 ? e64 : e;
     return 0;
@@ -1460,7 +1460,7 @@ HYPRE_Int HYPRE_MI_BoomerAMGRelaxLevel(HYPRE_Solver solver, HYPRE_Int level, HYP
   }
   a->amg.relax(level, relax_type, points, f.p);
   MI_HIP(hipStreamSynchronize(ctx().stream));
-  if (n) MI_HIP(hipMemcpy(u_host, Lv.u.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  if (n) d2h(u_host, Lv.u.p, (size_t)n * sizeof(double), nullptr);
   API_END
 }
 HYPRE_Int HYPRE_MI_ProfileEnable(HYPRE_Int id, HYPRE_Int capacity) {

@@ -1635,7 +1635,7 @@ void build_value_dictionary(DevCSR &A, hipStream_t s) {
     DVec<double> dsample(sample);
     hipLaunchKernelGGL(strided_sample_k, dim3((unsigned)((sample + 255) / 256)), dim3(256), 0, s, A.a.p, stride, (int)sample, dsample.p);
     MI_HIP(hipGetLastError());
-    MI_HIP(hipMemcpyAsync(hs.data(), dsample.p, sample * sizeof(double), hipMemcpyDeviceToHost, s));
+    d2h(hs.data(), dsample.p, sample * sizeof(double), s);
     MI_HIP(hipStreamSynchronize(s));
   }
   std::vector<long long> bits(sample);
@@ -1651,7 +1651,7 @@ void build_value_dictionary(DevCSR &A, hipStream_t s) {
   A.vidx.alloc((size_t)A.nnz);
   hipLaunchKernelGGL(value_index_k, dim3(4096), dim3(256), 0, s, (long long)A.nnz, A.a.p, dtab.p, nt, A.vidx.p, fail.p);
   int nfail = 0;
-  MI_HIP(hipMemcpyAsync(&nfail, fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  d2h(&nfail, fail.p, sizeof(int), s);
   MI_HIP(hipStreamSynchronize(s));
   if (nfail) {  // a value beyond the sample's 256: plain stream
     A.vidx.release();

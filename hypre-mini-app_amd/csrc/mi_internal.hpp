@@ -55,6 +55,13 @@ void dev_arena_hint(size_t bytes_more);
 void dev_arena_stats(long long *mapped, long long *in_use, long long *peak_mapped, long long *peak_in_use);
 void dev_arena_times(double *t_grow, double *t_drain, long long *grown, long long *drains, double *t_wait = nullptr);
 
+// Device -> host copy that is complete when it returns (it synchronises `s`).  Copies of up to 64 MiB go through a pinned
+// staging buffer of the library: a copy into PAGEABLE host memory (a stack variable, a std::vector) has the runtime
+// register that memory first, and that registration waits behind any hipMemCreate / hipMemMap in flight on another
+// thread -- the arena's grow-ahead thread, which may sit 30 ms per GiB in the driver: measured stalls of 0.1-6 s per
+// 4-byte read (profiles/debug/grow_contention.cpp); pinned targets are not affected.
+void d2h(void *dst, const void *src, size_t bytes, hipStream_t s);
+
 template <class T>
 struct DVec {
   T *p = nullptr;
@@ -92,7 +99,7 @@ struct DVec {
     alloc(h.size());
     if (!h.empty()) upload(h.data(), h.size());
   }
-  void download(T *h, size_t cnt) const { MI_HIP(hipMemcpy(h, p, cnt * sizeof(T), hipMemcpyDeviceToHost)); }
+  void download(T *h, size_t cnt) const { d2h(h, p, cnt * sizeof(T), nullptr); }
   std::vector<T> to_host() const {
     std::vector<T> h(n);
     if (n) download(h.data(), n);
@@ -116,7 +123,7 @@ struct LazyInts {
   const std::vector<int> &host() const {
     if (!host_ok) {
       h.resize(nd);
-      if (nd) MI_HIP(hipMemcpy(h.data(), d.p, nd * sizeof(int), hipMemcpyDeviceToHost));
+      if (nd) d2h(h.data(), d.p, nd * sizeof(int), nullptr);
       host_ok = true;
     }
     return h;

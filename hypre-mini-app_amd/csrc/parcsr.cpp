@@ -439,7 +439,7 @@ double par_dot_host(Comm &comm, const double *x, const double *y, int n, hipStre
   Ctx &c = ctx();
   double *slot = c.red_out.p + 255;
   par_dot(comm, x, y, n, slot, s);
-  MI_HIP(hipMemcpyAsync(c.h_pinned + 255, slot, sizeof(double), hipMemcpyDeviceToHost, s));
+  d2h(c.h_pinned + 255, slot, sizeof(double), s);
   MI_HIP(hipStreamSynchronize(s));
   return c.h_pinned[255];
 }

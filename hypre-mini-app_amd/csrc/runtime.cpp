@@ -96,6 +96,26 @@ void parallel_for(int64_t n, const std::function<void(int64_t, int64_t, int)> &f
     if (e) std::rethrow_exception(e);
 }
 
+void d2h(void *dst, const void *src, size_t bytes, hipStream_t s) {
+  if (!bytes) return;
+  static std::mutex m;
+  static char *stage = nullptr;
+  constexpr size_t STAGE = (size_t)4 << 20;
+  if (bytes > ((size_t)64 << 20)) {  // large: straight into the caller's memory
+    MI_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    return;
+  }
+  std::lock_guard<std::mutex> g(m);
+  if (!stage) MI_HIP(hipHostMalloc((void **)&stage, STAGE, hipHostMallocDefault));
+  for (size_t off = 0; off < bytes; off += STAGE) {
+    const size_t len = std::min(STAGE, bytes - off);
+    MI_HIP(hipMemcpyAsync(stage, (const char *)src + off, len, hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    memcpy((char *)dst + off, stage, len);
+  }
+}
+
 void zero_on_stream(void *p, size_t bytes) {
   if (!p || !bytes) return;
   ensure_init();

@@ -1377,10 +1377,10 @@ void DCsr::download(HostCSR &h, hipStream_t s) const {
   h.ia.resize((size_t)nrows + 1);
   h.ja.resize((size_t)nnz);
   h.a.resize((size_t)nnz);
-  MI_HIP(hipMemcpyAsync(h.ia.data(), ia.p, ((size_t)nrows + 1) * sizeof(long long), hipMemcpyDeviceToHost, s));
+  d2h(h.ia.data(), ia.p, ((size_t)nrows + 1) * sizeof(long long), s);
   if (nnz) {
-    MI_HIP(hipMemcpyAsync(h.ja.data(), ja.p, (size_t)nnz * sizeof(int), hipMemcpyDeviceToHost, s));
-    MI_HIP(hipMemcpyAsync(h.a.data(), a.p, (size_t)nnz * sizeof(double), hipMemcpyDeviceToHost, s));
+    d2h(h.ja.data(), ja.p, (size_t)nnz * sizeof(int), s);
+    d2h(h.a.data(), a.p, (size_t)nnz * sizeof(double), s);
   }
   MI_HIP(hipStreamSynchronize(s));
 }
@@ -1466,7 +1466,7 @@ void to_solve_format(DCsr &src, DevCSR &dst, hipStream_t s) {
     rowlen_hist_k<<<(unsigned)(((long long)n + (long long)BLK * HIST_RUN - 1) / ((long long)BLK * HIST_RUN)), BLK, 0, s>>>(
         n, src.ia.p, hist.p);
     std::vector<int> hh(LEN_BINS);
-    MI_HIP(hipMemcpyAsync(hh.data(), hist.p, LEN_BINS * sizeof(int), hipMemcpyDeviceToHost, s));
+    d2h(hh.data(), hist.p, LEN_BINS * sizeof(int), s);
     MI_HIP(hipStreamSynchronize(s));
     const long long kth = (long long)((double)(n - 1) * 0.95);
     long long run = 0;
@@ -1496,15 +1496,15 @@ void to_solve_format(DCsr &src, DevCSR &dst, hipStream_t s) {
       exclusive_scan(cnt.p, st.p, nsb, s);
       long long nt = 0;
       int un = 0;
-      MI_HIP(hipMemcpyAsync(&nt, st.p + nsb, sizeof(long long), hipMemcpyDeviceToHost, s));
-      MI_HIP(hipMemcpyAsync(&un, unal.p, sizeof(int), hipMemcpyDeviceToHost, s));
+      d2h(&nt, st.p + nsb, sizeof(long long), s);
+      d2h(&un, unal.p, sizeof(int), s);
       MI_HIP(hipStreamSynchronize(s));
       aligned = un == 0;
       dst.rb.alloc((size_t)nt + 1);
       MI_HIP(hipMemsetAsync(dst.rb.p, 0, sizeof(int), s));
       tile_schedule_k<true><<<g, BLK, 0, s>>>(n, nsb, src.ia.p, row_cap, block_rows, dst.tile_entries, nullptr, st.p, dst.rb.p, nullptr);
       blocks.resize((size_t)nt + 1);
-      MI_HIP(hipMemcpyAsync(blocks.data(), dst.rb.p, ((size_t)nt + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+      d2h(blocks.data(), dst.rb.p, ((size_t)nt + 1) * sizeof(int), s);
       MI_HIP(hipStreamSynchronize(s));
     } else {
       blocks.assign(1, 0);
@@ -1533,7 +1533,7 @@ void to_solve_format(DCsr &src, DevCSR &dst, hipStream_t s) {
     DVec<long long> uptr64((size_t)nb + 1);
     exclusive_scan(ucnt.p, uptr64.p, nb, s);
     long long tot = 0;
-    MI_HIP(hipMemcpyAsync(&tot, uptr64.p + nb, sizeof(long long), hipMemcpyDeviceToHost, s));
+    d2h(&tot, uptr64.p + nb, sizeof(long long), s);
     MI_HIP(hipStreamSynchronize(s));
     dst.uptr.alloc((size_t)nb + 1);
     dst.ucols.alloc((size_t)tot);
@@ -1587,7 +1587,7 @@ void zero_guess_operator(const DevCSR &A, int nc, int chunk, DCsr &Z, hipStream_
   }
   exclusive_scan(cnt.p, Z.ia.p, n, s);
   long long total = 0;
-  MI_HIP(hipMemcpyAsync(&total, Z.ia.p + n, sizeof(long long), hipMemcpyDeviceToHost, s));
+  d2h(&total, Z.ia.p + n, sizeof(long long), s);
   MI_HIP(hipStreamSynchronize(s));
   Z.nnz = total;
   Z.ja.alloc((size_t)total);
@@ -1611,16 +1611,16 @@ void solve_format_to_host(const DevCSR &src, HostCSR &h, hipStream_t s) {
   if (src.ia.p) {
     DVec<long long> ia_tmp;
     const long long *ia64 = wide_row_pointers(src, ia_tmp, s);
-    MI_HIP(hipMemcpyAsync(h.ia.data(), ia64, ((size_t)n + 1) * sizeof(long long), hipMemcpyDeviceToHost, s));
+    d2h(h.ia.data(), ia64, ((size_t)n + 1) * sizeof(long long), s);
     if (src.nnz) {
-      MI_HIP(hipMemcpyAsync(h.ja.data(), src.ja.p, (size_t)src.nnz * sizeof(int), hipMemcpyDeviceToHost, s));
-      MI_HIP(hipMemcpyAsync(h.a.data(), src.a.p, (size_t)src.nnz * sizeof(double), hipMemcpyDeviceToHost, s));
+      d2h(h.ja.data(), src.ja.p, (size_t)src.nnz * sizeof(int), s);
+      d2h(h.a.data(), src.a.p, (size_t)src.nnz * sizeof(double), s);
     }
     MI_HIP(hipStreamSynchronize(s));
   }
   if (src.rowmap.p && n) {  // stored row r is row rowmap[r] of the operator: hand the rows back in operator order
     std::vector<int> map((size_t)n);
-    MI_HIP(hipMemcpy(map.data(), src.rowmap.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    d2h(map.data(), src.rowmap.p, (size_t)n * sizeof(int), nullptr);
     HostCSR o;
     o.nrows = n;
     o.ncols = h.ncols;
@@ -1664,7 +1664,7 @@ void sparsify_non_galerkin(DCsr &A, double tol, hipStream_t s, int row0, const d
   B.ia.alloc((size_t)n + 1);
   exclusive_scan(cnt.p, B.ia.p, n, s);
   long long total = 0;
-  MI_HIP(hipMemcpyAsync(&total, B.ia.p + n, sizeof(long long), hipMemcpyDeviceToHost, s));
+  d2h(&total, B.ia.p + n, sizeof(long long), s);
   MI_HIP(hipStreamSynchronize(s));
   B.nnz = total;
   B.ja.alloc((size_t)total);
@@ -1718,12 +1718,12 @@ int locality_labels(const DCsr &A, const int *seeds_host, int nseeds, const unsi
     MI_HIP(hipMemsetAsync(changed.p, 0, sizeof(int), s));
     locality_round_k<<<(unsigned)((n + BLK - 1) / BLK), BLK, 0, s>>>(n, A.ia.p, A.ja.p, in, out, changed.p, segshift);
     int ch = 0;
-    MI_HIP(hipMemcpyAsync(&ch, changed.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    d2h(&ch, changed.p, sizeof(int), s);
     MI_HIP(hipStreamSynchronize(s));
     std::swap(in, out);
     if (!ch) break;
   }
-  MI_HIP(hipMemcpyAsync(label_host.data(), in, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+  d2h(label_host.data(), in, (size_t)n * sizeof(int), s);
   MI_HIP(hipStreamSynchronize(s));
   MI_HIP(hipGetLastError());
   return rounds;
@@ -1834,7 +1834,7 @@ bool locality_order_device(const DCsr &A, int segshift, int cluster, int max_rou
     loc_seg_fix_k<<<(unsigned)((nseg + BLK - 1) / BLK), BLK, 0, s>>>(nseg, segshift, seg_has.p, flag.p);
     exclusive_scan(flag.p, rank.p, n, s);
     long long ns = 0;
-    MI_HIP(hipMemcpyAsync(&ns, rank.p + n, sizeof(long long), hipMemcpyDeviceToHost, s));
+    d2h(&ns, rank.p + n, sizeof(long long), s);
     MI_HIP(hipStreamSynchronize(s));
     nseeds = (int)ns;
     loc_seed_label_k<<<gn, BLK, 0, s>>>(n, flag.p, rank.p, la.p);
@@ -1845,7 +1845,7 @@ bool locality_order_device(const DCsr &A, int segshift, int cluster, int max_rou
     MI_HIP(hipMemsetAsync(changed.p, 0, sizeof(int), s));
     locality_round_k<<<gn, BLK, 0, s>>>(n, A.ia.p, A.ja.p, in, out, changed.p, segshift);
     int ch = 0;
-    MI_HIP(hipMemcpyAsync(&ch, changed.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    d2h(&ch, changed.p, sizeof(int), s);
     MI_HIP(hipStreamSynchronize(s));
     std::swap(in, out);
     if (!ch) break;
@@ -1931,7 +1931,7 @@ void strength(const DCsr &A, double theta, double max_row_sum, DCsr &S, hipStrea
   }
   exclusive_scan(cnt.p, S.ia.p, n, s);
   long long total = 0;
-  MI_HIP(hipMemcpyAsync(&total, S.ia.p + n, sizeof(long long), hipMemcpyDeviceToHost, s));
+  d2h(&total, S.ia.p + n, sizeof(long long), s);
   MI_HIP(hipStreamSynchronize(s));
   S.nnz = total;
   S.ja.alloc((size_t)total);
@@ -1955,7 +1955,7 @@ void pmis(const DCsr &S, int seed, DVec<int> &cf, hipStream_t s) {
   if (S.nnz) col_count_k<<<grid_for((S.nnz + BLK - 1) / BLK), BLK, 0, s>>>(S.nnz, S.ja.p, incoming.p);
   pmis_init_k<<<grid, BLK, 0, s>>>(n, S.ia.p, incoming.p, seed ? seed : 13579, measure.p, cf.p, counter.p);
   int undecided = 0;
-  MI_HIP(hipMemcpyAsync(&undecided, counter.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  d2h(&undecided, counter.p, sizeof(int), s);
   MI_HIP(hipStreamSynchronize(s));
   int rounds = 0;
   while (undecided > 0) {
@@ -1965,7 +1965,7 @@ void pmis(const DCsr &S, int seed, DVec<int> &cf, hipStream_t s) {
     pmis_select_k<<<grid, BLK, 0, s>>>(n, cf.p, tmp.p);
     MI_HIP(hipMemsetAsync(counter.p, 0, sizeof(int), s));
     pmis_fpoints_k<<<grid, BLK, 0, s>>>(n, S.ia.p, S.ja.p, cf.p, counter.p);
-    MI_HIP(hipMemcpyAsync(&undecided, counter.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    d2h(&undecided, counter.p, sizeof(int), s);
     MI_HIP(hipStreamSynchronize(s));
   }
   MI_HIP(hipGetLastError());
@@ -1983,7 +1983,7 @@ bool interp(const DCsr &A, const DCsr &S, DVec<int> &cf, int interp_type, double
   MI_HIP(hipMemsetAsync(meta.p, 0, 16 * sizeof(int), s));
   interp_bound_k<<<grid_rows, BLK, 0, s>>>(n, S.ia.p, S.ja.p, cf.p, ext, pmax, T.p, cap.p, is_c.p, meta.p, meta.p + 4);
   int hmeta[16];
-  MI_HIP(hipMemcpyAsync(hmeta, meta.p, sizeof(hmeta), hipMemcpyDeviceToHost, s));
+  d2h(hmeta, meta.p, sizeof(hmeta), s);
   MI_HIP(hipStreamSynchronize(s));
   if (hmeta[3] > 0 && hmeta[4] > 1024) return false;  // a row may exceed the largest LDS table
   Bins bins;
@@ -1996,8 +1996,8 @@ bool interp(const DCsr &A, const DCsr &S, DVec<int> &cf, int interp_type, double
   exclusive_scan(is_c.p, f2c.p, n, s);
   exclusive_scan(cap.p, slack_ia.p, n, s);
   long long tot[2];
-  MI_HIP(hipMemcpyAsync(&tot[0], f2c.p + n, sizeof(long long), hipMemcpyDeviceToHost, s));
-  MI_HIP(hipMemcpyAsync(&tot[1], slack_ia.p + n, sizeof(long long), hipMemcpyDeviceToHost, s));
+  d2h(&tot[0], f2c.p + n, sizeof(long long), s);
+  d2h(&tot[1], slack_ia.p + n, sizeof(long long), s);
   MI_HIP(hipStreamSynchronize(s));
   nc = (int)tot[0];
   DVec<int> sj((size_t)tot[1]);
@@ -2026,7 +2026,7 @@ bool interp(const DCsr &A, const DCsr &S, DVec<int> &cf, int interp_type, double
   P.ia.alloc((size_t)n + 1);
   exclusive_scan(len.p, P.ia.p, n, s);
   long long total = 0;
-  MI_HIP(hipMemcpyAsync(&total, P.ia.p + n, sizeof(long long), hipMemcpyDeviceToHost, s));
+  d2h(&total, P.ia.p + n, sizeof(long long), s);
   MI_HIP(hipStreamSynchronize(s));
   P.nnz = total;
   P.ja.alloc((size_t)total);
@@ -2058,7 +2058,7 @@ void spgemm(const DCsr &A, const DCsr &B, DCsr &C, hipStream_t s) {
   // meta: [0..3] bin counts, [4] max T, [8..11] bin starts, [12..15] fill cursors
   row_products_k<<<grid_rows, BLK, 0, s>>>(n, A.ia.p, A.ja.p, B.ia.p, T.p, meta.p, meta.p + 4);
   int hmeta[16];
-  MI_HIP(hipMemcpyAsync(hmeta, meta.p, sizeof(hmeta), hipMemcpyDeviceToHost, s));
+  d2h(hmeta, meta.p, sizeof(hmeta), s);
   MI_HIP(hipStreamSynchronize(s));
   Bins bins;
   for (int b = 0; b < 4; b++) bins.start[b + 1] = bins.start[b] + hmeta[b];
@@ -2089,7 +2089,7 @@ void spgemm(const DCsr &A, const DCsr &B, DCsr &C, hipStream_t s) {
                      block_grid, s);
   exclusive_scan(nout.p, C.ia.p, n, s);
   long long total = 0;
-  MI_HIP(hipMemcpyAsync(&total, C.ia.p + n, sizeof(long long), hipMemcpyDeviceToHost, s));
+  d2h(&total, C.ia.p + n, sizeof(long long), s);
   MI_HIP(hipStreamSynchronize(s));
   C.nnz = total;
   C.ja.alloc((size_t)total);
@@ -2153,7 +2153,7 @@ void extract_rows(const DCsr &A, const int *rows, int nout, const int *colpos, D
   if (nout) perm_len_k<<<(unsigned)((nout + BLK - 1) / BLK), BLK, 0, s>>>(nout, A.ia.p, rows, len.p);
   exclusive_scan(len.p, B.ia.p, nout, s);
   long long total = 0;
-  MI_HIP(hipMemcpyAsync(&total, B.ia.p + nout, sizeof(long long), hipMemcpyDeviceToHost, s));
+  d2h(&total, B.ia.p + nout, sizeof(long long), s);
   MI_HIP(hipStreamSynchronize(s));
   B.nnz = total;
   B.ja.alloc((size_t)total);
@@ -2426,7 +2426,7 @@ void select_rows(const DCsr &A, const int *rows, int row0, int nout, const ExtCo
   if (nout) select_rows_k<false><<<grid, BLK, 0, s>>>(nout, rows, row0, A.ia.p, A.ja.p, A.a.p, m, len.p, nullptr, nullptr, nullptr);
   exclusive_scan(len.p, B.ia.p, nout, s);
   long long total = 0;
-  MI_HIP(hipMemcpyAsync(&total, B.ia.p + nout, sizeof(long long), hipMemcpyDeviceToHost, s));
+  d2h(&total, B.ia.p + nout, sizeof(long long), s);
   MI_HIP(hipStreamSynchronize(s));
   B.nnz = total;
   B.ja.alloc((size_t)total);
@@ -2451,7 +2451,7 @@ void remap_columns(DCsr &A, const ExtColMap &m, int new_ncols, hipStream_t s) {
   MI_HIP(hipMemsetAsync(bad.p, 0, sizeof(int), s));
   if (A.nnz) remap_cols_k<<<grid_for((A.nnz + BLK - 1) / BLK), BLK, 0, s>>>(A.nnz, A.ja.p, m, bad.p);
   int hbad = 0;
-  MI_HIP(hipMemcpyAsync(&hbad, bad.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  d2h(&hbad, bad.p, sizeof(int), s);
   MI_HIP(hipStreamSynchronize(s));
   MI_REQUIRE(hbad == 0, "remap_columns: a column has no image in the new index space");
   A.ncols = new_ncols;
@@ -2525,7 +2525,7 @@ int pmis_dist_init(const DCsr &S, int row0, int n, long long gid0, int seed, con
     pmisd_init_k<<<grid_for(((long long)n + BLK - 1) / BLK), BLK, 0, s>>>(n, row0, gid0, S.ia.p, cnt, seed ? seed : 13579, measure,
                                                                           cf, counter);
   int undecided = 0;
-  MI_HIP(hipMemcpyAsync(&undecided, counter, sizeof(int), hipMemcpyDeviceToHost, s));
+  d2h(&undecided, counter, sizeof(int), s);
   MI_HIP(hipStreamSynchronize(s));
   return undecided;
 }
@@ -2543,7 +2543,7 @@ int pmis_dist_fpoints(const DCsr &S, int row0, int n, int *cf, int *counter, hip
   MI_HIP(hipMemsetAsync(counter, 0, sizeof(int), s));
   if (n) pmisd_fpoints_k<<<grid_for(((long long)n + BLK - 1) / BLK), BLK, 0, s>>>(n, row0, S.ia.p, S.ja.p, cf, counter);
   int undecided = 0;
-  MI_HIP(hipMemcpyAsync(&undecided, counter, sizeof(int), hipMemcpyDeviceToHost, s));
+  d2h(&undecided, counter, sizeof(int), s);
   MI_HIP(hipStreamSynchronize(s));
   return undecided;
 }
@@ -2586,7 +2586,7 @@ long long count_c_points(const int *cf, int n, DVec<long long> &rank, hipStream_
   if (n) is_c_k<<<grid_for(((long long)n + BLK - 1) / BLK), BLK, 0, s>>>(n, cf, flag.p);
   exclusive_scan(flag.p, rank.p, n, s);
   long long nc = 0;
-  MI_HIP(hipMemcpyAsync(&nc, rank.p + n, sizeof(long long), hipMemcpyDeviceToHost, s));
+  d2h(&nc, rank.p + n, sizeof(long long), s);
   MI_HIP(hipStreamSynchronize(s));
   return nc;
 }
@@ -2607,13 +2607,13 @@ int rows_with_columns_outside(const DCsr &P, int c0, int c1, std::vector<int> &r
   rows_outside_k<<<grid_for(((long long)n + BLK - 1) / BLK), BLK, 0, s>>>(n, P.ia.p, P.ja.p, c0, c1, flag.p);
   exclusive_scan(flag.p, pos.p, n, s);
   long long cnt = 0;
-  MI_HIP(hipMemcpyAsync(&cnt, pos.p + n, sizeof(long long), hipMemcpyDeviceToHost, s));
+  d2h(&cnt, pos.p + n, sizeof(long long), s);
   MI_HIP(hipStreamSynchronize(s));
   if (cnt == 0) return 0;
   DVec<int> list((size_t)cnt);
   compact_fill_k<<<grid_for(((long long)n + BLK - 1) / BLK), BLK, 0, s>>>(n, flag.p, pos.p, list.p);
   rows_host.resize((size_t)cnt);
-  MI_HIP(hipMemcpyAsync(rows_host.data(), list.p, (size_t)cnt * sizeof(int), hipMemcpyDeviceToHost, s));
+  d2h(rows_host.data(), list.p, (size_t)cnt * sizeof(int), s);
   MI_HIP(hipStreamSynchronize(s));
   return (int)cnt;
 }
