@@ -2,6 +2,7 @@
 // Plain pointers and sizes in, HYPRE_Int error codes out; C++ exceptions never
 // cross it.  The driver ignores return codes (src/HypreSystem.cpp:723), so
 // failures also print to stderr and accumulate in the HYPRE-style error flag.
+#include <limits>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -173,6 +174,23 @@ int stub_fail(const char *family) {
   return record_error(HYPRE_ERROR_GENERIC, std::string(family) +
                                                " is outside the north-star path of this library (GMRES/BiCGSTAB + "
                                                "BoomerAMG) and is not implemented");
+}
+
+// End of every collective Setup / Solve on more than one rank: a transport whose waits are bounded (the peer-store
+// exchange) latches an error flag on the device when a wait expires and the kernels run on -- the halo was not
+// delivered, a sum was taken over stale slots.  The flag is read here, agreed on by all ranks (so that they leave
+// together and later collectives still match), the result is poisoned and the call fails (the plain HYPRE
+// API used to return 0 with a silently wrong x).
+void transport_gate(ParVector *x, const char *what) {
+  Ctx &c = ctx();
+  if (!c.inited || !c.comm || c.comm->size <= 1) return;
+  if (!comm_transport_verdict(*c.comm, c.stream)) return;
+  if (x && x->d.p && x->len() > 0) {
+    k::fill(x->all(), x->len(), std::numeric_limits<double>::quiet_NaN(), c.stream);
+    MI_HIP(hipStreamSynchronize(c.stream));
+  }
+  fail(HYPRE_ERROR_GENERIC, std::string(what) + ": the peer-store transport reported an expired wait on at least one rank "
+                                "(MI_HYPRE_IPC_TIMEOUT_MS); the result is invalid and has been overwritten with NaN");
 }
 
 void write_ij_matrix(const ParCSR &A, const char *filename, int rank) {
@@ -702,12 +720,14 @@ HYPRE_Int HYPRE_BoomerAMGSetup(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_
   API_BEGIN
   if (!A) fail(HYPRE_ERROR_ARG, "BoomerAMGSetup: NULL matrix");
   AMG(solver)->amg.setup(*PM(A));
+  transport_gate(nullptr, "BoomerAMGSetup");
   API_END
 }
 HYPRE_Int HYPRE_BoomerAMGSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x) {
   API_BEGIN
   if (!A || !b || !x) fail(HYPRE_ERROR_ARG, "BoomerAMGSolve: NULL argument");
   AMG(solver)->amg.solve(*PM(A), *PV(b), *PV(x));
+  transport_gate(PV(x), "BoomerAMGSolve");
   API_END
 }
 // a setting this implementation accepts but does not act on: said once per key, on stderr, whatever print_level
@@ -821,12 +841,14 @@ HYPRE_Int HYPRE_ParCSRGMRESSetup(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPR
   API_BEGIN
   if (!A || !b || !x) fail(HYPRE_ERROR_ARG, "GMRESSetup: NULL argument");
   GM(solver)->setup(*PM(A), *PV(b), *PV(x));
+  transport_gate(nullptr, "GMRESSetup");
   API_END
 }
 HYPRE_Int HYPRE_ParCSRGMRESSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x) {
   try {
     if (!A || !b || !x) fail(HYPRE_ERROR_ARG, "GMRESSolve: NULL argument");
     const int rc = GM(solver)->solve(*PM(A), *PV(b), *PV(x));
+    transport_gate(PV(x), "GMRESSolve");
     if (rc) g_error_flag |= rc;  // HYPRE_ERROR_CONV: reported, never fatal
     return rc;
   } catch (const std::exception &e) {
@@ -909,6 +931,7 @@ HYPRE_Int HYPRE_ParCSRGMRESSetCGS(HYPRE_Solver solver, HYPRE_Int) {
     API_BEGIN                                                                                                   \
     if (!A || !b || !x) fail(HYPRE_ERROR_ARG, #NAME "Setup: NULL argument");                                     \
     GET(solver)->setup(*PM(A), *PV(b), *PV(x));                                                                 \
+    transport_gate(nullptr, #NAME "Setup");                                                                      \
     API_END                                                                                                     \
   }                                                                                                             \
   HYPRE_Int HYPRE_ParCSR##NAME##Solve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b,             \
@@ -916,6 +939,7 @@ HYPRE_Int HYPRE_ParCSRGMRESSetCGS(HYPRE_Solver solver, HYPRE_Int) {
     try {                                                                                                       \
       if (!A || !b || !x) fail(HYPRE_ERROR_ARG, #NAME "Solve: NULL argument");                                   \
       const int rc = GET(solver)->solve(*PM(A), *PV(b), *PV(x));                                                \
+      transport_gate(PV(x), #NAME "Solve");                                                                      \
       if (rc) g_error_flag |= rc;                                                                               \
       return rc;                                                                                                \
     } catch (const std::exception &e) {                                                                         \
@@ -951,12 +975,14 @@ HYPRE_Int HYPRE_ParCSRBiCGSTABSetup(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, H
   API_BEGIN
   if (!A || !b || !x) fail(HYPRE_ERROR_ARG, "BiCGSTABSetup: NULL argument");
   BI(solver)->setup(*PM(A), *PV(b), *PV(x));
+  transport_gate(nullptr, "BiCGSTABSetup");
   API_END
 }
 HYPRE_Int HYPRE_ParCSRBiCGSTABSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x) {
   try {
     if (!A || !b || !x) fail(HYPRE_ERROR_ARG, "BiCGSTABSolve: NULL argument");
     const int rc = BI(solver)->solve(*PM(A), *PV(b), *PV(x));
+    transport_gate(PV(x), "BiCGSTABSolve");
     if (rc) g_error_flag |= rc;
     return rc;
   } catch (const std::exception &e) {
@@ -984,12 +1010,14 @@ HYPRE_Int HYPRE_ILUSetup(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVec
   API_BEGIN
   if (!A) fail(HYPRE_ERROR_ARG, "ILUSetup: NULL matrix");
   ILU(solver)->setup(*PM(A));
+  transport_gate(nullptr, "ILUSetup");
   API_END
 }
 HYPRE_Int HYPRE_ILUSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x) {
   API_BEGIN
   if (!A || !b || !x) fail(HYPRE_ERROR_ARG, "ILUSolve: NULL argument");
   ILU(solver)->solve(*PM(A), *PV(b), *PV(x));
+  transport_gate(PV(x), "ILUSolve");
   API_END
 }
 HYPRE_Int HYPRE_ILUGetNumIterations(HYPRE_Solver solver, HYPRE_Int *n) {
@@ -1121,7 +1149,9 @@ HYPRE_Int HYPRE_MI_CommEnablePeerStoreExchange(HYPRE_BigInt slot_bytes) {
   if (slot_bytes <= 0) slot_bytes = getenv("MI_HYPRE_IPC_SLOT_BYTES") ? atoll(getenv("MI_HYPRE_IPC_SLOT_BYTES")) : (4 << 20);
   if (slot_bytes % 16) fail(HYPRE_ERROR_ARG, "CommEnablePeerStoreExchange: the slot size must be a multiple of 16 bytes");
   MI_HIP(hipDeviceSynchronize());
-  ctx().comm = make_ipc_exchange_comm(std::move(ctx().comm), (size_t)slot_bytes);
+  // (a refusal throws before the communicator changes hands: ctx().comm keeps its transport and the call returns an error)
+  std::unique_ptr<Comm> wrapped = make_ipc_exchange_comm(ctx().comm, (size_t)slot_bytes);
+  ctx().comm = std::move(wrapped);
   API_END
 }
 HYPRE_Int HYPRE_MI_CommExchangeDevice(HYPRE_Int nsend, const HYPRE_Int *send_peers, void *const *send_ptrs,

@@ -365,25 +365,42 @@ struct IpcExchangeComm : Comm {
     return base + ((header_bytes() + 255) / 256) * 256 + ((size_t)from * 2 + slot) * slot_bytes;
   }
 
-  IpcExchangeComm(std::unique_ptr<Comm> in, size_t slot) : inner(std::move(in)), slot_bytes(slot) {
+  // Built on a communicator it does not own yet (`in` stays with the caller until make_ipc_exchange_comm adopts it): a
+  // refusal -- thrown on EVERY rank, decided from data all ranks hold alike -- leaves the caller's transport in place.
+  IpcExchangeComm(Comm &in, size_t slot) : slot_bytes(slot) {
     ensure_init();
-    rank = inner->rank;
-    size = inner->size;
-    label = std::string("ipc-peer-store + ") + inner->name();
+    rank = in.rank;
+    size = in.size;
+    label = std::string("ipc-peer-store + ") + in.name();
     const char *tm = getenv("MI_HYPRE_IPC_TIMEOUT_MS");
     spin_limit = (unsigned long long)(tm ? atoll(tm) : 20000) * 100000ull;  // wall_clock64 ticks at 100 MHz
     const size_t total = ar_offset() + ar_bytes();
     // Fine-grained device memory: flags and payload are written by OTHER devices while this one's kernels poll them
     // (system-scope atomics; coarse-grained memory may keep stale lines in this device's L2 until a kernel boundary).
-    // Where such an allocation cannot be had or exported -- the ranks then have to share one device, which is the
-    // only configuration this image's test box offers -- ordinary device memory is used (MI_HYPRE_IPC_FINEGRAINED=0
-    // forces that).
-    hipIpcMemHandle_t mine;
+    // Ordinary device memory is only valid when ALL ranks share one device (the one-GPU test box): every rank
+    // publishes the identity of its device with its handle, and a communicator whose ranks sit on different devices
+    // refuses mailboxes that are not fine-grained on every rank (MI_HYPRE_IPC_FINEGRAINED=0, which forces
+    // ordinary memory, is subject to the same check).
+    struct Card {
+      hipIpcMemHandle_t handle;
+      char bus[32];
+      int status;  // 1 fine-grained arena exported, 2 ordinary arena exported, 0 nothing
+    } mine;
+    memset(&mine, 0, sizeof(mine));
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetPCIBusId(mine.bus, (int)sizeof(mine.bus), dev) != hipSuccess) {
+      (void)hipGetLastError();
+      snprintf(mine.bus, sizeof(mine.bus), "device-%d-of-pid-%d", dev, (int)getpid());  // (unknown: never equal to a peer's)
+    }
+    if (const char *fake = getenv("MI_HYPRE_IPC_BUS_ID")) {  // test hook (tests/ipc_worker.py): the identity this rank publishes
+      memset(mine.bus, 0, sizeof(mine.bus));
+      strncpy(mine.bus, fake, sizeof(mine.bus) - 1);
+    }
     const bool want_fine = !(getenv("MI_HYPRE_IPC_FINEGRAINED") && atoi(getenv("MI_HYPRE_IPC_FINEGRAINED")) == 0);
-    bool fine = false;
     if (want_fine && hipExtMallocWithFlags((void **)&arena, total, hipDeviceMallocFinegrained) == hipSuccess) {
-      if (hipIpcGetMemHandle(&mine, arena) == hipSuccess) {
-        fine = true;
+      if (hipIpcGetMemHandle(&mine.handle, arena) == hipSuccess) {
+        mine.status = 1;
       } else {
         (void)hipGetLastError();
         (void)hipFree(arena);
@@ -393,24 +410,58 @@ struct IpcExchangeComm : Comm {
       (void)hipGetLastError();
       arena = nullptr;
     }
-    if (!fine) {
-      MI_HIP(hipMalloc((void **)&arena, total));
-      MI_HIP(hipIpcGetMemHandle(&mine, arena));
+    if (!mine.status) {
+      if (hipMalloc((void **)&arena, total) == hipSuccess && hipIpcGetMemHandle(&mine.handle, arena) == hipSuccess) {
+        mine.status = 2;
+      } else {
+        (void)hipGetLastError();
+        if (arena) (void)hipFree(arena);
+        arena = nullptr;
+      }
     }
-    label += fine ? " (fine-grained mailboxes)" : " (coarse-grained mailboxes)";
-    MI_HIP(hipMemset(arena, 0, total));
-    MI_HIP(hipDeviceSynchronize());
-    std::vector<hipIpcMemHandle_t> all((size_t)size);
-    inner->allgather_host(&mine, all.data(), sizeof(hipIpcMemHandle_t));
+    if (arena) {
+      MI_HIP(hipMemset(arena, 0, total));
+      MI_HIP(hipDeviceSynchronize());
+    }
+    std::vector<Card> all((size_t)size);
+    in.allgather_host(&mine, all.data(), sizeof(Card));
+    bool any_failed = false, all_fine = true, one_device = true;
+    for (int r = 0; r < size; r++) {
+      any_failed = any_failed || all[(size_t)r].status == 0;
+      all_fine = all_fine && all[(size_t)r].status == 1;
+      one_device = one_device && strncmp(all[(size_t)r].bus, all[0].bus, sizeof(mine.bus)) == 0;
+    }
+    auto refuse = [&](const std::string &why) {
+      if (arena) (void)hipFree(arena);
+      arena = nullptr;
+      fail(1, "peer-store exchange refused (the communicator keeps its transport): " + why);
+    };
+    if (any_failed) refuse("a rank could not allocate or export its mailbox arena");
+    if (!one_device && !all_fine)
+      refuse("the ranks are on different devices and not every mailbox arena is fine-grained device memory -- peer "
+             "stores into ordinary device memory may stay invisible to the polling device until a kernel boundary");
+    label += all_fine ? " (fine-grained mailboxes)" : " (coarse-grained mailboxes, ranks share one device)";
     peer_arena.assign((size_t)size, nullptr);
+    int opened = 1;
     for (int r = 0; r < size; r++) {
       if (r == rank) {
         peer_arena[(size_t)r] = arena;
         continue;
       }
       void *p = nullptr;
-      MI_HIP(hipIpcOpenMemHandle(&p, all[(size_t)r], hipIpcMemLazyEnablePeerAccess));
+      if (hipIpcOpenMemHandle(&p, all[(size_t)r].handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+        (void)hipGetLastError();
+        opened = 0;
+        break;
+      }
       peer_arena[(size_t)r] = (char *)p;
+    }
+    in.allreduce_host(&opened, 1, CommDType::I32, CommOp::MIN);
+    if (!opened) {
+      for (int r = 0; r < size; r++)
+        if (r != rank && peer_arena[(size_t)r]) (void)hipIpcCloseMemHandle(peer_arena[(size_t)r]);
+      peer_arena.clear();
+      refuse("a rank could not map a peer's mailbox arena (hipIpcOpenMemHandle)");
     }
     send_seq.assign((size_t)size, 0);
     recv_seq.assign((size_t)size, 0);
@@ -419,11 +470,11 @@ struct IpcExchangeComm : Comm {
     error_flag.alloc(1);
     MI_HIP(hipMemset(error_flag.p, 0, sizeof(int)));
     MI_HIP(hipDeviceSynchronize());
-    inner->barrier();  // every arena is mapped everywhere before the first message
+    in.barrier();  // every arena is mapped everywhere before the first message
   }
   ~IpcExchangeComm() override {
     (void)hipDeviceSynchronize();
-    for (int r = 0; r < size; r++)
+    for (int r = 0; r < (int)peer_arena.size(); r++)
       if (r != rank && peer_arena[(size_t)r]) (void)hipIpcCloseMemHandle(peer_arena[(size_t)r]);
     if (arena) (void)hipFree(arena);
   }
@@ -434,6 +485,8 @@ struct IpcExchangeComm : Comm {
   void allreduce_dev(void *buf, size_t count, CommDType t, CommOp op, hipStream_t s) override {
     static const bool on = !(getenv("MI_HYPRE_IPC_ALLREDUCE") && atoi(getenv("MI_HYPRE_IPC_ALLREDUCE")) == 0);
     if (!on || t != CommDType::F64 || op != CommOp::SUM || count == 0 || count > (size_t)k::IPC_AR_MAX || size > 16) {
+      // (a rank with an expired wait contributes NaN here too: see k::ipc_allreduce_k)
+      if (t == CommDType::F64 && op == CommOp::SUM && count > 0) k::ipc_poison((double *)buf, (int)count, error_flag.p, s);
       inner->allreduce_dev(buf, count, t, op, s);
       return;
     }
@@ -462,8 +515,7 @@ struct IpcExchangeComm : Comm {
   }
   void check_error(hipStream_t s) {
     int e = 0;
-    MI_HIP(hipMemcpyAsync(&e, error_flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
-    MI_HIP(hipStreamSynchronize(s));
+    d2h(&e, error_flag.p, sizeof(int), s);
     if (e) fail(1, "peer-store exchange: a neighbour's message did not arrive within the time limit (MI_HYPRE_IPC_TIMEOUT_MS)");
   }
   // messages larger than a slot travel in slot-sized parts, each with its own sequence number (both sides know the
@@ -542,9 +594,24 @@ struct IpcExchangeComm : Comm {
 };
 }  // namespace
 
-std::unique_ptr<Comm> make_ipc_exchange_comm(std::unique_ptr<Comm> inner, size_t slot_bytes) {
-  if (inner->size == 1) return inner;
-  return std::unique_ptr<Comm>(new IpcExchangeComm(std::move(inner), slot_bytes));
+// On refusal (mi::Error from the constructor, on every rank alike) `inner` is untouched: the caller keeps its transport.
+std::unique_ptr<Comm> make_ipc_exchange_comm(std::unique_ptr<Comm> &inner, size_t slot_bytes) {
+  if (inner->size == 1) return std::move(inner);
+  std::unique_ptr<IpcExchangeComm> c(new IpcExchangeComm(*inner, slot_bytes));
+  c->inner = std::move(inner);
+  return std::unique_ptr<Comm>(c.release());
+}
+// Has a bounded wait of the transport expired on ANY rank?  Collective over the wrapped communicator (every rank of a
+// peer-store communicator calls it at the same points: the end of every Setup / Solve, capi.cpp), so that all ranks
+// see the same verdict and leave together.  0 for transports that cannot fail silently.
+int comm_transport_verdict(Comm &c, hipStream_t s) {
+  auto *ipc = dynamic_cast<IpcExchangeComm *>(&c);
+  if (!ipc) return 0;
+  int e = 0;
+  d2h(&e, ipc->error_flag.p, sizeof(int), s);
+  e = e ? 1 : 0;
+  ipc->inner->allreduce_host(&e, 1, CommDType::I32, CommOp::MAX);
+  return e;
 }
 bool comm_check_transport_error(Comm &c, hipStream_t s) {
   if (auto *ipc = dynamic_cast<IpcExchangeComm *>(&c)) {

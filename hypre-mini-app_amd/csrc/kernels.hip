@@ -1347,8 +1347,11 @@ __global__ __launch_bounds__(1024) void ipc_exchange_k(IpcBatch B, unsigned long
   if (tid == 0) {
     int ok = 1;
     const unsigned long long t0 = wall_clock64();
+    // a rank whose flag is already up does not wait the full bound again (a dead transport would otherwise
+    // cost bound x exchanges before the end-of-solve check sees it): 1 ms per wait from then on
+    const unsigned long long limit = __hip_atomic_load(error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? min(spin_limit, 100000ull) : spin_limit;
     while (__hip_atomic_load(T.wait_word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < T.wait_value) {
-      if (wall_clock64() - t0 > spin_limit) {  // the peer never arrived: say so and fall through (no hang)
+      if (wall_clock64() - t0 > limit) {  // the peer never arrived: say so and fall through (no hang)
         ok = 0;
         atomicExch(error_flag, 1);
         break;
@@ -1393,11 +1396,20 @@ __global__ __launch_bounds__(1024) void ipc_exchange_k(IpcBatch B, unsigned long
 // 256 / 512 / 768 / 1024 / 2048 / 4096 / 16384 workgroups of 256 lanes -- three per CU stream best (fewer, longer
 // streams keep DRAM pages open); more only adds concurrent streams.  MI_HYPRE_VEC_BLOCKS overrides.
 // peer-store all-reduce: see kernels.hpp.  One workgroup of 64 lanes; lane r < size talks to rank r.
+__global__ __launch_bounds__(64) void ipc_poison_k(double *buf, int count, const int *error_flag) {
+  if ((int)threadIdx.x < count && __hip_atomic_load(error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    buf[threadIdx.x] = __longlong_as_double(0x7ff8000000000000LL);
+}
 __global__ __launch_bounds__(64) void ipc_allreduce_k(IpcAllreduce A, unsigned long long spin_limit, int *error_flag) {
   __shared__ double mine[IPC_AR_MAX];
   const int r = threadIdx.x;
   const int par = (int)(A.seq & 1ull);
-  if (r < A.count) mine[r] = A.buf[r];
+  // A rank whose error flag is up (one of its bounded waits expired: its data are no longer what the algorithm thinks)
+  // contributes NaN: EVERY rank then sees NaN in the SAME reduction and the Krylov loops' NaN test (gmres.c's IEEE check,
+  // krylov.cpp) takes all of them out of the loop at the same point -- the collectives that are not bounded (all-gathers
+  // of the wrapped communicator) stay matched, and the end-of-solve gate (capi.cpp) reports the failure on every rank.
+  const bool dead = __hip_atomic_load(error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+  if (r < A.count) mine[r] = dead ? __longlong_as_double(0x7ff8000000000000LL) : A.buf[r];
   __syncthreads();
   if (r < A.size && r != A.rank) {
     double *dst = A.peer_slots[r] + ((size_t)par * A.size + A.rank) * IPC_AR_MAX;
@@ -1407,8 +1419,9 @@ __global__ __launch_bounds__(64) void ipc_allreduce_k(IpcAllreduce A, unsigned l
   if (r < A.size && r != A.rank) {
     const unsigned long long *fl = A.my_flags + (size_t)par * A.size + r;
     const unsigned long long t0 = wall_clock64();
+    const unsigned long long limit = __hip_atomic_load(error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? min(spin_limit, 100000ull) : spin_limit;  // (see ipc_exchange_k)
     while (__hip_atomic_load(fl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < A.seq) {
-      if (wall_clock64() - t0 > spin_limit) {
+      if (wall_clock64() - t0 > limit) {
         atomicExch(error_flag, 1);
         break;
       }
@@ -1425,6 +1438,9 @@ __global__ __launch_bounds__(64) void ipc_allreduce_k(IpcAllreduce A, unsigned l
                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       sum = (q == 0) ? v : sum + v;
     }
+    // a sum over slots that never arrived must not pass for a number: NaN ends the Krylov loop's tests on every rank that
+    // timed out, and the end-of-solve check (capi.cpp transport_gate) reports it on all of them
+    if (__hip_atomic_load(error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) sum = __longlong_as_double(0x7ff8000000000000LL);
     A.buf[r] = sum;
   }
 }
@@ -1962,6 +1978,12 @@ void ipc_exchange(const IpcBatch &b, unsigned long long spin_limit, int *error_f
 
 void ipc_allreduce(const IpcAllreduce &a, unsigned long long spin_limit, int *error_flag, hipStream_t s) {
   hipLaunchKernelGGL(ipc_allreduce_k, dim3(1), dim3(64), 0, s, a, spin_limit, error_flag);
+  MI_HIP(hipGetLastError());
+}
+
+void ipc_poison(double *buf, int count, const int *error_flag, hipStream_t s) {
+  // (larger counts: the first 64 values are enough to turn every sum into NaN)
+  hipLaunchKernelGGL(ipc_poison_k, dim3(1), dim3(64), 0, s, buf, std::min(count, 64), error_flag);
   MI_HIP(hipGetLastError());
 }
 

@@ -185,6 +185,8 @@ struct IpcAllreduce {
   unsigned long long *peer_flags[16];
 };
 void ipc_allreduce(const IpcAllreduce &a, unsigned long long spin_limit, int *error_flag, hipStream_t s);
+// buf[0..count) = NaN when the transport's error flag is up (reductions that travel on the wrapped communicator)
+void ipc_poison(double *buf, int count, const int *error_flag, hipStream_t s);
 
 // IJ helpers
 void scatter_set(double *x, const int *idx, const double *vals, int n, hipStream_t s);

@@ -205,13 +205,19 @@ int GmresSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
   norms.clear();
   norms.push_back(r_norm);
   const bool chatty = print_level > 1 && comm.rank == 0;
+  // gmres.c's IEEE check: a NaN in b, x0 or the operator ends the solve at once (HYPRE_ERROR_GENERIC); the same test on
+  // every later residual estimate ends it as soon as a NaN appears (a preconditioner that broke down, a transport
+  // whose bounded wait expired -- k::ipc_allreduce_k hands out NaN then)
+  bool nan_seen = (b_norm != b_norm) || (r_norm != r_norm);
+  if (nan_seen && comm.rank == 0 && print_level > 0)
+    printf("ERROR detected by mi_hypre GMRES: NaN in the right-hand side, the initial guess or the operator\n");
   if (chatty) {
     printf("=============================================\n\n");
     printf("Iters     resid.norm     conv.rate  rel.res.norm\n");
     printf("-----    ------------    ---------- ------------\n");
   }
 
-  while (iter < max_iter) {
+  while (iter < max_iter && !nan_seen) {
     rs[0] = r_norm;
     if (r_norm == 0.0) {
       converged = true;
@@ -301,8 +307,13 @@ int GmresSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
       if (chatty)
         printf("% 5d    %e    %f   %e\n", iter, r_norm, prev > 0 ? r_norm / prev : 0.0,
                b_norm > 0 ? r_norm / b_norm : r_norm);
+      if (r_norm != r_norm) {
+        nan_seen = true;
+        break;
+      }
       if (r_norm <= eps && iter >= min_iter) break;
     }
+    if (nan_seen) break;  // no update of x from a Hessenberg matrix with NaNs
     // back substitution
     std::vector<double> y(rs.begin(), rs.begin() + i);
     y[(size_t)i - 1] = y[(size_t)i - 1] / hh[(size_t)i - 1][(size_t)i - 1];
@@ -378,6 +389,7 @@ int GmresSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
     printf("\n\nFinal L2 norm of residual: %e\n\n", r_norm);
     (void)r_norm_0;
   }
+  if (nan_seen) return 1;                               // HYPRE_ERROR_GENERIC, as gmres.c
   return (iter >= max_iter && r_norm > eps) ? 256 : 0;  // HYPRE_ERROR_CONV
 }
 
@@ -437,7 +449,8 @@ int PcgSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
   norms.push_back(std::sqrt(std::fabs(i_prod) / bi_prod));
   int i = 0;
   const bool chatty = print_level > 1 && comm.rank == 0;
-  while (i + 1 <= max_iter) {
+  bool pcg_nan = (bi_prod != bi_prod) || (i_prod != i_prod);
+  while (i + 1 <= max_iter && !pcg_nan) {
     i++;
     mv(1.0, pv.data(), 0.0, nullptr, sv.data());
     const double sdotp = par_dot_host(comm, sv.data(), pv.data(), n, s);
@@ -451,6 +464,10 @@ int PcgSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
     i_prod = two_norm ? par_dot_host(comm, r.data(), r.data(), n, s) : gamma;
     norms.push_back(std::sqrt(std::fabs(i_prod) / bi_prod));
     if (chatty) printf("% 5d    %e\n", i, norms.back());
+    if (i_prod != i_prod || sdotp != sdotp) {  // NaN (pcg.c's IEEE check, on every step: see GmresSolver::solve)
+      pcg_nan = true;
+      break;
+    }
     if (i_prod / bi_prod < eps && i >= min_iter) {
       converged = true;
       break;
@@ -464,6 +481,7 @@ int PcgSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
   num_iterations = i;
   rel_residual_norm = std::sqrt(std::fabs(i_prod) / bi_prod);
   solve_seconds = wall_time() - t_start;
+  if (pcg_nan) return 1;
   return (!converged && i >= max_iter) ? 256 : 0;
 }
 
@@ -517,7 +535,8 @@ int BicgstabSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
     }
     return false;
   };
-  while (!converged && iter < max_iter) {
+  bool bicg_nan = (b_norm != b_norm) || (r_norm != r_norm);
+  while (!converged && iter < max_iter && !bicg_nan) {
     iter++;
     precond_in_order(amg, A, pv, v, true);
     mv(1.0, v.data(), 0.0, nullptr, q.data());
@@ -541,6 +560,10 @@ int BicgstabSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
     r_norm = std::sqrt(par_dot_host(comm, r.data(), r.data(), n, s));
     norms.push_back(r_norm);
     if (chatty) printf("% 5d    %e    %e\n", iter, r_norm, b_norm > 0 ? r_norm / b_norm : r_norm);
+    if (r_norm != r_norm) {  // NaN (bicgstab.c's IEEE check, on every step: see GmresSolver::solve)
+      bicg_nan = true;
+      break;
+    }
     if (r_norm <= eps && iter >= min_iter && true_res_ok()) {
       converged = true;
       break;
@@ -559,6 +582,7 @@ int BicgstabSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
   num_iterations = iter;
   rel_residual_norm = (b_norm > 0.0) ? r_norm / b_norm : r_norm;
   solve_seconds = wall_time() - t_start;
+  if (bicg_nan) return 1;
   return (!converged && iter >= max_iter) ? 256 : 0;
 }
 

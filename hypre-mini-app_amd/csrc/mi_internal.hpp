@@ -300,9 +300,10 @@ struct CommCallbacks {
 std::unique_ptr<Comm> make_callback_comm(const CommCallbacks &cb, int rank, int size);
 // The neighbour exchange by peer stores into IPC-mapped mailboxes (comm.cpp IpcExchangeComm) on top of another
 // communicator, which keeps the reductions, gathers and host collectives; size 1: returns inner unchanged
-std::unique_ptr<Comm> make_ipc_exchange_comm(std::unique_ptr<Comm> inner, size_t slot_bytes);
+std::unique_ptr<Comm> make_ipc_exchange_comm(std::unique_ptr<Comm> &inner, size_t slot_bytes);
 // peer-store transport: raises an error when a bounded wait expired (no-op and false for other transports)
 bool comm_check_transport_error(Comm &c, hipStream_t s);
+int comm_transport_verdict(Comm &c, hipStream_t s);
 // RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT bootstrap (TCP hand-off of the ncclUniqueId)
 std::unique_ptr<Comm> make_comm_from_env();
 

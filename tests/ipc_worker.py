@@ -20,6 +20,74 @@ def payload(src, dst, rnd, nbytes):
     return rng.integers(0, 256, size=nbytes, dtype=np.uint8)
 
 
+def scenario_refuse(mi, dist, rank, size):
+    """Ranks that (claim to) sit on different devices with mailboxes in ordinary device memory: the transport must be
+    refused on every rank and the communicator must keep working on what it had."""
+    import torch
+
+    os.environ["MI_HYPRE_IPC_BUS_ID"] = f"test-device-{rank}"  # (test hook: the identity a rank publishes)
+    os.environ["MI_HYPRE_IPC_FINEGRAINED"] = "0"
+    C = mi.C
+    try:
+        mi.call("HYPRE_MI_CommEnablePeerStoreExchange", mi.c_big(4096))
+        raise AssertionError("coarse-grained mailboxes across devices were accepted")
+    except mi.HypreError as e:
+        assert "refused" in str(e) and "different devices" in str(e), str(e)
+    nm = C.create_string_buffer(128)
+    mi.call("HYPRE_MI_CommName", nm, 128)
+    assert not nm.value.decode().startswith("ipc-peer-store"), nm.value
+    t = torch.full((3,), float(rank + 1), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    mi.call("HYPRE_MI_CommAllreduceDevice", C.c_void_p(t.data_ptr()), 3)
+    assert np.allclose(t.cpu().numpy(), size * (size + 1) / 2.0)
+    # with one device identity for everybody the same ordinary-memory mailboxes are fine (ranks share the GPU)
+    os.environ["MI_HYPRE_IPC_BUS_ID"] = "test-device-shared"
+    mi.call("HYPRE_MI_CommEnablePeerStoreExchange", mi.c_big(4096))
+    mi.call("HYPRE_MI_CommName", nm, 128)
+    assert nm.value.decode().startswith("ipc-peer-store") and "coarse-grained" in nm.value.decode(), nm.value
+    if rank == 0:
+        print(f"ipc refusal ok: {size} ranks")
+
+
+def scenario_gate(mi, dist, rank, size):
+    """A wait that expires must not pass for a result: after rank 0 has waited in vain for a message (error flag latched
+    on rank 0 only), the next solve fails on EVERY rank through the plain HYPRE entry point and x is poisoned."""
+    import torch
+
+    os.environ["MI_HYPRE_IPC_TIMEOUT_MS"] = "300"
+    C = mi.C
+    mi.call("HYPRE_MI_CommEnablePeerStoreExchange", mi.c_big(1 << 16))
+    n = 12
+    A, b, x, _ = mi.build_laplace_system(n, n, n, 7, rank, size)
+    amg = mi.BoomerAMG(print_level=0)
+    gm = mi.GMRES(tolerance=1e-8, max_iterations=40, kspace=20, print_level=0)
+    gm.set_precond(amg)
+    gm.setup(A, b, x)
+    gm.solve(A, b, x)
+    assert gm.final_rel_res < 1e-8 and np.abs(x.get() - 1.0).max() < 1e-5
+    dist.barrier()
+    if rank == 0:
+        r = torch.zeros(64, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        try:
+            mi.call("HYPRE_MI_CommExchangeDevice", 0, None, None, None, 1, (C.c_int * 1)(1), (C.c_void_p * 1)(r.data_ptr()),
+                    (C.c_size_t * 1)(64))
+            raise AssertionError("a message nobody sent arrived")
+        except mi.HypreError as e:
+            assert "did not arrive" in str(e), str(e)
+    dist.barrier()
+    x.fill(0.0)
+    try:
+        gm.solve(A, b, x)
+        raise AssertionError(f"rank {rank}: a solve on a transport with an expired wait returned normally")
+    except mi.HypreError as e:
+        assert "peer-store transport" in str(e), str(e)
+    xs = x.get()
+    assert xs.size == 0 or np.all(np.isnan(xs)), "the result of the failed solve was not poisoned"
+    if rank == 0:
+        print(f"ipc gate ok: {size} ranks")
+
+
 def main():
     import torch
     import torch.distributed as dist
@@ -29,6 +97,13 @@ def main():
     mi = ge.load_binding()
     mi.init()
     mi.init_comm_torch(dist)
+    scenario = sys.argv[1] if len(sys.argv) > 1 else "raw"
+    if scenario in ("refuse", "gate"):
+        (scenario_refuse if scenario == "refuse" else scenario_gate)(mi, dist, rank, size)
+        dist.barrier()
+        mi.call("HYPRE_MI_CommFinalize")
+        dist.destroy_process_group()
+        return
     slot = 4096
     mi.call("HYPRE_MI_CommEnablePeerStoreExchange", mi.c_big(slot))
     C = mi.C

@@ -301,6 +301,22 @@ def test_peer_store_exchange_raw_shared_gpu(nproc):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("scenario,nproc", [("refuse", 2), ("gate", 2), ("gate", 3)])
+def test_peer_store_transport_failure_modes_shared_gpu(scenario, nproc):
+    """(refuse) mailboxes in ordinary device memory are refused when the ranks report different devices, and
+    the communicator keeps its transport; (gate) a bounded wait that expired makes the next Solve fail on every rank
+    through the plain HYPRE entry point, with x overwritten by NaN -- never a silently wrong result with return code 0."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr",
+           "127.0.0.1", "--master-port", str(30311 + nproc + (7 if scenario == "gate" else 0)),
+           os.path.join(ROOT, "tests", "ipc_worker.py"), scenario]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
+    assert p.returncode == 0, p.stdout[-4000:]
+    assert f"ipc {'refusal' if scenario == 'refuse' else 'gate'} ok: {nproc} ranks" in p.stdout
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("nproc,n,stencil,seq", [(2, 16, 7, -1), (3, 14, 7, 0), (4, 12, 27, 0), (4, 16, 7, 1000)])
 def test_device_solve_peer_store_transport_shared_gpu(nproc, n, stencil, seq):
     """The whole distributed solve with its halo updates on the peer-store transport (64 KiB slots: the fine-level

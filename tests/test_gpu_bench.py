@@ -52,6 +52,8 @@ def test_bench_single_gpu_contract():
     assert ms["ms_per_solve"] > 0 and 0 < ms["share_of_solve"] < 1
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    co = j["comm_ops"]  # one rank: nothing travels
+    assert co["halo_exchange"] == 0 and co["allreduce"] == 0 and co["allgather"] == 0 and co["expected_allreduce"] == 0
     assert 5 <= j["iterations_per_solve"] <= 30 and j["final_rel_residual"] <= 1e-8
 
 
@@ -62,15 +64,22 @@ def test_bench_two_ranks_rehearsal():
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29791", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-           "--grid", "64", "--no-cpu"]
+           "--grid", "64", "--no-cpu", "--ipc-sideline"]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-3000:]
     j = _json_line(p.stdout)
     assert j["n_gpus"] == 2 and j.get("rehearsal") is True and j["cpu_baseline"] is None
     assert 5 <= j["iterations_per_solve"] <= 30 and j["final_rel_residual"] <= 1e-8
     assert j["max_abs_error_vs_ones"] < 1e-5
-    # the N > 1 side-line: the same solves on the peer-store transport, behind its probe (bench.py peer_store_sideline)
-    side = j["sideline_peer_store"]
+    # what one solve asks of the interconnect: the library's counters over the timed region
+    co, m = j["comm_ops"], j["iterations_per_solve"]
+    assert co["allreduce"] == co["expected_allreduce"] == 3 + m + m * (m + 1) // 2, co
+    assert co["halo_exchange"] > m and co["allgather"] >= m and co["matvec_overlapped"] + co["gs_overlapped"] > 0, co
+    # the opt-in N > 1 side-line: the same solves on the peer-store transport, behind its probe, printed AFTER the headline
+    # as a second, tagged line (bench.py peer_store_sideline)
+    tagged = [l for l in p.stdout.splitlines() if l.startswith("[sideline_peer_store] ")]
+    assert len(tagged) == 1 and p.stdout.index(tagged[0]) > p.stdout.index('{"metric"'), p.stdout[-3000:]
+    side = json.loads(tagged[0][len("[sideline_peer_store] "):])
     assert side["ran"] is True and side["same_iterations_as_headline"] is True, side
     assert "ipc-peer-store" in side["transport"] and side["ms_per_step"] > 0
 
