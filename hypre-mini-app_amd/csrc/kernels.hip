@@ -1922,6 +1922,41 @@ void scale(double alpha, double *x, int n, hipStream_t s) {
   hipLaunchKernelGGL(scale_k<0>, dim3(vec_grid(n)), dim3(256), 0, s, (const double *)nullptr, alpha, x, n);
   MI_HIP(hipGetLastError());
 }
+// x *= 1 / sqrt(*sumsq_dev) as scale_k<1>, and -- first wave of the first workgroup, before it touches x -- the `count`
+// doubles at `slots` are stored into host memory the device can write (hipHostMalloc) followed by the number `seq` in a
+// flag word, system-scope release: the host reads the Hessenberg column of an Arnoldi step by polling that word, while
+// this kernel is still streaming the new basis vector, instead of a copy kernel and a stream synchronisation behind it
+// (one idle queue of ~70 us per step, profiles/r03_gaps_512.txt).
+__global__ __launch_bounds__(256) void scale_post_k(const double *__restrict__ sumsq_dev, double *__restrict__ x, int n,
+                                                    const double *__restrict__ slots, int count,
+                                                    double *__restrict__ host_out, unsigned long long *__restrict__ host_flag,
+                                                    unsigned long long seq) {
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    for (int j = threadIdx.x; j < count; j += 64)
+      __hip_atomic_store(host_out + j, slots[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // the wave's stores are out before the flag
+    if (threadIdx.x == 0) __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  const double t = sumsq_dev[0];
+  if (!(t > 0.0)) return;
+  const double a = 1.0 / sqrt(t);
+  const long long stride = (long long)gridDim.x * 512;
+  long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 2;
+  for (; i + 1 < n; i += stride) {
+    double2 v = *reinterpret_cast<double2 *>(x + i);
+    v.x *= a;
+    v.y *= a;
+    *reinterpret_cast<double2 *>(x + i) = v;
+  }
+  if (i < n) x[i] *= a;
+}
+void scale_inv_sqrt_post(const double *sumsq_dev, double *x, int n, const double *slots, int count, double *host_out,
+                         unsigned long long *host_flag, unsigned long long seq, hipStream_t s) {
+  // (n == 0: a rank without rows still posts)
+  hipLaunchKernelGGL(scale_post_k, dim3(n ? vec_grid(n) : 1), dim3(256), 0, s, sumsq_dev, x, n, slots, count, host_out,
+                     host_flag, seq);
+  MI_HIP(hipGetLastError());
+}
 void scale_inv_sqrt_dev(const double *sumsq_dev, double *x, int n, hipStream_t s) {
   if (n == 0) return;
   hipLaunchKernelGGL(scale_k<1>, dim3(vec_grid(n)), dim3(256), 0, s, sumsq_dev, 1.0, x, n);

@@ -131,6 +131,9 @@ void lin_comb(const double *const *vecs, const double *coef_host, int m, bool in
 void axpy(double alpha, const double *x, double *y, int n, hipStream_t s);
 void axpy_dev(const double *alpha_dev, double scale, const double *x, double *y, int n, hipStream_t s);
 void scale(double alpha, double *x, int n, hipStream_t s);
+// scale_inv_sqrt_dev + the `count` doubles at `slots` and then `seq` posted into host memory (see scale_post_k)
+void scale_inv_sqrt_post(const double *sumsq_dev, double *x, int n, const double *slots, int count, double *host_out,
+                         unsigned long long *host_flag, unsigned long long seq, hipStream_t s);
 void scale_inv_sqrt_dev(const double *sumsq_dev, double *x, int n, hipStream_t s);
 void fill(double *x, int n, double v, hipStream_t s);
 void copy(const double *x, double *y, int n, hipStream_t s);

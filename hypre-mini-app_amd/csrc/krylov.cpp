@@ -193,6 +193,31 @@ int GmresSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
   auto mv = [&](double alpha, const double *xv, double beta, const double *bv, double *yv) {
     matvec_all(A, alpha, xv, beta, bv, yv, nloc, nc, k::PROF_SPMV_L0);
   };
+  // p_i /= ||p_i|| and the step's Hessenberg column (the `count` leading device slots) into c.h_pinned: the scaling kernel
+  // posts the slots and a sequence number into pinned host memory before it starts on the vector, and the host polls the
+  // number -- Givens rotations, the convergence test and the launches of the next cycle happen while that kernel still
+  // runs, and no copy kernel or stream synchronisation stands between two steps (MI_HYPRE_GMRES_POLL=0: the round-3 way)
+  static const bool poll = !(getenv("MI_HYPRE_GMRES_POLL") && atoi(getenv("MI_HYPRE_GMRES_POLL")) == 0);
+  auto fetch_column = [&](const double *norm_slot, double *vec, int count) {
+    if (!poll || count > 255) {
+      k::scale_inv_sqrt_dev(norm_slot, vec, n, s);
+      MI_HIP(hipMemcpyAsync(c.h_pinned, slots, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, s));
+      MI_HIP(hipStreamSynchronize(s));
+      return;
+    }
+    const unsigned long long seq = ++c.post_seq;
+    k::scale_inv_sqrt_post(norm_slot, vec, n, slots, count, c.h_pinned + 256, c.h_post_flag, seq, s);
+    const double t0 = wall_time();
+    unsigned spins = 0;
+    while (__atomic_load_n(c.h_post_flag, __ATOMIC_ACQUIRE) != seq) {
+      if ((++spins & 0xffffu) == 0 && wall_time() - t0 > 30.0) {  // something is wrong with the queue: let the runtime say what
+        MI_HIP(hipStreamSynchronize(s));
+        if (__atomic_load_n(c.h_post_flag, __ATOMIC_ACQUIRE) != seq) fail(1, "GMRES: the Hessenberg column was not posted");
+        break;
+      }
+    }
+    memcpy(c.h_pinned, c.h_pinned + 256, (size_t)count * sizeof(double));
+  };
   ParVector &p0 = basis(0);
   mv(-1.0, x.all(), 1.0, b.all(), p0.data());
   const double b_norm = std::sqrt(par_dot_host(comm, b.all(), b.all(), n, s));
@@ -256,9 +281,7 @@ int GmresSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
                       slots + j, s);
           if (comm.size > 1) comm.allreduce_dev(slots + j, 1, CommDType::F64, CommOp::SUM, s), c.n_allreduce++;
         }
-        k::scale_inv_sqrt_dev(slots + i, pi.data(), n, s);
-        MI_HIP(hipMemcpyAsync(c.h_pinned, slots, (size_t)(i + 1) * sizeof(double), hipMemcpyDeviceToHost, s));
-        MI_HIP(hipStreamSynchronize(s));
+        fetch_column(slots + i, pi.data(), i + 1);
         for (int j = 0; j < i; j++) hh[(size_t)j][(size_t)i - 1] = c.h_pinned[j];
       } else {
         // classical Gram-Schmidt: per pass ONE block of inner products (one all-reduce of i values) and one
@@ -273,10 +296,7 @@ int GmresSolver::solve(ParCSR &A_in, ParVector &b_in, ParVector &x_in) {
         }
         double *nrm = (ortho == 1) ? slots + i : slots + 128 + i;  // adjacent to the last pass: one copy below
         par_dot(comm, pi.data(), pi.data(), n, nrm, s);
-        k::scale_inv_sqrt_dev(nrm, pi.data(), n, s);
-        MI_HIP(hipMemcpyAsync(c.h_pinned, slots, (size_t)(128 * (ortho - 1) + i + 1) * sizeof(double),
-                              hipMemcpyDeviceToHost, s));
-        MI_HIP(hipStreamSynchronize(s));
+        fetch_column(nrm, pi.data(), 128 * (ortho - 1) + i + 1);
         for (int j = 0; j < i; j++) {
           double hsum = c.h_pinned[j];
           if (ortho > 1) hsum += c.h_pinned[128 + j];

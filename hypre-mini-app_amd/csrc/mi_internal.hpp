@@ -324,6 +324,8 @@ struct Ctx {
   DVec<double> red_out;       // result slots (device scalars)
   DVec<unsigned> red_ticket;  // ticket counter of the reductions' last-block stage (kernels.hip finish_reduction)
   double *h_pinned = nullptr; // pinned host mirror of result slots
+  unsigned long long *h_post_flag = nullptr;  // sequence number a posting kernel stores after its values (k::scale_post_k)
+  unsigned long long post_seq = 0;
   int gs_chunk = 8;
   int verbose = 0;
   KernelTimer *timer = nullptr;

@@ -140,7 +140,11 @@ void ensure_init() {
   c.red_out.alloc(256);
   c.red_ticket.alloc(4);
   MI_HIP(hipMemset(c.red_ticket.p, 0, 4 * sizeof(unsigned)));
-  MI_HIP(hipHostMalloc((void **)&c.h_pinned, 256 * sizeof(double), hipHostMallocDefault));
+  // [0, 256): result slots the host reads; [256, 512): posted by kernels and polled (h_post_flag = the last word)
+  MI_HIP(hipHostMalloc((void **)&c.h_pinned, 512 * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));  // (coherent: a kernel's system-scope stores are visible to the polling host while the kernel runs)
+  memset(c.h_pinned, 0, 512 * sizeof(double));
+  c.h_post_flag = reinterpret_cast<unsigned long long *>(c.h_pinned + 511);
+  c.post_seq = 0;
   if (!c.comm) c.comm = make_self_comm();
   const char *ch = getenv("MI_HYPRE_GS_CHUNK");
   if (ch) c.gs_chunk = atoi(ch);
