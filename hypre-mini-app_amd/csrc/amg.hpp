@@ -166,6 +166,12 @@ struct BoomerAMG {
   // map of the whole sub-cycle (that level and everything below it) is tabulated at Setup by cycling the unit
   // vectors, and the cycle multiplies by it: one launch instead of ~9 per level (at 512^3: levels 8-11, 36 of the
   // ~75 latency-bound launches of a cycle).  Same operator, other rounding (1e-16 relative).
+  // what the tabulated maps depend on besides the operators: the cycle's parameters at tabulation time.  A setter that
+  // runs AFTER Setup (relax types, sweeps, weights, cycle type, HYPRE_MI_SetGSChunk, HYPRE_MI_SetZeroGuessMode) changes
+  // the cycle of the fine levels at once; cycle(0, ..) compares this signature and tabulates again when it differs
+  // (the frozen maps used to keep the old smoother on the coarse levels silently)
+  std::vector<double> collapsed_signature;
+  std::vector<double> cycle_signature() const;
   int collapsed_level = -1, collapsed_n = 0;
   DVec<double> collapsed_Bt;  // column j of the map = row j here (n x n)
   // second stage: the level above (at most MI_HYPRE_DENSE_TAIL_ROWS2 = 4608 rows), tabulated THROUGH the first map

@@ -339,6 +339,8 @@ bool BoomerAMG::zero_cycle_ignores_u(int level) {
 // one cycle on the level's own f (Lv.f) and u (Lv.u)
 void BoomerAMG::cycle(int level, bool u_is_zero) {
   const int nlev = (int)L.size();
+  if (level == 0 && collapsed_level >= 0 && collapsed_signature != cycle_signature())
+    build_collapsed_tail();  // a cycle parameter changed after Setup: the tabulated maps are of another cycle
   AmgLevel &Lv = L[(size_t)level];
   if (level == collapsed_level2 && u_is_zero) {  // the tabulated map of this level's whole sub-cycle
     k::dense_matvec_t(collapsed_Bt2.p, Lv.f.p, Lv.u.p, collapsed_n2, ctx().stream);
@@ -413,7 +415,24 @@ void BoomerAMG::tabulate_cycle(int lt, DVec<double> &Bt) {
   Lv.f.p = own_f;
 }
 
+std::vector<double> BoomerAMG::cycle_signature() const {
+  std::vector<double> v;
+  for (int k = 0; k < 3; k++) v.push_back(p.relax_type[k]), v.push_back(p.num_sweeps[k]);
+  v.push_back(p.relax_order);
+  v.push_back(p.relax_weight);
+  v.push_back(p.outer_weight);
+  v.push_back(p.cycle_type);
+  v.push_back(chunk());
+  v.push_back(zero_skip_mode());
+  v.push_back(p.smooth_type);
+  v.push_back(p.smooth_num_levels);
+  v.push_back(p.smooth_num_sweeps);
+  v.push_back(p.ilu_max_iter);
+  return v;
+}
+
 void BoomerAMG::build_collapsed_tail() {
+  collapsed_signature = cycle_signature();
   collapsed_level = collapsed_level2 = -1;
   collapsed_n = collapsed_n2 = 0;
   collapsed_Bt.release();

@@ -1285,6 +1285,23 @@ HYPRE_Int HYPRE_MI_SetZeroGuessMode(HYPRE_Int mode) {
   set_zero_skip_mode(mode);
   API_END
 }
+// test hook (tests/test_gpu_amg.py): every level's solution and scratch vectors of the hierarchy become NaN.  A cycle from
+// a zero guess that skips its zero-fills (BoomerAMG::zero_cycle_ignores_u) must still give the bits it gives on clean
+// vectors -- "never read" is checked, not assumed
+HYPRE_Int HYPRE_MI_BoomerAMGPoisonWorkVectors(HYPRE_Solver solver) {
+  API_BEGIN
+  BoomerAMG &a = AMG(solver)->amg;
+  const double nan = std::numeric_limits<double>::quiet_NaN();
+  hipStream_t s = ctx().stream;
+  for (BoomerAMG *h = &a; h; h = h->tail.get())
+    for (AmgLevel &Lv : h->L) {
+      if (Lv.u.p && Lv.n) k::fill(Lv.u.p, Lv.n, nan, s);
+      if (Lv.tmp.p && Lv.n) k::fill(Lv.tmp.p, Lv.n, nan, s);
+      if (Lv.snap.p && Lv.n) k::fill(Lv.snap.p, Lv.n, nan, s);
+    }
+  MI_HIP(hipStreamSynchronize(s));
+  API_END
+}
 HYPRE_Int HYPRE_MI_SetValueDictionary(HYPRE_Int on) {
   API_BEGIN
   k::set_value_dictionary(on != 0);
@@ -1382,7 +1399,7 @@ HYPRE_Int HYPRE_MI_BoomerAMGGetLevelCSRSize(HYPRE_Solver solver, HYPRE_Int level
   if (which == 7) {  // x cache of the level operator: tiles, 0, total unique columns over the tiles
     *nrows = L.A->d_diag.nblocks;
     *ncols = 0;
-    *nnz = (HYPRE_BigInt)L.A->d_diag.ucols.n;
+    *nnz = (HYPRE_BigInt)(L.A->d_diag.n_unique ? L.A->d_diag.n_unique : (long long)L.A->d_diag.ucols.n);
     return 0;
   }
   const ParCSR *M = nullptr;

@@ -183,7 +183,9 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_xc(int nb, int xchunk, cons
                                                              const unsigned short *__restrict__ lcol,
                                                              const double *__restrict__ x, double *__restrict__ y,
                                                              EpiArgs e, const unsigned char *__restrict__ vidx,
-                                                             const double *__restrict__ vlut) {
+                                                             const double *__restrict__ vlut,
+                                                             const unsigned short *__restrict__ ucode,
+                                                             const int *__restrict__ ubase) {
   constexpr int TILE = 8 * BLOCK;  // TILE / TILE_WIDE
   __shared__ double prod[TILE];
   __shared__ double slut[VAL8 ? 256 : 1];
@@ -215,14 +217,25 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_xc(int nb, int xchunk, cons
   }
   constexpr int NU = TILE / BLOCK;
   int uc[NU];
+  int myblock = 0;
+  if (ucode) {  // (uniform) block-coded list: 6-bit selector of one of the tile's <= 64 column blocks + 10-bit offset
+    myblock = LIST_LOAD(ubase + d1.w + (tid & 63));  // (padded: the 64 ints behind any tile's first block exist)
 #pragma unroll
-  for (int q = 0; q < NU; q++) {
-    const int k = tid + q * BLOCK;
-    // (nothing that needs the loaded id inside the branch: written as a select, the compiler put the id's 64-bit
-    // extension there and with it a wait after every load -- up to eight SERIAL round trips per tile; check the ISA
-    // when this line changes: no s_waitcnt between the list loads)
-    uc[q] = 0;
-    if (k < nu) uc[q] = LIST_LOAD(ucols + u0 + k);
+    for (int q = 0; q < NU; q++) {
+      const int k = tid + q * BLOCK;
+      uc[q] = 0;
+      if (k < nu) uc[q] = LIST_LOAD(ucode + u0 + k);
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < NU; q++) {
+      const int k = tid + q * BLOCK;
+      // (nothing that needs the loaded id inside the branch: written as a select, the compiler put the id's 64-bit
+      // extension there and with it a wait after every load -- up to eight SERIAL round trips per tile; check the ISA
+      // when this line changes: no s_waitcnt between the list loads)
+      uc[q] = 0;
+      if (k < nu) uc[q] = LIST_LOAD(ucols + u0 + k);
+    }
   }
   const long long base_al64 = base64 & ~1LL;
   const int base = (int)(base64 - base_al64), base_al = 0;  // tile-local: the aligned start is 0, the first entry 0 or 1
@@ -253,6 +266,10 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_xc(int nb, int xchunk, cons
   // the gathers: ALL of them in flight before the first LDS write, and before the loads below that depend on each other.
   // (Written as `if (k < nu) xs[k] = x[uc[q]]`, every load sat in a branch of its own with its wait and its LDS write:
   // up to eight serial round trips per tile.  Lanes beyond the list read x[0] -- uc is 0 there -- one cached sector.)
+  if (ucode) {  // (after the stream loads have been issued: the codes are waited for here)
+#pragma unroll
+    for (int q = 0; q < NU; q++) uc[q] = (__shfl(myblock, uc[q] >> 10, 64) << 10) | (uc[q] & 1023);
+  }
   double xv[NU];
 #pragma unroll
   for (int q = 0; q < NU; q++) xv[q] = x[uc[q]];
@@ -325,7 +342,8 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_xc(int nb, int xchunk, cons
 }
 
 __global__ __launch_bounds__(256) void tile_desc_k(int nb, const int *__restrict__ rb, const long long *__restrict__ ia,
-                                                   const int *__restrict__ uptr, int *__restrict__ desc) {
+                                                   const int *__restrict__ uptr, int *__restrict__ desc,
+                                                   const long long *__restrict__ bptr) {
   const int b = blockIdx.x * 256 + threadIdx.x;
   if (b >= nb) return;
   const int r0 = rb[b], r1 = rb[b + 1];
@@ -334,7 +352,42 @@ __global__ __launch_bounds__(256) void tile_desc_k(int nb, const int *__restrict
   const long long base = ia[r0], len = ia[r1] - base;
   // a single row longer than any tile (>= 2^31 entries it cannot be: such rows do not exist) keeps its true length
   d[0] = make_int4(r0, r1, (int)(unsigned)(base & 0xffffffffLL), (int)(len > 0x7fffffffLL ? 0x7fffffffLL : len));
-  d[1] = make_int4(u0, u1 - u0, (int)(base >> 32), 0);
+  d[1] = make_int4(u0, u1 - u0, (int)(base >> 32), bptr ? (int)bptr[b] : 0);
+}
+
+// Block-coded column lists (DevCSR::ucode / ubase): one wave per tile walks the tile's sorted unique columns in steps of
+// 64, a column opens a new block when its id >> 10 differs from its predecessor's.  FILL = false counts the blocks,
+// FILL = true writes the block numbers behind bptr[tile] and the 16-bit codes.
+template <bool FILL>
+__global__ __launch_bounds__(256) void ucode_blocks_k(int ntiles, const int *__restrict__ uptr, const int *__restrict__ ucols,
+                                                      int *__restrict__ nblk, const long long *__restrict__ bptr,
+                                                      int *__restrict__ ubase, unsigned short *__restrict__ ucode,
+                                                      int *__restrict__ maxblk) {
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (tile >= ntiles) return;
+  const int u0 = uptr[tile], u1 = uptr[tile + 1];
+  int run = 0, prev = -1;
+  for (int k0 = u0; k0 < u1; k0 += 64) {
+    const int k = k0 + lane;
+    const int c = k < u1 ? ucols[k] : -1;
+    const int blk = k < u1 ? (c >> 10) : -2;
+    int left = __shfl_up(blk, 1, 64);
+    if (lane == 0) left = prev;
+    const bool isnew = k < u1 && blk != left;
+    const unsigned long long m = __ballot(isnew);
+    const int sel = run + __popcll(m & ((2ull << lane) - 1ull)) - 1;  // blocks opened up to and including this lane
+    if (FILL) {
+      if (isnew) ubase[bptr[tile] + sel] = blk;
+      if (k < u1) ucode[k] = (unsigned short)(((sel & 63) << 10) | (c & 1023));
+    }
+    run += __popcll(m);
+    prev = __shfl(blk, 63, 64);
+  }
+  if (!FILL && lane == 0) {
+    nblk[tile] = run;
+    atomicMax(maxblk, run);
+  }
 }
 
 // compressed-row off-diagonal block: one lane per stored row (halo rows are few
@@ -785,7 +838,9 @@ __global__ __launch_bounds__(BLOCK, 2048 / BLOCK) void gs_tile_k(int blk0, int n
                                                         int row_begin, int row_end, int zero_from,
                                                         double *__restrict__ tout, int t_from,
                                                         const unsigned char *__restrict__ vidx,
-                                                        const double *__restrict__ vlut) {
+                                                        const double *__restrict__ vlut,
+                                                        const unsigned short *__restrict__ ucode,
+                                                        const int *__restrict__ ubase) {
 #define UOLD(j) (((j) < split ? u_lo : u_hi)[(j)])
   constexpr int TILE = 8 * BLOCK;        // TILE / TILE_WIDE
   __shared__ double buf[TILE];           // x cache, then products / in-chunk coefficients
@@ -813,7 +868,16 @@ __global__ __launch_bounds__(BLOCK, 2048 / BLOCK) void gs_tile_k(int blk0, int n
   const bool all_zero = zero_from <= 0;
   constexpr int NU = TILE / BLOCK;
   int ucid[NU];
-  if (!all_zero) {
+  int myblock = 0;
+  if (!all_zero && ucode) {  // (uniform) block-coded list, see spmv_stream_xc
+    myblock = LIST_LOAD(ubase + d1.w + (tid & 63));
+#pragma unroll
+    for (int q = 0; q < NU; q++) {
+      const int k = tid + q * BLOCK;
+      ucid[q] = 0;
+      if (k < nu) ucid[q] = LIST_LOAD(ucode + u0 + k);
+    }
+  } else if (!all_zero) {
 #pragma unroll
     for (int q = 0; q < NU; q++) {
       const int k = tid + q * BLOCK;
@@ -851,6 +915,10 @@ __global__ __launch_bounds__(BLOCK, 2048 / BLOCK) void gs_tile_k(int blk0, int n
   // batches -- the first covers tiles of up to 4 * BLOCK unique columns, i.e. nearly all of them.
   constexpr int GB = VAL8 ? NU : NU / 2;
   double xv[GB];
+  if (!all_zero && ucode) {
+#pragma unroll
+    for (int q = 0; q < NU; q++) ucid[q] = (__shfl(myblock, ucid[q] >> 10, 64) << 10) | (ucid[q] & 1023);
+  }
   if (!all_zero) {
 #pragma unroll
     for (int q = 0; q < GB; q++) {
@@ -1540,7 +1608,7 @@ static const char *launch_stream(int epi, const DevCSR &A, const double *x, doub
 #define XC_LAUNCH_W(EPI_, V8_)                                                                                       \
   name = "spmv_stream_xc<" #EPI_ ", 0, " #V8_ ", 512>";                                                              \
   hipLaunchKernelGGL((spmv_stream_xc<EPI_, 0, V8_, SPMV_BLOCK_WIDE>), grid, wide, 0, s, nb, xchunk, A.tdesc.p, A.ia.p, \
-                     A.ja.p, A.a.p, A.ucols.p, A.lcol.p, x, y, e, A.vidx.p, A.vlut.p)
+                     A.ja.p, A.a.p, A.ucols.p, A.lcol.p, x, y, e, A.vidx.p, A.vlut.p, A.ucode.p, A.ubase.p)
     if (A.val8) {
       if (epi == 0) {
         XC_LAUNCH_W(0, true);
@@ -1559,7 +1627,7 @@ static const char *launch_stream(int epi, const DevCSR &A, const double *x, doub
 #define XC_LAUNCH(EPI_, TAG_, V8_)                                                                                  \
   name = "spmv_stream_xc<" #EPI_ ", " #TAG_ ", " #V8_ ", 256>";                                                       \
   hipLaunchKernelGGL((spmv_stream_xc<EPI_, TAG_, V8_, SPMV_BLOCK>), grid, block, 0, s, nb, xchunk, A.tdesc.p, A.ia.p, A.ja.p, \
-                     A.a.p, A.ucols.p, A.lcol.p, x, y, e, A.vidx.p, A.vlut.p)
+                     A.a.p, A.ucols.p, A.lcol.p, x, y, e, A.vidx.p, A.vlut.p, A.ucode.p, A.ubase.p)
     if (A.val8) {
       if (epi == 0 && level0) {
         XC_LAUNCH(0, 1, true);
@@ -1679,13 +1747,52 @@ void build_value_dictionary(DevCSR &A, hipStream_t s) {
   A.val8 = true;
 }
 
+// block-coded column lists of an x-cache operator (DevCSR::ucode / ubase) from its 4-byte lists, which are released when
+// every tile fits (MI_HYPRE_UCODE=0: keep the 4-byte lists); bptr: per tile the start of its blocks in ubase
+static void build_block_coded_lists(DevCSR &A, DVec<long long> &bptr, hipStream_t s) {
+  A.ucode.release();
+  A.ubase.release();
+  A.n_unique = (long long)A.ucols.n;
+  static const bool on = !(getenv("MI_HYPRE_UCODE") && atoi(getenv("MI_HYPRE_UCODE")) == 0);
+  if (!on || !A.xcache || A.nblocks <= 0 || !A.uptr.p || A.ucols.n == 0) return;
+  const int nt = A.nblocks;
+  DVec<int> nblk((size_t)nt), maxblk(1);
+  MI_HIP(hipMemsetAsync(maxblk.p, 0, sizeof(int), s));
+  const dim3 grid((unsigned)((nt + 3) / 4));
+  hipLaunchKernelGGL(ucode_blocks_k<false>, grid, dim3(256), 0, s, nt, A.uptr.p, A.ucols.p, nblk.p, nullptr, nullptr, nullptr, maxblk.p);
+  MI_HIP(hipGetLastError());
+  int mx = 0;
+  d2h(&mx, maxblk.p, sizeof(int), s);
+  if (mx > 64) return;  // a tile whose columns spread over more than 64 blocks of 1024 ids: this operator keeps the 4-byte lists
+  bptr.alloc((size_t)nt + 1);
+  {
+    // exclusive scan of the tiles' block counts (tiles: at most a few hundred thousand -- one workgroup's worth of work;
+    // done on the host through the pinned staging buffer)
+    std::vector<int> hn = nblk.to_host();
+    std::vector<long long> hp((size_t)nt + 1, 0);
+    for (int t = 0; t < nt; t++) hp[(size_t)t + 1] = hp[(size_t)t] + hn[(size_t)t];
+    MI_HIP(hipMemcpyAsync(bptr.p, hp.data(), ((size_t)nt + 1) * sizeof(long long), hipMemcpyHostToDevice, s));
+    MI_HIP(hipStreamSynchronize(s));
+    A.ubase.alloc((size_t)hp[(size_t)nt], 64);  // (a wave loads 64 ints from a tile's first block on: padded)
+    MI_HIP(hipMemsetAsync(A.ubase.p, 0, ((size_t)hp[(size_t)nt] + 64) * sizeof(int), s));
+  }
+  A.ucode.alloc(A.ucols.n);
+  hipLaunchKernelGGL(ucode_blocks_k<true>, grid, dim3(256), 0, s, nt, A.uptr.p, A.ucols.p, nullptr, bptr.p, A.ubase.p, A.ucode.p, nullptr);
+  MI_HIP(hipGetLastError());
+  MI_HIP(hipStreamSynchronize(s));
+  A.ucols.release();
+}
+
 void build_tile_desc(DevCSR &A, const long long *ia64, hipStream_t s) {
   A.tdesc.release();
   if (A.nblocks <= 0 || !A.rb.p) return;
+  DVec<long long> bptr;
+  build_block_coded_lists(A, bptr, s);
   A.tdesc.alloc((size_t)A.nblocks * 8);
   hipLaunchKernelGGL(tile_desc_k, dim3((unsigned)((A.nblocks + 255) / 256)), dim3(256), 0, s, A.nblocks, A.rb.p, ia64,
-                     A.xcache ? A.uptr.p : nullptr, A.tdesc.p);
+                     A.xcache ? A.uptr.p : nullptr, A.tdesc.p, A.ucode.p ? bptr.p : nullptr);
   MI_HIP(hipGetLastError());
+  MI_HIP(hipStreamSynchronize(s));  // (bptr goes away)
   build_value_dictionary(A, s);
 }
 
@@ -1767,7 +1874,7 @@ void gs_hybrid(const DevCSR &A, const double *u_lo, const double *u_hi, int spli
   hipLaunchKernelGGL((gs_tile_k<V8_, BLOCK_>), dim3((unsigned)(b1 - b0)), dim3(BLOCK_), 0, s, b0, b1 - b0, A.tdesc.p, \
                      A.ia.p, A.a.p, A.ucols.p, A.lcol.p, cf, points, d, f, offc, u_lo, u_hi, split, out, fwd ? 1 : 0,  \
                      bwd ? 1 : 0, w, first_row, last_row, zero_from, tout, t_from, V8_ ? A.vidx.p : nullptr,          \
-                     V8_ ? A.vlut.p : nullptr)
+                     V8_ ? A.vlut.p : nullptr, A.ucode.p, A.ubase.p)
     const bool wide = A.tile_entries == SPMV_TILE_WIDE;
     if (b1 > b0 && A.val8 && wide) {
       GS_TILE_LAUNCH(true, SPMV_BLOCK_WIDE);

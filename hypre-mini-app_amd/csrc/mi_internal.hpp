@@ -218,6 +218,15 @@ struct DevCSR {
   std::vector<int> rb_host;  // host copy of rb (row ranges -> tile ranges)
   int max_tile_rows = 256;   // rows of the largest tile
   DVec<int> uptr, ucols;
+  // Round 4: the column lists in 2 instead of 4 bytes per unique column.  A tile's sorted unique columns fall into few
+  // aligned blocks of 1024 column ids (17-24 on the levels of a 3-D Laplacian hierarchy, never more than 52 at 128^3:
+  // a tile's rows and their neighbours live in a handful of cells of the internal numbering), so an id is a 6-bit
+  // selector of one of <= 64 block numbers of the tile (`ubase`, loaded once per wave, read by lane shuffle) and a
+  // 10-bit offset (`ucode`).  The lists were 1.7 of the 4.7 bytes a level-0 entry of the benchmark costs, and 1.07 of
+  // 11.1 on level 1.  An operator with a tile of more than 64 blocks keeps the 4-byte lists (`ucols`; ucode empty).
+  DVec<unsigned short> ucode;
+  DVec<int> ubase;
+  long long n_unique = 0;  // total length of the tiles' column lists
   DVec<unsigned short> lcol;
   // value dictionary (k::build_value_dictionary): operators with at most 256 distinct values (constant-coefficient
   // stencils such as the reference's own generator: 26 / -1, or 6 / -1) carry one byte per entry besides `a`; the
@@ -231,7 +240,7 @@ struct DevCSR {
   // consecutive rows then gather neighbouring fine entries -- while the coarse level's vectors are in its own
   // C-first order (amg_setup.cpp: setup_device).  Empty = identity.
   DVec<int> rowmap;
-  DVec<int> tdesc;  // 8 ints per tile: r0, r1, low word of ia[r0], ia[r1] - ia[r0], uptr[b], #unique columns, high word of ia[r0], 0 (k::build_tile_desc)
+  DVec<int> tdesc;  // 8 ints per tile: r0, r1, low word of ia[r0], ia[r1] - ia[r0], uptr[b], #unique columns, high word of ia[r0], first entry of the tile in ubase (k::build_tile_desc)
   bool empty() const { return nrows == 0 || nnz == 0; }
   void upload(const HostCSR &h);
 };

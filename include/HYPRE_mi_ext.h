@@ -74,6 +74,9 @@ HYPRE_Int HYPRE_MI_GetGSChunk(HYPRE_Int *rows_per_chunk);
  * (default, env MI_HYPRE_GS_ZERO_SKIP) the residual that follows also reuses the F pass's product with the C values
  * and reads the F rows without their C columns.  Same result up to summation order. */
 HYPRE_Int HYPRE_MI_SetZeroGuessMode(HYPRE_Int mode);
+/* test hook: fill every level's solution / scratch vectors with NaN (a zero-guess cycle that skips its zero-fills must
+ * not read them) */
+HYPRE_Int HYPRE_MI_BoomerAMGPoisonWorkVectors(HYPRE_Solver solver);
 /* Value dictionary of operators with at most 256 distinct values (constant-coefficient stencils such as the
  * reference generator's 26 / -1, /root/reference/src/laplace_3d_weak_scaling.hpp:558,600): one byte per entry instead
  * of the 8-byte value in the matrix stream; same doubles, same results.  on = 0 keeps the plain stream -- what a

@@ -11,6 +11,8 @@ Tolerances (fp64):
     solution within the reference's own closeness rule rtol 1e-6 / atol 1e-8
     (/root/reference/src/HypreSystem.cpp:815-818) of both the oracle and x* = 1.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -746,3 +748,91 @@ def test_seeded_solver_families_match_oracle(mi, oc, seed):
     if info["iters"] < 60:
         assert rc == 0 and abs(s.final_rel_res - info["rel_res"]) <= 1e-9, what
         assert _allclose_ref(x.get(), xo, rtol=1e-5, atol=1e-7), what
+
+
+def test_zero_guess_cycles_never_read_the_vectors_they_do_not_fill(mi):
+    """ADVICE r3: BoomerAMG::zero_cycle_ignores_u skips the zero-fill of a level's vector when the first sweep on the
+    zero guess overwrites every row without reading it.  "Never read" is checked here: with every level's solution and
+    scratch vectors poisoned with NaN before each solve, GMRES + BoomerAMG gives the bits it gives on clean vectors
+    (7- and 27-point, with the collapsed dense tail in play on the coarse levels)."""
+    for n, stencil in ((20, 7), (12, 27)):
+        A, b, x, rhs = mi.build_laplace_system(n, n, n, stencil)
+        amg = mi.BoomerAMG(print_level=0)
+        gm = mi.GMRES(tolerance=1e-10, max_iterations=100, kspace=50, print_level=0)
+        gm.set_precond(amg)
+        gm.setup(A, b, x)
+        assert gm.solve(A, b, x) == 0
+        ref = (gm.num_iterations, np.asarray(gm.residual_history()).copy(), x.get().copy())
+        assert amg.num_levels >= 3
+        for _ in range(2):
+            mi.call("HYPRE_MI_BoomerAMGPoisonWorkVectors", amg.h)
+            x.fill(0.0)
+            assert gm.solve(A, b, x) == 0
+            xs = x.get()
+            assert np.all(np.isfinite(xs))
+            assert gm.num_iterations == ref[0] and np.array_equal(np.asarray(gm.residual_history()), ref[1])
+            assert np.array_equal(xs, ref[2])
+
+
+def test_cycle_setters_after_setup_reach_the_collapsed_tail(mi, oc):
+    """the tabulated dense maps of the coarse tail were frozen at Setup, so a relax type or sweep count set
+    AFTER Setup changed the fine levels' cycle only.  Now the maps are tabulated again when the cycle's parameters
+    differ: a solver whose smoother is switched after Setup behaves exactly like one that was set up with it."""
+    n = 20
+    runs = []
+    for late in (False, True):
+        A, b, x, rhs = mi.build_laplace_system(n, n, n, 7)
+        kw = {} if late else {"relax_type": 6, "num_sweeps": 2}
+        amg = mi.BoomerAMG(print_level=0, **kw)
+        gm = mi.GMRES(tolerance=1e-10, max_iterations=100, kspace=50, print_level=0)
+        gm.set_precond(amg)
+        gm.setup(A, b, x)
+        if late:
+            assert gm.solve(A, b, x) == 0  # (the default cycle first: its maps exist and must go)
+            mi.call("HYPRE_BoomerAMGSetRelaxType", amg.h, 6)
+            mi.call("HYPRE_BoomerAMGSetNumSweeps", amg.h, 2)
+            x.fill(0.0)
+        assert gm.solve(A, b, x) == 0
+        runs.append((gm.num_iterations, np.asarray(gm.residual_history()).copy(), x.get().copy()))
+    assert runs[0][0] == runs[1][0]
+    assert np.allclose(runs[0][1], runs[1][1], rtol=1e-9, atol=0.0) and np.allclose(runs[0][2], runs[1][2], rtol=0, atol=1e-10)
+
+
+@pytest.mark.parametrize("n,stencil", [(24, 7)])
+def test_default_on_features_against_their_switches(n, stencil):
+    """features that are on by default and change the path of every solve, each against its own switch, in a
+    process of its own (the switches are read once): the device arena (MI_HYPRE_POOL 2) against the block cache (1) and
+    plain hipMalloc (0), skipped zero-fills, block-coded column lists, the polled Hessenberg column -- all bit for bit
+    the same solve -- and the collapsed dense tail, which is the same operator in another summation order (same
+    iteration count, history and solution to rounding)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(**env):
+        e = dict(os.environ, **{k: str(v) for k, v in env.items()})
+        p = subprocess.run([sys.executable, os.path.join(root, "tests", "env_worker.py"), str(n), str(stencil)], env=e,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout[-3000:]
+        line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
+        return json.loads(line[len("RESULT "):])
+
+    ref = run()
+    assert ref["levels"] >= 4 and ref["arena_mapped"] > 0
+    for env in ({"MI_HYPRE_POOL": 0}, {"MI_HYPRE_POOL": 1}, {"MI_HYPRE_SKIP_ZERO_FILL": 0}, {"MI_HYPRE_UCODE": 0},
+                {"MI_HYPRE_GMRES_POLL": 0}, {"MI_HYPRE_ARENA_AHEAD": 0}):
+        r = run(**env)
+        assert r["iters"] == ref["iters"] and r["hist"] == ref["hist"] and r["x"] == ref["x"], env
+        if "MI_HYPRE_POOL" in env:
+            assert r["arena_mapped"] == 0, env
+    r = run(MI_HYPRE_DENSE_TAIL_ROWS=0)
+    assert r["iters"] == ref["iters"]
+    h0 = np.array([float.fromhex(h) for h in ref["hist"]])
+    h1 = np.array([float.fromhex(h) for h in r["hist"]])
+    assert np.allclose(h0, h1, rtol=1e-8, atol=0.0)
+    x0 = np.frombuffer(bytes.fromhex(ref["x"]), dtype=np.float64)
+    x1 = np.frombuffer(bytes.fromhex(r["x"]), dtype=np.float64)
+    assert np.abs(x0 - x1).max() < 1e-10
+
