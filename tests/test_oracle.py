@@ -662,3 +662,253 @@ def test_per_processor_coarsening_types_on_several_parts(oc):
         amg = oc.Amg(A, oc.default_params(coarsen_type=t, part_starts=ps, redundant_rows=0))
         x, info = oc.gmres(A, b, kdim=30, tol=1e-8, maxit=60, amg=amg)
         assert info["converged"] and np.allclose(x, 1.0, atol=1e-6), t
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Round 4: the coarsening of the upstream sample input -- coarsen_type 6, Falgout
+# (/root/reference/etc/hypre_app.yaml:35) -- against an INDEPENDENT plain-Python statement of its three pieces, written
+# for this test from the published descriptions (Ruge / Stueben 1987, section 4.6, with the bucket lists of HYPRE's
+# first pass; Cleary / Falgout / Henson / Jones 1998 for the second pass; Cleary / Luby / Jones / Plassmann for the
+# independent-set rounds): no code shared with oracle.c or amg_setup.cpp, other data structures (ordered dictionaries
+# instead of linked lists, an edge set instead of flag arrays).
+# ---------------------------------------------------------------------------------------------------------------
+def _rs_first_pass(S):
+    """Ruge-Stueben first pass.  lambda_i = number of points that depend strongly on i.  Undecided points wait in one
+    queue per value of lambda, in the order in which they (re-)entered it; the next C point is the oldest member of the
+    highest non-empty queue; the points that depend on it become F, and everything an F point depends on becomes more
+    attractive (+1); what the new C point itself depends on becomes less attractive (-1, F at zero).  Returns +1 / -1 /
+    -3 (a row without strong connections) per point."""
+    from collections import OrderedDict
+
+    S = S.tocsr()
+    n = S.shape[0]
+    row = [list(S.indices[S.indptr[i]:S.indptr[i + 1]]) for i in range(n)]           # i depends on row[i]
+    col = [[] for _ in range(n)]                                                      # col[j] depend on j, ascending
+    for i in range(n):
+        for j in row[i]:
+            col[j].append(i)
+    lam = [len(col[i]) for i in range(n)]
+    state = [0] * n
+    queues = {}
+
+    def leave(i):
+        queues[lam[i]].pop(i)
+
+    def join(i):
+        queues.setdefault(lam[i], OrderedDict())[i] = True
+
+    for i in range(n):
+        if not row[i]:
+            state[i], lam[i] = -3, 0
+    # the points enter in index order; a point nobody depends on is F at once, and what IT depends on gains one -- a
+    # neighbour that already waits moves to the back of the next queue, one that has not entered yet just counts higher
+    for j in range(n):
+        if state[j] != 0:
+            continue
+        if lam[j] > 0:
+            join(j)
+            continue
+        state[j] = -1
+        for nb in row[j]:
+            if state[nb] != 0:
+                continue
+            if nb < j:
+                if lam[nb] > 0:
+                    leave(nb)
+                lam[nb] += 1
+                join(nb)
+            else:
+                lam[nb] += 1
+    while True:
+        live = [m for m, q in queues.items() if q and m > 0]
+        if not live:
+            break
+        c = next(iter(queues[max(live)]))
+        leave(c)
+        state[c], lam[c] = 1, 0
+        for f in col[c]:
+            if state[f] != 0:
+                continue
+            state[f] = -1
+            leave(f)
+            for g in row[f]:
+                if state[g] == 0:
+                    leave(g)
+                    lam[g] += 1
+                    join(g)
+        for d in row[c]:
+            if state[d] != 0:
+                continue
+            leave(d)
+            lam[d] -= 1
+            if lam[d] > 0:
+                join(d)
+                continue
+            state[d] = -1
+            for g in row[d]:
+                if state[g] == 0:
+                    leave(g)
+                    lam[g] += 1
+                    join(g)
+    assert all(s_ != 0 for s_ in state)
+    return np.array(state), row
+
+
+def _rs_second_pass(state, row):
+    """Every strong F-F connection needs a common C point: going through the F points in order, the first strong F
+    neighbour without one becomes C tentatively; if there is a second one, the point itself becomes C instead and the
+    tentative one returns to F."""
+    state = state.copy()
+    for i in range(len(state)):
+        if state[i] != -1:
+            continue
+        tentative = None
+        while True:
+            mine = {c for c in row[i] if state[c] == 1}
+            lonely = next((j for j in row[i] if state[j] == -1 and not (mine & {c for c in row[j] if state[c] == 1})), None)
+            if lonely is None:
+                break
+            if tentative is None:
+                tentative = lonely
+                state[lonely] = 1
+            else:
+                state[i] = 1
+                state[tentative] = -1
+                break
+    return state
+
+
+def _park_miller(seed, count):
+    out, x = [], seed
+    for _ in range(count):
+        x = (16807 * x) % 2147483647
+        out.append(x / 2147483647.0)
+    return out
+
+
+def _cljp_on_boundary(S, state, part):
+    """The CLJP rounds of Falgout coarsening on several parts, in the form this repository specifies:
+    interior points (no strong connection into another part) keep their Ruge-Stueben verdict and stop voting -- their
+    outgoing edges leave the graph -- boundary points are decided by independent-set rounds on w = |S^T| + random:
+    a point that outweighs all its undecided neighbours becomes C; edges out of a C point leave (H1); an undecided
+    point drops its edges to C points and to undecided points that share one of those C points (H2); every removed edge
+    i -> j costs j one unit, and an undecided point below 1 becomes F."""
+    S = S.tocsr()
+    n = S.shape[0]
+    row = [list(S.indices[S.indptr[i]:S.indptr[i + 1]]) for i in range(n)]
+    w = np.zeros(n)
+    for i in range(n):
+        for j in row[i]:
+            w[j] += 1.0
+    w += np.array(_park_miller(2747, n))
+    state = state.copy()
+    edges = {(i, j) for i in range(n) for j in row[i]}
+    interior = np.array([all(part[j] == part[i] for j in row[i]) for i in range(n)])
+    undecided = []
+    for i in range(n):
+        if interior[i]:
+            continue
+        if w[i] < 1.0:
+            state[i] = -1
+        else:
+            state[i] = 0
+            undecided.append(i)
+
+    def drop(i, j):
+        if (i, j) in edges:
+            edges.discard((i, j))
+            if state[j] == 0:
+                w[j] -= 1.0
+
+    for i in range(n):
+        if interior[i]:
+            for j in row[i]:
+                drop(i, j)
+    first = True
+    while True:
+        if not first:
+            if not undecided:
+                break
+            und = set(undecided)
+            winners = [i for i in undecided
+                       if all(w[i] > w[j] for j in row[i] if j in und) and all(w[i] > w[k] for k in undecided if i in row[k])]
+            # (ties do not occur: the random parts differ)
+            for i in winners:
+                state[i] = 1
+            for i in winners:
+                for j in row[i]:
+                    drop(i, j)
+        first = False
+        for i in undecided:
+            if state[i] != 0:
+                continue
+            mine = {c for c in row[i] if state[c] == 1}
+            for c in mine:
+                edges.discard((i, c))   # (a C point's weight no longer matters)
+            for j in row[i]:
+                if state[j] == 0 and (i, j) in edges and mine & set(row[j]):
+                    drop(i, j)
+        nxt = []
+        for i in undecided:
+            if state[i] == 1:
+                continue
+            if w[i] < 1.0:
+                state[i] = -1
+            else:
+                nxt.append(i)
+        undecided = nxt
+    return state
+
+
+@pytest.mark.parametrize("n,stencil,aniso", [(12, 7, 0.0), (8, 27, 0.0), (10, 7, 0.05), (1500, 0, 0.0), (1100, 0, 1.0)])
+def test_ruge_stueben_and_falgout_against_an_independent_restatement(oc, n, stencil, aniso):
+    if stencil == 0:
+        # an unstructured M-matrix (a chain plus seeded random couplings of two strengths, so that the strength graph is
+        # neither regular nor symmetric): here the second pass finds F-F pairs without a common C point
+        rng = np.random.default_rng(4242 + n)
+        R = sp.random(n, n, density=4.0 / n, random_state=rng, format="csr")
+        R.data[:] = np.where(rng.random(R.nnz) < 0.5, 1.0, 0.3 if aniso else 1.0)
+        R = (R + R.T + sp.diags([np.ones(n - 1), np.ones(n - 1)], [-1, 1])).tocsr()
+        R = (R - sp.diags(R.diagonal())).tocsr()
+        R.eliminate_zeros()
+        M = (-abs(R) + sp.diags(np.asarray(abs(R).sum(axis=1)).ravel() * 1.05 + 1e-3)).tocsr()
+        M.sort_indices()
+        A = oc.Csr.from_scipy(M)
+    elif aniso:
+        T = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(n, n))
+        I = sp.identity(n)
+        M = (sp.kron(sp.kron(I, I), T) + sp.kron(sp.kron(I, T), I) + aniso * sp.kron(sp.kron(T, I), I)).tocsr()
+        M.sort_indices()
+        A = oc.Csr.from_scipy(M)
+    else:
+        A, _ = oc.Csr.laplace(n, n, n, stencil)
+        M = A.to_scipy().tocsr()
+        M.sort_indices()
+    N = M.shape[0]
+    S = _strength_pattern(M)
+    first, row = _rs_first_pass(S)
+    both = _rs_second_pass(first, row)
+    # one part: types 11 (first pass) and 1 (both passes); 6 (Falgout) and 10 (HMIS) leave nothing to CLJP / PMIS there
+    assert np.array_equal(_natural_cf(oc.Amg(A, oc.default_params(coarsen_type=11))), np.where(first == -3, -1, first))
+    got1 = _natural_cf(oc.Amg(A, oc.default_params(coarsen_type=1)))
+    assert np.array_equal(got1, np.where(both == -3, -1, both))
+    assert np.array_equal(_natural_cf(oc.Amg(A, oc.default_params(coarsen_type=6))), got1)
+    if stencil == 0:
+        assert not np.array_equal(first, both)  # (the second pass has work to do on the unstructured operators)
+    # several parts: the two passes on every part's own graph, then CLJP on the boundary from the interior verdicts
+    ps = np.array([0, N // 3 + 5, 2 * N // 3 - 7, N])
+    part = np.searchsorted(ps, np.arange(N), side="right") - 1
+    per_part = np.zeros(N, dtype=int)
+    for q in range(3):
+        lo, hi = ps[q], ps[q + 1]
+        Sq = S[lo:hi][:, lo:hi].tocsr()
+        fq, rq = _rs_first_pass(Sq)
+        per_part[lo:hi] = _rs_second_pass(fq, rq)
+    per_part = np.where(per_part == -3, -1, per_part)
+    got = _natural_cf(oc.Amg(A, oc.default_params(coarsen_type=1, part_starts=ps, redundant_rows=0)))
+    assert np.array_equal(got, per_part)
+    falgout = _cljp_on_boundary(S, per_part, part)
+    got6 = _natural_cf(oc.Amg(A, oc.default_params(coarsen_type=6, part_starts=ps, redundant_rows=0)))
+    assert np.array_equal(got6, falgout), int((got6 != falgout).sum())
+    assert (got6 != per_part).any()  # (the boundary was decided anew)
+
