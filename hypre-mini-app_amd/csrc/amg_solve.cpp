@@ -387,27 +387,80 @@ void BoomerAMG::cycle(int level, bool u_is_zero) {
 }
 
 // tabulate the map f -> u of cycle(lt, true) by cycling the unit vectors (row j of Bt = column j of the map)
+namespace {
+// HIP events recorded inside a captured graph would be replayed into the same event objects: with any profiling class
+// switched on the tabulation takes the plain launches
+bool any_profile_class_on() {
+  KernelTimer *t = ctx().timer;
+  if (!t) return false;
+  for (int i = 0; i < k::PROF_COUNT; i++)
+    if (t->enabled[i]) return true;
+  return false;
+}
+}  // namespace
+
 void BoomerAMG::tabulate_cycle(int lt, DVec<double> &Bt) {
   AmgLevel &Lv = L[(size_t)lt];
   const int n = Lv.n;
   hipStream_t s = ctx().stream;
   Bt.alloc((size_t)n * (size_t)n);
-  DVec<double> one(1);
-  const double h_one = 1.0;
-  MI_HIP(hipMemcpyAsync(one.p, &h_one, sizeof(double), hipMemcpyHostToDevice, s));
   double *own_f = Lv.f.p;
   DVec<double> e((size_t)n);
+  DVec<int> col(1);
   zero_on_stream(e.p, (size_t)n * sizeof(double));
+  MI_HIP(hipMemsetAsync(col.p, 0, sizeof(int), s));
   Lv.f.p = e.p;
+  // One column = unit vector, (fill,) cycle, store: ~10 launches of a few microseconds each, n columns -- tens of
+  // thousands of dispatches whose cost is the host's launch path (0.7 s of a 5.3 s setup at 512^3, and the loop
+  // rocprofv3's counter collection fell over in).  The column number lives on the device, so the sequence
+  // is the same for every column: it is captured once as a HIP graph and replayed (MI_HYPRE_TAIL_GRAPH=0, or a capture
+  // that fails: plain launches).  The first column always runs plainly -- anything a level allocates on first use
+  // happens there, outside the capture.
+  auto one_column = [&]() {
+    k::tab_unit(e.p, col.p, s);
+    if (!zero_cycle_ignores_u(lt)) k::fill(Lv.u.p, n, 0.0, s);
+    cycle(lt, true);
+    k::tab_store(Bt.p, Lv.u.p, n, col.p, s);
+  };
+  static const bool want_graph = !(getenv("MI_HYPRE_TAIL_GRAPH") && atoi(getenv("MI_HYPRE_TAIL_GRAPH")) == 0);
   try {
-    for (int j = 0; j < n; j++) {
-      MI_HIP(hipMemcpyAsync(e.p + j, one.p, sizeof(double), hipMemcpyDeviceToDevice, s));
-      if (!zero_cycle_ignores_u(lt)) k::fill(Lv.u.p, n, 0.0, s);
-      cycle(lt, true);
-      MI_HIP(hipMemcpyAsync(Bt.p + (size_t)j * (size_t)n, Lv.u.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
-      MI_HIP(hipMemsetAsync(e.p + j, 0, sizeof(double), s));
+    int done = 0;
+    if (n > 0) {
+      one_column();
+      done = 1;
+    }
+    hipGraphExec_t exec = nullptr;
+    if (want_graph && n > 2 && !any_profile_class_on()) {
+      MI_HIP(hipStreamSynchronize(s));
+      hipGraph_t graph = nullptr;
+      bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+      if (ok) {
+        try {
+          one_column();
+        } catch (...) {
+          ok = false;
+        }
+        if (hipStreamEndCapture(s, &graph) != hipSuccess || !graph) ok = false;
+      }
+      if (ok && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+        ok = false;
+        exec = nullptr;
+      }
+      if (graph) (void)hipGraphDestroy(graph);
+      if (!ok) {
+        (void)hipGetLastError();
+        exec = nullptr;
+        // (the capture recorded no work: the column counter still says `done`)
+      }
+    }
+    for (int j = done; j < n; j++) {
+      if (exec)
+        MI_HIP(hipGraphLaunch(exec, s));
+      else
+        one_column();
     }
     MI_HIP(hipStreamSynchronize(s));
+    if (exec) (void)hipGraphExecDestroy(exec);
   } catch (...) {
     Lv.f.p = own_f;
     throw;

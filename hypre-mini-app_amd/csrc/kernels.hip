@@ -2069,6 +2069,31 @@ void scale_inv_sqrt_dev(const double *sumsq_dev, double *x, int n, hipStream_t s
   hipLaunchKernelGGL(scale_k<1>, dim3(vec_grid(n)), dim3(256), 0, s, sumsq_dev, 1.0, x, n);
   MI_HIP(hipGetLastError());
 }
+// Tabulation of a linear map column by column inside ONE captured graph (BoomerAMG::tabulate_cycle): the column number
+// lives in device memory, so that every replay of the graph is the same sequence of launches.
+//   tab_unit_k : e = unit vector number *col (the previous column's 1 is cleared)
+//   tab_store_k: column *col of Bt = u, then ++*col (one workgroup: n is at most a few thousand)
+__global__ __launch_bounds__(64) void tab_unit_k(double *__restrict__ e, const int *__restrict__ col) {
+  if (threadIdx.x == 0) {
+    const int j = *col;
+    if (j > 0) e[j - 1] = 0.0;
+    e[j] = 1.0;
+  }
+}
+__global__ __launch_bounds__(256) void tab_store_k(double *__restrict__ Bt, const double *__restrict__ u, int n, int *__restrict__ col) {
+  const int j = *col;
+  for (int i = threadIdx.x; i < n; i += 256) Bt[(size_t)j * (size_t)n + i] = u[i];
+  __syncthreads();
+  if (threadIdx.x == 0) *col = j + 1;
+}
+void tab_unit(double *e, const int *col, hipStream_t s) {
+  hipLaunchKernelGGL(tab_unit_k, dim3(1), dim3(64), 0, s, e, col);
+  MI_HIP(hipGetLastError());
+}
+void tab_store(double *Bt, const double *u, int n, int *col, hipStream_t s) {
+  hipLaunchKernelGGL(tab_store_k, dim3(1), dim3(256), 0, s, Bt, u, n, col);
+  MI_HIP(hipGetLastError());
+}
 void fill(double *x, int n, double v, hipStream_t s) {
   if (n == 0) return;
   hipLaunchKernelGGL(fill_k, dim3(vec_grid(n)), dim3(256), 0, s, x, n, v);

@@ -193,6 +193,9 @@ void ipc_poison(double *buf, int count, const int *error_flag, hipStream_t s);
 
 // IJ helpers
 void scatter_set(double *x, const int *idx, const double *vals, int n, hipStream_t s);
+// column-by-column tabulation inside a captured graph (see tab_unit_k / tab_store_k)
+void tab_unit(double *e, const int *col, hipStream_t s);
+void tab_store(double *Bt, const double *u, int n, int *col, hipStream_t s);
 void scatter_add(double *x, const int *idx, const double *vals, int n, hipStream_t s);
 
 }  // namespace k

@@ -21,12 +21,22 @@ elif [ "$mode" = setup ]; then
     python3 "$REPO/bench.py" --steps 1 --warmup 0 --no-cpu --no-general --sideline-non-galerkin 0 > "$REPO/gpurun_out/prof_setup.log" 2>&1
   python3 "$REPO/profiles/setup_split.py" "$REPO/gpurun_out/prof_setup" > "$REPO/gpurun_out/setup_split_512.txt" 2>&1 || true
 else
-  # counter passes: without the collapsed coarse tail -- tabulating it means ~50 000 tiny dispatches at Setup, and
-  # rocprofv3's counter collection crashed in that loop (segmentation fault inside its dispatch interception); the
-  # level-0 kernels whose traffic is measured here are the same either way
-  export MI_HYPRE_DENSE_TAIL_ROWS=0
+  # counter passes.  Round 3 ran them WITHOUT the collapsed coarse tail: tabulating it means ~50 000 tiny dispatches at
+  # Setup, and rocprofv3's counter collection crashed in that loop (segmentation fault).  Round 4: the first
+  # pass is tried with the default tail; its outcome is recorded in gpurun_out/pmc_tail_attempt.txt (exit code, the tail of
+  # the log) and the passes that are kept run without the tail only if that attempt failed -- the level-0 kernels whose
+  # traffic is measured are the same either way.
+  set +e
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$REPO/gpurun_out/prof_fetch" -- \
     python3 "$REPO/bench.py" --steps 1 --warmup 0 --no-cpu ${PMC_BENCH_ARGS:---no-general} > "$REPO/gpurun_out/prof_fetch.log" 2>&1
+  rc=$?
+  { echo "rocprofv3 --pmc FETCH_SIZE with the default collapsed tail: exit code $rc"; grep -v "^[EW]2026" "$REPO/gpurun_out/prof_fetch.log" | tail -15; } > "$REPO/gpurun_out/pmc_tail_attempt.txt"
+  set -e
+  if [ $rc -ne 0 ]; then
+    export MI_HYPRE_DENSE_TAIL_ROWS=0
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$REPO/gpurun_out/prof_fetch" -- \
+      python3 "$REPO/bench.py" --steps 1 --warmup 0 --no-cpu ${PMC_BENCH_ARGS:---no-general} > "$REPO/gpurun_out/prof_fetch.log" 2>&1
+  fi
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$REPO/gpurun_out/prof_write" -- \
     python3 "$REPO/bench.py" --steps 1 --warmup 0 --no-cpu ${PMC_BENCH_ARGS:---no-general} > "$REPO/gpurun_out/prof_write.log" 2>&1
   # the same two passes for a general operator (value dictionary off: 8-byte values in the level-0 stream)
