@@ -2596,6 +2596,22 @@ void BoomerAMG::setup_device() {
     printf("   device arena (since the process started): %.1f GiB mapped (peak %.1f), %.1f GiB in use (peak %.1f); %lld chunks mapped, %.2f s inside "
            "hipMemCreate/Map (grow-ahead thread), requests waited %.2f s for it; %lld stream drains before a reuse, %.2f s\n",
            mp / 1073741824.0, pm / 1073741824.0, iu / 1073741824.0, pu / 1073741824.0, gr, tg, tw, dr, td);
+    printf("   block-coded column lists (tiles that keep a 4-byte list / tiles; most 1024-id blocks in a tile):");
+    for (size_t li = 0; li < L.size() && li < 6; li++) {
+      const AmgLevel &Lv = L[li];
+      if (!Lv.A->d_diag.xcache) continue;
+      auto show = [](const char *nm, const DevCSR &M) {
+        printf(" %s %d/%d (%d)%s", nm, M.ucode_wide_tiles, M.nblocks, M.ucode_max_blocks, M.ucode.p ? "" : " off");
+      };
+      printf(" L%zu[", li);
+      show("A", Lv.A->d_diag);
+      if (Lv.has_Az) show("Az", Lv.Az);
+      if (Lv.has_Ar) show("Ar", Lv.Ar);
+      if (Lv.Pm && Lv.Pm->d_diag.xcache) show("P", Lv.Pm->d_diag);
+      if (Lv.Rm && Lv.Rm->d_diag.xcache) show("R", Lv.Rm->d_diag);
+      printf("]");
+    }
+    printf("\n");
     printf("   value dictionaries (1-byte value stream):");
     for (size_t li = 0; li < L.size(); li++) {
       const AmgLevel &Lv = L[li];

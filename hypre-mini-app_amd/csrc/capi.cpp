@@ -739,6 +739,20 @@ static void warn_ignored(const char *key, double v) {
   if (current_comm().rank == 0)
     fprintf(stderr, "mi_hypre BoomerAMG: %s = %g is accepted but NOT implemented; the setting has no effect\n", key, v);
 }
+// non_galerkin_tol / non_galerkin_level_tols (src/HypreSystem.cpp:161-176) select THIS library's drop-and-lump rule
+// (DESIGN.md section 3), not the algorithm of HYPRE's par_nongalerkin.c, which is not restated (its source is not in the
+// tree and the recollection of it is not reliable enough to claim it): the same YAML key builds another hierarchy than
+// libHYPRE would.  Said once, on stderr, whatever print_level -- a user of the reference's inputs should not have to read
+// DESIGN.md to learn it.
+static void note_non_galerkin_rule(double v) {
+  static bool said = false;
+  if (said || !(v > 0.0)) return;
+  said = true;
+  if (current_comm().rank == 0)
+    fprintf(stderr, "mi_hypre BoomerAMG: non-Galerkin tolerance %g: coarse operators are sparsified by this library's rule (an "
+                    "entry below tol * min(row maxima) is lumped onto the diagonal), NOT by HYPRE's par_nongalerkin.c algorithm -- "
+                    "hierarchy and iteration counts differ from libHYPRE's for this setting\n", v);
+}
 #define AMG_SET(NAME, TYPE, STMT)                               \
   HYPRE_Int HYPRE_BoomerAMGSet##NAME(HYPRE_Solver solver, TYPE v) { \
     API_BEGIN                                                   \
@@ -775,7 +789,7 @@ AMG_SET(AggTruncFactor, HYPRE_Real, p.agg_trunc_factor = v)
 AMG_SET(KeepTranspose, HYPRE_Int, p.keep_transpose = v)
 AMG_SET(RAP2, HYPRE_Int, p.rap2 = v)
 AMG_SET(Variant, HYPRE_Int, if (v != 0) warn_ignored("variant", v))
-AMG_SET(NonGalerkinTol, HYPRE_Real, if (v < 0.0 || v > 1.0) fail(HYPRE_ERROR_ARG, "non_galerkin_tol must be in [0, 1]"); p.non_galerkin_tol = v)
+AMG_SET(NonGalerkinTol, HYPRE_Real, if (v < 0.0 || v > 1.0) fail(HYPRE_ERROR_ARG, "non_galerkin_tol must be in [0, 1]"); p.non_galerkin_tol = v; note_non_galerkin_rule(v))
 AMG_SET(SmoothType, HYPRE_Int, p.smooth_type = v)  /* acts through smooth_num_levels > 0; checked at Setup */
 AMG_SET(SmoothNumLevels, HYPRE_Int, p.smooth_num_levels = v)
 AMG_SET(ILUType, HYPRE_Int, p.ilu_type = v)
@@ -799,6 +813,7 @@ HYPRE_Int HYPRE_BoomerAMGSetLevelNonGalerkinTol(HYPRE_Solver solver, HYPRE_Real 
   if (level < 0 || level > 1000) fail(HYPRE_ERROR_ARG, "non_galerkin_level_tols: bad level");
   if ((int)p.non_galerkin_level_tol.size() <= level) p.non_galerkin_level_tol.resize((size_t)level + 1, -1.0);
   p.non_galerkin_level_tol[(size_t)level] = tol;
+  note_non_galerkin_rule(tol);
   API_END
 }
 HYPRE_Int HYPRE_BoomerAMGSetCycleRelaxType(HYPRE_Solver solver, HYPRE_Int relax_type, HYPRE_Int k) {

@@ -218,7 +218,9 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_xc(int nb, int xchunk, cons
   constexpr int NU = TILE / BLOCK;
   int uc[NU];
   int myblock = 0;
-  if (ucode) {  // (uniform) block-coded list: 6-bit selector of one of the tile's <= 64 column blocks + 10-bit offset
+  const bool coded = ucode && d1.w >= 0;  // (uniform per tile) a tile with more than 64 blocks keeps a 4-byte list, in the side list
+  if (ucode && !coded) ucols += (-d1.w - 1) - u0;
+  if (coded) {  // block-coded list: 6-bit selector of one of the tile's <= 64 column blocks + 10-bit offset
     myblock = LIST_LOAD(ubase + d1.w + (tid & 63));  // (padded: the 64 ints behind any tile's first block exist)
 #pragma unroll
     for (int q = 0; q < NU; q++) {
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_xc(int nb, int xchunk, cons
   // the gathers: ALL of them in flight before the first LDS write, and before the loads below that depend on each other.
   // (Written as `if (k < nu) xs[k] = x[uc[q]]`, every load sat in a branch of its own with its wait and its LDS write:
   // up to eight serial round trips per tile.  Lanes beyond the list read x[0] -- uc is 0 there -- one cached sector.)
-  if (ucode) {  // (after the stream loads have been issued: the codes are waited for here)
+  if (coded) {  // (after the stream loads have been issued: the codes are waited for here)
 #pragma unroll
     for (int q = 0; q < NU; q++) uc[q] = (__shfl(myblock, uc[q] >> 10, 64) << 10) | (uc[q] & 1023);
   }
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(256) void tile_desc_k(int nb, const int *__restrict
   const long long base = ia[r0], len = ia[r1] - base;
   // a single row longer than any tile (>= 2^31 entries it cannot be: such rows do not exist) keeps its true length
   d[0] = make_int4(r0, r1, (int)(unsigned)(base & 0xffffffffLL), (int)(len > 0x7fffffffLL ? 0x7fffffffLL : len));
-  d[1] = make_int4(u0, u1 - u0, (int)(base >> 32), bptr ? (int)bptr[b] : 0);
+  d[1] = make_int4(u0, u1 - u0, (int)(base >> 32), bptr ? (int)bptr[b] : 0);  // (>= 0: coded tile; < 0: -(offset in the side list) - 1)
 }
 
 // Block-coded column lists (DevCSR::ucode / ubase): one wave per tile walks the tile's sorted unique columns in steps of
@@ -362,11 +364,16 @@ template <bool FILL>
 __global__ __launch_bounds__(256) void ucode_blocks_k(int ntiles, const int *__restrict__ uptr, const int *__restrict__ ucols,
                                                       int *__restrict__ nblk, const long long *__restrict__ bptr,
                                                       int *__restrict__ ubase, unsigned short *__restrict__ ucode,
-                                                      int *__restrict__ maxblk) {
+                                                      int *__restrict__ maxblk, int *__restrict__ wide_list) {
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (tile >= ntiles) return;
   const int u0 = uptr[tile], u1 = uptr[tile + 1];
+  if (FILL && bptr[tile] < 0) {  // a tile with more than 64 blocks: its 4-byte list moves to the compact side list
+    const long long w0 = -bptr[tile] - 1;
+    for (int k = u0 + lane; k < u1; k += 64) wide_list[w0 + (k - u0)] = ucols[k];
+    return;
+  }
   int run = 0, prev = -1;
   for (int k0 = u0; k0 < u1; k0 += 64) {
     const int k = k0 + lane;
@@ -869,7 +876,9 @@ __global__ __launch_bounds__(BLOCK, 2048 / BLOCK) void gs_tile_k(int blk0, int n
   constexpr int NU = TILE / BLOCK;
   int ucid[NU];
   int myblock = 0;
-  if (!all_zero && ucode) {  // (uniform) block-coded list, see spmv_stream_xc
+  const bool coded = ucode && d1.w >= 0;  // (uniform per tile, see spmv_stream_xc)
+  if (ucode && !coded) ucols += (-d1.w - 1) - u0;
+  if (!all_zero && coded) {
     myblock = LIST_LOAD(ubase + d1.w + (tid & 63));
 #pragma unroll
     for (int q = 0; q < NU; q++) {
@@ -915,7 +924,7 @@ __global__ __launch_bounds__(BLOCK, 2048 / BLOCK) void gs_tile_k(int blk0, int n
   // batches -- the first covers tiles of up to 4 * BLOCK unique columns, i.e. nearly all of them.
   constexpr int GB = VAL8 ? NU : NU / 2;
   double xv[GB];
-  if (!all_zero && ucode) {
+  if (!all_zero && coded) {
 #pragma unroll
     for (int q = 0; q < NU; q++) ucid[q] = (__shfl(myblock, ucid[q] >> 10, 64) << 10) | (ucid[q] & 1023);
   }
@@ -1747,40 +1756,55 @@ void build_value_dictionary(DevCSR &A, hipStream_t s) {
   A.val8 = true;
 }
 
-// block-coded column lists of an x-cache operator (DevCSR::ucode / ubase) from its 4-byte lists, which are released when
-// every tile fits (MI_HYPRE_UCODE=0: keep the 4-byte lists); bptr: per tile the start of its blocks in ubase
+// block-coded column lists of an x-cache operator (DevCSR::ucode / ubase) from its 4-byte lists (MI_HYPRE_UCODE=0: keep
+// those).  Per tile: at most 64 blocks of 1024 ids -> coded, bptr[tile] = start of its blocks in ubase; more (tiles at the
+// seams of the internal numbering's cells and segments: a few per cent at 512^3) -> the tile keeps a 4-byte list, moved to a
+// compact side list (A.ucols afterwards), bptr[tile] = -(its offset there) - 1.
 static void build_block_coded_lists(DevCSR &A, DVec<long long> &bptr, hipStream_t s) {
   A.ucode.release();
   A.ubase.release();
   A.n_unique = (long long)A.ucols.n;
-  static const bool on = !(getenv("MI_HYPRE_UCODE") && atoi(getenv("MI_HYPRE_UCODE")) == 0);
+  A.ucode_max_blocks = 0;
+  A.ucode_wide_tiles = 0;
+  // OFF by default: measured at 512^3 (profiles/r04_ab_block_coded_lists.txt) the decode -- a wave-wide block table and one
+  // ds_bpermute per column between the list load and the gather -- costs the tile Gauss-Seidel kernel and the residual SpMVs
+  // of levels 1-2 more (+3..12 %) than the 2 bytes per unique column save; only the level-0 dictionary SpMV gains (-5 %)
+  static const bool on = getenv("MI_HYPRE_UCODE") && atoi(getenv("MI_HYPRE_UCODE")) != 0;
   if (!on || !A.xcache || A.nblocks <= 0 || !A.uptr.p || A.ucols.n == 0) return;
   const int nt = A.nblocks;
   DVec<int> nblk((size_t)nt), maxblk(1);
   MI_HIP(hipMemsetAsync(maxblk.p, 0, sizeof(int), s));
   const dim3 grid((unsigned)((nt + 3) / 4));
-  hipLaunchKernelGGL(ucode_blocks_k<false>, grid, dim3(256), 0, s, nt, A.uptr.p, A.ucols.p, nblk.p, nullptr, nullptr, nullptr, maxblk.p);
+  hipLaunchKernelGGL(ucode_blocks_k<false>, grid, dim3(256), 0, s, nt, A.uptr.p, A.ucols.p, nblk.p, nullptr, nullptr, nullptr, maxblk.p, nullptr);
   MI_HIP(hipGetLastError());
-  int mx = 0;
-  d2h(&mx, maxblk.p, sizeof(int), s);
-  if (mx > 64) return;  // a tile whose columns spread over more than 64 blocks of 1024 ids: this operator keeps the 4-byte lists
-  bptr.alloc((size_t)nt + 1);
-  {
-    // exclusive scan of the tiles' block counts (tiles: at most a few hundred thousand -- one workgroup's worth of work;
-    // done on the host through the pinned staging buffer)
-    std::vector<int> hn = nblk.to_host();
-    std::vector<long long> hp((size_t)nt + 1, 0);
-    for (int t = 0; t < nt; t++) hp[(size_t)t + 1] = hp[(size_t)t] + hn[(size_t)t];
-    MI_HIP(hipMemcpyAsync(bptr.p, hp.data(), ((size_t)nt + 1) * sizeof(long long), hipMemcpyHostToDevice, s));
-    MI_HIP(hipStreamSynchronize(s));
-    A.ubase.alloc((size_t)hp[(size_t)nt], 64);  // (a wave loads 64 ints from a tile's first block on: padded)
-    MI_HIP(hipMemsetAsync(A.ubase.p, 0, ((size_t)hp[(size_t)nt] + 64) * sizeof(int), s));
+  MI_HIP(hipStreamSynchronize(s));  // (DVec::to_host copies on the null stream, which does not wait for this one)
+  const std::vector<int> hn = nblk.to_host();   // (tiles: at most a few hundred thousand; through the pinned staging buffer)
+  const std::vector<int> hu = A.uptr.to_host();
+  std::vector<long long> hp((size_t)nt + 1, 0);
+  long long nb_tot = 0, wide_tot = 0;
+  for (int t = 0; t < nt; t++) {
+    A.ucode_max_blocks = std::max(A.ucode_max_blocks, hn[(size_t)t]);
+    if (hn[(size_t)t] <= 64) {
+      hp[(size_t)t] = nb_tot;
+      nb_tot += hn[(size_t)t];
+    } else {
+      hp[(size_t)t] = -wide_tot - 1;
+      wide_tot += hu[(size_t)t + 1] - hu[(size_t)t];
+      A.ucode_wide_tiles++;
+    }
   }
+  if (wide_tot * 2 > (long long)A.ucols.n) return;  // mostly wide tiles: not worth two formats -- the 4-byte lists stay
+  bptr.alloc((size_t)nt + 1);
+  MI_HIP(hipMemcpyAsync(bptr.p, hp.data(), ((size_t)nt + 1) * sizeof(long long), hipMemcpyHostToDevice, s));
+  MI_HIP(hipStreamSynchronize(s));
+  A.ubase.alloc((size_t)nb_tot, 64);  // (a wave loads 64 ints from a tile's first block on: padded)
+  MI_HIP(hipMemsetAsync(A.ubase.p, 0, ((size_t)nb_tot + 64) * sizeof(int), s));
   A.ucode.alloc(A.ucols.n);
-  hipLaunchKernelGGL(ucode_blocks_k<true>, grid, dim3(256), 0, s, nt, A.uptr.p, A.ucols.p, nullptr, bptr.p, A.ubase.p, A.ucode.p, nullptr);
+  DVec<int> wide((size_t)wide_tot);
+  hipLaunchKernelGGL(ucode_blocks_k<true>, grid, dim3(256), 0, s, nt, A.uptr.p, A.ucols.p, nullptr, bptr.p, A.ubase.p, A.ucode.p, nullptr, wide.p);
   MI_HIP(hipGetLastError());
   MI_HIP(hipStreamSynchronize(s));
-  A.ucols.release();
+  A.ucols = std::move(wide);  // what is left of the 4-byte lists: the wide tiles'
 }
 
 void build_tile_desc(DevCSR &A, const long long *ia64, hipStream_t s) {

@@ -223,10 +223,13 @@ struct DevCSR {
   // a tile's rows and their neighbours live in a handful of cells of the internal numbering), so an id is a 6-bit
   // selector of one of <= 64 block numbers of the tile (`ubase`, loaded once per wave, read by lane shuffle) and a
   // 10-bit offset (`ucode`).  The lists were 1.7 of the 4.7 bytes a level-0 entry of the benchmark costs, and 1.07 of
-  // 11.1 on level 1.  An operator with a tile of more than 64 blocks keeps the 4-byte lists (`ucols`; ucode empty).
+  // 11.1 on level 1.  A TILE with more than 64 blocks keeps a 4-byte list (`ucols` then holds only those tiles' lists, one
+  // after the other; the tile descriptor's last word says which kind and where).
   DVec<unsigned short> ucode;
   DVec<int> ubase;
   long long n_unique = 0;  // total length of the tiles' column lists
+  int ucode_max_blocks = 0;  // most 1024-id blocks any tile's columns fall into
+  int ucode_wide_tiles = 0;  // tiles with more than 64 blocks: they keep a 4-byte list (in `ucols`, compact)
   DVec<unsigned short> lcol;
   // value dictionary (k::build_value_dictionary): operators with at most 256 distinct values (constant-coefficient
   // stencils such as the reference's own generator: 26 / -1, or 6 / -1) carry one byte per entry besides `a`; the

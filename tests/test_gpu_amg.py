@@ -802,7 +802,7 @@ def test_cycle_setters_after_setup_reach_the_collapsed_tail(mi, oc):
 def test_default_on_features_against_their_switches(n, stencil):
     """features that are on by default and change the path of every solve, each against its own switch, in a
     process of its own (the switches are read once): the device arena (MI_HYPRE_POOL 2) against the block cache (1) and
-    plain hipMalloc (0), skipped zero-fills, block-coded column lists, the polled Hessenberg column -- all bit for bit
+    plain hipMalloc (0), skipped zero-fills, the (optional) block-coded column lists, the polled Hessenberg column -- all bit for bit
     the same solve -- and the collapsed dense tail, which is the same operator in another summation order (same
     iteration count, history and solution to rounding)."""
     import json
@@ -821,7 +821,7 @@ def test_default_on_features_against_their_switches(n, stencil):
 
     ref = run()
     assert ref["levels"] >= 4 and ref["arena_mapped"] > 0
-    for env in ({"MI_HYPRE_POOL": 0}, {"MI_HYPRE_POOL": 1}, {"MI_HYPRE_SKIP_ZERO_FILL": 0}, {"MI_HYPRE_UCODE": 0},
+    for env in ({"MI_HYPRE_POOL": 0}, {"MI_HYPRE_POOL": 1}, {"MI_HYPRE_SKIP_ZERO_FILL": 0}, {"MI_HYPRE_UCODE": 1},
                 {"MI_HYPRE_GMRES_POLL": 0}, {"MI_HYPRE_ARENA_AHEAD": 0}):
         r = run(**env)
         assert r["iters"] == ref["iters"] and r["hist"] == ref["hist"] and r["x"] == ref["x"], env
