@@ -279,7 +279,13 @@ HYPRE_Int HYPRE_SetExecutionPolicy(HYPRE_ExecutionPolicy pol) {
 HYPRE_Int HYPRE_SetGPUMemoryPoolSize(HYPRE_Int, HYPRE_Int, HYPRE_Int, size_t) { return 0; }
 HYPRE_Int hypre_SetCubMemPoolSize(unsigned, unsigned, unsigned, size_t) { return 0; }
 HYPRE_Int HYPRE_SetUmpireDevicePoolName(const char *) { return 0; }
-HYPRE_Int HYPRE_SetUmpireDevicePoolSize(size_t) { return 0; }
+// the reference's device pool (umpire_device_pool_mbs, src/main.cpp:107-114): its initial size is what this library's arena
+// maps ahead of demand, in the background (runtime.cpp); before HYPRE_Init (no device yet) the call does nothing
+HYPRE_Int HYPRE_SetUmpireDevicePoolSize(size_t nbytes) {
+  API_BEGIN
+  if (ctx().inited) dev_arena_reserve(nbytes);
+  API_END
+}
 HYPRE_Int HYPRE_SetSpGemmUseVendor(HYPRE_Int) { return 0; }
 HYPRE_Int HYPRE_SetSpMVUseVendor(HYPRE_Int) { return 0; }
 HYPRE_Int HYPRE_SetSpTransUseVendor(HYPRE_Int) { return 0; }

@@ -52,6 +52,7 @@ void dev_free(void *p);
 void dev_pool_trim();
 void dev_pool_stats(long long *cached_bytes, long long *hits, long long *misses);
 void dev_arena_hint(size_t bytes_more);
+void dev_arena_reserve(size_t bytes_total);
 void dev_arena_stats(long long *mapped, long long *in_use, long long *peak_mapped, long long *peak_in_use);
 void dev_arena_times(double *t_grow, double *t_drain, long long *grown, long long *drains, double *t_wait = nullptr);
 

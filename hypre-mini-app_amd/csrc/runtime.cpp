@@ -579,6 +579,24 @@ void dev_pool_stats(long long *cached_bytes, long long *hits, long long *misses)
 
 // Expected growth, from whoever knows it (IJMatrixAssemble and BoomerAMGSetup: a multiple of the operator's bytes): the
 // grow-ahead thread maps up to in_use + bytes in the background, capped at half of what the device has free now.
+// HYPRE_SetUmpireDevicePoolSize (the reference's `umpire_device_pool_mbs`, /root/reference/src/main.cpp:107-114): the
+// initial size of the device pool = that many bytes of the arena mapped in the background from now on
+void dev_arena_reserve(size_t bytes_total) {
+  DevPool &P = pool();
+  P.init();
+  if (P.enabled != 2 || bytes_total == 0) return;
+  DevArena &A = arena();
+  std::unique_lock<std::mutex> g(A.m);
+  if (!A.init() || !A.grower_on) return;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+    (void)hipGetLastError();
+    return;
+  }
+  A.target = std::max(A.target, std::min(bytes_total, A.mapped + free_b / 2));
+  A.cv_work.notify_one();
+}
+
 void dev_arena_hint(size_t bytes_more) {
   DevPool &P = pool();
   P.init();
