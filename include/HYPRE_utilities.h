@@ -61,6 +61,8 @@ HYPRE_Int HYPRE_SetExecutionPolicy(HYPRE_ExecutionPolicy pol);
 HYPRE_Int HYPRE_SetGPUMemoryPoolSize(HYPRE_Int bin_growth, HYPRE_Int min_bin, HYPRE_Int max_bin, size_t max_bytes);
 HYPRE_Int hypre_SetCubMemPoolSize(unsigned bin_growth, unsigned min_bin, unsigned max_bin, size_t max_bytes);
 HYPRE_Int HYPRE_SetUmpireDevicePoolName(const char *name);
+/* src/main.cpp:107-114 (YAML `umpire_device_pool_mbs`): the initial size of the device pool -- this library's device
+ * arena maps that many bytes ahead of demand, in the background (after HYPRE_Init) */
 HYPRE_Int HYPRE_SetUmpireDevicePoolSize(size_t nbytes);
 HYPRE_Int HYPRE_SetSpGemmUseVendor(HYPRE_Int use_vendor);
 HYPRE_Int HYPRE_SetSpMVUseVendor(HYPRE_Int use_vendor);
