@@ -1735,7 +1735,9 @@ void BoomerAMG::setup_host(ParCSR &A0) {
   t_phase[5] = wall_time() - t_setup_start;
   host_ready = true;
   if (getenv("MI_HYPRE_SETUP_TIMING") && comm.rank == 0)
-    printf("mi_hypre host setup: strength %.2f  pmis %.2f  interp %.2f  galerkin %.2f  ordering/slicing %.2f  total %.2f s\n",
+    // (wall time per phase of the hierarchy build; on levels the device builds this is kernel time -- the split into
+    // device-busy and device-idle time comes from a trace: profiles/setup_split.py)
+    printf("mi_hypre hierarchy build (wall per phase): strength %.2f  pmis %.2f  interp %.2f  galerkin %.2f  ordering/slicing %.2f  total %.2f s\n",
            t_phase[0], t_phase[1], t_phase[2], t_phase[3], t_phase[4], t_phase[5]);
 }
 
@@ -2623,7 +2625,7 @@ void BoomerAMG::setup_device() {
   if (p.print_level > 0 && comm.rank == 0) {
     printf("mi_hypre BoomerAMG setup: %d levels, operator complexity %.3f, chunk %d, %.3f s\n", total_levels(),
            operator_complexity(), ch, setup_seconds);
-    printf("   host phases: strength %.2f  pmis %.2f  interp %.2f  galerkin %.2f  C-first ordering %.2f  (host total %.2f) s\n",
+    printf("   hierarchy build, wall per phase: strength %.2f  pmis %.2f  interp %.2f  galerkin %.2f  C-first ordering %.2f  (total %.2f) s\n",
            t_phase[0], t_phase[1], t_phase[2], t_phase[3], t_phase[4], t_phase[5]);
     for (int li = 0; li < total_levels(); li++) {
       int loc = 0;
