@@ -98,6 +98,15 @@ void parallel_for(int64_t n, const std::function<void(int64_t, int64_t, int)> &f
 
 void d2h(void *dst, const void *src, size_t bytes, hipStream_t s) {
   if (!bytes) return;
+  if (s == nullptr) {
+    // a copy on the null stream does not wait for the library's (non-blocking) streams: whoever downloads that way
+    // (DVec::to_host, LazyInts::host) means "what the kernels launched so far have produced"
+    Ctx &c = g_ctx;
+    if (c.inited) {
+      MI_HIP(hipStreamSynchronize(c.stream));
+      MI_HIP(hipStreamSynchronize(c.comm_stream));
+    }
+  }
   static std::mutex m;
   static char *stage = nullptr;
   constexpr size_t STAGE = (size_t)4 << 20;
