@@ -624,7 +624,7 @@ def main():
         # HBM traffic per launch comes from a separate rocprofv3 --pmc pass (the counters cannot be read from
         # inside this process): the newest recorded figure for this configuration, labelled as recorded
         def recorded_traffic(field):
-            for tname in ("traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
+            for tname in ("traffic_r04.json", "traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
                 tpath = os.path.join(ROOT, "profiles", tname)
                 if os.path.exists(tpath):
                     try:
