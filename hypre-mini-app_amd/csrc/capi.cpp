@@ -1323,6 +1323,90 @@ HYPRE_Int HYPRE_MI_BoomerAMGPoisonWorkVectors(HYPRE_Solver solver) {
   MI_HIP(hipStreamSynchronize(s));
   API_END
 }
+// test hook (tests/test_gpu_kernels.py): a seeded storm of allocations and releases of every size class through
+// dev_alloc / dev_free, every live block filled with its own byte pattern and checked before it is released -- two
+// blocks that overlap, a block handed out twice or a trim that unmaps live memory show up as a wrong byte (or a fault).
+// Returns the number of blocks that were verified; *peak_bytes = the most bytes live at once.
+HYPRE_Int HYPRE_MI_ArenaSelfTest(HYPRE_Int seed, HYPRE_Int rounds, HYPRE_BigInt max_block_bytes, HYPRE_BigInt *verified,
+                                 HYPRE_BigInt *peak_bytes) {
+  API_BEGIN
+  ensure_init();
+  struct Blk {
+    unsigned char *p;
+    size_t n;
+    unsigned char tag;
+  };
+  std::vector<Blk> live;
+  unsigned long long x = 88172645463325252ull ^ (unsigned long long)seed;
+  auto rnd = [&]() {
+    x ^= x << 13;
+    x ^= x >> 7;
+    x ^= x << 17;
+    return x;
+  };
+  long long ok = 0;
+  size_t cur = 0, peak = 0;
+  hipStream_t s = ctx().stream;
+  DVec<unsigned long long> dres(3);
+  auto differing = [&](const Blk &b, unsigned long long res[3]) {
+    const unsigned long long init[3] = {0ull, ~0ull, 0ull};
+    MI_HIP(hipMemcpyAsync(dres.p, init, sizeof(init), hipMemcpyHostToDevice, s));
+    k::bytes_differ(b.p, b.n, b.tag, dres.p, s);
+    d2h(res, dres.p, 3 * sizeof(unsigned long long), s);
+  };
+  auto check_and_free = [&](size_t idx) {
+    Blk b = live[idx];
+    live[idx] = live.back();
+    live.pop_back();
+    unsigned long long res[3];
+    differing(b, res);  // EVERY byte of the block
+    if (res[0])
+      fail(HYPRE_ERROR_GENERIC, "arena self-test: a live block was overwritten: " + std::to_string(res[0]) + " of " + std::to_string(b.n) +
+                                    " bytes differ, first at " + std::to_string(res[1]) + ", last at " + std::to_string(res[2]) +
+                                    "; block at arena offset " + std::to_string((unsigned long long)(b.p - (unsigned char *)nullptr) & 0xffffffffffull));
+    dev_free(b.p);
+    cur -= b.n;
+    ok++;
+  };
+  for (int r = 0; r < rounds; r++) {
+    const unsigned long long v = rnd();
+    const bool grow = live.empty() || (v & 3) != 0 || live.size() < 8;
+    if (grow && live.size() < 4096) {
+      // sizes spread over the classes: bytes .. max_block_bytes, log-uniform
+      const int bits = 1 + (int)(rnd() % 34);
+      size_t n = (size_t)(rnd() & ((1ull << bits) - 1)) + 1;
+      n = std::min<size_t>(n, (size_t)std::max<HYPRE_BigInt>(1, max_block_bytes));
+      Blk b{(unsigned char *)dev_alloc(n), n, (unsigned char)(1 + (rnd() % 250))};
+      for (const Blk &o : live)  // the allocator's own bookkeeping first: no two live blocks may intersect
+        if (b.p < o.p + o.n && o.p < b.p + b.n)
+          fail(HYPRE_ERROR_GENERIC, "arena self-test: the allocator handed out a block that intersects a live one (round " +
+                                        std::to_string(r) + ", " + std::to_string(n) + " bytes)");
+      if (getenv("MI_ARENA_TEST_OWN_FILL"))
+        k::fill_bytes(b.p, n, b.tag, s);
+      else
+        MI_HIP(hipMemsetAsync(b.p, b.tag, n, s));
+      if (getenv("MI_ARENA_TEST_VERIFY_FILL")) {  // (diagnosis: is the fill itself complete?)
+        unsigned long long res[3];
+        differing(b, res);
+        if (res[0])
+          fail(HYPRE_ERROR_GENERIC, "arena self-test: the fill of a fresh block is incomplete: " + std::to_string(res[0]) + " of " +
+                                        std::to_string(n) + " bytes, first " + std::to_string(res[1]) + ", last " + std::to_string(res[2]));
+      }
+      live.push_back(b);
+      cur += n;
+      peak = std::max(peak, cur);
+    } else {
+      check_and_free((size_t)(rnd() % live.size()));
+    }
+    if ((r & 255) == 255 && !getenv("MI_ARENA_TEST_NO_TRIM")) dev_pool_trim();  // unmap free chunks from the top in the middle of it all
+  }
+  MI_HIP(hipStreamSynchronize(s));
+  while (!live.empty()) check_and_free(live.size() - 1);
+  dev_pool_trim();
+  if (verified) *verified = ok;
+  if (peak_bytes) *peak_bytes = (HYPRE_BigInt)peak;
+  API_END
+}
 HYPRE_Int HYPRE_MI_SetValueDictionary(HYPRE_Int on) {
   API_BEGIN
   k::set_value_dictionary(on != 0);

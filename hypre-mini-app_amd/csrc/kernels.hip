@@ -2110,6 +2110,35 @@ __global__ __launch_bounds__(256) void tab_store_k(double *__restrict__ Bt, cons
   __syncthreads();
   if (threadIdx.x == 0) *col = j + 1;
 }
+// test support (HYPRE_MI_ArenaSelfTest): bytes of p[0..n) that differ from `tag`: their number and the first and last offset
+__global__ __launch_bounds__(256) void bytes_differ_k(const unsigned char *__restrict__ p, size_t n, unsigned char tag,
+                                                      unsigned long long *__restrict__ out) {
+  size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+  unsigned long long cnt = 0, first = ~0ull, last = 0;
+  for (; i < n; i += (size_t)gridDim.x * 256)
+    if (p[i] != tag) {
+      cnt++;
+      if (i < first) first = i;
+      if (i > last) last = i;
+    }
+  if (cnt) {
+    atomicAdd(out, cnt);
+    atomicMin(out + 1, first);
+    atomicMax(out + 2, last);
+  }
+}
+__global__ __launch_bounds__(256) void fill_bytes_k(unsigned char *__restrict__ p, size_t n, unsigned char tag) {
+  size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+  for (; i < n; i += (size_t)gridDim.x * 256) p[i] = tag;
+}
+void fill_bytes(unsigned char *p, size_t n, unsigned char tag, hipStream_t s) {
+  hipLaunchKernelGGL(fill_bytes_k, dim3(2048), dim3(256), 0, s, p, n, tag);
+  MI_HIP(hipGetLastError());
+}
+void bytes_differ(const unsigned char *p, size_t n, unsigned char tag, unsigned long long *out3, hipStream_t s) {
+  hipLaunchKernelGGL(bytes_differ_k, dim3(2048), dim3(256), 0, s, p, n, tag, out3);
+  MI_HIP(hipGetLastError());
+}
 void tab_unit(double *e, const int *col, hipStream_t s) {
   hipLaunchKernelGGL(tab_unit_k, dim3(1), dim3(64), 0, s, e, col);
   MI_HIP(hipGetLastError());

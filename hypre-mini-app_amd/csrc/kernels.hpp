@@ -194,6 +194,8 @@ void ipc_poison(double *buf, int count, const int *error_flag, hipStream_t s);
 // IJ helpers
 void scatter_set(double *x, const int *idx, const double *vals, int n, hipStream_t s);
 // column-by-column tabulation inside a captured graph (see tab_unit_k / tab_store_k)
+void bytes_differ(const unsigned char *p, size_t n, unsigned char tag, unsigned long long *out3, hipStream_t s);
+void fill_bytes(unsigned char *p, size_t n, unsigned char tag, hipStream_t s);
 void tab_unit(double *e, const int *col, hipStream_t s);
 void tab_store(double *Bt, const double *u, int n, int *col, hipStream_t s);
 void scatter_add(double *x, const int *idx, const double *vals, int n, hipStream_t s);

@@ -257,9 +257,19 @@ struct DevArena {
   std::mutex m;
   int state = 0;  // 0 untried, 1 working, -1 unavailable
   char *base = nullptr;
-  size_t va_size = 0, chunk = 0, mapped = 0;
+  // `top`: where the next chunk is mapped.  It only ever rises: an address range that was unmapped (trim) is NEVER mapped
+  // again -- on this stack (ROCm 7.2, gfx950) kernels that write a range which was unmapped and mapped onto new physical
+  // memory lose part of their stores (stale translations: profiles/debug/vmm_remap_probe.cpp, 9 of 40 fill / verify
+  // cycles incomplete, with hipMemsetAsync and with a plain kernel, with and without a device synchronisation after the
+  // unmap; profiles/debug/vmm_burn_probe.cpp: 0 of 59 when the addresses are not reused).  Address space is cheap (8 TiB
+  // reserved), so trimmed ranges are simply abandoned.  `mapped` = bytes mapped now.
+  size_t va_size = 0, chunk = 0, top = 0, mapped = 0;
   int device = 0;
-  std::vector<hipMemGenericAllocationHandle_t> handles;  // one per mapped chunk, bottom to top
+  struct Chunk {
+    size_t off;
+    hipMemGenericAllocationHandle_t h;
+  };
+  std::vector<Chunk> handles;  // mapped chunks, ascending offsets
   struct Free {
     size_t size;
     unsigned long long epoch;  // newest release that went into this range
@@ -273,7 +283,7 @@ struct DevArena {
   double t_grow = 0.0, t_drain = 0.0;  // seconds inside hipMemCreate / Map / SetAccess, and waiting for the streams
   double t_wait = 0.0;                 // seconds an allocation waited for the grow-ahead thread
   // Grow-ahead thread: where the driver has to clear the memory first (30 ms per GiB, see above) a chunk is worth
-  // having BEFORE a request needs it.  The thread keeps `headroom()` bytes of mapped, free space at the top; a request
+  // having BEFORE a request needs it.  The thread keeps `headroom()` bytes of mapped, free space in the arena; a request
   // that does not fit wakes it and waits for chunks (the only writer of `mapped` is then the thread).  MI_HYPRE_ARENA_AHEAD=0:
   // no thread, growth inside the request.
   std::thread grower;
@@ -284,7 +294,7 @@ struct DevArena {
   size_t top_free() const {
     if (free_by_off.empty()) return 0;
     auto last = std::prev(free_by_off.end());
-    return last->first + last->second.size == mapped ? last->second.size : 0;
+    return last->first + last->second.size == top ? last->second.size : 0;
   }
   size_t headroom() const {
     static const double gb = getenv("MI_HYPRE_ARENA_AHEAD_GB") ? atof(getenv("MI_HYPRE_ARENA_AHEAD_GB")) : 16.0;
@@ -310,12 +320,15 @@ struct DevArena {
     chunk = (want_chunk + gran - 1) / gran * gran;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = (size_t)288 << 30;
-    va_size = ((2 * total_b + chunk - 1) / chunk + 1) * chunk;  // address space is free: twice the device's memory
+    // address space is free, and trimmed ranges are abandoned, not reused: 8 TiB (then 2 TiB, then 4x the device's memory)
     void *b = nullptr;
-    if (hipMemAddressReserve(&b, va_size, 0, nullptr, 0) != hipSuccess || !b) {
+    for (size_t want_va : {(size_t)8 << 40, (size_t)2 << 40, 4 * total_b}) {
+      va_size = ((want_va + chunk - 1) / chunk) * chunk;
+      if (hipMemAddressReserve(&b, va_size, 0, nullptr, 0) == hipSuccess && b) break;
       (void)hipGetLastError();
-      return false;
+      b = nullptr;
     }
+    if (!b) return false;
     base = (char *)b;
     state = 1;
     if (!(getenv("MI_HYPRE_ARENA_AHEAD") && atoi(getenv("MI_HYPRE_ARENA_AHEAD")) == 0)) {
@@ -359,10 +372,10 @@ struct DevArena {
     (void)hipSetDevice(device);
     std::unique_lock<std::mutex> lk(m);
     for (;;) {
-      cv_work.wait(lk, [this] { return grower_stop || (!paused && !oom && (demand > 0 || mapped < target || (in_use > 0 && top_free() < headroom()))); });
+      cv_work.wait(lk, [this] { return grower_stop || (!paused && !oom && (demand > 0 || mapped < target || (in_use > 0 && mapped - in_use < headroom()))); });
       if (grower_stop) return;
       grower_busy = true;
-      const size_t at = mapped;
+      const size_t at = top;
       lk.unlock();
       const double t0 = wall_time();
       const bool ok = map_one(at);
@@ -371,7 +384,8 @@ struct DevArena {
       grower_busy = false;
       t_grow += dt;
       if (ok) {
-        handles.push_back(pending_handle);
+        handles.push_back(Chunk{at, pending_handle});
+        top += chunk;
         mapped += chunk;
         put_free(at, chunk, 0);
         peak_mapped = std::max(peak_mapped, mapped);
@@ -416,34 +430,35 @@ struct DevArena {
     hipMemAccessDesc acc = {};
     acc.location = prop.location;
     acc.flags = hipMemAccessFlagsProtReadWrite;
-    const size_t old_mapped = mapped;
+    const size_t old_top = top;
     const double tg0 = wall_time();
     for (size_t q = 0; q < n; q++) {
-      if (mapped + chunk > va_size) break;
+      if (top + chunk > va_size) break;
       hipMemGenericAllocationHandle_t h;
       if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) {
         (void)hipGetLastError();
         break;
       }
-      if (hipMemMap(base + mapped, chunk, 0, h, 0) != hipSuccess) {
+      if (hipMemMap(base + top, chunk, 0, h, 0) != hipSuccess) {
         (void)hipGetLastError();
         (void)hipMemRelease(h);
         break;
       }
-      if (hipMemSetAccess(base + mapped, chunk, &acc, 1) != hipSuccess) {
+      if (hipMemSetAccess(base + top, chunk, &acc, 1) != hipSuccess) {
         (void)hipGetLastError();
-        (void)hipMemUnmap(base + mapped, chunk);
+        (void)hipMemUnmap(base + top, chunk);
         (void)hipMemRelease(h);
         break;
       }
-      handles.push_back(h);
+      handles.push_back(Chunk{top, h});
+      top += chunk;
       mapped += chunk;
     }
-    if (mapped > old_mapped) put_free(old_mapped, mapped - old_mapped, 0);
+    if (top > old_top) put_free(old_top, top - old_top, 0);
     peak_mapped = std::max(peak_mapped, mapped);
     grown++;
     t_grow += wall_time() - tg0;
-    return mapped - old_mapped == n * chunk;
+    return top - old_top == n * chunk;
   }
   void *alloc(size_t bytes, std::unique_lock<std::mutex> &lk) {
     size_t want = bytes < 256 ? 256 : (bytes + 255) / 256 * 256;
@@ -491,7 +506,7 @@ struct DevArena {
       drains++;
       drained_epoch = e;
     }
-    if (grower_on && !oom && top_free() < headroom()) cv_work.notify_one();
+    if (grower_on && !oom && mapped - in_use < headroom()) cv_work.notify_one();  // (free bytes anywhere in the arena, not only at the top)
     return base + off;
   }
   bool owns(const void *p) const { return state > 0 && (const char *)p >= base && (const char *)p < base + va_size; }
@@ -518,25 +533,26 @@ struct DevArena {
     target = 0;
     if (free_by_off.empty()) return;
     auto last = std::prev(free_by_off.end());
-    if (last->first + last->second.size != mapped) return;
+    if (last->first + last->second.size != top) return;  // (what is free at the top; after a trim the top is "burned" and nothing is)
     const size_t start = last->first + std::min(keep, last->second.size);
-    const size_t new_mapped = (start + chunk - 1) / chunk * chunk;
-    if (new_mapped >= mapped) return;
+    const size_t new_end = (start + chunk - 1) / chunk * chunk;
+    if (new_end >= top) return;
     drain_library_streams();
     drained_epoch = release_epoch;
     const Free f = last->second;
     const size_t off = last->first;
     free_by_size.erase({f.size, off});
     free_by_off.erase(last);
-    while (mapped > new_mapped) {
-      mapped -= chunk;
-      (void)hipMemUnmap(base + mapped, chunk);
-      (void)hipMemRelease(handles.back());
+    // whole chunks in [new_end, top) go back to the driver; their ADDRESSES are abandoned (`top` stays where it is)
+    while (!handles.empty() && handles.back().off >= new_end) {
+      (void)hipMemUnmap(base + handles.back().off, chunk);
+      (void)hipMemRelease(handles.back().h);
       handles.pop_back();
+      mapped -= chunk;
     }
-    if (mapped > off) {
-      free_by_off[off] = Free{mapped - off, f.epoch};
-      free_by_size.insert({mapped - off, off});
+    if (new_end > off) {
+      free_by_off[off] = Free{new_end - off, f.epoch};
+      free_by_size.insert({new_end - off, off});
     }
   }
 };

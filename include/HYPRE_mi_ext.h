@@ -77,6 +77,10 @@ HYPRE_Int HYPRE_MI_SetZeroGuessMode(HYPRE_Int mode);
 /* test hook: fill every level's solution / scratch vectors with NaN (a zero-guess cycle that skips its zero-fills must
  * not read them) */
 HYPRE_Int HYPRE_MI_BoomerAMGPoisonWorkVectors(HYPRE_Solver solver);
+/* test hook: a seeded storm of device allocations / releases of every size through the library's allocator (arena, block
+ * cache or plain, whatever MI_HYPRE_POOL says), every block pattern-filled and checked before its release */
+HYPRE_Int HYPRE_MI_ArenaSelfTest(HYPRE_Int seed, HYPRE_Int rounds, HYPRE_BigInt max_block_bytes, HYPRE_BigInt *verified,
+                                 HYPRE_BigInt *peak_bytes);
 /* Value dictionary of operators with at most 256 distinct values (constant-coefficient stencils such as the
  * reference generator's 26 / -1, /root/reference/src/laplace_3d_weak_scaling.hpp:558,600): one byte per entry instead
  * of the 8-byte value in the matrix stream; same doubles, same results.  on = 0 keeps the plain stream -- what a
