@@ -57,6 +57,13 @@ __device__ __forceinline__ T nt_load(const T *p) {
 #define LIST_LOAD(p) (*(p))
 #endif
 
+// Timing ablations of the tile kernels (profiles/debug/ablate_table.py; results are WRONG with any bit set, never in a
+// shipped build): -DMI_ABLATE=<bits>  1: every gather reads one of x's first 64 entries (the list is still loaded)
+// 2: no column-list load  4: no matrix-stream loads  8: no LDS product phase / row sums (SpMV), no 8x8 sweep (GS)
+#ifndef MI_ABLATE
+#define MI_ABLATE 0
+#endif
+
 __device__ __forceinline__ int xcd_remap(int bid, int chunk) { return (bid & 7) * chunk + (bid >> 3); }
 
 // ---------------------------------------------------------------------------
@@ -193,6 +200,10 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_xc(int nb, int xchunk, cons
   const int blk = xcd_remap(blockIdx.x, xchunk);
   if (blk >= nb) return;
   const int tid = threadIdx.x;
+  if (MI_ABLATE & 128) {  // launch only
+    if (tid == 0 && blk == nb + 1) y[0] = 0.0;
+    return;
+  }
   // (the table entry waits in a register until the LDS writes before the first barrier: stored here, the kernel began
   // with a load, a wait and a write before anything else was requested)
   double lutv = 0.0;
@@ -200,6 +211,10 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_xc(int nb, int xchunk, cons
   const int4 d0 = reinterpret_cast<const int4 *>(tdesc)[2 * blk];
   const int4 d1 = reinterpret_cast<const int4 *>(tdesc)[2 * blk + 1];
   const int r0 = d0.x, r1 = d0.y, len = d0.w, u0 = d1.x, nu = d1.y;
+  if (MI_ABLATE & 64) {  // launch + descriptor
+    if (tid == 0 && r0 + len + u0 + nu + d1.z == -12345) y[0] = lutv;
+    return;
+  }
   // the tile's entry range starts at a 64-bit offset (operators beyond 2^31 entries); everything below is tile-local
   const long long base64 = ((long long)d1.z << 32) | (long long)(unsigned)d0.z;
   if (len >= TILE) {
@@ -236,7 +251,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_xc(int nb, int xchunk, cons
       // extension there and with it a wait after every load -- up to eight SERIAL round trips per tile; check the ISA
       // when this line changes: no s_waitcnt between the list loads)
       uc[q] = 0;
-      if (k < nu) uc[q] = LIST_LOAD(ucols + u0 + k);
+      if (!(MI_ABLATE & 2) && k < nu) uc[q] = LIST_LOAD(ucols + u0 + k);
     }
   }
   const long long base_al64 = base64 & ~1LL;
@@ -257,7 +272,8 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_xc(int nb, int xchunk, cons
     const int k = 2 * tid + it * 2 * BLOCK;
     cw[it] = 0;
     vw[it] = 0;
-    if (k < cnt) {
+    if (MI_ABLATE & 4) vv[it] = d2_t{1.0, 1.0};
+    if (!(MI_ABLATE & 4) && k < cnt) {
       if (VAL8)
         vw[it] = STREAM_LOAD(reinterpret_cast<const unsigned short *>(vidx + base_al + k));
       else
@@ -274,7 +290,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_xc(int nb, int xchunk, cons
   }
   double xv[NU];
 #pragma unroll
-  for (int q = 0; q < NU; q++) xv[q] = x[uc[q]];
+  for (int q = 0; q < NU; q++) xv[q] = x[(MI_ABLATE & 1) ? min(uc[q], 63) : uc[q]];
   // the entry range of the first row a thread sums (operators that the tile Gauss-Seidel kernel also sweeps have
   // <= BLOCK rows per tile: one row per thread; SpMV-only operators with short rows -- P, R, the residual
   // sub-operator -- get up to 4 x BLOCK rows to fill their tiles)
@@ -287,8 +303,10 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_xc(int nb, int xchunk, cons
   double bpre = 0.0;  // EPI 0 with beta != 0: the b entry of this thread's row, requested with the other loads
   int ro = r0 + rr;   // EPI 0: where this thread's row lands in y (operators stored in another row order)
   if (rr < nr) {
-    s0 = (int)((unsigned)ia[r0 + rr] - ia_off);
-    s1 = (int)((unsigned)ia[r0 + rr + 1] - ia_off);
+    if (!(MI_ABLATE & 16)) {
+      s0 = (int)((unsigned)ia[r0 + rr] - ia_off);
+      s1 = (int)((unsigned)ia[r0 + rr + 1] - ia_off);
+    }
     if (EPI == 0 && e.rowmap && lane == 0) ro = e.rowmap[r0 + rr];
     if (EPI == 0 && e.beta != 0.0 && lane == 0) bpre = epi_b(e, ro);
   }
@@ -312,6 +330,13 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_xc(int nb, int xchunk, cons
       vv[it].x = ok0 ? vv[it].x * xs[cw[it] & XC_ID_MASK] : 0.0;
       vv[it].y = ok1 ? vv[it].y * xs[(cw[it] >> 16) & XC_ID_MASK] : 0.0;
     }
+  }
+  if (MI_ABLATE & 8) {
+    double s = (double)(s1 - s0);
+#pragma unroll
+    for (int it = 0; it < NIT; it++) s += vv[it].x + vv[it].y;
+    if (rr < nr && lane == 0 && (!(MI_ABLATE & 32) || s == -12345.0)) __builtin_nontemporal_store(e.alpha * s + e.beta * bpre, y + ro);
+    return;
   }
   __syncthreads();  // every x-cache read is done: the array becomes the product buffer
 #pragma unroll
@@ -891,7 +916,7 @@ __global__ __launch_bounds__(BLOCK, 2048 / BLOCK) void gs_tile_k(int blk0, int n
     for (int q = 0; q < NU; q++) {
       const int k = tid + q * BLOCK;
       ucid[q] = 0;
-      if (k < nu) ucid[q] = LIST_LOAD(ucols + u0 + k);
+      if (!(MI_ABLATE & 2) && k < nu) ucid[q] = LIST_LOAD(ucols + u0 + k);
     }
   }
   const long long base_al64 = base64 & ~1LL;
@@ -910,7 +935,8 @@ __global__ __launch_bounds__(BLOCK, 2048 / BLOCK) void gs_tile_k(int blk0, int n
     const int k = 2 * tid + it * 2 * BLOCK;
     cw[it] = 0;
     vw[it] = 0;
-    if (k < cnt) {
+    if (MI_ABLATE & 4) vv[it] = d2_t{1.0, 1.0};
+    if (!(MI_ABLATE & 4) && k < cnt) {
       if (VAL8)
         vw[it] = STREAM_LOAD(reinterpret_cast<const unsigned short *>(vidx + base_al + k));
       else
@@ -931,7 +957,7 @@ __global__ __launch_bounds__(BLOCK, 2048 / BLOCK) void gs_tile_k(int blk0, int n
   if (!all_zero) {
 #pragma unroll
     for (int q = 0; q < GB; q++) {
-      const int j = (ucid[q] >= zero_from) ? 0 : ucid[q];
+      const int j = (ucid[q] >= zero_from) ? 0 : ((MI_ABLATE & 1) ? min(ucid[q], 63) : ucid[q]);
       xv[q] = UOLD(j);
     }
   }
@@ -1049,7 +1075,7 @@ __global__ __launch_bounds__(BLOCK, 2048 / BLOCK) void gs_tile_k(int blk0, int n
   for (int j = 0; j < 8; j++) uc[j] = __shfl(myu, gbase + j * LPR, 64);
 #pragma unroll
   for (int dir = 0; dir < 2; dir++) {
-    if (dir == 0 ? !fwd : !bwd) continue;
+    if ((MI_ABLATE & 8) || (dir == 0 ? !fwd : !bwd)) continue;
 #pragma unroll
     for (int tt = 0; tt < 8; tt++) {
       const int t = (dir == 0) ? tt : 7 - tt;
