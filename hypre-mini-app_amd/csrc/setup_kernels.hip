@@ -123,6 +123,42 @@ __global__ __launch_bounds__(BLK) void bin_fill_k(int n, const int *__restrict__
   if (b >= 0) rows[bin_start[b] + base[b] + off] = (int)i;
 }
 
+// Lanes of one wave that hand LDS data to each other between two steps (groups of G <= 64 lanes never straddle a wave):
+// the wave's LDS operations execute in program order, so all that is needed is that the compiler keeps that order.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+// Between the phases of a kernel whose rows are owned by groups of G lanes: a group inside one wave needs no workgroup
+// barrier (with one, every wave of the workgroup waits for the slowest row of all of them at every phase).
+template <int G>
+__device__ __forceinline__ void group_sync() {
+  if (G <= 64)
+    wave_lds_sync();
+  else
+    __syncthreads();
+}
+
+// rows of one bin split by the EXACT number of distinct columns the symbolic pass found (order inside a part is irrelevant)
+__global__ __launch_bounds__(BLK) void split_rows_k(int nlist, const int *__restrict__ rows, const int *__restrict__ nout,
+                                                    int thresh, int *__restrict__ small, int *__restrict__ big,
+                                                    int *__restrict__ counters) {
+  __shared__ int cnt[2], base[2];
+  if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const long long k = bid() * BLK + threadIdx.x;
+  int row = 0, part = -1, off = 0;
+  if (k < nlist) {
+    row = rows[k];
+    part = nout[row] <= thresh ? 0 : 1;
+    off = atomicAdd(&cnt[part], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) base[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&counters[threadIdx.x], cnt[threadIdx.x]) : 0;
+  __syncthreads();
+  if (part >= 0) (part == 0 ? small : big)[base[part] + off] = row;
+}
+
 // ---------------------------------------------------------------- SpGEMM, one group of G lanes per row
 // S = lanes that share one row of B during the hash phase (power of two <= G)
 template <int G, int CAP, bool NUMERIC>
@@ -145,7 +181,7 @@ __global__ __launch_bounds__(BLK) void spgemm_group_k(int nlist, const int *__re
   const int row = active ? rows[gi] : 0;
   for (int t = lane; t < H; t += G) tab[g][t] = EMPTY;
   if (lane == 0) cnt[g] = 0;
-  __syncthreads();
+  group_sync<G>();
   long long a0 = 0, a1 = 0;
   if (active) {
     a0 = Aia[row];
@@ -160,7 +196,7 @@ __global__ __launch_bounds__(BLK) void spgemm_group_k(int nlist, const int *__re
       }
     }
   }
-  __syncthreads();
+  group_sync<G>();
   if (!active) return;
   const int no = cnt[g];
   if (!NUMERIC) {
@@ -174,6 +210,102 @@ __global__ __launch_bounds__(BLK) void spgemm_group_k(int nlist, const int *__re
     for (int t = 0; t < no; t++) rank += (list[g][t] < j);
     Cja[c0 + rank] = j;
     Ca[c0 + rank] = row_dot(a0, a1, Aja, Aa, Bia, Bja, Ba, j);
+  }
+}
+
+// Numeric phase of the same product (round 4).  spgemm_group_k<.,.,true> finds every entry of C by its own walk over
+// A's row with a binary search in each row of B: (entries of C) x (entries of A's row) x log(row of B) dependent loads --
+// 13 x the products of a Galerkin row.  Here the group walks A's row ONCE, in stored order, one entry per step; the G
+// lanes take the entries of that row of B (distinct columns), and each adds its product to the column's slot of an
+// LDS hash table: first product assigned, the rest added, in the order of A's row -- the order of the host loop and of
+// row_dot, so the sums are the same bits.  Steps are separated by wave_lds_sync (a step's slot may be the next step's).
+template <int G, int CAP>
+__global__ __launch_bounds__(BLK) void spgemm_accum_k(int nlist, const int *__restrict__ rows,
+                                                      const long long *__restrict__ Aia, const int *__restrict__ Aja,
+                                                      const double *__restrict__ Aa, const long long *__restrict__ Bia,
+                                                      const int *__restrict__ Bja, const double *__restrict__ Ba,
+                                                      const long long *__restrict__ Cia, int *__restrict__ Cja,
+                                                      double *__restrict__ Ca) {
+  constexpr int H = 2 * CAP;
+  constexpr int LOGH = (H == 64) ? 6 : (H == 256) ? 8 : 10;
+  static_assert(H == 64 || H == 256 || H == 1024, "table size");
+  static_assert(G <= 64 && 64 % G == 0, "a group lives inside one wave");
+  constexpr int GP = BLK / G;
+  __shared__ double val[GP][H];
+  __shared__ int tab[GP][H];
+  __shared__ int keys[GP][CAP];             // discovered columns, in discovery order
+  __shared__ unsigned short slots[GP][CAP];  // their table slots
+  __shared__ int cnt[GP];
+  const int g = threadIdx.x / G, lane = threadIdx.x % G;
+  const long long gi = bid() * GP + g;
+  const bool active = gi < nlist;
+  const int row = active ? rows[gi] : 0;
+  for (int t = lane; t < H; t += G) tab[g][t] = EMPTY;
+  if (lane == 0) cnt[g] = 0;
+  wave_lds_sync();
+  if (!active) return;
+  const long long a0 = Aia[row], a1 = Aia[row + 1];
+  constexpr unsigned mask = (1u << LOGH) - 1u;
+  auto add = [&](int j, double prod) {
+    unsigned sl = ((unsigned)j * 2654435761u) >> (32 - LOGH);
+    while (true) {
+      const int old = atomicCAS(&tab[g][sl], EMPTY, j);
+      if (old == EMPTY) {
+        val[g][sl] = prod;
+        const int p = atomicAdd(&cnt[g], 1);
+        keys[g][p] = j;
+        slots[g][p] = (unsigned short)sl;
+        return;
+      }
+      if (old == j) {
+        val[g][sl] = val[g][sl] + prod;
+        return;
+      }
+      sl = (sl + 1u) & mask;
+    }
+  };
+  // G entries of A's row at a time: lane l fetches entry l and the bounds of its row of B (two round trips for all of
+  // them together); the steps then read them by shuffle, and the loads of step t + 1 are in flight while step t adds
+  for (long long base = a0; base < a1; base += G) {
+    const long long kal = base + lane;
+    const bool has = kal < a1;
+    const int krl = has ? Aja[kal] : 0;
+    const double avl = has ? Aa[kal] : 0.0;
+    const long long b0l = has ? Bia[krl] : 0, b1l = has ? Bia[krl + 1] : 0;
+    const int nstep = (int)((a1 - base < (long long)G) ? (a1 - base) : (long long)G);
+    long long nb0 = __shfl(b0l, 0, G), nb1 = __shfl(b1l, 0, G);
+    int nj = 0;
+    double nbv = 0.0;
+    if (nb0 + lane < nb1) {
+      nj = Bja[nb0 + lane];
+      nbv = Ba[nb0 + lane];
+    }
+    for (int t = 0; t < nstep; t++) {
+      const long long b0 = nb0, b1 = nb1;
+      const int j = nj;
+      const double bv = nbv;
+      const double av = __shfl(avl, t, G);
+      if (t + 1 < nstep) {
+        nb0 = __shfl(b0l, t + 1, G);
+        nb1 = __shfl(b1l, t + 1, G);
+        if (nb0 + lane < nb1) {
+          nj = Bja[nb0 + lane];
+          nbv = Ba[nb0 + lane];
+        }
+      }
+      if (b0 + lane < b1) add(j, av * bv);
+      for (long long kb = b0 + lane + G; kb < b1; kb += G) add(Bja[kb], av * Ba[kb]);
+      wave_lds_sync();
+    }
+  }
+  const int no = cnt[g];
+  const long long c0 = Cia[row];
+  for (int r = lane; r < no; r += G) {
+    const int j = keys[g][r];
+    int rank = 0;
+    for (int t = 0; t < no; t++) rank += (keys[g][t] < j);
+    Cja[c0 + rank] = j;
+    Ca[c0 + rank] = val[g][slots[g][r]];
   }
 }
 
@@ -535,8 +667,13 @@ template <int CAP>
 struct InterpGroup {
   int hkey[2 * CAP];
   int hval[2 * CAP];  // discovery position, later the entry's index q
-  int ckey[CAP];
-  int cseq[CAP];  // discovery positions of the compacted entries, later the keep flags
+  union {
+    struct {
+      int ckey[CAP];
+      int cseq[CAP];  // discovery positions of the compacted entries, later the keep flags
+    };
+    double sfback[CAP];  // between the ranking and the truncation: per strong neighbour, its entry in column i
+  };
   int ord[CAP];   // fine ids in discovery order
   double rv[CAP];
   double sfsum[CAP];
@@ -557,6 +694,15 @@ __device__ __forceinline__ int ig_find(const int *hkey, int key) {
   }
 }
 
+// -DMI_INTERP_STOP=<phase>: timing ablation, the kernel returns after that phase with empty rows (never in a shipped build)
+#ifndef MI_INTERP_STOP
+#define MI_INTERP_STOP 0
+#endif
+#define INTERP_STOP_AFTER(P)                       \
+  if (MI_INTERP_STOP == (P)) {                     \
+    if (work && lane == 0) len_out[i] = 0;         \
+    return;                                        \
+  }
 template <int G, int CAP, int BT>
 __global__ __launch_bounds__(BT) void interp_group_k(int nlist, const int *__restrict__ rows, int ext,
                                                      const long long *__restrict__ Aia, const int *__restrict__ Aja,
@@ -593,7 +739,7 @@ __global__ __launch_bounds__(BT) void interp_group_k(int nlist, const int *__res
     L.hval[t] = 0x7fffffff;
   }
   if (lane == 0) L.cnt = 0;
-  __syncthreads();
+  group_sync<G>();
   const long long s0 = work ? Sia[i] : 0, s1 = work ? Sia[i + 1] : 0;
   // ---- 1. interpolatory set with discovery positions
   if (work) {
@@ -614,15 +760,24 @@ __global__ __launch_bounds__(BT) void interp_group_k(int nlist, const int *__res
       if (c1 == C_PT) {
         put(i1, kl * INTERP_SEQ);
       } else if (c1 == F_PT && ext) {
+        // (four entries per round trip: ids together, then their marks together -- one entry at a time this walk was a
+        // chain of 2 x |row| dependent loads)
         const long long t0 = Sia[i1], t1 = Sia[i1 + 1];
-        for (long long kk = t0; kk < t1; kk++) {
-          const int k1 = Sja[kk];
-          if (cf[k1] == C_PT) put(k1, kl * INTERP_SEQ + 1 + (int)(kk - t0));
+        for (long long kk = t0; kk < t1; kk += 4) {
+          int k1[4], m1[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) k1[u] = (kk + u < t1) ? Sja[kk + u] : -1;
+#pragma unroll
+          for (int u = 0; u < 4; u++) m1[u] = (k1[u] >= 0) ? cf[k1[u]] : 0;
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (k1[u] >= 0 && m1[u] == C_PT) put(k1[u], kl * INTERP_SEQ + 1 + (int)(kk + u - t0));
         }
       }
     }
   }
-  __syncthreads();
+  group_sync<G>();
+  INTERP_STOP_AFTER(1)
   // ---- 2. compaction
   if (work)
     for (int t = lane; t < H; t += G)
@@ -631,7 +786,7 @@ __global__ __launch_bounds__(BT) void interp_group_k(int nlist, const int *__res
         L.ckey[p] = L.hkey[t];
         L.cseq[p] = L.hval[t];
       }
-  __syncthreads();
+  group_sync<G>();
   const int len = work ? L.cnt : 0;
   // ---- 3. discovery order: ord[rank] = key, hash value = rank
   if (work)
@@ -642,115 +797,254 @@ __global__ __launch_bounds__(BT) void interp_group_k(int nlist, const int *__res
       L.ord[rank] = L.ckey[p];
       L.hval[ig_find<LOGH>(L.hkey, L.ckey[p])] = rank;
     }
-  __syncthreads();
+  group_sync<G>();
+  INTERP_STOP_AFTER(3)
   // ---- 4. per strong F neighbour: sign of its diagonal and the sum its connection is distributed over
   if (work)
     for (long long k = s0 + lane; k < s1; k += G) {
       const int i1 = Sja[k];
       const int kl = (int)(k - s0);
-      double sum = 0.0;
+      double sum = 0.0, back = 0.0;
       signed char sg = 1;
       if (cf[i1] == F_PT) {
         const long long r0 = Aia[i1], r1 = Aia[i1 + 1];
+        // its diagonal: rows are stored with ascending columns (the searches below rely on it as well)
         double dk = 0.0;
-        for (long long kk = r0; kk < r1; kk++)
-          if (Aja[kk] == i1) dk = Aa[kk];
+        {
+          long long lo = r0, hi = r1;
+          while (lo < hi) {
+            const long long mid = (lo + hi) >> 1;
+            if (Aja[mid] < i1)
+              lo = mid + 1;
+            else
+              hi = mid;
+          }
+          if (lo < r1 && Aja[lo] == i1) dk = Aa[lo];
+        }
         const double sgn = (dk < 0) ? -1.0 : 1.0;
         sg = (dk < 0) ? -1 : 1;
-        for (long long kk = r0; kk < r1; kk++) {
-          const int i2 = Aja[kk];
-          if (i2 == i1) continue;
-          const double v = Aa[kk];
-          if (!(sgn * v < 0)) continue;
-          if ((ext && i2 == i) || (cf[i2] == C_PT && ig_find<LOGH>(L.hkey, i2) >= 0)) sum += v;
+        // the row once, four entries per round trip, summed in stored order.  (The table holds C points only, so being
+        // in it is the whole test; it used to be preceded by a load of the entry's mark.)
+        for (long long kk = r0; kk < r1; kk += 4) {
+          int c2[4];
+          double w2[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            c2[u] = (kk + u < r1) ? Aja[kk + u] : i1;
+            w2[u] = (kk + u < r1) ? Aa[kk + u] : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int i2 = c2[u];
+            if (i2 == i1) continue;
+            const double v = w2[u];
+            // the neighbour's entry in column i, for the accumulation of the diagonal (which used to walk this row again,
+            // one neighbour after the other: the longest dependent chain of the kernel); magnitude 2 = present
+            if (i2 == i) {
+              back = v;
+              sg = (signed char)(2 * sg);
+            }
+            if (!(sgn * v < 0)) continue;
+            if ((ext && i2 == i) || ig_find<LOGH>(L.hkey, i2) >= 0) sum += v;
+          }
         }
       }
       L.sfsum[kl] = sum;
       L.sfsgn[kl] = sg;
+      L.sfback[kl] = back;
     }
-  __syncthreads();
-  // ---- 5. weights: lane q accumulates entry q; the last lane accumulates the diagonal
-  if (work) {
-    const long long r0 = Aia[i], r1 = Aia[i + 1];
-    for (int q = lane; q < len; q += G) {
-      const int myid = L.ord[q];
-      double acc = 0.0;
-      long long sp = s0;
-      for (long long k = r0; k < r1; k++) {
-        const int i1 = Aja[k];
-        const bool strong = (sp < s1 && Sja[sp] == i1);
-        const int kl = (int)(sp - s0);
-        if (strong) sp++;
-        if (i1 == i) continue;
-        const double aik = Aa[k];
-        if (i1 == myid) {
-          acc += aik;
-        } else if (strong && cf[i1] == F_PT) {
-          const double sum = L.sfsum[kl];
-          if (sum != 0.0) {
-            const double distribute = aik / sum;
-            long long lo = Aia[i1];
-            const long long end = Aia[i1 + 1];
-            long long hi = end;
-            while (lo < hi) {
-              const long long mid = (lo + hi) >> 1;
-              if (Aja[mid] < myid)
-                lo = mid + 1;
-              else
-                hi = mid;
+  group_sync<G>();
+  INTERP_STOP_AFTER(4)
+  // ---- 5. weights.  The group walks row i ONCE, in stored order, one entry per step (round 4; before, every lane q walked
+  // the row for its own entry and searched each strong F neighbour's row for it, and one lane did the same for the
+  // diagonal): an interpolatory point adds its coefficient to its own weight; a strong F neighbour's row is spread over
+  // the lanes, and every entry of it that is an interpolatory point of the right sign adds distribute * value to that
+  // point's weight -- per weight at most one term per step, so each weight still sums its terms in the order of row i,
+  // with the same operations as the host loop.  The diagonal's terms are lane 0's, in the same order.  G entries of the
+  // row are fetched at a time (lane l: entry l, its mark, its position among the strong connections, the bounds of its
+  // row); the steps read them by shuffle, and the first entries of the next step's row are in flight during a step.
+  if constexpr (G <= 64) {
+    if (work)
+      for (int q = lane; q < len; q += G) L.rv[q] = 0.0;
+    if (work && lane == 0) L.diag = 0.0;
+    group_sync<G>();
+    if (work) {
+      const long long r0 = Aia[i], r1 = Aia[i + 1];
+      // the diagonal's sum starts from a_ii (host loop): fetched before the walk
+      for (long long k = r0 + lane; k < r1; k += G)
+        if (Aja[k] == i) L.diag = Aa[k];
+      group_sync<G>();
+      double diagonal = L.diag;
+      for (long long base = r0; base < r1; base += G) {
+        const long long kal = base + lane;
+        const bool has = kal < r1;
+        const int i1l = has ? Aja[kal] : i;
+        const double al = has ? Aa[kal] : 0.0;
+        const int c1l = (has && i1l != i) ? cf[i1l] : 0;
+        int kll = -1;  // position among the strong connections (ascending columns in both rows)
+        long long b0l = 0, b1l = 0;
+        if (has && i1l != i) {
+          long long lo = s0, hi = s1;
+          while (lo < hi) {
+            const long long mid = (lo + hi) >> 1;
+            if (Sja[mid] < i1l)
+              lo = mid + 1;
+            else
+              hi = mid;
+          }
+          if (lo < s1 && Sja[lo] == i1l) kll = (int)(lo - s0);
+          if (kll >= 0 && c1l == F_PT) {
+            b0l = Aia[i1l];
+            b1l = Aia[i1l + 1];
+          }
+        }
+        const int nstep = (int)((r1 - base < (long long)G) ? (r1 - base) : (long long)G);
+        long long nb0 = __shfl(b0l, 0, G), nb1 = __shfl(b1l, 0, G);
+        int nj = 0;
+        double nv = 0.0;
+        if (nb0 + lane < nb1) {
+          nj = Aja[nb0 + lane];
+          nv = Aa[nb0 + lane];
+        }
+        for (int t = 0; t < nstep; t++) {
+          const long long b0 = nb0, b1 = nb1;
+          const int j0 = nj;
+          const double v0 = nv;
+          const int i1 = __shfl(i1l, t, G);
+          const double aik = __shfl(al, t, G);
+          const int c1 = __shfl(c1l, t, G);
+          const int kl = __shfl(kll, t, G);
+          if (t + 1 < nstep) {
+            nb0 = __shfl(b0l, t + 1, G);
+            nb1 = __shfl(b1l, t + 1, G);
+            if (nb0 + lane < nb1) {
+              nj = Aja[nb0 + lane];
+              nv = Aa[nb0 + lane];
             }
-            if (lo < end && Aja[lo] == myid) {
-              const double v = Aa[lo];
-              if ((double)L.sfsgn[kl] * v < 0) acc += distribute * v;
+          }
+          if (i1 != i) {
+            const int slot = (c1 == C_PT) ? ig_find<LOGH>(L.hkey, i1) : -1;
+            if (slot >= 0) {  // interpolatory point
+              if (lane == 0) {
+                const int q = L.hval[slot];
+                L.rv[q] = L.rv[q] + aik;
+              }
+            } else if (kl >= 0 && c1 == F_PT) {
+              const double sum = L.sfsum[kl];
+              if (sum != 0.0) {
+                const double distribute = aik / sum;
+                const int sg = L.sfsgn[kl];
+                auto spread = [&](int i2, double v) {
+                  if (!((sg < 0 ? -v : v) < 0)) return;
+                  const int sl2 = ig_find<LOGH>(L.hkey, i2);
+                  if (sl2 >= 0) {
+                    const int q = L.hval[sl2];
+                    L.rv[q] = L.rv[q] + distribute * v;
+                  }
+                };
+                if (b0 + lane < b1) spread(j0, v0);
+                for (long long kk = b0 + lane + G; kk < b1; kk += G) spread(Aja[kk], Aa[kk]);
+                if (lane == 0 && ext && (sg == 2 || sg == -2)) {
+                  const double v = L.sfback[kl];
+                  if ((sg < 0 ? -v : v) < 0) diagonal += distribute * v;
+                }
+              } else if (lane == 0) {
+                diagonal += aik;
+              }
+            } else if (lane == 0) {
+              diagonal += aik;
+            }
+          }
+          group_sync<G>();
+        }
+      }
+      if (lane == 0) L.diag = diagonal;
+    }
+  } else {
+    // one row per workgroup (up to 1024 candidates; groups wider than a wave cannot pass the row by shuffle): lane q
+    // accumulates entry q by its own walk over row i, the last lane the diagonal
+    if (work) {
+      const long long r0 = Aia[i], r1 = Aia[i + 1];
+      for (int q = lane; q < len; q += G) {
+        const int myid = L.ord[q];
+        double acc = 0.0;
+        long long sp = s0;
+        for (long long k = r0; k < r1; k++) {
+          const int i1 = Aja[k];
+          const bool strong = (sp < s1 && Sja[sp] == i1);
+          const int kl = (int)(sp - s0);
+          if (strong) sp++;
+          if (i1 == i) continue;
+          const double aik = Aa[k];
+          if (i1 == myid) {
+            acc += aik;
+          } else if (strong && cf[i1] == F_PT) {
+            const double sum = L.sfsum[kl];
+            if (sum != 0.0) {
+              const double distribute = aik / sum;
+              long long lo = Aia[i1];
+              const long long end = Aia[i1 + 1];
+              long long hi = end;
+              while (lo < hi) {
+                const long long mid = (lo + hi) >> 1;
+                if (Aja[mid] < myid)
+                  lo = mid + 1;
+                else
+                  hi = mid;
+              }
+              if (lo < end && Aja[lo] == myid) {
+                const double v = Aa[lo];
+                if ((L.sfsgn[kl] < 0 ? -v : v) < 0) acc += distribute * v;
+              }
             }
           }
         }
+        L.rv[q] = acc;
       }
-      L.rv[q] = acc;
-    }
-    if (lane == G - 1) {
-      double diagonal = 0.0;
-      for (long long k = r0; k < r1; k++)
-        if (Aja[k] == i) diagonal = Aa[k];
-      long long sp = s0;
-      for (long long k = r0; k < r1; k++) {
-        const int i1 = Aja[k];
-        const bool strong = (sp < s1 && Sja[sp] == i1);
-        const int kl = (int)(sp - s0);
-        if (strong) sp++;
-        if (i1 == i) continue;
-        const double aik = Aa[k];
-        const int c1 = cf[i1];
-        if (c1 == C_PT && ig_find<LOGH>(L.hkey, i1) >= 0) continue;  // interpolatory point
-        if (strong && c1 == F_PT) {
-          const double sum = L.sfsum[kl];
-          if (sum != 0.0) {
-            if (ext) {
-              const double distribute = aik / sum;
-              const long long q0 = Aia[i1], q1 = Aia[i1 + 1];
-              for (long long kk = q0; kk < q1; kk++)
-                if (Aja[kk] == i) {
-                  const double v = Aa[kk];
-                  if ((double)L.sfsgn[kl] * v < 0) diagonal += distribute * v;
+      if (lane == G - 1) {
+        double diagonal = 0.0;
+        for (long long k = r0; k < r1; k++)
+          if (Aja[k] == i) diagonal = Aa[k];
+        long long sp = s0;
+        for (long long k = r0; k < r1; k++) {
+          const int i1 = Aja[k];
+          const bool strong = (sp < s1 && Sja[sp] == i1);
+          const int kl = (int)(sp - s0);
+          if (strong) sp++;
+          if (i1 == i) continue;
+          const double aik = Aa[k];
+          const int c1 = cf[i1];
+          if (c1 == C_PT && ig_find<LOGH>(L.hkey, i1) >= 0) continue;  // interpolatory point
+          if (strong && c1 == F_PT) {
+            const double sum = L.sfsum[kl];
+            if (sum != 0.0) {
+              if (ext) {
+                const double distribute = aik / sum;
+                const int sg = L.sfsgn[kl];
+                if (sg == 2 || sg == -2) {
+                  const double v = L.sfback[kl];
+                  if ((sg < 0 ? -v : v) < 0) diagonal += distribute * v;
                 }
+              }
+            } else {
+              diagonal += aik;
             }
           } else {
             diagonal += aik;
           }
-        } else {
-          diagonal += aik;
         }
+        L.diag = diagonal;
       }
-      L.diag = diagonal;
     }
   }
-  __syncthreads();
+  group_sync<G>();
   if (work) {
     const double diagonal = L.diag;
     if (diagonal != 0.0)
       for (int q = lane; q < len; q += G) L.rv[q] = L.rv[q] / -diagonal;
   }
-  __syncthreads();
+  group_sync<G>();
+  INTERP_STOP_AFTER(5)
   // ---- 6. truncation: keep the pmax largest by (|p| descending, position ascending) among those >= factor*max
   if (work) {
     double maxabs = 0.0;
@@ -771,7 +1065,7 @@ __global__ __launch_bounds__(BT) void interp_group_k(int nlist, const int *__res
       L.cseq[q] = keep;
     }
   }
-  __syncthreads();
+  group_sync<G>();
   if (work && lane == 0) {
     double row_sum = 0.0, kept = 0.0;
     int nk = 0;
@@ -786,7 +1080,7 @@ __global__ __launch_bounds__(BT) void interp_group_k(int nlist, const int *__res
     L.nkept = nk;
     len_out[i] = nk;
   }
-  __syncthreads();
+  group_sync<G>();
   if (work) {
     const long long o = slack_ia[i];
     const double scale = L.scale;
@@ -1397,15 +1691,57 @@ void launch_bins(const Bins &bins, const int *rows, const int *T, int S_hint, co
                  hipStream_t s) {
   const int n0 = bins.start[1] - bins.start[0], n1 = bins.start[2] - bins.start[1], n2 = bins.start[3] - bins.start[2],
             n3 = bins.start[4] - bins.start[3];
-  if (n0)
-    spgemm_group_k<8, 32, NUMERIC><<<grid_for(((long long)n0 + 31) / 32), BLK, 0, s>>>(
-        n0, rows + bins.start[0], std::min(S_hint, 8), A.ia.p, A.ja.p, A.a.p, B.ia.p, B.ja.p, B.a.p, nout, Cia, Cja, Ca);
-  if (n1)
-    spgemm_group_k<16, 128, NUMERIC><<<grid_for(((long long)n1 + 15) / 16), BLK, 0, s>>>(
-        n1, rows + bins.start[1], std::min(S_hint, 16), A.ia.p, A.ja.p, A.a.p, B.ia.p, B.ja.p, B.a.p, nout, Cia, Cja, Ca);
-  if (n2)
-    spgemm_group_k<64, 512, NUMERIC><<<grid_for(((long long)n2 + 3) / 4), BLK, 0, s>>>(
-        n2, rows + bins.start[2], std::min(S_hint, 64), A.ia.p, A.ja.p, A.a.p, B.ia.p, B.ja.p, B.a.p, nout, Cia, Cja, Ca);
+  // MI_HYPRE_SPGEMM_ACCUM=0: the numeric phase by per-entry search (spgemm_group_k<.,.,true>), as before round 4
+  static const bool accum = [] {
+    const char *e = getenv("MI_HYPRE_SPGEMM_ACCUM");
+    return !(e && atoi(e) == 0);
+  }();
+  if (NUMERIC && accum) {
+    // the bins bound a row's PRODUCTS; its table only has to hold its distinct columns, which the symbolic pass has counted
+    // (a Galerkin row of the 7-point benchmark: 377 products, 30 columns): rows whose count fits the next smaller table
+    // take it -- 15 instead of 60 KB of LDS per workgroup, four times the rows in flight
+    DVec<int> part;
+    int hc[2][2] = {{0, 0}, {0, 0}};  // [bin 1 / bin 2][small / big]
+    const int *small1 = nullptr, *big1 = nullptr, *small2 = nullptr, *big2 = nullptr;
+    if (n1 || n2) {
+      part.alloc((size_t)2 * ((size_t)n1 + (size_t)n2) + 4);
+      int *cnt = part.p + 2 * ((size_t)n1 + (size_t)n2);
+      MI_HIP(hipMemsetAsync(cnt, 0, 4 * sizeof(int), s));
+      int *s1 = part.p, *b1 = part.p + n1, *s2 = part.p + 2 * (size_t)n1, *b2 = s2 + n2;
+      if (n1) split_rows_k<<<grid_for(((long long)n1 + BLK - 1) / BLK), BLK, 0, s>>>(n1, rows + bins.start[1], nout, 32, s1, b1, cnt);
+      if (n2) split_rows_k<<<grid_for(((long long)n2 + BLK - 1) / BLK), BLK, 0, s>>>(n2, rows + bins.start[2], nout, 128, s2, b2, cnt + 2);
+      d2h(&hc[0][0], cnt, 4 * sizeof(int), s);
+      MI_HIP(hipStreamSynchronize(s));
+      small1 = s1, big1 = b1, small2 = s2, big2 = b2;
+    }
+    if (n0)
+      spgemm_accum_k<8, 32><<<grid_for(((long long)n0 + 31) / 32), BLK, 0, s>>>(
+          n0, rows + bins.start[0], A.ia.p, A.ja.p, A.a.p, B.ia.p, B.ja.p, B.a.p, Cia, Cja, Ca);
+    if (hc[0][0])
+      spgemm_accum_k<16, 32><<<grid_for(((long long)hc[0][0] + 15) / 16), BLK, 0, s>>>(
+          hc[0][0], small1, A.ia.p, A.ja.p, A.a.p, B.ia.p, B.ja.p, B.a.p, Cia, Cja, Ca);
+    if (hc[0][1])
+      spgemm_accum_k<16, 128><<<grid_for(((long long)hc[0][1] + 15) / 16), BLK, 0, s>>>(
+          hc[0][1], big1, A.ia.p, A.ja.p, A.a.p, B.ia.p, B.ja.p, B.a.p, Cia, Cja, Ca);
+    if (hc[1][0])
+      spgemm_accum_k<64, 128><<<grid_for(((long long)hc[1][0] + 3) / 4), BLK, 0, s>>>(
+          hc[1][0], small2, A.ia.p, A.ja.p, A.a.p, B.ia.p, B.ja.p, B.a.p, Cia, Cja, Ca);
+    if (hc[1][1])
+      spgemm_accum_k<64, 512><<<grid_for(((long long)hc[1][1] + 3) / 4), BLK, 0, s>>>(
+          hc[1][1], big2, A.ia.p, A.ja.p, A.a.p, B.ia.p, B.ja.p, B.a.p, Cia, Cja, Ca);
+    MI_HIP(hipGetLastError());
+    MI_HIP(hipStreamSynchronize(s));  // `part` is released on return
+  } else {
+    if (n0)
+      spgemm_group_k<8, 32, NUMERIC><<<grid_for(((long long)n0 + 31) / 32), BLK, 0, s>>>(
+          n0, rows + bins.start[0], std::min(S_hint, 8), A.ia.p, A.ja.p, A.a.p, B.ia.p, B.ja.p, B.a.p, nout, Cia, Cja, Ca);
+    if (n1)
+      spgemm_group_k<16, 128, NUMERIC><<<grid_for(((long long)n1 + 15) / 16), BLK, 0, s>>>(
+          n1, rows + bins.start[1], std::min(S_hint, 16), A.ia.p, A.ja.p, A.a.p, B.ia.p, B.ja.p, B.a.p, nout, Cia, Cja, Ca);
+    if (n2)
+      spgemm_group_k<64, 512, NUMERIC><<<grid_for(((long long)n2 + 3) / 4), BLK, 0, s>>>(
+          n2, rows + bins.start[2], std::min(S_hint, 64), A.ia.p, A.ja.p, A.a.p, B.ia.p, B.ja.p, B.a.p, nout, Cia, Cja, Ca);
+  }
   if (n3)
     spgemm_block_k<NUMERIC><<<(unsigned)std::min(n3, block_grid), BLK, 0, s>>>(
         n3, rows + bins.start[3], T, B.ncols, S_hint, gscratch, scratch_per_block, A.ia.p, A.ja.p, A.a.p, B.ia.p,
