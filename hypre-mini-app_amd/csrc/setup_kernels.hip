@@ -1700,35 +1700,56 @@ void launch_bins(const Bins &bins, const int *rows, const int *T, int S_hint, co
     // the bins bound a row's PRODUCTS; its table only has to hold its distinct columns, which the symbolic pass has counted
     // (a Galerkin row of the 7-point benchmark: 377 products, 30 columns): rows whose count fits the next smaller table
     // take it -- 15 instead of 60 KB of LDS per workgroup, four times the rows in flight
-    DVec<int> part;
-    int hc[2][2] = {{0, 0}, {0, 0}};  // [bin 1 / bin 2][small / big]
-    const int *small1 = nullptr, *big1 = nullptr, *small2 = nullptr, *big2 = nullptr;
-    if (n1 || n2) {
-      part.alloc((size_t)2 * ((size_t)n1 + (size_t)n2) + 4);
-      int *cnt = part.p + 2 * ((size_t)n1 + (size_t)n2);
-      MI_HIP(hipMemsetAsync(cnt, 0, 4 * sizeof(int), s));
-      int *s1 = part.p, *b1 = part.p + n1, *s2 = part.p + 2 * (size_t)n1, *b2 = s2 + n2;
+    // The same for the rows beyond 512 products (one workgroup per row in the symbolic pass): up to 512 distinct columns
+    // they run here too -- a Galerkin row of a coarse level has 500-1000 products and 100-150 columns; what is left
+    // goes to spgemm_block_k below.
+    DVec<int> part, part3;
+    int hc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // bin 1 small/big, bin 2 small/big, bin 3 small/rest, rest of bin 3 mid/big
+    int *s1 = nullptr, *b1 = nullptr, *s2 = nullptr, *b2 = nullptr, *s3 = nullptr, *r3 = nullptr, *m3 = nullptr, *g3 = nullptr;
+    if (n1 || n2 || n3) {
+      const size_t tot = (size_t)n1 + (size_t)n2 + (size_t)n3;
+      part.alloc(2 * tot + 8);
+      int *cnt = part.p + 2 * tot;
+      MI_HIP(hipMemsetAsync(cnt, 0, 8 * sizeof(int), s));
+      s1 = part.p, b1 = s1 + n1, s2 = b1 + n1, b2 = s2 + n2, s3 = b2 + n2, r3 = s3 + n3;
       if (n1) split_rows_k<<<grid_for(((long long)n1 + BLK - 1) / BLK), BLK, 0, s>>>(n1, rows + bins.start[1], nout, 32, s1, b1, cnt);
       if (n2) split_rows_k<<<grid_for(((long long)n2 + BLK - 1) / BLK), BLK, 0, s>>>(n2, rows + bins.start[2], nout, 128, s2, b2, cnt + 2);
-      d2h(&hc[0][0], cnt, 4 * sizeof(int), s);
+      if (n3) split_rows_k<<<grid_for(((long long)n3 + BLK - 1) / BLK), BLK, 0, s>>>(n3, rows + bins.start[3], nout, 128, s3, r3, cnt + 4);
+      d2h(hc, cnt, 6 * sizeof(int), s);
       MI_HIP(hipStreamSynchronize(s));
-      small1 = s1, big1 = b1, small2 = s2, big2 = b2;
+      if (hc[5]) {
+        part3.alloc(2 * (size_t)hc[5]);
+        m3 = part3.p, g3 = m3 + hc[5];
+        split_rows_k<<<grid_for(((long long)hc[5] + BLK - 1) / BLK), BLK, 0, s>>>(hc[5], r3, nout, 512, m3, g3, cnt + 6);
+        d2h(hc + 6, cnt + 6, 2 * sizeof(int), s);
+        MI_HIP(hipStreamSynchronize(s));
+      }
     }
     if (n0)
       spgemm_accum_k<8, 32><<<grid_for(((long long)n0 + 31) / 32), BLK, 0, s>>>(
           n0, rows + bins.start[0], A.ia.p, A.ja.p, A.a.p, B.ia.p, B.ja.p, B.a.p, Cia, Cja, Ca);
-    if (hc[0][0])
-      spgemm_accum_k<16, 32><<<grid_for(((long long)hc[0][0] + 15) / 16), BLK, 0, s>>>(
-          hc[0][0], small1, A.ia.p, A.ja.p, A.a.p, B.ia.p, B.ja.p, B.a.p, Cia, Cja, Ca);
-    if (hc[0][1])
-      spgemm_accum_k<16, 128><<<grid_for(((long long)hc[0][1] + 15) / 16), BLK, 0, s>>>(
-          hc[0][1], big1, A.ia.p, A.ja.p, A.a.p, B.ia.p, B.ja.p, B.a.p, Cia, Cja, Ca);
-    if (hc[1][0])
-      spgemm_accum_k<64, 128><<<grid_for(((long long)hc[1][0] + 3) / 4), BLK, 0, s>>>(
-          hc[1][0], small2, A.ia.p, A.ja.p, A.a.p, B.ia.p, B.ja.p, B.a.p, Cia, Cja, Ca);
-    if (hc[1][1])
-      spgemm_accum_k<64, 512><<<grid_for(((long long)hc[1][1] + 3) / 4), BLK, 0, s>>>(
-          hc[1][1], big2, A.ia.p, A.ja.p, A.a.p, B.ia.p, B.ja.p, B.a.p, Cia, Cja, Ca);
+    if (hc[0])
+      spgemm_accum_k<16, 32><<<grid_for(((long long)hc[0] + 15) / 16), BLK, 0, s>>>(
+          hc[0], s1, A.ia.p, A.ja.p, A.a.p, B.ia.p, B.ja.p, B.a.p, Cia, Cja, Ca);
+    if (hc[1])
+      spgemm_accum_k<16, 128><<<grid_for(((long long)hc[1] + 15) / 16), BLK, 0, s>>>(
+          hc[1], b1, A.ia.p, A.ja.p, A.a.p, B.ia.p, B.ja.p, B.a.p, Cia, Cja, Ca);
+    if (hc[2])
+      spgemm_accum_k<64, 128><<<grid_for(((long long)hc[2] + 3) / 4), BLK, 0, s>>>(
+          hc[2], s2, A.ia.p, A.ja.p, A.a.p, B.ia.p, B.ja.p, B.a.p, Cia, Cja, Ca);
+    if (hc[3])
+      spgemm_accum_k<64, 512><<<grid_for(((long long)hc[3] + 3) / 4), BLK, 0, s>>>(
+          hc[3], b2, A.ia.p, A.ja.p, A.a.p, B.ia.p, B.ja.p, B.a.p, Cia, Cja, Ca);
+    if (hc[4])
+      spgemm_accum_k<64, 128><<<grid_for(((long long)hc[4] + 3) / 4), BLK, 0, s>>>(
+          hc[4], s3, A.ia.p, A.ja.p, A.a.p, B.ia.p, B.ja.p, B.a.p, Cia, Cja, Ca);
+    if (hc[6])
+      spgemm_accum_k<64, 512><<<grid_for(((long long)hc[6] + 3) / 4), BLK, 0, s>>>(
+          hc[6], m3, A.ia.p, A.ja.p, A.a.p, B.ia.p, B.ja.p, B.a.p, Cia, Cja, Ca);
+    if (hc[7])
+      spgemm_block_k<true><<<(unsigned)std::min(hc[7], block_grid), BLK, 0, s>>>(
+          hc[7], g3, T, B.ncols, S_hint, gscratch, scratch_per_block, A.ia.p, A.ja.p, A.a.p, B.ia.p, B.ja.p, B.a.p, nout,
+          Cia, Cja, Ca);
     MI_HIP(hipGetLastError());
     MI_HIP(hipStreamSynchronize(s));  // `part` is released on return
   } else {
@@ -1742,7 +1763,7 @@ void launch_bins(const Bins &bins, const int *rows, const int *T, int S_hint, co
       spgemm_group_k<64, 512, NUMERIC><<<grid_for(((long long)n2 + 3) / 4), BLK, 0, s>>>(
           n2, rows + bins.start[2], std::min(S_hint, 64), A.ia.p, A.ja.p, A.a.p, B.ia.p, B.ja.p, B.a.p, nout, Cia, Cja, Ca);
   }
-  if (n3)
+  if (n3 && !(NUMERIC && accum))
     spgemm_block_k<NUMERIC><<<(unsigned)std::min(n3, block_grid), BLK, 0, s>>>(
         n3, rows + bins.start[3], T, B.ncols, S_hint, gscratch, scratch_per_block, A.ia.p, A.ja.p, A.a.p, B.ia.p,
         B.ja.p, B.a.p, nout, Cia, Cja, Ca);
