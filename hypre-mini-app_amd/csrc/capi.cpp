@@ -1327,6 +1327,31 @@ HYPRE_Int HYPRE_MI_BoomerAMGPoisonWorkVectors(HYPRE_Solver solver) {
 // dev_alloc / dev_free, every live block filled with its own byte pattern and checked before it is released -- two
 // blocks that overlap, a block handed out twice or a trim that unmaps live memory show up as a wrong byte (or a fault).
 // Returns the number of blocks that were verified; *peak_bytes = the most bytes live at once.
+HYPRE_Int HYPRE_MI_TileScheduleCheck(HYPRE_Int n, const HYPRE_BigInt *row_ptr, HYPRE_Int row_cap, HYPRE_Int tile_entries,
+                                     HYPRE_Int *ntiles, HYPRE_Int *mismatch) {
+  API_BEGIN
+  ensure_init();
+  MI_REQUIRE(n >= 0 && row_ptr && mismatch, "TileScheduleCheck: arguments");
+  MI_REQUIRE(tile_entries == k::SPMV_TILE || tile_entries == k::SPMV_TILE_WIDE, "TileScheduleCheck: tile_entries is 2048 or 4096");
+  static_assert(sizeof(HYPRE_BigInt) == sizeof(long long), "row pointer width");
+  bool aligned_h = true, aligned_d = true;
+  const std::vector<int> host = k::build_row_blocks((int)n, reinterpret_cast<const int64_t *>(row_ptr), &aligned_h, (int)row_cap,
+                                                    (int)tile_entries);
+  DVec<long long> ia((size_t)n + 1);
+  MI_HIP(hipMemcpy(ia.p, row_ptr, ((size_t)n + 1) * sizeof(long long), hipMemcpyHostToDevice));
+  DVec<int> rb;
+  std::vector<int> dev;
+  sk::tile_schedule_device((int)n, ia.p, (int)row_cap, (int)tile_entries, rb, dev, aligned_d, ctx().stream);
+  if (ntiles) *ntiles = (HYPRE_Int)host.size() - 1;
+  *mismatch = 0;
+  const size_t m = std::min(host.size(), dev.size());
+  for (size_t t = 0; t < m && !*mismatch; t++)
+    if (host[t] != dev[t]) *mismatch = (HYPRE_Int)t + 1;
+  if (!*mismatch && host.size() != dev.size()) *mismatch = (HYPRE_Int)m + 1;
+  if (!*mismatch && aligned_h != aligned_d) *mismatch = (HYPRE_Int)m + 2;
+  API_END
+}
+
 HYPRE_Int HYPRE_MI_ArenaSelfTest(HYPRE_Int seed, HYPRE_Int rounds, HYPRE_BigInt max_block_bytes, HYPRE_BigInt *verified,
                                  HYPRE_BigInt *peak_bytes) {
   API_BEGIN

@@ -46,8 +46,10 @@ inline int prof_level(int base, int level) { return level < PROF_LEVELS ? base +
 // operator (1 GB of them per operator at 512^3, copied over PCIe first); the price is one underfull tile per 8192 rows.
 // tile_end(): one step of the schedule, shared by the host routine and the device kernel.
 constexpr int TILE_SUPER_ROWS = 8192;
+// (ia: anything indexable by a row that yields its first entry -- the row pointers themselves, or the device kernel's
+// staged copy of a super-block's chunk boundaries)
 template <class IA>
-__host__ __device__ inline int tile_end(int r, int limit, const IA *ia, int row_cap, int block_rows, int tile_entries,
+__host__ __device__ inline int tile_end(int r, int limit, const IA &ia, int row_cap, int block_rows, int tile_entries,
                                         bool &aligned) {
   const long long start = (long long)ia[r];
   int e = r;
@@ -63,6 +65,47 @@ __host__ __device__ inline int tile_end(int r, int limit, const IA *ia, int row_
     // keep one slot of slack for the aligned-pair start
     while (e < limit && e - r < row_cap && (long long)ia[e + 1] - start <= tile_entries - 1) e++;
     if (e == r) e = r + 1;  // a single row longer than the tile
+  }
+  return e;
+}
+// The same step by bisection (the device schedule, sk::to_solve_format): the entry counts ascend with the row, so "as many
+// whole chunks / rows as fit" is the last candidate end whose count fits -- ~10 dependent reads per tile instead of one
+// per chunk or per row (SpMV-only operators are scheduled row by row: 8192 dependent reads per super-block, 8 ms per
+// launch at 512^3).  tests/test_gpu_kernels.py compares the two on random row lengths (HYPRE_MI_TileScheduleCheck).
+template <class IA>
+__host__ __device__ inline int tile_end_bisect(int r, int limit, const IA &ia, int row_cap, int block_rows, int tile_entries,
+                                               bool &aligned) {
+  const long long start = (long long)ia[r];
+  const long long room = (long long)tile_entries - 1;
+  int e = r;
+  if ((r & 7) == 0 && row_cap <= block_rows) {
+    // candidate ends e_m = min(r + 8 m, limit), m = 1 .. M (the iterations the loop above can make)
+    const int by_cap = (row_cap + 7) / 8, by_rows = (limit - r + 7) / 8;
+    const int M = by_cap < by_rows ? by_cap : by_rows;
+    int lo = 0, hi = M;  // the answer m lies in [lo, hi]; m = 0: not even one chunk
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      const int em = (r + 8 * mid < limit) ? r + 8 * mid : limit;
+      if ((long long)ia[em] - start <= room)
+        lo = mid;
+      else
+        hi = mid - 1;
+    }
+    if (lo > 0) e = (r + 8 * lo < limit) ? r + 8 * lo : limit;
+  }
+  if (e == r) {
+    aligned = false;
+    const int top = ((long long)r + row_cap < (long long)limit) ? r + row_cap : limit;
+    int lo = r, hi = top;  // the last e in [r, top] with ia[e] - start <= room (e = r always qualifies)
+    while (lo < hi) {
+      const int mid = (int)(((long long)lo + hi + 1) >> 1);
+      if ((long long)ia[mid] - start <= room)
+        lo = mid;
+      else
+        hi = mid - 1;
+    }
+    e = lo;
+    if (e == r) e = r + 1;
   }
   return e;
 }

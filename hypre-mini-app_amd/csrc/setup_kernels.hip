@@ -1796,7 +1796,7 @@ __global__ __launch_bounds__(BLK) void tile_schedule_k(int n, int nsb, const lon
   int c = 0;
   long long w = FILL ? start[sb] + 1 : 0;
   while (r < limit) {
-    const int e = k::tile_end(r, limit, ia, row_cap, block_rows, tile_entries, aligned);
+    const int e = k::tile_end_bisect(r, limit, ia, row_cap, block_rows, tile_entries, aligned);
     if (FILL) rb[w++] = e;
     c++;
     r = e;
@@ -1805,6 +1805,39 @@ __global__ __launch_bounds__(BLK) void tile_schedule_k(int n, int nsb, const lon
   if (!FILL && !aligned) *unaligned = 1;
 }
 }  // namespace
+
+// k::build_row_blocks on the device: rb (device) and blocks (host) = the tile boundaries, aligned = every tile starts on
+// a multiple of 8 rows and was cut at whole chunks
+void tile_schedule_device(int n, const long long *ia, int row_cap_in, int tile_entries, DVec<int> &rb,
+                          std::vector<int> &blocks, bool &aligned, hipStream_t s) {
+  const int block_rows = tile_entries == k::SPMV_TILE_WIDE ? k::SPMV_BLOCK_WIDE : k::SPMV_BLOCK;
+  const int row_cap = std::max(row_cap_in, block_rows);
+  const int nsb = (int)(((long long)n + k::TILE_SUPER_ROWS - 1) / k::TILE_SUPER_ROWS);
+  aligned = true;
+  if (nsb > 0) {
+    DVec<int> cnt((size_t)nsb), unal(1);
+    DVec<long long> st((size_t)nsb + 1);
+    MI_HIP(hipMemsetAsync(unal.p, 0, sizeof(int), s));
+    const unsigned g = (unsigned)((nsb + BLK - 1) / BLK);
+    tile_schedule_k<false><<<g, BLK, 0, s>>>(n, nsb, ia, row_cap, block_rows, tile_entries, cnt.p, nullptr, nullptr, unal.p);
+    exclusive_scan(cnt.p, st.p, nsb, s);
+    long long nt = 0;
+    int un = 0;
+    d2h(&nt, st.p + nsb, sizeof(long long), s);
+    d2h(&un, unal.p, sizeof(int), s);
+    MI_HIP(hipStreamSynchronize(s));
+    aligned = un == 0;
+    rb.alloc((size_t)nt + 1);
+    MI_HIP(hipMemsetAsync(rb.p, 0, sizeof(int), s));
+    tile_schedule_k<true><<<g, BLK, 0, s>>>(n, nsb, ia, row_cap, block_rows, tile_entries, nullptr, st.p, rb.p, nullptr);
+    blocks.resize((size_t)nt + 1);
+    d2h(blocks.data(), rb.p, ((size_t)nt + 1) * sizeof(int), s);
+    MI_HIP(hipStreamSynchronize(s));
+  } else {
+    blocks.assign(1, 0);
+    rb.upload(blocks);
+  }
+}
 
 void to_solve_format(DCsr &src, DevCSR &dst, hipStream_t s) {
   const int n = src.nrows;
@@ -1835,39 +1868,12 @@ void to_solve_format(DCsr &src, DevCSR &dst, hipStream_t s) {
       }
     }
   }
-  // greedy row-block schedule, super-block by super-block on the device (k::tile_end; round 3 copied the row pointers
-  // to the host -- 1 GB per operator of 134 M rows -- and walked them there)
+  // greedy row-block schedule, super-block by super-block on the device (round 3 copied the row pointers to the host --
+  // 1 GB per operator of 134 M rows -- and walked them there)
   bool aligned = true;
   dst.tile_entries = k::choose_tile_entries(dst.nnz, n);
   std::vector<int> blocks;
-  {
-    const int block_rows = dst.tile_entries == k::SPMV_TILE_WIDE ? k::SPMV_BLOCK_WIDE : k::SPMV_BLOCK;
-    const int row_cap = std::max(dst.row_cap, block_rows);
-    const int nsb = (int)(((long long)n + k::TILE_SUPER_ROWS - 1) / k::TILE_SUPER_ROWS);
-    if (nsb > 0) {
-      DVec<int> cnt((size_t)nsb), unal(1);
-      DVec<long long> st((size_t)nsb + 1);
-      MI_HIP(hipMemsetAsync(unal.p, 0, sizeof(int), s));
-      const unsigned g = (unsigned)((nsb + BLK - 1) / BLK);
-      tile_schedule_k<false><<<g, BLK, 0, s>>>(n, nsb, src.ia.p, row_cap, block_rows, dst.tile_entries, cnt.p, nullptr, nullptr, unal.p);
-      exclusive_scan(cnt.p, st.p, nsb, s);
-      long long nt = 0;
-      int un = 0;
-      d2h(&nt, st.p + nsb, sizeof(long long), s);
-      d2h(&un, unal.p, sizeof(int), s);
-      MI_HIP(hipStreamSynchronize(s));
-      aligned = un == 0;
-      dst.rb.alloc((size_t)nt + 1);
-      MI_HIP(hipMemsetAsync(dst.rb.p, 0, sizeof(int), s));
-      tile_schedule_k<true><<<g, BLK, 0, s>>>(n, nsb, src.ia.p, row_cap, block_rows, dst.tile_entries, nullptr, st.p, dst.rb.p, nullptr);
-      blocks.resize((size_t)nt + 1);
-      d2h(blocks.data(), dst.rb.p, ((size_t)nt + 1) * sizeof(int), s);
-      MI_HIP(hipStreamSynchronize(s));
-    } else {
-      blocks.assign(1, 0);
-      dst.rb.upload(blocks);
-    }
-  }
+  tile_schedule_device(n, src.ia.p, dst.row_cap, dst.tile_entries, dst.rb, blocks, aligned, s);
   if (dst.row_cap > (dst.tile_entries == k::SPMV_TILE_WIDE ? k::SPMV_BLOCK_WIDE : k::SPMV_BLOCK)) aligned = false;  // such tiles are not for the tile Gauss-Seidel kernel
   dst.nblocks = (int)blocks.size() - 1;
   dst.rb_host = blocks;

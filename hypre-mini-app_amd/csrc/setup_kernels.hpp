@@ -74,6 +74,10 @@ void extract_rows(const DCsr &A, const int *rows, int nout, const int *colpos, D
 // schedule and x cache of the SpMV (DevCSR::upload builds the same from host arrays).  src's column and
 // value arrays are MOVED into dst; only the row pointers travel to the host (for the greedy block schedule).
 void to_solve_format(DCsr &src, DevCSR &dst, hipStream_t s);
+// its tile schedule alone (k::build_row_blocks on the device, one thread per super-block, k::tile_end_bisect): rb on the
+// device, blocks on the host, aligned = all tiles start on a multiple of 8 rows and were cut at whole chunks
+void tile_schedule_device(int n, const long long *ia, int row_cap, int tile_entries, DVec<int> &rb, std::vector<int> &blocks,
+                          bool &aligned, hipStream_t s);
 // the host buffer to_solve_format keeps between calls goes back to the system (end of a setup)
 void release_host_scratch();
 // The part of a C-first ordered square block (C points = indices < nc) that a FIRST relaxation sweep on a

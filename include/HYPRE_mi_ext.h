@@ -77,6 +77,12 @@ HYPRE_Int HYPRE_MI_SetZeroGuessMode(HYPRE_Int mode);
 /* test hook: fill every level's solution / scratch vectors with NaN (a zero-guess cycle that skips its zero-fills must
  * not read them) */
 HYPRE_Int HYPRE_MI_BoomerAMGPoisonWorkVectors(HYPRE_Solver solver);
+/* test hook: the tile schedule of an operator with the given row pointers (host, n + 1 entries), built by the device
+ * routine of the setup (bisection per tile) and by the host routine (the plain greedy loop); *mismatch = 0 when the two
+ * agree tile by tile and in the chunk-alignment flag, else 1 + the index of the first tile that differs; *ntiles = the
+ * host's tile count.  row_cap: 256 (operators a Gauss-Seidel kernel sweeps) ... 1024 (SpMV only); tile_entries: 2048 / 4096 */
+HYPRE_Int HYPRE_MI_TileScheduleCheck(HYPRE_Int n, const HYPRE_BigInt *row_ptr, HYPRE_Int row_cap, HYPRE_Int tile_entries,
+                                     HYPRE_Int *ntiles, HYPRE_Int *mismatch);
 /* test hook: a seeded storm of device allocations / releases of every size through the library's allocator (arena, block
  * cache or plain, whatever MI_HYPRE_POOL says), every block pattern-filled and checked before its release */
 HYPRE_Int HYPRE_MI_ArenaSelfTest(HYPRE_Int seed, HYPRE_Int rounds, HYPRE_BigInt max_block_bytes, HYPRE_BigInt *verified,

@@ -155,3 +155,37 @@ def test_device_arena_allocation_storm(mi, seed, rounds, max_block):
     mi.call("HYPRE_MI_GetCounter", b"arena_in_use_bytes", mi.C.byref(v))
     assert v.value == before
 
+
+
+@pytest.mark.parametrize("case", ["short", "long_wide", "spmv_only", "with_giants", "empty_rows", "ragged_end", "tiny"])
+def test_device_tile_schedule_equals_the_host_loop(mi, case):
+    """The setup cuts every operator into tiles on the device, one thread per super-block of 8192 rows, each tile end found
+    by bisection on the row pointers (k::tile_end_bisect); the host routine (small operators, and the definition) walks
+    chunk by chunk / row by row (k::tile_end).  Same tiles, same chunk-alignment flag, on seeded row lengths of every
+    kind the hierarchy produces: 3-8 entries per row, 100-300 with 4096-entry tiles, SpMV-only operators (up to 1024 rows
+    per tile, row granularity), rows longer than a tile, empty rows, a row count that is no multiple of 8 or 8192."""
+    rng = np.random.default_rng({"short": 1, "long_wide": 2, "spmv_only": 3, "with_giants": 4, "empty_rows": 5,
+                                 "ragged_end": 6, "tiny": 7}[case])
+    row_cap, tile = 256, 2048
+    if case == "short":
+        lens = rng.integers(3, 9, size=200_003)
+    elif case == "long_wide":
+        lens, row_cap, tile = rng.integers(100, 301, size=40_000), 512, 4096
+    elif case == "spmv_only":
+        lens, row_cap = rng.integers(1, 5, size=150_001), 1024
+    elif case == "with_giants":
+        lens = rng.integers(5, 60, size=60_000)
+        lens[rng.integers(0, lens.size, size=200)] = rng.integers(2048, 9000, size=200)
+    elif case == "empty_rows":
+        lens = rng.integers(0, 3, size=90_000) * rng.integers(0, 40, size=90_000)
+    elif case == "ragged_end":
+        lens = rng.integers(20, 90, size=8192 * 3 + 5)
+    else:
+        lens = rng.integers(1, 10, size=13)
+    ia = np.zeros(lens.size + 1, dtype=np.int64)
+    np.cumsum(lens, out=ia[1:])
+    nt, bad = mi.c_int(), mi.c_int()
+    mi.call("HYPRE_MI_TileScheduleCheck", int(lens.size), ia.ctypes.data_as(mi.C.POINTER(mi.C.c_longlong)), row_cap, tile,
+            mi.C.byref(nt), mi.C.byref(bad))
+    assert bad.value == 0, f"first differing tile (1-based): {bad.value} of {nt.value}"
+    assert nt.value >= max(1, lens.size // 1024)
