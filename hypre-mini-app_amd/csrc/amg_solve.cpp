@@ -491,7 +491,10 @@ void BoomerAMG::build_collapsed_tail() {
   collapsed_Bt.release();
   collapsed_Bt2.release();
   static const long long max_rows = getenv("MI_HYPRE_DENSE_TAIL_ROWS") ? atoll(getenv("MI_HYPRE_DENSE_TAIL_ROWS")) : 1024;
-  static const long long max_rows2 = getenv("MI_HYPRE_DENSE_TAIL_ROWS2") ? atoll(getenv("MI_HYPRE_DENSE_TAIL_ROWS2")) : 4608;
+  // (the second stage is an option since the end of round 4: tabulating the 4275 columns of level 7 at 512^3 costs 0.29 s of
+  // a 2.9 s setup and saves ~9 short launches per cycle, which the solve does not show -- 669.1 / 670.6 ms without against
+  // 670.0 / 672.2 ms with, alternating runs on one box)
+  static const long long max_rows2 = getenv("MI_HYPRE_DENSE_TAIL_ROWS2") ? atoll(getenv("MI_HYPRE_DENSE_TAIL_ROWS2")) : 0;
   if (max_rows <= 0 || my_comm().size != 1 || tail) return;
   const int nlev = (int)L.size();
   int lt = -1;

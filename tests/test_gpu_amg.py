@@ -827,12 +827,15 @@ def test_default_on_features_against_their_switches(n, stencil):
         assert r["iters"] == ref["iters"] and r["hist"] == ref["hist"] and r["x"] == ref["x"], env
         if "MI_HYPRE_POOL" in env:
             assert r["arena_mapped"] == 0, env
-    r = run(MI_HYPRE_DENSE_TAIL_ROWS=0)
-    assert r["iters"] == ref["iters"]
-    h0 = np.array([float.fromhex(h) for h in ref["hist"]])
-    h1 = np.array([float.fromhex(h) for h in r["hist"]])
-    assert np.allclose(h0, h1, rtol=1e-8, atol=0.0)
-    x0 = np.frombuffer(bytes.fromhex(ref["x"]), dtype=np.float64)
-    x1 = np.frombuffer(bytes.fromhex(r["x"]), dtype=np.float64)
-    assert np.abs(x0 - x1).max() < 1e-10
+    # no tail at all, and the optional second stage (the level above the collapsed one tabulated through its map: the
+    # default of rounds 3-4, an option since)
+    for env in ({"MI_HYPRE_DENSE_TAIL_ROWS": 0}, {"MI_HYPRE_DENSE_TAIL_ROWS2": 4608}):
+        r = run(**env)
+        assert r["iters"] == ref["iters"], env
+        h0 = np.array([float.fromhex(h) for h in ref["hist"]])
+        h1 = np.array([float.fromhex(h) for h in r["hist"]])
+        assert np.allclose(h0, h1, rtol=1e-8, atol=0.0), env
+        x0 = np.frombuffer(bytes.fromhex(ref["x"]), dtype=np.float64)
+        x1 = np.frombuffer(bytes.fromhex(r["x"]), dtype=np.float64)
+        assert np.abs(x0 - x1).max() < 1e-10, env
 
