@@ -727,8 +727,8 @@ def main():
             "expected_allreduce": (3 + m_it + m_it * (m_it + 1) // 2) if world > 1 else 0,
             "note": "halo_exchange counts neighbour exchanges (matvec + relaxation + transfer operators); matvec_overlapped / "
                     "gs_overlapped went beside the diag-block kernel on the side stream, gs_in_order did not; all zero on one rank.  "
-                    "Kernel launches are not counted in-process: a rocprofv3 trace of this workload on one GPU has 1191 launches per "
-                    "solve, 288 of them shorter than 25 us (3.4 ms together), and 0.35 ms per solve outside kernels "
+                    "Kernel launches are not counted in-process: a rocprofv3 trace of this workload on one GPU has 1324 launches per "
+                    "solve, 440 of them shorter than 25 us (4.7 ms together), and 0.35 ms per solve outside kernels "
                     "(RECORDED: profiles/r04_gaps_512.txt)",
         }
         if rehearsal:
