@@ -1073,6 +1073,48 @@ __global__ __launch_bounds__(BLOCK, 2048 / BLOCK) void gs_tile_k(int blk0, int n
   double uc[8];
 #pragma unroll
   for (int j = 0; j < 8; j++) uc[j] = __shfl(myu, gbase + j * LPR, 64);
+  // The phase is VALU throughput (profiles/r04_ablation_tile_kernels.txt: 16 steps x (8 double FMAs + update + cross-lane
+  // read) on every wave = a quarter of a pass).  Every lane forms ITS row's sum at every step although only row t's is
+  // used at step t; what can be shared without touching the order of the additions (S, then columns 0..7 ascending):
+  // * forward, rows above t already hold their new values when row t's turn comes, and they are the FIRST terms of its
+  //   sum: `acc` = S + the terms of the columns swept so far is carried along (one FMA per step), step t adds the 8 - t
+  //   remaining terms to a copy of it -- 44 instead of 64 FMAs.  (Backward the new values are the LAST terms; the prefix
+  //   over the old ones has a different length in every lane, and masking it costs what it saves: all 8 terms there.)
+  // * the row's own value at its step is uc[t] (the lane's copy of the chunk's values), so `myu` need not follow the
+  //   sweep: it is picked out of uc[] once at the end instead of a select per step.
+  // Same operations on the same operands for the row whose turn it is; the other lanes' results were never used.
+#if !defined(MI_GS_SHARED_PREFIX) || MI_GS_SHARED_PREFIX
+  if (!(MI_ABLATE & 8)) {
+    if (fwd) {
+      double acc = S;
+#pragma unroll
+      for (int t = 0; t < 8; t++) {
+        double sacc = acc;
+#pragma unroll
+        for (int j = t; j < 8; j++) sacc += crow[j] * uc[j];
+        const double nu2 = uc[t] + (myrhs - sacc) * wd;  // unselected rows: wd == 0
+        const double b = __shfl(nu2, gbase + t * LPR, 64);
+        uc[t] = b;
+        acc += crow[t] * b;
+      }
+    }
+    if (bwd) {
+#pragma unroll
+      for (int tt = 0; tt < 8; tt++) {
+        const int t = 7 - tt;
+        double sacc = S;
+#pragma unroll
+        for (int j = 0; j < 8; j++) sacc += crow[j] * uc[j];
+        const double nu2 = uc[t] + (myrhs - sacc) * wd;
+        uc[t] = __shfl(nu2, gbase + t * LPR, 64);
+      }
+    }
+    if (fwd || bwd) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) myu = (g == j) ? uc[j] : myu;
+    }
+  }
+#else
 #pragma unroll
   for (int dir = 0; dir < 2; dir++) {
     if ((MI_ABLATE & 8) || (dir == 0 ? !fwd : !bwd)) continue;
@@ -1088,6 +1130,7 @@ __global__ __launch_bounds__(BLOCK, 2048 / BLOCK) void gs_tile_k(int blk0, int n
       if (g == t) myu = b;
     }
   }
+#endif
   if (rl < nr && sub == 0) u_new[i] = myu;
 #undef UOLD
 }
