@@ -675,6 +675,17 @@ void *dev_alloc(size_t bytes) {
       if (!p)
         fail(2, "device arena: cannot map " + std::to_string(bytes) + " more bytes (" + std::to_string(A.mapped) +
                     " mapped, " + std::to_string(A.in_use) + " in use): out of device memory");
+      // MI_HYPRE_POISON_ALLOC=1 (debugging / tests): every block is handed out full of 0xFF bytes -- NaN as a double, -1 as
+      // an integer.  A chunk is zero the first time it is used (the driver clears it) and holds its last owner's data ever
+      // after, so code that reads memory it has not written works in a short test and fails in a long run; with the
+      // poison it fails at once.  (Synchronous: the block's last owner was drained by A.alloc when that was needed.)
+      static const bool poison = getenv("MI_HYPRE_POISON_ALLOC") && atoi(getenv("MI_HYPRE_POISON_ALLOC")) != 0;
+      if (poison && bytes) {
+        g.unlock();
+        drain_library_streams();
+        MI_HIP(hipMemset(p, 0xFF, bytes));
+        MI_HIP(hipDeviceSynchronize());
+      }
       return p;
     }
     P.enabled = 1;  // no virtual-memory API here: the size-class cache

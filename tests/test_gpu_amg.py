@@ -839,3 +839,29 @@ def test_default_on_features_against_their_switches(n, stencil):
         x1 = np.frombuffer(bytes.fromhex(r["x"]), dtype=np.float64)
         assert np.abs(x0 - x1).max() < 1e-10, env
 
+
+
+@pytest.mark.parametrize("n,stencil", [(40, 7), (24, 27)])
+def test_nothing_reads_memory_it_has_not_written(n, stencil):
+    """The device arena hands out driver-cleared memory the first time a chunk is used and the last owner's data ever
+    after, so code that relies on zeros it never wrote passes a short test and fails in a long run.  With
+    MI_HYPRE_POISON_ALLOC=1 every block comes full of 0xFF bytes (NaN / -1): the same setup (device kernels on every level
+    above 500 rows) and the same solve, bit for bit, as without."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(**env):
+        e = dict(os.environ, MI_HYPRE_DEVICE_SETUP_MIN_ROWS="500", **{k: str(v) for k, v in env.items()})
+        p = subprocess.run([sys.executable, os.path.join(root, "tests", "env_worker.py"), str(n), str(stencil)], env=e,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert p.returncode == 0, p.stdout[-3000:]
+        line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
+        return json.loads(line[len("RESULT "):])
+
+    ref = run()
+    r = run(MI_HYPRE_POISON_ALLOC=1)
+    assert r["iters"] == ref["iters"] and r["levels"] == ref["levels"]
+    assert r["hist"] == ref["hist"] and r["x"] == ref["x"]
