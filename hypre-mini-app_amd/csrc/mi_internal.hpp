@@ -11,6 +11,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 namespace mi {
@@ -85,12 +86,16 @@ struct DVec {
     if (p) dev_free((void *)p);
     p = nullptr, n = 0;
   }
-  // pad elements are allocated and zeroed past n (kernels read whole vectors of 2)
+  // pad elements are allocated past n (kernels read whole vectors of 2).  Floating-point arrays get them ZEROED: the
+  // BLAS-1 kernels run over pairs and include the element past an odd n in their sums.  Integer arrays (row pointers,
+  // columns, lists, marks, the setup's temporaries -- four fifths of the ~2400 allocations of a 512^3 setup) only need the
+  // pad to exist: every kernel that loads them in pairs masks the element past the end (a launch and a synchronisation
+  // per allocation was 0.1 s of a 2.6 s setup).  MI_HYPRE_POISON_ALLOC=1 fills them with 0xFF in the tests.
   void alloc(size_t n_, size_t pad = 2) {
     release();
     n = n_;
     p = (T *)dev_alloc((n + pad) * sizeof(T));
-    if (pad) {  // finished before any stream can touch the allocation
+    if (pad && std::is_floating_point<T>::value) {  // finished before any stream can touch the allocation
       MI_HIP(hipMemsetAsync((void *)(p + n), 0, pad * sizeof(T), nullptr));
       MI_HIP(hipStreamSynchronize(nullptr));
     }
