@@ -712,8 +712,8 @@ __global__ __launch_bounds__(BT) void interp_group_k(int nlist, const int *__res
                                                      const long long *__restrict__ slack_ia, int *__restrict__ Pj,
                                                      double *__restrict__ Pa, int *__restrict__ len_out) {
   constexpr int H = 2 * CAP;
-  constexpr int LOGH = (H == 64) ? 6 : (H == 256) ? 8 : (H == 1024) ? 10 : 11;
-  static_assert(H == 64 || H == 256 || H == 1024 || H == 2048, "table size");
+  constexpr int LOGH = (H == 32) ? 5 : (H == 64) ? 6 : (H == 256) ? 8 : (H == 1024) ? 10 : 11;
+  static_assert(H == 32 || H == 64 || H == 256 || H == 1024 || H == 2048, "table size");
   constexpr int GP = BT / G;
   __shared__ InterpGroup<CAP> grp[GP];
   InterpGroup<CAP> &L = grp[threadIdx.x / G];
@@ -2371,10 +2371,29 @@ bool interp(const DCsr &A, const DCsr &S, DVec<int> &cf, int interp_type, double
     interp_group_k<256, 1024, 256><<<grid_for(n3), 256, 0, s>>>(
         n3, rows.p + bins.start[3], ext, A.ia.p, A.ja.p, A.a.p, S.ia.p, S.ja.p, cf.p, f2c.p, trunc_factor, pmax,
         slack_ia.p, sj.p, sa.p, len.p);
-  if (n0)
-    interp_group_k<8, 32, 256><<<grid_for(((long long)n0 + 31) / 32), 256, 0, s>>>(
-        n0, rows.p + bins.start[0], ext, A.ia.p, A.ja.p, A.a.p, S.ia.p, S.ja.p, cf.p, f2c.p, trunc_factor, pmax,
-        slack_ia.p, sj.p, sa.p, len.p);
+  if (n0) {
+    // the kernel's rows in flight are bounded by LDS (1.5 KB per row with 32-entry tables: 3 workgroups per CU), and what a
+    // row costs is ~30 dependent round trips: rows with at most 16 candidates (C points, rows of a 7-point operator) take
+    // half-size tables = twice the rows in flight
+    DVec<int> part0((size_t)2 * (size_t)n0 + 2);
+    int *cnt0 = part0.p + 2 * (size_t)n0;
+    int h0[2] = {0, 0};
+    MI_HIP(hipMemsetAsync(cnt0, 0, 2 * sizeof(int), s));
+    split_rows_k<<<grid_for(((long long)n0 + BLK - 1) / BLK), BLK, 0, s>>>(n0, rows.p + bins.start[0], T.p, 16, part0.p,
+                                                                         part0.p + n0, cnt0);
+    d2h(h0, cnt0, sizeof(h0), s);
+    MI_HIP(hipStreamSynchronize(s));
+    if (h0[0])
+      interp_group_k<8, 16, 256><<<grid_for(((long long)h0[0] + 31) / 32), 256, 0, s>>>(
+          h0[0], part0.p, ext, A.ia.p, A.ja.p, A.a.p, S.ia.p, S.ja.p, cf.p, f2c.p, trunc_factor, pmax, slack_ia.p, sj.p,
+          sa.p, len.p);
+    if (h0[1])
+      interp_group_k<8, 32, 256><<<grid_for(((long long)h0[1] + 31) / 32), 256, 0, s>>>(
+          h0[1], part0.p + n0, ext, A.ia.p, A.ja.p, A.a.p, S.ia.p, S.ja.p, cf.p, f2c.p, trunc_factor, pmax, slack_ia.p,
+          sj.p, sa.p, len.p);
+    MI_HIP(hipGetLastError());
+    MI_HIP(hipStreamSynchronize(s));  // part0 is released at the end of this block
+  }
   if (n1)
     interp_group_k<16, 128, 128><<<grid_for(((long long)n1 + 7) / 8), 128, 0, s>>>(
         n1, rows.p + bins.start[1], ext, A.ia.p, A.ja.p, A.a.p, S.ia.p, S.ja.p, cf.p, f2c.p, trunc_factor, pmax,
