@@ -454,6 +454,20 @@ int pow2_at_most(double v, int cap) {
 }
 
 
+// value of lane gbase + q of the wave (q a compile-time constant of an unrolled loop): a group that is the whole wave reads
+// it through a scalar register (v_readlane, no LDS crossbar), smaller groups shuffle
+template <int G>
+__device__ __forceinline__ double group_value(double v, int gbase, int q) {
+  if (G == 64) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), q);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), q);
+    return __hiloint2double(hi, lo);
+  }
+  return __shfl(v, gbase + q, 64);
+}
+// bit gbase + q of a ballot
+__device__ __forceinline__ bool ballot_bit(unsigned long long m, int pos) { return (m >> pos) & 1ull; }
+
 // ---------------------------------------------------------------- strength of connection
 // G lanes share one row (G = 1 for short rows: thread per row).  With one thread per row a wave touches 64 rows
 // whose entries are row-length x 12 B apart: on the 30-150-entry rows of the coarse levels every load fetched a
@@ -485,13 +499,17 @@ __global__ __launch_bounds__(BLK) void strength_k(int n, const long long *__rest
       scale_pos = fmax(scale_pos, v);
       scale_neg = fmin(scale_neg, v);
     }
+    // the row sum in stored order: every lane adds the G values one after the other.  Only the value travels per step
+    // (round 4: the diagonal flag travelled too, by a third cross-lane read per step); which of them is the diagonal
+    // comes out of one ballot.
+    const unsigned long long dmask = (G > 1) ? __ballot(isd) : 0ull;
+    const int rem = (int)((k1 - k0 - t) < (long long)G ? (k1 - k0 - t) : (long long)G);  // entries of this batch
 #pragma unroll
     for (int q = 0; q < G; q++) {
-      const double vq = (G > 1) ? __shfl(v, gbase + q, 64) : v;
-      const int dq = (G > 1) ? __shfl((int)isd, gbase + q, 64) : (int)isd;
-      if (k0 + t + q < k1) {
+      const double vq = (G > 1) ? group_value<G>(v, gbase, q) : v;
+      if (q < rem) {
         row_sum += vq;
-        if (dq) diag = vq;
+        if ((G > 1) ? ballot_bit(dmask, gbase + q) : isd) diag = vq;
       }
     }
   }
@@ -1447,15 +1465,27 @@ __global__ __launch_bounds__(BLK) void level_norms_k(int n, const long long *__r
         h = 0.5 * fabs(v);
     }
     const bool isd = ok && j == i;
+    // in stored order: every lane adds the G values one after the other.  Only the value travels per step; which
+    // entries are the diagonal / count half comes out of ballots (round 4: h and the flag travelled too, five
+    // cross-lane reads per step), and h is recomputed from the value: |v| resp. |v| / 2, the same bits.
+    const bool half = ok && !isd && h != 0.0;
+    const unsigned long long dmask = (G > 1) ? __ballot(isd) : 0ull;
+    const unsigned long long hmask = (G > 1) ? __ballot(half) : 0ull;
+    const int rem = (int)((k1 - k0 - t) < (long long)G ? (k1 - k0 - t) : (long long)G);
 #pragma unroll
     for (int q = 0; q < G; q++) {
-      const double vq = (G > 1) ? __shfl(v, gbase + q, 64) : v;
-      const double hq = (G > 1) ? __shfl(h, gbase + q, 64) : h;
-      const int dq = (G > 1) ? __shfl((int)isd, gbase + q, 64) : (int)isd;
-      if (k0 + t + q < k1) {
-        full += fabs(vq);
-        if (dq) d = vq;
-        if (hq != 0.0) l1 += hq;  // the host adds only the contributing entries, in stored order
+      const double vq = (G > 1) ? group_value<G>(v, gbase, q) : v;
+      if (q < rem) {
+        const bool dq = (G > 1) ? ballot_bit(dmask, gbase + q) : isd;
+        const bool hq = (G > 1) ? ballot_bit(hmask, gbase + q) : half;
+        const double av = fabs(vq);
+        full += av;
+        if (dq) {
+          d = vq;
+          if (av != 0.0) l1 += av;  // the host adds only the contributing entries, in stored order
+        } else if (hq) {
+          l1 += 0.5 * av;
+        }
       }
     }
   }
