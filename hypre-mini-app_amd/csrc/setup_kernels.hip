@@ -696,7 +696,7 @@ struct InterpGroup {
   double rv[CAP];
   double sfsum[CAP];
   signed char sfsgn[CAP];
-  int cnt, nkept;
+  int cnt, nkept, nkeys;  // nkeys: distinct candidates so far (TRY instantiations only)
   double diag, scale;
 };
 
@@ -721,7 +721,12 @@ __device__ __forceinline__ int ig_find(const int *hkey, int key) {
     if (work && lane == 0) len_out[i] = 0;         \
     return;                                        \
   }
-template <int G, int CAP, int BT>
+// TRY: the tables are SMALLER than the row's bound (the bound counts candidates with their multiplicity -- 60-100 for a
+// row of a 27-point operator that ends with ~20 distinct ones -- and LDS per row is what limits the rows in flight): the
+// row is given up as soon as it turns out not to fit (more than CAP distinct candidates, or more than CAP strong
+// connections) and marked len_out = -1; the caller runs the marked rows through the instantiation sized by the bound.
+// A row that fits gives the same result either way (nothing below depends on the table size).
+template <int G, int CAP, int BT, bool TRY = false>
 __global__ __launch_bounds__(BT) void interp_group_k(int nlist, const int *__restrict__ rows, int ext,
                                                      const long long *__restrict__ Aia, const int *__restrict__ Aja,
                                                      const double *__restrict__ Aa, const long long *__restrict__ Sia,
@@ -756,11 +761,12 @@ __global__ __launch_bounds__(BT) void interp_group_k(int nlist, const int *__res
     L.hkey[t] = EMPTY;
     L.hval[t] = 0x7fffffff;
   }
-  if (lane == 0) L.cnt = 0;
+  if (lane == 0) L.cnt = 0, L.nkeys = 0;
   group_sync<G>();
   const long long s0 = work ? Sia[i] : 0, s1 = work ? Sia[i + 1] : 0;
+  const bool too_long = TRY && (s1 - s0 > (long long)CAP);  // the per-connection arrays hold CAP entries
   // ---- 1. interpolatory set with discovery positions
-  if (work) {
+  if (work && !too_long) {
     for (long long k = s0 + lane; k < s1; k += G) {
       const int i1 = Sja[k];
       const int c1 = cf[i1];
@@ -768,9 +774,18 @@ __global__ __launch_bounds__(BT) void interp_group_k(int nlist, const int *__res
       auto put = [&](int key, int seq) {
         const unsigned mask = (1u << LOGH) - 1u;
         unsigned sl = ((unsigned)key * 2654435761u) >> (32 - LOGH);
+        if (TRY) {
+          // at most CAP + G keys ever enter the table of 2 CAP slots (every lane looks at the count before it inserts),
+          // so the probe below always meets the key or a free slot
+          if (*(volatile int *)&L.nkeys > CAP) return;
+        }
         while (true) {
           const int old = atomicCAS(&L.hkey[sl], EMPTY, key);
-          if (old == EMPTY || old == key) break;
+          if (old == EMPTY) {
+            if (TRY) atomicAdd(&L.nkeys, 1);
+            break;
+          }
+          if (old == key) break;
           sl = (sl + 1u) & mask;
         }
         atomicMin(&L.hval[sl], seq);
@@ -795,6 +810,10 @@ __global__ __launch_bounds__(BT) void interp_group_k(int nlist, const int *__res
     }
   }
   group_sync<G>();
+  if (TRY && work && (too_long || L.nkeys > CAP)) {  // does not fit: the caller's second launch takes the row
+    if (lane == 0) len_out[i] = -1;
+    return;
+  }
   INTERP_STOP_AFTER(1)
   // ---- 2. compaction
   if (work)
@@ -2424,10 +2443,36 @@ bool interp(const DCsr &A, const DCsr &S, DVec<int> &cf, int interp_type, double
     MI_HIP(hipGetLastError());
     MI_HIP(hipStreamSynchronize(s));  // part0 is released at the end of this block
   }
-  if (n1)
-    interp_group_k<16, 128, 128><<<grid_for(((long long)n1 + 7) / 8), 128, 0, s>>>(
-        n1, rows.p + bins.start[1], ext, A.ia.p, A.ja.p, A.a.p, S.ia.p, S.ja.p, cf.p, f2c.p, trunc_factor, pmax,
-        slack_ia.p, sj.p, sa.p, len.p);
+  if (n1) {
+    // bound 33 ... 128: first with 32-entry tables (a quarter of the LDS, four times the rows in flight); the rows that do
+    // not fit come back marked and go through the tables sized by the bound.  MI_HYPRE_INTERP_TRY=0: all of them there.
+    static const bool try_small = !(getenv("MI_HYPRE_INTERP_TRY") && atoi(getenv("MI_HYPRE_INTERP_TRY")) == 0);
+    const int *big = rows.p + bins.start[1];
+    int nbig = n1;
+    DVec<int> part1;
+    if (try_small) {
+      static_assert(16 <= 32, "CAP + G keys must stay below the 2 CAP slots of the table");
+      interp_group_k<16, 32, 256, true><<<grid_for(((long long)n1 + 15) / 16), 256, 0, s>>>(
+          n1, rows.p + bins.start[1], ext, A.ia.p, A.ja.p, A.a.p, S.ia.p, S.ja.p, cf.p, f2c.p, trunc_factor, pmax,
+          slack_ia.p, sj.p, sa.p, len.p);
+      part1.alloc((size_t)2 * (size_t)n1 + 2);
+      int *cnt1 = part1.p + 2 * (size_t)n1;
+      int h1[2] = {0, 0};
+      MI_HIP(hipMemsetAsync(cnt1, 0, 2 * sizeof(int), s));
+      split_rows_k<<<grid_for(((long long)n1 + BLK - 1) / BLK), BLK, 0, s>>>(n1, rows.p + bins.start[1], len.p, -1, part1.p,
+                                                                           part1.p + n1, cnt1);
+      d2h(h1, cnt1, sizeof(h1), s);
+      MI_HIP(hipStreamSynchronize(s));
+      big = part1.p;  // the rows marked -1
+      nbig = h1[0];
+    }
+    if (nbig)
+      interp_group_k<16, 128, 128><<<grid_for(((long long)nbig + 7) / 8), 128, 0, s>>>(
+          nbig, big, ext, A.ia.p, A.ja.p, A.a.p, S.ia.p, S.ja.p, cf.p, f2c.p, trunc_factor, pmax, slack_ia.p, sj.p, sa.p,
+          len.p);
+    MI_HIP(hipGetLastError());
+    MI_HIP(hipStreamSynchronize(s));  // part1 is released at the end of this block
+  }
   if (n2)
     interp_group_k<64, 512, 128><<<grid_for(((long long)n2 + 1) / 2), 128, 0, s>>>(
         n2, rows.p + bins.start[2], ext, A.ia.p, A.ja.p, A.a.p, S.ia.p, S.ja.p, cf.p, f2c.p, trunc_factor, pmax,
