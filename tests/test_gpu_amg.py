@@ -865,3 +865,10 @@ def test_nothing_reads_memory_it_has_not_written(n, stencil):
     r = run(MI_HYPRE_POISON_ALLOC=1)
     assert r["iters"] == ref["iters"] and r["levels"] == ref["levels"]
     assert r["hist"] == ref["hist"] and r["x"] == ref["x"]
+    # the setup kernels restated in round 4 against the ones they replaced (kept behind switches): the sparse products'
+    # numeric phase by accumulation / by one search per output entry, the interpolation's optimistic small tables / the
+    # tables sized by the candidate bound -- the same hierarchy, hence the same solve, bit for bit
+    for env in ({"MI_HYPRE_SPGEMM_ACCUM": 0}, {"MI_HYPRE_INTERP_TRY": 0}):
+        r = run(**env)
+        assert r["iters"] == ref["iters"] and r["levels"] == ref["levels"], env
+        assert r["hist"] == ref["hist"] and r["x"] == ref["x"], env
