@@ -2216,6 +2216,15 @@ void tab_store(double *Bt, const double *u, int n, int *col, hipStream_t s) {
   hipLaunchKernelGGL(tab_store_k, dim3(1), dim3(256), 0, s, Bt, u, n, col);
   MI_HIP(hipGetLastError());
 }
+namespace {
+__global__ void load_module_k(int *p) {
+  if (p) *p = 0;
+}
+}  // namespace
+void load_device_code(hipStream_t s) {  // see sk::load_device_code
+  load_module_k<<<1, 1, 0, s>>>(nullptr);
+  MI_HIP(hipGetLastError());
+}
 void fill(double *x, int n, double v, hipStream_t s) {
   if (n == 0) return;
   hipLaunchKernelGGL(fill_k, dim3(vec_grid(n)), dim3(256), 0, s, x, n, v);

@@ -178,6 +178,7 @@ void scale(double alpha, double *x, int n, hipStream_t s);
 void scale_inv_sqrt_post(const double *sumsq_dev, double *x, int n, const double *slots, int count, double *host_out,
                          unsigned long long *host_flag, unsigned long long seq, hipStream_t s);
 void scale_inv_sqrt_dev(const double *sumsq_dev, double *x, int n, hipStream_t s);
+void load_device_code(hipStream_t s);
 void fill(double *x, int n, double v, hipStream_t s);
 void copy(const double *x, double *y, int n, hipStream_t s);
 void gather(const double *x, const int *map, double *out, int n, hipStream_t s);

@@ -14,6 +14,7 @@
 #include <unordered_map>
 
 #include "kernels.hpp"
+#include "setup_kernels.hpp"
 #include "mi_internal.hpp"
 #include "parcsr.hpp"
 #include "profile.hpp"
@@ -141,6 +142,13 @@ void ensure_init() {
   if (e != hipSuccess || ndev == 0)
     fail(1, "mi_hypre: no HIP device available (this library has no CPU path; it needs an MI355X/gfx950 GPU)");
   MI_HIP(hipGetDevice(&c.device));
+  // MI_HYPRE_SPIN_WAIT=1: host waits (hipStreamSynchronize & co.) spin instead of sleeping on the interrupt.  A setup makes
+  // ~400 short host <-> device round trips (counts, totals, the tile schedules); on a host whose wake-ups are slow each
+  // of them costs a millisecond instead of 20 us (profiles/r04_setup_split_512.txt: 0.65 s of a 2.83 s setup idle on one
+  // box, 0.18 s of 2.66 s on another).  Process-wide and therefore opt-in; refused silently where the runtime says no.
+  if (getenv("MI_HYPRE_SPIN_WAIT") && atoi(getenv("MI_HYPRE_SPIN_WAIT")) != 0) {
+    if (hipSetDeviceFlags(hipDeviceScheduleSpin) != hipSuccess) (void)hipGetLastError();
+  }
   MI_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
   MI_HIP(hipStreamCreateWithFlags(&c.comm_stream, hipStreamNonBlocking));
   MI_HIP(hipEventCreateWithFlags(&c.ev_packed, hipEventDisableTiming));
@@ -155,6 +163,11 @@ void ensure_init() {
   c.h_post_flag = reinterpret_cast<unsigned long long *>(c.h_pinned + 511);
   c.post_seq = 0;
   if (!c.comm) c.comm = make_self_comm();
+  // both translation units' device code now (the runtime would load each at its first launch, i.e. inside the first
+  // Assemble / Setup: 0.2-0.4 s of a 2.3 s setup in the first process on a machine, whose disk cache is cold)
+  k::load_device_code(c.stream);
+  sk::load_device_code(c.stream);
+  MI_HIP(hipStreamSynchronize(c.stream));
   const char *ch = getenv("MI_HYPRE_GS_CHUNK");
   if (ch) c.gs_chunk = atoi(ch);
   if (c.gs_chunk < 1) c.gs_chunk = 1;

@@ -1830,6 +1830,18 @@ std::vector<int64_t> &host_scratch_i64() {
 void release_host_scratch() { std::vector<int64_t>().swap(host_scratch_i64()); }
 
 namespace {
+__global__ void load_module_k(int *p) {
+  if (p) *p = 0;
+}
+}  // namespace
+// The runtime loads a translation unit's device code at the first launch of any of its kernels (from the library file,
+// which the first process on a machine reads from a cold disk cache): HYPRE_Init takes that, not the first setup.
+void load_device_code(hipStream_t s) {
+  load_module_k<<<1, 1, 0, s>>>(nullptr);
+  MI_HIP(hipGetLastError());
+}
+
+namespace {
 // tile schedule, one thread per super-block of k::TILE_SUPER_ROWS rows (k::tile_end is the host routine's step):
 // FILL = false counts the super-block's tiles, FILL = true writes their ends behind start[sb]
 template <bool FILL>

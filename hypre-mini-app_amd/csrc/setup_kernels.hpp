@@ -80,6 +80,8 @@ void tile_schedule_device(int n, const long long *ia, int row_cap, int tile_entr
                           bool &aligned, hipStream_t s);
 // the host buffer to_solve_format keeps between calls goes back to the system (end of a setup)
 void release_host_scratch();
+// launches an empty kernel of this translation unit: its device code is loaded now (HYPRE_Init) instead of at the first setup
+void load_device_code(hipStream_t s);
 // The part of a C-first ordered square block (C points = indices < nc) that a FIRST relaxation sweep on a
 // zero guess can touch: every row keeps the entries inside its own chunk of `chunk` rows, F rows also their C
 // columns (written by the C pass that precedes the F pass).  Everything else multiplies zeros.  Columns stay

@@ -532,8 +532,8 @@ def build_laplace_system(nx, ny, nz, stencil=7, rank=0, size=1):
     """IJ matrix + rhs + zero x for this rank's block rows of the n^3 Laplacian."""
     N = nx * ny * nz
     ilower, iupper = row_partition(N, size, rank)
-    g = laplace3d(nx, ny, nz, stencil, ilower, iupper)
-    A = IJMatrix(ilower, iupper)
+    A = IJMatrix(ilower, iupper)  # (created before the entries are generated, as the reference's driver does: the library
+    g = laplace3d(nx, ny, nz, stencil, ilower, iupper)  # starts mapping device memory as soon as it knows the row count)
     A.set_values_ptr(g["nnz"], g["rows"], g["cols"], g["vals"])
     A.assemble()
     rhs = np.ctypeslib.as_array(C.cast(g["rhs"], C.POINTER(c_dbl)), shape=(g["nloc"],)).copy()
